@@ -1,0 +1,228 @@
+/*
+ * mi355_nrphy.h -- C ABI of the MI355X-native 5G NR downlink PHY hot path.
+ *
+ * This is the drop-in boundary for the PDSCH processor + OFDM modulator of the reference
+ * (ushasigh/srsran-edgeric-5g, srsRAN-5G-ER/lib/phy).  Every entry point names the reference
+ * interface it replaces (R/ = srsRAN-5G-ER/).  Plain C: POD structs, raw pointers and sizes, int
+ * status codes, no exceptions, no C++ or torch types.
+ *
+ * Conventions
+ *  - Bit buffers are MSB-first packed bytes (bit i lives in byte i/8, mask 0x80 >> (i%8)), the layout
+ *    of the reference's bit_buffer (R/include/srsran/adt/bit_buffer.h:98-190).
+ *  - A resource grid is an array [port][symbol(14)][subcarrier] of cbf16 (two bf16, real then
+ *    imaginary, 4 bytes), subcarrier fastest -- the layout of resource_grid_impl
+ *    (R/lib/phy/support/resource_grid_impl.cpp:29-57).  Batches add a leading [grid] dimension.
+ *  - IQ output is complex float32 (real, imag), [grid][port][sample] with the slot's symbols back
+ *    to back (cyclic prefix first), as ofdm_slot_modulator produces it
+ *    (R/lib/phy/lower/modulation/ofdm_modulator_impl.cpp:115-139).
+ *  - Pointers named d_* are device (HBM) pointers valid on the context's device; `stream` is a
+ *    hipStream_t passed as void* (NULL = the context's own stream).  Calls that take a stream are
+ *    asynchronous with respect to the host and never allocate, so they can be captured in a hipGraph.
+ */
+#ifndef MI355_NRPHY_H
+#define MI355_NRPHY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRPHY_MAX_RB 275
+#define NRPHY_NRE 12
+#define NRPHY_NSYMB 14
+#define NRPHY_MAX_PORTS 4
+#define NRPHY_MAX_LAYERS 4
+#define NRPHY_PRB_WORDS 5      /* 5 x 64 bits >= 275 PRB */
+#define NRPHY_MAX_RESERVED 4   /* re_pattern_list::MAX_RE_PATTERN, R/include/srsran/phy/support/re_pattern.h:142 */
+#define NRPHY_MAX_CODEBLOCKS 162 /* MAX_NOF_SEGMENTS, R/include/srsran/ran/sch/sch_constants.h:38 */
+
+/* Status codes.  The reference aborts (srsran_assert) on argument errors; this ABI returns a code. */
+enum {
+  NRPHY_OK               = 0,
+  NRPHY_ERR_INVALID_PDU  = 1, /* pdsch_pdu_validator::is_valid() == false */
+  NRPHY_ERR_ARGUMENT     = 2, /* size mismatch, null pointer, unsupported size */
+  NRPHY_ERR_DEVICE       = 3, /* HIP runtime error (no GPU, launch failure) */
+  NRPHY_ERR_CAPACITY     = 4  /* batch exceeds the plan/context limits */
+};
+
+/* RE pattern: {prb_mask, re_mask, symbols} of R/include/srsran/phy/support/re_pattern.h:40-77.
+ * prb_mask bit p = PRB p of the grid (CRB index), re_mask bit k = subcarrier k of the PRB,
+ * symbol_mask bit l = OFDM symbol l of the slot. */
+typedef struct nrphy_re_pattern {
+  uint64_t prb_mask[NRPHY_PRB_WORDS];
+  uint16_t re_mask;
+  uint16_t symbol_mask;
+  uint32_t reserved_;
+} nrphy_re_pattern_t;
+
+/* POD mirror of pdsch_processor::pdu_t (R/include/srsran/phy/upper/channel_processors/pdsch_processor.h:58-155). */
+typedef struct nrphy_pdsch_pdu {
+  uint32_t slot_index;       /* slot_point::slot_index(): slot within the radio frame (DM-RS c_init) */
+  uint32_t rnti;
+  uint32_t bwp_start_rb;
+  uint32_t bwp_size_rb;
+  uint32_t cp;               /* 0 = normal (the only one the reference's processor handles with 14 symbols) */
+  uint32_t qm;               /* bits per symbol of codeword 0: 2 QPSK, 4 16QAM, 6 64QAM, 8 256QAM */
+  uint32_t rv;               /* redundancy version 0..3 */
+  uint32_t nof_codewords;    /* must be 1 (validator) */
+  uint32_t n_id;
+  uint32_t ref_point;        /* 0 = CRB0, 1 = PRB0 */
+  uint32_t dmrs_symbol_mask; /* bit l = symbol l carries DM-RS */
+  uint32_t dmrs_type;        /* 1 or 2; only 1 is valid */
+  uint32_t scrambling_id;
+  uint32_t n_scid;
+  uint32_t nof_cdm_groups_without_data;
+  uint32_t start_symbol_index;
+  uint32_t nof_symbols;
+  uint32_t ldpc_base_graph;  /* 1 or 2 */
+  uint32_t tbs_lbrm_bytes;
+  uint32_t vrb_contiguous;   /* rb_allocation::is_contiguous() of the VRB mask (validator rule) */
+  uint64_t prb_mask[NRPHY_PRB_WORDS]; /* freq_alloc.get_prb_mask(bwp_start_rb, bwp_size_rb): allocated PRBs, grid-indexed */
+  uint32_t nof_reserved;
+  uint32_t tb_size_bytes;    /* data[0].size() */
+  nrphy_re_pattern_t reserved[NRPHY_MAX_RESERVED];
+  float    ratio_pdsch_dmrs_to_sss_dB;
+  float    ratio_pdsch_data_to_sss_dB;
+  /* precoding_configuration (R/include/srsran/phy/support/precoding_configuration.h) */
+  uint32_t nof_layers;
+  uint32_t nof_ports;
+  uint32_t prg_size_rb;
+  uint32_t nof_prg;
+  const float* precoding;    /* host pointer: [nof_prg][nof_ports][nof_layers] complex (re, im) */
+} nrphy_pdsch_pdu_t;
+
+/* Scalars the reference derives per PDU (pdsch_processor_impl.cpp:75-136, ldpc_segmenter_impl.cpp:90-160,
+ * ldpc.h:128-228).  Filled by nrphy_pdsch_derive(); useful to size buffers. */
+typedef struct nrphy_pdsch_derived {
+  uint32_t nof_re;            /* data RE per layer */
+  uint32_t nof_codeblocks;    /* C */
+  uint32_t lifting_size;      /* Zc */
+  uint32_t segment_length;    /* K = Kb*Zc */
+  uint32_t cb_info_bits;      /* K' - L_cb */
+  uint32_t nof_filler_bits;   /* F */
+  uint32_t nof_tb_crc_bits;   /* 16 or 24 */
+  uint32_t nof_cb_crc_bits;   /* 0 or 24 */
+  uint32_t zero_pad;          /* zero bits appended to the last CB */
+  uint32_t full_length;       /* N = 66*Zc or 50*Zc */
+  uint32_t n_ref;             /* Nref */
+  uint32_t n_cb;              /* Ncb = min(N, Nref) */
+  uint32_t k0;                /* rate-matching start */
+  uint32_t nof_short_segments;
+  uint32_t rm_length_short;   /* E of the short segments */
+  uint32_t rm_length_long;    /* E of the others */
+  uint32_t codeword_bits;     /* G */
+} nrphy_pdsch_derived_t;
+
+/* ofdm_modulator_configuration, R/include/srsran/phy/lower/modulation/ofdm_modulator.h:34-47. */
+typedef struct nrphy_ofdm_config {
+  uint32_t numerology;
+  uint32_t bw_rb;
+  uint32_t dft_size;
+  uint32_t cp;        /* 0 normal, 1 extended */
+  float    scale;
+  double   center_freq_hz;
+} nrphy_ofdm_config_t;
+
+typedef struct nrphy_ctx nrphy_ctx_t;
+typedef struct nrphy_pdsch_plan nrphy_pdsch_plan_t;
+typedef struct nrphy_ofdm_plan nrphy_ofdm_plan_t;
+
+/* ---- library ------------------------------------------------------------------------------- */
+const char* nrphy_version(void);
+const char* nrphy_strerror(int status);
+
+/* Creates the device context (streams, constant tables).  Replaces the factory chain
+ * create_downlink_processor_factory_sw / _hw (R/lib/phy/upper/upper_phy_factories.cpp:659-919).
+ * Fails with NRPHY_ERR_DEVICE when no HIP device is present: there is no CPU fallback. */
+int nrphy_create(nrphy_ctx_t** ctx, int device_id);
+int nrphy_destroy(nrphy_ctx_t* ctx);
+int nrphy_synchronize(nrphy_ctx_t* ctx, void* stream);
+
+/* ---- host-only helpers (no device work) ------------------------------------------------------ */
+/* pdsch_pdu_validator::is_valid (R/lib/phy/upper/channel_processors/pdsch_processor_validator_impl.cpp:99-181).
+ * Returns NRPHY_OK or NRPHY_ERR_INVALID_PDU. */
+int nrphy_pdsch_validate(const nrphy_pdsch_pdu_t* pdu);
+/* Per-PDU derived scalars (see nrphy_pdsch_derived_t). */
+int nrphy_pdsch_derive(const nrphy_pdsch_pdu_t* pdu, nrphy_pdsch_derived_t* out);
+/* tbs_calculator_calculate (R/lib/ran/sch/tbs_calculator.cpp:124-144); returns TBS in bits. */
+uint32_t nrphy_tbs_calculate(uint32_t nof_symb_sh, uint32_t nof_dmrs_prb, uint32_t nof_oh_prb, uint32_t qm,
+                             float target_code_rate, uint32_t nof_layers, uint32_t n_prb);
+/* ofdm_symbol_modulator::get_symbol_size (R/lib/phy/lower/modulation/ofdm_modulator_impl.h:68-71),
+ * symbol_index counted within the subframe; and ofdm_slot_modulator::get_slot_size. */
+uint32_t nrphy_ofdm_symbol_size(const nrphy_ofdm_config_t* cfg, uint32_t symbol_index);
+uint32_t nrphy_ofdm_slot_size(const nrphy_ofdm_config_t* cfg, uint32_t slot_index);
+
+/* ---- seam A: pdsch_processor::process, batched ------------------------------------------------
+ * Replaces pdsch_processor::process (pdsch_processor.h:167-170; impl pdsch_processor_impl.cpp:30-73,
+ * per-codeblock form pdsch_processor_concurrent_impl.cpp:55-338).
+ *
+ * A plan holds n_pdu PDUs.  PDU i reads its transport block at d_tb + tb_offset[i] and writes grid
+ * number grid_index[i] of a batch of grids with nof_ports x 14 x nof_subc cbf16 each.  Creating a plan
+ * validates every PDU (NRPHY_ERR_INVALID_PDU names none; use nrphy_pdsch_validate to find it), derives
+ * the per-PDU and per-codeblock descriptors and uploads them; it may be run any number of times. */
+int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
+                            const uint64_t* tb_offset, const uint32_t* grid_index, uint32_t nof_grids,
+                            uint32_t grid_nof_ports, uint32_t grid_nof_subc, nrphy_pdsch_plan_t** plan);
+int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan);
+/* Total number of codeblocks / rate-matched codeword bits of the plan, and PDU i's offset (in bits,
+ * a multiple of 32) into the codeword tap buffers. */
+uint32_t nrphy_pdsch_plan_nof_codeblocks(const nrphy_pdsch_plan_t* plan);
+uint64_t nrphy_pdsch_plan_codeword_bits(const nrphy_pdsch_plan_t* plan);
+uint64_t nrphy_pdsch_plan_codeword_offset(const nrphy_pdsch_plan_t* plan, uint32_t pdu);
+
+/* Runs the whole PDSCH path of every PDU of the plan: TB CRC, segmentation, CB CRC, LDPC encoding,
+ * rate matching, bit interleaving, scrambling, modulation, layer mapping, precoding, RE mapping and
+ * DM-RS generation.  d_grid may be NULL (encode only, seam B semantics).  Optional taps, either may be
+ * NULL: d_cw_rm receives the rate-matched + interleaved codeword of pdsch_encoder::encode
+ * (pdsch_encoder_impl.cpp:28-72) packed MSB-first, d_cw_scrambled the same after scrambling
+ * (pdsch_modulator_impl.cpp:30-44).  The caller zeroes the grids (resource_grid::set_all_zero) or
+ * passes zero_grids != 0 to have the run clear them first. */
+int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, void* d_grid, uint8_t* d_cw_rm,
+                    uint8_t* d_cw_scrambled, int zero_grids, void* stream);
+
+/* Host-span convenience with the reference's single-PDU semantics: copies the TB in, runs, copies
+ * the grid out (blocking).  grid points to nof_ports x 14 x nof_subc cbf16 in host memory and is
+ * overwritten only on the REs the PDU maps (like resource_grid_mapper), unless it is NULL.
+ * cw_rm / cw_scrambled: optional host taps of codeword_bits bits (packed). */
+int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb, void* grid,
+                             uint32_t grid_nof_ports, uint32_t grid_nof_subc, uint8_t* cw_rm,
+                             uint8_t* cw_scrambled);
+
+/* ---- seam B pieces: ldpc_encoder::encode, batched ----------------------------------------------
+ * Replaces ldpc_encoder::encode (R/lib/phy/upper/channel_coding/ldpc/ldpc_encoder_impl.cpp:44-81) for
+ * n_cb codeblocks that share (base graph, lifting size).  d_msg: n_cb messages of Kb*Zc bits, each
+ * starting on a multiple of msg_stride_bytes; filler bits are zeros.  d_out: n_cb outputs of
+ * out_bits bits (the codeblock without its first 2*Zc bits, out_bits <= (N_full-2)*Zc), each starting
+ * on a multiple of out_stride_bytes. */
+int nrphy_ldpc_encode(nrphy_ctx_t* ctx, uint32_t base_graph, uint32_t lifting_size, uint32_t n_cb,
+                      const uint8_t* d_msg, uint32_t msg_stride_bytes, uint32_t out_bits, uint8_t* d_out,
+                      uint32_t out_stride_bytes, void* stream);
+
+/* ---- seam C: ofdm_slot_modulator / ofdm_symbol_modulator, batched -------------------------------
+ * Replaces ofdm_symbol_modulator::modulate and ofdm_slot_modulator::modulate
+ * (R/include/srsran/phy/lower/modulation/ofdm_modulator.h:54-101; impl ofdm_modulator_impl.cpp:56-139).
+ * Grid layout as above with nof_subc = 12*bw_rb.  Grid g is modulated as slot slot_index[g] of the
+ * subframe (NULL: all slot 0) into d_iq + g * nof_ports * slot_size_max, port after port, where
+ * slot_size_max = nrphy_ofdm_plan_slot_stride() (the size of slot 0, the largest). */
+int nrphy_ofdm_plan_create(nrphy_ctx_t* ctx, const nrphy_ofdm_config_t* cfg, uint32_t nof_ports,
+                           nrphy_ofdm_plan_t** plan);
+int nrphy_ofdm_plan_destroy(nrphy_ofdm_plan_t* plan);
+uint32_t nrphy_ofdm_plan_slot_stride(const nrphy_ofdm_plan_t* plan);
+int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid, const uint32_t* slot_index,
+                   float* d_iq, void* stream);
+/* Host-span single-symbol form of ofdm_symbol_modulator::modulate: grid is one grid in host memory. */
+int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t port_index,
+                                    uint32_t symbol_index, float* output, uint32_t output_size);
+
+/* dft_processor::run (R/include/srsran/phy/generic_functions/dft_processor.h:34-73; generic impl
+ * dft_processor_generic_impl.cpp:14-218).  Unnormalised DFT of `size` complex floats, `batch` of them
+ * back to back.  inverse != 0 uses exp(+j...).  Sizes: powers of two 128..4096 (more in later rounds). */
+int nrphy_dft_run(nrphy_ctx_t* ctx, uint32_t size, int inverse, uint32_t batch, const float* d_in, float* d_out,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_NRPHY_H */

@@ -1,0 +1,226 @@
+"""ctypes mirror of include/mi355_nrphy.h (the C ABI) plus PDU construction helpers.
+
+The structures here are the POD mirror of the reference's ``pdsch_processor::pdu_t``
+(srsRAN-5G-ER/include/srsran/phy/upper/channel_processors/pdsch_processor.h:58-155) and
+``ofdm_modulator_configuration`` (include/srsran/phy/lower/modulation/ofdm_modulator.h:34-47).
+Pure host-side plumbing: no compute happens in this module.
+"""
+import ctypes as C
+
+import numpy as np
+
+MAX_RB = 275
+NRE = 12
+NSYMB = 14
+MAX_PORTS = 4
+MAX_LAYERS = 4
+PRB_WORDS = 5
+MAX_RESERVED = 4
+MAX_CODEBLOCKS = 162
+
+OK = 0
+ERR_INVALID_PDU = 1
+ERR_ARGUMENT = 2
+ERR_DEVICE = 3
+ERR_CAPACITY = 4
+
+TBS_LBRM_DEFAULT = 159749  # tbs_lbrm_default, include/srsran/ran/sch/sch_constants.h:47
+
+
+class RePattern(C.Structure):
+    _fields_ = [
+        ("prb_mask", C.c_uint64 * PRB_WORDS),
+        ("re_mask", C.c_uint16),
+        ("symbol_mask", C.c_uint16),
+        ("reserved_", C.c_uint32),
+    ]
+
+
+class PdschPdu(C.Structure):
+    _fields_ = [
+        ("slot_index", C.c_uint32),
+        ("rnti", C.c_uint32),
+        ("bwp_start_rb", C.c_uint32),
+        ("bwp_size_rb", C.c_uint32),
+        ("cp", C.c_uint32),
+        ("qm", C.c_uint32),
+        ("rv", C.c_uint32),
+        ("nof_codewords", C.c_uint32),
+        ("n_id", C.c_uint32),
+        ("ref_point", C.c_uint32),
+        ("dmrs_symbol_mask", C.c_uint32),
+        ("dmrs_type", C.c_uint32),
+        ("scrambling_id", C.c_uint32),
+        ("n_scid", C.c_uint32),
+        ("nof_cdm_groups_without_data", C.c_uint32),
+        ("start_symbol_index", C.c_uint32),
+        ("nof_symbols", C.c_uint32),
+        ("ldpc_base_graph", C.c_uint32),
+        ("tbs_lbrm_bytes", C.c_uint32),
+        ("vrb_contiguous", C.c_uint32),
+        ("prb_mask", C.c_uint64 * PRB_WORDS),
+        ("nof_reserved", C.c_uint32),
+        ("tb_size_bytes", C.c_uint32),
+        ("reserved", RePattern * MAX_RESERVED),
+        ("ratio_pdsch_dmrs_to_sss_dB", C.c_float),
+        ("ratio_pdsch_data_to_sss_dB", C.c_float),
+        ("nof_layers", C.c_uint32),
+        ("nof_ports", C.c_uint32),
+        ("prg_size_rb", C.c_uint32),
+        ("nof_prg", C.c_uint32),
+        ("precoding", C.POINTER(C.c_float)),
+    ]
+
+
+class PdschDerived(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "nof_re", "nof_codeblocks", "lifting_size", "segment_length", "cb_info_bits", "nof_filler_bits",
+        "nof_tb_crc_bits", "nof_cb_crc_bits", "zero_pad", "full_length", "n_ref", "n_cb", "k0",
+        "nof_short_segments", "rm_length_short", "rm_length_long", "codeword_bits")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class OfdmConfig(C.Structure):
+    _fields_ = [
+        ("numerology", C.c_uint32),
+        ("bw_rb", C.c_uint32),
+        ("dft_size", C.c_uint32),
+        ("cp", C.c_uint32),
+        ("scale", C.c_float),
+        ("center_freq_hz", C.c_double),
+    ]
+
+
+def prb_mask_words(prbs):
+    """Bit mask words (5 x uint64) with the given PRB indices set."""
+    words = [0] * PRB_WORDS
+    for p in prbs:
+        words[p // 64] |= 1 << (p % 64)
+    return words
+
+
+def bits_to_mask(bits):
+    m = 0
+    for i, b in enumerate(bits):
+        if b:
+            m |= 1 << i
+    return m
+
+
+def identity_precoding(nof_layers):
+    """precoding_configuration::make_wideband(make_identity(n)) -- [1][n][n] complex."""
+    w = np.zeros((1, nof_layers, nof_layers, 2), dtype=np.float32)
+    for i in range(nof_layers):
+        w[0, i, i, 0] = 1.0
+    return w
+
+
+def make_pdu(*, slot_index=0, rnti=1, bwp_start_rb=0, bwp_size_rb=52, qm=2, rv=0, n_id=0, ref_point=0,
+             dmrs_symbols=(2,), dmrs_type=1, scrambling_id=0, n_scid=0, nof_cdm_groups_without_data=2,
+             prb_start=0, prb_count=52, prbs=None, start_symbol=0, nof_symbols=14, base_graph=1,
+             tbs_lbrm_bytes=TBS_LBRM_DEFAULT, reserved=(), ratio_dmrs_dB=0.0, ratio_data_dB=0.0,
+             precoding=None, prg_size_rb=MAX_RB, tb_size_bytes=0, nof_codewords=1, cp=0, vrb_contiguous=None):
+    """Builds a PdschPdu.  ``precoding`` is an array [nof_prg][nof_ports][nof_layers] complex64 or
+    [...][2] float32; ``reserved`` a sequence of (prbs, re_bits[12], symbol_bits[14]).  The numpy weight
+    array is attached to the returned struct (``_keepalive``) so the pointer stays valid."""
+    pdu = PdschPdu()
+    pdu.slot_index = slot_index
+    pdu.rnti = rnti
+    pdu.bwp_start_rb = bwp_start_rb
+    pdu.bwp_size_rb = bwp_size_rb
+    pdu.cp = cp
+    pdu.qm = qm
+    pdu.rv = rv
+    pdu.nof_codewords = nof_codewords
+    pdu.n_id = n_id
+    pdu.ref_point = ref_point
+    pdu.dmrs_symbol_mask = sum(1 << l for l in dmrs_symbols)
+    pdu.dmrs_type = dmrs_type
+    pdu.scrambling_id = scrambling_id
+    pdu.n_scid = n_scid
+    pdu.nof_cdm_groups_without_data = nof_cdm_groups_without_data
+    pdu.start_symbol_index = start_symbol
+    pdu.nof_symbols = nof_symbols
+    pdu.ldpc_base_graph = base_graph
+    pdu.tbs_lbrm_bytes = tbs_lbrm_bytes
+    if prbs is None:
+        prbs = list(range(prb_start, prb_start + prb_count))
+    prbs = sorted(prbs)
+    contiguous = len(prbs) > 0 and prbs[-1] - prbs[0] + 1 == len(prbs)
+    pdu.vrb_contiguous = int(contiguous if vrb_contiguous is None else vrb_contiguous)
+    for i, w in enumerate(prb_mask_words(prbs)):
+        pdu.prb_mask[i] = w
+    pdu.nof_reserved = len(reserved)
+    for i, (rprbs, re_bits, sym_bits) in enumerate(reserved):
+        for j, w in enumerate(prb_mask_words(rprbs)):
+            pdu.reserved[i].prb_mask[j] = w
+        pdu.reserved[i].re_mask = bits_to_mask(re_bits)
+        pdu.reserved[i].symbol_mask = bits_to_mask(sym_bits)
+    pdu.tb_size_bytes = tb_size_bytes
+    pdu.ratio_pdsch_dmrs_to_sss_dB = ratio_dmrs_dB
+    pdu.ratio_pdsch_data_to_sss_dB = ratio_data_dB
+    if precoding is None:
+        precoding = identity_precoding(1)
+    w = np.asarray(precoding)
+    if np.iscomplexobj(w):
+        w = np.stack([w.real, w.imag], axis=-1)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    assert w.ndim == 4 and w.shape[3] == 2, "precoding must be [nof_prg][nof_ports][nof_layers] complex"
+    pdu.nof_prg, pdu.nof_ports, pdu.nof_layers = w.shape[0], w.shape[1], w.shape[2]
+    pdu.prg_size_rb = prg_size_rb
+    pdu.precoding = w.ctypes.data_as(C.POINTER(C.c_float))
+    pdu._keepalive = w
+    return pdu
+
+
+def declare(lib, prefix="nrphy_"):
+    """Attaches argtypes/restypes for the entry points of include/mi355_nrphy.h found in ``lib``.
+    The same signatures (with prefix ``oracle_``) are exported by the CPU oracle."""
+    P = C.POINTER
+    vp, u8p, u32, u64, i32 = C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+
+    def sig(name, restype, *argtypes):
+        fn = getattr(lib, prefix + name, None)
+        if fn is not None:
+            fn.restype = restype
+            fn.argtypes = list(argtypes)
+
+    sig("version", C.c_char_p)
+    sig("strerror", C.c_char_p, i32)
+    sig("create", i32, P(vp), i32)
+    sig("destroy", i32, vp)
+    sig("synchronize", i32, vp, vp)
+    sig("pdsch_validate", i32, P(PdschPdu))
+    sig("pdsch_derive", i32, P(PdschPdu), P(PdschDerived))
+    sig("tbs_calculate", u32, u32, u32, u32, u32, C.c_float, u32, u32)
+    sig("ofdm_symbol_size", u32, P(OfdmConfig), u32)
+    sig("ofdm_slot_size", u32, P(OfdmConfig), u32)
+    sig("pdsch_plan_create", i32, vp, u32, P(PdschPdu), P(u64), P(u32), u32, u32, u32, P(vp))
+    sig("pdsch_plan_destroy", i32, vp)
+    sig("pdsch_plan_nof_codeblocks", u32, vp)
+    sig("pdsch_plan_codeword_bits", u64, vp)
+    sig("pdsch_plan_codeword_offset", u64, vp, u32)
+    sig("pdsch_run", i32, vp, u8p, vp, u8p, u8p, i32, vp)
+    sig("pdsch_process_host", i32, vp, P(PdschPdu), u8p, vp, u32, u32, u8p, u8p)
+    sig("ldpc_encode", i32, vp, u32, u32, u32, u8p, u32, u32, u8p, u32, vp)
+    sig("ofdm_plan_create", i32, vp, P(OfdmConfig), u32, P(vp))
+    sig("ofdm_plan_destroy", i32, vp)
+    sig("ofdm_plan_slot_stride", u32, vp)
+    sig("ofdm_run", i32, vp, u32, vp, vp, vp, vp)
+    sig("ofdm_modulate_symbol_host", i32, vp, vp, u32, u32, vp, u32)
+    sig("dft_run", i32, vp, u32, i32, u32, vp, vp, vp)
+    return lib
+
+
+# Symbols include/mi355_nrphy.h declares; tests check the shared library exports every one.
+ABI_SYMBOLS = [
+    "nrphy_version", "nrphy_strerror", "nrphy_create", "nrphy_destroy", "nrphy_synchronize",
+    "nrphy_pdsch_validate", "nrphy_pdsch_derive", "nrphy_tbs_calculate", "nrphy_ofdm_symbol_size",
+    "nrphy_ofdm_slot_size", "nrphy_pdsch_plan_create", "nrphy_pdsch_plan_destroy",
+    "nrphy_pdsch_plan_nof_codeblocks", "nrphy_pdsch_plan_codeword_bits", "nrphy_pdsch_plan_codeword_offset",
+    "nrphy_pdsch_run", "nrphy_pdsch_process_host", "nrphy_ldpc_encode", "nrphy_ofdm_plan_create",
+    "nrphy_ofdm_plan_destroy", "nrphy_ofdm_plan_slot_stride", "nrphy_ofdm_run",
+    "nrphy_ofdm_modulate_symbol_host", "nrphy_dft_run",
+]

@@ -1,0 +1,265 @@
+"""TEST INFRASTRUCTURE: numpy-level wrappers over the CPU checkers.
+
+* ``oracle()``  -> oracle/liboracle.so, the plain-C restatement (travels to the GPU box).
+* ``ref()``     -> oracle/_ref/libsrsref.so, the reference's own sources compiled by oracle/Makefile
+                   (exists only where /root/reference was available at build time; None otherwise).
+
+Nothing in the product imports this module.
+"""
+import ctypes as C
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "srsran-edgeric-5g_amd")
+
+
+def load_package():
+    """Imports the (hyphen-named) package directory as module ``srsran_edgeric_5g_amd``."""
+    name = "srsran_edgeric_5g_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(PKG_DIR, "__init__.py"),
+                                                  submodule_search_locations=[PKG_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+pkg = load_package()
+abi = pkg.abi
+
+_P = C.POINTER
+_u32, _vp, _f, _i = C.c_uint32, C.c_void_p, C.c_float, C.c_int
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CpuBackend:
+    """Uniform numpy API over the oracle (prefix 'oracle_') or the compiled reference (prefix 'ref_')."""
+
+    def __init__(self, lib, prefix):
+        self.lib = lib
+        self.prefix = prefix
+        self.is_ref = prefix == "ref_"
+        g = lambda n: getattr(lib, prefix + n)
+        g("tbs_calculate").restype = _u32
+        g("tbs_calculate").argtypes = [_u32, _u32, _u32, _u32, _f, _u32, _u32]
+        g("crc").restype = _u32
+        g("crc").argtypes = [_u32, _vp, _u32]
+        g("ldpc_segment").restype = _i
+        g("ldpc_segment").argtypes = [_u32] * 6 + [_vp, _u32, _vp, _u32, _vp, _vp]
+        g("ldpc_encode").restype = _i
+        g("ldpc_rate_match").restype = _i
+        g("ldpc_rate_match").argtypes = [_u32] * 6 + [_vp, _u32, _vp, _u32]
+        g("prg_apply_xor").restype = None
+        g("prg_apply_xor").argtypes = [_u32, _u32, _vp, _u32]
+        g("prg_generate_float").restype = None
+        g("prg_generate_float").argtypes = [_u32, _u32, _f, _vp, _u32]
+        g("modulate_ci8").restype = _f
+        g("modulate_ci8").argtypes = [_u32, _vp, _u32, _vp]
+        g("pdsch_validate").restype = _i
+        g("pdsch_validate").argtypes = [_P(abi.PdschPdu)]
+        g("dft").restype = _i
+        g("dft").argtypes = [_u32, _i, _vp, _vp]
+        g("ofdm_modulate_slot").restype = _i
+        g("ofdm_modulate_slot").argtypes = [_P(abi.OfdmConfig), _vp, _u32, _u32, _vp]
+        if self.is_ref:
+            g("ldpc_encode").argtypes = [_u32, _u32, _vp, _u32, _vp, _i]
+            g("pdsch_process").restype = _i
+            g("pdsch_process").argtypes = [_P(abi.PdschPdu), _vp, _vp, _u32, _u32, _i, _i]
+            g("pdsch_encode").restype = _i
+            g("pdsch_encode").argtypes = [_u32] * 6 + [_vp, _u32, _vp, _i]
+            g("precoding_codebook").restype = _u32
+            g("precoding_codebook").argtypes = [_u32] * 4 + [_vp]
+            g("bench_pdsch").restype = C.c_double
+            g("bench_pdsch").argtypes = [_P(abi.PdschPdu), _vp, _u32, _u32, _P(abi.OfdmConfig), _u32, _u32, _i]
+        else:
+            g("ldpc_encode").argtypes = [_u32, _u32, _vp, _u32, _vp]
+            g("pdsch_process").restype = _i
+            g("pdsch_process").argtypes = [_P(abi.PdschPdu), _vp, _vp, _u32, _u32, _vp, _vp]
+            g("pdsch_encode").restype = _i
+            g("pdsch_encode").argtypes = [_P(abi.PdschPdu), _vp, _vp]
+            g("pdsch_derive").restype = _i
+            g("pdsch_derive").argtypes = [_P(abi.PdschPdu), _P(abi.PdschDerived)]
+            g("crc_bits").restype = _u32
+            g("crc_bits").argtypes = [_u32, _vp, _u32]
+            g("ofdm_symbol_size").restype = _u32
+            g("ofdm_symbol_size").argtypes = [_P(abi.OfdmConfig), _u32]
+            g("ofdm_slot_size").restype = _u32
+            g("ofdm_slot_size").argtypes = [_P(abi.OfdmConfig), _u32]
+            g("bench").restype = C.c_double
+            g("bench").argtypes = [_P(abi.PdschPdu), _vp, _u32, _u32, _P(abi.OfdmConfig), _u32, _u32]
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    # ---- scalar helpers -------------------------------------------------------------------------
+    def tbs(self, nof_symb_sh, nof_dmrs_prb, nof_oh_prb, qm, rate_x1024, nof_layers, n_prb):
+        return int(self._f("tbs_calculate")(nof_symb_sh, nof_dmrs_prb, nof_oh_prb, qm, float(rate_x1024),
+                                            nof_layers, n_prb))
+
+    def crc(self, poly, data):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        return int(self._f("crc")(poly, _ptr(data), data.size))
+
+    def validate(self, pdu):
+        return int(self._f("pdsch_validate")(C.byref(pdu)))
+
+    # ---- coding ------------------------------------------------------------------------------------
+    def segment(self, bg, rv, qm, nref, nof_layers, nof_ch_symbols, tb):
+        tb = np.ascontiguousarray(tb, dtype=np.uint8)
+        stride = 8448 // 8
+        segs = np.zeros((abi.MAX_CODEBLOCKS, stride), np.uint8)
+        meta = np.zeros((abi.MAX_CODEBLOCKS, 5), np.uint32)
+        zc = C.c_uint32(0)
+        n = self._f("ldpc_segment")(bg, rv, qm, nref, nof_layers, nof_ch_symbols, _ptr(tb), tb.size, _ptr(segs),
+                                    stride, _ptr(meta), C.addressof(zc))
+        k = (22 if bg == 1 else 10) * zc.value
+        return segs[:n, :(k + 7) // 8].copy(), meta[:n].copy(), zc.value
+
+    def ldpc_encode(self, bg, zc, msg_packed, out_bits, simd=1):
+        msg_packed = np.ascontiguousarray(msg_packed, dtype=np.uint8)
+        out = np.zeros((out_bits + 7) // 8, np.uint8)
+        args = [bg, zc, _ptr(msg_packed), out_bits, _ptr(out)]
+        if self.is_ref:
+            args.append(simd)
+        rc = self._f("ldpc_encode")(*args)
+        assert rc == 0, rc
+        return out
+
+    def rate_match(self, bg, zc, rv, qm, nref, nof_filler, codeblock_packed, rm_length):
+        cb = np.ascontiguousarray(codeblock_packed, dtype=np.uint8)
+        n = (66 if bg == 1 else 50) * zc
+        out = np.zeros((rm_length + 7) // 8, np.uint8)
+        rc = self._f("ldpc_rate_match")(bg, zc, rv, qm, nref, nof_filler, _ptr(cb), n, _ptr(out), rm_length)
+        assert rc == 0, rc
+        return out
+
+    def prg_xor(self, c_init, offset, data_packed, nbits):
+        d = np.array(data_packed, dtype=np.uint8, copy=True)
+        self._f("prg_apply_xor")(c_init, offset, _ptr(d), nbits)
+        return d
+
+    def prg_float(self, c_init, offset, value, n):
+        out = np.zeros(n, np.float32)
+        self._f("prg_generate_float")(c_init, offset, float(value), _ptr(out), n)
+        return out
+
+    def modulate(self, qm, bits_packed, nsym):
+        b = np.ascontiguousarray(bits_packed, dtype=np.uint8)
+        out = np.zeros((nsym, 2), np.int8)
+        scale = self._f("modulate_ci8")(qm, _ptr(b), nsym, _ptr(out))
+        return out, float(scale)
+
+    # ---- PDSCH ------------------------------------------------------------------------------------
+    def derive(self, pdu):
+        d = abi.PdschDerived()
+        assert not self.is_ref
+        self._f("pdsch_derive")(C.byref(pdu), C.byref(d))
+        return d.as_dict()
+
+    def pdsch_encode(self, pdu, tb, derived=None, simd=1):
+        """Packed rate-matched codeword (before scrambling)."""
+        tb = np.ascontiguousarray(tb, dtype=np.uint8)
+        if self.is_ref:
+            d = derived
+            unpacked = np.zeros(d["codeword_bits"], np.uint8)
+            rc = self._f("pdsch_encode")(pdu.ldpc_base_graph, pdu.rv, pdu.qm, d["n_ref"], pdu.nof_layers,
+                                         d["nof_re"] * pdu.nof_layers, _ptr(tb), tb.size, _ptr(unpacked), simd)
+            assert rc == 0
+            return np.packbits(unpacked)
+        d = self.derive(pdu)
+        out = np.zeros((d["codeword_bits"] + 7) // 8, np.uint8)
+        rc = self._f("pdsch_encode")(C.byref(pdu), _ptr(tb), _ptr(out))
+        assert rc == 0
+        return out
+
+    def pdsch_process(self, pdu, tb, nof_ports, nof_subc, simd=1, impl=0, taps=False, codeword_bits=None):
+        """Returns grid [nof_ports][14][nof_subc][2] uint16 (raw bf16) (+ (cw_rm, cw_scr) for the oracle)."""
+        tb = np.ascontiguousarray(tb, dtype=np.uint8)
+        grid = np.zeros((nof_ports, 14, nof_subc, 2), np.uint16)
+        if self.is_ref:
+            rc = self._f("pdsch_process")(C.byref(pdu), _ptr(tb), _ptr(grid), nof_ports, nof_subc, impl, simd)
+            assert rc == 0, rc
+            return grid
+        if taps:
+            nb = (codeword_bits + 7) // 8
+            rm = np.zeros(nb, np.uint8)
+            scr = np.zeros(nb, np.uint8)
+            rc = self._f("pdsch_process")(C.byref(pdu), _ptr(tb), _ptr(grid), nof_ports, nof_subc, _ptr(rm), _ptr(scr))
+            assert rc == 0, rc
+            return grid, rm, scr
+        rc = self._f("pdsch_process")(C.byref(pdu), _ptr(tb), _ptr(grid), nof_ports, nof_subc, None, None)
+        assert rc == 0, rc
+        return grid
+
+    # ---- OFDM ---------------------------------------------------------------------------------------
+    def dft(self, x, inverse):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.zeros_like(x)
+        rc = self._f("dft")(x.size, int(inverse), _ptr(x), _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def ofdm_slot(self, cfg, grid, slot_index=0):
+        """grid: [nof_ports][14][12*bw_rb][2] uint16 -> iq [nof_ports][slot_size] complex64."""
+        grid = np.ascontiguousarray(grid, dtype=np.uint16)
+        nof_ports = grid.shape[0]
+        iq = np.zeros((nof_ports, 2 * (cfg.dft_size + cfg.dft_size // 8) * 14), np.complex64)  # generous
+        n = self._f("ofdm_modulate_slot")(C.byref(cfg), _ptr(grid), nof_ports, slot_index, _ptr(iq))
+        assert n > 0, n
+        return iq.reshape(-1)[: nof_ports * n].reshape(nof_ports, n).copy()
+
+    def codebook(self, kind, a=0, b=0, c=0):
+        assert self.is_ref
+        w = np.zeros((4, 4, 2), np.float32)
+        r = self._f("precoding_codebook")(kind, a, b, c, _ptr(w))
+        ports, layers = r >> 8, r & 0xFF
+        return w.reshape(-1)[: ports * layers * 2].reshape(1, ports, layers, 2).copy()
+
+
+_ORACLE = None
+_REF = None
+
+
+def build_oracle():
+    """Compiles oracle/liboracle.so when missing or stale (gcc, a second or two)."""
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    src = os.path.join(ROOT, "oracle", "nrphy_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, capture_output=True,
+                       timeout=300)
+    return so
+
+
+def oracle():
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = CpuBackend(C.CDLL(build_oracle()), "oracle_")
+    return _ORACLE
+
+
+def ref():
+    """The compiled reference, or None when oracle/_ref was not built (e.g. on the GPU box)."""
+    global _REF
+    so = os.path.join(ROOT, "oracle", "_ref", "libsrsref.so")
+    if _REF is None and os.path.exists(so):
+        _REF = CpuBackend(C.CDLL(so), "ref_")
+    return _REF
+
+
+def bf16_to_f32(u16):
+    return (np.asarray(u16, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def grid_to_complex(grid_u16):
+    f = bf16_to_f32(grid_u16)
+    return f[..., 0] + 1j * f[..., 1]
