@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PDSCH slots/s (+ IQ Gsamples/s) at 100 MHz / 4 layers / 256-QAM on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path (TB CRC -> segmentation -> LDPC -> rate matching -> scrambling -> QAM ->
+layer mapping/precoding/RE mapping -> DM-RS -> OFDM) over one batch of --slots BASELINE-config-3 slots per GPU with
+distinct transport blocks already resident in HBM.  Slots are independent, so ranks just own disjoint slot batches
+(weak scaling, no data-path collective); RCCL is used for the barrier and the max-over-ranks time only.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=15.0):
+    """Times the CPU path on the host cores for a bounded sample of the same workload (rank 0, N=1 only).
+    Uses the compiled reference (oracle/_ref, kind "reference") when that library travelled with the repository,
+    the C oracle (kind "port") otherwise."""
+    import ctypes as C
+    import backends
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    r = backends.ref()
+    if r is not None:
+        kind = "reference"
+
+        def run(threads, reps):
+            return r.lib.ref_bench_pdsch(C.byref(pdu), tb.ctypes.data, nof_ports, nof_subc, C.byref(ofdm), threads,
+                                         reps, 1)
+    else:
+        kind = "port"
+        o = backends.oracle()
+
+        def run(threads, reps):
+            return o.lib.oracle_bench(C.byref(pdu), tb.ctypes.data, nof_ports, nof_subc, C.byref(ofdm), threads, reps)
+    t1 = run(cores, 1)  # calibration pass (also warms caches)
+    reps = int(max(2, min(2000, budget_s / max(t1, 1e-4))))
+    dt = run(cores, reps)
+    return {
+        "value": cores * reps / dt,
+        "unit": "slots/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": "%d threads x %d config-3 slots each (PDSCH %s + OFDM generic radix-2 DFT), %.1f s" % (
+            cores, reps, "AVX2 LDPC/precoder" if kind == "reference" else "scalar C oracle", dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--slots", type=int, default=256, help="slots per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import backends
+    import cases
+    lib = backends.pkg.lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = lib.Context(local_rank)
+    slots = args.slots
+    pdu0, nof_ports, nof_subc, ofdm = cases.baseline_config(3)
+    d0 = lib.derive(pdu0)
+    pdus = [cases.baseline_config(3, slot_index=i % 20)[0] for i in range(slots)]
+    stride = (pdu0.tb_size_bytes + 255) & ~255
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    d_tb = torch.randint(0, 256, (slots, stride), dtype=torch.uint8, device="cuda", generator=gen)
+    plan = lib.PdschPlan(ctx, pdus, [i * stride for i in range(slots)], list(range(slots)), slots, nof_ports, nof_subc)
+    oplan = lib.OfdmPlan(ctx, ofdm, nof_ports)
+    d_grid = torch.zeros((slots, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
+    d_iq = torch.zeros((slots, nof_ports, oplan.slot_stride, 2), dtype=torch.float32, device="cuda")
+    d_slot = torch.tensor([i % 2 for i in range(slots)], dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        plan.run(d_tb, d_grid, zero_grids=True)
+        oplan.run(slots, d_grid, d_iq, d_slot_index=d_slot)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    plan.enable_timing(args.steps)
+    oplan.enable_timing(args.steps)
+    barrier()
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    (ms_crc, ms_cb, ms_dmrs, ms_run), _ = plan.kernel_times()
+    ms_ofdm, _ = oplan.kernel_time()
+
+    if rank == 0:
+        total_slots = world * slots * args.steps
+        samples_per_slot = nof_ports * oplan.slot_stride
+        # Algorithmic bytes per slot: TB read + grid written once (incl. zeros) +
+        # grid read by the OFDM modulator + IQ write.
+        grid_bytes = nof_ports * 14 * nof_subc * 4
+        alg_pdsch = pdu0.tb_size_bytes + grid_bytes
+        alg_ofdm = grid_bytes + samples_per_slot * 8
+        data_re_bytes = d0["nof_re"] * nof_ports * 4
+        kernels = {
+            # name: (avg ms per launch, algorithmic bytes per launch)
+            "ofdm_kernel<4096>": (ms_ofdm, slots * alg_ofdm),
+            "codeblock_kernel": (ms_cb, slots * (pdu0.tb_size_bytes + data_re_bytes)),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("slots") == slots and dom in tj.get("hbm_bytes_per_launch", {}):
+                    traffic = tj["hbm_bytes_per_launch"][dom]
+            except Exception:
+                traffic = None
+
+        def roof(name):
+            ms, nbytes = kernels[name]
+            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4),
+                    "algorithmic_bytes_per_launch": int(nbytes)}
+
+        roofline = roof(dom)
+        roofline["traffic"] = traffic
+        out = {
+            "metric": "pdsch_slots_per_sec",
+            "value": round(total_slots / dt, 1),
+            "unit": "slots/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 bit-packed GF(2) + bf16 grid + f32 IQ",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: 100 MHz (FFT 4096, 30 kHz SCS, 273 PRB grid) 4-layer 256-QAM "
+                                   "R=948/1024 full-TBS PDSCH (TBS 868584 bit, 104 CB, BG1 Zc 384) + 4-port OFDM",
+                       "slots_per_gpu_per_step": slots, "parallelism": "slot-sharded x%d, no data-path collective" % world},
+            "iq_gsamples_per_sec": round(total_slots * samples_per_slot / dt / 1e9, 3),
+            "whole_path_hbm_frac": round(total_slots * (alg_pdsch + alg_ofdm) / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "kernel_ms": {"tb_crc": round(ms_crc, 4), "codeblock": round(ms_cb, 4), "dmrs": round(ms_dmrs, 4),
+                          "pdsch_run_incl_memset": round(ms_run, 4), "ofdm": round(ms_ofdm, 4)},
+            "roofline": roofline,
+            "roofline_other": [roof(k) for k in kernels if k != dom],
+        }
+        # Sanity: slot 0 of the last step against the CPU oracle (checker only, outside the timed region).
+        try:
+            o = backends.oracle()
+            tb0 = d_tb[0, : pdu0.tb_size_bytes].cpu().numpy()
+            want = o.pdsch_process(pdus[0], tb0, nof_ports, nof_subc)
+            got = d_grid[0].cpu().numpy().view(np.uint16).reshape(want.shape)
+            out["verified_vs_oracle"] = bool(np.array_equal(got, want))
+        except Exception as e:  # the oracle is optional at bench time
+            out["verified_vs_oracle"] = "unavailable: %s" % e
+        if world == 1 and not args.no_cpu_baseline:
+            tb_host = d_tb[0, : pdu0.tb_size_bytes].cpu().numpy().copy()
+            out["cpu_baseline"] = cpu_baseline(pdus[0], tb_host, nof_ports, nof_subc, ofdm)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

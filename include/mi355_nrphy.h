@@ -182,6 +182,15 @@ uint64_t nrphy_pdsch_plan_codeword_offset(const nrphy_pdsch_plan_t* plan, uint32
 int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, void* d_grid, uint8_t* d_cw_rm,
                     uint8_t* d_cw_scrambled, int zero_grids, void* stream);
 
+/* Per-kernel device timing for the benchmark (the counterpart of logging_pdsch_processor_decorator,
+ * R/lib/phy/upper/channel_processors/channel_processor_factories.cpp:1164-1240, which times process()).
+ * After enabling with room for max_runs runs, every nrphy_pdsch_run records HIP events around its kernels on the
+ * stream it launches on.  nrphy_pdsch_plan_kernel_times synchronises those events and returns the average
+ * duration in milliseconds of {tb_crc, codeblock, dmrs, whole run} over the recorded runs (count in *nof_runs),
+ * then resets the recording. */
+int nrphy_pdsch_plan_enable_timing(nrphy_pdsch_plan_t* plan, uint32_t max_runs);
+int nrphy_pdsch_plan_kernel_times(nrphy_pdsch_plan_t* plan, float avg_ms[4], uint32_t* nof_runs);
+
 /* Host-span convenience with the reference's single-PDU semantics: copies the TB in, runs, copies
  * the grid out (blocking).  grid points to nof_ports x 14 x nof_subc cbf16 in host memory and is
  * overwritten only on the REs the PDU maps (like resource_grid_mapper), unless it is NULL.
@@ -212,6 +221,9 @@ int nrphy_ofdm_plan_destroy(nrphy_ofdm_plan_t* plan);
 uint32_t nrphy_ofdm_plan_slot_stride(const nrphy_ofdm_plan_t* plan);
 int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid, const uint32_t* slot_index,
                    float* d_iq, void* stream);
+/* Same for the OFDM kernel: average milliseconds per nrphy_ofdm_run launch. */
+int nrphy_ofdm_plan_enable_timing(nrphy_ofdm_plan_t* plan, uint32_t max_runs);
+int nrphy_ofdm_plan_kernel_time(nrphy_ofdm_plan_t* plan, float* avg_ms, uint32_t* nof_runs);
 /* Host-span single-symbol form of ofdm_symbol_modulator::modulate: grid is one grid in host memory. */
 int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t port_index,
                                     uint32_t symbol_index, float* output, uint32_t output_size);

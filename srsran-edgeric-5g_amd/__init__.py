@@ -5,5 +5,6 @@ library ``csrc/libmi355nrphy.so`` (built by ``build.py`` / ``__graft_entry__.bui
 package never falls back to a CPU implementation -- ``lib.load()`` raises when the library is missing.
 """
 from . import abi  # noqa: F401
+from . import lib  # noqa: F401
 
-__all__ = ["abi"]
+__all__ = ["abi", "lib"]

@@ -203,6 +203,10 @@ def declare(lib, prefix="nrphy_"):
     sig("pdsch_plan_codeword_bits", u64, vp)
     sig("pdsch_plan_codeword_offset", u64, vp, u32)
     sig("pdsch_run", i32, vp, u8p, vp, u8p, u8p, i32, vp)
+    sig("pdsch_plan_enable_timing", i32, vp, u32)
+    sig("pdsch_plan_kernel_times", i32, vp, P(C.c_float), P(u32))
+    sig("ofdm_plan_enable_timing", i32, vp, u32)
+    sig("ofdm_plan_kernel_time", i32, vp, P(C.c_float), P(u32))
     sig("pdsch_process_host", i32, vp, P(PdschPdu), u8p, vp, u32, u32, u8p, u8p)
     sig("ldpc_encode", i32, vp, u32, u32, u32, u8p, u32, u32, u8p, u32, vp)
     sig("ofdm_plan_create", i32, vp, P(OfdmConfig), u32, P(vp))
@@ -220,7 +224,8 @@ ABI_SYMBOLS = [
     "nrphy_pdsch_validate", "nrphy_pdsch_derive", "nrphy_tbs_calculate", "nrphy_ofdm_symbol_size",
     "nrphy_ofdm_slot_size", "nrphy_pdsch_plan_create", "nrphy_pdsch_plan_destroy",
     "nrphy_pdsch_plan_nof_codeblocks", "nrphy_pdsch_plan_codeword_bits", "nrphy_pdsch_plan_codeword_offset",
-    "nrphy_pdsch_run", "nrphy_pdsch_process_host", "nrphy_ldpc_encode", "nrphy_ofdm_plan_create",
+    "nrphy_pdsch_run", "nrphy_pdsch_plan_enable_timing", "nrphy_pdsch_plan_kernel_times",
+    "nrphy_ofdm_plan_enable_timing", "nrphy_ofdm_plan_kernel_time", "nrphy_pdsch_process_host", "nrphy_ldpc_encode", "nrphy_ofdm_plan_create",
     "nrphy_ofdm_plan_destroy", "nrphy_ofdm_plan_slot_stride", "nrphy_ofdm_run",
     "nrphy_ofdm_modulate_symbol_host", "nrphy_dft_run",
 ]

@@ -1,0 +1,215 @@
+// Device helpers for MSB-first packed bit arrays held in 32-bit words, CRC arithmetic and the Gold sequence.
+// gfx950 only: 64-lane wavefronts are assumed throughout.
+#pragma once
+
+#include "nrphy_internal.h"
+
+namespace nrphy {
+
+constexpr int WAVE = 64;
+
+// Orders the LDS traffic of the lanes of ONE wavefront (the codeblock kernel runs one wave per workgroup, so a
+// workgroup barrier is a wave barrier; kept as a function to make the intent explicit).
+__device__ __forceinline__ void wave_sync()
+{
+  __syncthreads();
+}
+
+// n most significant bits set, n in [0, 32].
+__device__ __forceinline__ uint32_t topmask(uint32_t n)
+{
+  return n == 0 ? 0u : (0xFFFFFFFFu << (32u - n));
+}
+
+// 32 bits starting at bit `pos` of the MSB-first bit array `a` (reads words pos/32 and pos/32 + 1).
+__device__ __forceinline__ uint32_t ext32(const uint32_t* a, uint32_t pos)
+{
+  uint32_t w = pos >> 5, sh = pos & 31u;
+  return __funnelshift_l(a[w + 1], a[w], sh);
+}
+
+// Big-endian 32-bit load from a byte stream viewed as words: word i = bytes 4i..4i+3, first byte in the MSBs.
+__device__ __forceinline__ uint32_t be_word(const uint32_t* words, uint32_t i)
+{
+  return __builtin_bswap32(words[i]);
+}
+
+// ORs the `nbits` most significant bits of `value` into the bit array at bit `pos` (LDS, shared by lanes).
+__device__ __forceinline__ void or_bits_lds(uint32_t* a, uint32_t pos, uint32_t value, uint32_t nbits)
+{
+  value &= topmask(nbits);
+  uint32_t w = pos >> 5, sh = pos & 31u;
+  uint32_t hi = value >> sh;
+  if (hi) {
+    atomicOr(&a[w], hi);
+  }
+  if (sh) {
+    uint32_t lo = value << (32u - sh);
+    if (lo) {
+      atomicOr(&a[w + 1], lo);
+    }
+  }
+}
+
+// Same on global memory (codeword taps; the buffer is zeroed by the caller).
+__device__ __forceinline__ void or_bits_global(uint32_t* a, uint64_t pos, uint32_t value, uint32_t nbits)
+{
+  value &= topmask(nbits);
+  uint64_t w  = pos >> 5;
+  uint32_t sh = (uint32_t)pos & 31u;
+  // The tap buffers are byte streams: store words big-endian.
+  uint32_t hi = value >> sh;
+  if (hi) {
+    atomicOr(&a[w], __builtin_bswap32(hi));
+  }
+  if (sh) {
+    uint32_t lo = value << (32u - sh);
+    if (lo) {
+      atomicOr(&a[w + 1], __builtin_bswap32(lo));
+    }
+  }
+}
+
+// ---- CRC (TS 38.212 Section 5.1): remainder arithmetic in GF(2)[x] / poly, `order` in {16, 24} ---------------
+struct CrcPoly {
+  uint32_t poly;  // including the leading term
+  uint32_t order;
+};
+__device__ __forceinline__ CrcPoly crc24a()
+{
+  return {0x1864CFBu, 24u};
+}
+__device__ __forceinline__ CrcPoly crc24b()
+{
+  return {0x1800063u, 24u};
+}
+__device__ __forceinline__ CrcPoly crc16()
+{
+  return {0x11021u, 16u};
+}
+
+// a * b mod poly, operands below 2^order.
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b, CrcPoly c)
+{
+  uint32_t top = 1u << c.order, r = 0;
+  for (int i = (int)c.order - 1; i >= 0; --i) {
+    r <<= 1;
+    if (r & top) {
+      r ^= c.poly;
+    }
+    if ((b >> i) & 1u) {
+      r ^= a;
+    }
+  }
+  return r;
+}
+
+// x^e mod poly.
+__device__ __forceinline__ uint32_t crc_xpow(uint32_t e, CrcPoly c)
+{
+  uint32_t result = 1, base = 2; // x
+  while (e) {
+    if (e & 1u) {
+      result = crc_mulmod(result, base, c);
+    }
+    base = crc_mulmod(base, base, c);
+    e >>= 1;
+  }
+  return result;
+}
+
+// Table entry b: (b(x) * x^order) mod poly; 256 entries in LDS, filled by fill_crc_table().
+__device__ __forceinline__ uint32_t crc_table_entry(uint32_t b, CrcPoly c)
+{
+  uint32_t top = 1u << c.order;
+  uint32_t r   = b << (c.order - 8u);
+  for (int k = 0; k != 8; ++k) {
+    r <<= 1;
+    if (r & top) {
+      r ^= c.poly;
+    }
+  }
+  return r & (top - 1u);
+}
+
+// reg <- remainder after shifting the 4 bytes of `word` (MSB first) through the register.
+__device__ __forceinline__ uint32_t crc_update_word(uint32_t reg, uint32_t word, const uint32_t* table, CrcPoly c)
+{
+  uint32_t mask = (1u << c.order) - 1u, sh = c.order - 8u;
+#pragma unroll
+  for (int k = 0; k != 4; ++k) {
+    uint32_t byte = (word >> (24 - 8 * k)) & 0xFFu;
+    uint32_t idx  = ((reg >> sh) ^ byte) & 0xFFu;
+    reg           = ((reg << 8) & mask) ^ table[idx];
+  }
+  return reg;
+}
+
+// XOR reduction over the 64 lanes of a wave.
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v)
+{
+#pragma unroll
+  for (int off = 32; off != 0; off >>= 1) {
+    v ^= __shfl_xor(v, off, WAVE);
+  }
+  return v;
+}
+
+// ---- Gold sequence (TS 38.211 Section 5.2.1) --------------------------------------------------------------
+// Generates `nwords` 32-bit words (MSB-first) of c(n) for n in [32*first_word, 32*(first_word + nwords)) into
+// the LDS array `out`, executed by one full wavefront.  x1 comes from the precomputed table, x2 from c_init:
+//  1. jump the 31-bit x2 state to offset Nc + 32*first_word with the matrices (M2)^(2^k): lane r evaluates row r
+//     and the wave assembles the new state with a ballot ("wavefront-ballot parity");
+//  2. the first 31 words one after the other (a word is the state plus one recurrence bit; M2^32 advances it);
+//  3. every further word in parallel from W[k] = W[k-28] ^ W[k-29] ^ W[k-30] ^ W[k-31], the x2 recurrence lifted
+//     to 32-bit words (squaring the characteristic polynomial five times: p(x)^32 = p(x^32) over GF(2)).
+// Replaces pseudo_random_generator_impl::{init,advance,apply_xor}
+// (R/lib/phy/upper/sequence_generators/pseudo_random_generator_impl.cpp:58-82,248-316).
+__device__ __forceinline__ uint32_t gold_matvec(const uint32_t* rows, uint32_t state, uint32_t lane)
+{
+  uint32_t bit = (lane < 31u) ? (__popc(rows[lane & 31u] & state) & 1u) : 0u;
+  return (uint32_t)__ballot(bit != 0) & 0x7FFFFFFFu;
+}
+
+__device__ inline void gold_generate_wave(const GoldTables* gold, const uint32_t* x1_words, uint32_t c_init,
+                                          uint32_t first_word, uint32_t nwords, uint32_t* out, uint32_t lane)
+{
+  uint32_t state  = c_init & 0x7FFFFFFFu;
+  uint32_t offset = 1600u + 32u * first_word;
+  for (int k = 0; k != GOLD_JUMP_BITS; ++k) {
+    if ((offset >> k) & 1u) { // wave-uniform
+      state = gold_matvec(gold->x2_jump[k], state, lane);
+    }
+  }
+  uint32_t head = nwords < 31u ? nwords : 31u;
+  for (uint32_t w = 0; w != head; ++w) {
+    uint32_t next = __popc(state & 0xFu) & 1u; // x2(n+31) = x2(n+3)^x2(n+2)^x2(n+1)^x2(n)
+    if (lane == 0) {
+      out[w] = __brev(state | (next << 31));
+    }
+    state = gold_matvec(gold->x2_jump[5], state, lane);
+  }
+  wave_sync();
+  for (uint32_t base = 31; base < nwords; base += 28) {
+    uint32_t k = base + lane;
+    if (lane < 28u && k < nwords) {
+      out[k] = out[k - 28] ^ out[k - 29] ^ out[k - 30] ^ out[k - 31];
+    }
+    wave_sync();
+  }
+  for (uint32_t k = lane; k < nwords; k += WAVE) {
+    out[k] ^= x1_words[first_word + k];
+  }
+  wave_sync();
+}
+
+// round-to-nearest-even float -> bf16 exactly as the reference stores the grid
+// (to_bf16, R/include/srsran/adt/bf16.h:39-56); values here are finite.
+__device__ __forceinline__ uint32_t to_bf16_bits(float v)
+{
+  uint32_t u = __float_as_uint(v);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+} // namespace nrphy

@@ -1,0 +1,1247 @@
+// Host side of libmi355nrphy.so: the C ABI of include/mi355_nrphy.h.
+//
+// Per-PDU scalar derivation (what pdsch_processor_impl / ldpc_segmenter_impl / ldpc_rate_matcher_impl compute on
+// the CPU before their loops), plan construction and kernel launches.  No compute happens here and there is no CPU
+// fallback: every entry point that produces PHY output needs a HIP device.
+#include "nrphy_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace nrphy;
+
+namespace {
+
+struct nr_ldpc_edge_t {
+  uint8_t  row;
+  uint8_t  col;
+  uint16_t shift[8];
+};
+#include "nr_ldpc_bg.inc"
+
+const uint16_t LIFTING_SIZES[NOF_LIFTING_SIZES] = {
+    2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13,  14,  15,  16,  18,  20,  22,  24,  26,  28,  30,  32,  36,  40, 44,
+    48, 52, 56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128, 144, 160, 176, 192, 208, 224, 240, 256, 288, 320, 352, 384};
+
+int lifting_position(unsigned zc)
+{
+  for (int i = 0; i != NOF_LIFTING_SIZES; ++i) {
+    if (LIFTING_SIZES[i] == zc) {
+      return i;
+    }
+  }
+  return -1;
+}
+
+// Lifting-set index i_LS: Zc = a * 2^j, a in {2, 3, 5, 7, 9, 11, 13, 15} (TS 38.212 Table 5.3.2-1).
+int lifting_set_index(unsigned zc)
+{
+  static const unsigned base[8] = {2, 3, 5, 7, 9, 11, 13, 15};
+  for (int i = 0; i != 8; ++i) {
+    for (unsigned v = base[i]; v <= 384; v *= 2) {
+      if (v == zc) {
+        return i;
+      }
+    }
+  }
+  return -1;
+}
+
+unsigned divide_ceil(unsigned a, unsigned b)
+{
+  return (a + b - 1) / b;
+}
+
+bool mask_test(const uint64_t* w, unsigned i)
+{
+  return (w[i >> 6] >> (i & 63)) & 1U;
+}
+
+int mask_lowest(const uint64_t* w)
+{
+  for (unsigned i = 0; i != 64 * NRPHY_PRB_WORDS; ++i) {
+    if (mask_test(w, i)) {
+      return (int)i;
+    }
+  }
+  return -1;
+}
+
+int mask_highest(const uint64_t* w)
+{
+  int hi = -1;
+  for (unsigned i = 0; i != 64 * NRPHY_PRB_WORDS; ++i) {
+    if (mask_test(w, i)) {
+      hi = (int)i;
+    }
+  }
+  return hi;
+}
+
+void build_lifted_graph(unsigned bg, unsigned zc, LiftedGraph& g)
+{
+  const nr_ldpc_edge_t* edges   = (bg == 1) ? NR_LDPC_BG1_EDGES : NR_LDPC_BG2_EDGES;
+  const unsigned        n_edges = (bg == 1) ? NR_LDPC_BG1_NOF_EDGES : NR_LDPC_BG2_NOF_EDGES;
+  const unsigned        kb      = (bg == 1) ? 22 : 10;
+  const unsigned        rows    = (bg == 1) ? 46 : 42;
+  const int             ils     = lifting_set_index(zc);
+  std::memset(&g, 0, sizeof(g));
+  int      core_shift[4] = {-1, -1, -1, -1};
+  unsigned count         = 0;
+  for (unsigned m = 0; m != rows; ++m) {
+    g.row_ptr[m] = (uint16_t)count;
+    for (unsigned e = 0; e != n_edges; ++e) {
+      if (edges[e].row != m) {
+        continue;
+      }
+      unsigned col = edges[e].col, shift = edges[e].shift[ils] % zc;
+      if (m < 4) {
+        if (col == kb) {
+          core_shift[m] = (int)shift;
+        }
+        if (col >= kb) {
+          continue; // core rows: systematic part only, the parity part is solved in closed form
+        }
+      } else if (col >= kb + 4) {
+        continue; // the identity column of an extension row is its own parity block
+      }
+      g.edge[count++] = (col << 16) | shift;
+    }
+  }
+  for (unsigned m = rows; m != MAX_BG_ROWS + 2; ++m) {
+    g.row_ptr[m] = (uint16_t)count;
+  }
+  unsigned mid = (core_shift[1] >= 0) ? 1 : 2;
+  int      s0 = core_shift[0], s3 = core_shift[3], sm = core_shift[mid];
+  g.core_mid = (uint16_t)mid;
+  g.core_s0  = (uint16_t)s0;
+  g.core_s3  = (uint16_t)s3;
+  g.core_b   = (uint16_t)((s0 == s3) ? sm : ((s0 == sm) ? s3 : s0));
+}
+
+// ---- Gold sequence tables (TS 38.211 Section 5.2.1) -----------------------------------------------------------
+// 31x31 matrices over GF(2) as 31 row masks.
+void mat_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) // out = a * b
+{
+  uint32_t bt[31];                      // columns of b
+  for (int c = 0; c != 31; ++c) {
+    uint32_t col = 0;
+    for (int r = 0; r != 31; ++r) {
+      col |= ((b[r] >> c) & 1U) << r;
+    }
+    bt[c] = col;
+  }
+  uint32_t tmp[31];
+  for (int r = 0; r != 31; ++r) {
+    uint32_t row = 0;
+    for (int c = 0; c != 31; ++c) {
+      row |= (uint32_t)(__builtin_popcount(a[r] & bt[c]) & 1) << c;
+    }
+    tmp[r] = row;
+  }
+  std::memcpy(out, tmp, sizeof(tmp));
+}
+
+void build_gold_tables(GoldTables& t, std::vector<uint32_t>& x1_words)
+{
+  std::memset(&t, 0, sizeof(t));
+  // One step of x2: state'[j] = state[j+1], state'[30] = state[3]^state[2]^state[1]^state[0].
+  uint32_t m[31];
+  for (int r = 0; r != 30; ++r) {
+    m[r] = 1U << (r + 1);
+  }
+  m[30] = 0xF;
+  for (int k = 0; k != GOLD_JUMP_BITS; ++k) {
+    std::memcpy(t.x2_jump[k], m, sizeof(m));
+    mat_mul(m, m, m);
+  }
+  // x^(32 m) mod CRC24B.
+  const uint32_t poly = 0x1800063U, top = 1U << 24;
+  uint32_t       v    = 1;
+  for (int i = 0; i != CRC_POW_WORDS; ++i) {
+    t.crc24b_pow32[i] = v;
+    for (int s = 0; s != 32; ++s) {
+      v <<= 1;
+      if (v & top) {
+        v ^= poly;
+      }
+    }
+  }
+  // x1(n + 1600), MSB-first words: x1(n+31) = x1(n+3) ^ x1(n), x1(0) = 1.
+  x1_words.assign(GOLD_X1_WORDS, 0);
+  uint32_t x1 = 1;
+  for (int i = 0; i != 1600; ++i) {
+    uint32_t f = ((x1 >> 3) ^ x1) & 1U;
+    x1         = (x1 >> 1) | (f << 30);
+  }
+  for (size_t n = 0; n != (size_t)GOLD_X1_WORDS * 32; ++n) {
+    if (x1 & 1U) {
+      x1_words[n >> 5] |= 0x80000000U >> (n & 31);
+    }
+    uint32_t f = ((x1 >> 3) ^ x1) & 1U;
+    x1         = (x1 >> 1) | (f << 30);
+  }
+}
+
+template <typename T>
+hipError_t upload(T** dptr, const void* src, size_t bytes)
+{
+  *dptr = nullptr;
+  if (bytes == 0) {
+    bytes = 16;
+    hipError_t e = hipMalloc((void**)dptr, bytes);
+    return e;
+  }
+  hipError_t e = hipMalloc((void**)dptr, bytes);
+  if (e != hipSuccess) {
+    return e;
+  }
+  return hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
+}
+
+} // namespace
+
+struct nrphy_ctx {
+  int          device   = 0;
+  hipStream_t  stream   = nullptr;
+  LiftedGraph* d_graphs = nullptr;
+  GoldTables*  d_gold   = nullptr;
+  uint32_t*    d_x1     = nullptr;
+  float2*      d_twiddle[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // 128 .. 4096
+};
+
+struct nrphy_pdsch_plan {
+  nrphy_ctx*            ctx = nullptr;
+  std::vector<PduDev>   pdus;
+  std::vector<uint64_t> cw_offset;
+  uint64_t              cw_bits = 0;
+  uint32_t              nof_grids = 0, grid_nof_ports = 0, grid_nof_subc = 0;
+  PduDev*               d_pdus = nullptr;
+  CbWork*               d_work = nullptr;
+  DmrsWork*             d_dmrs = nullptr;
+  float*                d_weights = nullptr;
+  uint16_t*             d_re_table = nullptr;
+  uint32_t*             d_tb_crc = nullptr;
+  uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0;
+  std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs
+  uint32_t              timed_runs = 0, max_timed_runs = 0;
+};
+
+struct nrphy_ofdm_plan {
+  nrphy_ctx*          ctx = nullptr;
+  nrphy_ofdm_config_t cfg;
+  uint32_t            nof_ports = 0, nsymb = 14, slot_stride = 0, nsym_subframe = 0;
+  float2*             d_phase = nullptr;
+  uint32_t*           d_cp = nullptr;
+  uint32_t*           d_off = nullptr;
+  std::vector<uint32_t> cp, off;
+  std::vector<hipEvent_t> events; // 2 per recorded run
+  uint32_t            timed_runs = 0, max_timed_runs = 0;
+};
+
+// ================================================================================================================
+// Scalars
+// ================================================================================================================
+extern "C" const char* nrphy_version(void)
+{
+  return "mi355-nrphy 0.1 (gfx950)";
+}
+
+extern "C" const char* nrphy_strerror(int status)
+{
+  switch (status) {
+    case NRPHY_OK:
+      return "ok";
+    case NRPHY_ERR_INVALID_PDU:
+      return "invalid PDSCH PDU (pdsch_pdu_validator::is_valid is false)";
+    case NRPHY_ERR_ARGUMENT:
+      return "invalid argument";
+    case NRPHY_ERR_DEVICE:
+      return "HIP device error (no GPU or kernel launch failure); there is no CPU fallback";
+    case NRPHY_ERR_CAPACITY:
+      return "capacity exceeded";
+    default:
+      return "unknown status";
+  }
+}
+
+// pdsch_processor_validator_impl::is_valid (R/lib/phy/upper/channel_processors/pdsch_processor_validator_impl.cpp:99-181),
+// plus the checks the reference leaves to assertions deeper in the chain (modulation, rv, base graph, sizes).
+extern "C" int nrphy_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
+{
+  if (pdu == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const unsigned nsymb = pdu->cp ? 12 : 14;
+  const int      lo = mask_lowest(pdu->prb_mask), hi = mask_highest(pdu->prb_mask);
+  if (lo < 0 || (unsigned)lo < pdu->bwp_start_rb || (unsigned)hi >= pdu->bwp_start_rb + pdu->bwp_size_rb ||
+      pdu->bwp_start_rb + pdu->bwp_size_rb > NRPHY_MAX_RB) {
+    return NRPHY_ERR_INVALID_PDU; // freq_alloc.is_bwp_valid
+  }
+  if (pdu->dmrs_symbol_mask == 0 || (pdu->dmrs_symbol_mask >> nsymb) != 0) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
+  const unsigned first_dmrs = (unsigned)__builtin_ctz(pdu->dmrs_symbol_mask);
+  const unsigned last_dmrs  = 31U - (unsigned)__builtin_clz(pdu->dmrs_symbol_mask);
+  if (first_dmrs < pdu->start_symbol_index || last_dmrs >= pdu->start_symbol_index + pdu->nof_symbols ||
+      nsymb < pdu->start_symbol_index + pdu->nof_symbols) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
+  if (pdu->dmrs_type != 1 || pdu->nof_cdm_groups_without_data > 2 || !pdu->vrb_contiguous) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
+  if (pdu->nof_ports == 0 || pdu->nof_ports > NRPHY_MAX_PORTS || pdu->nof_layers == 0 ||
+      pdu->nof_layers > pdu->nof_ports) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
+  if (pdu->nof_codewords != 1 || pdu->tbs_lbrm_bytes == 0 || pdu->nof_reserved > NRPHY_MAX_RESERVED) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
+  for (unsigned r = 0; r != pdu->nof_reserved; ++r) {
+    if (pdu->reserved[r].symbol_mask & pdu->dmrs_symbol_mask) {
+      return NRPHY_ERR_INVALID_PDU; // check_dmrs_and_reserved_collision
+    }
+  }
+  if ((pdu->qm != 2 && pdu->qm != 4 && pdu->qm != 6 && pdu->qm != 8) || pdu->rv > 3 ||
+      (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->tb_size_bytes == 0 || pdu->nof_prg == 0 ||
+      pdu->prg_size_rb == 0 || pdu->precoding == nullptr || pdu->cp != 0) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
+  return NRPHY_OK;
+}
+
+namespace {
+
+// Data-RE mask of OFDM symbol l: allocation minus reserved minus DM-RS pattern
+// (pdsch_modulator_impl.cpp:52-106, re_pattern.cpp:27-60, dmrs_mapping.h:69-123).
+void data_re_mask(const nrphy_pdsch_pdu_t& pdu, unsigned l, std::vector<uint8_t>& mask)
+{
+  std::fill(mask.begin(), mask.end(), 0);
+  if (l < pdu.start_symbol_index || l >= pdu.start_symbol_index + pdu.nof_symbols) {
+    return;
+  }
+  const unsigned nof_prb = (unsigned)mask.size() / 12;
+  for (unsigned p = 0; p != nof_prb; ++p) {
+    if (mask_test(pdu.prb_mask, p)) {
+      std::fill(mask.begin() + 12 * p, mask.begin() + 12 * p + 12, 1);
+    }
+  }
+  for (unsigned r = 0; r != pdu.nof_reserved; ++r) {
+    const nrphy_re_pattern_t& pat = pdu.reserved[r];
+    if (!((pat.symbol_mask >> l) & 1U)) {
+      continue;
+    }
+    for (unsigned p = 0; p != nof_prb; ++p) {
+      if (!mask_test(pat.prb_mask, p)) {
+        continue;
+      }
+      for (unsigned k = 0; k != 12; ++k) {
+        if ((pat.re_mask >> k) & 1U) {
+          mask[12 * p + k] = 0;
+        }
+      }
+    }
+  }
+  if ((pdu.dmrs_symbol_mask >> l) & 1U) {
+    for (unsigned p = pdu.bwp_start_rb; p < pdu.bwp_start_rb + pdu.bwp_size_rb && p < nof_prb; ++p) {
+      for (unsigned k = 0; k != 12; ++k) {
+        if ((k % 2) < pdu.nof_cdm_groups_without_data) {
+          mask[12 * p + k] = 0;
+        }
+      }
+    }
+  }
+}
+
+void derive(const nrphy_pdsch_pdu_t& pdu, unsigned nof_re, nrphy_pdsch_derived_t& d)
+{
+  const unsigned bg      = pdu.ldpc_base_graph;
+  const unsigned tb_bits = 8 * pdu.tb_size_bytes;
+  const unsigned tb_crc  = (tb_bits <= 3824) ? 16 : 24;
+  const unsigned b       = tb_bits + tb_crc;
+  const unsigned kcb     = (bg == 1) ? 8448 : 3840;
+  const unsigned C       = (b <= kcb) ? 1 : divide_ceil(b, kcb - 24);
+  const unsigned b_out   = b + ((C > 1) ? 24 * C : 0);
+  unsigned       ref_len = 22;
+  if (bg == 2) {
+    ref_len = (b > 640) ? 10 : (b > 560) ? 9 : (b > 192) ? 8 : 6;
+  }
+  unsigned zc = 0;
+  for (unsigned i = 0; i != NOF_LIFTING_SIZES; ++i) {
+    if (LIFTING_SIZES[i] * C * ref_len >= b_out) {
+      zc = LIFTING_SIZES[i];
+      break;
+    }
+  }
+  const unsigned K      = ((bg == 1) ? 22 : 10) * zc;
+  const unsigned cb_crc = (C > 1) ? 24 : 0;
+  const unsigned info   = divide_ceil(b_out, C) - cb_crc;
+  const unsigned N      = ((bg == 1) ? 66 : 50) * zc;
+  uint64_t       nref   = ((uint64_t)pdu.tbs_lbrm_bytes * 8 * 3) / (2 * C); // ldpc::compute_N_ref
+  nref                  = std::min<uint64_t>(nref, 66 * 384);
+  d.nof_re              = nof_re;
+  d.nof_codeblocks      = C;
+  d.lifting_size        = zc;
+  d.segment_length      = K;
+  d.cb_info_bits        = info;
+  d.nof_filler_bits     = K - info - cb_crc;
+  d.nof_tb_crc_bits     = tb_crc;
+  d.nof_cb_crc_bits     = cb_crc;
+  d.zero_pad            = (info + cb_crc) * C - b_out;
+  d.full_length         = N;
+  d.n_ref               = (uint32_t)nref;
+  d.n_cb                = (nref > 0 && nref < N) ? (uint32_t)nref : N;
+  static const double shift_bg1[4] = {0, 17, 33, 56};
+  static const double shift_bg2[4] = {0, 13, 25, 43};
+  const double tmp      = (((bg == 1) ? shift_bg1 : shift_bg2)[pdu.rv] * d.n_cb) / N; // ldpc_rate_matcher_impl.cpp:89-90
+  d.k0                  = (uint32_t)((uint16_t)std::floor(tmp)) * zc;
+  d.nof_short_segments  = C - (nof_re % C);
+  d.rm_length_short     = (nof_re / C) * pdu.nof_layers * pdu.qm;
+  d.rm_length_long      = divide_ceil(nof_re, C) * pdu.nof_layers * pdu.qm;
+  d.codeword_bits       = nof_re * pdu.nof_layers * pdu.qm;
+}
+
+unsigned count_data_re(const nrphy_pdsch_pdu_t& pdu)
+{
+  std::vector<uint8_t> mask(NRPHY_MAX_RB * 12);
+  unsigned             count = 0;
+  for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+    data_re_mask(pdu, l, mask);
+    for (uint8_t m : mask) {
+      count += m;
+    }
+  }
+  return count;
+}
+
+} // namespace
+
+extern "C" int nrphy_pdsch_derive(const nrphy_pdsch_pdu_t* pdu, nrphy_pdsch_derived_t* out)
+{
+  if (pdu == nullptr || out == nullptr || pdu->tb_size_bytes == 0 || pdu->nof_layers == 0 || pdu->qm == 0 ||
+      (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->rv > 3) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  derive(*pdu, count_data_re(*pdu), *out);
+  return NRPHY_OK;
+}
+
+// TS 38.214 Section 5.1.3.2 (tbs_calculator_calculate, R/lib/ran/sch/tbs_calculator.cpp:31-144).
+extern "C" uint32_t nrphy_tbs_calculate(uint32_t nof_symb_sh, uint32_t nof_dmrs_prb, uint32_t nof_oh_prb, uint32_t qm,
+                                        float target_code_rate, uint32_t nof_layers, uint32_t n_prb)
+{
+  static const uint16_t table[93] = {
+      24,   32,   40,   48,   56,   64,   72,   80,   88,   96,   104,  112,  120,  128,  136,  144,  152,  160,  168,
+      176,  184,  192,  208,  224,  240,  256,  272,  288,  304,  320,  336,  352,  368,  384,  408,  432,  456,  480,
+      504,  528,  552,  576,  608,  640,  672,  704,  736,  768,  808,  848,  888,  928,  984,  1032, 1064, 1128, 1160,
+      1192, 1224, 1256, 1288, 1320, 1352, 1416, 1480, 1544, 1608, 1672, 1736, 1800, 1864, 1928, 2024, 2088, 2152, 2216,
+      2280, 2408, 2472, 2536, 2600, 2664, 2728, 2792, 2856, 2976, 3104, 3240, 3368, 3496, 3624, 3752, 3824};
+  const unsigned nof_re_prime = 12 * nof_symb_sh - nof_dmrs_prb - nof_oh_prb;
+  const unsigned nof_re       = std::min(nof_re_prime, 156U) * n_prb;
+  const float    tcr          = target_code_rate * (1.F / 1024);
+  const float    nof_info     = 1.0F * (float)nof_re * tcr * (float)qm * (float)nof_layers;
+  if (nof_info <= 3824) {
+    unsigned n = 3;
+    if (nof_info > 512) {
+      n = (unsigned)std::floor(std::log2(nof_info)) - 6U;
+    }
+    const unsigned p2    = 1U << n;
+    const unsigned prime = std::max(24U, p2 * (unsigned)std::floor(nof_info / (float)p2));
+    for (uint16_t v : table) {
+      if (v >= prime) {
+        return v;
+      }
+    }
+    return 3824;
+  }
+  const unsigned n     = (unsigned)(std::floor(std::log2(nof_info - 24)) - 5.0F);
+  const unsigned p2    = 1U << n;
+  const unsigned prime = std::max(3840U, p2 * (unsigned)std::round((nof_info - 24) / (float)p2));
+  unsigned       C     = 1;
+  if (tcr <= 0.25F) {
+    C = divide_ceil(prime + 24, 3816);
+  } else if (prime > 8424) {
+    C = divide_ceil(prime + 24, 8424);
+  }
+  return 8 * C * divide_ceil(prime + 24, 8 * C) - 24;
+}
+
+namespace {
+
+// cyclic_prefix::get_length + phy_time_unit::to_samples (R/include/srsran/ran/cyclic_prefix.h:93-104,
+// phy_time_unit.h:100-111): units of kappa*Tc at 15 kHz -> samples at 15 kHz * 2^mu * dft_size.
+unsigned cp_length(const nrphy_ofdm_config_t& c, unsigned symbol_index)
+{
+  const unsigned mu    = c.numerology;
+  unsigned       units = 144U >> mu;
+  if (c.cp) {
+    units = 512U >> mu;
+  } else if (symbol_index == 0 || symbol_index == 7U * (1U << mu)) {
+    units += 16;
+  }
+  return (unsigned)(((uint64_t)units * c.dft_size * (1U << mu)) / 2048U);
+}
+
+} // namespace
+
+extern "C" uint32_t nrphy_ofdm_symbol_size(const nrphy_ofdm_config_t* cfg, uint32_t symbol_index)
+{
+  return cp_length(*cfg, symbol_index) + cfg->dft_size;
+}
+
+extern "C" uint32_t nrphy_ofdm_slot_size(const nrphy_ofdm_config_t* cfg, uint32_t slot_index)
+{
+  const unsigned nsymb = cfg->cp ? 12 : 14;
+  unsigned       n     = 0;
+  for (unsigned l = 0; l != nsymb; ++l) {
+    n += nrphy_ofdm_symbol_size(cfg, nsymb * slot_index + l);
+  }
+  return n;
+}
+
+// ================================================================================================================
+// Context
+// ================================================================================================================
+#define HIP_TRY(expr)                                                                                                  \
+  do {                                                                                                                 \
+    if ((expr) != hipSuccess) {                                                                                        \
+      return NRPHY_ERR_DEVICE;                                                                                         \
+    }                                                                                                                  \
+  } while (0)
+
+extern "C" int nrphy_create(nrphy_ctx_t** out, int device_id)
+{
+  if (out == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  *out      = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) {
+    return NRPHY_ERR_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device_id));
+  nrphy_ctx* ctx = new (std::nothrow) nrphy_ctx;
+  if (ctx == nullptr) {
+    return NRPHY_ERR_CAPACITY;
+  }
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return NRPHY_ERR_DEVICE;
+  }
+  std::vector<LiftedGraph> graphs(NOF_GRAPHS);
+  for (unsigned bg = 1; bg <= 2; ++bg) {
+    for (int i = 0; i != NOF_LIFTING_SIZES; ++i) {
+      build_lifted_graph(bg, LIFTING_SIZES[i], graphs[(bg - 1) * NOF_LIFTING_SIZES + i]);
+    }
+  }
+  GoldTables            gold;
+  std::vector<uint32_t> x1;
+  build_gold_tables(gold, x1);
+  if (upload(&ctx->d_graphs, graphs.data(), graphs.size() * sizeof(LiftedGraph)) != hipSuccess ||
+      upload(&ctx->d_gold, &gold, sizeof(gold)) != hipSuccess ||
+      upload(&ctx->d_x1, x1.data(), x1.size() * sizeof(uint32_t)) != hipSuccess) {
+    nrphy_destroy(ctx);
+    return NRPHY_ERR_DEVICE;
+  }
+  *out = ctx;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_destroy(nrphy_ctx_t* ctx)
+{
+  if (ctx == nullptr) {
+    return NRPHY_OK;
+  }
+  (void)hipSetDevice(ctx->device);
+  (void)hipFree(ctx->d_graphs);
+  (void)hipFree(ctx->d_gold);
+  (void)hipFree(ctx->d_x1);
+  for (float2* t : ctx->d_twiddle) {
+    (void)hipFree(t);
+  }
+  if (ctx->stream) {
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_synchronize(nrphy_ctx_t* ctx, void* stream)
+{
+  if (ctx == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+  return NRPHY_OK;
+}
+
+namespace {
+
+int twiddle_slot(uint32_t size)
+{
+  switch (size) {
+    case 128:
+      return 0;
+    case 256:
+      return 1;
+    case 512:
+      return 2;
+    case 1024:
+      return 3;
+    case 2048:
+      return 4;
+    case 4096:
+      return 5;
+    default:
+      return -1;
+  }
+}
+
+// exp(+j 2 pi k / N) computed in double precision and rounded once.
+const float2* get_twiddle(nrphy_ctx* ctx, uint32_t size)
+{
+  int slot = twiddle_slot(size);
+  if (slot < 0) {
+    return nullptr;
+  }
+  if (ctx->d_twiddle[slot] == nullptr) {
+    std::vector<float2> tw(size);
+    for (uint32_t k = 0; k != size; ++k) {
+      double ang = 2.0 * M_PI * (double)k / (double)size;
+      tw[k]      = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    if (upload(&ctx->d_twiddle[slot], tw.data(), tw.size() * sizeof(float2)) != hipSuccess) {
+      return nullptr;
+    }
+  }
+  return ctx->d_twiddle[slot];
+}
+
+} // namespace
+
+// ================================================================================================================
+// PDSCH plan
+// ================================================================================================================
+extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
+                                       const uint64_t* tb_offset, const uint32_t* grid_index, uint32_t nof_grids,
+                                       uint32_t grid_nof_ports, uint32_t grid_nof_subc, nrphy_pdsch_plan_t** out)
+{
+  if (ctx == nullptr || out == nullptr || (n_pdu != 0 && (pdus == nullptr || tb_offset == nullptr)) ||
+      grid_nof_ports == 0 || grid_nof_ports > NRPHY_MAX_PORTS || grid_nof_subc == 0 || grid_nof_subc % 12 != 0 ||
+      grid_nof_subc > NRPHY_MAX_RB * 12) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(ctx->device));
+  nrphy_pdsch_plan* plan = new (std::nothrow) nrphy_pdsch_plan;
+  if (plan == nullptr) {
+    return NRPHY_ERR_CAPACITY;
+  }
+  plan->ctx            = ctx;
+  plan->nof_grids      = nof_grids;
+  plan->grid_nof_ports = grid_nof_ports;
+  plan->grid_nof_subc  = grid_nof_subc;
+
+  std::vector<CbWork>   work;
+  std::vector<DmrsWork> dmrs;
+  std::vector<float>    weights;
+  std::vector<uint16_t> re_table;
+  std::vector<uint8_t>  mask(grid_nof_subc);
+  std::vector<uint16_t> list;
+  uint64_t              cw_bits = 0;
+  int                   status  = NRPHY_OK;
+
+  for (uint32_t i = 0; i != n_pdu && status == NRPHY_OK; ++i) {
+    const nrphy_pdsch_pdu_t& pdu = pdus[i];
+    if (nrphy_pdsch_validate(&pdu) != NRPHY_OK) {
+      status = NRPHY_ERR_INVALID_PDU;
+      break;
+    }
+    const uint32_t g = grid_index ? grid_index[i] : 0;
+    if (g >= nof_grids || pdu.nof_ports > grid_nof_ports || (tb_offset[i] & 3U) != 0 ||
+        12U * (unsigned)(mask_highest(pdu.prb_mask) + 1) > grid_nof_subc) {
+      status = NRPHY_ERR_ARGUMENT;
+      break;
+    }
+    PduDev pd;
+    std::memset(&pd, 0, sizeof(pd));
+    // RE mapping tables.
+    unsigned nof_re = 0;
+    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+      pd.sym_re_start[l] = nof_re;
+      data_re_mask(pdu, l, mask);
+      list.clear();
+      for (unsigned k = 0; k != grid_nof_subc; ++k) {
+        if (mask[k]) {
+          list.push_back((uint16_t)k);
+        }
+      }
+      if (list.empty()) {
+        pd.sym_kind[l] = SYM_NONE;
+      } else if ((unsigned)(list.back() - list.front()) + 1 == list.size()) {
+        pd.sym_kind[l] = SYM_CONTIGUOUS;
+        pd.sym_arg[l]  = list.front();
+      } else {
+        pd.sym_kind[l] = SYM_TABLE;
+        pd.sym_arg[l]  = (uint32_t)re_table.size();
+        // Reuse the previous symbol's list when identical (the common case).
+        for (unsigned lp = 0; lp != l; ++lp) {
+          if (pd.sym_kind[lp] == SYM_TABLE && pd.sym_re_start[lp + 1] - pd.sym_re_start[lp] == list.size() &&
+              std::equal(list.begin(), list.end(), re_table.begin() + pd.sym_arg[lp])) {
+            pd.sym_arg[l] = pd.sym_arg[lp];
+            break;
+          }
+        }
+        if (pd.sym_arg[l] == re_table.size()) {
+          re_table.insert(re_table.end(), list.begin(), list.end());
+        }
+      }
+      nof_re += (unsigned)list.size();
+      pd.sym_re_start[l + 1] = nof_re;
+    }
+    if (nof_re == 0) {
+      status = NRPHY_ERR_INVALID_PDU;
+      break;
+    }
+    nrphy_pdsch_derived_t d;
+    derive(pdu, nof_re, d);
+    if (d.lifting_size == 0 || d.nof_codeblocks > NRPHY_MAX_CODEBLOCKS || d.nof_codeblocks > nof_re ||
+        d.rm_length_short == 0) {
+      status = NRPHY_ERR_INVALID_PDU;
+      break;
+    }
+    const unsigned kb = (pdu.ldpc_base_graph == 1) ? 22 : 10;
+    pd.tb_offset      = tb_offset[i];
+    pd.cw_bit_offset  = cw_bits;
+    pd.tb_bytes       = pdu.tb_size_bytes;
+    pd.grid_index     = g;
+    pd.graph          = (pdu.ldpc_base_graph - 1) * NOF_LIFTING_SIZES + (uint32_t)lifting_position(d.lifting_size);
+    pd.zc             = d.lifting_size;
+    pd.kb             = kb;
+    pd.K              = d.segment_length;
+    pd.info_bits      = d.cb_info_bits;
+    pd.filler         = d.nof_filler_bits;
+    pd.tb_crc_bits    = d.nof_tb_crc_bits;
+    pd.cb_crc_bits    = d.nof_cb_crc_bits;
+    pd.zero_pad       = d.zero_pad;
+    pd.C              = d.nof_codeblocks;
+    pd.n_short        = d.nof_short_segments;
+    pd.e_short        = d.rm_length_short;
+    pd.e_long         = d.rm_length_long;
+    pd.n_cb           = d.n_cb;
+    pd.k0             = d.k0;
+    pd.qm             = pdu.qm;
+    pd.nof_layers     = pdu.nof_layers;
+    pd.nof_ports      = pdu.nof_ports;
+    pd.c_init         = (pdu.rnti << 15) + pdu.n_id; // q = 0 (pdsch_modulator_impl.cpp:35)
+    pd.nof_re         = nof_re;
+    // Parity rows rate matching can reach (the reference always computes all of them, pdsch_encoder_impl.cpp:52).
+    {
+      const unsigned nsys = (kb - 2) * d.lifting_size;
+      unsigned       fs = std::min(nsys - d.nof_filler_bits, d.n_cb), fe = std::min(nsys, d.n_cb);
+      const unsigned flen = fe - fs, n_valid = d.n_cb - flen;
+      const unsigned rank0 = d.k0 < fs ? d.k0 : (d.k0 < fe ? fs : d.k0 - flen);
+      unsigned       last; // highest circular-buffer position read
+      if (rank0 + d.rm_length_long > n_valid) {
+        last = d.n_cb - 1;
+      } else {
+        unsigned u = rank0 + d.rm_length_long - 1;
+        last       = u < fs ? u : u + flen;
+      }
+      const unsigned nodes = divide_ceil(last + 1 + 2 * d.lifting_size, d.lifting_size);
+      pd.nof_rows          = std::max(4U, nodes > kb ? nodes - kb : 0U);
+    }
+    // Precoding weights: data weights carry the modulation and power scaling (pdsch_modulator_impl.cpp:98-102).
+    {
+      const float avg     = (pdu.qm == 2) ? 2.0F : (pdu.qm == 4) ? 10.0F : (pdu.qm == 6) ? 42.0F : 170.0F;
+      float       scaling = std::sqrt(1 / avg);
+      const float cfg     = std::pow(10.0F, -pdu.ratio_pdsch_data_to_sss_dB / 20.0F);
+      if (std::isnormal(cfg)) {
+        scaling *= cfg;
+      }
+      const unsigned nw      = 2 * pdu.nof_prg * pdu.nof_ports * pdu.nof_layers;
+      pd.weights_offset      = (uint32_t)weights.size();
+      for (unsigned k = 0; k != nw; ++k) {
+        weights.push_back(pdu.precoding[k] * scaling);
+      }
+      pd.dmrs_weights_offset = (uint32_t)weights.size();
+      weights.insert(weights.end(), pdu.precoding, pdu.precoding + nw);
+      pd.nof_prg       = pdu.nof_prg;
+      pd.prg_size_subc = pdu.prg_size_rb * 12;
+    }
+    // DM-RS (dmrs_pdsch_processor_impl.cpp:84-106).
+    pd.dmrs_symbol_mask = pdu.dmrs_symbol_mask;
+    pd.dmrs_ref_rb      = (pdu.ref_point == 1) ? pdu.bwp_start_rb : 0;
+    {
+      const float amp   = std::pow(10.0F, -pdu.ratio_pdsch_dmrs_to_sss_dB / 20.0F);
+      pd.dmrs_amplitude = (float)(M_SQRT1_2 * (double)amp);
+    }
+    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+      const uint64_t a  = (uint64_t)(14 * pdu.slot_index + l + 1) * (2 * pdu.scrambling_id + 1);
+      pd.dmrs_c_init[l] = (uint32_t)(((a << 17) + (2 * pdu.scrambling_id + (pdu.n_scid ? 1 : 0))) & 0x7FFFFFFFULL);
+      if ((pdu.dmrs_symbol_mask >> l) & 1U) {
+        dmrs.push_back({i, l});
+      }
+    }
+    for (unsigned w = 0; w != NRPHY_PRB_WORDS; ++w) {
+      pd.prb_mask[2 * w]     = (uint32_t)pdu.prb_mask[w];
+      pd.prb_mask[2 * w + 1] = (uint32_t)(pdu.prb_mask[w] >> 32);
+    }
+    pd.first_prb = (uint32_t)mask_lowest(pdu.prb_mask);
+    pd.end_prb   = (uint32_t)mask_highest(pdu.prb_mask) + 1;
+    // Work items: every codeblock owns a whole number of RE (rm_length is a multiple of nof_layers * Qm).
+    const unsigned lq = pdu.nof_layers * pdu.qm;
+    for (unsigned cb = 0; cb != d.nof_codeblocks; ++cb) {
+      const unsigned nre = ((cb < d.nof_short_segments) ? d.rm_length_short : d.rm_length_long) / lq;
+      for (unsigned begin = 0; begin < nre; begin += RE_CHUNK) {
+        work.push_back({i, cb, begin, std::min<unsigned>(RE_CHUNK, nre - begin)});
+      }
+    }
+    plan->n_cb += d.nof_codeblocks;
+    plan->cw_offset.push_back(cw_bits);
+    cw_bits += (d.codeword_bits + 31U) & ~31ULL;
+    plan->pdus.push_back(pd);
+  }
+  if (status != NRPHY_OK) {
+    delete plan;
+    return status;
+  }
+  plan->cw_bits = cw_bits;
+  plan->n_work  = (uint32_t)work.size();
+  plan->n_dmrs  = (uint32_t)dmrs.size();
+  if (upload(&plan->d_pdus, plan->pdus.data(), plan->pdus.size() * sizeof(PduDev)) != hipSuccess ||
+      upload(&plan->d_work, work.data(), work.size() * sizeof(CbWork)) != hipSuccess ||
+      upload(&plan->d_dmrs, dmrs.data(), dmrs.size() * sizeof(DmrsWork)) != hipSuccess ||
+      upload(&plan->d_weights, weights.data(), weights.size() * sizeof(float)) != hipSuccess ||
+      upload(&plan->d_re_table, re_table.data(), re_table.size() * sizeof(uint16_t)) != hipSuccess ||
+      hipMalloc((void**)&plan->d_tb_crc, sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size())) != hipSuccess) {
+    nrphy_pdsch_plan_destroy(plan);
+    return NRPHY_ERR_DEVICE;
+  }
+  *out = plan;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
+{
+  if (plan == nullptr) {
+    return NRPHY_OK;
+  }
+  (void)hipSetDevice(plan->ctx->device);
+  (void)hipFree(plan->d_pdus);
+  (void)hipFree(plan->d_work);
+  (void)hipFree(plan->d_dmrs);
+  (void)hipFree(plan->d_weights);
+  (void)hipFree(plan->d_re_table);
+  (void)hipFree(plan->d_tb_crc);
+  for (hipEvent_t e : plan->events) {
+    (void)hipEventDestroy(e);
+  }
+  delete plan;
+  return NRPHY_OK;
+}
+
+extern "C" uint32_t nrphy_pdsch_plan_nof_codeblocks(const nrphy_pdsch_plan_t* plan)
+{
+  return plan ? plan->n_cb : 0;
+}
+
+extern "C" uint64_t nrphy_pdsch_plan_codeword_bits(const nrphy_pdsch_plan_t* plan)
+{
+  return plan ? plan->cw_bits : 0;
+}
+
+extern "C" uint64_t nrphy_pdsch_plan_codeword_offset(const nrphy_pdsch_plan_t* plan, uint32_t pdu)
+{
+  return (plan && pdu < plan->cw_offset.size()) ? plan->cw_offset[pdu] : 0;
+}
+
+extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, void* d_grid, uint8_t* d_cw_rm,
+                               uint8_t* d_cw_scrambled, int zero_grids, void* stream)
+{
+  if (plan == nullptr || d_tb == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  nrphy_ctx*  ctx = plan->ctx;
+  hipStream_t s   = stream ? (hipStream_t)stream : ctx->stream;
+  PdschLaunch p;
+  p.pdus           = plan->d_pdus;
+  p.work           = plan->d_work;
+  p.dmrs_work      = plan->d_dmrs;
+  p.weights        = plan->d_weights;
+  p.re_table       = plan->d_re_table;
+  p.graphs         = ctx->d_graphs;
+  p.gold           = ctx->d_gold;
+  p.x1_words       = ctx->d_x1;
+  p.tb_crc         = plan->d_tb_crc;
+  p.n_pdu          = (uint32_t)plan->pdus.size();
+  p.n_work         = plan->n_work;
+  p.n_dmrs_work    = plan->n_dmrs;
+  p.grid_nof_ports = plan->grid_nof_ports;
+  p.grid_nof_subc  = plan->grid_nof_subc;
+  const size_t cw_bytes = (size_t)(plan->cw_bits / 8);
+  if (d_grid && zero_grids) {
+    HIP_TRY(hipMemsetAsync(d_grid, 0,
+                           (size_t)plan->nof_grids * plan->grid_nof_ports * NRPHY_NSYMB * plan->grid_nof_subc * 4, s));
+  }
+  if (d_cw_rm) {
+    HIP_TRY(hipMemsetAsync(d_cw_rm, 0, cw_bytes, s));
+  }
+  if (d_cw_scrambled) {
+    HIP_TRY(hipMemsetAsync(d_cw_scrambled, 0, cw_bytes, s));
+  }
+  hipEvent_t* ev = nullptr;
+  if (plan->timed_runs < plan->max_timed_runs) {
+    ev = &plan->events[4 * plan->timed_runs++];
+    HIP_TRY(hipEventRecord(ev[0], s));
+  }
+  HIP_TRY(launch_tb_crc(p, d_tb, s));
+  if (ev) {
+    HIP_TRY(hipEventRecord(ev[1], s));
+  }
+  HIP_TRY(launch_codeblocks(p, d_tb, (uint32_t*)d_grid, (uint32_t*)d_cw_rm, (uint32_t*)d_cw_scrambled, s));
+  if (ev) {
+    HIP_TRY(hipEventRecord(ev[2], s));
+  }
+  if (d_grid) {
+    // After the data: with nof_cdm_groups_without_data == 0 the reference lets DM-RS overwrite data RE.
+    HIP_TRY(launch_dmrs(p, (uint32_t*)d_grid, s));
+  }
+  if (ev) {
+    HIP_TRY(hipEventRecord(ev[3], s));
+  }
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_pdsch_plan_enable_timing(nrphy_pdsch_plan_t* plan, uint32_t max_runs)
+{
+  if (plan == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  for (hipEvent_t e : plan->events) {
+    (void)hipEventDestroy(e);
+  }
+  plan->events.assign(4 * (size_t)max_runs, nullptr);
+  for (hipEvent_t& e : plan->events) {
+    HIP_TRY(hipEventCreate(&e));
+  }
+  plan->max_timed_runs = max_runs;
+  plan->timed_runs     = 0;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_pdsch_plan_kernel_times(nrphy_pdsch_plan_t* plan, float avg_ms[4], uint32_t* nof_runs)
+{
+  if (plan == nullptr || avg_ms == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  double sum[4] = {0, 0, 0, 0};
+  for (uint32_t r = 0; r != plan->timed_runs; ++r) {
+    hipEvent_t* ev = &plan->events[4 * r];
+    HIP_TRY(hipEventSynchronize(ev[3]));
+    float ms = 0;
+    for (int k = 0; k != 3; ++k) {
+      HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+      sum[k] += ms;
+    }
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3]));
+    sum[3] += ms;
+  }
+  for (int k = 0; k != 4; ++k) {
+    avg_ms[k] = plan->timed_runs ? (float)(sum[k] / plan->timed_runs) : 0.f;
+  }
+  if (nof_runs) {
+    *nof_runs = plan->timed_runs;
+  }
+  plan->timed_runs = 0;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb, void* grid,
+                                        uint32_t grid_nof_ports, uint32_t grid_nof_subc, uint8_t* cw_rm,
+                                        uint8_t* cw_scrambled)
+{
+  if (ctx == nullptr || pdu == nullptr || tb == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  nrphy_pdsch_plan_t* plan   = nullptr;
+  uint64_t            tb_off = 0;
+  uint32_t            gi     = 0;
+  int rc = nrphy_pdsch_plan_create(ctx, 1, pdu, &tb_off, &gi, 1, grid_nof_ports, grid_nof_subc, &plan);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  const size_t tb_alloc   = ((size_t)pdu->tb_size_bytes + 7) & ~(size_t)3;
+  const size_t grid_bytes = (size_t)grid_nof_ports * NRPHY_NSYMB * grid_nof_subc * 4;
+  const size_t cw_bytes   = (size_t)(plan->cw_bits / 8);
+  uint8_t *    d_tb = nullptr, *d_grid = nullptr, *d_rm = nullptr, *d_scr = nullptr;
+  rc = NRPHY_ERR_DEVICE;
+  do {
+    if (hipMalloc((void**)&d_tb, tb_alloc) != hipSuccess || hipMemset(d_tb, 0, tb_alloc) != hipSuccess ||
+        hipMemcpy(d_tb, tb, pdu->tb_size_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+      break;
+    }
+    if (grid && (hipMalloc((void**)&d_grid, grid_bytes) != hipSuccess ||
+                 hipMemcpy(d_grid, grid, grid_bytes, hipMemcpyHostToDevice) != hipSuccess)) {
+      break;
+    }
+    if (cw_rm && hipMalloc((void**)&d_rm, cw_bytes) != hipSuccess) {
+      break;
+    }
+    if (cw_scrambled && hipMalloc((void**)&d_scr, cw_bytes) != hipSuccess) {
+      break;
+    }
+    rc = nrphy_pdsch_run(plan, d_tb, d_grid, d_rm, d_scr, 0, ctx->stream);
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      break;
+    }
+    nrphy_pdsch_derived_t d;
+    nrphy_pdsch_derive(pdu, &d);
+    const size_t cw_out = (d.codeword_bits + 7) / 8;
+    if (grid && hipMemcpy(grid, d_grid, grid_bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    if (cw_rm && hipMemcpy(cw_rm, d_rm, cw_out, hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    if (cw_scrambled && hipMemcpy(cw_scrambled, d_scr, cw_out, hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    rc = NRPHY_OK;
+  } while (false);
+  (void)hipFree(d_tb);
+  (void)hipFree(d_grid);
+  (void)hipFree(d_rm);
+  (void)hipFree(d_scr);
+  nrphy_pdsch_plan_destroy(plan);
+  return rc;
+}
+
+extern "C" int nrphy_ldpc_encode(nrphy_ctx_t* ctx, uint32_t base_graph, uint32_t lifting_size, uint32_t n_cb,
+                                 const uint8_t* d_msg, uint32_t msg_stride_bytes, uint32_t out_bits, uint8_t* d_out,
+                                 uint32_t out_stride_bytes, void* stream)
+{
+  if (ctx == nullptr || (base_graph != 1 && base_graph != 2) || d_msg == nullptr || d_out == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const int pos = lifting_position(lifting_size);
+  const unsigned kb = (base_graph == 1) ? 22 : 10, nfull = (base_graph == 1) ? 68 : 52;
+  if (pos < 0 || out_bits == 0 || out_bits > (nfull - 2) * lifting_size ||
+      msg_stride_bytes < (kb * lifting_size + 7) / 8 || out_stride_bytes < (out_bits + 7) / 8) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(launch_ldpc_encode(ctx->d_graphs, (base_graph - 1) * NOF_LIFTING_SIZES + (uint32_t)pos, kb, lifting_size,
+                             n_cb, d_msg, msg_stride_bytes, out_bits, d_out, out_stride_bytes,
+                             stream ? (hipStream_t)stream : ctx->stream));
+  return NRPHY_OK;
+}
+
+// ================================================================================================================
+// OFDM
+// ================================================================================================================
+extern "C" int nrphy_ofdm_plan_create(nrphy_ctx_t* ctx, const nrphy_ofdm_config_t* cfg, uint32_t nof_ports,
+                                      nrphy_ofdm_plan_t** out)
+{
+  if (ctx == nullptr || cfg == nullptr || out == nullptr || nof_ports == 0 || cfg->numerology > 4 ||
+      !dft_size_supported(cfg->dft_size) || cfg->dft_size <= 12 * cfg->bw_rb || cfg->bw_rb == 0 || cfg->cp != 0 ||
+      !std::isnormal(cfg->scale)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (get_twiddle(ctx, cfg->dft_size) == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  nrphy_ofdm_plan* plan = new (std::nothrow) nrphy_ofdm_plan;
+  if (plan == nullptr) {
+    return NRPHY_ERR_CAPACITY;
+  }
+  plan->ctx           = ctx;
+  plan->cfg           = *cfg;
+  plan->nof_ports     = nof_ports;
+  plan->nsymb         = 14;
+  plan->nsym_subframe = 14U << cfg->numerology;
+  plan->slot_stride   = nrphy_ofdm_slot_size(cfg, 0);
+  // Phase compensation (TS 38.211 Section 5.4; phase_compensation_lut.h:49-82) times the scale.
+  const double        srate = 15000.0 * (double)(1U << cfg->numerology) * (double)cfg->dft_size;
+  std::vector<float2> phase(plan->nsym_subframe);
+  plan->cp.resize(plan->nsym_subframe);
+  plan->off.resize(plan->nsym_subframe);
+  unsigned offset = 0, in_slot = 0;
+  for (unsigned s = 0; s != plan->nsym_subframe; ++s) {
+    if (s % plan->nsymb == 0) {
+      in_slot = 0;
+    }
+    const unsigned cp = cp_length(*cfg, s);
+    offset += cp;
+    const double ph = -2.0 * M_PI * cfg->center_freq_hz * ((double)offset / srate);
+    const float  pr = (float)std::cos(ph), pi = (float)std::sin(ph);
+    phase[s]        = make_float2(pr * cfg->scale, pi * cfg->scale);
+    plan->cp[s]     = cp;
+    plan->off[s]    = in_slot;
+    in_slot += cp + cfg->dft_size;
+    offset += cfg->dft_size;
+  }
+  if (upload(&plan->d_phase, phase.data(), phase.size() * sizeof(float2)) != hipSuccess ||
+      upload(&plan->d_cp, plan->cp.data(), plan->cp.size() * sizeof(uint32_t)) != hipSuccess ||
+      upload(&plan->d_off, plan->off.data(), plan->off.size() * sizeof(uint32_t)) != hipSuccess) {
+    nrphy_ofdm_plan_destroy(plan);
+    return NRPHY_ERR_DEVICE;
+  }
+  *out = plan;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ofdm_plan_destroy(nrphy_ofdm_plan_t* plan)
+{
+  if (plan == nullptr) {
+    return NRPHY_OK;
+  }
+  (void)hipSetDevice(plan->ctx->device);
+  (void)hipFree(plan->d_phase);
+  (void)hipFree(plan->d_cp);
+  (void)hipFree(plan->d_off);
+  for (hipEvent_t e : plan->events) {
+    (void)hipEventDestroy(e);
+  }
+  delete plan;
+  return NRPHY_OK;
+}
+
+extern "C" uint32_t nrphy_ofdm_plan_slot_stride(const nrphy_ofdm_plan_t* plan)
+{
+  return plan ? plan->slot_stride : 0;
+}
+
+extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid,
+                              const uint32_t* slot_index, float* d_iq, void* stream)
+{
+  if (plan == nullptr || d_grid == nullptr || d_iq == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  nrphy_ctx* ctx = plan->ctx;
+  OfdmLaunch p;
+  p.dft_size    = plan->cfg.dft_size;
+  p.rg_size     = 12 * plan->cfg.bw_rb;
+  p.nof_ports   = plan->nof_ports;
+  p.nsymb       = plan->nsymb;
+  p.slot_stride = plan->slot_stride;
+  p.twiddle     = get_twiddle(ctx, plan->cfg.dft_size);
+  p.phase       = plan->d_phase;
+  p.cp_len      = plan->d_cp;
+  p.sym_offset  = plan->d_off;
+  hipStream_t s  = stream ? (hipStream_t)stream : ctx->stream;
+  hipEvent_t* ev = nullptr;
+  if (plan->timed_runs < plan->max_timed_runs) {
+    ev = &plan->events[2 * plan->timed_runs++];
+    HIP_TRY(hipEventRecord(ev[0], s));
+  }
+  HIP_TRY(launch_ofdm(p, nof_grids, (const uint32_t*)d_grid, slot_index, (float2*)d_iq, s));
+  if (ev) {
+    HIP_TRY(hipEventRecord(ev[1], s));
+  }
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ofdm_plan_enable_timing(nrphy_ofdm_plan_t* plan, uint32_t max_runs)
+{
+  if (plan == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  for (hipEvent_t e : plan->events) {
+    (void)hipEventDestroy(e);
+  }
+  plan->events.assign(2 * (size_t)max_runs, nullptr);
+  for (hipEvent_t& e : plan->events) {
+    HIP_TRY(hipEventCreate(&e));
+  }
+  plan->max_timed_runs = max_runs;
+  plan->timed_runs     = 0;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ofdm_plan_kernel_time(nrphy_ofdm_plan_t* plan, float* avg_ms, uint32_t* nof_runs)
+{
+  if (plan == nullptr || avg_ms == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  double sum = 0;
+  for (uint32_t r = 0; r != plan->timed_runs; ++r) {
+    HIP_TRY(hipEventSynchronize(plan->events[2 * r + 1]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, plan->events[2 * r], plan->events[2 * r + 1]));
+    sum += ms;
+  }
+  *avg_ms = plan->timed_runs ? (float)(sum / plan->timed_runs) : 0.f;
+  if (nof_runs) {
+    *nof_runs = plan->timed_runs;
+  }
+  plan->timed_runs = 0;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t port_index,
+                                               uint32_t symbol_index, float* output, uint32_t output_size)
+{
+  if (plan == nullptr || grid == nullptr || output == nullptr || port_index >= plan->nof_ports ||
+      symbol_index >= plan->nsym_subframe ||
+      output_size != plan->cp[symbol_index] + plan->cfg.dft_size) { // ofdm_modulator_impl.cpp:68-75
+    return NRPHY_ERR_ARGUMENT;
+  }
+  nrphy_ctx*   ctx        = plan->ctx;
+  const size_t grid_words = (size_t)plan->nof_ports * NRPHY_NSYMB * 12 * plan->cfg.bw_rb;
+  const size_t iq_samples = (size_t)plan->nof_ports * plan->slot_stride;
+  uint32_t *   d_grid = nullptr, *d_slot = nullptr;
+  float2*      d_iq   = nullptr;
+  const uint32_t slot = symbol_index / plan->nsymb;
+  int            rc   = NRPHY_ERR_DEVICE;
+  do {
+    if (hipMalloc((void**)&d_grid, grid_words * 4) != hipSuccess ||
+        hipMemcpy(d_grid, grid, grid_words * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void**)&d_iq, iq_samples * sizeof(float2)) != hipSuccess ||
+        upload(&d_slot, &slot, sizeof(slot)) != hipSuccess) {
+      break;
+    }
+    rc = nrphy_ofdm_run(plan, 1, d_grid, d_slot, (float*)d_iq, ctx->stream);
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      break;
+    }
+    const size_t src = (size_t)port_index * plan->slot_stride + plan->off[symbol_index];
+    if (hipMemcpy(output, d_iq + src, (size_t)output_size * sizeof(float2), hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    rc = NRPHY_OK;
+  } while (false);
+  (void)hipFree(d_grid);
+  (void)hipFree(d_iq);
+  (void)hipFree(d_slot);
+  return rc;
+}
+
+extern "C" int nrphy_dft_run(nrphy_ctx_t* ctx, uint32_t size, int inverse, uint32_t batch, const float* d_in,
+                             float* d_out, void* stream)
+{
+  if (ctx == nullptr || d_in == nullptr || d_out == nullptr || !dft_size_supported(size)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const float2* tw = get_twiddle(ctx, size);
+  if (tw == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  HIP_TRY(launch_dft(size, inverse, batch, tw, (const float2*)d_in, (float2*)d_out,
+                     stream ? (hipStream_t)stream : ctx->stream));
+  return NRPHY_OK;
+}

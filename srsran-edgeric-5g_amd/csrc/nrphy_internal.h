@@ -1,0 +1,153 @@
+// Internal declarations shared by the host side (nrphy_host.cpp) and the HIP kernels of libmi355nrphy.so.
+// Not part of the ABI (that is include/mi355_nrphy.h).
+#pragma once
+
+#include "mi355_nrphy.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nrphy {
+
+// ---- LDPC base graphs -------------------------------------------------------------------------------------
+// One lifted graph per (base graph, lifting size): 2 x 51 graphs, built once per context from the
+// 3GPP TS 38.212 Tables 5.3.2-2/-3 edge list (nr_ldpc_bg.inc).  The role of the reference's
+// ldpc_graph_impl array (R/lib/phy/upper/channel_coding/ldpc/ldpc_graph_impl.cpp:29-65), laid out for the GPU:
+// per check row a contiguous run of packed edges (column << 16 | shift), the identity column of extension rows
+// dropped, plus the three numbers that describe the dual-diagonal core (see ldpc_device.h).
+constexpr int NOF_LIFTING_SIZES = 51;
+constexpr int NOF_GRAPHS        = 2 * NOF_LIFTING_SIZES;
+constexpr int MAX_BG_ROWS       = 46;
+constexpr int MAX_BG_EDGES      = 316;
+
+struct LiftedGraph {
+  uint16_t row_ptr[MAX_BG_ROWS + 2]; // edges of row m: [row_ptr[m], row_ptr[m+1])
+  uint16_t core_b;                   // P^b p0 = sum(aux): the odd shift out of column Kb
+  uint16_t core_s0;                  // shift of (row 0, column Kb)
+  uint16_t core_s3;                  // shift of (row 3, column Kb)
+  uint16_t core_mid;                 // 1: row 1 has the third edge of column Kb (BG1); 2: row 2 (BG2)
+  uint32_t edge[MAX_BG_EDGES];       // column << 16 | lifted shift; core rows: systematic columns only
+};
+
+// ---- Gold sequence tables -----------------------------------------------------------------------------------
+// x2 jump matrices: row r of (M2)^(2^k) as a 31-bit mask, k = 0..GOLD_JUMP_BITS-1 (state bit j = x2(n + j)).
+constexpr int GOLD_JUMP_BITS  = 24;
+constexpr int GOLD_X1_WORDS   = 1 << 16; // x1(n + 1600) for n < 2^21 bits, MSB-first words
+
+constexpr int CRC_POW_WORDS = 288;     // >= 8448 / 32 + 1
+
+struct GoldTables {
+  uint32_t x2_jump[GOLD_JUMP_BITS][32];
+  uint32_t crc24b_pow32[CRC_POW_WORDS]; // x^(32 m) mod g_CRC24B(x): places a lane's partial CB-CRC
+};
+
+// ---- PDSCH plan ---------------------------------------------------------------------------------------------
+constexpr int RE_CHUNK = 512; // data RE handled by one wavefront
+
+enum SymKind : uint32_t { SYM_NONE = 0, SYM_CONTIGUOUS = 1, SYM_TABLE = 2 };
+
+// Everything the device needs to know about one PDU (derived on the host at plan creation).
+struct PduDev {
+  uint64_t tb_offset;      // byte offset of the transport block in d_tb (multiple of 4)
+  uint64_t cw_bit_offset;  // bit offset of the codeword in the tap buffers (multiple of 32)
+  uint32_t tb_bytes;
+  uint32_t grid_index;
+  uint32_t graph;          // index into the lifted graph array
+  uint32_t zc;
+  uint32_t kb;             // 22 or 10
+  uint32_t K;              // Kb * Zc
+  uint32_t info_bits;      // K' - L_cb
+  uint32_t filler;         // F
+  uint32_t tb_crc_bits;    // 16 or 24
+  uint32_t cb_crc_bits;    // 0 or 24
+  uint32_t zero_pad;
+  uint32_t C;
+  uint32_t n_short;
+  uint32_t e_short;
+  uint32_t e_long;
+  uint32_t n_cb;
+  uint32_t k0;
+  uint32_t nof_rows;       // parity rows to compute (>= 4): enough for every bit rate matching reads
+  uint32_t qm;
+  uint32_t nof_layers;
+  uint32_t nof_ports;
+  uint32_t c_init;         // scrambling sequence initialisation
+  uint32_t nof_re;
+  uint32_t weights_offset; // floats: data weights (scaled) [nof_prg][P][L][2] in the plan's weight array
+  uint32_t dmrs_weights_offset; // floats: unscaled weights, same shape
+  uint32_t nof_prg;
+  uint32_t prg_size_subc;
+  // RE mapping: data RE r of OFDM symbol l sits on subcarrier
+  //   SYM_CONTIGUOUS: sym_arg[l] + r,   SYM_TABLE: re_table[sym_arg[l] + r]
+  uint32_t sym_re_start[NRPHY_NSYMB + 1]; // prefix count of data RE before symbol l
+  uint32_t sym_kind[NRPHY_NSYMB];
+  uint32_t sym_arg[NRPHY_NSYMB];
+  // DM-RS
+  uint32_t dmrs_symbol_mask;
+  uint32_t dmrs_c_init[NRPHY_NSYMB];
+  uint32_t dmrs_ref_rb;
+  float    dmrs_amplitude;
+  uint32_t prb_mask[2 * NRPHY_PRB_WORDS];
+  uint32_t first_prb;
+  uint32_t end_prb;
+};
+
+// One wavefront of the codeblock kernel: RE [re_begin, re_begin + re_count) of codeblock cb of PDU pdu.
+struct CbWork {
+  uint32_t pdu;
+  uint32_t cb;
+  uint32_t re_begin; // first RE of the chunk, counted within the codeblock
+  uint32_t re_count;
+};
+
+// One workgroup of the DM-RS kernel: OFDM symbol `symbol` of PDU `pdu`.
+struct DmrsWork {
+  uint32_t pdu;
+  uint32_t symbol;
+};
+
+struct PdschLaunch {
+  const PduDev*      pdus;
+  const CbWork*      work;
+  const DmrsWork*    dmrs_work;
+  const float*       weights;
+  const uint16_t*    re_table;
+  const LiftedGraph* graphs;
+  const GoldTables*  gold;
+  const uint32_t*    x1_words;
+  uint32_t*          tb_crc; // [n_pdu]
+  uint32_t           n_pdu;
+  uint32_t           n_work;
+  uint32_t           n_dmrs_work;
+  uint32_t           grid_nof_ports;
+  uint32_t           grid_nof_subc;
+};
+
+// Kernel launchers (defined in the .hip files).
+hipError_t launch_tb_crc(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream);
+hipError_t launch_codeblocks(const PdschLaunch& p, const uint8_t* d_tb, uint32_t* d_grid, uint32_t* d_cw_rm,
+                             uint32_t* d_cw_scr, hipStream_t stream);
+hipError_t launch_dmrs(const PdschLaunch& p, uint32_t* d_grid, hipStream_t stream);
+hipError_t launch_ldpc_encode(const LiftedGraph* graphs, uint32_t graph, uint32_t kb, uint32_t zc, uint32_t n_cb,
+                              const uint8_t* d_msg, uint32_t msg_stride, uint32_t out_bits, uint8_t* d_out,
+                              uint32_t out_stride, hipStream_t stream);
+
+// ---- OFDM ---------------------------------------------------------------------------------------------------
+struct OfdmLaunch {
+  uint32_t       dft_size;
+  uint32_t       rg_size;     // 12 * bw_rb
+  uint32_t       nof_ports;
+  uint32_t       nsymb;       // symbols per slot
+  uint32_t       slot_stride; // samples per (grid, port) in the output
+  const float2*  twiddle;     // exp(+j 2 pi k / N), k < N
+  const float2*  phase;       // [symbols per subframe] phase compensation * scale
+  const uint32_t* cp_len;     // [symbols per subframe]
+  const uint32_t* sym_offset; // [symbols per subframe] start of the symbol within its slot (samples)
+};
+hipError_t launch_ofdm(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* d_grid, const uint32_t* d_slot_index,
+                       float2* d_iq, hipStream_t stream);
+hipError_t launch_dft(uint32_t size, int inverse, uint32_t batch, const float2* twiddle_fwd_inv, const float2* d_in,
+                      float2* d_out, hipStream_t stream);
+bool       dft_size_supported(uint32_t size);
+
+} // namespace nrphy

@@ -1,0 +1,223 @@
+"""Loader and thin object wrappers for csrc/libmi355nrphy.so (the C ABI of include/mi355_nrphy.h).
+
+There is deliberately no CPU implementation behind these classes: if the HIP library is missing or no GPU is
+present the constructors raise.  PyTorch is used only as the device-memory allocator / stream provider of the
+callers (tests, bench.py): tensors are passed down as raw device pointers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmi355nrphy.so")
+
+_LIB = None
+
+
+class NrphyError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        super().__init__("%s failed: status %d (%s)" % (what, status, strerror(status)))
+
+
+def load():
+    """Returns the ctypes handle of libmi355nrphy.so; raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("HIP library %s is missing: run `python srsran-edgeric-5g_amd/build.py` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        _LIB = abi.declare(C.CDLL(LIB_PATH))
+    return _LIB
+
+
+def strerror(status):
+    return load().nrphy_strerror(status).decode()
+
+
+def _check(status, what):
+    if status != abi.OK:
+        raise NrphyError(status, what)
+
+
+def _dptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """nrphy_ctx: device tables + default stream.  Replaces the reference's factory chain."""
+
+    def __init__(self, device_id=0):
+        self.lib = load()
+        h = C.c_void_p()
+        _check(self.lib.nrphy_create(C.byref(h), device_id), "nrphy_create")
+        self.handle = h
+        self.device_id = device_id
+
+    def close(self):
+        if self.handle:
+            self.lib.nrphy_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self, stream=None):
+        _check(self.lib.nrphy_synchronize(self.handle, stream), "nrphy_synchronize")
+
+    # ---- single-PDU host-span entry points (reference semantics) --------------------------------------
+    def pdsch_process_host(self, pdu, tb, nof_ports, nof_subc, grid=None, taps=False):
+        """pdsch_processor::process with host spans.  Returns grid [ports][14][subc][2] uint16 (raw bf16)
+        and, with taps, the packed rate-matched and scrambled codewords."""
+        tb = np.ascontiguousarray(tb, dtype=np.uint8)
+        if grid is None:
+            grid = np.zeros((nof_ports, 14, nof_subc, 2), np.uint16)
+        d = derive(pdu)
+        nb = (d["codeword_bits"] + 7) // 8
+        rm = np.zeros(nb, np.uint8) if taps else None
+        scr = np.zeros(nb, np.uint8) if taps else None
+        _check(self.lib.nrphy_pdsch_process_host(
+            self.handle, C.byref(pdu), tb.ctypes.data, grid.ctypes.data, nof_ports, nof_subc,
+            rm.ctypes.data if taps else None, scr.ctypes.data if taps else None), "nrphy_pdsch_process_host")
+        return (grid, rm, scr) if taps else grid
+
+    def ldpc_encode(self, base_graph, lifting_size, d_msg, msg_stride, out_bits, d_out, out_stride, n_cb, stream=None):
+        _check(self.lib.nrphy_ldpc_encode(self.handle, base_graph, lifting_size, n_cb, _dptr(d_msg), msg_stride,
+                                          out_bits, _dptr(d_out), out_stride, stream), "nrphy_ldpc_encode")
+
+    def dft(self, size, inverse, batch, d_in, d_out, stream=None):
+        _check(self.lib.nrphy_dft_run(self.handle, size, int(inverse), batch, _dptr(d_in), _dptr(d_out), stream),
+               "nrphy_dft_run")
+
+
+class PdschPlan:
+    """nrphy_pdsch_plan: a batch of PDUs with their grids; run() launches the whole PDSCH path."""
+
+    def __init__(self, ctx, pdus, tb_offsets, grid_indices, nof_grids, nof_ports, nof_subc):
+        self.ctx = ctx
+        n = len(pdus)
+        arr = (abi.PdschPdu * n)(*pdus)
+        self._keep = [getattr(p, "_keepalive", None) for p in pdus]
+        offs = (C.c_uint64 * n)(*tb_offsets)
+        gidx = (C.c_uint32 * n)(*grid_indices)
+        h = C.c_void_p()
+        _check(ctx.lib.nrphy_pdsch_plan_create(ctx.handle, n, arr, offs, gidx, nof_grids, nof_ports, nof_subc,
+                                               C.byref(h)), "nrphy_pdsch_plan_create")
+        self.handle = h
+        self.nof_grids, self.nof_ports, self.nof_subc = nof_grids, nof_ports, nof_subc
+
+    @property
+    def nof_codeblocks(self):
+        return int(self.ctx.lib.nrphy_pdsch_plan_nof_codeblocks(self.handle))
+
+    @property
+    def codeword_bits(self):
+        return int(self.ctx.lib.nrphy_pdsch_plan_codeword_bits(self.handle))
+
+    def codeword_offset(self, pdu):
+        return int(self.ctx.lib.nrphy_pdsch_plan_codeword_offset(self.handle, pdu))
+
+    def run(self, d_tb, d_grid, d_cw_rm=None, d_cw_scr=None, zero_grids=True, stream=None):
+        _check(self.ctx.lib.nrphy_pdsch_run(self.handle, _dptr(d_tb), _dptr(d_grid), _dptr(d_cw_rm), _dptr(d_cw_scr),
+                                            int(zero_grids), stream), "nrphy_pdsch_run")
+
+    def enable_timing(self, max_runs):
+        _check(self.ctx.lib.nrphy_pdsch_plan_enable_timing(self.handle, max_runs), "nrphy_pdsch_plan_enable_timing")
+
+    def kernel_times(self):
+        """Average ms of (tb_crc, codeblock, dmrs, whole run) over the recorded runs, and the run count."""
+        ms = (C.c_float * 4)()
+        n = C.c_uint32(0)
+        _check(self.ctx.lib.nrphy_pdsch_plan_kernel_times(self.handle, ms, C.byref(n)), "nrphy_pdsch_plan_kernel_times")
+        return [float(x) for x in ms], int(n.value)
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.nrphy_pdsch_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OfdmPlan:
+    """nrphy_ofdm_plan: ofdm_modulator_configuration + port count."""
+
+    def __init__(self, ctx, cfg, nof_ports):
+        self.ctx = ctx
+        self.cfg = cfg
+        self.nof_ports = nof_ports
+        h = C.c_void_p()
+        _check(ctx.lib.nrphy_ofdm_plan_create(ctx.handle, C.byref(cfg), nof_ports, C.byref(h)),
+               "nrphy_ofdm_plan_create")
+        self.handle = h
+        self.slot_stride = int(ctx.lib.nrphy_ofdm_plan_slot_stride(h))
+
+    def run(self, nof_grids, d_grid, d_iq, d_slot_index=None, stream=None):
+        _check(self.ctx.lib.nrphy_ofdm_run(self.handle, nof_grids, _dptr(d_grid), _dptr(d_slot_index), _dptr(d_iq),
+                                           stream), "nrphy_ofdm_run")
+
+    def enable_timing(self, max_runs):
+        _check(self.ctx.lib.nrphy_ofdm_plan_enable_timing(self.handle, max_runs), "nrphy_ofdm_plan_enable_timing")
+
+    def kernel_time(self):
+        ms = C.c_float(0)
+        n = C.c_uint32(0)
+        _check(self.ctx.lib.nrphy_ofdm_plan_kernel_time(self.handle, C.byref(ms), C.byref(n)),
+               "nrphy_ofdm_plan_kernel_time")
+        return float(ms.value), int(n.value)
+
+    def modulate_symbol_host(self, grid, port, symbol_index):
+        grid = np.ascontiguousarray(grid, dtype=np.uint16)
+        n = symbol_size(self.cfg, symbol_index)
+        out = np.zeros(n, np.complex64)
+        _check(self.ctx.lib.nrphy_ofdm_modulate_symbol_host(self.handle, grid.ctypes.data, port, symbol_index,
+                                                            out.ctypes.data, n), "nrphy_ofdm_modulate_symbol_host")
+        return out
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.nrphy_ofdm_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- host-only helpers (no GPU needed) ---------------------------------------------------------------------------
+def validate(pdu):
+    return int(load().nrphy_pdsch_validate(C.byref(pdu)))
+
+
+def derive(pdu):
+    d = abi.PdschDerived()
+    _check(load().nrphy_pdsch_derive(C.byref(pdu), C.byref(d)), "nrphy_pdsch_derive")
+    return d.as_dict()
+
+
+def tbs_calculate(nof_symb_sh, nof_dmrs_prb, nof_oh_prb, qm, rate_x1024, nof_layers, n_prb):
+    return int(load().nrphy_tbs_calculate(nof_symb_sh, nof_dmrs_prb, nof_oh_prb, qm, float(rate_x1024), nof_layers,
+                                          n_prb))
+
+
+def symbol_size(cfg, symbol_index):
+    return int(load().nrphy_ofdm_symbol_size(C.byref(cfg), symbol_index))
+
+
+def slot_size(cfg, slot_index):
+    return int(load().nrphy_ofdm_slot_size(C.byref(cfg), slot_index))

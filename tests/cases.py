@@ -1,0 +1,89 @@
+"""TEST INFRASTRUCTURE: PDU / OFDM configurations shared by the parity tests, the golden generator and bench.py.
+
+BASELINE.json configs: all use normal CP, DM-RS type 1 on symbols {2, 7, 11} with 2 CDM groups
+without data, PDSCH symbols 0-11, rnti 1, n_id 0, rv 0, CRB0, no reserved RE, 0 dB, tbs_lbrm = 159749 bytes.
+"""
+import os
+
+import numpy as np
+
+import backends
+
+abi = backends.abi
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def codebook(name):
+    """Precoding matrices of TS 38.214 the reference benchmark uses, stored from the reference
+    (tests/golden/generate.py -> codebooks.npz): [1][ports][layers][2] float32."""
+    return np.load(os.path.join(GOLDEN, "codebooks.npz"))[name]
+
+
+def tbs(nof_symb, dmrs_re_per_prb, qm, rate_x1024, layers, n_prb):
+    return backends.pkg.lib.tbs_calculate(nof_symb, dmrs_re_per_prb, 0, qm, rate_x1024, layers, n_prb)
+
+
+def baseline_config(cfg, rnti=1, n_id=0, slot_index=0):
+    """(pdu, nof_ports, nof_subc, ofdm_cfg) of BASELINE config 1, 2 or 3."""
+    if cfg == 1:   # 10 MHz SISO QPSK R=120/1024, FFT 1024
+        n_prb, bw, qm, rate, w, mu, n = 52, 52, 2, 120, codebook("single_port"), 0, 1024
+        bg = 2
+    elif cfg == 2:  # 20 MHz 2-layer 64-QAM R=873/1024, FFT 2048
+        n_prb, bw, qm, rate, w, mu, n = 106, 106, 6, 873, codebook("two_layer_two_ports_0"), 0, 2048
+        bg = 1
+    elif cfg == 3:  # 100 MHz 4-layer 256-QAM R=948/1024, FFT 4096
+        n_prb, bw, qm, rate, w, mu, n = 270, 273, 8, 948, codebook("four_layer_four_ports_0_0"), 1, 4096
+        bg = 1
+    else:
+        raise ValueError(cfg)
+    layers = w.shape[2]
+    tb_bits = tbs(12, 36, qm, rate, layers, n_prb)
+    pdu = abi.make_pdu(slot_index=slot_index, rnti=rnti, n_id=n_id, bwp_start_rb=0, bwp_size_rb=bw, qm=qm,
+                       dmrs_symbols=(2, 7, 11), nof_cdm_groups_without_data=2, prb_start=0, prb_count=n_prb,
+                       start_symbol=0, nof_symbols=12, base_graph=bg, precoding=w, tb_size_bytes=tb_bits // 8)
+    ofdm = abi.OfdmConfig(mu, bw, n, 0, 1.0, 3.5e9 if cfg == 3 else 2.4e9)
+    return pdu, w.shape[1], bw * 12, ofdm
+
+
+def mixed_cell(cell_id, slot_index=0):
+    """BASELINE config 4: one 100 MHz cell-slot with four 68-PRB PDUs (QPSK, 16/64/256-QAM), 4 layers each."""
+    w = codebook("four_layer_four_ports_0_0")
+    pdus = []
+    for ue, (qm, rate) in enumerate(((2, 120), (4, 658), (6, 873), (8, 948))):
+        tb_bits = tbs(12, 36, qm, rate, 4, 68)
+        bg = 2 if (rate <= 256 or tb_bits <= 292 or (tb_bits <= 3824 and rate <= 686)) else 1
+        pdus.append(abi.make_pdu(slot_index=slot_index, rnti=ue + 1, n_id=cell_id, bwp_size_rb=273, qm=qm,
+                                 dmrs_symbols=(2, 7, 11), prb_start=68 * ue, prb_count=68, nof_symbols=12,
+                                 base_graph=bg, precoding=w, tb_size_bytes=tb_bits // 8))
+    return pdus, 4, 273 * 12
+
+
+RESERVED_26 = [
+    (range(1, 26, 1), [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 1] + [0] * 10),
+    (range(1, 26, 2), [0] * 11 + [1], [0, 0, 0, 0, 1] + [0] * 9),
+    (range(2, 26, 2), [0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0], [0] * 12 + [1, 0]),
+]
+
+
+def unit_test_like_pdus(rng):
+    """PDUs in the style of the reference's pdsch_processor_test_data.h (26-PRB grid, reserved RE patterns, identity
+    precoding, 1-4 layers, all modulations, both base graphs, CRB0/PRB0, odd power ratios)."""
+    out = []
+    for layers in (1, 2, 3, 4):
+        for qm in (2, 4, 6, 8):
+            n_prb = int(rng.integers(1, 20))
+            start = int(rng.integers(1, 26 - n_prb))
+            tb_bits = tbs(12, 12 * 4, qm, int(rng.integers(100, 900)), layers, n_prb)
+            out.append(abi.make_pdu(
+                slot_index=int(rng.integers(0, 20)), rnti=int(rng.integers(1, 65535)), bwp_start_rb=1, bwp_size_rb=25,
+                qm=qm, n_id=int(rng.integers(0, 1024)), dmrs_symbols=(2, 5, 8, 11),
+                scrambling_id=int(rng.integers(0, 65536)), n_scid=layers & 1, nof_cdm_groups_without_data=2,
+                prb_start=start, prb_count=n_prb, start_symbol=2, nof_symbols=12, base_graph=1 + (qm < 6),
+                reserved=RESERVED_26, precoding=abi.identity_precoding(layers), tb_size_bytes=tb_bits // 8,
+                ref_point=layers & 1, ratio_dmrs_dB=-3.0 if layers > 2 else 0.0, ratio_data_dB=1.5 * (layers - 1),
+                rv=(layers + qm) % 4))
+    return out
+
+
+def random_tb(rng, pdu):
+    return rng.integers(0, 256, pdu.tb_size_bytes, dtype=np.uint8)

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ from the COMPILED REFERENCE (oracle/_ref/libsrsref.so, built by
+`make -C oracle ref` from /root/reference).  Run in the build container only; the outputs (small .npz files: inputs +
+expected outputs, never reference source) are committed and travel to the GPU box.
+
+    python tests/golden/generate.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import backends  # noqa: E402
+
+abi = backends.abi
+r = backends.ref()
+assert r is not None, "build oracle/_ref first: make -C oracle ref"
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# 1. Precoding codebooks the BASELINE configs use.
+np.savez(os.path.join(HERE, "codebooks.npz"),
+         single_port=r.codebook(1), two_layer_two_ports_0=r.codebook(3, 0),
+         four_layer_four_ports_0_0=r.codebook(7, 0, 0), one_layer_two_ports_1=r.codebook(2, 1),
+         three_layer_four_ports_1_0=r.codebook(6, 1, 0), two_layer_four_ports_1_0_1=r.codebook(5, 1, 0, 1))
+
+import cases  # noqa: E402  (needs codebooks.npz)
+
+# 2. LDPC encoder: every (base graph, lifting size), one random message, full-length output
+#    (the configurations of ldpc_enc_dec_test.cpp: 51 lifting sizes x 2 base graphs).
+rng = np.random.default_rng(38212)
+msgs, outs, keys = [], [], []
+for bg in (1, 2):
+    kb = 22 if bg == 1 else 10
+    for zc in [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52,
+               56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128, 144, 160, 176, 192, 208, 224, 240, 256, 288, 320, 352,
+               384]:
+        msg = np.packbits(rng.integers(0, 2, kb * zc, dtype=np.uint8))
+        n = (66 if bg == 1 else 50) * zc
+        out = r.ldpc_encode(bg, zc, msg, n, simd=1)
+        assert np.array_equal(out, r.ldpc_encode(bg, zc, msg, n, simd=0))
+        keys.append((bg, zc))
+        msgs.append(msg)
+        outs.append(out)
+np.savez_compressed(os.path.join(HERE, "ldpc_encoder.npz"), keys=np.array(keys),
+                    **{"msg_%d_%d" % k: m for k, m in zip(keys, msgs)},
+                    **{"out_%d_%d" % k: o for k, o in zip(keys, outs)})
+
+# 3. PDSCH processor: BASELINE configs 1-3 + unit-test-like PDUs.  Stored: seed for the TB, SHA-256 of the codeword
+#    and of the grid, and the first/last 64 grid words of every port (small files; the TB is regenerated from the seed).
+def pdu_fields(pdu):
+    return {n: np.array(getattr(pdu, n)) for n, _ in abi.PdschPdu._fields_
+            if n not in ("prb_mask", "reserved", "precoding")}
+
+
+golden = {}
+items = [("cfg%d" % c,) + cases.baseline_config(c)[:3] for c in (1, 2, 3)]
+for i, pdu in enumerate(cases.unit_test_like_pdus(np.random.default_rng(2024))):
+    items.append(("unit%02d" % i, pdu, 4, 26 * 12))
+o = backends.oracle()
+for name, pdu, nof_ports, nof_subc in items:
+    tb = np.random.default_rng(abs(hash(name)) % 2**32 if False else sum(map(ord, name))).integers(
+        0, 256, pdu.tb_size_bytes, dtype=np.uint8)
+    d = o.derive(pdu)
+    grid = r.pdsch_process(pdu, tb, nof_ports, nof_subc, simd=1)
+    cw = r.pdsch_encode(pdu, tb, d)[: (d["codeword_bits"] + 7) // 8]
+    g32 = grid.view(np.uint32).reshape(nof_ports, -1)
+    nz = [np.flatnonzero(g32[p]) for p in range(nof_ports)]
+    golden[name + "_tb_seed"] = np.array(sum(map(ord, name)))
+    golden[name + "_cw_sha"] = np.array(sha(cw))
+    golden[name + "_grid_sha"] = np.array(sha(grid))
+    golden[name + "_cw_head"] = cw[:64].copy()
+    for p in range(nof_ports):
+        idx = nz[p][:64] if len(nz[p]) else np.zeros(0, np.int64)
+        golden["%s_p%d_idx" % (name, p)] = idx
+        golden["%s_p%d_val" % (name, p)] = g32[p][idx]
+np.savez_compressed(os.path.join(HERE, "pdsch_processor.npz"), **golden)
+
+# 4. OFDM modulator: random bf16 grid rows -> reference IQ (generic DFT; FFTW is absent here), sub-sampled.
+rng = np.random.default_rng(38211)
+og = {}
+for name, (mu, bw, n, fc, slot) in {"n4096": (1, 273, 4096, 3.5e9, 1), "n2048": (0, 106, 2048, 2.4e9, 0),
+                                    "n1024": (0, 52, 1024, 2.4e9, 0)}.items():
+    cfg = abi.OfdmConfig(mu, bw, n, 0, 1.0 / np.sqrt(n), fc)
+    grid = (rng.standard_normal((1, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    iq = r.ofdm_slot(cfg, grid, slot)
+    og[name + "_grid"] = grid
+    og[name + "_iq"] = iq
+    og[name + "_cfg"] = np.array([mu, bw, n, fc, slot], dtype=np.float64)
+np.savez_compressed(os.path.join(HERE, "ofdm_modulator.npz"), **og)
+print("golden vectors written to", HERE)

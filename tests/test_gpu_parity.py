@@ -1,0 +1,347 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs, against the
+golden vectors generated from the compiled reference, and -- at BASELINE sizes -- through size-independent properties.
+
+Bit-exact for everything integer (codewords, scrambled bits) and for the bf16 grid; 1e-5 relative for the fp32 IQ.
+"""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import backends
+import cases
+
+abi = backends.abi
+lib = backends.pkg.lib
+pytestmark = pytest.mark.gpu
+
+LIFTING_SIZES = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52,
+                 56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128, 144, 160, 176, 192, 208, 224, 240, 256, 288, 320, 352,
+                 384]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LDPC encoder: all 102 lifted graphs, several output lengths (mirrors ldpc_enc_dec_test.cpp LDPCEncTest)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bg", [1, 2])
+def test_ldpc_encoder_all_graphs_vs_oracle(gpu_ctx, oracle, bg):
+    import torch
+    rng = np.random.default_rng(100 + bg)
+    kb, nshort = (22, 66) if bg == 1 else (10, 50)
+    for zc in LIFTING_SIZES:
+        n_cb = 3
+        kbytes = (kb * zc + 7) // 8
+        msgs = np.zeros((n_cb, kbytes + 3), np.uint8)
+        for i in range(n_cb):
+            msgs[i, :kbytes] = np.packbits(rng.integers(0, 2, kb * zc, dtype=np.uint8))
+        d_msg = dev(msgs)
+        full = nshort * zc
+        for out_bits in sorted({full, (kb + 2) * zc, full - 3 * zc - 1, kb * zc + 2 * zc + 5}):
+            stride = (out_bits + 7) // 8 + 5
+            d_out = torch.zeros((n_cb, stride), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            gpu_ctx.ldpc_encode(bg, zc, d_msg, msgs.shape[1], out_bits, d_out, stride, n_cb)
+            gpu_ctx.synchronize()
+            out = d_out.cpu().numpy()
+            for i in range(n_cb):
+                want = oracle.ldpc_encode(bg, zc, msgs[i, :kbytes], out_bits)
+                assert np.array_equal(out[i, : len(want)], want), (bg, zc, out_bits, i)
+                assert not out[i, len(want):].any()
+
+
+def test_ldpc_encoder_vs_reference_golden(gpu_ctx):
+    import torch
+    g = np.load(os.path.join(cases.GOLDEN, "ldpc_encoder.npz"))
+    for bg, zc in g["keys"]:
+        msg = g["msg_%d_%d" % (bg, zc)]
+        want = g["out_%d_%d" % (bg, zc)]
+        out_bits = (66 if bg == 1 else 50) * int(zc)
+        d_msg = dev(np.concatenate([msg, np.zeros(4, np.uint8)]))
+        d_out = torch.zeros(len(want) + 4, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        gpu_ctx.ldpc_encode(int(bg), int(zc), d_msg, len(msg) + 4, out_bits, d_out, len(want) + 4, 1)
+        gpu_ctx.synchronize()
+        assert np.array_equal(d_out.cpu().numpy()[: len(want)], want), (bg, zc)
+
+
+def test_ldpc_encoder_linearity_full_size(gpu_ctx):
+    """Size-independent property at the maximum size: the code is linear, encode(a ^ b) == encode(a) ^ encode(b)."""
+    import torch
+    rng = np.random.default_rng(7)
+    n_cb, kbytes, out_bits = 512, 8448 // 8, 66 * 384
+    a = rng.integers(0, 256, (n_cb, kbytes), dtype=np.uint8)
+    b = rng.integers(0, 256, (n_cb, kbytes), dtype=np.uint8)
+    outs = []
+    for m in (a, b, a ^ b):
+        d_out = torch.zeros((n_cb, out_bits // 8), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        gpu_ctx.ldpc_encode(1, 384, dev(m), kbytes, out_bits, d_out, out_bits // 8, n_cb)
+        gpu_ctx.synchronize()
+        outs.append(d_out.cpu().numpy())
+    assert np.array_equal(outs[0] ^ outs[1], outs[2])
+    assert np.array_equal(outs[0][:, : (20 * 384) // 8], a[:, (2 * 384) // 8: (22 * 384) // 8])  # systematic part
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PDSCH processor
+# ---------------------------------------------------------------------------------------------------------------------
+def run_single(gpu_ctx, oracle, pdu, tb, nof_ports, nof_subc):
+    d = oracle.derive(pdu)
+    assert lib.derive(pdu) == d
+    grid, rm, scr = gpu_ctx.pdsch_process_host(pdu, tb, nof_ports, nof_subc, taps=True)
+    ogrid, orm, oscr = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc, taps=True, codeword_bits=d["codeword_bits"])
+    assert np.array_equal(rm, orm), "rate-matched codeword differs"
+    assert np.array_equal(scr, oscr), "scrambled codeword differs"
+    bad = np.argwhere(grid != ogrid)
+    assert bad.size == 0, "grid differs at %s ..." % bad[:4].tolist()
+    return grid, rm
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_pdsch_baseline_configs_vs_oracle_and_golden(gpu_ctx, oracle, cfg):
+    pdu, nof_ports, nof_subc, _ = cases.baseline_config(cfg)
+    name = "cfg%d" % cfg
+    g = np.load(os.path.join(cases.GOLDEN, "pdsch_processor.npz"))
+    tb = np.random.default_rng(int(g[name + "_tb_seed"])).integers(0, 256, pdu.tb_size_bytes, dtype=np.uint8)
+    grid, rm = run_single(gpu_ctx, oracle, pdu, tb, nof_ports, nof_subc)
+    # Reference-generated golden: codeword and grid hashes.
+    assert sha(rm) == str(g[name + "_cw_sha"])
+    assert sha(grid) == str(g[name + "_grid_sha"])
+
+
+def test_pdsch_unit_test_like_pdus(gpu_ctx, oracle):
+    g = np.load(os.path.join(cases.GOLDEN, "pdsch_processor.npz"))
+    for i, pdu in enumerate(cases.unit_test_like_pdus(np.random.default_rng(2024))):
+        name = "unit%02d" % i
+        assert lib.validate(pdu) == 0
+        tb = np.random.default_rng(int(g[name + "_tb_seed"])).integers(0, 256, pdu.tb_size_bytes, dtype=np.uint8)
+        grid, rm = run_single(gpu_ctx, oracle, pdu, tb, 4, 26 * 12)
+        assert sha(rm) == str(g[name + "_cw_sha"]), name
+        assert sha(grid) == str(g[name + "_grid_sha"]), name
+
+
+def edge_case_pdus():
+    rng = np.random.default_rng(99)
+    w22 = (rng.standard_normal((3, 2, 2, 2)) * 0.5).astype(np.float32)       # 3 PRGs, complex random weights
+    w42 = (rng.standard_normal((1, 4, 2, 2)) * 0.5).astype(np.float32)
+    w43 = (rng.standard_normal((2, 4, 3, 2)) * 0.5).astype(np.float32)
+    out = []
+    # E > Ncb wrap-around repetition (config 1 style) with rv 2 and 3.
+    for rv in (2, 3):
+        out.append(("wrap_rv%d" % rv, abi.make_pdu(bwp_size_rb=52, qm=2, dmrs_symbols=(2, 11), prb_count=52,
+                                                   nof_symbols=14, base_graph=2, rv=rv, tb_size_bytes=100), 1, 52 * 12))
+    # Tiny LBRM buffer (the reference benchmark's quirk: Nref of a few hundred bits).
+    out.append(("tiny_lbrm", abi.make_pdu(bwp_size_rb=30, qm=6, dmrs_symbols=(3,), prb_start=2, prb_count=20,
+                                          nof_symbols=10, start_symbol=1, tbs_lbrm_bytes=3168, tb_size_bytes=4000,
+                                          precoding=w22, prg_size_rb=8), 2, 30 * 12))
+    # One CDM group without data: data shares the DM-RS symbols on the other comb.
+    out.append(("cdm1", abi.make_pdu(bwp_size_rb=24, qm=4, dmrs_symbols=(2, 9), nof_cdm_groups_without_data=1,
+                                     prb_start=0, prb_count=24, nof_symbols=13, tb_size_bytes=1500, rv=1,
+                                     precoding=abi.identity_precoding(1)), 1, 24 * 12))
+    # 2 layers on 4 ports with random complex weights, PRB0 reference point, BWP offset, power ratios.
+    out.append(("l2p4", abi.make_pdu(bwp_start_rb=5, bwp_size_rb=40, qm=8, dmrs_symbols=(2, 3), prb_start=9,
+                                     prb_count=17, nof_symbols=12, start_symbol=2, ref_point=1, tb_size_bytes=7000,
+                                     precoding=w42, ratio_dmrs_dB=3.0, ratio_data_dB=-1.25, slot_index=13,
+                                     scrambling_id=40000, n_scid=1, rnti=65535, n_id=1023), 4, 48 * 12))
+    # 3 layers, 2 PRGs, smallest transport blocks (CRC16, BG2 with Kb 6/8/9).
+    for nbytes in (3, 10, 30, 75, 85):
+        out.append(("small%d" % nbytes, abi.make_pdu(bwp_size_rb=20, qm=2, dmrs_symbols=(2,), prb_start=3, prb_count=4,
+                                                     nof_symbols=9, base_graph=2, tb_size_bytes=nbytes,
+                                                     precoding=w43, prg_size_rb=10), 4, 20 * 12))
+    # Zero-pad on the last codeblock and CB sizes that are not byte aligned.
+    for nbytes in (1057, 2111, 3341):
+        out.append(("pad%d" % nbytes, abi.make_pdu(bwp_size_rb=60, qm=6, dmrs_symbols=(2, 7), prb_count=55,
+                                                   nof_symbols=14, tb_size_bytes=nbytes, base_graph=2, rv=1), 1,
+                    60 * 12))
+    return out
+
+
+def test_pdsch_edge_cases(gpu_ctx, oracle):
+    rng = np.random.default_rng(5)
+    for name, pdu, nof_ports, nof_subc in edge_case_pdus():
+        assert lib.validate(pdu) == 0, name
+        assert oracle.validate(pdu) == 0, name
+        try:
+            run_single(gpu_ctx, oracle, pdu, cases.random_tb(rng, pdu), nof_ports, nof_subc)
+        except AssertionError as e:
+            raise AssertionError("%s: %s" % (name, e))
+
+
+def test_pdsch_batched_plan_mixed_cell(gpu_ctx, oracle):
+    """BASELINE config 4 shape: several cells x 4 PDUs per grid in ONE plan, TBs concatenated in one device buffer."""
+    import torch
+    rng = np.random.default_rng(11)
+    n_cells = 3
+    pdus, offs, gidx, tbs = [], [], [], []
+    pos = 0
+    for c in range(n_cells):
+        cell_pdus, nof_ports, nof_subc = cases.mixed_cell(c, slot_index=c)
+        for p in cell_pdus:
+            tb = cases.random_tb(rng, p)
+            pdus.append(p)
+            offs.append(pos)
+            gidx.append(c)
+            tbs.append(tb)
+            pos += (len(tb) + 15) & ~15
+    buf = np.zeros(pos + 16, np.uint8)
+    for o, tb in zip(offs, tbs):
+        buf[o:o + len(tb)] = tb
+    plan = lib.PdschPlan(gpu_ctx, pdus, offs, gidx, n_cells, nof_ports, nof_subc)
+    d_grid = torch.full((n_cells, nof_ports, 14, nof_subc), 0x7FFF7FFF, dtype=torch.int32, device="cuda")
+    d_rm = torch.zeros(plan.codeword_bits // 8, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    plan.run(dev(buf), d_grid, d_cw_rm=d_rm, zero_grids=True)
+    gpu_ctx.synchronize()
+    grids = d_grid.cpu().numpy().view(np.uint16).reshape(n_cells, nof_ports, 14, nof_subc, 2)
+    rm = d_rm.cpu().numpy()
+    for c in range(n_cells):
+        want = np.zeros((nof_ports, 14, nof_subc, 2), np.uint16)
+        for i in range(4 * c, 4 * c + 4):
+            d = oracle.derive(pdus[i])
+            g, orm, _ = oracle.pdsch_process(pdus[i], tbs[i], nof_ports, nof_subc, taps=True,
+                                             codeword_bits=d["codeword_bits"])
+            want |= g  # PDUs of one cell occupy disjoint RE
+            o = plan.codeword_offset(i) // 8
+            assert np.array_equal(rm[o:o + len(orm)], orm), (c, i)
+        assert np.array_equal(grids[c], want), c
+    plan.close()
+
+
+def test_pdsch_full_size_batch_properties(gpu_ctx, oracle):
+    """At BASELINE size (config 3, 64 slots in one launch): identical inputs give identical grids (no cross-slot
+    interference), different TBs differ, and one slot of the batch matches the oracle bit for bit."""
+    import torch
+    pdu, nof_ports, nof_subc, _ = cases.baseline_config(3)
+    n = 64
+    rng = np.random.default_rng(3)
+    tb_a, tb_b = cases.random_tb(rng, pdu), cases.random_tb(rng, pdu)
+    stride = (pdu.tb_size_bytes + 63) & ~63
+    buf = np.zeros(n * stride + 64, np.uint8)
+    for i in range(n):
+        buf[i * stride: i * stride + pdu.tb_size_bytes] = tb_b if i == 5 else tb_a
+    plan = lib.PdschPlan(gpu_ctx, [pdu] * n, [i * stride for i in range(n)], list(range(n)), n, nof_ports, nof_subc)
+    assert plan.nof_codeblocks == 104 * n
+    d_grid = torch.zeros((n, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    plan.run(dev(buf), d_grid)
+    gpu_ctx.synchronize()
+    g = d_grid.cpu().numpy()
+    for i in range(1, n):
+        if i != 5:
+            assert np.array_equal(g[i], g[0]), i
+    assert not np.array_equal(g[5], g[0])
+    want = oracle.pdsch_process(pdu, tb_b, nof_ports, nof_subc)
+    assert np.array_equal(g[5].view(np.uint16).reshape(want.shape), want)
+    # Unallocated RE stay zero: PRB 270-272 and symbols 12-13.
+    assert not g[:, :, 12:, :].any() and not g[:, :, :, 270 * 12:].any()
+    plan.close()
+
+
+def test_pdsch_invalid_pdus_are_refused(gpu_ctx):
+    """Error behaviour of the boundary: what the reference asserts on is returned as NRPHY_ERR_INVALID_PDU."""
+    pdu, nof_ports, nof_subc, _ = cases.baseline_config(1)
+    tb = np.zeros(pdu.tb_size_bytes, np.uint8)
+    pdu.dmrs_type = 2
+    with pytest.raises(lib.NrphyError) as e:
+        gpu_ctx.pdsch_process_host(pdu, tb, nof_ports, nof_subc)
+    assert e.value.status == abi.ERR_INVALID_PDU
+    pdu.dmrs_type = 1
+    with pytest.raises(lib.NrphyError) as e:
+        gpu_ctx.pdsch_process_host(pdu, tb, nof_ports, 12 * 10)   # grid smaller than the allocation
+    assert e.value.status == abi.ERR_ARGUMENT
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# OFDM modulator + DFT
+# ---------------------------------------------------------------------------------------------------------------------
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("size", [128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_dft_vs_oracle(gpu_ctx, oracle, size, inverse):
+    import torch
+    rng = np.random.default_rng(size + inverse)
+    batch = 5
+    x = (rng.standard_normal((batch, size)) + 1j * rng.standard_normal((batch, size))).astype(np.complex64)
+    d_in = dev(x.view(np.float32))
+    d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    gpu_ctx.dft(size, inverse, batch, d_in, d_out)
+    gpu_ctx.synchronize()
+    out = d_out.cpu().numpy().view(np.complex64)
+    for i in range(batch):
+        want = oracle.dft(x[i], inverse)
+        assert rel_err(out[i], want) < 1e-5   # north-star tolerance; reference test uses MSE < 1e-6 / peak < 1e-3
+
+
+@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024"])
+def test_ofdm_modulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
+    import torch
+    g = np.load(os.path.join(cases.GOLDEN, "ofdm_modulator.npz"))
+    mu, bw, n, fc, slot = g[name + "_cfg"]
+    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), 0, 1.0 / np.sqrt(n), float(fc))
+    grid = g[name + "_grid"]
+    plan = lib.OfdmPlan(gpu_ctx, cfg, 1)
+    assert plan.slot_stride == lib.slot_size(cfg, 0)
+    d_iq = torch.zeros((1, 1, plan.slot_stride, 2), dtype=torch.float32, device="cuda")
+    d_slot = dev(np.array([int(slot)], np.uint32).view(np.int32))
+    torch.cuda.synchronize()
+    plan.run(1, dev(grid.view(np.uint32).view(np.int32)), d_iq, d_slot_index=d_slot)
+    gpu_ctx.synchronize()
+    iq = d_iq.cpu().numpy().view(np.complex64).reshape(-1)
+    want = oracle.ofdm_slot(cfg, grid, int(slot))[0]
+    assert rel_err(iq[: len(want)], want) < 1e-5
+    assert rel_err(iq[: len(want)], g[name + "_iq"][0]) < 1e-5   # reference output (its own test allows 5e-5)
+    # Structure checks of ofdm_modulator_unittest.cpp: the cyclic prefix repeats the symbol tail.
+    off = 0
+    for l in range(14):
+        size = lib.symbol_size(cfg, 14 * int(slot) + l)
+        cp = size - int(n)
+        assert np.array_equal(iq[off: off + cp], iq[off + int(n): off + size])
+        off += size
+    # Host-span single-symbol entry point (ofdm_symbol_modulator::modulate semantics).
+    sym = 14 * int(slot) + 3
+    one = plan.modulate_symbol_host(grid, 0, sym)
+    start = sum(lib.symbol_size(cfg, 14 * int(slot) + l) for l in range(3))
+    assert np.array_equal(one, iq[start: start + len(one)])
+    plan.close()
+
+
+def test_end_to_end_slot_batch(gpu_ctx, oracle):
+    """PDSCH + OFDM chained on the device for a small batch of config-2 slots, against the oracle chain."""
+    import torch
+    pdu, nof_ports, nof_subc, ofdm = cases.baseline_config(2)
+    n = 3
+    rng = np.random.default_rng(21)
+    tbs = [cases.random_tb(rng, pdu) for _ in range(n)]
+    stride = (pdu.tb_size_bytes + 63) & ~63
+    buf = np.zeros(n * stride + 64, np.uint8)
+    for i, tb in enumerate(tbs):
+        buf[i * stride: i * stride + len(tb)] = tb
+    plan = lib.PdschPlan(gpu_ctx, [pdu] * n, [i * stride for i in range(n)], list(range(n)), n, nof_ports, nof_subc)
+    oplan = lib.OfdmPlan(gpu_ctx, ofdm, nof_ports)
+    d_grid = torch.zeros((n, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
+    d_iq = torch.zeros((n, nof_ports, oplan.slot_stride, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    plan.run(dev(buf), d_grid)
+    torch.cuda.synchronize()
+    oplan.run(n, d_grid, d_iq)
+    gpu_ctx.synchronize()
+    iq = d_iq.cpu().numpy().view(np.complex64).reshape(n, nof_ports, -1)
+    for i in range(n):
+        grid = oracle.pdsch_process(pdu, tbs[i], nof_ports, nof_subc)
+        want = oracle.ofdm_slot(ofdm, grid, 0)
+        assert rel_err(iq[i], want) < 1e-5
