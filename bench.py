@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=15.0):
+def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=20.0):
     """Times the CPU path on the host cores for a bounded sample of the same workload (rank 0, N=1 only).
     Uses the compiled reference (oracle/_ref, kind "reference") when that library travelled with the repository,
     the C oracle (kind "port") otherwise."""
@@ -45,7 +45,8 @@ def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=15.0):
 
         def run(threads, reps):
             return o.lib.oracle_bench(C.byref(pdu), tb.ctypes.data, nof_ports, nof_subc, C.byref(ofdm), threads, reps)
-    t1 = run(cores, 1)  # calibration pass (also warms caches)
+    run(cores, 1)       # warms caches / page-faults the buffers
+    t1 = run(cores, 4) / 4.0  # calibration: seconds per slot per thread
     reps = int(max(2, min(2000, budget_s / max(t1, 1e-4))))
     dt = run(cores, reps)
     return {

@@ -27,6 +27,12 @@ def load():
     """Returns the ctypes handle of libmi355nrphy.so; raises if it has not been built."""
     global _LIB
     if _LIB is None:
+        try:
+            # PyTorch bundles its own HIP runtime; let it load first so that this library binds to the same
+            # libamdhip64 instead of bringing a second runtime into the process (device memory comes from torch).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("HIP library %s is missing: run `python srsran-edgeric-5g_amd/build.py` "
                                "(there is no CPU fallback)" % LIB_PATH)
