@@ -121,17 +121,15 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # Whole-job totals: slots and IQ samples summed over ranks, time = max over ranks (RCCL all-reduce of 3 numbers).
+    samples_per_slot = nof_ports * oplan.slot_stride
+    total_slots, total_samples, dt = backends.pkg.sharding.aggregate(
+        dist, torch.device("cuda", local_rank), slots * args.steps, slots * args.steps * samples_per_slot, dt)
 
     (ms_crc, ms_cb, ms_dmrs, ms_run), _ = plan.kernel_times()
     ms_ofdm, _ = oplan.kernel_time()
 
     if rank == 0:
-        total_slots = world * slots * args.steps
-        samples_per_slot = nof_ports * oplan.slot_stride
         # Algorithmic bytes per slot: TB read + grid written once (incl. zeros) +
         # grid read by the OFDM modulator + IQ write.
         grid_bytes = nof_ports * 14 * nof_subc * 4
@@ -179,7 +177,7 @@ def main():
             "config": {"workload": "BASELINE config 3: 100 MHz (FFT 4096, 30 kHz SCS, 273 PRB grid) 4-layer 256-QAM "
                                    "R=948/1024 full-TBS PDSCH (TBS 868584 bit, 104 CB, BG1 Zc 384) + 4-port OFDM",
                        "slots_per_gpu_per_step": slots, "parallelism": "slot-sharded x%d, no data-path collective" % world},
-            "iq_gsamples_per_sec": round(total_slots * samples_per_slot / dt / 1e9, 3),
+            "iq_gsamples_per_sec": round(total_samples / dt / 1e9, 3),
             "whole_path_hbm_frac": round(total_slots * (alg_pdsch + alg_ofdm) / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
             "kernel_ms": {"tb_crc": round(ms_crc, 4), "codeblock": round(ms_cb, 4), "dmrs": round(ms_dmrs, 4),
                           "pdsch_run_incl_memset": round(ms_run, 4), "ofdm": round(ms_ofdm, 4)},

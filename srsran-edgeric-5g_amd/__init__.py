@@ -6,5 +6,6 @@ package never falls back to a CPU implementation -- ``lib.load()`` raises when t
 """
 from . import abi  # noqa: F401
 from . import lib  # noqa: F401
+from . import sharding  # noqa: F401
 
-__all__ = ["abi", "lib"]
+__all__ = ["abi", "lib", "sharding"]

@@ -1,0 +1,138 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, host-side logic (validator,
+derivation, TBS, OFDM sizes) agrees with the oracle, the product fails loudly without a GPU, and the multi-GPU
+sharding/aggregation path works over gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+import backends
+import cases
+
+abi = backends.abi
+lib = backends.pkg.lib
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(backends.ROOT, "include", "mi355_nrphy.h")).read()
+    declared = set(re.findall(r"\b(nrphy_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(abi.ABI_SYMBOLS), declared ^ set(abi.ABI_SYMBOLS)
+    handle = lib.load()
+    for name in declared:
+        assert hasattr(handle, name), name
+
+
+def test_pod_layout_matches_header():
+    """ctypes mirror vs the C compiler's layout of the PODs (sizes computed by a tiny C program)."""
+    import subprocess
+    import tempfile
+    src = r'''#include "mi355_nrphy.h"
+#include <stdio.h>
+#include <stddef.h>
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(nrphy_pdsch_pdu_t), offsetof(nrphy_pdsch_pdu_t, prb_mask),
+ offsetof(nrphy_pdsch_pdu_t, reserved), offsetof(nrphy_pdsch_pdu_t, precoding), sizeof(nrphy_re_pattern_t),
+ sizeof(nrphy_pdsch_derived_t), sizeof(nrphy_ofdm_config_t));return 0;}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(backends.ROOT, "include"), os.path.join(d, "t.c"), "-o",
+                        os.path.join(d, "t")], check=True, timeout=120)
+        out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, timeout=60).stdout.split()
+    want = [C.sizeof(abi.PdschPdu), abi.PdschPdu.prb_mask.offset, abi.PdschPdu.reserved.offset,
+            abi.PdschPdu.precoding.offset, C.sizeof(abi.RePattern), C.sizeof(abi.PdschDerived), C.sizeof(abi.OfdmConfig)]
+    assert [int(x) for x in out] == want
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lib.NrphyError) as e:
+        lib.Context(0)
+    assert e.value.status == abi.ERR_DEVICE
+
+
+def test_host_derivation_matches_oracle(oracle):
+    import test_gpu_parity
+    rng = np.random.default_rng(1)
+    pdus = [cases.baseline_config(c)[0] for c in (1, 2, 3)] + cases.unit_test_like_pdus(rng) + cases.mixed_cell(1)[0]
+    pdus += [p for _, p, _, _ in test_gpu_parity.edge_case_pdus()]
+    for pdu in pdus:
+        assert lib.validate(pdu) == oracle.validate(pdu) == 0
+        assert lib.derive(pdu) == oracle.derive(pdu)
+    for args in [(12, 36, 0, 8, 948, 4, 270), (12, 36, 0, 2, 120, 1, 52), (14, 12, 0, 4, 378, 3, 17), (2, 6, 6, 2, 30, 1, 1),
+                 (13, 24, 12, 6, 666, 2, 273)]:
+        assert lib.tbs_calculate(*args) == oracle.tbs(*args)
+    for mu, n in ((0, 1024), (0, 2048), (1, 4096), (2, 512), (3, 256)):
+        cfg = abi.OfdmConfig(mu, 10, n, 0, 1.0, 0.0)
+        for sym in range(14 << mu):
+            assert lib.symbol_size(cfg, sym) == oracle._f("ofdm_symbol_size")(cfg, sym)
+        for slot in range(1 << mu):
+            assert lib.slot_size(cfg, slot) == oracle._f("ofdm_slot_size")(cfg, slot)
+    # 30 kHz, N = 4096: CP 352 on symbols 0 and 14 of the subframe, 288 elsewhere; 61440 samples per slot.
+    cfg = abi.OfdmConfig(1, 273, 4096, 0, 1.0, 0.0)
+    assert [lib.symbol_size(cfg, s) - 4096 for s in (0, 1, 13, 14, 15)] == [352, 288, 288, 352, 288]
+    assert lib.slot_size(cfg, 0) == lib.slot_size(cfg, 1) == 61440
+
+
+def test_validator_rules():
+    """Each rule of pdsch_processor_validator_impl::is_valid (pdsch_processor_validator_test.cpp)."""
+    base = dict(bwp_start_rb=1, bwp_size_rb=25, qm=4, dmrs_symbols=(2, 7), prb_start=3, prb_count=10, start_symbol=2,
+                nof_symbols=10, tb_size_bytes=100, precoding=abi.identity_precoding(2))
+    assert lib.validate(abi.make_pdu(**base)) == abi.OK
+    bad = [dict(dmrs_symbols=(1,)), dict(dmrs_symbols=(12,)), dict(dmrs_type=2), dict(start_symbol=6, dmrs_symbols=(7,)),
+           dict(tbs_lbrm_bytes=0), dict(prb_start=20), dict(nof_cdm_groups_without_data=3), dict(nof_codewords=2),
+           dict(vrb_contiguous=0), dict(precoding=np.zeros((1, 1, 2, 2), np.float32)),  # more layers than ports
+           dict(reserved=[(range(0, 26), [1] * 12, [0, 0, 1] + [0] * 11)]), dict(qm=3), dict(rv=4), dict(base_graph=3),
+           dict(tb_size_bytes=0)]
+    for change in bad:
+        assert lib.validate(abi.make_pdu(**dict(base, **change))) == abi.ERR_INVALID_PDU, change
+
+
+# ---- multi-GPU path over gloo ------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, total_slots, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharding = backends.load_package().sharding
+    first, n = sharding.shard_slots(total_slots, rank, world)
+    dist.barrier()
+    slots, samples, seconds = sharding.aggregate(dist, torch.device("cpu"), n, n * 245760, 0.5 + 0.25 * rank)
+    out.put((rank, first, n, slots, samples, seconds))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slot_sharding_and_aggregation_gloo_world2():
+    import torch.multiprocessing as mp
+    sharding = backends.load_package().sharding
+    for total, world in ((10, 3), (7, 8), (256, 4)):
+        parts = [sharding.shard_slots(total, r, world) for r in range(world)]
+        assert sum(n for _, n in parts) == total
+        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+    assert sorted({sharding.cell_affine_rank(c, s, 8, 4) for c in range(4) for s in range(2)}) == list(range(8))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 257, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[1:3] for r in res] == [(0, 129), (129, 128)]
+    for r in res:
+        assert r[3] == 257 and r[4] == 257 * 245760 and abs(r[5] - 0.75) < 1e-9

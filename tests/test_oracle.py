@@ -1,0 +1,271 @@
+"""CPU tests (no GPU): pin the C oracle.
+
+1. Against the golden vectors generated from the compiled reference (tests/golden/*.npz) -- always runs.
+2. Against the compiled reference itself (oracle/_ref/libsrsref.so) on fresh random inputs -- runs wherever
+   `make -C oracle ref` was possible (this container); skipped on machines without /root/reference.
+3. Against known-answer restatements that need no vectors (bit-serial Gold generator, polynomial long division,
+   TS 38.211 modulation formulae, numpy FFT), as the reference's own unit tests do
+   (pseudo_random_generator_test.cpp:101-123, crc_calculator_generic_impl.cpp:59-85, dft_processor_test.cpp:43-91).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import backends
+import cases
+
+abi = backends.abi
+
+LIFTING_SIZES = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52,
+                 56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128, 144, 160, 176, 192, 208, 224, 240, 256, 288, 320, 352,
+                 384]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1. golden vectors from the reference
+# ---------------------------------------------------------------------------------------------------------------------
+def test_oracle_ldpc_encoder_golden(oracle):
+    g = np.load(os.path.join(cases.GOLDEN, "ldpc_encoder.npz"))
+    assert len(g["keys"]) == 102
+    for bg, zc in g["keys"]:
+        out_bits = (66 if bg == 1 else 50) * int(zc)
+        got = oracle.ldpc_encode(int(bg), int(zc), g["msg_%d_%d" % (bg, zc)], out_bits)
+        assert np.array_equal(got, g["out_%d_%d" % (bg, zc)]), (bg, zc)
+
+
+def test_oracle_pdsch_processor_golden(oracle):
+    g = np.load(os.path.join(cases.GOLDEN, "pdsch_processor.npz"))
+    items = [("cfg%d" % c,) + cases.baseline_config(c)[:3] for c in (1, 2, 3)]
+    for i, pdu in enumerate(cases.unit_test_like_pdus(np.random.default_rng(2024))):
+        items.append(("unit%02d" % i, pdu, 4, 26 * 12))
+    for name, pdu, nof_ports, nof_subc in items:
+        tb = np.random.default_rng(int(g[name + "_tb_seed"])).integers(0, 256, pdu.tb_size_bytes, dtype=np.uint8)
+        d = oracle.derive(pdu)
+        grid, rm, _ = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc, taps=True, codeword_bits=d["codeword_bits"])
+        assert sha(rm) == str(g[name + "_cw_sha"]), name
+        assert np.array_equal(rm[:64], g[name + "_cw_head"]), name
+        assert sha(grid) == str(g[name + "_grid_sha"]), name
+        g32 = grid.view(np.uint32).reshape(nof_ports, -1)
+        for p in range(nof_ports):
+            assert np.array_equal(g32[p][g["%s_p%d_idx" % (name, p)]], g["%s_p%d_val" % (name, p)]), (name, p)
+
+
+@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024"])
+def test_oracle_ofdm_golden(oracle, name):
+    g = np.load(os.path.join(cases.GOLDEN, "ofdm_modulator.npz"))
+    mu, bw, n, fc, slot = g[name + "_cfg"]
+    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), 0, 1.0 / np.sqrt(n), float(fc))
+    iq = oracle.ofdm_slot(cfg, g[name + "_grid"], int(slot))
+    want = g[name + "_iq"]
+    # The reference's own tolerance is |err| / sqrt(N) < 5e-5 (ofdm_modulator_vectortest.cpp:30); ours: 1e-5 relative.
+    assert np.abs(iq - want).max() / np.abs(want).max() < 1e-5
+
+
+def test_baseline_config_derived_values(oracle):
+    """The derived sizes SURVEY.md section 8d lists for the BASELINE configs."""
+    d = oracle.derive(cases.baseline_config(3)[0])
+    assert (d["nof_codeblocks"], d["lifting_size"], d["nof_filler_bits"], d["nof_re"]) == (104, 384, 72, 29160)
+    assert (d["rm_length_short"], d["rm_length_long"], d["nof_short_segments"], d["n_cb"]) == (8960, 8992, 64, 18432)
+    assert cases.baseline_config(3)[0].tb_size_bytes * 8 == 868584
+    d = oracle.derive(cases.baseline_config(2)[0])
+    assert (d["nof_codeblocks"], d["lifting_size"], d["nof_filler_bits"], d["nof_re"]) == (14, 384, 80, 11448)
+    assert cases.baseline_config(2)[0].tb_size_bytes * 8 == 116792
+    d = oracle.derive(cases.baseline_config(1)[0])
+    assert (d["nof_codeblocks"], d["lifting_size"], d["nof_filler_bits"], d["rm_length_short"]) == (1, 144, 104, 11232)
+    assert cases.baseline_config(1)[0].tb_size_bytes * 8 == 1320
+    sizes = [(p.tb_size_bytes * 8, oracle.derive(p)["nof_codeblocks"]) for p in cases.mixed_cell(0)[0]]
+    assert sizes == [(6920, 2), (75792, 9), (151608, 18), (217128, 26)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 2. the compiled reference on fresh inputs
+# ---------------------------------------------------------------------------------------------------------------------
+def test_oracle_vs_ref_scalars_and_crc(oracle, ref):
+    rng = np.random.default_rng(1)
+    for args in [(12, 36, 0, 8, 948, 4, 270), (12, 36, 0, 2, 120, 1, 52), (12, 36, 0, 6, 873, 2, 106), (14, 12, 0, 4, 378, 3, 17),
+                 (2, 6, 6, 2, 30, 1, 1), (13, 24, 12, 6, 666, 2, 273), (7, 12, 18, 8, 711.5, 4, 100)]:
+        assert oracle.tbs(*args) == ref.tbs(*args), args
+    for n in (1, 3, 100, 1044, 108573):
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        for poly in (16, 0x24A, 0x24B):
+            assert oracle.crc(poly, data) == ref.crc(poly, data)
+
+
+def test_oracle_vs_ref_ldpc_encoder_all_graphs(oracle, ref):
+    rng = np.random.default_rng(2)
+    for bg in (1, 2):
+        kb, nshort = (22, 66) if bg == 1 else (10, 50)
+        for zc in LIFTING_SIZES:
+            msg = np.packbits(rng.integers(0, 2, kb * zc, dtype=np.uint8))
+            for out_bits in {nshort * zc, (kb + 2) * zc, nshort * zc - 3 * zc - 1, kb * zc + 2 * zc + 5}:
+                assert np.array_equal(oracle.ldpc_encode(bg, zc, msg, out_bits), ref.ldpc_encode(bg, zc, msg, out_bits, 1))
+
+
+def test_oracle_vs_ref_segmenter_and_rate_matcher(oracle, ref):
+    rng = np.random.default_rng(3)
+    for bg, nbytes, qm, layers, nre in ((1, 108573, 8, 4, 29160), (2, 165, 2, 1, 5616), (1, 14599, 6, 2, 11448),
+                                        (2, 20, 2, 1, 300), (1, 1055, 4, 1, 3000), (2, 479, 4, 3, 999), (1, 3000, 6, 4, 4001),
+                                        (2, 3, 2, 1, 100), (1, 4000, 8, 2, 777)):
+        tb = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        sa, ma, za = oracle.segment(bg, 0, qm, 25344, layers, nre * layers, tb)
+        sb, mb, zb = ref.segment(bg, 0, qm, 25344, layers, nre * layers, tb)
+        assert za == zb and np.array_equal(ma, mb)
+        k = (22 if bg == 1 else 10) * za
+        assert np.array_equal(np.unpackbits(sa, axis=1)[:, :k], np.unpackbits(sb, axis=1)[:, :k])
+    for bg, zc, rv, qm, nref, nf, e in ((1, 384, 0, 8, 18432, 72, 8992), (2, 144, 0, 2, 0, 104, 11232), (1, 384, 2, 6, 0, 80, 9804),
+                                        (2, 352, 3, 4, 8000, 24, 5000), (1, 16, 1, 2, 0, 5, 2000), (1, 384, 1, 8, 365, 72, 8992),
+                                        (2, 7, 3, 2, 0, 30, 2304)):
+        cb = np.packbits(rng.integers(0, 2, (66 if bg == 1 else 50) * zc, dtype=np.uint8))
+        assert np.array_equal(oracle.rate_match(bg, zc, rv, qm, nref, nf, cb, e), ref.rate_match(bg, zc, rv, qm, nref, nf, cb, e))
+
+
+def test_oracle_vs_ref_prg_and_modulation(oracle, ref):
+    rng = np.random.default_rng(4)
+    for c_init, off, n in ((1 << 15, 0, 1000), (0x12345678, 777, 933120), (5, 100000, 336), (0x7FFFFFFF, 1, 64)):
+        d = rng.integers(0, 256, (n + 7) // 8, dtype=np.uint8)
+        assert np.array_equal(oracle.prg_xor(c_init, off, d, n)[: n // 8], ref.prg_xor(c_init, off, d, n)[: n // 8])
+        assert np.array_equal(oracle.prg_float(c_init, off, 0.7, 333), ref.prg_float(c_init, off, 0.7, 333))
+    for qm in (2, 4, 6, 8):
+        bits = rng.integers(0, 256, qm * 100, dtype=np.uint8)
+        a, sa = oracle.modulate(qm, bits, 800)
+        b, sb = ref.modulate(qm, bits, 800)
+        assert np.array_equal(a, b) and sa == sb
+
+
+def test_oracle_vs_ref_pdsch_processor(oracle, ref):
+    """Grid bit-exact against the reference's generic, AVX2 and "lite" processors, codeword against pdsch_encoder."""
+    import test_gpu_parity
+    rng = np.random.default_rng(5)
+    items = [(c, ) + cases.baseline_config(c)[:3] for c in (1, 2, 3)]
+    items += [(i, pdu, 4, 26 * 12) for i, pdu in enumerate(cases.unit_test_like_pdus(rng))]
+    items += [(n, p, a, b) for n, p, a, b in test_gpu_parity.edge_case_pdus() if p.nof_prg == 1]
+    for name, pdu, nof_ports, nof_subc in items:
+        assert oracle.validate(pdu) == ref.validate(pdu) == 0
+        tb = cases.random_tb(rng, pdu)
+        d = oracle.derive(pdu)
+        grid, rm, _ = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc, taps=True, codeword_bits=d["codeword_bits"])
+        nb = d["codeword_bits"] // 8
+        assert np.array_equal(rm[:nb], ref.pdsch_encode(pdu, tb, d)[:nb]), name
+        for simd, impl in ((1, 0), (0, 0), (1, 1)):
+            assert np.array_equal(grid, ref.pdsch_process(pdu, tb, nof_ports, nof_subc, simd=simd, impl=impl)), (name, simd, impl)
+
+
+def test_oracle_vs_ref_validator(oracle, ref):
+    def variants():
+        base = dict(bwp_start_rb=1, bwp_size_rb=25, qm=4, dmrs_symbols=(2, 7), prb_start=3, prb_count=10, start_symbol=2,
+                    nof_symbols=10, tb_size_bytes=100, precoding=abi.identity_precoding(2))
+        yield dict(base)
+        yield dict(base, dmrs_symbols=(1,))                       # DM-RS before the allocation
+        yield dict(base, dmrs_symbols=(12,))                      # DM-RS after the allocation
+        yield dict(base, dmrs_type=2)
+        yield dict(base, start_symbol=6, nof_symbols=10, dmrs_symbols=(7,))  # beyond the slot
+        yield dict(base, tbs_lbrm_bytes=0)
+        yield dict(base, prb_start=20, prb_count=10)              # outside the BWP
+        yield dict(base, nof_cdm_groups_without_data=3)
+        yield dict(base, reserved=[(range(0, 26), [1] * 12, [0, 0, 1] + [0] * 11)])   # collides with DM-RS symbol 2
+        yield dict(base, reserved=[(range(0, 26), [1] * 12, [0, 0, 0, 1] + [0] * 10)])
+    for kw in variants():
+        pdu = abi.make_pdu(**kw)
+        assert (oracle.validate(pdu) == 0) == (ref.validate(pdu) == 0), kw
+        assert (backends.pkg.lib.validate(pdu) == 0) == (ref.validate(pdu) == 0), kw
+
+
+def test_oracle_vs_ref_dft_and_ofdm(oracle, ref):
+    rng = np.random.default_rng(6)
+    for n in (128, 256, 384, 512, 1024, 1536, 2048, 4096):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        for inv in (0, 1):
+            a, b = oracle.dft(x, inv), ref.dft(x, inv)
+            assert np.abs(a - b).max() / np.abs(b).max() < 2e-6
+    for mu, bw, n, fc, slot in ((1, 273, 4096, 3.5e9, 0), (1, 273, 4096, 3.5e9, 1), (0, 52, 1024, 2.4e9, 0), (0, 106, 2048, 0.0, 0),
+                                (2, 24, 512, 28e9, 3)):
+        cfg = abi.OfdmConfig(mu, bw, n, 0, 0.37, fc)
+        grid = (rng.standard_normal((2, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        a, b = oracle.ofdm_slot(cfg, grid, slot), ref.ofdm_slot(cfg, grid, slot)
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() / np.abs(b).max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 3. known-answer restatements
+# ---------------------------------------------------------------------------------------------------------------------
+def gold_bits(c_init, n):
+    x1 = [1] + [0] * 30
+    x2 = [(c_init >> i) & 1 for i in range(31)]
+    for i in range(1600 + n):
+        x1.append(x1[i + 3] ^ x1[i])
+        x2.append(x2[i + 3] ^ x2[i + 2] ^ x2[i + 1] ^ x2[i])
+    return np.array([x1[i + 1600] ^ x2[i + 1600] for i in range(n)], np.uint8)
+
+
+def test_oracle_gold_sequence_known_answer(oracle):
+    for c_init in (0, 1, 0x5A5A5A5, 0x7FFFFFFF):
+        n = 2000
+        want = gold_bits(c_init, n + 37)
+        got = np.unpackbits(oracle.prg_xor(c_init, 37, np.zeros(n // 8, np.uint8), n))
+        assert np.array_equal(got, want[37:])
+
+
+def test_oracle_crc_long_division(oracle):
+    rng = np.random.default_rng(8)
+    for poly_id, poly, order in ((16, 0x11021, 16), (0x24A, 0x1864CFB, 24), (0x24B, 0x1800063, 24)):
+        data = rng.integers(0, 256, 57, dtype=np.uint8)
+        reg = 0
+        for b in list(np.unpackbits(data)) + [0] * order:
+            reg = (reg << 1) | int(b)
+            if reg >> order:
+                reg ^= poly
+        assert oracle.crc(poly_id, data) == reg
+
+
+def test_oracle_modulation_formulae(oracle):
+    """TS 38.211 Section 5.1.3-5.1.6 closed forms."""
+    for qm in (2, 4, 6, 8):
+        nsym = 1 << qm
+        bits = np.array([[(i >> (qm - 1 - j)) & 1 for j in range(qm)] for i in range(nsym)], np.uint8)
+        got, scale = oracle.modulate(qm, np.packbits(bits.reshape(-1)), nsym)
+        b = 1 - 2 * bits.astype(np.int32)
+        if qm == 2:
+            re, im = b[:, 0], b[:, 1]
+        elif qm == 4:
+            re, im = b[:, 0] * (2 - b[:, 2]), b[:, 1] * (2 - b[:, 3])
+        elif qm == 6:
+            re, im = b[:, 0] * (4 - b[:, 2] * (2 - b[:, 4])), b[:, 1] * (4 - b[:, 3] * (2 - b[:, 5]))
+        else:
+            re = b[:, 0] * (8 - b[:, 2] * (4 - b[:, 4] * (2 - b[:, 6])))
+            im = b[:, 1] * (8 - b[:, 3] * (4 - b[:, 5] * (2 - b[:, 7])))
+        assert np.array_equal(got[:, 0], re) and np.array_equal(got[:, 1], im)
+        assert abs(scale - 1 / np.sqrt({2: 2, 4: 10, 6: 42, 8: 170}[qm])) < 1e-7
+
+
+def test_oracle_dft_vs_numpy(oracle):
+    rng = np.random.default_rng(9)
+    for n in (128, 384, 1024, 4096):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        assert np.abs(oracle.dft(x, 0) - np.fft.fft(x.astype(np.complex128))).max() < 1e-5 * np.sqrt(n) * 4
+        assert np.abs(oracle.dft(x, 1) - np.fft.ifft(x.astype(np.complex128)) * n).max() < 1e-5 * np.sqrt(n) * 4
+
+
+def test_oracle_ofdm_structure(oracle):
+    """ofdm_modulator_unittest.cpp:134-167: bin placement, guard zeros, scale and CP copy, for a single active subcarrier."""
+    cfg = abi.OfdmConfig(1, 24, 512, 0, 2.0, 0.0)
+    rg = 24 * 12
+    for k in (0, 1, rg // 2 - 1, rg // 2, rg - 1):
+        grid = np.zeros((1, 14, rg, 2), np.uint16)
+        grid[0, 3, k, 0] = 0x3F80  # 1.0 in bf16
+        iq = oracle.ofdm_slot(cfg, grid, 0)[0]
+        sizes = [oracle._f("ofdm_symbol_size")(cfg, l) for l in range(14)]
+        start = sum(sizes[:3])
+        cp = sizes[3] - 512
+        sym = iq[start + cp: start + sizes[3]]
+        bin_ = k - rg // 2                        # subcarrier k sits at frequency bin k - rg/2 (mod N)
+        want = 2.0 * np.exp(2j * np.pi * bin_ * np.arange(512) / 512)
+        assert np.abs(sym - want).max() < 1e-5
+        assert np.array_equal(iq[start: start + cp], sym[-cp:])
+        assert not iq[:start].any() and not iq[start + sizes[3]:].any()
