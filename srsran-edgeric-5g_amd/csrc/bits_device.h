@@ -160,7 +160,7 @@ __device__ __forceinline__ uint32_t wave_xor(uint32_t v)
 // the LDS array `out`, executed by one full wavefront.  x1 comes from the precomputed table, x2 from c_init:
 //  1. jump the 31-bit x2 state to offset Nc + 32*first_word with the matrices (M2)^(2^k): lane r evaluates row r
 //     and the wave assembles the new state with a ballot ("wavefront-ballot parity");
-//  2. the first 31 words one after the other (a word is the state plus one recurrence bit; M2^32 advances it);
+//  2. the first 31 words in parallel, lane w evaluating the 32 parities of word w (they are linear in the state);
 //  3. every further word in parallel from W[k] = W[k-28] ^ W[k-29] ^ W[k-30] ^ W[k-31], the x2 recurrence lifted
 //     to 32-bit words (squaring the characteristic polynomial five times: p(x)^32 = p(x^32) over GF(2)).
 // Replaces pseudo_random_generator_impl::{init,advance,apply_xor}
@@ -181,13 +181,14 @@ __device__ inline void gold_generate_wave(const GoldTables* gold, const uint32_t
       state = gold_matvec(gold->x2_jump[k], state, lane);
     }
   }
-  uint32_t head = nwords < 31u ? nwords : 31u;
-  for (uint32_t w = 0; w != head; ++w) {
-    uint32_t next = __popc(state & 0xFu) & 1u; // x2(n+31) = x2(n+3)^x2(n+2)^x2(n+1)^x2(n)
-    if (lane == 0) {
-      out[w] = __brev(state | (next << 31));
+  // The first 31 words are linear in the state: lane w evaluates the 32 parities of word w.
+  if (lane < 31u && lane < nwords) {
+    uint32_t word = 0;
+#pragma unroll 8
+    for (uint32_t t = 0; t != 32; ++t) {
+      word |= (__popc(gold->x2_head[t][lane] & state) & 1u) << (31u - t);
     }
-    state = gold_matvec(gold->x2_jump[5], state, lane);
+    out[lane] = word;
   }
   wave_sync();
   for (uint32_t base = 31; base < nwords; base += 28) {

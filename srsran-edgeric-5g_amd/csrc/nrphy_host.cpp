@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <vector>
 
@@ -159,7 +160,18 @@ void build_gold_tables(GoldTables& t, std::vector<uint32_t>& x1_words)
     std::memcpy(t.x2_jump[k], m, sizeof(m));
     mat_mul(m, m, m);
   }
-  // x^(32 m) mod CRC24B.
+  // The next 992 bits are linear in the state: x2_head[t][w] is the state mask of bit 32 w + t.
+  for (int i = 0; i != 31; ++i) {
+    uint32_t st = 1U << i;
+    for (int n = 0; n != 992; ++n) {
+      if (st & 1U) {
+        t.x2_head[n & 31][n >> 5] |= 1U << i;
+      }
+      uint32_t f = ((st >> 3) ^ (st >> 2) ^ (st >> 1) ^ st) & 1U;
+      st         = (st >> 1) | (f << 30);
+    }
+  }
+  // x^(32 m) mod CRC24B and the CRC24B byte table.
   const uint32_t poly = 0x1800063U, top = 1U << 24;
   uint32_t       v    = 1;
   for (int i = 0; i != CRC_POW_WORDS; ++i) {
@@ -170,6 +182,16 @@ void build_gold_tables(GoldTables& t, std::vector<uint32_t>& x1_words)
         v ^= poly;
       }
     }
+  }
+  for (uint32_t b = 0; b != 256; ++b) {
+    uint32_t r = b << 16;
+    for (int k = 0; k != 8; ++k) {
+      r <<= 1;
+      if (r & top) {
+        r ^= poly;
+      }
+    }
+    t.crc24b_table[b] = r & (top - 1);
   }
   // x1(n + 1600), MSB-first words: x1(n+31) = x1(n+3) ^ x1(n), x1(0) = 1.
   x1_words.assign(GOLD_X1_WORDS, 0);
@@ -226,7 +248,9 @@ struct nrphy_pdsch_plan {
   float*                d_weights = nullptr;
   uint16_t*             d_re_table = nullptr;
   uint32_t*             d_tb_crc = nullptr;
-  uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0;
+  CrcWork*              d_crc_work = nullptr;
+  uint32_t*             d_crc_pow = nullptr;
+  uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0, n_crc_work = 0;
   std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs
   uint32_t              timed_runs = 0, max_timed_runs = 0;
 };
@@ -649,6 +673,9 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
 
   std::vector<CbWork>   work;
   std::vector<DmrsWork> dmrs;
+  std::vector<CrcWork>  crc_work;
+  std::vector<uint32_t> crc_pow;
+  std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint32_t>> crc_pow_index; // (bytes, order) -> (offset, chunk)
   std::vector<float>    weights;
   std::vector<uint16_t> re_table;
   std::vector<uint8_t>  mask(grid_nof_subc);
@@ -785,7 +812,10 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
       const uint64_t a  = (uint64_t)(14 * pdu.slot_index + l + 1) * (2 * pdu.scrambling_id + 1);
       pd.dmrs_c_init[l] = (uint32_t)(((a << 17) + (2 * pdu.scrambling_id + (pdu.n_scid ? 1 : 0))) & 0x7FFFFFFFULL);
       if ((pdu.dmrs_symbol_mask >> l) & 1U) {
-        dmrs.push_back({i, l});
+        const uint32_t first = (uint32_t)mask_lowest(pdu.prb_mask), end = (uint32_t)mask_highest(pdu.prb_mask) + 1;
+        for (uint32_t b = first; b < end; b += DMRS_PRB_CHUNK) {
+          dmrs.push_back({i, l, b, std::min<uint32_t>(end, b + DMRS_PRB_CHUNK)});
+        }
       }
     }
     for (unsigned w = 0; w != NRPHY_PRB_WORDS; ++w) {
@@ -794,6 +824,60 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     }
     pd.first_prb = (uint32_t)mask_lowest(pdu.prb_mask);
     pd.end_prb   = (uint32_t)mask_highest(pdu.prb_mask) + 1;
+    // TB-CRC work: ~64 bytes per thread; the per-thread factors x^(8 * bytes after the chunk) are shared by every
+    // PDU with the same transport block size.
+    {
+      const uint32_t n = pdu.tb_size_bytes, order = d.nof_tb_crc_bits;
+      auto           it = crc_pow_index.find({n, order});
+      if (it == crc_pow_index.end()) {
+        const uint32_t threads = divide_ceil(divide_ceil(n, 64), 256) * 256;
+        const uint32_t chunk   = (divide_ceil(n, threads) + 3U) & ~3U;
+        const uint32_t poly = (order == 16) ? 0x11021U : 0x1864CFBU, top = 1U << order;
+        auto mulmod = [&](uint32_t a, uint32_t b) {
+          uint32_t r = 0;
+          for (int k = (int)order - 1; k >= 0; --k) {
+            r <<= 1;
+            if (r & top) {
+              r ^= poly;
+            }
+            if ((b >> k) & 1U) {
+              r ^= a;
+            }
+          }
+          return r;
+        };
+        auto xpow_bytes = [&](uint32_t nbytes) { // x^(8 nbytes) mod poly
+          uint32_t r = 1;
+          for (uint32_t k = 0; k != 8 * nbytes; ++k) {
+            r <<= 1;
+            if (r & top) {
+              r ^= poly;
+            }
+          }
+          return r;
+        };
+        const uint32_t offset   = (uint32_t)crc_pow.size();
+        const uint32_t nonempty = divide_ceil(n, chunk);
+        crc_pow.resize(offset + threads, 0);
+        const uint32_t xchunk = xpow_bytes(chunk);
+        uint32_t       pw     = 1; // thread nonempty-1 has nothing after it
+        crc_pow[offset + nonempty - 1] = pw;
+        if (nonempty > 1) {
+          pw                              = xpow_bytes(n - (nonempty - 1) * chunk); // bytes of the last chunk
+          crc_pow[offset + nonempty - 2] = pw;
+          for (int g = (int)nonempty - 3; g >= 0; --g) {
+            pw                   = mulmod(pw, xchunk);
+            crc_pow[offset + g] = pw;
+          }
+        }
+        it = crc_pow_index.insert({{n, order}, {offset, chunk}}).first;
+      }
+      const uint32_t offset = it->second.first, chunk = it->second.second;
+      const uint32_t threads = divide_ceil(divide_ceil(n, 64), 256) * 256;
+      for (uint32_t t0 = 0; t0 < threads && t0 * chunk < n; t0 += 256) {
+        crc_work.push_back({i, t0, chunk, offset});
+      }
+    }
     // Work items: every codeblock owns a whole number of RE (rm_length is a multiple of nof_layers * Qm).
     const unsigned lq = pdu.nof_layers * pdu.qm;
     for (unsigned cb = 0; cb != d.nof_codeblocks; ++cb) {
@@ -814,7 +898,10 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   plan->cw_bits = cw_bits;
   plan->n_work  = (uint32_t)work.size();
   plan->n_dmrs  = (uint32_t)dmrs.size();
-  if (upload(&plan->d_pdus, plan->pdus.data(), plan->pdus.size() * sizeof(PduDev)) != hipSuccess ||
+  plan->n_crc_work = (uint32_t)crc_work.size();
+  if (upload(&plan->d_crc_work, crc_work.data(), crc_work.size() * sizeof(CrcWork)) != hipSuccess ||
+      upload(&plan->d_crc_pow, crc_pow.data(), crc_pow.size() * sizeof(uint32_t)) != hipSuccess ||
+      upload(&plan->d_pdus, plan->pdus.data(), plan->pdus.size() * sizeof(PduDev)) != hipSuccess ||
       upload(&plan->d_work, work.data(), work.size() * sizeof(CbWork)) != hipSuccess ||
       upload(&plan->d_dmrs, dmrs.data(), dmrs.size() * sizeof(DmrsWork)) != hipSuccess ||
       upload(&plan->d_weights, weights.data(), weights.size() * sizeof(float)) != hipSuccess ||
@@ -839,6 +926,8 @@ extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
   (void)hipFree(plan->d_weights);
   (void)hipFree(plan->d_re_table);
   (void)hipFree(plan->d_tb_crc);
+  (void)hipFree(plan->d_crc_work);
+  (void)hipFree(plan->d_crc_pow);
   for (hipEvent_t e : plan->events) {
     (void)hipEventDestroy(e);
   }
@@ -873,6 +962,9 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.pdus           = plan->d_pdus;
   p.work           = plan->d_work;
   p.dmrs_work      = plan->d_dmrs;
+  p.crc_work       = plan->d_crc_work;
+  p.crc_pow        = plan->d_crc_pow;
+  p.n_crc_work     = plan->n_crc_work;
   p.weights        = plan->d_weights;
   p.re_table       = plan->d_re_table;
   p.graphs         = ctx->d_graphs;
@@ -889,6 +981,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     HIP_TRY(hipMemsetAsync(d_grid, 0,
                            (size_t)plan->nof_grids * plan->grid_nof_ports * NRPHY_NSYMB * plan->grid_nof_subc * 4, s));
   }
+  HIP_TRY(hipMemsetAsync(plan->d_tb_crc, 0, sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size()), s));
   if (d_cw_rm) {
     HIP_TRY(hipMemsetAsync(d_cw_rm, 0, cw_bytes, s));
   }

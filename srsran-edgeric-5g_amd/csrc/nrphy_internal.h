@@ -38,7 +38,11 @@ constexpr int CRC_POW_WORDS = 288;     // >= 8448 / 32 + 1
 
 struct GoldTables {
   uint32_t x2_jump[GOLD_JUMP_BITS][32];
+  // x2_head[t][w]: mask over the 31-bit state giving bit t of word w of the next 31 words (w < 31): the first 992
+  // sequence bits are linear in the state, so 31 lanes produce the 31 seed words of the word recurrence in parallel.
+  uint32_t x2_head[32][32];
   uint32_t crc24b_pow32[CRC_POW_WORDS]; // x^(32 m) mod g_CRC24B(x): places a lane's partial CB-CRC
+  uint32_t crc24b_table[256];           // byte table of CRC24B
 };
 
 // ---- PDSCH plan ---------------------------------------------------------------------------------------------
@@ -101,15 +105,31 @@ struct CbWork {
 };
 
 // One workgroup of the DM-RS kernel: OFDM symbol `symbol` of PDU `pdu`.
+constexpr int DMRS_PRB_CHUNK = 32; // PRBs per DM-RS wavefront
+
 struct DmrsWork {
   uint32_t pdu;
   uint32_t symbol;
+  uint32_t prb_begin;
+  uint32_t prb_end;
+};
+
+// One 256-thread workgroup of the TB-CRC kernel: threads [thread_begin, thread_begin + 256) of the PDU's split;
+// thread g reduces bytes [g * chunk, (g+1) * chunk) and scales by crc_pow[pow_offset + g] = x^(8 * bytes after).
+struct CrcWork {
+  uint32_t pdu;
+  uint32_t thread_begin;
+  uint32_t chunk;      // bytes per thread, multiple of 4
+  uint32_t pow_offset; // into the plan's crc_pow table
 };
 
 struct PdschLaunch {
   const PduDev*      pdus;
   const CbWork*      work;
   const DmrsWork*    dmrs_work;
+  const CrcWork*     crc_work;
+  const uint32_t*    crc_pow;
+  uint32_t           n_crc_work;
   const float*       weights;
   const uint16_t*    re_table;
   const LiftedGraph* graphs;

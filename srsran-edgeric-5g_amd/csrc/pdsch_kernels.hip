@@ -1,10 +1,11 @@
 // PDSCH processor kernels for gfx950 (MI355X).
 //
-//   tb_crc_kernel      transport-block CRC, chunk-parallel with GF(2) polynomial combine
+//   tb_crc_kernel      transport-block CRC: every thread reduces a 4-byte-aligned chunk with a byte table, scales
+//                      its remainder by x^(8 * bytes after) (table built at plan time) and XORs it into the result
 //   codeblock_kernel   one wavefront per codeblock (or per 512-RE chunk of it): segmentation, CB-CRC, LDPC
 //                      base-graph expansion in LDS, rate matching + bit interleaving by index arithmetic, Gold
 //                      scrambling, QAM mapping, layer mapping, precoding and RE mapping straight into the grid
-//   dmrs_kernel        PDSCH DM-RS generation, CDM, precoding and mapping
+//   dmrs_kernel        PDSCH DM-RS generation, CDM, precoding and mapping, one wavefront per 32 PRBs of a symbol
 //   ldpc_encode_kernel the LDPC encoder alone (seam B / unit parity)
 //
 // Together they replace pdsch_processor_impl::process (R/lib/phy/upper/channel_processors/pdsch_processor_impl.cpp:30-184)
@@ -15,8 +16,8 @@ namespace nrphy {
 
 // ================================================================================================================
 // Transport block CRC (TS 38.212 Section 5.1; reference: ldpc_segmenter_impl.cpp:126, crc_calculator_lut_impl.cpp).
-// One 256-thread workgroup per PDU.  Thread t reduces the aligned chunk [t*c, (t+1)*c) with a byte table, then the
-// partial remainders are shifted to their place by multiplying with x^(8 * bytes after the chunk) mod poly.
+// CRC(M) = sum_t CRC(chunk_t) * x^(8 * bytes after chunk_t) mod g(x): the chunks are independent, the combine is an
+// XOR, so a transport block is spread over as many 256-thread workgroups as it takes to give each thread ~64 bytes.
 // ================================================================================================================
 constexpr int TB_CRC_THREADS = 256;
 
@@ -24,64 +25,38 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void tb_crc_kernel(PdschLaunch p, c
 {
   __shared__ uint32_t table[256];
   __shared__ uint32_t partial[TB_CRC_THREADS / WAVE];
-  __shared__ uint32_t xpow[2];
 
-  const PduDev&   pd   = p.pdus[blockIdx.x];
-  const uint32_t  tid  = threadIdx.x;
-  const CrcPoly   c    = (pd.tb_crc_bits == 16) ? crc16() : crc24a();
-  const uint32_t  n    = pd.tb_bytes;
-  const uint32_t* w    = reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset);
+  const CrcWork   wk  = p.crc_work[blockIdx.x];
+  const PduDev&   pd  = p.pdus[wk.pdu];
+  const uint32_t  tid = threadIdx.x;
+  const CrcPoly   c   = (pd.tb_crc_bits == 16) ? crc16() : crc24a();
+  const uint32_t  n   = pd.tb_bytes;
+  const uint32_t* w   = reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset);
 
   table[tid] = crc_table_entry(tid, c);
   __syncthreads();
 
-  // Chunk size in bytes, a multiple of 4; nchunks non-empty chunks, the last one holds r in (0, chunk] bytes.
-  uint32_t chunk   = ((n + TB_CRC_THREADS - 1) / TB_CRC_THREADS + 3u) & ~3u;
-  uint32_t nchunks = (n + chunk - 1) / chunk;
-  uint32_t r_last  = n - (nchunks - 1) * chunk;
-  if (tid == 0) {
-    xpow[0] = crc_xpow(8u * chunk, c);  // x^(8*chunk)
-  }
-  if (tid == WAVE) {
-    xpow[1] = crc_xpow(8u * r_last, c); // x^(8*r_last)
-  }
-  __syncthreads();
-
-  uint32_t reg = 0;
-  if (tid < nchunks) {
-    uint32_t begin = tid * chunk;
-    uint32_t len   = (tid == nchunks - 1) ? r_last : chunk;
-    uint32_t nfull = len >> 2;
+  const uint32_t g     = wk.thread_begin + tid;
+  const uint32_t begin = g * wk.chunk;
+  uint32_t       reg   = 0;
+  if (begin < n) {
+    const uint32_t len   = (n - begin < wk.chunk) ? n - begin : wk.chunk;
+    const uint32_t nfull = len >> 2;
     for (uint32_t i = 0; i != nfull; ++i) {
       reg = crc_update_word(reg, be_word(w, (begin >> 2) + i), table, c);
     }
-    uint32_t tail = len & 3u;
+    const uint32_t tail = len & 3u;
     if (tail) {
       // The last word is only partially inside the transport block: shift its bytes in one by one.
-      uint32_t word = be_word(w, (begin >> 2) + nfull);
-      uint32_t mask = (1u << c.order) - 1u, sh = c.order - 8u;
+      const uint32_t word = be_word(w, (begin >> 2) + nfull);
+      const uint32_t mask = (1u << c.order) - 1u, sh = c.order - 8u;
       for (uint32_t k = 0; k != tail; ++k) {
         uint32_t byte = (word >> (24 - 8 * k)) & 0xFFu;
         uint32_t idx  = ((reg >> sh) ^ byte) & 0xFFu;
         reg           = ((reg << 8) & mask) ^ table[idx];
       }
     }
-    // Bytes after this chunk: (nchunks - 2 - tid) * chunk + r_last for all but the last chunk.
-    if (tid != nchunks - 1) {
-      uint32_t xb = xpow[0];
-      uint32_t xr = xpow[1];
-      uint32_t e  = nchunks - 2 - tid;
-      uint32_t pw = xr;
-      uint32_t b  = xb;
-      while (e) {
-        if (e & 1u) {
-          pw = crc_mulmod(pw, b, c);
-        }
-        b = crc_mulmod(b, b, c);
-        e >>= 1;
-      }
-      reg = crc_mulmod(reg, pw, c);
-    }
+    reg = crc_mulmod(reg, p.crc_pow[wk.pow_offset + g], c);
   }
   reg = wave_xor(reg);
   if ((tid & (WAVE - 1)) == 0) {
@@ -93,16 +68,16 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void tb_crc_kernel(PdschLaunch p, c
     for (int i = 0; i != TB_CRC_THREADS / WAVE; ++i) {
       crc ^= partial[i];
     }
-    p.tb_crc[blockIdx.x] = crc;
+    atomicXor(&p.tb_crc[wk.pdu], crc); // tb_crc is zeroed by the run before this kernel
   }
 }
 
 hipError_t launch_tb_crc(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream)
 {
-  if (p.n_pdu == 0) {
+  if (p.n_crc_work == 0) {
     return hipSuccess;
   }
-  hipLaunchKernelGGL(tb_crc_kernel, dim3(p.n_pdu), dim3(TB_CRC_THREADS), 0, stream, p, d_tb);
+  hipLaunchKernelGGL(tb_crc_kernel, dim3(p.n_crc_work), dim3(TB_CRC_THREADS), 0, stream, p, d_tb);
   return hipGetLastError();
 }
 
@@ -114,26 +89,18 @@ struct CbShared {
   LdpcScratch ldpc;
   uint32_t    crc_table[256];
   uint32_t    gold[RE_CHUNK + 40]; // scrambling words of the chunk (+ misalignment, + read-ahead)
+  float       w[2 * NRPHY_MAX_PORTS * NRPHY_MAX_LAYERS]; // wideband precoding weights [port][layer] (re, im)
 };
-
-// 32 bits of the transport block starting at bit `pos` (global memory, big-endian words).
-__device__ __forceinline__ uint32_t tb_ext32(const uint32_t* w, uint32_t pos)
-{
-  uint32_t i = pos >> 5, sh = pos & 31u;
-  uint32_t hi = be_word(w, i);
-  uint32_t lo = sh ? be_word(w, i + 1) : 0u;
-  return __funnelshift_l(lo, hi, sh);
-}
 
 // Fills lin with the K bits of codeblock `cb` (payload, TB CRC + zero padding on the last codeblock, CB CRC, filler
 // zeros) and zeroes the parity region up to `total_words`.
-__device__ inline void build_codeblock(const PduDev& pd, uint32_t cb, const uint32_t* tbw, uint32_t tb_crc,
+__device__ inline void build_codeblock(const PduDev& pd, uint32_t cb, const uint32_t* tbw, const uint32_t* tb_crc_ptr,
                                        const GoldTables* tables, CbShared* sh, uint32_t total_words, uint32_t lane)
 {
-  const bool     last     = (cb == pd.C - 1);
-  const uint32_t used     = pd.info_bits - (last ? pd.tb_crc_bits + pd.zero_pad : 0u);
-  const uint32_t tb_pos   = cb * pd.info_bits;
-  const uint32_t tb_bits  = pd.tb_bytes * 8u;
+  const bool     last    = (cb == pd.C - 1);
+  const uint32_t used    = pd.info_bits - (last ? pd.tb_crc_bits + pd.zero_pad : 0u);
+  const uint32_t tb_pos  = cb * pd.info_bits;
+  const uint32_t tb_bits = pd.tb_bytes * 8u;
   for (uint32_t j = lane; j < total_words; j += WAVE) {
     uint32_t pos = 32u * j, v = 0;
     if (pos < used) {
@@ -150,16 +117,15 @@ __device__ inline void build_codeblock(const PduDev& pd, uint32_t cb, const uint
     }
     sh->lin[j] = v;
   }
-  if (lane < 256 / WAVE * WAVE) {
-    // CRC24B byte table (4 entries per lane).
+  if (pd.cb_crc_bits) {
 #pragma unroll
     for (int k = 0; k != 4; ++k) {
-      sh->crc_table[lane * 4 + k] = crc_table_entry(lane * 4 + k, crc24b());
+      sh->crc_table[lane + WAVE * k] = tables->crc24b_table[lane + WAVE * k];
     }
   }
   wave_sync();
   if (last && lane == 0) {
-    or_bits_lds(sh->lin, used, tb_crc << (32u - pd.tb_crc_bits), pd.tb_crc_bits);
+    or_bits_lds(sh->lin, used, *tb_crc_ptr << (32u - pd.tb_crc_bits), pd.tb_crc_bits);
   }
   wave_sync();
   if (pd.cb_crc_bits) {
@@ -199,7 +165,7 @@ __device__ inline void build_codeblock(const PduDev& pd, uint32_t cb, const uint
 // ================================================================================================================
 // Rate matching index arithmetic (TS 38.212 Section 5.4.2; reference: ldpc_rate_matcher_impl.cpp:37-144).
 // Bit t of the selected sequence e_0, e_1, ... is circular-buffer bit pos(t); the buffer skips the filler interval
-// [fs, fe) and wraps at Ncb.  lin holds the codeblock including the 2*Zc punctured bits, hence the + 2*Zc.
+// [fs, fs + flen) and wraps at Ncb.  lin holds the codeblock including the 2*Zc punctured bits, hence the + 2*Zc.
 // ================================================================================================================
 struct RmIndex {
   uint32_t fs;       // first filler position (clamped to Ncb)
@@ -225,11 +191,12 @@ __device__ __forceinline__ RmIndex rm_index_init(const PduDev& pd)
   return r;
 }
 
-// Position in the circular buffer of selected bit t, and the number of selected bits that follow contiguously.
-__device__ __forceinline__ uint32_t rm_pos(const RmIndex& r, uint32_t t, uint32_t& run)
+// Circular-buffer position of selected bit t.  WRAP = false: the caller knows rank0 + t < n_valid.
+template <bool WRAP>
+__device__ __forceinline__ uint32_t rm_pos(const RmIndex& r, uint32_t t)
 {
   uint32_t u = r.rank0 + t;
-  if (u >= r.n_valid) {
+  if (WRAP && u >= r.n_valid) {
     uint32_t q = (uint32_t)((float)u * r.inv_valid);
     u -= q * r.n_valid;
     if ((int32_t)u < 0) {
@@ -238,25 +205,22 @@ __device__ __forceinline__ uint32_t rm_pos(const RmIndex& r, uint32_t t, uint32_
       u -= r.n_valid;
     }
   }
-  if (u < r.fs) {
-    run = r.fs - u;
-    return u;
-  }
-  run = r.n_valid - u;
-  return u + r.flen;
+  return u < r.fs ? u : u + r.flen;
 }
 
 // ================================================================================================================
 // Modulation mapper (TS 38.211 Section 5.1; reference: modulation_mapper_lut_impl.cpp:39-65): Qm bits (first bit
 // in the MSB of idx) -> un-normalised odd integers, as the reference's ci8 table.
 // ================================================================================================================
-__device__ __forceinline__ void qam_map(uint32_t qm, uint32_t idx, float& re, float& im)
+template <int QM>
+__device__ __forceinline__ void qam_map(uint32_t idx, float& re, float& im)
 {
   // Even bit positions (from the MSB) drive the real axis, odd positions the imaginary axis:
   // d = (1-2b0)[2^(h-1) - (1-2b2)[2^(h-2) - ...]], evaluated from the innermost term outwards.
-  int h  = (int)(qm >> 1);
-  int r  = 1 - 2 * (int)((idx >> 1) & 1u);
-  int q  = 1 - 2 * (int)(idx & 1u);
+  constexpr int h = QM / 2;
+  int           r = 1 - 2 * (int)((idx >> 1) & 1u);
+  int           q = 1 - 2 * (int)(idx & 1u);
+#pragma unroll
   for (int lvl = 1; lvl < h; ++lvl) {
     int br = (int)((idx >> (2 * lvl + 1)) & 1u);
     int bq = (int)((idx >> (2 * lvl)) & 1u);
@@ -277,6 +241,166 @@ __device__ __forceinline__ void cmul_ref(float xr, float xi, float wr, float wi,
   outi     = __fmaf_rn(xi, wr, t1);
 }
 
+struct ChunkGeom {
+  uint32_t E;      // rate-matched length of the codeblock
+  uint32_t cw_cb;  // first codeword bit of the codeblock
+  uint32_t gmis;   // misalignment of the chunk's first bit within its first scrambling word
+};
+
+// ================================================================================================================
+// Output stage of the codeblock kernel for one (modulation order, layer count): rate matching, interleaving,
+// scrambling, modulation, layer mapping, precoding, RE mapping.  Compile-time QM and L unroll every inner loop.
+// ================================================================================================================
+template <int QM, int L, bool WRAP>
+__device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd, const CbWork& wk, const CbShared& sh,
+                                          const ChunkGeom& g, uint32_t lane, uint32_t* __restrict__ d_grid,
+                                          uint32_t* __restrict__ d_cw_rm, uint32_t* __restrict__ d_cw_scr)
+{
+  constexpr uint32_t LQ    = QM * L;
+  const uint32_t     esym  = g.E / QM;           // rows of the bit interleaver
+  const uint32_t     zc2   = 2u * pd.zc;
+  const RmIndex      rm    = rm_index_init(pd);
+  const uint32_t     re_cb = g.cw_cb / LQ;       // first RE of the codeblock within the PDU
+  const uint32_t     P     = pd.nof_ports;
+  const bool         one_prg = pd.nof_prg == 1;
+  const float*       wbase = p.weights + pd.weights_offset;
+  const size_t       grid_base = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
+  const uint64_t     cw_bit0 = pd.cw_bit_offset + g.cw_cb + (uint64_t)wk.re_begin * LQ;
+
+  bool any_table = false;
+#pragma unroll
+  for (int l = 0; l != NRPHY_NSYMB; ++l) {
+    any_table |= pd.sym_kind[l] == SYM_TABLE;
+  }
+
+  for (uint32_t r = lane; r < wk.re_count; r += WAVE) {
+    const uint32_t re_in_cb = wk.re_begin + r;
+    const uint32_t sym0     = re_in_cb * L; // first modulation symbol of the RE within the codeblock
+    // Rate matching + bit interleaving: bit j of symbol s is selected bit j*esym + s; the L symbols of an RE are
+    // consecutive, so for each j one funnel read yields the bit of every layer unless the run crosses the filler
+    // gap or the end of the circular buffer.
+    uint32_t v = 0; // the RE's L*Qm codeword bits, first bit in the MSB
+#pragma unroll
+    for (int j = 0; j != QM; ++j) {
+      const uint32_t t     = (uint32_t)j * esym + sym0;
+      const uint32_t first = rm_pos<WRAP>(rm, t);
+      uint32_t       bits;
+      if (L == 1 || rm_pos<WRAP>(rm, t + L - 1) == first + (L - 1)) {
+        bits = ext32(sh.lin, first + zc2);
+      } else {
+        bits = 0;
+#pragma unroll
+        for (int l = 0; l != L; ++l) {
+          uint32_t pl = rm_pos<WRAP>(rm, t + l) + zc2;
+          bits |= ((sh.lin[pl >> 5] >> (31u - (pl & 31u))) & 1u) << (31 - l);
+        }
+      }
+#pragma unroll
+      for (int l = 0; l != L; ++l) { // layer l's bit goes to position l*Qm + j of the RE's bit group
+        v |= ((bits >> (31 - l)) & 1u) << (31 - (l * QM + j));
+      }
+    }
+    if (d_cw_rm) {
+      or_bits_global(d_cw_rm, cw_bit0 + (uint64_t)r * LQ, v, LQ);
+    }
+    // Scrambling (TS 38.211 Section 7.3.1.1).
+    v ^= ext32(sh.gold, g.gmis + r * LQ) & topmask(LQ);
+    if (d_cw_scr) {
+      or_bits_global(d_cw_scr, cw_bit0 + (uint64_t)r * LQ, v, LQ);
+    }
+    if (d_grid == nullptr) {
+      continue;
+    }
+    // RE position: OFDM symbol from the per-symbol prefix counts, subcarrier from the symbol's pattern.
+    const uint32_t re_pdu = re_cb + re_in_cb;
+    uint32_t       l_sym = 0, start = 0, arg = pd.sym_arg[0];
+#pragma unroll
+    for (int l = 1; l != NRPHY_NSYMB; ++l) {
+      bool ge = re_pdu >= pd.sym_re_start[l];
+      l_sym += ge ? 1u : 0u;
+      start = ge ? pd.sym_re_start[l] : start;
+      arg   = ge ? pd.sym_arg[l] : arg;
+    }
+    uint32_t subc = arg + (re_pdu - start);
+    if (any_table && pd.sym_kind[l_sym] == SYM_TABLE) {
+      subc = (uint32_t)p.re_table[subc];
+    }
+    // Modulation + layer mapping + precoding (resource_grid_mapper_impl.cpp:279-437, channel_precoder_avx2.cpp:214-342).
+    float xr[L], xi[L];
+#pragma unroll
+    for (int l = 0; l != L; ++l) {
+      qam_map<QM>((v >> (32 - (l + 1) * QM)) & ((1u << QM) - 1u), xr[l], xi[l]);
+    }
+    uint32_t* out = d_grid + grid_base + (size_t)l_sym * p.grid_nof_subc + subc;
+    if (one_prg) {
+      // Wideband precoding (the common case): the weights sit in LDS, every lane reads the same words (broadcast).
+#pragma unroll 1
+      for (uint32_t port = 0; port != P; ++port) {
+        const float* w = &sh.w[2 * port * L];
+        float        accr, acci;
+        cmul_ref(xr[0], xi[0], w[0], w[1], accr, acci);
+#pragma unroll
+        for (int l = 1; l != L; ++l) {
+          float pr, pi;
+          cmul_ref(xr[l], xi[l], w[2 * l], w[2 * l + 1], pr, pi);
+          accr = __fadd_rn(accr, pr);
+          acci = __fadd_rn(acci, pi);
+        }
+        out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = to_bf16_bits(accr) | (to_bf16_bits(acci) << 16);
+      }
+    } else {
+      uint32_t prg = subc / pd.prg_size_subc;
+      prg          = prg >= pd.nof_prg ? pd.nof_prg - 1 : prg;
+      const float* w = wbase + 2u * prg * P * L;
+      for (uint32_t port = 0; port != P; ++port) {
+        float accr, acci;
+        cmul_ref(xr[0], xi[0], w[2 * (port * L)], w[2 * (port * L) + 1], accr, acci);
+#pragma unroll
+        for (int l = 1; l != L; ++l) {
+          float pr, pi;
+          cmul_ref(xr[l], xi[l], w[2 * (port * L + l)], w[2 * (port * L + l) + 1], pr, pi);
+          accr = __fadd_rn(accr, pr);
+          acci = __fadd_rn(acci, pi);
+        }
+        out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = to_bf16_bits(accr) | (to_bf16_bits(acci) << 16);
+      }
+    }
+  }
+}
+
+template <int QM, int L>
+__device__ __forceinline__ void map_chunk_select(const PdschLaunch& p, const PduDev& pd, const CbWork& wk,
+                                                 const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
+                                                 uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
+{
+  if (wrap) {
+    map_chunk<QM, L, true>(p, pd, wk, sh, g, lane, d_grid, d_cw_rm, d_cw_scr);
+  } else {
+    map_chunk<QM, L, false>(p, pd, wk, sh, g, lane, d_grid, d_cw_rm, d_cw_scr);
+  }
+}
+
+template <int QM>
+__device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, const PduDev& pd, const CbWork& wk,
+                                                 const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
+                                                 uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
+{
+  switch (pd.nof_layers) { // wave-uniform
+    case 1:
+      map_chunk_select<QM, 1>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+    case 2:
+      map_chunk_select<QM, 2>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+    case 3:
+      map_chunk_select<QM, 3>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+    default:
+      map_chunk_select<QM, 4>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+  }
+}
+
 // ================================================================================================================
 // The codeblock kernel.
 // ================================================================================================================
@@ -292,105 +416,46 @@ __global__ __launch_bounds__(WAVE) void codeblock_kernel(PdschLaunch p, const ui
 
   // 1. Segmentation + CRC attachment.
   const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
-  const uint32_t tb_crc      = p.tb_crc[wk.pdu];
-  build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), tb_crc, p.gold, &sh, total_words,
-                  lane);
+  build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), &p.tb_crc[wk.pdu], p.gold, &sh,
+                  total_words, lane);
 
   // 2. LDPC encoding (only the parity rows that rate matching can reach).
   ldpc_encode_wave(&p.graphs[pd.graph], kb, zc, pd.nof_rows, sh.lin, &sh.ldpc, lane);
 
-  // 3. This wave's slice of the codeword.
-  const uint32_t lq      = pd.nof_layers * pd.qm;                 // bits per RE
+  // 3. This wave's slice of the codeword and its scrambling sequence.
+  const uint32_t lq      = pd.nof_layers * pd.qm; // bits per RE
   const bool     is_long = wk.cb >= pd.n_short;
-  const uint32_t E       = is_long ? pd.e_long : pd.e_short;
-  const uint32_t cw_cb   = is_long ? pd.n_short * pd.e_short + (wk.cb - pd.n_short) * pd.e_long : wk.cb * pd.e_short;
-  const uint32_t esym    = E / pd.qm;                             // rows of the bit interleaver
-  const uint32_t bit0    = cw_cb + wk.re_begin * lq;              // first codeword bit of the chunk
-  const uint32_t gw0     = bit0 >> 5;
-  const uint32_t gmis    = bit0 & 31u;
-  const uint32_t gwords  = (gmis + wk.re_count * lq + 31u) >> 5;
-  gold_generate_wave(p.gold, p.x1_words, pd.c_init, gw0, gwords, sh.gold, lane);
+  ChunkGeom      g;
+  g.E     = is_long ? pd.e_long : pd.e_short;
+  g.cw_cb = is_long ? pd.n_short * pd.e_short + (wk.cb - pd.n_short) * pd.e_long : wk.cb * pd.e_short;
+  const uint32_t bit0   = g.cw_cb + wk.re_begin * lq; // first codeword bit of the chunk
+  g.gmis                = bit0 & 31u;
+  const uint32_t gwords = (g.gmis + wk.re_count * lq + 31u) >> 5;
+  gold_generate_wave(p.gold, p.x1_words, pd.c_init, bit0 >> 5, gwords, sh.gold, lane);
   if (lane < 8) {
     sh.gold[gwords + lane] = 0;
   }
+  if (lane < 2 * pd.nof_ports * pd.nof_layers) {
+    sh.w[lane] = p.weights[pd.weights_offset + lane];
+  }
   wave_sync();
 
-  const RmIndex  rm        = rm_index_init(pd);
-  const uint32_t re_cb     = cw_cb / lq;                          // first RE of the codeblock within the PDU
-  const uint32_t L = pd.nof_layers, P = pd.nof_ports, qm = pd.qm;
-  const float*   wbase     = p.weights + pd.weights_offset;
-  const size_t   grid_base = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
-
-  for (uint32_t r = lane; r < wk.re_count; r += WAVE) {
-    const uint32_t re_in_cb = wk.re_begin + r;
-    const uint32_t sym0     = re_in_cb * L; // first modulation symbol of the RE within the codeblock
-    // 3a. Rate matching + bit interleaving: bit j of symbol s is selected bit j*esym + s.
-    uint32_t v = 0; // the RE's L*Qm codeword bits, first bit in the MSB
-    for (uint32_t j = 0; j != qm; ++j) {
-      uint32_t t = j * esym + sym0, run;
-      uint32_t pos = rm_pos(rm, t, run);
-      uint32_t bits;
-      if (run >= L) {
-        bits = ext32(sh.lin, pos + 2u * zc); // L consecutive selected bits: one per layer
-      } else {
-        bits = 0;
-        for (uint32_t l = 0; l != L; ++l) {
-          uint32_t rr;
-          uint32_t pl = rm_pos(rm, t + l, rr);
-          bits |= ((sh.lin[(pl + 2u * zc) >> 5] >> (31u - ((pl + 2u * zc) & 31u))) & 1u) << (31u - l);
-        }
-      }
-      // Layer l's bit goes to position l*Qm + j of the RE's bit group.
-      for (uint32_t l = 0; l != L; ++l) {
-        v |= ((bits >> (31u - l)) & 1u) << (31u - (l * qm + j));
-      }
-    }
-    const uint64_t cw_bit = pd.cw_bit_offset + bit0 + (uint64_t)r * lq;
-    if (d_cw_rm) {
-      or_bits_global(d_cw_rm, cw_bit, v, lq);
-    }
-    // 3b. Scrambling (TS 38.211 Section 7.3.1.1).
-    v ^= ext32(sh.gold, gmis + r * lq) & topmask(lq);
-    if (d_cw_scr) {
-      or_bits_global(d_cw_scr, cw_bit, v, lq);
-    }
-    if (d_grid == nullptr) {
-      continue;
-    }
-    // 3c. RE position: OFDM symbol from the per-symbol prefix counts, subcarrier from the symbol's pattern.
-    const uint32_t re_pdu = re_cb + re_in_cb;
-    uint32_t       l_sym  = 0;
-#pragma unroll
-    for (uint32_t l = 1; l != NRPHY_NSYMB; ++l) {
-      l_sym += (re_pdu >= pd.sym_re_start[l]) ? 1u : 0u;
-    }
-    const uint32_t idx  = re_pdu - pd.sym_re_start[l_sym];
-    const uint32_t subc = (pd.sym_kind[l_sym] == SYM_TABLE) ? (uint32_t)p.re_table[pd.sym_arg[l_sym] + idx]
-                                                            : pd.sym_arg[l_sym] + idx;
-    const float* w = wbase;
-    if (pd.nof_prg > 1) {
-      uint32_t prg = subc / pd.prg_size_subc;
-      prg          = prg >= pd.nof_prg ? pd.nof_prg - 1 : prg;
-      w += 2u * prg * P * L;
-    }
-    // 3d. Modulation + layer mapping + precoding (resource_grid_mapper_impl.cpp:279-437, channel_precoder_avx2.cpp:214-342).
-    float xr[NRPHY_MAX_LAYERS], xi[NRPHY_MAX_LAYERS];
-    for (uint32_t l = 0; l != L; ++l) {
-      uint32_t sidx = (v >> (32u - (l + 1u) * qm)) & ((1u << qm) - 1u);
-      qam_map(qm, sidx, xr[l], xi[l]);
-    }
-    for (uint32_t port = 0; port != P; ++port) {
-      float accr, acci;
-      cmul_ref(xr[0], xi[0], w[2 * (port * L)], w[2 * (port * L) + 1], accr, acci);
-      for (uint32_t l = 1; l != L; ++l) {
-        float pr, pi;
-        cmul_ref(xr[l], xi[l], w[2 * (port * L + l)], w[2 * (port * L + l) + 1], pr, pi);
-        accr = __fadd_rn(accr, pr);
-        acci = __fadd_rn(acci, pi);
-      }
-      d_grid[grid_base + ((size_t)port * NRPHY_NSYMB + l_sym) * p.grid_nof_subc + subc] =
-          to_bf16_bits(accr) | (to_bf16_bits(acci) << 16);
-    }
+  // 4. Rate matching ... RE mapping, specialised per (Qm, layers); `wrap` = the selection wraps around Ncb.
+  const RmIndex rm   = rm_index_init(pd);
+  const bool    wrap = rm.rank0 + g.E > rm.n_valid;
+  switch (pd.qm) { // wave-uniform
+    case 2:
+      map_chunk_layers<2>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+    case 4:
+      map_chunk_layers<4>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+    case 6:
+      map_chunk_layers<6>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+    default:
+      map_chunk_layers<8>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
   }
 }
 
@@ -406,9 +471,9 @@ hipError_t launch_codeblocks(const PdschLaunch& p, const uint8_t* d_tb, uint32_t
 
 // ================================================================================================================
 // DM-RS for PDSCH (TS 38.211 Section 7.4.1.1; reference: dmrs_pdsch_processor_impl.cpp:84-262, dmrs_helper.h:44-109,
-// resource_grid_mapper_impl.cpp:47-133).  One wavefront per (PDU, DM-RS symbol).
+// resource_grid_mapper_impl.cpp:47-133).  One wavefront per (PDU, DM-RS symbol, 32-PRB chunk).
 // ================================================================================================================
-constexpr int DMRS_GOLD_WORDS = (NRPHY_MAX_RB * 12) / 32 + 8;
+constexpr int DMRS_GOLD_WORDS = (DMRS_PRB_CHUNK * 12) / 32 + 8;
 
 __global__ __launch_bounds__(WAVE) void dmrs_kernel(PdschLaunch p, uint32_t* __restrict__ d_grid)
 {
@@ -419,18 +484,18 @@ __global__ __launch_bounds__(WAVE) void dmrs_kernel(PdschLaunch p, uint32_t* __r
   const uint32_t      L = pd.nof_layers, P = pd.nof_ports;
 
   // Pilot r(n) uses c(2n), c(2n+1); PRB prb holds n = 6*(prb - ref) .. +5, i.e. sequence bits 12*(prb - ref) .. +11.
-  const uint32_t bit_first = 12u * (pd.first_prb - pd.dmrs_ref_rb);
-  const uint32_t bit_end   = 12u * (pd.end_prb - pd.dmrs_ref_rb);
+  const uint32_t bit_first = 12u * (wk.prb_begin - pd.dmrs_ref_rb);
+  const uint32_t bit_end   = 12u * (wk.prb_end - pd.dmrs_ref_rb);
   const uint32_t w0        = bit_first >> 5;
   const uint32_t nwords    = ((bit_end + 31u) >> 5) - w0;
   gold_generate_wave(p.gold, p.x1_words, pd.dmrs_c_init[wk.symbol], w0, nwords, gold, lane);
 
-  const float    a         = pd.dmrs_amplitude;
-  const uint32_t nof_items = (pd.end_prb - pd.first_prb) * 6u;
-  const size_t   grid_base = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
+  const float    a          = pd.dmrs_amplitude;
+  const uint32_t nof_items  = (wk.prb_end - wk.prb_begin) * 6u;
+  const size_t   grid_base  = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
   const uint32_t nof_groups = (L + 1u) >> 1;
   for (uint32_t item = lane; item < nof_items; item += WAVE) {
-    const uint32_t prb = pd.first_prb + item / 6u;
+    const uint32_t prb = wk.prb_begin + item / 6u;
     const uint32_t kp  = item % 6u;
     if (!((pd.prb_mask[prb >> 5] >> (prb & 31u)) & 1u)) {
       continue;
