@@ -228,11 +228,17 @@ int nrphy_ofdm_plan_kernel_time(nrphy_ofdm_plan_t* plan, float* avg_ms, uint32_t
 int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t port_index,
                                     uint32_t symbol_index, float* output, uint32_t output_size);
 
+/* Host-span whole-slot form of ofdm_slot_modulator::modulate for every port of one grid: iq receives
+ * nof_ports x nrphy_ofdm_slot_size(cfg, slot_index) complex samples, port after port (blocking). */
+int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t slot_index, float* iq);
+
 /* dft_processor::run (R/include/srsran/phy/generic_functions/dft_processor.h:34-73; generic impl
  * dft_processor_generic_impl.cpp:14-218).  Unnormalised DFT of `size` complex floats, `batch` of them
  * back to back.  inverse != 0 uses exp(+j...).  Sizes: powers of two 128..4096 (more in later rounds). */
 int nrphy_dft_run(nrphy_ctx_t* ctx, uint32_t size, int inverse, uint32_t batch, const float* d_in, float* d_out,
                   void* stream);
+/* Host-span form of dft_processor::run for one transform (blocking). */
+int nrphy_dft_run_host(nrphy_ctx_t* ctx, uint32_t size, int inverse, const float* in, float* out);
 
 #ifdef __cplusplus
 }

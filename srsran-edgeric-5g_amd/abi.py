@@ -215,6 +215,8 @@ def declare(lib, prefix="nrphy_"):
     sig("ofdm_run", i32, vp, u32, vp, vp, vp, vp)
     sig("ofdm_modulate_symbol_host", i32, vp, vp, u32, u32, vp, u32)
     sig("dft_run", i32, vp, u32, i32, u32, vp, vp, vp)
+    sig("dft_run_host", i32, vp, u32, i32, vp, vp)
+    sig("ofdm_modulate_slot_host", i32, vp, vp, u32, vp)
     return lib
 
 
@@ -227,5 +229,5 @@ ABI_SYMBOLS = [
     "nrphy_pdsch_run", "nrphy_pdsch_plan_enable_timing", "nrphy_pdsch_plan_kernel_times",
     "nrphy_ofdm_plan_enable_timing", "nrphy_ofdm_plan_kernel_time", "nrphy_pdsch_process_host", "nrphy_ldpc_encode", "nrphy_ofdm_plan_create",
     "nrphy_ofdm_plan_destroy", "nrphy_ofdm_plan_slot_stride", "nrphy_ofdm_run",
-    "nrphy_ofdm_modulate_symbol_host", "nrphy_dft_run",
+    "nrphy_ofdm_modulate_symbol_host", "nrphy_ofdm_modulate_slot_host", "nrphy_dft_run", "nrphy_dft_run_host",
 ]

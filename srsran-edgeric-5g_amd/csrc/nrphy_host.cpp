@@ -1338,3 +1338,75 @@ extern "C" int nrphy_dft_run(nrphy_ctx_t* ctx, uint32_t size, int inverse, uint3
                      stream ? (hipStream_t)stream : ctx->stream));
   return NRPHY_OK;
 }
+
+extern "C" int nrphy_dft_run_host(nrphy_ctx_t* ctx, uint32_t size, int inverse, const float* in, float* out)
+{
+  if (ctx == nullptr || in == nullptr || out == nullptr || !dft_size_supported(size)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const size_t bytes = (size_t)size * sizeof(float2);
+  float *      d_in = nullptr, *d_out = nullptr;
+  int          rc   = NRPHY_ERR_DEVICE;
+  do {
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&d_in, bytes) != hipSuccess ||
+        hipMalloc((void**)&d_out, bytes) != hipSuccess ||
+        hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+      break;
+    }
+    rc = nrphy_dft_run(ctx, size, inverse, 1, d_in, d_out, ctx->stream);
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    rc = NRPHY_OK;
+  } while (false);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+extern "C" int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t slot_index, float* iq)
+{
+  if (plan == nullptr || grid == nullptr || iq == nullptr || slot_index >= (1U << plan->cfg.numerology)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  nrphy_ctx*     ctx        = plan->ctx;
+  const size_t   grid_words = (size_t)plan->nof_ports * NRPHY_NSYMB * 12 * plan->cfg.bw_rb;
+  const size_t   iq_samples = (size_t)plan->nof_ports * plan->slot_stride;
+  const uint32_t slot_size  = nrphy_ofdm_slot_size(&plan->cfg, slot_index);
+  uint32_t *     d_grid = nullptr, *d_slot = nullptr;
+  float2*        d_iq   = nullptr;
+  int            rc     = NRPHY_ERR_DEVICE;
+  do {
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&d_grid, grid_words * 4) != hipSuccess ||
+        hipMemcpy(d_grid, grid, grid_words * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void**)&d_iq, iq_samples * sizeof(float2)) != hipSuccess ||
+        upload(&d_slot, &slot_index, sizeof(slot_index)) != hipSuccess) {
+      break;
+    }
+    rc = nrphy_ofdm_run(plan, 1, d_grid, d_slot, (float*)d_iq, ctx->stream);
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      break;
+    }
+    bool ok = true;
+    for (uint32_t port = 0; port != plan->nof_ports && ok; ++port) {
+      ok = hipMemcpy(iq + 2 * (size_t)port * slot_size, d_iq + (size_t)port * plan->slot_stride,
+                     (size_t)slot_size * sizeof(float2), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (ok) {
+      rc = NRPHY_OK;
+    }
+  } while (false);
+  (void)hipFree(d_grid);
+  (void)hipFree(d_iq);
+  (void)hipFree(d_slot);
+  return rc;
+}

@@ -1,11 +1,13 @@
 // OFDM modulator and DFT kernels for gfx950 (MI355X).
 //
-// One workgroup transforms one OFDM symbol: the resource-grid row is read straight from HBM into the first
-// butterfly stage (bin placement and guard zeros are index arithmetic), the transform runs as an in-LDS Stockham
-// autosort FFT with radix-16/8/4/2 register butterflies, and the last stage applies phase compensation x scale and
-// writes the useful part plus the cyclic prefix.  Replaces ofdm_symbol_modulator_impl::modulate
-// (R/lib/phy/lower/modulation/ofdm_modulator_impl.cpp:56-100) and dft_processor_generic_impl::run
-// (R/lib/phy/generic_functions/dft_processor_generic_impl.cpp:14-218).
+// One workgroup modulates the OFDM symbols of one (grid, port) one after the other.  A symbol's resource-grid row
+// goes from HBM straight into the registers of the first butterfly stage (bin placement and guard zeros are index
+// arithmetic); while the transform of symbol l runs in LDS (Stockham autosort, radix-16/8/4/2 register butterflies)
+// the row of symbol l+1 is already in flight.  Twiddles are powers of one table value per thread and stage, built in
+// registers, so the only global traffic is the algorithmic one: grid in, IQ out.  The last stage applies phase
+// compensation x scale and writes the useful part plus the cyclic prefix.
+// Replaces ofdm_symbol_modulator_impl::modulate (R/lib/phy/lower/modulation/ofdm_modulator_impl.cpp:56-100) and
+// dft_processor_generic_impl::run (R/lib/phy/generic_functions/dft_processor_generic_impl.cpp:14-218).
 #include "nrphy_internal.h"
 
 namespace nrphy {
@@ -97,14 +99,14 @@ struct Butterfly<SIGN, 16> {
     dft4<SIGN>(a[2], a[6], a[10], a[14]);
     dft4<SIGN>(a[3], a[7], a[11], a[15]);
     // Twiddles W16^(n2 k1) on element a[4 k1 + n2].
-    a[5]  = cmul(a[5], make_float2(c1, SIGN * s1));   // 1*1
-    a[6]  = cmul(a[6], make_float2(h, SIGN * h));     // 2*1
-    a[7]  = cmul(a[7], make_float2(s1, SIGN * c1));   // 3*1
-    a[9]  = cmul(a[9], make_float2(h, SIGN * h));     // 1*2
-    a[10] = mulj<SIGN>(a[10]);                        // 2*2
-    a[11] = cmul(a[11], make_float2(-h, SIGN * h));   // 3*2
-    a[13] = cmul(a[13], make_float2(s1, SIGN * c1));  // 1*3
-    a[14] = cmul(a[14], make_float2(-h, SIGN * h));   // 2*3
+    a[5]  = cmul(a[5], make_float2(c1, SIGN * s1));    // 1*1
+    a[6]  = cmul(a[6], make_float2(h, SIGN * h));      // 2*1
+    a[7]  = cmul(a[7], make_float2(s1, SIGN * c1));    // 3*1
+    a[9]  = cmul(a[9], make_float2(h, SIGN * h));      // 1*2
+    a[10] = mulj<SIGN>(a[10]);                         // 2*2
+    a[11] = cmul(a[11], make_float2(-h, SIGN * h));    // 3*2
+    a[13] = cmul(a[13], make_float2(s1, SIGN * c1));   // 1*3
+    a[14] = cmul(a[14], make_float2(-h, SIGN * h));    // 2*3
     a[15] = cmul(a[15], make_float2(-c1, -SIGN * s1)); // 3*3 = 9 -> W16^9
     // Outer transforms over n2 for each k1; result a[4 k1 + k2] = X[k1 + 4 k2].
     dft4<SIGN>(a[0], a[1], a[2], a[3]);
@@ -122,22 +124,110 @@ struct Butterfly<SIGN, 16> {
   }
 };
 
+// a[j] *= b^j for j = 1..R-1.  Powers are built from b^2, b^4, b^8 (squarings) so that every power is at most
+// three multiplications deep (a few ulp), and applied at once to keep few values live.
+template <int R>
+__device__ __forceinline__ void apply_twiddle_powers(float2 b, float2 (&a)[R])
+{
+  a[1] = cmul(a[1], b);
+  if (R > 2) {
+    const float2 b2 = cmul(b, b);
+    a[2]            = cmul(a[2], b2);
+    a[3]            = cmul(a[3], cmul(b2, b));
+    if (R > 4) {
+      const float2 b4 = cmul(b2, b2);
+      a[4]            = cmul(a[4], b4);
+      a[5]            = cmul(a[5], cmul(b4, b));
+      a[6]            = cmul(a[6], cmul(b4, b2));
+      a[7]            = cmul(a[7], cmul(b4, cmul(b2, b)));
+      if (R > 8) {
+        const float2 b8 = cmul(b4, b4);
+        a[8]            = cmul(a[8], b8);
+        a[9]            = cmul(a[9], cmul(b8, b));
+        a[10]           = cmul(a[10], cmul(b8, b2));
+        a[11]           = cmul(a[11], cmul(b8, cmul(b2, b)));
+        const float2 b12 = cmul(b8, b4);
+        a[12]            = cmul(a[12], b12);
+        a[13]            = cmul(a[13], cmul(b12, b));
+        a[14]            = cmul(a[14], cmul(b12, b2));
+        a[15]            = cmul(a[15], cmul(b12, cmul(b2, b)));
+      }
+    }
+  }
+}
+
 // LDS index padding: one extra element every 16 keeps the stride-16 stores of the first stage off a single bank.
 __device__ __forceinline__ uint32_t pad(uint32_t i)
 {
   return i + (i >> 4);
 }
 
-// One Stockham stage (decimation in frequency, autosort).  n = current transform length, s = N / n the stride.
-//   a[k] = x[q + s (p + k n/R)],   y[q + s (R p + j)] = DFT_R(a)[j] * w_n^(j p),   p < n/R, q < s.
-// FIRST reads through `load(i)` instead of LDS, LAST writes through `store(i, v)` instead of LDS.
-template <int SIGN, int N, int T, int R, int S, bool FIRST, bool LAST, typename Load, typename Store>
-__device__ __forceinline__ void stage(float2* lds, const float2* __restrict__ tw, uint32_t tid, Load load, Store store)
+// Radix plans: N = R0 * R1 * R2 (R2 = 1 when two stages suffice), T = threads per transform = N / 16.
+template <int N>
+struct Plan;
+template <> struct Plan<4096> { static constexpr int R0 = 16, R1 = 16, R2 = 16, T = 256; };
+template <> struct Plan<2048> { static constexpr int R0 = 16, R1 = 16, R2 = 8, T = 128; };
+template <> struct Plan<1024> { static constexpr int R0 = 16, R1 = 16, R2 = 4, T = 64; };
+template <> struct Plan<512>  { static constexpr int R0 = 16, R1 = 16, R2 = 2, T = 64; };
+template <> struct Plan<256>  { static constexpr int R0 = 16, R1 = 16, R2 = 1, T = 64; };
+template <> struct Plan<128>  { static constexpr int R0 = 16, R1 = 8, R2 = 1, T = 64; };
+
+// Input index k-th element of the first-stage butterfly of thread `tid`: x[tid + k * N / R0].
+template <int N>
+__device__ __forceinline__ uint32_t first_stage_index(uint32_t tid, int k)
 {
-  constexpr int NB    = N / R;                 // butterflies
-  constexpr int ITERS = (NB + T - 1) / T;      // per thread
-  constexpr int n     = N / S;
-  constexpr int n1    = n / R;
+  return tid + k * (N / Plan<N>::R0);
+}
+
+// Twiddle bases of a thread: stage s multiplies output j of its butterfly by (w_n^p)^j with w_n^p = tw[p * S].
+template <int N>
+struct TwiddleBase {
+  float2 b0, b1; // first and second stage (the last stage of a plan has n1 = 1: no twiddles)
+};
+
+template <int SIGN, int N>
+__device__ __forceinline__ TwiddleBase<N> load_twiddle_base(const float2* __restrict__ tw, uint32_t tid)
+{
+  using P = Plan<N>;
+  TwiddleBase<N> t;
+  // Stage 0: S = 1, p = butterfly index = tid (threads beyond N/R0 butterflies are idle in that stage).
+  t.b0 = tw[tid & (N - 1)];
+  // Stage 1: S = R0, p = b / R0 for butterfly b = tid (+ it*T); only the first iteration's base is kept here, the
+  // others are derived in the stage (see stage_lds).
+  t.b1 = tw[((tid / P::R0) * P::R0) & (N - 1)];
+  if (SIGN < 0) {
+    t.b0.y = -t.b0.y;
+    t.b1.y = -t.b1.y;
+  }
+  return t;
+}
+
+// First Stockham stage on registers a[k] = x[tid + k N/R0]: y[R0 p + j] = DFT(a)[j] * w^(j p), p = tid, S = 1.
+template <int SIGN, int N>
+__device__ __forceinline__ void stage_first(float2 (&a)[Plan<N>::R0], float2 base, float2* lds, uint32_t tid)
+{
+  constexpr int R  = Plan<N>::R0;
+  constexpr int NB = N / R;
+  if (NB >= Plan<N>::T || tid < NB) {
+    Butterfly<SIGN, R>::run(a);
+    apply_twiddle_powers<R>(base, a);
+#pragma unroll
+    for (int j = 0; j != R; ++j) {
+      lds[pad(R * tid + j)] = a[j];
+    }
+  }
+  __syncthreads();
+}
+
+// A later Stockham stage (decimation in frequency, autosort).  n = N / S is the current transform length.
+//   a[k] = x[q + S (p + k n/R)],   y[q + S (R p + j)] = DFT_R(a)[j] * w_n^(j p),   p < n/R, q < S.
+template <int SIGN, int N, int T, int R, int S, bool LAST, typename Store>
+__device__ __forceinline__ void stage_lds(float2* lds, const float2* __restrict__ tw, float2 base, uint32_t tid,
+                                          Store store)
+{
+  constexpr int NB    = N / R;
+  constexpr int ITERS = (NB + T - 1) / T;
+  constexpr int n1    = N / S / R;
   float2        a[ITERS][R];
 #pragma unroll
   for (int it = 0; it != ITERS; ++it) {
@@ -146,30 +236,30 @@ __device__ __forceinline__ void stage(float2* lds, const float2* __restrict__ tw
       uint32_t p = b / S, q = b % S;
 #pragma unroll
       for (int k = 0; k != R; ++k) {
-        uint32_t idx = q + S * (p + k * n1);
-        a[it][k]     = FIRST ? load(idx) : lds[pad(idx)];
+        a[it][k] = lds[pad(q + S * (p + k * n1))];
       }
     }
   }
-  if (!FIRST) {
-    __syncthreads(); // every read of this stage is done before anyone overwrites
-  }
+  __syncthreads(); // every read of this stage is done before anyone overwrites
 #pragma unroll
   for (int it = 0; it != ITERS; ++it) {
     uint32_t b = tid + it * T;
     if (NB % T == 0 || b < NB) {
       uint32_t p = b / S, q = b % S;
       Butterfly<SIGN, R>::run(a[it]);
+      if (n1 > 1) {
+        float2 bs = base;
+        if (it > 0) { // p differs per iteration: fetch this iteration's base (rare plans only)
+          bs = tw[(p * S) & (N - 1)];
+          if (SIGN < 0) {
+            bs.y = -bs.y;
+          }
+        }
+        apply_twiddle_powers<R>(bs, a[it]);
+      }
 #pragma unroll
       for (int j = 0; j != R; ++j) {
-        float2 v = a[it][j];
-        if (n1 > 1 && j > 0) {
-          float2 w = tw[(j * p * S) & (N - 1)]; // exp(+2 pi i j p / n)
-          if (SIGN < 0) {
-            w.y = -w.y;
-          }
-          v = cmul(v, w);
-        }
+        float2   v   = a[it][j];
         uint32_t idx = q + S * (R * p + j);
         if (LAST) {
           store(idx, v);
@@ -184,66 +274,81 @@ __device__ __forceinline__ void stage(float2* lds, const float2* __restrict__ tw
   }
 }
 
-// Radix plans: N = R0 * R1 * R2 (R2 = 1 when two stages suffice), T = threads per transform.
-template <int N>
-struct Plan;
-template <> struct Plan<4096> { static constexpr int R0 = 16, R1 = 16, R2 = 16, T = 256; };
-template <> struct Plan<2048> { static constexpr int R0 = 16, R1 = 16, R2 = 8, T = 128; };
-template <> struct Plan<1024> { static constexpr int R0 = 16, R1 = 16, R2 = 4, T = 64; };
-template <> struct Plan<512>  { static constexpr int R0 = 16, R1 = 16, R2 = 2, T = 64; };
-template <> struct Plan<256>  { static constexpr int R0 = 16, R1 = 16, R2 = 1, T = 64; };
-template <> struct Plan<128>  { static constexpr int R0 = 16, R1 = 8, R2 = 1, T = 64; };
-
-template <int SIGN, int N, typename Load, typename Store>
-__device__ __forceinline__ void fft_lds(float2* lds, const float2* __restrict__ tw, uint32_t tid, Load load, Store store)
+template <int SIGN, int N, typename Store>
+__device__ __forceinline__ void fft_from_registers(float2 (&a)[Plan<N>::R0], const TwiddleBase<N>& tb, float2* lds,
+                                                   const float2* __restrict__ tw, uint32_t tid, Store store)
 {
   using P = Plan<N>;
   constexpr int T = P::T;
-  auto no_load  = [](uint32_t) { return make_float2(0.f, 0.f); };
-  auto no_store = [](uint32_t, float2) {};
-  stage<SIGN, N, T, P::R0, 1, true, false>(lds, tw, tid, load, no_store);
+  auto no_store   = [](uint32_t, float2) {};
+  stage_first<SIGN, N>(a, tb.b0, lds, tid);
   if constexpr (P::R2 == 1) {
-    stage<SIGN, N, T, P::R1, P::R0, false, true>(lds, tw, tid, no_load, store);
+    stage_lds<SIGN, N, T, P::R1, P::R0, true>(lds, tw, tb.b1, tid, store);
   } else {
-    stage<SIGN, N, T, P::R1, P::R0, false, false>(lds, tw, tid, no_load, no_store);
-    stage<SIGN, N, T, P::R2, P::R0 * P::R1, false, true>(lds, tw, tid, no_load, store);
+    stage_lds<SIGN, N, T, P::R1, P::R0, false>(lds, tw, tb.b1, tid, no_store);
+    stage_lds<SIGN, N, T, P::R2, P::R0 * P::R1, true>(lds, tw, tb.b1, tid, store);
   }
+  __syncthreads(); // the LDS buffer is reused by the next transform of this workgroup
 }
 
 // ================================================================================================================
-// OFDM symbol modulator.  blockIdx.x = (grid * nof_ports + port) * nsymb + symbol.
+// OFDM slot modulator.  blockIdx.x = (grid * nof_ports + port) * groups + group; a workgroup modulates SPW
+// consecutive symbols of its (grid, port).  With SPW > 1 the next symbol's row is fetched while the current one is
+// transformed.
 // ================================================================================================================
 template <int N>
+__device__ __forceinline__ void load_symbol_row(uint32_t (&a)[Plan<N>::R0], const uint32_t* __restrict__ row,
+                                                uint32_t half, uint32_t tid)
+{
+  // Bin placement (ofdm_modulator_impl.cpp:83-87): lower grid half -> top bins, upper half -> bins from DC, guard
+  // bins zero.  Branch-free: guard bins read element 0 and discard it.
+#pragma unroll
+  for (int k = 0; k != Plan<N>::R0; ++k) {
+    const uint32_t i   = first_stage_index<N>(tid, k);
+    const bool     lo  = i < half;
+    const bool     hi  = (i >= N - half) && (i < N);
+    const uint32_t idx = lo ? i + half : (hi ? i - (N - half) : 0u);
+    const uint32_t v   = row[idx];
+    a[k]               = (lo || hi) ? v : 0u; // cbf16: real in the low half, imaginary in the high half
+  }
+}
+
+template <int N, int SPW>
 __global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_grid,
                                                           const uint32_t* __restrict__ d_slot_index,
                                                           float2* __restrict__ d_iq)
 {
   __shared__ float2 lds[N + N / 16 + 16];
-  const uint32_t    tid    = threadIdx.x;
-  const uint32_t    l      = blockIdx.x % p.nsymb;
-  const uint32_t    gp     = blockIdx.x / p.nsymb; // grid * nof_ports + port
+  const uint32_t    tid_in = threadIdx.x;
+  const uint32_t    groups = (p.nsymb + SPW - 1) / SPW;
+  const uint32_t    gp     = blockIdx.x / groups; // grid * nof_ports + port
+  const uint32_t    l0     = (blockIdx.x % groups) * SPW;
+  const uint32_t    l1     = (l0 + SPW < p.nsymb) ? l0 + SPW : p.nsymb;
   const uint32_t    g      = gp / p.nof_ports;
   const uint32_t    slot   = d_slot_index ? d_slot_index[g] : 0u;
-  const uint32_t    sym    = slot * p.nsymb + l;   // symbol index within the subframe
   const uint32_t    half   = p.rg_size >> 1;
-  const uint32_t*   row    = d_grid + ((size_t)gp * NRPHY_NSYMB + l) * p.rg_size;
-  const uint32_t    cp     = p.cp_len[sym];
-  const float2      ph     = p.phase[sym];
-  float2*           out    = d_iq + (size_t)gp * p.slot_stride + p.sym_offset[sym];
+  const uint32_t*   rows   = d_grid + (size_t)gp * NRPHY_NSYMB * p.rg_size;
+  float2*           iq     = d_iq + (size_t)gp * p.slot_stride;
 
-  // Bin placement (ofdm_modulator_impl.cpp:83-87): lower grid half -> top bins, upper half -> bins from DC.
-  auto load = [&](uint32_t i) {
-    uint32_t k;
-    if (i < half) {
-      k = i + half;
-    } else if (i >= N - half) {
-      k = i - (N - half);
-    } else {
-      return make_float2(0.f, 0.f);
-    }
-    uint32_t v = row[k];
-    return make_float2(__uint_as_float(v << 16), __uint_as_float(v & 0xFFFF0000u));
-  };
+  // NOTE: a symbol loop with a register prefetch of the next row was tried (SPW = 2..14): hipcc hoists the ~100
+  // loop-invariant per-thread LDS/global addresses of the three stages out of the loop, the kernel needs 226+
+  // VGPRs and one workgroup per CU stays resident; one symbol per workgroup at 127 VGPRs keeps four.
+  static_assert(SPW == 1, "one OFDM symbol per workgroup");
+  (void)l1;
+  const uint32_t       tid = tid_in;
+  const uint32_t       l   = l0;
+  const TwiddleBase<N> tb  = load_twiddle_base<+1, N>(p.twiddle, tid);
+  uint32_t             raw[Plan<N>::R0];
+  load_symbol_row<N>(raw, rows + (size_t)l * p.rg_size, half, tid);
+  float2 cur[Plan<N>::R0];
+#pragma unroll
+  for (int k = 0; k != Plan<N>::R0; ++k) {
+    cur[k] = make_float2(__uint_as_float(raw[k] << 16), __uint_as_float(raw[k] & 0xFFFF0000u));
+  }
+  const uint32_t sym = slot * p.nsymb + l; // symbol index within the subframe
+  const uint32_t cp  = p.cp_len[sym];
+  const float2   ph  = p.phase[sym];
+  float2*        out = iq + p.sym_offset[sym];
   // Phase compensation x scale, then the cyclic prefix is the tail of the symbol (ofdm_modulator_impl.cpp:92-99).
   auto store = [&](uint32_t i, float2 v) {
     float2 y    = cmul(v, ph);
@@ -252,15 +357,18 @@ __global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const ui
       out[i - (N - cp)] = y;
     }
   };
-  fft_lds<+1, N>(lds, p.twiddle, tid, load, store);
+  fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
 }
+
+constexpr int OFDM_SYMBOLS_PER_WG = 1;
 
 template <int N>
 static hipError_t launch_ofdm_n(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* d_grid,
                                 const uint32_t* d_slot_index, float2* d_iq, hipStream_t stream)
 {
-  uint32_t blocks = nof_grids * p.nof_ports * p.nsymb;
-  hipLaunchKernelGGL(ofdm_kernel<N>, dim3(blocks), dim3(Plan<N>::T), 0, stream, p, d_grid, d_slot_index, d_iq);
+  constexpr int SPW    = OFDM_SYMBOLS_PER_WG;
+  uint32_t      blocks = nof_grids * p.nof_ports * ((p.nsymb + SPW - 1) / SPW);
+  hipLaunchKernelGGL((ofdm_kernel<N, SPW>), dim3(blocks), dim3(Plan<N>::T), 0, stream, p, d_grid, d_slot_index, d_iq);
   return hipGetLastError();
 }
 
@@ -296,11 +404,18 @@ __global__ __launch_bounds__(Plan<N>::T) void dft_kernel(const float2* __restric
                                                          float2* __restrict__ d_out)
 {
   __shared__ float2 lds[N + N / 16 + 16];
+  const uint32_t    tid = threadIdx.x;
   const float2*     in  = d_in + (size_t)blockIdx.x * N;
   float2*           out = d_out + (size_t)blockIdx.x * N;
-  auto              load  = [&](uint32_t i) { return in[i]; };
-  auto              store = [&](uint32_t i, float2 v) { out[i] = v; };
-  fft_lds<SIGN, N>(lds, tw, threadIdx.x, load, store);
+  const TwiddleBase<N> tb = load_twiddle_base<SIGN, N>(tw, tid);
+  float2            a[Plan<N>::R0];
+#pragma unroll
+  for (int k = 0; k != Plan<N>::R0; ++k) {
+    uint32_t i = first_stage_index<N>(tid, k);
+    a[k]       = (i < N) ? in[i] : make_float2(0.f, 0.f);
+  }
+  auto store = [&](uint32_t i, float2 v) { out[i] = v; };
+  fft_from_registers<SIGN, N>(a, tb, lds, tw, tid, store);
 }
 
 template <int N>

@@ -345,3 +345,22 @@ def test_end_to_end_slot_batch(gpu_ctx, oracle):
         grid = oracle.pdsch_process(pdu, tbs[i], nof_ports, nof_subc)
         want = oracle.ofdm_slot(ofdm, grid, 0)
         assert rel_err(iq[i], want) < 1e-5
+
+
+def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
+    """The host-span entry points the srsRAN adaptors call (dft_processor::run, ofdm_slot_modulator::modulate)."""
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal(1024) + 1j * rng.standard_normal(1024)).astype(np.complex64)
+    out = np.zeros_like(x)
+    rc = gpu_ctx.lib.nrphy_dft_run_host(gpu_ctx.handle, 1024, 1, x.ctypes.data, out.ctypes.data)
+    assert rc == 0 and rel_err(out, oracle.dft(x, 1)) < 1e-5
+    assert gpu_ctx.lib.nrphy_dft_run_host(gpu_ctx.handle, 1000, 1, x.ctypes.data, out.ctypes.data) == abi.ERR_ARGUMENT
+    cfg = abi.OfdmConfig(1, 51, 2048, 0, 0.5, 3.6e9)
+    grid = (rng.standard_normal((2, 14, 51 * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    plan = lib.OfdmPlan(gpu_ctx, cfg, 2)
+    for slot in (0, 1):
+        n = lib.slot_size(cfg, slot)
+        iq = np.zeros((2, n), np.complex64)
+        assert gpu_ctx.lib.nrphy_ofdm_modulate_slot_host(plan.handle, grid.ctypes.data, slot, iq.ctypes.data) == 0
+        assert rel_err(iq, oracle.ofdm_slot(cfg, grid, slot)) < 1e-5
+    plan.close()

@@ -136,3 +136,18 @@ def test_slot_sharding_and_aggregation_gloo_world2():
     assert [r[1:3] for r in res] == [(0, 129), (129, 128)]
     for r in res:
         assert r[3] == 257 and r[4] == 257 * 245760 and abs(r[5] - 0.75) < 1e-9
+
+
+def test_adaptors_compile_against_reference_headers(tmp_path):
+    """The srsRAN-side adaptors (seams A, B, C) must compile against the reference's own interface headers."""
+    import subprocess
+    ref = "/root/reference/srsRAN-5G-ER"
+    if not os.path.isdir(ref):
+        pytest.skip("reference headers not available on this machine")
+    src = tmp_path / "check.cpp"
+    src.write_text('#include "mi355_nrphy_srsran.h"\nint main() { return 0; }\n')
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-w", "-I", os.path.join(backends.ROOT, "include"),
+           "-I", os.path.join(backends.PKG_DIR, "adaptors"), "-I", ref + "/include", "-I", ref + "/external/fmt/include",
+           "-I", ref + "/external", str(src)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
