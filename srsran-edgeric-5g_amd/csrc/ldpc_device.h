@@ -15,14 +15,22 @@ constexpr int LDPC_MAX_WPB   = 12;                      // words per Zc-bit bloc
 constexpr int LDPC_LIN_WORDS = (68 * 384) / 32 + 2;     // whole BG1 codeblock + read-ahead padding
 
 // Word j of block `base` (bit offset of a Zc-bit block) rotated by s: output bit t of the word is block bit
-// (s + 32j + t) mod Zc; bits at or beyond Zc are zero.  Needs 0 <= s < Zc and 32j < Zc.  One wrap at most because
-// a word never holds more than Zc valid bits.
+// (s + 32j + t) mod Zc; bits at or beyond Zc are zero.  Needs 0 <= s < Zc and 32j < Zc.
+// ALIGNED (Zc a multiple of 32, which covers every large lifting size): whole words, the wrap is a word index wrap.
+// Otherwise one wrap at most, because a word never holds more than Zc valid bits.
+template <bool ALIGNED>
 __device__ __forceinline__ uint32_t rot_word(const uint32_t* a, uint32_t base, uint32_t zc, uint32_t s, uint32_t j)
 {
+  uint32_t start = s + 32u * j;
+  start          = start >= zc ? start - zc : start;
+  if (ALIGNED) {
+    const uint32_t wpb = zc >> 5, bw = base >> 5;
+    const uint32_t w0 = start >> 5, sh = start & 31u;
+    const uint32_t w1 = (w0 + 1u == wpb) ? 0u : w0 + 1u;
+    return __funnelshift_l(a[bw + w1], a[bw + w0], sh);
+  }
   uint32_t n_valid = zc - 32u * j;
   n_valid          = n_valid > 32u ? 32u : n_valid;
-  uint32_t start   = s + 32u * j;
-  start            = start >= zc ? start - zc : start;
   uint32_t first   = zc - start;
   first            = first > n_valid ? n_valid : first;
   uint32_t v       = ext32(a, base + start) & topmask(first);
@@ -40,10 +48,11 @@ struct LdpcScratch {
 
 // Stores word j of a parity block at variable node `node` of lin.  Word-aligned blocks are plain stores; other
 // lifting sizes merge with LDS atomics because neighbouring lanes share words (the parity region is zeroed first).
+template <bool ALIGNED>
 __device__ __forceinline__ void put_block_word(uint32_t* lin, uint32_t node, uint32_t zc, uint32_t j, uint32_t v)
 {
   uint32_t pos = node * zc + 32u * j;
-  if ((zc & 31u) == 0) {
+  if (ALIGNED) {
     lin[pos >> 5] = v;
   } else {
     uint32_t n_valid = zc - 32u * j;
@@ -51,21 +60,30 @@ __device__ __forceinline__ void put_block_word(uint32_t* lin, uint32_t node, uin
   }
 }
 
+// XOR over the edges of check row m of the rotated blocks, word j.
+template <bool ALIGNED>
+__device__ __forceinline__ uint32_t row_word(const LiftedGraph* g, const uint32_t* lin, uint32_t zc, uint32_t m,
+                                             uint32_t j)
+{
+  uint32_t acc = 0;
+  for (uint32_t e = g->row_ptr[m]; e != g->row_ptr[m + 1]; ++e) {
+    uint32_t edge = g->edge[e];
+    acc ^= rot_word<ALIGNED>(lin, (edge >> 16) * zc, zc, edge & 0xFFFFu, j);
+  }
+  return acc;
+}
+
 // Computes parity blocks Kb .. Kb + nof_rows - 1 of the codeblock whose Kb systematic blocks are in lin.
 // lin words from ceil(Kb*Zc/32) on must be zero on entry.  All 64 lanes of the wave call this.
-__device__ inline void ldpc_encode_wave(const LiftedGraph* g, uint32_t kb, uint32_t zc, uint32_t nof_rows,
-                                        uint32_t* lin, LdpcScratch* sc, uint32_t lane)
+template <bool ALIGNED>
+__device__ inline void ldpc_encode_wave_impl(const LiftedGraph* g, uint32_t kb, uint32_t zc, uint32_t nof_rows,
+                                             uint32_t* lin, LdpcScratch* sc, uint32_t lane)
 {
   const uint32_t wpb = (zc + 31u) >> 5;
   // Core rows 0..3: XOR of the rotated systematic blocks (TS 38.212 Section 5.3.2, H restricted to columns < Kb).
   for (uint32_t item = lane; item < 4u * wpb; item += WAVE) {
     uint32_t m = item / wpb, j = item - m * wpb;
-    uint32_t acc = 0;
-    for (uint32_t e = g->row_ptr[m]; e != g->row_ptr[m + 1]; ++e) {
-      uint32_t edge = g->edge[e];
-      acc ^= rot_word(lin, (edge >> 16) * zc, zc, edge & 0xFFFFu, j);
-    }
-    sc->aux[m][j] = acc;
+    sc->aux[m][j] = row_word<ALIGNED>(g, lin, zc, m, j);
   }
   wave_sync();
   if (lane < wpb) {
@@ -80,20 +98,20 @@ __device__ inline void ldpc_encode_wave(const LiftedGraph* g, uint32_t kb, uint3
   uint32_t p0w = 0;
   if (lane < wpb) {
     uint32_t b = g->core_b;
-    p0w        = rot_word(sc->sum, 0, zc, b == 0 ? 0 : zc - b, lane);
+    p0w        = rot_word<ALIGNED>(sc->sum, 0, zc, b == 0 ? 0 : zc - b, lane);
     sc->p0[lane] = p0w;
   }
   wave_sync();
   if (lane < wpb) {
     // Row 0: aux0 + P^s0 p0 + p1 = 0.  Row 3: aux3 + P^s3 p0 + p3 = 0.  The core row without an edge in column Kb
     // closes the chain: BG1 row 2: aux2 + p2 + p3 = 0;  BG2 row 1: aux1 + p1 + p2 = 0.
-    uint32_t p1 = sc->aux[0][lane] ^ rot_word(sc->p0, 0, zc, g->core_s0, lane);
-    uint32_t p3 = sc->aux[3][lane] ^ rot_word(sc->p0, 0, zc, g->core_s3, lane);
+    uint32_t p1 = sc->aux[0][lane] ^ rot_word<ALIGNED>(sc->p0, 0, zc, g->core_s0, lane);
+    uint32_t p3 = sc->aux[3][lane] ^ rot_word<ALIGNED>(sc->p0, 0, zc, g->core_s3, lane);
     uint32_t p2 = (g->core_mid == 1) ? (sc->aux[2][lane] ^ p3) : (sc->aux[1][lane] ^ p1);
-    put_block_word(lin, kb + 0, zc, lane, p0w);
-    put_block_word(lin, kb + 1, zc, lane, p1);
-    put_block_word(lin, kb + 2, zc, lane, p2);
-    put_block_word(lin, kb + 3, zc, lane, p3);
+    put_block_word<ALIGNED>(lin, kb + 0, zc, lane, p0w);
+    put_block_word<ALIGNED>(lin, kb + 1, zc, lane, p1);
+    put_block_word<ALIGNED>(lin, kb + 2, zc, lane, p2);
+    put_block_word<ALIGNED>(lin, kb + 3, zc, lane, p3);
   }
   wave_sync();
   // Extension rows: the parity bit is the XOR of every other entry of its check row (columns < Kb + 4).
@@ -101,14 +119,19 @@ __device__ inline void ldpc_encode_wave(const LiftedGraph* g, uint32_t kb, uint3
   for (uint32_t item = lane; item < ext_items; item += WAVE) {
     uint32_t m = item / wpb, j = item - m * wpb;
     m += 4u;
-    uint32_t acc = 0;
-    for (uint32_t e = g->row_ptr[m]; e != g->row_ptr[m + 1]; ++e) {
-      uint32_t edge = g->edge[e];
-      acc ^= rot_word(lin, (edge >> 16) * zc, zc, edge & 0xFFFFu, j);
-    }
-    put_block_word(lin, kb + m, zc, j, acc);
+    put_block_word<ALIGNED>(lin, kb + m, zc, j, row_word<ALIGNED>(g, lin, zc, m, j));
   }
   wave_sync();
+}
+
+__device__ inline void ldpc_encode_wave(const LiftedGraph* g, uint32_t kb, uint32_t zc, uint32_t nof_rows,
+                                        uint32_t* lin, LdpcScratch* sc, uint32_t lane)
+{
+  if ((zc & 31u) == 0) { // wave-uniform
+    ldpc_encode_wave_impl<true>(g, kb, zc, nof_rows, lin, sc, lane);
+  } else {
+    ldpc_encode_wave_impl<false>(g, kb, zc, nof_rows, lin, sc, lane);
+  }
 }
 
 } // namespace nrphy

@@ -193,6 +193,19 @@ void build_gold_tables(GoldTables& t, std::vector<uint32_t>& x1_words)
     }
     t.crc24b_table[b] = r & (top - 1);
   }
+  // Modulation tables: d = (1-2b0)[2^(h-1) - (1-2b2)[2^(h-2) - ...]] on the even bits, same on the odd bits for
+  // the imaginary part (TS 38.211 Sections 5.1.3-5.1.6), h = Qm / 2.
+  for (unsigned q = 0; q != 4; ++q) {
+    const unsigned qm = 2 * (q + 1), h = q + 1;
+    for (unsigned idx = 0; idx != (1U << qm); ++idx) {
+      int re = 1 - 2 * (int)((idx >> 1) & 1U), im = 1 - 2 * (int)(idx & 1U);
+      for (unsigned lvl = 1; lvl < h; ++lvl) {
+        re = (1 - 2 * (int)((idx >> (2 * lvl + 1)) & 1U)) * ((1 << lvl) - re);
+        im = (1 - 2 * (int)((idx >> (2 * lvl)) & 1U)) * ((1 << lvl) - im);
+      }
+      t.qam_lut[q][idx] = make_float2((float)re, (float)im);
+    }
+  }
   // x1(n + 1600), MSB-first words: x1(n+31) = x1(n+3) ^ x1(n), x1(0) = 1.
   x1_words.assign(GOLD_X1_WORDS, 0);
   uint32_t x1 = 1;

@@ -43,6 +43,9 @@ struct GoldTables {
   uint32_t x2_head[32][32];
   uint32_t crc24b_pow32[CRC_POW_WORDS]; // x^(32 m) mod g_CRC24B(x): places a lane's partial CB-CRC
   uint32_t crc24b_table[256];           // byte table of CRC24B
+  // Modulation tables (TS 38.211 Section 5.1): qam_lut[Qm/2 - 1][index of Qm bits, first bit in the MSB] = the
+  // un-normalised odd-integer symbol of the reference's ci8 table, as floats (re, im).
+  float2 qam_lut[4][256];
 };
 
 // ---- PDSCH plan ---------------------------------------------------------------------------------------------

@@ -3,8 +3,9 @@
 //   tb_crc_kernel      transport-block CRC: every thread reduces a 4-byte-aligned chunk with a byte table, scales
 //                      its remainder by x^(8 * bytes after) (table built at plan time) and XORs it into the result
 //   codeblock_kernel   one wavefront per codeblock (or per 512-RE chunk of it): segmentation, CB-CRC, LDPC
-//                      base-graph expansion in LDS, rate matching + bit interleaving by index arithmetic, Gold
-//                      scrambling, QAM mapping, layer mapping, precoding and RE mapping straight into the grid
+//                      base-graph expansion in LDS, rate matching + bit interleaving as a word-level bit-matrix
+//                      transposition, Gold scrambling, QAM mapping through an LDS table, layer mapping, precoding
+//                      and RE mapping straight into the grid
 //   dmrs_kernel        PDSCH DM-RS generation, CDM, precoding and mapping, one wavefront per 32 PRBs of a symbol
 //   ldpc_encode_kernel the LDPC encoder alone (seam B / unit parity)
 //
@@ -87,9 +88,13 @@ hipError_t launch_tb_crc(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t 
 struct CbShared {
   uint32_t    lin[LDPC_LIN_WORDS];
   LdpcScratch ldpc;
-  uint32_t    crc_table[256];
-  uint32_t    gold[RE_CHUNK + 40]; // scrambling words of the chunk (+ misalignment, + read-ahead)
-  float       w[2 * NRPHY_MAX_PORTS * NRPHY_MAX_LAYERS]; // wideband precoding weights [port][layer] (re, im)
+  union {
+    uint32_t crc_table[256]; // CRC24B byte table while the codeblock is built ...
+    float2   qam[256];       // ... then the modulation table (index = Qm bits, value = ci8 symbol as floats)
+  } lut;
+  uint32_t gold[RE_CHUNK + 40]; // scrambling words of the chunk (+ misalignment, + read-ahead)
+  uint32_t symb[RE_CHUNK + 16]; // interleaver output: one byte per modulation symbol, Qm bits in the byte's MSBs
+  float    w[2 * NRPHY_MAX_PORTS * NRPHY_MAX_LAYERS]; // wideband precoding weights [port][layer] (re, im)
 };
 
 // Fills lin with the K bits of codeblock `cb` (payload, TB CRC + zero padding on the last codeblock, CB CRC, filler
@@ -120,7 +125,7 @@ __device__ inline void build_codeblock(const PduDev& pd, uint32_t cb, const uint
   if (pd.cb_crc_bits) {
 #pragma unroll
     for (int k = 0; k != 4; ++k) {
-      sh->crc_table[lane + WAVE * k] = tables->crc24b_table[lane + WAVE * k];
+      sh->lut.crc_table[lane + WAVE * k] = tables->crc24b_table[lane + WAVE * k];
     }
   }
   wave_sync();
@@ -149,7 +154,7 @@ __device__ inline void build_codeblock(const PduDev& pd, uint32_t cb, const uint
       } else {
         word = ext32(sh->lin, 32u * j - pad);
       }
-      reg = crc_update_word(reg, word, sh->crc_table, crc24b());
+      reg = crc_update_word(reg, word, sh->lut.crc_table, crc24b());
     }
     if (b < nw && reg != 0) {
       reg = crc_mulmod(reg, tables->crc24b_pow32[nw - b], crc24b());
@@ -191,9 +196,11 @@ __device__ __forceinline__ RmIndex rm_index_init(const PduDev& pd)
   return r;
 }
 
-// Circular-buffer position of selected bit t.  WRAP = false: the caller knows rank0 + t < n_valid.
+// 32 consecutive selected bits e_t .. e_(t+31), first bit in the MSB (bits beyond the codeblock's E are don't-care).
+// A run of selected bits is contiguous in lin until it meets the filler gap or the end of the circular buffer; the
+// common case is one funnel read, crossings are stitched piece by piece.  WRAP = false: rank0 + E <= n_valid.
 template <bool WRAP>
-__device__ __forceinline__ uint32_t rm_pos(const RmIndex& r, uint32_t t)
+__device__ __forceinline__ uint32_t rm_gather32(const RmIndex& r, const uint32_t* lin, uint32_t zc2, uint32_t t)
 {
   uint32_t u = r.rank0 + t;
   if (WRAP && u >= r.n_valid) {
@@ -205,30 +212,42 @@ __device__ __forceinline__ uint32_t rm_pos(const RmIndex& r, uint32_t t)
       u -= r.n_valid;
     }
   }
-  return u < r.fs ? u : u + r.flen;
+  uint32_t run = (u < r.fs) ? r.fs - u : r.n_valid - u; // selected bits until the next discontinuity
+  uint32_t out = ext32(lin, (u < r.fs ? u : u + r.flen) + zc2);
+  if (run >= 32u) {
+    return out;
+  }
+  out &= topmask(run);
+  uint32_t filled = run;
+  while (filled < 32u) {
+    u += run;
+    if (u >= r.n_valid) {
+      if (!WRAP) {
+        break; // past the end of the selection: the remaining bits are never used
+      }
+      u = 0;
+    }
+    run            = (u < r.fs) ? r.fs - u : r.n_valid - u;
+    run            = run > 32u - filled ? 32u - filled : run;
+    uint32_t piece = ext32(lin, (u < r.fs ? u : u + r.flen) + zc2);
+    out |= (piece & topmask(run)) >> filled;
+    filled += run;
+  }
+  return out;
 }
 
-// ================================================================================================================
-// Modulation mapper (TS 38.211 Section 5.1; reference: modulation_mapper_lut_impl.cpp:39-65): Qm bits (first bit
-// in the MSB of idx) -> un-normalised odd integers, as the reference's ci8 table.
-// ================================================================================================================
-template <int QM>
-__device__ __forceinline__ void qam_map(uint32_t idx, float& re, float& im)
+// 8x8 bit-matrix transposition of the 64-bit word (hi:lo), rows = bytes (most significant first), columns = bits
+// (most significant first): three rounds of masked swaps (Hacker's Delight 7-3), on 32-bit halves.
+__device__ __forceinline__ void transpose8x8(uint32_t& hi, uint32_t& lo)
 {
-  // Even bit positions (from the MSB) drive the real axis, odd positions the imaginary axis:
-  // d = (1-2b0)[2^(h-1) - (1-2b2)[2^(h-2) - ...]], evaluated from the innermost term outwards.
-  constexpr int h = QM / 2;
-  int           r = 1 - 2 * (int)((idx >> 1) & 1u);
-  int           q = 1 - 2 * (int)(idx & 1u);
-#pragma unroll
-  for (int lvl = 1; lvl < h; ++lvl) {
-    int br = (int)((idx >> (2 * lvl + 1)) & 1u);
-    int bq = (int)((idx >> (2 * lvl)) & 1u);
-    r      = (1 - 2 * br) * ((1 << lvl) - r);
-    q      = (1 - 2 * bq) * ((1 << lvl) - q);
-  }
-  re = (float)r;
-  im = (float)q;
+  hi = (hi & 0xAA55AA55u) | ((hi & 0x00AA00AAu) << 7) | ((hi >> 7) & 0x00AA00AAu);
+  lo = (lo & 0xAA55AA55u) | ((lo & 0x00AA00AAu) << 7) | ((lo >> 7) & 0x00AA00AAu);
+  hi = (hi & 0xCCCC3333u) | ((hi & 0x0000CCCCu) << 14) | ((hi >> 14) & 0x0000CCCCu);
+  lo = (lo & 0xCCCC3333u) | ((lo & 0x0000CCCCu) << 14) | ((lo >> 14) & 0x0000CCCCu);
+  uint32_t nhi = (hi & 0xF0F0F0F0u) | ((lo & 0xF0F0F0F0u) >> 4);
+  uint32_t nlo = (lo & 0x0F0F0F0Fu) | ((hi & 0x0F0F0F0Fu) << 4);
+  hi           = nhi;
+  lo           = nlo;
 }
 
 // x * w evaluated like the reference's SIMD precoder (channel_precoder_avx2.cpp:51-56):
@@ -241,6 +260,16 @@ __device__ __forceinline__ void cmul_ref(float xr, float xi, float wr, float wi,
   outi     = __fmaf_rn(xi, wr, t1);
 }
 
+// (re, im) -> cbf16 word, round to nearest even like to_bf16 (R/include/srsran/adt/bf16.h:39-56); v_cvt_pk_bf16_f32.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float  f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_cbf16(float re, float im)
+{
+  f32x2_t  v = {re, im};
+  bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<uint32_t*>(&b);
+}
+
 struct ChunkGeom {
   uint32_t E;      // rate-matched length of the codeblock
   uint32_t cw_cb;  // first codeword bit of the codeblock
@@ -248,121 +277,164 @@ struct ChunkGeom {
 };
 
 // ================================================================================================================
-// Output stage of the codeblock kernel for one (modulation order, layer count): rate matching, interleaving,
-// scrambling, modulation, layer mapping, precoding, RE mapping.  Compile-time QM and L unroll every inner loop.
+// Output stage of the codeblock kernel for one (modulation order, layer count).
+//
+// Phase A -- rate matching + bit interleaving (TS 38.212 Section 5.4.2.2) as a bit-matrix transposition: the
+//   interleaver writes E/Qm-bit rows and reads columns, so 32 consecutive modulation symbols are the columns of
+//   Qm row words.  A lane gathers the Qm row words of its 32 symbols and transposes them 8x8-block-wise into one
+//   byte per symbol (symbol bits in the byte's MSBs) -- 8x less work than extracting bit by bit.
+// Phase B -- per RE: scramble, QAM table lookup, layer mapping + precoding, bf16, coalesced stores.
 // ================================================================================================================
 template <int QM, int L, bool WRAP>
-__device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd, const CbWork& wk, const CbShared& sh,
+__device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd, const CbWork& wk, CbShared& sh,
                                           const ChunkGeom& g, uint32_t lane, uint32_t* __restrict__ d_grid,
                                           uint32_t* __restrict__ d_cw_rm, uint32_t* __restrict__ d_cw_scr)
 {
   constexpr uint32_t LQ    = QM * L;
-  const uint32_t     esym  = g.E / QM;           // rows of the bit interleaver
+  const uint32_t     esym  = g.E / QM; // rows of the bit interleaver have esym bits
   const uint32_t     zc2   = 2u * pd.zc;
   const RmIndex      rm    = rm_index_init(pd);
-  const uint32_t     re_cb = g.cw_cb / LQ;       // first RE of the codeblock within the PDU
-  const uint32_t     P     = pd.nof_ports;
-  const bool         one_prg = pd.nof_prg == 1;
-  const float*       wbase = p.weights + pd.weights_offset;
-  const size_t       grid_base = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
-  const uint64_t     cw_bit0 = pd.cw_bit_offset + g.cw_cb + (uint64_t)wk.re_begin * LQ;
 
-  bool any_table = false;
+  // ---- Phase A ----
+  {
+    const uint32_t s0   = wk.re_begin * L;             // first modulation symbol of the chunk (multiple of 32)
+    const uint32_t nblk = (wk.re_count * L + 31u) >> 5;
+    for (uint32_t blk = lane; blk < nblk; blk += WAVE) {
+      uint32_t row[8];
+#pragma unroll
+      for (int j = 0; j != 8; ++j) {
+        row[j] = (j < QM) ? rm_gather32<WRAP>(rm, sh.lin, zc2, (uint32_t)j * esym + s0 + 32u * blk) : 0u;
+      }
+#pragma unroll
+      for (int m = 0; m != 4; ++m) { // columns 8m .. 8m+7
+        const int sft = 24 - 8 * m;
+        uint32_t  hi  = (((row[0] >> sft) & 0xFFu) << 24) | (((row[1] >> sft) & 0xFFu) << 16) |
+                      (((row[2] >> sft) & 0xFFu) << 8) | ((row[3] >> sft) & 0xFFu);
+        uint32_t lo = (((row[4] >> sft) & 0xFFu) << 24) | (((row[5] >> sft) & 0xFFu) << 16) |
+                      (((row[6] >> sft) & 0xFFu) << 8) | ((row[7] >> sft) & 0xFFu);
+        transpose8x8(hi, lo);
+        sh.symb[8u * blk + 2u * m]      = hi; // symbols 8m .. 8m+3 of the block
+        sh.symb[8u * blk + 2u * m + 1u] = lo; // symbols 8m+4 .. 8m+7
+      }
+    }
+    if (lane < 8) {
+      sh.symb[8u * nblk + lane] = 0; // read-ahead padding
+    }
+    // Modulation table (the CRC table it shares LDS with is no longer needed).
+    for (uint32_t i = lane; i < (1u << QM); i += WAVE) {
+      sh.lut.qam[i] = p.gold->qam_lut[QM / 2 - 1][i];
+    }
+    wave_sync();
+  }
+
+  // ---- Phase B ----
+  const uint32_t re_cb   = g.cw_cb / LQ; // first RE of the codeblock within the PDU
+  const uint32_t P       = pd.nof_ports;
+  const bool     one_prg = pd.nof_prg == 1;
+  const float*   wbase   = p.weights + pd.weights_offset;
+  const size_t   grid_base = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
+  const uint64_t cw_bit0 = pd.cw_bit_offset + g.cw_cb + (uint64_t)wk.re_begin * LQ;
+  bool           any_table = false;
 #pragma unroll
   for (int l = 0; l != NRPHY_NSYMB; ++l) {
     any_table |= pd.sym_kind[l] == SYM_TABLE;
   }
 
-  for (uint32_t r = lane; r < wk.re_count; r += WAVE) {
-    const uint32_t re_in_cb = wk.re_begin + r;
-    const uint32_t sym0     = re_in_cb * L; // first modulation symbol of the RE within the codeblock
-    // Rate matching + bit interleaving: bit j of symbol s is selected bit j*esym + s; the L symbols of an RE are
-    // consecutive, so for each j one funnel read yields the bit of every layer unless the run crosses the filler
-    // gap or the end of the circular buffer.
-    uint32_t v = 0; // the RE's L*Qm codeword bits, first bit in the MSB
+  for (uint32_t r0 = 0; r0 < wk.re_count; r0 += WAVE) { // r0 is wave-uniform
+    const uint32_t r = r0 + lane;
+    // OFDM symbol of the first and last RE of this 64-lane group (scalar): almost always the same one.
+    const uint32_t re_first = re_cb + wk.re_begin + r0;
+    const uint32_t re_last  = re_first + ((wk.re_count - r0 < WAVE ? wk.re_count - r0 : WAVE) - 1u);
+    uint32_t       l_first = 0, l_last = 0;
 #pragma unroll
-    for (int j = 0; j != QM; ++j) {
-      const uint32_t t     = (uint32_t)j * esym + sym0;
-      const uint32_t first = rm_pos<WRAP>(rm, t);
-      uint32_t       bits;
-      if (L == 1 || rm_pos<WRAP>(rm, t + L - 1) == first + (L - 1)) {
-        bits = ext32(sh.lin, first + zc2);
-      } else {
-        bits = 0;
+    for (int l = 1; l != NRPHY_NSYMB; ++l) {
+      l_first += (re_first >= pd.sym_re_start[l]) ? 1u : 0u;
+      l_last += (re_last >= pd.sym_re_start[l]) ? 1u : 0u;
+    }
+    if (r >= wk.re_count) {
+      continue;
+    }
+    const uint32_t bytes = ext32(sh.symb, 8u * r * L);           // the RE's L symbol bytes, first in the MSB
+    const uint32_t gbits = ext32(sh.gold, g.gmis + r * LQ);      // its L*Qm scrambling bits, first in the MSB
+    uint32_t       idx[L];
+    uint32_t       v_rm = 0;
 #pragma unroll
-        for (int l = 0; l != L; ++l) {
-          uint32_t pl = rm_pos<WRAP>(rm, t + l) + zc2;
-          bits |= ((sh.lin[pl >> 5] >> (31u - (pl & 31u))) & 1u) << (31 - l);
-        }
-      }
-#pragma unroll
-      for (int l = 0; l != L; ++l) { // layer l's bit goes to position l*Qm + j of the RE's bit group
-        v |= ((bits >> (31 - l)) & 1u) << (31 - (l * QM + j));
-      }
+    for (int l = 0; l != L; ++l) {
+      const uint32_t raw = ((bytes >> (24 - 8 * l)) & 0xFFu) >> (8 - QM);
+      v_rm |= raw << (32 - (l + 1) * QM);
+      idx[l] = raw ^ ((gbits >> (32 - (l + 1) * QM)) & ((1u << QM) - 1u)); // scrambling, TS 38.211 Section 7.3.1.1
     }
     if (d_cw_rm) {
-      or_bits_global(d_cw_rm, cw_bit0 + (uint64_t)r * LQ, v, LQ);
+      or_bits_global(d_cw_rm, cw_bit0 + (uint64_t)r * LQ, v_rm, LQ);
     }
-    // Scrambling (TS 38.211 Section 7.3.1.1).
-    v ^= ext32(sh.gold, g.gmis + r * LQ) & topmask(LQ);
     if (d_cw_scr) {
-      or_bits_global(d_cw_scr, cw_bit0 + (uint64_t)r * LQ, v, LQ);
+      or_bits_global(d_cw_scr, cw_bit0 + (uint64_t)r * LQ, v_rm ^ (gbits & topmask(LQ)), LQ);
     }
     if (d_grid == nullptr) {
       continue;
     }
     // RE position: OFDM symbol from the per-symbol prefix counts, subcarrier from the symbol's pattern.
-    const uint32_t re_pdu = re_cb + re_in_cb;
-    uint32_t       l_sym = 0, start = 0, arg = pd.sym_arg[0];
+    const uint32_t re_pdu = re_first + lane;
+    uint32_t       l_sym, subc;
+    if (l_first == l_last) {
+      l_sym = l_first;
+      subc  = pd.sym_arg[l_first] + (re_pdu - pd.sym_re_start[l_first]);
+    } else {
+      uint32_t start = 0, arg = pd.sym_arg[0];
+      l_sym          = 0;
 #pragma unroll
-    for (int l = 1; l != NRPHY_NSYMB; ++l) {
-      bool ge = re_pdu >= pd.sym_re_start[l];
-      l_sym += ge ? 1u : 0u;
-      start = ge ? pd.sym_re_start[l] : start;
-      arg   = ge ? pd.sym_arg[l] : arg;
+      for (int l = 1; l != NRPHY_NSYMB; ++l) {
+        bool ge = re_pdu >= pd.sym_re_start[l];
+        l_sym += ge ? 1u : 0u;
+        start = ge ? pd.sym_re_start[l] : start;
+        arg   = ge ? pd.sym_arg[l] : arg;
+      }
+      subc = arg + (re_pdu - start);
     }
-    uint32_t subc = arg + (re_pdu - start);
     if (any_table && pd.sym_kind[l_sym] == SYM_TABLE) {
       subc = (uint32_t)p.re_table[subc];
     }
-    // Modulation + layer mapping + precoding (resource_grid_mapper_impl.cpp:279-437, channel_precoder_avx2.cpp:214-342).
-    float xr[L], xi[L];
+    // Modulation (table lookup) + layer mapping + precoding
+    // (resource_grid_mapper_impl.cpp:279-437, channel_precoder_avx2.cpp:214-342).
+    float2 x[L];
 #pragma unroll
     for (int l = 0; l != L; ++l) {
-      qam_map<QM>((v >> (32 - (l + 1) * QM)) & ((1u << QM) - 1u), xr[l], xi[l]);
+      x[l] = sh.lut.qam[idx[l]];
     }
     uint32_t* out = d_grid + grid_base + (size_t)l_sym * p.grid_nof_subc + subc;
+    // Two copies of the port loop on purpose: one pointer that may address LDS or global memory would be a generic
+    // pointer and every weight read a flat load.
     if (one_prg) {
-      // Wideband precoding (the common case): the weights sit in LDS, every lane reads the same words (broadcast).
+      // Wideband precoding (the common case): weights in LDS, every lane reads the same words (broadcast).
 #pragma unroll 1
       for (uint32_t port = 0; port != P; ++port) {
-        const float* w = &sh.w[2 * port * L];
-        float        accr, acci;
-        cmul_ref(xr[0], xi[0], w[0], w[1], accr, acci);
+        float accr, acci;
+        cmul_ref(x[0].x, x[0].y, sh.w[2 * port * L], sh.w[2 * port * L + 1], accr, acci);
 #pragma unroll
         for (int l = 1; l != L; ++l) {
           float pr, pi;
-          cmul_ref(xr[l], xi[l], w[2 * l], w[2 * l + 1], pr, pi);
+          cmul_ref(x[l].x, x[l].y, sh.w[2 * (port * L + l)], sh.w[2 * (port * L + l) + 1], pr, pi);
           accr = __fadd_rn(accr, pr);
           acci = __fadd_rn(acci, pi);
         }
-        out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = to_bf16_bits(accr) | (to_bf16_bits(acci) << 16);
+        out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = pack_cbf16(accr, acci);
       }
     } else {
       uint32_t prg = subc / pd.prg_size_subc;
       prg          = prg >= pd.nof_prg ? pd.nof_prg - 1 : prg;
       const float* w = wbase + 2u * prg * P * L;
+#pragma unroll 1
       for (uint32_t port = 0; port != P; ++port) {
         float accr, acci;
-        cmul_ref(xr[0], xi[0], w[2 * (port * L)], w[2 * (port * L) + 1], accr, acci);
+        cmul_ref(x[0].x, x[0].y, w[2 * port * L], w[2 * port * L + 1], accr, acci);
 #pragma unroll
         for (int l = 1; l != L; ++l) {
           float pr, pi;
-          cmul_ref(xr[l], xi[l], w[2 * (port * L + l)], w[2 * (port * L + l) + 1], pr, pi);
+          cmul_ref(x[l].x, x[l].y, w[2 * (port * L + l)], w[2 * (port * L + l) + 1], pr, pi);
           accr = __fadd_rn(accr, pr);
           acci = __fadd_rn(acci, pi);
         }
-        out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = to_bf16_bits(accr) | (to_bf16_bits(acci) << 16);
+        out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = pack_cbf16(accr, acci);
       }
     }
   }
@@ -370,7 +442,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd
 
 template <int QM, int L>
 __device__ __forceinline__ void map_chunk_select(const PdschLaunch& p, const PduDev& pd, const CbWork& wk,
-                                                 const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
+                                                 CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
                                                  uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
 {
   if (wrap) {
@@ -382,7 +454,7 @@ __device__ __forceinline__ void map_chunk_select(const PdschLaunch& p, const Pdu
 
 template <int QM>
 __device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, const PduDev& pd, const CbWork& wk,
-                                                 const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
+                                                 CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
                                                  uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
 {
   switch (pd.nof_layers) { // wave-uniform
@@ -529,7 +601,7 @@ __global__ __launch_bounds__(WAVE) void dmrs_kernel(PdschLaunch p, uint32_t* __r
           }
         }
         d_grid[grid_base + ((size_t)port * NRPHY_NSYMB + wk.symbol) * p.grid_nof_subc + subc] =
-            to_bf16_bits(accr) | (to_bf16_bits(acci) << 16);
+            pack_cbf16(accr, acci);
       }
     }
   }
