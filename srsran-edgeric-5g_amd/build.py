@@ -16,7 +16,10 @@ SOURCES = ["nrphy_host.cpp", "pdsch_kernels.hip", "ofdm_kernels.hip"]
 HEADERS = ["nrphy_internal.h", "bits_device.h", "ldpc_device.h", "nr_ldpc_bg.inc",
            os.path.join(ROOT, "include", "mi355_nrphy.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+# The PDSCH kernels define their arithmetic with explicit __fmul_rn/__fmaf_rn (bit-exact grid), so contraction is
+# off there; the FFT has a 1e-5 tolerance and profits from fused multiply-adds.
+CONTRACT = {"ofdm_kernels.hip": "-ffp-contract=fast"}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
@@ -36,7 +39,8 @@ def build(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + FLAGS + [CONTRACT.get(src, "-ffp-contract=off"), "-x", "hip", "-c", os.path.join(CSRC, src),
+               "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -264,6 +264,7 @@ struct nrphy_pdsch_plan {
   CrcWork*              d_crc_work = nullptr;
   uint32_t*             d_crc_pow = nullptr;
   uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0, n_crc_work = 0;
+  uint32_t              lds_lin_words = 0, lds_gold_words = 0, lds_symb_words = 0;
   std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs
   uint32_t              timed_runs = 0, max_timed_runs = 0;
 };
@@ -896,9 +897,16 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     for (unsigned cb = 0; cb != d.nof_codeblocks; ++cb) {
       const unsigned nre = ((cb < d.nof_short_segments) ? d.rm_length_short : d.rm_length_long) / lq;
       for (unsigned begin = 0; begin < nre; begin += RE_CHUNK) {
-        work.push_back({i, cb, begin, std::min<unsigned>(RE_CHUNK, nre - begin)});
+        const unsigned count = std::min<unsigned>(RE_CHUNK, nre - begin);
+        work.push_back({i, cb, begin, count});
+        // LDS the wave needs: scrambling words (+ misalignment, + 8 read-ahead), symbol bytes (32 per block + 8 words).
+        plan->lds_gold_words = std::max<uint32_t>(plan->lds_gold_words, ((31 + count * lq + 31) / 32 + 8 + 3) & ~3U);
+        plan->lds_symb_words = std::max<uint32_t>(plan->lds_symb_words,
+                                                  (((count * pdu.nof_layers + 31) / 32) * 8 + 8 + 3) & ~3U);
       }
     }
+    plan->lds_lin_words = std::max<uint32_t>(plan->lds_lin_words,
+                                             ((((kb + pd.nof_rows) * d.lifting_size + 31) / 32) + 2 + 3) & ~3U);
     plan->n_cb += d.nof_codeblocks;
     plan->cw_offset.push_back(cw_bits);
     cw_bits += (d.codeword_bits + 31U) & ~31ULL;
@@ -989,6 +997,9 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.n_dmrs_work    = plan->n_dmrs;
   p.grid_nof_ports = plan->grid_nof_ports;
   p.grid_nof_subc  = plan->grid_nof_subc;
+  p.lds_lin_words  = plan->lds_lin_words;
+  p.lds_gold_words = plan->lds_gold_words;
+  p.lds_symb_words = plan->lds_symb_words;
   const size_t cw_bytes = (size_t)(plan->cw_bits / 8);
   if (d_grid && zero_grids) {
     HIP_TRY(hipMemsetAsync(d_grid, 0,

@@ -144,6 +144,9 @@ struct PdschLaunch {
   uint32_t           n_dmrs_work;
   uint32_t           grid_nof_ports;
   uint32_t           grid_nof_subc;
+  uint32_t           lds_lin_words;  // dynamic LDS carve of the codeblock kernel (words, multiples of 4)
+  uint32_t           lds_gold_words;
+  uint32_t           lds_symb_words;
 };
 
 // Kernel launchers (defined in the .hip files).

@@ -85,16 +85,23 @@ hipError_t launch_tb_crc(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t 
 // ================================================================================================================
 // Codeblock construction in LDS (TS 38.212 Section 5.2.2; reference: ldpc_segmenter_impl.cpp:148-217).
 // ================================================================================================================
-struct CbShared {
-  uint32_t    lin[LDPC_LIN_WORDS];
+// LDS of one codeblock wavefront.  The bit arrays are sized per launch (dynamic LDS: the plan knows the largest
+// codeblock, scrambling run and symbol run it contains), which at the headline configuration keeps ~6 KB per wave
+// instead of ~10 KB and lets the CU hold 6 waves per SIMD.
+struct CbStatic {
   LdpcScratch ldpc;
   union {
     uint32_t crc_table[256]; // CRC24B byte table while the codeblock is built ...
     float2   qam[256];       // ... then the modulation table (index = Qm bits, value = ci8 symbol as floats)
   } lut;
-  uint32_t gold[RE_CHUNK + 40]; // scrambling words of the chunk (+ misalignment, + read-ahead)
-  uint32_t symb[RE_CHUNK + 16]; // interleaver output: one byte per modulation symbol, Qm bits in the byte's MSBs
-  float    w[2 * NRPHY_MAX_PORTS * NRPHY_MAX_LAYERS]; // wideband precoding weights [port][layer] (re, im)
+  float w[2 * NRPHY_MAX_PORTS * NRPHY_MAX_LAYERS]; // wideband precoding weights [port][layer] (re, im)
+};
+
+struct CbShared {
+  uint32_t* lin;  // codeblock bits, (Kb + rows) * Zc bits (+ read-ahead)
+  uint32_t* gold; // scrambling words of the chunk (+ misalignment, + read-ahead)
+  uint32_t* symb; // interleaver output: one byte per modulation symbol, Qm bits in the byte's MSBs
+  CbStatic* st;
 };
 
 // Fills lin with the K bits of codeblock `cb` (payload, TB CRC + zero padding on the last codeblock, CB CRC, filler
@@ -125,7 +132,7 @@ __device__ inline void build_codeblock(const PduDev& pd, uint32_t cb, const uint
   if (pd.cb_crc_bits) {
 #pragma unroll
     for (int k = 0; k != 4; ++k) {
-      sh->lut.crc_table[lane + WAVE * k] = tables->crc24b_table[lane + WAVE * k];
+      sh->st->lut.crc_table[lane + WAVE * k] = tables->crc24b_table[lane + WAVE * k];
     }
   }
   wave_sync();
@@ -154,7 +161,7 @@ __device__ inline void build_codeblock(const PduDev& pd, uint32_t cb, const uint
       } else {
         word = ext32(sh->lin, 32u * j - pad);
       }
-      reg = crc_update_word(reg, word, sh->lut.crc_table, crc24b());
+      reg = crc_update_word(reg, word, sh->st->lut.crc_table, crc24b());
     }
     if (b < nw && reg != 0) {
       reg = crc_mulmod(reg, tables->crc24b_pow32[nw - b], crc24b());
@@ -286,7 +293,7 @@ struct ChunkGeom {
 // Phase B -- per RE: scramble, QAM table lookup, layer mapping + precoding, bf16, coalesced stores.
 // ================================================================================================================
 template <int QM, int L, bool WRAP>
-__device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd, const CbWork& wk, CbShared& sh,
+__device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd, const CbWork& wk, const CbShared& sh,
                                           const ChunkGeom& g, uint32_t lane, uint32_t* __restrict__ d_grid,
                                           uint32_t* __restrict__ d_cw_rm, uint32_t* __restrict__ d_cw_scr)
 {
@@ -322,7 +329,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd
     }
     // Modulation table (the CRC table it shares LDS with is no longer needed).
     for (uint32_t i = lane; i < (1u << QM); i += WAVE) {
-      sh.lut.qam[i] = p.gold->qam_lut[QM / 2 - 1][i];
+      sh.st->lut.qam[i] = p.gold->qam_lut[QM / 2 - 1][i];
     }
     wave_sync();
   }
@@ -399,7 +406,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd
     float2 x[L];
 #pragma unroll
     for (int l = 0; l != L; ++l) {
-      x[l] = sh.lut.qam[idx[l]];
+      x[l] = sh.st->lut.qam[idx[l]];
     }
     uint32_t* out = d_grid + grid_base + (size_t)l_sym * p.grid_nof_subc + subc;
     // Two copies of the port loop on purpose: one pointer that may address LDS or global memory would be a generic
@@ -409,11 +416,11 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd
 #pragma unroll 1
       for (uint32_t port = 0; port != P; ++port) {
         float accr, acci;
-        cmul_ref(x[0].x, x[0].y, sh.w[2 * port * L], sh.w[2 * port * L + 1], accr, acci);
+        cmul_ref(x[0].x, x[0].y, sh.st->w[2 * port * L], sh.st->w[2 * port * L + 1], accr, acci);
 #pragma unroll
         for (int l = 1; l != L; ++l) {
           float pr, pi;
-          cmul_ref(x[l].x, x[l].y, sh.w[2 * (port * L + l)], sh.w[2 * (port * L + l) + 1], pr, pi);
+          cmul_ref(x[l].x, x[l].y, sh.st->w[2 * (port * L + l)], sh.st->w[2 * (port * L + l) + 1], pr, pi);
           accr = __fadd_rn(accr, pr);
           acci = __fadd_rn(acci, pi);
         }
@@ -442,7 +449,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd
 
 template <int QM, int L>
 __device__ __forceinline__ void map_chunk_select(const PdschLaunch& p, const PduDev& pd, const CbWork& wk,
-                                                 CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
+                                                 const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
                                                  uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
 {
   if (wrap) {
@@ -454,7 +461,7 @@ __device__ __forceinline__ void map_chunk_select(const PdschLaunch& p, const Pdu
 
 template <int QM>
 __device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, const PduDev& pd, const CbWork& wk,
-                                                 CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
+                                                 const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
                                                  uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
 {
   switch (pd.nof_layers) { // wave-uniform
@@ -480,7 +487,13 @@ __global__ __launch_bounds__(WAVE) void codeblock_kernel(PdschLaunch p, const ui
                                                          uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
                                                          uint32_t* __restrict__ d_cw_scr)
 {
-  __shared__ CbShared sh;
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+  __shared__ CbStatic st;
+  CbShared            sh;
+  sh.lin  = dyn_lds;
+  sh.gold = dyn_lds + p.lds_lin_words;
+  sh.symb = sh.gold + p.lds_gold_words;
+  sh.st   = &st;
   const uint32_t      lane = threadIdx.x;
   const CbWork        wk   = p.work[blockIdx.x];
   const PduDev&       pd   = p.pdus[wk.pdu];
@@ -492,7 +505,7 @@ __global__ __launch_bounds__(WAVE) void codeblock_kernel(PdschLaunch p, const ui
                   total_words, lane);
 
   // 2. LDPC encoding (only the parity rows that rate matching can reach).
-  ldpc_encode_wave(&p.graphs[pd.graph], kb, zc, pd.nof_rows, sh.lin, &sh.ldpc, lane);
+  ldpc_encode_wave(&p.graphs[pd.graph], kb, zc, pd.nof_rows, sh.lin, &st.ldpc, lane);
 
   // 3. This wave's slice of the codeword and its scrambling sequence.
   const uint32_t lq      = pd.nof_layers * pd.qm; // bits per RE
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(WAVE) void codeblock_kernel(PdschLaunch p, const ui
     sh.gold[gwords + lane] = 0;
   }
   if (lane < 2 * pd.nof_ports * pd.nof_layers) {
-    sh.w[lane] = p.weights[pd.weights_offset + lane];
+    st.w[lane] = p.weights[pd.weights_offset + lane];
   }
   wave_sync();
 
@@ -537,7 +550,9 @@ hipError_t launch_codeblocks(const PdschLaunch& p, const uint8_t* d_tb, uint32_t
   if (p.n_work == 0) {
     return hipSuccess;
   }
-  hipLaunchKernelGGL(codeblock_kernel, dim3(p.n_work), dim3(WAVE), 0, stream, p, d_tb, d_grid, d_cw_rm, d_cw_scr);
+  const size_t lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_gold_words + p.lds_symb_words);
+  hipLaunchKernelGGL(codeblock_kernel, dim3(p.n_work), dim3(WAVE), lds_bytes, stream, p, d_tb, d_grid, d_cw_rm,
+                     d_cw_scr);
   return hipGetLastError();
 }
 
