@@ -176,9 +176,17 @@ __device__ inline void gold_generate_wave(const GoldTables* gold, const uint32_t
 {
   uint32_t state  = c_init & 0x7FFFFFFFu;
   uint32_t offset = 1600u + 32u * first_word;
+  // Row `lane` of every jump matrix first (independent loads, one latency), then the dependent mat-vec chain.
+  uint32_t jump_row[GOLD_JUMP_BITS];
+#pragma unroll
+  for (int k = 0; k != GOLD_JUMP_BITS; ++k) {
+    jump_row[k] = gold->x2_jump[k][lane & 31u];
+  }
+#pragma unroll
   for (int k = 0; k != GOLD_JUMP_BITS; ++k) {
     if ((offset >> k) & 1u) { // wave-uniform
-      state = gold_matvec(gold->x2_jump[k], state, lane);
+      uint32_t bit = (lane < 31u) ? (__popc(jump_row[k] & state) & 1u) : 0u;
+      state        = (uint32_t)__ballot(bit != 0) & 0x7FFFFFFFu;
     }
   }
   // The first 31 words are linear in the state: lane w evaluates the 32 parities of word w.

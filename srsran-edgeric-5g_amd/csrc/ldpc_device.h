@@ -60,14 +60,30 @@ __device__ __forceinline__ void put_block_word(uint32_t* lin, uint32_t node, uin
   }
 }
 
+// The rows of the lifted graph a codeblock needs, staged in LDS: gbuf[0 .. LDPC_GRAPH_ROWPTR) = row_ptr,
+// gbuf[LDPC_GRAPH_ROWPTR ..) = packed edges.  (Read from global memory inside the edge loop, every edge would cost a
+// dependent L2 round trip.)
+constexpr uint32_t LDPC_GRAPH_ROWPTR = 48;
+
+__device__ __forceinline__ void stage_graph(const LiftedGraph* g, uint32_t nof_rows, uint32_t* gbuf, uint32_t lane)
+{
+  if (lane <= nof_rows) {
+    gbuf[lane] = g->row_ptr[lane];
+  }
+  const uint32_t nedges = g->row_ptr[nof_rows];
+  for (uint32_t e = lane; e < nedges; e += WAVE) {
+    gbuf[LDPC_GRAPH_ROWPTR + e] = g->edge[e];
+  }
+}
+
 // XOR over the edges of check row m of the rotated blocks, word j.
 template <bool ALIGNED>
-__device__ __forceinline__ uint32_t row_word(const LiftedGraph* g, const uint32_t* lin, uint32_t zc, uint32_t m,
+__device__ __forceinline__ uint32_t row_word(const uint32_t* gbuf, const uint32_t* lin, uint32_t zc, uint32_t m,
                                              uint32_t j)
 {
   uint32_t acc = 0;
-  for (uint32_t e = g->row_ptr[m]; e != g->row_ptr[m + 1]; ++e) {
-    uint32_t edge = g->edge[e];
+  for (uint32_t e = gbuf[m], end = gbuf[m + 1]; e != end; ++e) {
+    uint32_t edge = gbuf[LDPC_GRAPH_ROWPTR + e];
     acc ^= rot_word<ALIGNED>(lin, (edge >> 16) * zc, zc, edge & 0xFFFFu, j);
   }
   return acc;
@@ -76,14 +92,14 @@ __device__ __forceinline__ uint32_t row_word(const LiftedGraph* g, const uint32_
 // Computes parity blocks Kb .. Kb + nof_rows - 1 of the codeblock whose Kb systematic blocks are in lin.
 // lin words from ceil(Kb*Zc/32) on must be zero on entry.  All 64 lanes of the wave call this.
 template <bool ALIGNED>
-__device__ inline void ldpc_encode_wave_impl(const LiftedGraph* g, uint32_t kb, uint32_t zc, uint32_t nof_rows,
-                                             uint32_t* lin, LdpcScratch* sc, uint32_t lane)
+__device__ inline void ldpc_encode_wave_impl(const LiftedGraph* g, const uint32_t* gbuf, uint32_t kb, uint32_t zc,
+                                             uint32_t nof_rows, uint32_t* lin, LdpcScratch* sc, uint32_t lane)
 {
   const uint32_t wpb = (zc + 31u) >> 5;
   // Core rows 0..3: XOR of the rotated systematic blocks (TS 38.212 Section 5.3.2, H restricted to columns < Kb).
   for (uint32_t item = lane; item < 4u * wpb; item += WAVE) {
     uint32_t m = item / wpb, j = item - m * wpb;
-    sc->aux[m][j] = row_word<ALIGNED>(g, lin, zc, m, j);
+    sc->aux[m][j] = row_word<ALIGNED>(gbuf, lin, zc, m, j);
   }
   wave_sync();
   if (lane < wpb) {
@@ -119,18 +135,19 @@ __device__ inline void ldpc_encode_wave_impl(const LiftedGraph* g, uint32_t kb, 
   for (uint32_t item = lane; item < ext_items; item += WAVE) {
     uint32_t m = item / wpb, j = item - m * wpb;
     m += 4u;
-    put_block_word<ALIGNED>(lin, kb + m, zc, j, row_word<ALIGNED>(g, lin, zc, m, j));
+    put_block_word<ALIGNED>(lin, kb + m, zc, j, row_word<ALIGNED>(gbuf, lin, zc, m, j));
   }
   wave_sync();
 }
 
-__device__ inline void ldpc_encode_wave(const LiftedGraph* g, uint32_t kb, uint32_t zc, uint32_t nof_rows,
-                                        uint32_t* lin, LdpcScratch* sc, uint32_t lane)
+// gbuf: LDS, LDPC_GRAPH_ROWPTR + (edges of rows < nof_rows) words, already filled by stage_graph() and synchronised.
+__device__ inline void ldpc_encode_wave(const LiftedGraph* g, const uint32_t* gbuf, uint32_t kb, uint32_t zc,
+                                        uint32_t nof_rows, uint32_t* lin, LdpcScratch* sc, uint32_t lane)
 {
   if ((zc & 31u) == 0) { // wave-uniform
-    ldpc_encode_wave_impl<true>(g, kb, zc, nof_rows, lin, sc, lane);
+    ldpc_encode_wave_impl<true>(g, gbuf, kb, zc, nof_rows, lin, sc, lane);
   } else {
-    ldpc_encode_wave_impl<false>(g, kb, zc, nof_rows, lin, sc, lane);
+    ldpc_encode_wave_impl<false>(g, gbuf, kb, zc, nof_rows, lin, sc, lane);
   }
 }
 

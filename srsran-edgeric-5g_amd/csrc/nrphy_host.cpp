@@ -247,6 +247,7 @@ struct nrphy_ctx {
   GoldTables*  d_gold   = nullptr;
   uint32_t*    d_x1     = nullptr;
   float2*      d_twiddle[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // 128 .. 4096
+  std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
 };
 
 struct nrphy_pdsch_plan {
@@ -263,8 +264,13 @@ struct nrphy_pdsch_plan {
   uint32_t*             d_tb_crc = nullptr;
   CrcWork*              d_crc_work = nullptr;
   uint32_t*             d_crc_pow = nullptr;
+  ZeroWork*             d_zero_work = nullptr;
+  ZeroSeg*              d_zero_segs = nullptr;
+  uint32_t              n_zero_work = 0;
+  uint32_t              epoch = 0;          // selects the TB-CRC accumulator of the current run
+  bool                  dmrs_separate = false; // DM-RS must overwrite data RE: keep it in its own, later launch
   uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0, n_crc_work = 0;
-  uint32_t              lds_lin_words = 0, lds_gold_words = 0, lds_symb_words = 0;
+  uint32_t              lds_lin_words = 0, lds_gold_words = 0, lds_symb_words = 0, lds_graph_words = 0;
   std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs
   uint32_t              timed_runs = 0, max_timed_runs = 0;
 };
@@ -580,6 +586,7 @@ extern "C" int nrphy_create(nrphy_ctx_t** out, int device_id)
   GoldTables            gold;
   std::vector<uint32_t> x1;
   build_gold_tables(gold, x1);
+  ctx->graphs = graphs;
   if (upload(&ctx->d_graphs, graphs.data(), graphs.size() * sizeof(LiftedGraph)) != hipSuccess ||
       upload(&ctx->d_gold, &gold, sizeof(gold)) != hipSuccess ||
       upload(&ctx->d_x1, x1.data(), x1.size() * sizeof(uint32_t)) != hipSuccess) {
@@ -688,6 +695,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   std::vector<CbWork>   work;
   std::vector<DmrsWork> dmrs;
   std::vector<CrcWork>  crc_work;
+  std::vector<std::vector<uint32_t>> pdus_of_grid(nof_grids);
   std::vector<uint32_t> crc_pow;
   std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint32_t>> crc_pow_index; // (bytes, order) -> (offset, chunk)
   std::vector<float>    weights;
@@ -838,14 +846,18 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     }
     pd.first_prb = (uint32_t)mask_lowest(pdu.prb_mask);
     pd.end_prb   = (uint32_t)mask_highest(pdu.prb_mask) + 1;
+    if (pdu.nof_cdm_groups_without_data < (pdu.nof_layers + 1) / 2) {
+      plan->dmrs_separate = true; // data is mapped on RE that also carry DM-RS: the reference lets DM-RS win
+    }
+    pdus_of_grid[g].push_back(i);
     // TB-CRC work: ~64 bytes per thread; the per-thread factors x^(8 * bytes after the chunk) are shared by every
     // PDU with the same transport block size.
     {
       const uint32_t n = pdu.tb_size_bytes, order = d.nof_tb_crc_bits;
       auto           it = crc_pow_index.find({n, order});
       if (it == crc_pow_index.end()) {
-        const uint32_t threads = divide_ceil(divide_ceil(n, 64), 256) * 256;
-        const uint32_t chunk   = (divide_ceil(n, threads) + 3U) & ~3U;
+        const uint32_t threads = divide_ceil(divide_ceil(n, TB_CRC_CHUNK_BYTES), 256) * 256;
+        const uint32_t chunk   = TB_CRC_CHUNK_BYTES;
         const uint32_t poly = (order == 16) ? 0x11021U : 0x1864CFBU, top = 1U << order;
         auto mulmod = [&](uint32_t a, uint32_t b) {
           uint32_t r = 0;
@@ -887,7 +899,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
         it = crc_pow_index.insert({{n, order}, {offset, chunk}}).first;
       }
       const uint32_t offset = it->second.first, chunk = it->second.second;
-      const uint32_t threads = divide_ceil(divide_ceil(n, 64), 256) * 256;
+      const uint32_t threads = divide_ceil(divide_ceil(n, TB_CRC_CHUNK_BYTES), 256) * 256;
       for (uint32_t t0 = 0; t0 < threads && t0 * chunk < n; t0 += 256) {
         crc_work.push_back({i, t0, chunk, offset});
       }
@@ -907,6 +919,8 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     }
     plan->lds_lin_words = std::max<uint32_t>(plan->lds_lin_words,
                                              ((((kb + pd.nof_rows) * d.lifting_size + 31) / 32) + 2 + 3) & ~3U);
+    plan->lds_graph_words = std::max<uint32_t>(
+        plan->lds_graph_words, (48U + ctx->graphs[pd.graph].row_ptr[std::min<uint32_t>(pd.nof_rows, MAX_BG_ROWS)] + 3U) & ~3U);
     plan->n_cb += d.nof_codeblocks;
     plan->cw_offset.push_back(cw_bits);
     cw_bits += (d.codeword_bits + 31U) & ~31ULL;
@@ -916,6 +930,71 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     delete plan;
     return status;
   }
+  // Zero-fill work: per (grid, port) the runs of subcarriers no PDU maps (data or DM-RS).
+  std::vector<ZeroWork> zero_work;
+  std::vector<ZeroSeg>  zero_segs;
+  {
+    std::map<std::vector<uint64_t>, std::pair<uint32_t, uint32_t>> seen; // segment list -> (begin, count)
+    std::vector<uint8_t>  cov((size_t)NRPHY_NSYMB * grid_nof_subc);
+    std::vector<uint64_t> key;
+    for (uint32_t g = 0; g != nof_grids; ++g) {
+      for (uint32_t port = 0; port != grid_nof_ports; ++port) {
+        std::fill(cov.begin(), cov.end(), 0);
+        for (uint32_t i : pdus_of_grid[g]) {
+          const nrphy_pdsch_pdu_t& pdu = pdus[i];
+          if (port >= pdu.nof_ports) {
+            continue;
+          }
+          for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+            uint8_t* row = &cov[(size_t)l * grid_nof_subc];
+            data_re_mask(pdu, l, mask);
+            for (unsigned k = 0; k != grid_nof_subc; ++k) {
+              row[k] |= mask[k];
+            }
+            if ((pdu.dmrs_symbol_mask >> l) & 1U) {
+              const unsigned groups = (pdu.nof_layers + 1) / 2;
+              for (unsigned prb = 0; 12 * prb < grid_nof_subc; ++prb) {
+                if (mask_test(pdu.prb_mask, prb)) {
+                  for (unsigned k = 0; k != 12; ++k) {
+                    row[12 * prb + k] |= (k % 2) < groups;
+                  }
+                }
+              }
+            }
+          }
+        }
+        key.clear();
+        for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+          const uint8_t* row = &cov[(size_t)l * grid_nof_subc];
+          unsigned       k   = 0;
+          while (k < grid_nof_subc) {
+            if (row[k]) {
+              ++k;
+              continue;
+            }
+            unsigned k0 = k;
+            while (k < grid_nof_subc && !row[k]) {
+              ++k;
+            }
+            key.push_back(((uint64_t)l << 32) | ((uint64_t)k0 << 16) | (k - k0));
+          }
+        }
+        if (key.empty()) {
+          continue;
+        }
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+          const uint32_t begin = (uint32_t)zero_segs.size();
+          for (uint64_t v : key) {
+            zero_segs.push_back({(uint16_t)(v >> 32), (uint16_t)((v >> 16) & 0xFFFF), (uint16_t)(v & 0xFFFF), 0});
+          }
+          it = seen.insert({key, {begin, (uint32_t)key.size()}}).first;
+        }
+        zero_work.push_back({g, port, it->second.first, it->second.second});
+      }
+    }
+  }
+  plan->n_zero_work = (uint32_t)zero_work.size();
   plan->cw_bits = cw_bits;
   plan->n_work  = (uint32_t)work.size();
   plan->n_dmrs  = (uint32_t)dmrs.size();
@@ -927,10 +1006,15 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
       upload(&plan->d_dmrs, dmrs.data(), dmrs.size() * sizeof(DmrsWork)) != hipSuccess ||
       upload(&plan->d_weights, weights.data(), weights.size() * sizeof(float)) != hipSuccess ||
       upload(&plan->d_re_table, re_table.data(), re_table.size() * sizeof(uint16_t)) != hipSuccess ||
-      hipMalloc((void**)&plan->d_tb_crc, sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size())) != hipSuccess) {
+      upload(&plan->d_zero_work, zero_work.data(), zero_work.size() * sizeof(ZeroWork)) != hipSuccess ||
+      upload(&plan->d_zero_segs, zero_segs.data(), zero_segs.size() * sizeof(ZeroSeg)) != hipSuccess ||
+      hipMalloc((void**)&plan->d_tb_crc, 2 * sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size())) != hipSuccess ||
+      hipMemset(plan->d_tb_crc, 0, 2 * sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size())) != hipSuccess) {
     nrphy_pdsch_plan_destroy(plan);
     return NRPHY_ERR_DEVICE;
   }
+  // The dynamic LDS of the codeblock launch also serves the DM-RS waves it may carry.
+  plan->lds_lin_words = std::max<uint32_t>(plan->lds_lin_words, 64);
   *out = plan;
   return NRPHY_OK;
 }
@@ -949,6 +1033,8 @@ extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
   (void)hipFree(plan->d_tb_crc);
   (void)hipFree(plan->d_crc_work);
   (void)hipFree(plan->d_crc_pow);
+  (void)hipFree(plan->d_zero_work);
+  (void)hipFree(plan->d_zero_segs);
   for (hipEvent_t e : plan->events) {
     (void)hipEventDestroy(e);
   }
@@ -991,7 +1077,16 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.graphs         = ctx->d_graphs;
   p.gold           = ctx->d_gold;
   p.x1_words       = ctx->d_x1;
-  p.tb_crc         = plan->d_tb_crc;
+  // Two TB-CRC accumulators alternate between runs: this run XORs into one, its codeblock kernel clears the other.
+  const size_t   n_acc = std::max<size_t>(1, plan->pdus.size());
+  p.tb_crc             = plan->d_tb_crc + (plan->epoch & 1U) * n_acc;
+  p.tb_crc_next        = plan->d_tb_crc + ((plan->epoch + 1U) & 1U) * n_acc;
+  plan->epoch++;
+  const bool merge_dmrs = d_grid != nullptr && !plan->dmrs_separate;
+  p.zero_work          = plan->d_zero_work;
+  p.zero_segs          = plan->d_zero_segs;
+  p.n_zero_work        = (d_grid != nullptr && zero_grids) ? plan->n_zero_work : 0;
+  p.n_dmrs_in_launch   = merge_dmrs ? plan->n_dmrs : 0;
   p.n_pdu          = (uint32_t)plan->pdus.size();
   p.n_work         = plan->n_work;
   p.n_dmrs_work    = plan->n_dmrs;
@@ -1000,12 +1095,8 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.lds_lin_words  = plan->lds_lin_words;
   p.lds_gold_words = plan->lds_gold_words;
   p.lds_symb_words = plan->lds_symb_words;
+  p.lds_graph_words = plan->lds_graph_words;
   const size_t cw_bytes = (size_t)(plan->cw_bits / 8);
-  if (d_grid && zero_grids) {
-    HIP_TRY(hipMemsetAsync(d_grid, 0,
-                           (size_t)plan->nof_grids * plan->grid_nof_ports * NRPHY_NSYMB * plan->grid_nof_subc * 4, s));
-  }
-  HIP_TRY(hipMemsetAsync(plan->d_tb_crc, 0, sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size()), s));
   if (d_cw_rm) {
     HIP_TRY(hipMemsetAsync(d_cw_rm, 0, cw_bytes, s));
   }
@@ -1025,8 +1116,8 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   if (ev) {
     HIP_TRY(hipEventRecord(ev[2], s));
   }
-  if (d_grid) {
-    // After the data: with nof_cdm_groups_without_data == 0 the reference lets DM-RS overwrite data RE.
+  if (d_grid && !merge_dmrs) {
+    // After the data: when data RE share a CDM group with DM-RS the reference lets DM-RS overwrite them.
     HIP_TRY(launch_dmrs(p, (uint32_t*)d_grid, s));
   }
   if (ev) {

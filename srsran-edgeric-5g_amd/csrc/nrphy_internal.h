@@ -109,6 +109,7 @@ struct CbWork {
 
 // One workgroup of the DM-RS kernel: OFDM symbol `symbol` of PDU `pdu`.
 constexpr int DMRS_PRB_CHUNK = 32; // PRBs per DM-RS wavefront
+constexpr uint32_t TB_CRC_CHUNK_BYTES = 64; // transport-block bytes per TB-CRC thread (upper bound)
 
 struct DmrsWork {
   uint32_t pdu;
@@ -126,7 +127,28 @@ struct CrcWork {
   uint32_t pow_offset; // into the plan's crc_pow table
 };
 
+// Grid words no PDU of the plan maps must read as zero (resource_grid::set_all_zero in the reference).  Instead of
+// clearing whole grids and overwriting most of them, the plan lists the uncovered runs and a few waves of the
+// codeblock launch write zeros there: every grid word is written exactly once per run.
+struct ZeroSeg {
+  uint16_t symbol;
+  uint16_t k0;
+  uint16_t count;
+  uint16_t pad_;
+};
+struct ZeroWork {
+  uint32_t grid;
+  uint32_t port;
+  uint32_t seg_begin;
+  uint32_t seg_count;
+};
+
 struct PdschLaunch {
+  const ZeroWork*    zero_work;
+  const ZeroSeg*     zero_segs;
+  uint32_t           n_zero_work;     // zero-fill waves appended to the codeblock launch (0: caller cleared the grids)
+  uint32_t           n_dmrs_in_launch; // DM-RS waves appended to the codeblock launch (0: separate launch)
+  uint32_t*          tb_crc_next;     // the other TB-CRC accumulator, cleared for the next run
   const PduDev*      pdus;
   const CbWork*      work;
   const DmrsWork*    dmrs_work;
@@ -147,6 +169,7 @@ struct PdschLaunch {
   uint32_t           lds_lin_words;  // dynamic LDS carve of the codeblock kernel (words, multiples of 4)
   uint32_t           lds_gold_words;
   uint32_t           lds_symb_words;
+  uint32_t           lds_graph_words;
 };
 
 // Kernel launchers (defined in the .hip files).

@@ -20,12 +20,16 @@ namespace nrphy {
 // CRC(M) = sum_t CRC(chunk_t) * x^(8 * bytes after chunk_t) mod g(x): the chunks are independent, the combine is an
 // XOR, so a transport block is spread over as many 256-thread workgroups as it takes to give each thread ~64 bytes.
 // ================================================================================================================
-constexpr int TB_CRC_THREADS = 256;
+constexpr int      TB_CRC_THREADS     = 256;
+constexpr uint32_t TB_CRC_CHUNK_WORDS = TB_CRC_CHUNK_BYTES / 4; // words per thread (the plan uses exactly this chunk)
 
 __global__ __launch_bounds__(TB_CRC_THREADS) void tb_crc_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
 {
   __shared__ uint32_t table[256];
   __shared__ uint32_t partial[TB_CRC_THREADS / WAVE];
+  // The workgroup's 16 KiB of the transport block, staged with coalesced loads; thread t then walks words
+  // [17 t, 17 t + 16): the odd stride keeps the 64 lanes on different banks.
+  __shared__ uint32_t stage[TB_CRC_THREADS * (TB_CRC_CHUNK_WORDS + 1)];
 
   const CrcWork   wk  = p.crc_work[blockIdx.x];
   const PduDev&   pd  = p.pdus[wk.pdu];
@@ -35,21 +39,31 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void tb_crc_kernel(PdschLaunch p, c
   const uint32_t* w   = reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset);
 
   table[tid] = crc_table_entry(tid, c);
+  const uint32_t word0  = wk.thread_begin * TB_CRC_CHUNK_WORDS; // first word of the workgroup's region
+  const uint32_t nwords = (n + 3u) >> 2;                        // words holding transport block bytes
+#pragma unroll
+  for (uint32_t it = 0; it != TB_CRC_CHUNK_WORDS; ++it) {
+    const uint32_t i  = it * TB_CRC_THREADS + tid; // word within the region: consecutive lanes, consecutive words
+    const uint32_t gw = word0 + i;
+    const uint32_t v  = (gw < nwords) ? be_word(w, gw) : 0u;
+    stage[(i / TB_CRC_CHUNK_WORDS) * (TB_CRC_CHUNK_WORDS + 1) + (i % TB_CRC_CHUNK_WORDS)] = v;
+  }
   __syncthreads();
 
   const uint32_t g     = wk.thread_begin + tid;
-  const uint32_t begin = g * wk.chunk;
+  const uint32_t begin = g * TB_CRC_CHUNK_BYTES;
   uint32_t       reg   = 0;
   if (begin < n) {
-    const uint32_t len   = (n - begin < wk.chunk) ? n - begin : wk.chunk;
-    const uint32_t nfull = len >> 2;
+    const uint32_t  len  = (n - begin < TB_CRC_CHUNK_BYTES) ? n - begin : TB_CRC_CHUNK_BYTES;
+    const uint32_t* mine = &stage[tid * (TB_CRC_CHUNK_WORDS + 1)];
+    const uint32_t  nfull = len >> 2;
     for (uint32_t i = 0; i != nfull; ++i) {
-      reg = crc_update_word(reg, be_word(w, (begin >> 2) + i), table, c);
+      reg = crc_update_word(reg, mine[i], table, c);
     }
     const uint32_t tail = len & 3u;
     if (tail) {
       // The last word is only partially inside the transport block: shift its bytes in one by one.
-      const uint32_t word = be_word(w, (begin >> 2) + nfull);
+      const uint32_t word = mine[nfull];
       const uint32_t mask = (1u << c.order) - 1u, sh = c.order - 8u;
       for (uint32_t k = 0; k != tail; ++k) {
         uint32_t byte = (word >> (24 - 8 * k)) & 0xFFu;
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void tb_crc_kernel(PdschLaunch p, c
     for (int i = 0; i != TB_CRC_THREADS / WAVE; ++i) {
       crc ^= partial[i];
     }
-    atomicXor(&p.tb_crc[wk.pdu], crc); // tb_crc is zeroed by the run before this kernel
+    atomicXor(&p.tb_crc[wk.pdu], crc); // the accumulator was cleared by the previous run (or at plan creation)
   }
 }
 
@@ -101,6 +115,7 @@ struct CbShared {
   uint32_t* lin;  // codeblock bits, (Kb + rows) * Zc bits (+ read-ahead)
   uint32_t* gold; // scrambling words of the chunk (+ misalignment, + read-ahead)
   uint32_t* symb; // interleaver output: one byte per modulation symbol, Qm bits in the byte's MSBs
+  uint32_t* graph; // row pointers + edges of the lifted graph rows this codeblock needs
   CbStatic* st;
 };
 
@@ -481,92 +496,16 @@ __device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, const Pdu
 }
 
 // ================================================================================================================
-// The codeblock kernel.
-// ================================================================================================================
-__global__ __launch_bounds__(WAVE) void codeblock_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
-                                                         uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
-                                                         uint32_t* __restrict__ d_cw_scr)
-{
-  extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-  __shared__ CbStatic st;
-  CbShared            sh;
-  sh.lin  = dyn_lds;
-  sh.gold = dyn_lds + p.lds_lin_words;
-  sh.symb = sh.gold + p.lds_gold_words;
-  sh.st   = &st;
-  const uint32_t      lane = threadIdx.x;
-  const CbWork        wk   = p.work[blockIdx.x];
-  const PduDev&       pd   = p.pdus[wk.pdu];
-  const uint32_t      zc = pd.zc, kb = pd.kb;
-
-  // 1. Segmentation + CRC attachment.
-  const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
-  build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), &p.tb_crc[wk.pdu], p.gold, &sh,
-                  total_words, lane);
-
-  // 2. LDPC encoding (only the parity rows that rate matching can reach).
-  ldpc_encode_wave(&p.graphs[pd.graph], kb, zc, pd.nof_rows, sh.lin, &st.ldpc, lane);
-
-  // 3. This wave's slice of the codeword and its scrambling sequence.
-  const uint32_t lq      = pd.nof_layers * pd.qm; // bits per RE
-  const bool     is_long = wk.cb >= pd.n_short;
-  ChunkGeom      g;
-  g.E     = is_long ? pd.e_long : pd.e_short;
-  g.cw_cb = is_long ? pd.n_short * pd.e_short + (wk.cb - pd.n_short) * pd.e_long : wk.cb * pd.e_short;
-  const uint32_t bit0   = g.cw_cb + wk.re_begin * lq; // first codeword bit of the chunk
-  g.gmis                = bit0 & 31u;
-  const uint32_t gwords = (g.gmis + wk.re_count * lq + 31u) >> 5;
-  gold_generate_wave(p.gold, p.x1_words, pd.c_init, bit0 >> 5, gwords, sh.gold, lane);
-  if (lane < 8) {
-    sh.gold[gwords + lane] = 0;
-  }
-  if (lane < 2 * pd.nof_ports * pd.nof_layers) {
-    st.w[lane] = p.weights[pd.weights_offset + lane];
-  }
-  wave_sync();
-
-  // 4. Rate matching ... RE mapping, specialised per (Qm, layers); `wrap` = the selection wraps around Ncb.
-  const RmIndex rm   = rm_index_init(pd);
-  const bool    wrap = rm.rank0 + g.E > rm.n_valid;
-  switch (pd.qm) { // wave-uniform
-    case 2:
-      map_chunk_layers<2>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
-      break;
-    case 4:
-      map_chunk_layers<4>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
-      break;
-    case 6:
-      map_chunk_layers<6>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
-      break;
-    default:
-      map_chunk_layers<8>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
-      break;
-  }
-}
-
-hipError_t launch_codeblocks(const PdschLaunch& p, const uint8_t* d_tb, uint32_t* d_grid, uint32_t* d_cw_rm,
-                             uint32_t* d_cw_scr, hipStream_t stream)
-{
-  if (p.n_work == 0) {
-    return hipSuccess;
-  }
-  const size_t lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_gold_words + p.lds_symb_words);
-  hipLaunchKernelGGL(codeblock_kernel, dim3(p.n_work), dim3(WAVE), lds_bytes, stream, p, d_tb, d_grid, d_cw_rm,
-                     d_cw_scr);
-  return hipGetLastError();
-}
-
-// ================================================================================================================
 // DM-RS for PDSCH (TS 38.211 Section 7.4.1.1; reference: dmrs_pdsch_processor_impl.cpp:84-262, dmrs_helper.h:44-109,
 // resource_grid_mapper_impl.cpp:47-133).  One wavefront per (PDU, DM-RS symbol, 32-PRB chunk).
 // ================================================================================================================
 constexpr int DMRS_GOLD_WORDS = (DMRS_PRB_CHUNK * 12) / 32 + 8;
 
-__global__ __launch_bounds__(WAVE) void dmrs_kernel(PdschLaunch p, uint32_t* __restrict__ d_grid)
+// gold: LDS scratch of at least DMRS_GOLD_WORDS words.
+__device__ __forceinline__ void dmrs_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid,
+                                 uint32_t* gold, uint32_t lane)
 {
-  __shared__ uint32_t gold[DMRS_GOLD_WORDS];
-  const uint32_t      lane = threadIdx.x;
-  const DmrsWork      wk   = p.dmrs_work[blockIdx.x];
+  const DmrsWork      wk   = p.dmrs_work[item_index];
   const PduDev&       pd   = p.pdus[wk.pdu];
   const uint32_t      L = pd.nof_layers, P = pd.nof_ports;
 
@@ -622,6 +561,121 @@ __global__ __launch_bounds__(WAVE) void dmrs_kernel(PdschLaunch p, uint32_t* __r
   }
 }
 
+// Writes zeros to the grid words of one (grid, port) that no PDU of the plan maps.
+__device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid, uint32_t lane)
+{
+  const ZeroWork wk   = p.zero_work[item_index];
+  uint32_t*      base = d_grid + ((size_t)wk.grid * p.grid_nof_ports + wk.port) * NRPHY_NSYMB * p.grid_nof_subc;
+  for (uint32_t i = 0; i != wk.seg_count; ++i) {
+    const ZeroSeg sg  = p.zero_segs[wk.seg_begin + i];
+    uint32_t*     row = base + (size_t)sg.symbol * p.grid_nof_subc + sg.k0;
+    for (uint32_t k = lane; k < sg.count; k += WAVE) {
+      row[k] = 0u;
+    }
+  }
+}
+
+// ================================================================================================================
+// The codeblock kernel.  Blocks [0, n_work) build codeblocks; the launch may carry two more kinds of wave behind
+// them so that their short, latency-bound work overlaps the codeblock waves instead of paying for own launches:
+// DM-RS waves and zero-fill waves for the grid words nobody maps.
+// ================================================================================================================
+
+__global__ __launch_bounds__(WAVE) void codeblock_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
+                                                         uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
+                                                         uint32_t* __restrict__ d_cw_scr)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+  __shared__ CbStatic st;
+  CbShared            sh;
+  sh.lin  = dyn_lds;
+  sh.gold = dyn_lds + p.lds_lin_words;
+  sh.symb  = sh.gold + p.lds_gold_words;
+  sh.graph = sh.symb + p.lds_symb_words;
+  sh.st    = &st;
+  const uint32_t      lane = threadIdx.x;
+  if (blockIdx.x >= p.n_work) { // wave-uniform
+    const uint32_t extra = blockIdx.x - p.n_work;
+    if (extra < p.n_dmrs_in_launch) {
+      dmrs_wave(p, extra, d_grid, dyn_lds, lane);
+    } else {
+      zero_wave(p, extra - p.n_dmrs_in_launch, d_grid, lane);
+    }
+    return;
+  }
+  // Clear the other TB-CRC accumulator for the next run (this run reads p.tb_crc only).
+  if (blockIdx.x * WAVE < p.n_pdu && blockIdx.x * WAVE + lane < p.n_pdu) {
+    p.tb_crc_next[blockIdx.x * WAVE + lane] = 0u;
+  }
+  const CbWork        wk   = p.work[blockIdx.x];
+  const PduDev&       pd   = p.pdus[wk.pdu];
+  const uint32_t      zc = pd.zc, kb = pd.kb;
+
+  // 1. Segmentation + CRC attachment (the graph rows ride along: their loads overlap the transport block's).
+  stage_graph(&p.graphs[pd.graph], pd.nof_rows, sh.graph, lane);
+  const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
+  build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), &p.tb_crc[wk.pdu], p.gold, &sh,
+                  total_words, lane);
+
+  // 2. LDPC encoding (only the parity rows that rate matching can reach).
+  ldpc_encode_wave(&p.graphs[pd.graph], sh.graph, kb, zc, pd.nof_rows, sh.lin, &st.ldpc, lane);
+
+  // 3. This wave's slice of the codeword and its scrambling sequence.
+  const uint32_t lq      = pd.nof_layers * pd.qm; // bits per RE
+  const bool     is_long = wk.cb >= pd.n_short;
+  ChunkGeom      g;
+  g.E     = is_long ? pd.e_long : pd.e_short;
+  g.cw_cb = is_long ? pd.n_short * pd.e_short + (wk.cb - pd.n_short) * pd.e_long : wk.cb * pd.e_short;
+  const uint32_t bit0   = g.cw_cb + wk.re_begin * lq; // first codeword bit of the chunk
+  g.gmis                = bit0 & 31u;
+  const uint32_t gwords = (g.gmis + wk.re_count * lq + 31u) >> 5;
+  gold_generate_wave(p.gold, p.x1_words, pd.c_init, bit0 >> 5, gwords, sh.gold, lane);
+  if (lane < 8) {
+    sh.gold[gwords + lane] = 0;
+  }
+  if (lane < 2 * pd.nof_ports * pd.nof_layers) {
+    st.w[lane] = p.weights[pd.weights_offset + lane];
+  }
+  wave_sync();
+
+  // 4. Rate matching ... RE mapping, specialised per (Qm, layers); `wrap` = the selection wraps around Ncb.
+  const RmIndex rm   = rm_index_init(pd);
+  const bool    wrap = rm.rank0 + g.E > rm.n_valid;
+  switch (pd.qm) { // wave-uniform
+    case 2:
+      map_chunk_layers<2>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+    case 4:
+      map_chunk_layers<4>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+    case 6:
+      map_chunk_layers<6>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+    default:
+      map_chunk_layers<8>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      break;
+  }
+}
+
+hipError_t launch_codeblocks(const PdschLaunch& p, const uint8_t* d_tb, uint32_t* d_grid, uint32_t* d_cw_rm,
+                             uint32_t* d_cw_scr, hipStream_t stream)
+{
+  if (p.n_work == 0) {
+    return hipSuccess;
+  }
+  const size_t lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_gold_words + p.lds_symb_words + p.lds_graph_words);
+  const uint32_t blocks = p.n_work + (d_grid ? p.n_dmrs_in_launch + p.n_zero_work : 0u);
+  hipLaunchKernelGGL(codeblock_kernel, dim3(blocks), dim3(WAVE), lds_bytes, stream, p, d_tb, d_grid, d_cw_rm,
+                     d_cw_scr);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(WAVE) void dmrs_kernel(PdschLaunch p, uint32_t* __restrict__ d_grid)
+{
+  __shared__ uint32_t gold[DMRS_GOLD_WORDS];
+  dmrs_wave(p, blockIdx.x, d_grid, gold, threadIdx.x);
+}
+
 hipError_t launch_dmrs(const PdschLaunch& p, uint32_t* d_grid, hipStream_t stream)
 {
   if (p.n_dmrs_work == 0) {
@@ -640,6 +694,7 @@ __global__ __launch_bounds__(WAVE) void ldpc_encode_kernel(const LiftedGraph* gr
                                                            uint8_t* __restrict__ d_out, uint32_t out_stride)
 {
   __shared__ uint32_t    lin[LDPC_LIN_WORDS];
+  __shared__ uint32_t    gbuf[LDPC_GRAPH_ROWPTR + MAX_BG_EDGES];
   __shared__ LdpcScratch scratch;
   const uint32_t         lane = threadIdx.x;
   const uint8_t*         msg  = d_msg + (size_t)blockIdx.x * msg_stride;
@@ -662,8 +717,9 @@ __global__ __launch_bounds__(WAVE) void ldpc_encode_kernel(const LiftedGraph* gr
     v            = pos >= K ? 0u : (K - pos < 32u ? v & topmask(K - pos) : v);
     lin[j]       = v;
   }
+  stage_graph(&graphs[graph], nof_rows, gbuf, lane);
   wave_sync();
-  ldpc_encode_wave(&graphs[graph], kb, zc, nof_rows, lin, &scratch, lane);
+  ldpc_encode_wave(&graphs[graph], gbuf, kb, zc, nof_rows, lin, &scratch, lane);
   const uint32_t out_bytes = (out_bits + 7u) >> 3;
   for (uint32_t j = lane; 4u * j < out_bytes; j += WAVE) {
     uint32_t v   = ext32(lin, 2u * zc + 32u * j);
