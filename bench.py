@@ -47,7 +47,7 @@ def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=20.0):
             return o.lib.oracle_bench(C.byref(pdu), tb.ctypes.data, nof_ports, nof_subc, C.byref(ofdm), threads, reps)
     run(cores, 1)       # warms caches / page-faults the buffers
     t1 = run(cores, 4) / 4.0  # calibration: seconds per slot per thread
-    reps = int(max(2, min(2000, budget_s / max(t1, 1e-4))))
+    reps = int(max(2, min(20000, budget_s / max(t1, 1e-4))))
     dt = run(cores, reps)
     return {
         "value": cores * reps / dt,
@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--slots", type=int, default=256, help="slots per GPU per step")
+    ap.add_argument("--slots", type=int, default=1024, help="slots per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -149,6 +149,15 @@ def edge_case_pdus():
     out.append(("cdm1", abi.make_pdu(bwp_size_rb=24, qm=4, dmrs_symbols=(2, 9), nof_cdm_groups_without_data=1,
                                      prb_start=0, prb_count=24, nof_symbols=13, tb_size_bytes=1500, rv=1,
                                      precoding=abi.identity_precoding(1)), 1, 24 * 12))
+    # Four layers but only one CDM group without data: data RE share the second DM-RS comb and DM-RS must win
+    # (the reference maps DM-RS after the data; here that forces the separate, later DM-RS launch).
+    out.append(("cdm1_l4", abi.make_pdu(bwp_size_rb=30, qm=6, dmrs_symbols=(2, 10), nof_cdm_groups_without_data=1,
+                                        prb_start=4, prb_count=21, nof_symbols=12, start_symbol=1, tb_size_bytes=5000,
+                                        precoding=abi.identity_precoding(4)), 4, 30 * 12))
+    # No CDM group without data at all: data on every RE of the DM-RS symbols, DM-RS overwrites its comb.
+    out.append(("cdm0", abi.make_pdu(bwp_size_rb=20, qm=2, dmrs_symbols=(3,), nof_cdm_groups_without_data=0,
+                                     prb_start=0, prb_count=20, nof_symbols=8, start_symbol=2, tb_size_bytes=300,
+                                     precoding=abi.identity_precoding(2)), 2, 20 * 12))
     # 2 layers on 4 ports with random complex weights, PRB0 reference point, BWP offset, power ratios.
     out.append(("l2p4", abi.make_pdu(bwp_start_rb=5, bwp_size_rb=40, qm=8, dmrs_symbols=(2, 3), prb_start=9,
                                      prb_count=17, nof_symbols=12, start_symbol=2, ref_point=1, tb_size_bytes=7000,
