@@ -179,7 +179,7 @@ def main():
                        "slots_per_gpu_per_step": slots, "parallelism": "slot-sharded x%d, no data-path collective" % world},
             "iq_gsamples_per_sec": round(total_samples / dt / 1e9, 3),
             "whole_path_hbm_frac": round(total_slots * (alg_pdsch + alg_ofdm) / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
-            "kernel_ms": {"tb_crc": round(ms_crc, 4), "codeblock_dmrs_zerofill": round(ms_cb, 4),
+            "kernel_ms": {"prologue_tbcrc_scrambling_seq": round(ms_crc, 4), "codeblock_dmrs_zerofill": round(ms_cb, 4),
                           "separate_dmrs": round(ms_dmrs, 4), "pdsch_run": round(ms_run, 4), "ofdm": round(ms_ofdm, 4)},
             "roofline": roofline,
             "roofline_other": [roof(k) for k in kernels if k != dom],

@@ -266,11 +266,13 @@ struct nrphy_pdsch_plan {
   uint32_t*             d_crc_pow = nullptr;
   ZeroWork*             d_zero_work = nullptr;
   ZeroSeg*              d_zero_segs = nullptr;
+  uint32_t*             d_scr = nullptr;    // scrambling sequences, rewritten by every run's prologue
+  uint64_t              scr_words = 0;
   uint32_t              n_zero_work = 0;
   uint32_t              epoch = 0;          // selects the TB-CRC accumulator of the current run
   bool                  dmrs_separate = false; // DM-RS must overwrite data RE: keep it in its own, later launch
   uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0, n_crc_work = 0;
-  uint32_t              lds_lin_words = 0, lds_gold_words = 0, lds_symb_words = 0, lds_graph_words = 0;
+  uint32_t              lds_lin_words = 0, lds_symb_words = 0, lds_graph_words = 0;
   std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs
   uint32_t              timed_runs = 0, max_timed_runs = 0;
 };
@@ -911,8 +913,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
       for (unsigned begin = 0; begin < nre; begin += RE_CHUNK) {
         const unsigned count = std::min<unsigned>(RE_CHUNK, nre - begin);
         work.push_back({i, cb, begin, count});
-        // LDS the wave needs: scrambling words (+ misalignment, + 8 read-ahead), symbol bytes (32 per block + 8 words).
-        plan->lds_gold_words = std::max<uint32_t>(plan->lds_gold_words, ((31 + count * lq + 31) / 32 + 8 + 3) & ~3U);
+        // LDS the wave needs for the symbol bytes (32 per block + 8 words).
         plan->lds_symb_words = std::max<uint32_t>(plan->lds_symb_words,
                                                   (((count * pdu.nof_layers + 31) / 32) * 8 + 8 + 3) & ~3U);
       }
@@ -921,6 +922,10 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
                                              ((((kb + pd.nof_rows) * d.lifting_size + 31) / 32) + 2 + 3) & ~3U);
     plan->lds_graph_words = std::max<uint32_t>(
         plan->lds_graph_words, (48U + ctx->graphs[pd.graph].row_ptr[std::min<uint32_t>(pd.nof_rows, MAX_BG_ROWS)] + 3U) & ~3U);
+    // Scrambling sequence of the PDU: one word per 32 codeword bits plus the word a misaligned read runs into.
+    pd.scr_offset = (uint32_t)plan->scr_words;
+    pd.scr_words  = (d.codeword_bits + 31U) / 32U + 1U;
+    plan->scr_words += (pd.scr_words + 3U) & ~3ULL;
     plan->n_cb += d.nof_codeblocks;
     plan->cw_offset.push_back(cw_bits);
     cw_bits += (d.codeword_bits + 31U) & ~31ULL;
@@ -1008,6 +1013,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
       upload(&plan->d_re_table, re_table.data(), re_table.size() * sizeof(uint16_t)) != hipSuccess ||
       upload(&plan->d_zero_work, zero_work.data(), zero_work.size() * sizeof(ZeroWork)) != hipSuccess ||
       upload(&plan->d_zero_segs, zero_segs.data(), zero_segs.size() * sizeof(ZeroSeg)) != hipSuccess ||
+      hipMalloc((void**)&plan->d_scr, sizeof(uint32_t) * std::max<uint64_t>(4, plan->scr_words)) != hipSuccess ||
       hipMalloc((void**)&plan->d_tb_crc, 2 * sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size())) != hipSuccess ||
       hipMemset(plan->d_tb_crc, 0, 2 * sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size())) != hipSuccess) {
     nrphy_pdsch_plan_destroy(plan);
@@ -1035,6 +1041,7 @@ extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
   (void)hipFree(plan->d_crc_pow);
   (void)hipFree(plan->d_zero_work);
   (void)hipFree(plan->d_zero_segs);
+  (void)hipFree(plan->d_scr);
   for (hipEvent_t e : plan->events) {
     (void)hipEventDestroy(e);
   }
@@ -1085,6 +1092,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   const bool merge_dmrs = d_grid != nullptr && !plan->dmrs_separate;
   p.zero_work          = plan->d_zero_work;
   p.zero_segs          = plan->d_zero_segs;
+  p.scr                = plan->d_scr;
   p.n_zero_work        = (d_grid != nullptr && zero_grids) ? plan->n_zero_work : 0;
   p.n_dmrs_in_launch   = merge_dmrs ? plan->n_dmrs : 0;
   p.n_pdu          = (uint32_t)plan->pdus.size();
@@ -1093,9 +1101,13 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.grid_nof_ports = plan->grid_nof_ports;
   p.grid_nof_subc  = plan->grid_nof_subc;
   p.lds_lin_words  = plan->lds_lin_words;
-  p.lds_gold_words = plan->lds_gold_words;
   p.lds_symb_words = plan->lds_symb_words;
   p.lds_graph_words = plan->lds_graph_words;
+  {
+    // Profiling aid: stop the codeblock waves after a stage to time the stages apart (outputs are then incomplete).
+    static const char* stage_env = std::getenv("NRPHY_PROFILE_STAGE");
+    p.profile_stage              = stage_env ? (uint32_t)std::atoi(stage_env) : 0;
+  }
   const size_t cw_bytes = (size_t)(plan->cw_bits / 8);
   if (d_cw_rm) {
     HIP_TRY(hipMemsetAsync(d_cw_rm, 0, cw_bytes, s));
@@ -1108,7 +1120,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     ev = &plan->events[4 * plan->timed_runs++];
     HIP_TRY(hipEventRecord(ev[0], s));
   }
-  HIP_TRY(launch_tb_crc(p, d_tb, s));
+  HIP_TRY(launch_prologue(p, d_tb, s));
   if (ev) {
     HIP_TRY(hipEventRecord(ev[1], s));
   }

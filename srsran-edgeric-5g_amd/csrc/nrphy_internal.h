@@ -79,6 +79,8 @@ struct PduDev {
   uint32_t nof_layers;
   uint32_t nof_ports;
   uint32_t c_init;         // scrambling sequence initialisation
+  uint32_t scr_offset;     // word offset of the PDU's scrambling sequence in the plan's buffer
+  uint32_t scr_words;      // words of it the prologue generates: ceil(G / 32) + read-ahead
   uint32_t nof_re;
   uint32_t weights_offset; // floats: data weights (scaled) [nof_prg][P][L][2] in the plan's weight array
   uint32_t dmrs_weights_offset; // floats: unscaled weights, same shape
@@ -149,6 +151,7 @@ struct PdschLaunch {
   uint32_t           n_zero_work;     // zero-fill waves appended to the codeblock launch (0: caller cleared the grids)
   uint32_t           n_dmrs_in_launch; // DM-RS waves appended to the codeblock launch (0: separate launch)
   uint32_t*          tb_crc_next;     // the other TB-CRC accumulator, cleared for the next run
+  uint32_t*          scr;             // scrambling sequences c(n) of every PDU, MSB-first words (prologue -> codeblocks)
   const PduDev*      pdus;
   const CbWork*      work;
   const DmrsWork*    dmrs_work;
@@ -167,13 +170,13 @@ struct PdschLaunch {
   uint32_t           grid_nof_ports;
   uint32_t           grid_nof_subc;
   uint32_t           lds_lin_words;  // dynamic LDS carve of the codeblock kernel (words, multiples of 4)
-  uint32_t           lds_gold_words;
   uint32_t           lds_symb_words;
   uint32_t           lds_graph_words;
+  uint32_t           profile_stage; // 0 = run everything; n > 0 = codeblock waves stop after stage n (NRPHY_PROFILE_STAGE)
 };
 
 // Kernel launchers (defined in the .hip files).
-hipError_t launch_tb_crc(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream);
+hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream);
 hipError_t launch_codeblocks(const PdschLaunch& p, const uint8_t* d_tb, uint32_t* d_grid, uint32_t* d_cw_rm,
                              uint32_t* d_cw_scr, hipStream_t stream);
 hipError_t launch_dmrs(const PdschLaunch& p, uint32_t* d_grid, hipStream_t stream);

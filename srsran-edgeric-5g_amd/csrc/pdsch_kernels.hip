@@ -1,7 +1,8 @@
 // PDSCH processor kernels for gfx950 (MI355X).
 //
-//   tb_crc_kernel      transport-block CRC: every thread reduces a 4-byte-aligned chunk with a byte table, scales
-//                      its remainder by x^(8 * bytes after) (table built at plan time) and XORs it into the result
+//   prologue_kernel    per-PDU work the codeblock waves consume: the transport-block CRC (every thread reduces a
+//                      4-byte-aligned chunk with a byte table, scales its remainder by x^(8 * bytes after) -- table
+//                      built at plan time -- and XORs it into the result) and the PDU's scrambling sequence
 //   codeblock_kernel   one wavefront per codeblock (or per 512-RE chunk of it): segmentation, CB-CRC, LDPC
 //                      base-graph expansion in LDS, rate matching + bit interleaving as a word-level bit-matrix
 //                      transposition, Gold scrambling, QAM mapping through an LDS table, layer mapping, precoding
@@ -23,7 +24,12 @@ namespace nrphy {
 constexpr int      TB_CRC_THREADS     = 256;
 constexpr uint32_t TB_CRC_CHUNK_WORDS = TB_CRC_CHUNK_BYTES / 4; // words per thread (the plan uses exactly this chunk)
 
-__global__ __launch_bounds__(TB_CRC_THREADS) void tb_crc_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
+static_assert(TB_CRC_THREADS * (TB_CRC_CHUNK_WORDS + 1) >= GOLD_RING_WORDS, "the Gold ring reuses the CRC staging area");
+
+// Blocks [0, n_pdu): scrambling sequence of one PDU (TS 38.211 Section 7.3.1.1; reference:
+// pdsch_modulator_impl.cpp:43-60 runs the generator once per codeword too).  Blocks [n_pdu, n_pdu + n_crc_work):
+// transport-block CRC.
+__global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
 {
   __shared__ uint32_t table[256];
   __shared__ uint32_t partial[TB_CRC_THREADS / WAVE];
@@ -31,7 +37,13 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void tb_crc_kernel(PdschLaunch p, c
   // [17 t, 17 t + 16): the odd stride keeps the 64 lanes on different banks.
   __shared__ uint32_t stage[TB_CRC_THREADS * (TB_CRC_CHUNK_WORDS + 1)];
 
-  const CrcWork   wk  = p.crc_work[blockIdx.x];
+  if (blockIdx.x < p.n_pdu) { // workgroup-uniform; first in the grid: these have the longest dependent chain
+    const PduDev& pd = p.pdus[blockIdx.x];
+    gold_sequence_workgroup(p.gold, p.x1_words, pd.c_init, pd.scr_words, p.scr + pd.scr_offset, stage, threadIdx.x,
+                            TB_CRC_THREADS);
+    return;
+  }
+  const CrcWork   wk  = p.crc_work[blockIdx.x - p.n_pdu];
   const PduDev&   pd  = p.pdus[wk.pdu];
   const uint32_t  tid = threadIdx.x;
   const CrcPoly   c   = (pd.tb_crc_bits == 16) ? crc16() : crc24a();
@@ -87,12 +99,12 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void tb_crc_kernel(PdschLaunch p, c
   }
 }
 
-hipError_t launch_tb_crc(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream)
+hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream)
 {
-  if (p.n_crc_work == 0) {
+  if (p.n_crc_work + p.n_pdu == 0) {
     return hipSuccess;
   }
-  hipLaunchKernelGGL(tb_crc_kernel, dim3(p.n_crc_work), dim3(TB_CRC_THREADS), 0, stream, p, d_tb);
+  hipLaunchKernelGGL(prologue_kernel, dim3(p.n_crc_work + p.n_pdu), dim3(TB_CRC_THREADS), 0, stream, p, d_tb);
   return hipGetLastError();
 }
 
@@ -113,7 +125,6 @@ struct CbStatic {
 
 struct CbShared {
   uint32_t* lin;  // codeblock bits, (Kb + rows) * Zc bits (+ read-ahead)
-  uint32_t* gold; // scrambling words of the chunk (+ misalignment, + read-ahead)
   uint32_t* symb; // interleaver output: one byte per modulation symbol, Qm bits in the byte's MSBs
   uint32_t* graph; // row pointers + edges of the lifted graph rows this codeblock needs
   CbStatic* st;
@@ -295,7 +306,7 @@ __device__ __forceinline__ uint32_t pack_cbf16(float re, float im)
 struct ChunkGeom {
   uint32_t E;      // rate-matched length of the codeblock
   uint32_t cw_cb;  // first codeword bit of the codeblock
-  uint32_t gmis;   // misalignment of the chunk's first bit within its first scrambling word
+  uint32_t bit0;   // first codeword bit of the chunk
 };
 
 // ================================================================================================================
@@ -349,6 +360,9 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd
     wave_sync();
   }
 
+  if (p.profile_stage == 4) {
+    return;
+  }
   // ---- Phase B ----
   const uint32_t re_cb   = g.cw_cb / LQ; // first RE of the codeblock within the PDU
   const uint32_t P       = pd.nof_ports;
@@ -356,6 +370,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd
   const float*   wbase   = p.weights + pd.weights_offset;
   const size_t   grid_base = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
   const uint64_t cw_bit0 = pd.cw_bit_offset + g.cw_cb + (uint64_t)wk.re_begin * LQ;
+  const uint32_t* __restrict__ scr = p.scr + pd.scr_offset;
   bool           any_table = false;
 #pragma unroll
   for (int l = 0; l != NRPHY_NSYMB; ++l) {
@@ -377,7 +392,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd
       continue;
     }
     const uint32_t bytes = ext32(sh.symb, 8u * r * L);           // the RE's L symbol bytes, first in the MSB
-    const uint32_t gbits = ext32(sh.gold, g.gmis + r * LQ);      // its L*Qm scrambling bits, first in the MSB
+    const uint32_t gbits = ext32(scr, g.bit0 + r * LQ);          // its L*Qm scrambling bits (prologue), MSB first
     uint32_t       idx[L];
     uint32_t       v_rm = 0;
 #pragma unroll
@@ -581,7 +596,7 @@ __device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_in
 // DM-RS waves and zero-fill waves for the grid words nobody maps.
 // ================================================================================================================
 
-__global__ __launch_bounds__(WAVE) void codeblock_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
+__global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
                                                          uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
                                                          uint32_t* __restrict__ d_cw_scr)
 {
@@ -589,8 +604,7 @@ __global__ __launch_bounds__(WAVE) void codeblock_kernel(PdschLaunch p, const ui
   __shared__ CbStatic st;
   CbShared            sh;
   sh.lin  = dyn_lds;
-  sh.gold = dyn_lds + p.lds_lin_words;
-  sh.symb  = sh.gold + p.lds_gold_words;
+  sh.symb  = dyn_lds + p.lds_lin_words;
   sh.graph = sh.symb + p.lds_symb_words;
   sh.st    = &st;
   const uint32_t      lane = threadIdx.x;
@@ -617,27 +631,30 @@ __global__ __launch_bounds__(WAVE) void codeblock_kernel(PdschLaunch p, const ui
   build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), &p.tb_crc[wk.pdu], p.gold, &sh,
                   total_words, lane);
 
+  if (p.profile_stage == 1) {
+    return;
+  }
   // 2. LDPC encoding (only the parity rows that rate matching can reach).
   ldpc_encode_wave(&p.graphs[pd.graph], sh.graph, kb, zc, pd.nof_rows, sh.lin, &st.ldpc, lane);
 
-  // 3. This wave's slice of the codeword and its scrambling sequence.
+  if (p.profile_stage == 2) {
+    return;
+  }
+  // 3. This wave's slice of the codeword (its scrambling bits were generated by the prologue).
   const uint32_t lq      = pd.nof_layers * pd.qm; // bits per RE
   const bool     is_long = wk.cb >= pd.n_short;
   ChunkGeom      g;
   g.E     = is_long ? pd.e_long : pd.e_short;
   g.cw_cb = is_long ? pd.n_short * pd.e_short + (wk.cb - pd.n_short) * pd.e_long : wk.cb * pd.e_short;
-  const uint32_t bit0   = g.cw_cb + wk.re_begin * lq; // first codeword bit of the chunk
-  g.gmis                = bit0 & 31u;
-  const uint32_t gwords = (g.gmis + wk.re_count * lq + 31u) >> 5;
-  gold_generate_wave(p.gold, p.x1_words, pd.c_init, bit0 >> 5, gwords, sh.gold, lane);
-  if (lane < 8) {
-    sh.gold[gwords + lane] = 0;
-  }
+  g.bit0  = g.cw_cb + wk.re_begin * lq;
   if (lane < 2 * pd.nof_ports * pd.nof_layers) {
     st.w[lane] = p.weights[pd.weights_offset + lane];
   }
   wave_sync();
 
+  if (p.profile_stage == 3) {
+    return;
+  }
   // 4. Rate matching ... RE mapping, specialised per (Qm, layers); `wrap` = the selection wraps around Ncb.
   const RmIndex rm   = rm_index_init(pd);
   const bool    wrap = rm.rank0 + g.E > rm.n_valid;
@@ -663,7 +680,7 @@ hipError_t launch_codeblocks(const PdschLaunch& p, const uint8_t* d_tb, uint32_t
   if (p.n_work == 0) {
     return hipSuccess;
   }
-  const size_t lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_gold_words + p.lds_symb_words + p.lds_graph_words);
+  const size_t lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_symb_words + p.lds_graph_words);
   const uint32_t blocks = p.n_work + (d_grid ? p.n_dmrs_in_launch + p.n_zero_work : 0u);
   hipLaunchKernelGGL(codeblock_kernel, dim3(blocks), dim3(WAVE), lds_bytes, stream, p, d_tb, d_grid, d_cw_rm,
                      d_cw_scr);
