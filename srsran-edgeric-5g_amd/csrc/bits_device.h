@@ -8,6 +8,17 @@ namespace nrphy {
 
 constexpr int WAVE = 64;
 
+// Plan tables (PDU descriptors, work lists) never change while a kernel runs.  Reading them through the constant
+// address space tells the compiler so: wave-uniform reads become scalar loads into SGPRs (one s_load_dwordx16 for
+// sixteen fields) instead of vector loads + v_readfirstlane with a full memory round trip each.
+#define NRPHY_CONSTANT __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const NRPHY_CONSTANT T* to_constant(const T* p)
+{
+  return (const NRPHY_CONSTANT T*)p;
+}
+typedef const NRPHY_CONSTANT PduDev& PduRef;
+
 // Orders the LDS traffic of the lanes of ONE wavefront (the codeblock kernel runs one wave per workgroup, so a
 // workgroup barrier is a wave barrier; kept as a function to make the intent explicit).
 __device__ __forceinline__ void wave_sync()

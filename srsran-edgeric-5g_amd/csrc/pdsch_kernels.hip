@@ -38,13 +38,14 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   __shared__ uint32_t stage[TB_CRC_THREADS * (TB_CRC_CHUNK_WORDS + 1)];
 
   if (blockIdx.x < p.n_pdu) { // workgroup-uniform; first in the grid: these have the longest dependent chain
-    const PduDev& pd = p.pdus[blockIdx.x];
+    PduRef pd = *to_constant(&p.pdus[blockIdx.x]);
     gold_sequence_workgroup(p.gold, p.x1_words, pd.c_init, pd.scr_words, p.scr + pd.scr_offset, stage, threadIdx.x,
                             TB_CRC_THREADS);
     return;
   }
-  const CrcWork   wk  = p.crc_work[blockIdx.x - p.n_pdu];
-  const PduDev&   pd  = p.pdus[wk.pdu];
+  const auto*     wkc = to_constant(&p.crc_work[blockIdx.x - p.n_pdu]);
+  const CrcWork   wk  = {wkc->pdu, wkc->thread_begin, wkc->chunk, wkc->pow_offset};
+  PduRef          pd  = *to_constant(&p.pdus[wk.pdu]);
   const uint32_t  tid = threadIdx.x;
   const CrcPoly   c   = (pd.tb_crc_bits == 16) ? crc16() : crc24a();
   const uint32_t  n   = pd.tb_bytes;
@@ -132,7 +133,7 @@ struct CbShared {
 
 // Fills lin with the K bits of codeblock `cb` (payload, TB CRC + zero padding on the last codeblock, CB CRC, filler
 // zeros) and zeroes the parity region up to `total_words`.
-__device__ inline void build_codeblock(const PduDev& pd, uint32_t cb, const uint32_t* tbw, const uint32_t* tb_crc_ptr,
+__device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* tbw, const uint32_t* tb_crc_ptr,
                                        const GoldTables* tables, CbShared* sh, uint32_t total_words, uint32_t lane)
 {
   const bool     last    = (cb == pd.C - 1);
@@ -213,7 +214,7 @@ struct RmIndex {
   float    inv_valid;
 };
 
-__device__ __forceinline__ RmIndex rm_index_init(const PduDev& pd)
+__device__ __forceinline__ RmIndex rm_index_init(PduRef pd)
 {
   RmIndex  r;
   uint32_t nsys = (pd.kb - 2u) * pd.zc;
@@ -319,7 +320,7 @@ struct ChunkGeom {
 // Phase B -- per RE: scramble, QAM table lookup, layer mapping + precoding, bf16, coalesced stores.
 // ================================================================================================================
 template <int QM, int L, bool WRAP>
-__device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd, const CbWork& wk, const CbShared& sh,
+__device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const CbWork& wk, const CbShared& sh,
                                           const ChunkGeom& g, uint32_t lane, uint32_t* __restrict__ d_grid,
                                           uint32_t* __restrict__ d_cw_rm, uint32_t* __restrict__ d_cw_scr)
 {
@@ -478,7 +479,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, const PduDev& pd
 }
 
 template <int QM, int L>
-__device__ __forceinline__ void map_chunk_select(const PdschLaunch& p, const PduDev& pd, const CbWork& wk,
+__device__ __forceinline__ void map_chunk_select(const PdschLaunch& p, PduRef pd, const CbWork& wk,
                                                  const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
                                                  uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
 {
@@ -490,7 +491,7 @@ __device__ __forceinline__ void map_chunk_select(const PdschLaunch& p, const Pdu
 }
 
 template <int QM>
-__device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, const PduDev& pd, const CbWork& wk,
+__device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, PduRef pd, const CbWork& wk,
                                                  const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
                                                  uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
 {
@@ -520,8 +521,9 @@ constexpr int DMRS_GOLD_WORDS = (DMRS_PRB_CHUNK * 12) / 32 + 8;
 __device__ __forceinline__ void dmrs_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid,
                                  uint32_t* gold, uint32_t lane)
 {
-  const DmrsWork      wk   = p.dmrs_work[item_index];
-  const PduDev&       pd   = p.pdus[wk.pdu];
+  const auto*         wkc  = to_constant(&p.dmrs_work[item_index]);
+  const DmrsWork      wk   = {wkc->pdu, wkc->symbol, wkc->prb_begin, wkc->prb_end};
+  PduRef              pd   = *to_constant(&p.pdus[wk.pdu]);
   const uint32_t      L = pd.nof_layers, P = pd.nof_ports;
 
   // Pilot r(n) uses c(2n), c(2n+1); PRB prb holds n = 6*(prb - ref) .. +5, i.e. sequence bits 12*(prb - ref) .. +11.
@@ -579,10 +581,12 @@ __device__ __forceinline__ void dmrs_wave(const PdschLaunch& p, uint32_t item_in
 // Writes zeros to the grid words of one (grid, port) that no PDU of the plan maps.
 __device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid, uint32_t lane)
 {
-  const ZeroWork wk   = p.zero_work[item_index];
+  const auto*    wkc  = to_constant(&p.zero_work[item_index]);
+  const ZeroWork wk   = {wkc->grid, wkc->port, wkc->seg_begin, wkc->seg_count};
   uint32_t*      base = d_grid + ((size_t)wk.grid * p.grid_nof_ports + wk.port) * NRPHY_NSYMB * p.grid_nof_subc;
   for (uint32_t i = 0; i != wk.seg_count; ++i) {
-    const ZeroSeg sg  = p.zero_segs[wk.seg_begin + i];
+    const auto*   sgc = to_constant(&p.zero_segs[wk.seg_begin + i]);
+    const ZeroSeg sg  = {sgc->symbol, sgc->k0, sgc->count, 0};
     uint32_t*     row = base + (size_t)sg.symbol * p.grid_nof_subc + sg.k0;
     for (uint32_t k = lane; k < sg.count; k += WAVE) {
       row[k] = 0u;
@@ -621,8 +625,9 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
   if (blockIdx.x * WAVE < p.n_pdu && blockIdx.x * WAVE + lane < p.n_pdu) {
     p.tb_crc_next[blockIdx.x * WAVE + lane] = 0u;
   }
-  const CbWork        wk   = p.work[blockIdx.x];
-  const PduDev&       pd   = p.pdus[wk.pdu];
+  const auto*         wkc  = to_constant(&p.work[blockIdx.x]);
+  const CbWork        wk   = {wkc->pdu, wkc->cb, wkc->re_begin, wkc->re_count};
+  PduRef              pd   = *to_constant(&p.pdus[wk.pdu]);
   const uint32_t      zc = pd.zc, kb = pd.kb;
 
   // 1. Segmentation + CRC attachment (the graph rows ride along: their loads overlap the transport block's).
