@@ -1359,6 +1359,11 @@ extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const
   p.phase       = plan->d_phase;
   p.cp_len      = plan->d_cp;
   p.sym_offset  = plan->d_off;
+  {
+    // Profiling aid (profiles/): 1 = drop the IQ stores, 2 = drop the grid loads, 3 = both (outputs are then wrong).
+    static const char* probe_env = std::getenv("NRPHY_OFDM_PROBE");
+    p.probe                      = probe_env ? (uint32_t)std::atoi(probe_env) : 0;
+  }
   hipStream_t s  = stream ? (hipStream_t)stream : ctx->stream;
   hipEvent_t* ev = nullptr;
   if (plan->timed_runs < plan->max_timed_runs) {

@@ -195,6 +195,7 @@ struct OfdmLaunch {
   const float2*  phase;       // [symbols per subframe] phase compensation * scale
   const uint32_t* cp_len;     // [symbols per subframe]
   const uint32_t* sym_offset; // [symbols per subframe] start of the symbol within its slot (samples)
+  uint32_t       probe;       // NRPHY_OFDM_PROBE: timing-only runs with the loads and/or stores range-checked away
 };
 hipError_t launch_ofdm(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* d_grid, const uint32_t* d_slot_index,
                        float2* d_iq, hipStream_t stream);

@@ -1,54 +1,115 @@
 // OFDM modulator and DFT kernels for gfx950 (MI355X).
 //
-// One workgroup modulates the OFDM symbols of one (grid, port) one after the other.  A symbol's resource-grid row
-// goes from HBM straight into the registers of the first butterfly stage (bin placement and guard zeros are index
-// arithmetic); while the transform of symbol l runs in LDS (Stockham autosort, radix-16/8/4/2 register butterflies)
-// the row of symbol l+1 is already in flight.  Twiddles are powers of one table value per thread and stage, built in
+// One workgroup transforms one OFDM symbol of one (grid, port).  The symbol's resource-grid row goes from HBM
+// straight into the registers of the first butterfly stage (bin placement is index arithmetic, the guard zeros come
+// from the buffer range check); the transform runs in LDS (Stockham autosort, radix-16/8/4/2 register butterflies
+// written with packed-FP32 instructions).  Twiddles are powers of one table value per thread and stage, built in
 // registers, so the only global traffic is the algorithmic one: grid in, IQ out.  The last stage applies phase
 // compensation x scale and writes the useful part plus the cyclic prefix.
 // Replaces ofdm_symbol_modulator_impl::modulate (R/lib/phy/lower/modulation/ofdm_modulator_impl.cpp:56-100) and
 // dft_processor_generic_impl::run (R/lib/phy/generic_functions/dft_processor_generic_impl.cpp:14-218).
-#include "nrphy_internal.h"
+#include "bits_device.h"
+
+#include <type_traits>
 
 namespace nrphy {
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b)
+template <uint32_t V>
+using Const = std::integral_constant<uint32_t, V>;
+
+// f(Const<0>{}), ..., f(Const<COUNT - 1>{}): a loop whose index is a compile-time constant inside the body.
+template <class F, uint32_t... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<uint32_t, I...>)
 {
-  return make_float2(a.x + b.x, a.y + b.y);
+  (f(Const<I>{}), ...);
 }
-__device__ __forceinline__ float2 csub(float2 a, float2 b)
+template <uint32_t COUNT, class F>
+__device__ __forceinline__ void static_for(F&& f)
 {
-  return make_float2(a.x - b.x, a.y - b.y);
+  static_for_impl(f, std::make_integer_sequence<uint32_t, COUNT>{});
 }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+
+// ---- complex arithmetic on packed FP32 ------------------------------------------------------------------------
+// A complex number is one 64-bit VGPR pair (re, im) and every operation below is one or two v_pk_*_f32
+// instructions.  hipcc pairs scalar float code into packed instructions on its own, but it cannot negate or swap one
+// half of an operand (it emits both variants and v_mov's the halves back together), so the operations that need
+// op_sel / neg_lo / neg_hi are written out: the register butterflies are VALU-bound, not memory-bound.
+typedef float cf __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ cf cadd(cf a, cf b)
 {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+  return a + b;
 }
-// Multiplication by sign * j (sign = +1: inverse transform, -1: direct).
+__device__ __forceinline__ cf csub(cf a, cf b)
+{
+  return a - b;
+}
+// a * b:  t = (a.im b.im, a.re b.im);  result = (a.re b.re - t.lo, a.im b.re + t.hi).
+__device__ __forceinline__ cf cmul(cf a, cf b)
+{
+  cf t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
+}
+// The same with a wave-uniform b held in an SGPR pair (constants, the per-symbol phase).
+__device__ __forceinline__ cf cmul_uniform(cf a, cf b)
+{
+  cf t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+  return r;
+}
+// a + j b = (a.re - b.im, a.im + b.re) and a - j b = (a.re + b.im, a.im - b.re).
+__device__ __forceinline__ cf add_jb(cf a, cf b)
+{
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ cf sub_jb(cf a, cf b)
+{
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// a + SIGN j b, a - SIGN j b (SIGN = +1: inverse transform, -1: direct).
 template <int SIGN>
-__device__ __forceinline__ float2 mulj(float2 a)
+__device__ __forceinline__ cf add_sjb(cf a, cf b)
 {
-  return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+  return SIGN > 0 ? add_jb(a, b) : sub_jb(a, b);
+}
+template <int SIGN>
+__device__ __forceinline__ cf sub_sjb(cf a, cf b)
+{
+  return SIGN > 0 ? sub_jb(a, b) : add_jb(a, b);
+}
+__device__ __forceinline__ cf make_cf(float re, float im)
+{
+  cf r = {re, im};
+  return r;
 }
 
 // ---- register butterflies: a[k] <- sum_n a[n] * exp(SIGN * 2 pi i n k / R), natural order in and out ---------
 template <int SIGN>
-__device__ __forceinline__ void dft2(float2& a0, float2& a1)
+__device__ __forceinline__ void dft2(cf& a0, cf& a1)
 {
-  float2 t = a0;
-  a0       = cadd(t, a1);
-  a1       = csub(t, a1);
+  cf t = a0;
+  a0   = cadd(t, a1);
+  a1   = csub(t, a1);
 }
 
-template <int SIGN>
-__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3)
+// ROT2: input a2 still has to be multiplied by SIGN j (a twiddle of the enclosing transform, folded in for free).
+template <int SIGN, bool ROT2 = false>
+__device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2, cf& a3)
 {
-  float2 p0 = cadd(a0, a2), q0 = csub(a0, a2);
-  float2 p1 = cadd(a1, a3), q1 = mulj<SIGN>(csub(a1, a3));
-  a0        = cadd(p0, p1);
-  a1        = cadd(q0, q1);
-  a2        = csub(p0, p1);
-  a3        = csub(q0, q1);
+  cf p0 = ROT2 ? add_sjb<SIGN>(a0, a2) : cadd(a0, a2);
+  cf q0 = ROT2 ? sub_sjb<SIGN>(a0, a2) : csub(a0, a2);
+  cf p1 = cadd(a1, a3), d = csub(a1, a3);
+  a0    = cadd(p0, p1);
+  a1    = add_sjb<SIGN>(q0, d);
+  a2    = csub(p0, p1);
+  a3    = sub_sjb<SIGN>(q0, d);
 }
 
 template <int SIGN, int R>
@@ -56,29 +117,28 @@ struct Butterfly;
 
 template <int SIGN>
 struct Butterfly<SIGN, 2> {
-  static __device__ __forceinline__ void run(float2 (&a)[2]) { dft2<SIGN>(a[0], a[1]); }
+  static __device__ __forceinline__ void run(cf (&a)[2]) { dft2<SIGN>(a[0], a[1]); }
 };
 template <int SIGN>
 struct Butterfly<SIGN, 4> {
-  static __device__ __forceinline__ void run(float2 (&a)[4]) { dft4<SIGN>(a[0], a[1], a[2], a[3]); }
+  static __device__ __forceinline__ void run(cf (&a)[4]) { dft4<SIGN>(a[0], a[1], a[2], a[3]); }
 };
 template <int SIGN>
 struct Butterfly<SIGN, 8> {
   // 8 = 2 x 4: X[k1 + 2 k2] = sum_{n2<4} W8^(n2 k1) W4^(n2 k2) [ sum_{n1<2} x[4 n1 + n2] W2^(n1 k1) ].
-  static __device__ __forceinline__ void run(float2 (&a)[8])
+  static __device__ __forceinline__ void run(cf (&a)[8])
   {
     constexpr float h = 0.70710678118654752440f;
     dft2<SIGN>(a[0], a[4]);
     dft2<SIGN>(a[1], a[5]);
     dft2<SIGN>(a[2], a[6]);
     dft2<SIGN>(a[3], a[7]);
-    // k1 = 1 row: multiply by W8^n2, n2 = 1, 2, 3.
-    a[5] = cmul(a[5], make_float2(h, SIGN * h));
-    a[6] = mulj<SIGN>(a[6]);
-    a[7] = cmul(a[7], make_float2(-h, SIGN * h));
-    dft4<SIGN>(a[0], a[1], a[2], a[3]); // k1 = 0: X[0], X[2], X[4], X[6]
-    dft4<SIGN>(a[4], a[5], a[6], a[7]); // k1 = 1: X[1], X[3], X[5], X[7]
-    float2 x1 = a[4], x2 = a[1], x3 = a[5], x4 = a[2], x5 = a[6], x6 = a[3];
+    // k1 = 1 row: multiply by W8^n2, n2 = 1, 2, 3 (n2 = 2 is SIGN j, folded into the butterfly).
+    a[5] = cmul_uniform(a[5], make_cf(h, SIGN * h));
+    a[7] = cmul_uniform(a[7], make_cf(-h, SIGN * h));
+    dft4<SIGN>(a[0], a[1], a[2], a[3]);       // k1 = 0: X[0], X[2], X[4], X[6]
+    dft4<SIGN, true>(a[4], a[5], a[6], a[7]); // k1 = 1: X[1], X[3], X[5], X[7]
+    cf x1 = a[4], x2 = a[1], x3 = a[5], x4 = a[2], x5 = a[6], x6 = a[3];
     a[1] = x1;
     a[2] = x2;
     a[3] = x3;
@@ -90,7 +150,7 @@ struct Butterfly<SIGN, 8> {
 template <int SIGN>
 struct Butterfly<SIGN, 16> {
   // 16 = 4 x 4: X[k1 + 4 k2] = sum_{n2<4} W16^(n2 k1) W4^(n2 k2) [ sum_{n1<4} x[4 n1 + n2] W4^(n1 k1) ].
-  static __device__ __forceinline__ void run(float2 (&a)[16])
+  static __device__ __forceinline__ void run(cf (&a)[16])
   {
     constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
     // Inner transforms over n1 (stride 4) for each n2; result index k1 replaces n1.
@@ -98,23 +158,22 @@ struct Butterfly<SIGN, 16> {
     dft4<SIGN>(a[1], a[5], a[9], a[13]);
     dft4<SIGN>(a[2], a[6], a[10], a[14]);
     dft4<SIGN>(a[3], a[7], a[11], a[15]);
-    // Twiddles W16^(n2 k1) on element a[4 k1 + n2].
-    a[5]  = cmul(a[5], make_float2(c1, SIGN * s1));    // 1*1
-    a[6]  = cmul(a[6], make_float2(h, SIGN * h));      // 2*1
-    a[7]  = cmul(a[7], make_float2(s1, SIGN * c1));    // 3*1
-    a[9]  = cmul(a[9], make_float2(h, SIGN * h));      // 1*2
-    a[10] = mulj<SIGN>(a[10]);                         // 2*2
-    a[11] = cmul(a[11], make_float2(-h, SIGN * h));    // 3*2
-    a[13] = cmul(a[13], make_float2(s1, SIGN * c1));   // 1*3
-    a[14] = cmul(a[14], make_float2(-h, SIGN * h));    // 2*3
-    a[15] = cmul(a[15], make_float2(-c1, -SIGN * s1)); // 3*3 = 9 -> W16^9
+    // Twiddles W16^(n2 k1) on element a[4 k1 + n2]; W16^4 = SIGN j on a[10] is folded into its butterfly.
+    a[5]  = cmul_uniform(a[5], make_cf(c1, SIGN * s1));    // 1*1
+    a[6]  = cmul_uniform(a[6], make_cf(h, SIGN * h));      // 2*1
+    a[7]  = cmul_uniform(a[7], make_cf(s1, SIGN * c1));    // 3*1
+    a[9]  = cmul_uniform(a[9], make_cf(h, SIGN * h));      // 1*2
+    a[11] = cmul_uniform(a[11], make_cf(-h, SIGN * h));    // 3*2
+    a[13] = cmul_uniform(a[13], make_cf(s1, SIGN * c1));   // 1*3
+    a[14] = cmul_uniform(a[14], make_cf(-h, SIGN * h));    // 2*3
+    a[15] = cmul_uniform(a[15], make_cf(-c1, -SIGN * s1)); // 3*3 = 9 -> W16^9
     // Outer transforms over n2 for each k1; result a[4 k1 + k2] = X[k1 + 4 k2].
     dft4<SIGN>(a[0], a[1], a[2], a[3]);
     dft4<SIGN>(a[4], a[5], a[6], a[7]);
-    dft4<SIGN>(a[8], a[9], a[10], a[11]);
+    dft4<SIGN, true>(a[8], a[9], a[10], a[11]);
     dft4<SIGN>(a[12], a[13], a[14], a[15]);
     // Transpose 4x4 to natural order: X[k1 + 4 k2] currently at a[4 k1 + k2].
-    float2 t;
+    cf t;
     t = a[1];  a[1] = a[4];   a[4] = t;
     t = a[2];  a[2] = a[8];   a[8] = t;
     t = a[3];  a[3] = a[12];  a[12] = t;
@@ -127,30 +186,30 @@ struct Butterfly<SIGN, 16> {
 // a[j] *= b^j for j = 1..R-1.  Powers are built from b^2, b^4, b^8 (squarings) so that every power is at most
 // three multiplications deep (a few ulp), and applied at once to keep few values live.
 template <int R>
-__device__ __forceinline__ void apply_twiddle_powers(float2 b, float2 (&a)[R])
+__device__ __forceinline__ void apply_twiddle_powers(cf b, cf (&a)[R])
 {
   a[1] = cmul(a[1], b);
   if (R > 2) {
-    const float2 b2 = cmul(b, b);
-    a[2]            = cmul(a[2], b2);
-    a[3]            = cmul(a[3], cmul(b2, b));
+    const cf b2 = cmul(b, b);
+    a[2]        = cmul(a[2], b2);
+    a[3]        = cmul(a[3], cmul(b2, b));
     if (R > 4) {
-      const float2 b4 = cmul(b2, b2);
-      a[4]            = cmul(a[4], b4);
-      a[5]            = cmul(a[5], cmul(b4, b));
-      a[6]            = cmul(a[6], cmul(b4, b2));
-      a[7]            = cmul(a[7], cmul(b4, cmul(b2, b)));
+      const cf b4 = cmul(b2, b2);
+      a[4]        = cmul(a[4], b4);
+      a[5]        = cmul(a[5], cmul(b4, b));
+      a[6]        = cmul(a[6], cmul(b4, b2));
+      a[7]        = cmul(a[7], cmul(b4, cmul(b2, b)));
       if (R > 8) {
-        const float2 b8 = cmul(b4, b4);
-        a[8]            = cmul(a[8], b8);
-        a[9]            = cmul(a[9], cmul(b8, b));
-        a[10]           = cmul(a[10], cmul(b8, b2));
-        a[11]           = cmul(a[11], cmul(b8, cmul(b2, b)));
-        const float2 b12 = cmul(b8, b4);
-        a[12]            = cmul(a[12], b12);
-        a[13]            = cmul(a[13], cmul(b12, b));
-        a[14]            = cmul(a[14], cmul(b12, b2));
-        a[15]            = cmul(a[15], cmul(b12, cmul(b2, b)));
+        const cf b8 = cmul(b4, b4);
+        a[8]        = cmul(a[8], b8);
+        a[9]        = cmul(a[9], cmul(b8, b));
+        a[10]       = cmul(a[10], cmul(b8, b2));
+        a[11]       = cmul(a[11], cmul(b8, cmul(b2, b)));
+        const cf b12 = cmul(b8, b4);
+        a[12]        = cmul(a[12], b12);
+        a[13]        = cmul(a[13], cmul(b12, b));
+        a[14]        = cmul(a[14], cmul(b12, b2));
+        a[15]        = cmul(a[15], cmul(b12, cmul(b2, b)));
       }
     }
   }
@@ -182,7 +241,7 @@ __device__ __forceinline__ uint32_t first_stage_index(uint32_t tid, int k)
 // Twiddle bases of a thread: stage s multiplies output j of its butterfly by (w_n^p)^j with w_n^p = tw[p * S].
 template <int N>
 struct TwiddleBase {
-  float2 b0, b1; // first and second stage (the last stage of a plan has n1 = 1: no twiddles)
+  cf b0, b1; // first and second stage (the last stage of a plan has n1 = 1: no twiddles)
 };
 
 template <int SIGN, int N>
@@ -191,20 +250,18 @@ __device__ __forceinline__ TwiddleBase<N> load_twiddle_base(const float2* __rest
   using P = Plan<N>;
   TwiddleBase<N> t;
   // Stage 0: S = 1, p = butterfly index = tid (threads beyond N/R0 butterflies are idle in that stage).
-  t.b0 = tw[tid & (N - 1)];
+  const float2 w0 = tw[tid & (N - 1)];
   // Stage 1: S = R0, p = b / R0 for butterfly b = tid (+ it*T); only the first iteration's base is kept here, the
   // others are derived in the stage (see stage_lds).
-  t.b1 = tw[((tid / P::R0) * P::R0) & (N - 1)];
-  if (SIGN < 0) {
-    t.b0.y = -t.b0.y;
-    t.b1.y = -t.b1.y;
-  }
+  const float2 w1 = tw[((tid / P::R0) * P::R0) & (N - 1)];
+  t.b0            = make_cf(w0.x, SIGN < 0 ? -w0.y : w0.y);
+  t.b1            = make_cf(w1.x, SIGN < 0 ? -w1.y : w1.y);
   return t;
 }
 
 // First Stockham stage on registers a[k] = x[tid + k N/R0]: y[R0 p + j] = DFT(a)[j] * w^(j p), p = tid, S = 1.
 template <int SIGN, int N>
-__device__ __forceinline__ void stage_first(float2 (&a)[Plan<N>::R0], float2 base, float2* lds, uint32_t tid)
+__device__ __forceinline__ void stage_first(cf (&a)[Plan<N>::R0], cf base, cf* lds, uint32_t tid)
 {
   constexpr int R  = Plan<N>::R0;
   constexpr int NB = N / R;
@@ -222,13 +279,13 @@ __device__ __forceinline__ void stage_first(float2 (&a)[Plan<N>::R0], float2 bas
 // A later Stockham stage (decimation in frequency, autosort).  n = N / S is the current transform length.
 //   a[k] = x[q + S (p + k n/R)],   y[q + S (R p + j)] = DFT_R(a)[j] * w_n^(j p),   p < n/R, q < S.
 template <int SIGN, int N, int T, int R, int S, bool LAST, typename Store>
-__device__ __forceinline__ void stage_lds(float2* lds, const float2* __restrict__ tw, float2 base, uint32_t tid,
+__device__ __forceinline__ void stage_lds(cf* lds, const float2* __restrict__ tw, cf base, uint32_t tid,
                                           Store store)
 {
   constexpr int NB    = N / R;
   constexpr int ITERS = (NB + T - 1) / T;
   constexpr int n1    = N / S / R;
-  float2        a[ITERS][R];
+  cf            a[ITERS][R];
 #pragma unroll
   for (int it = 0; it != ITERS; ++it) {
     uint32_t b = tid + it * T;
@@ -248,23 +305,21 @@ __device__ __forceinline__ void stage_lds(float2* lds, const float2* __restrict_
       uint32_t p = b / S, q = b % S;
       Butterfly<SIGN, R>::run(a[it]);
       if (n1 > 1) {
-        float2 bs = base;
+        cf bs = base;
         if (it > 0) { // p differs per iteration: fetch this iteration's base (rare plans only)
-          bs = tw[(p * S) & (N - 1)];
-          if (SIGN < 0) {
-            bs.y = -bs.y;
-          }
+          const float2 w = tw[(p * S) & (N - 1)];
+          bs             = make_cf(w.x, SIGN < 0 ? -w.y : w.y);
         }
         apply_twiddle_powers<R>(bs, a[it]);
       }
+      if constexpr (LAST) {
+        // The last stage has S * R = N, hence p = 0: output index = q + S * j, a per-thread part and a constant.
+        static_assert(S * R == N, "last stage");
+        static_for<R>([&](auto J) { store(q, Const<S * decltype(J)::value>{}, Const<S>{}, a[it][decltype(J)::value]); });
+      } else {
 #pragma unroll
-      for (int j = 0; j != R; ++j) {
-        float2   v   = a[it][j];
-        uint32_t idx = q + S * (R * p + j);
-        if (LAST) {
-          store(idx, v);
-        } else {
-          lds[pad(idx)] = v;
+        for (int j = 0; j != R; ++j) {
+          lds[pad(q + S * (R * p + j))] = a[it][j];
         }
       }
     }
@@ -275,12 +330,12 @@ __device__ __forceinline__ void stage_lds(float2* lds, const float2* __restrict_
 }
 
 template <int SIGN, int N, typename Store>
-__device__ __forceinline__ void fft_from_registers(float2 (&a)[Plan<N>::R0], const TwiddleBase<N>& tb, float2* lds,
+__device__ __forceinline__ void fft_from_registers(cf (&a)[Plan<N>::R0], const TwiddleBase<N>& tb, cf* lds,
                                                    const float2* __restrict__ tw, uint32_t tid, Store store)
 {
   using P = Plan<N>;
   constexpr int T = P::T;
-  auto no_store   = [](uint32_t, float2) {};
+  auto no_store   = [](uint32_t, auto, auto, cf) {};
   stage_first<SIGN, N>(a, tb.b0, lds, tid);
   if constexpr (P::R2 == 1) {
     stage_lds<SIGN, N, T, P::R1, P::R0, true>(lds, tw, tb.b1, tid, store);
@@ -296,20 +351,29 @@ __device__ __forceinline__ void fft_from_registers(float2 (&a)[Plan<N>::R0], con
 // consecutive symbols of its (grid, port).  With SPW > 1 the next symbol's row is fetched while the current one is
 // transformed.
 // ================================================================================================================
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+// Cache policy of the IQ stores.  Non-temporal (aux = 2) was measured: +6 % in the arithmetic-free probe
+// (profiles/probes/stream_mix.hip, 16-byte stores) but -7 % in this kernel with its 8-byte stores; default it is.
+constexpr int AUX_NT = 0;
+
+// blockIdx = (symbol group, port, grid): no index arithmetic to undo, every per-symbol quantity is wave-uniform and
+// lives in SGPRs.  A workgroup modulates SPW consecutive symbols of its (grid, port); the row of the next symbol is
+// fetched into registers before the current one is transformed, so reads stay in flight during the butterflies.
+// The row is read through a buffer descriptor sized to the row: bin placement (ofdm_modulator_impl.cpp:83-87: lower
+// grid half -> top bins, upper half -> bins from DC, guard bins zero) is j = (i + rg_size / 2) mod N and the
+// hardware range check supplies the zeros of the guard bins.  The output goes through a second descriptor with the
+// constant part of every address in the scalar offset.
 template <int N>
-__device__ __forceinline__ void load_symbol_row(uint32_t (&a)[Plan<N>::R0], const uint32_t* __restrict__ row,
-                                                uint32_t half, uint32_t tid)
+__device__ __forceinline__ void load_symbol_row(uint32_t (&raw)[Plan<N>::R0], const OfdmLaunch& p,
+                                                const uint32_t* row, uint32_t t4)
 {
-  // Bin placement (ofdm_modulator_impl.cpp:83-87): lower grid half -> top bins, upper half -> bins from DC, guard
-  // bins zero.  Branch-free: guard bins read element 0 and discard it.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t*>(row), 0, (int)((p.probe & 2u) ? 0u : p.rg_size * 4u), 0x00020000);
 #pragma unroll
   for (int k = 0; k != Plan<N>::R0; ++k) {
-    const uint32_t i   = first_stage_index<N>(tid, k);
-    const bool     lo  = i < half;
-    const bool     hi  = (i >= N - half) && (i < N);
-    const uint32_t idx = lo ? i + half : (hi ? i - (N - half) : 0u);
-    const uint32_t v   = row[idx];
-    a[k]               = (lo || hi) ? v : 0u; // cbf16: real in the low half, imaginary in the high half
+    const uint32_t off = (t4 + (uint32_t)k * (N / Plan<N>::R0) * 4u) & (4u * N - 1u);
+    raw[k]             = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
   }
 }
 
@@ -318,57 +382,70 @@ __global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const ui
                                                           const uint32_t* __restrict__ d_slot_index,
                                                           float2* __restrict__ d_iq)
 {
-  __shared__ float2 lds[N + N / 16 + 16];
-  const uint32_t    tid_in = threadIdx.x;
-  const uint32_t    groups = (p.nsymb + SPW - 1) / SPW;
-  const uint32_t    gp     = blockIdx.x / groups; // grid * nof_ports + port
-  const uint32_t    l0     = (blockIdx.x % groups) * SPW;
-  const uint32_t    l1     = (l0 + SPW < p.nsymb) ? l0 + SPW : p.nsymb;
-  const uint32_t    g      = gp / p.nof_ports;
-  const uint32_t    slot   = d_slot_index ? d_slot_index[g] : 0u;
-  const uint32_t    half   = p.rg_size >> 1;
-  const uint32_t*   rows   = d_grid + (size_t)gp * NRPHY_NSYMB * p.rg_size;
-  float2*           iq     = d_iq + (size_t)gp * p.slot_stride;
+  __shared__ cf     lds[N + N / 16 + 16];
+  const uint32_t    tid  = threadIdx.x;
+  const uint32_t    l0   = blockIdx.x * SPW;
+  const uint32_t    l1   = (l0 + SPW < p.nsymb) ? l0 + SPW : p.nsymb;
+  const uint32_t    gp   = blockIdx.z * p.nof_ports + blockIdx.y; // grid * nof_ports + port
+  const uint32_t    slot = d_slot_index ? to_constant(d_slot_index)[blockIdx.z] : 0u;
+  const uint32_t    t4   = (tid + (p.rg_size >> 1)) * 4u;
+  const uint32_t*   rows = d_grid + (size_t)gp * NRPHY_NSYMB * p.rg_size;
+  float2*           iq   = d_iq + (size_t)gp * p.slot_stride;
 
-  // NOTE: a symbol loop with a register prefetch of the next row was tried (SPW = 2..14): hipcc hoists the ~100
-  // loop-invariant per-thread LDS/global addresses of the three stages out of the loop, the kernel needs 226+
-  // VGPRs and one workgroup per CU stays resident; one symbol per workgroup at 127 VGPRs keeps four.
-  static_assert(SPW == 1, "one OFDM symbol per workgroup");
-  (void)l1;
-  const uint32_t       tid = tid_in;
-  const uint32_t       l   = l0;
-  const TwiddleBase<N> tb  = load_twiddle_base<+1, N>(p.twiddle, tid);
+  const TwiddleBase<N> tb = load_twiddle_base<+1, N>(p.twiddle, tid);
   uint32_t             raw[Plan<N>::R0];
-  load_symbol_row<N>(raw, rows + (size_t)l * p.rg_size, half, tid);
-  float2 cur[Plan<N>::R0];
+  load_symbol_row<N>(raw, p, rows + (size_t)l0 * p.rg_size, t4);
+  for (uint32_t l = l0; l < l1; ++l) {
+    cf cur[Plan<N>::R0];
 #pragma unroll
-  for (int k = 0; k != Plan<N>::R0; ++k) {
-    cur[k] = make_float2(__uint_as_float(raw[k] << 16), __uint_as_float(raw[k] & 0xFFFF0000u));
-  }
-  const uint32_t sym = slot * p.nsymb + l; // symbol index within the subframe
-  const uint32_t cp  = p.cp_len[sym];
-  const float2   ph  = p.phase[sym];
-  float2*        out = iq + p.sym_offset[sym];
-  // Phase compensation x scale, then the cyclic prefix is the tail of the symbol (ofdm_modulator_impl.cpp:92-99).
-  auto store = [&](uint32_t i, float2 v) {
-    float2 y    = cmul(v, ph);
-    out[cp + i] = y;
-    if (i >= N - cp) {
-      out[i - (N - cp)] = y;
+    for (int k = 0; k != Plan<N>::R0; ++k) {
+      cur[k] = make_cf(__uint_as_float(raw[k] << 16), __uint_as_float(raw[k] & 0xFFFF0000u)); // cbf16: re low, im high
     }
-  };
-  fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
+    if (SPW > 1 && l + 1 < l1) {
+      // The 16 load offsets are two instructions each; hidden from loop-invariant code motion they cost no
+      // registers across the butterflies.
+      uint32_t t4_now = t4;
+      asm volatile("" : "+v"(t4_now));
+      load_symbol_row<N>(raw, p, rows + (size_t)(l + 1) * p.rg_size, t4_now);
+    }
+    const uint32_t sym = slot * p.nsymb + l; // symbol index within the subframe
+    const uint32_t cp  = to_constant(p.cp_len)[sym];
+    const cf       ph  = make_cf(to_constant(p.phase)[sym].x, to_constant(p.phase)[sym].y);
+    const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
+        iq + to_constant(p.sym_offset)[sym], 0, (int)((p.probe & 1u) ? 0u : (N + cp) * 8u), 0x00020000);
+    // Phase compensation x scale, then the cyclic prefix is the tail of the symbol (ofdm_modulator_impl.cpp:92-99).
+    // The cyclic prefix never exceeds N / 4 (extended CP), so only the outputs of the last quarter test for it.
+    auto store = [&](uint32_t q, auto base, auto span, cf v) {
+      constexpr uint32_t B = decltype(base)::value, S = decltype(span)::value;
+      const cf           y = cmul_uniform(v, ph);
+      const u32x2_t      d = {__float_as_uint(y.x), __float_as_uint(y.y)};
+      __builtin_amdgcn_raw_buffer_store_b64(d, rsrc_out, (int)(q * 8u), (int)((cp + B) * 8u), AUX_NT);
+      if constexpr (B + S > N - N / 4) {
+        const uint32_t i = q + B;
+        if (i >= N - cp) {
+          __builtin_amdgcn_raw_buffer_store_b64(d, rsrc_out, (int)((i - (N - cp)) * 8u), 0, AUX_NT);
+        }
+      }
+    };
+    fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
+  }
 }
 
-constexpr int OFDM_SYMBOLS_PER_WG = 1;
+// Symbols per workgroup.  Measured at 1024 slots: 1 -> 0.512 ms, 7 (with the register prefetch) -> 0.519 ms; the
+// arithmetic-free probe of the same traffic (profiles/probes/stream_mix.hip) takes 0.495 ms, so the kernel sits at the
+// memory system's rate for this access shape either way and 1 keeps small batches spread over the chip.
+#ifndef NRPHY_OFDM_SPW
+#define NRPHY_OFDM_SPW 1
+#endif
+constexpr int OFDM_SYMBOLS_PER_WG = NRPHY_OFDM_SPW;
 
 template <int N>
 static hipError_t launch_ofdm_n(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* d_grid,
                                 const uint32_t* d_slot_index, float2* d_iq, hipStream_t stream)
 {
   constexpr int SPW    = OFDM_SYMBOLS_PER_WG;
-  uint32_t      blocks = nof_grids * p.nof_ports * ((p.nsymb + SPW - 1) / SPW);
-  hipLaunchKernelGGL((ofdm_kernel<N, SPW>), dim3(blocks), dim3(Plan<N>::T), 0, stream, p, d_grid, d_slot_index, d_iq);
+  hipLaunchKernelGGL((ofdm_kernel<N, SPW>), dim3((p.nsymb + SPW - 1) / SPW, p.nof_ports, nof_grids), dim3(Plan<N>::T), 0, stream, p,
+                     d_grid, d_slot_index, d_iq);
   return hipGetLastError();
 }
 
@@ -403,18 +480,19 @@ template <int SIGN, int N>
 __global__ __launch_bounds__(Plan<N>::T) void dft_kernel(const float2* __restrict__ tw, const float2* __restrict__ d_in,
                                                          float2* __restrict__ d_out)
 {
-  __shared__ float2 lds[N + N / 16 + 16];
+  __shared__ cf     lds[N + N / 16 + 16];
   const uint32_t    tid = threadIdx.x;
   const float2*     in  = d_in + (size_t)blockIdx.x * N;
   float2*           out = d_out + (size_t)blockIdx.x * N;
   const TwiddleBase<N> tb = load_twiddle_base<SIGN, N>(tw, tid);
-  float2            a[Plan<N>::R0];
+  cf                a[Plan<N>::R0];
 #pragma unroll
   for (int k = 0; k != Plan<N>::R0; ++k) {
-    uint32_t i = first_stage_index<N>(tid, k);
-    a[k]       = (i < N) ? in[i] : make_float2(0.f, 0.f);
+    const uint32_t i = first_stage_index<N>(tid, k);
+    const float2   v = (i < N) ? in[i] : make_float2(0.f, 0.f);
+    a[k]             = make_cf(v.x, v.y);
   }
-  auto store = [&](uint32_t i, float2 v) { out[i] = v; };
+  auto store = [&](uint32_t q, auto base, auto, cf v) { out[q + decltype(base)::value] = make_float2(v.x, v.y); };
   fft_from_registers<SIGN, N>(a, tb, lds, tw, tid, store);
 }
 
