@@ -6,7 +6,7 @@ import glob
 import sys
 
 root = sys.argv[1]
-for st in [1, 2, 3, 4, 0]:
+for st in [5, 6, 7, 1, 2, 3, 4, 0]:
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.defaultdict(set)
     for path in glob.glob("%s/stage%d/*/*counter_collection.csv" % (root, st)):

@@ -926,6 +926,10 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     pd.scr_offset = (uint32_t)plan->scr_words;
     pd.scr_words  = (d.codeword_bits + 31U) / 32U + 1U;
     plan->scr_words += (pd.scr_words + 3U) & ~3ULL;
+    // ... followed by one DM-RS sequence per DM-RS symbol.
+    pd.dmrs_seq_offset = (uint32_t)plan->scr_words;
+    pd.dmrs_seq_words  = (12U * (pd.end_prb - pd.dmrs_ref_rb) + 31U) / 32U + 1U;
+    plan->scr_words += ((uint64_t)pd.dmrs_seq_words * (unsigned)__builtin_popcount(pdu.dmrs_symbol_mask) + 3U) & ~3ULL;
     plan->n_cb += d.nof_codeblocks;
     plan->cw_offset.push_back(cw_bits);
     cw_bits += (d.codeword_bits + 31U) & ~31ULL;

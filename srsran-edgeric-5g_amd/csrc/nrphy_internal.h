@@ -95,6 +95,8 @@ struct PduDev {
   uint32_t dmrs_symbol_mask;
   uint32_t dmrs_c_init[NRPHY_NSYMB];
   uint32_t dmrs_ref_rb;
+  uint32_t dmrs_seq_offset; // word offset of the DM-RS sequences (one per DM-RS symbol, in symbol order)
+  uint32_t dmrs_seq_words;  // words per DM-RS symbol: sequence bits [0, 12 * (end_prb - dmrs_ref_rb))
   float    dmrs_amplitude;
   uint32_t prb_mask[2 * NRPHY_PRB_WORDS];
   uint32_t first_prb;

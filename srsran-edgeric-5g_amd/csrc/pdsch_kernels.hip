@@ -41,6 +41,15 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
     PduRef pd = *to_constant(&p.pdus[blockIdx.x]);
     gold_sequence_workgroup(p.gold, p.x1_words, pd.c_init, pd.scr_words, p.scr + pd.scr_offset, stage, threadIdx.x,
                             TB_CRC_THREADS);
+    // ... and the DM-RS sequence of every DM-RS symbol (dmrs_pdsch_processor_impl.cpp:84-106), from bit 0 to the
+    // last allocated PRB.
+    uint32_t* seq = p.scr + pd.dmrs_seq_offset;
+    for (uint32_t mask = pd.dmrs_symbol_mask; mask != 0; mask &= mask - 1u) { // workgroup-uniform
+      const uint32_t l = (uint32_t)__ffs(mask) - 1u;
+      gold_sequence_workgroup(p.gold, p.x1_words, pd.dmrs_c_init[l], pd.dmrs_seq_words, seq, stage, threadIdx.x,
+                              TB_CRC_THREADS);
+      seq += pd.dmrs_seq_words;
+    }
     return;
   }
   const auto*     wkc = to_constant(&p.crc_work[blockIdx.x - p.n_pdu]);
@@ -134,7 +143,8 @@ struct CbShared {
 // Fills lin with the K bits of codeblock `cb` (payload, TB CRC + zero padding on the last codeblock, CB CRC, filler
 // zeros) and zeroes the parity region up to `total_words`.
 __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* tbw, const uint32_t* tb_crc_ptr,
-                                       const GoldTables* tables, CbShared* sh, uint32_t total_words, uint32_t lane)
+                                       const GoldTables* tables, CbShared* sh, uint32_t total_words, uint32_t lane,
+                                       uint32_t profile_stage)
 {
   const bool     last    = (cb == pd.C - 1);
   const uint32_t used    = pd.info_bits - (last ? pd.tb_crc_bits + pd.zero_pad : 0u);
@@ -163,6 +173,9 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
     }
   }
   wave_sync();
+  if (profile_stage == 7) {
+    return;
+  }
   if (last && lane == 0) {
     or_bits_lds(sh->lin, used, *tb_crc_ptr << (32u - pd.tb_crc_bits), pd.tb_crc_bits);
   }
@@ -515,66 +528,86 @@ __device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, PduRef pd
 // DM-RS for PDSCH (TS 38.211 Section 7.4.1.1; reference: dmrs_pdsch_processor_impl.cpp:84-262, dmrs_helper.h:44-109,
 // resource_grid_mapper_impl.cpp:47-133).  One wavefront per (PDU, DM-RS symbol, 32-PRB chunk).
 // ================================================================================================================
-constexpr int DMRS_GOLD_WORDS = (DMRS_PRB_CHUNK * 12) / 32 + 8;
-
-// gold: LDS scratch of at least DMRS_GOLD_WORDS words.
-__device__ __forceinline__ void dmrs_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid,
-                                 uint32_t* gold, uint32_t lane)
+// The pilots of the wave's PRBs for one layer count: r(n) = a ((1 - 2 c(2n)) + j (1 - 2 c(2n + 1))) from the symbol's
+// sequence (generated by the prologue), CDM weights, precoding, mapping.  W: where the weights are read from
+// (constant address space = scalar loads for wideband precoding, global memory per lane otherwise).
+template <int L, typename W>
+__device__ __forceinline__ void dmrs_precode(float dr, float di, bool odd, uint32_t P, W w, uint32_t* out,
+                                             size_t port_stride)
 {
-  const auto*         wkc  = to_constant(&p.dmrs_work[item_index]);
-  const DmrsWork      wk   = {wkc->pdu, wkc->symbol, wkc->prb_begin, wkc->prb_end};
-  PduRef              pd   = *to_constant(&p.pdus[wk.pdu]);
-  const uint32_t      L = pd.nof_layers, P = pd.nof_ports;
+  // CDM (TS 38.211 Table 7.4.1.1.2-1): w_f = {+1, -1} on odd DM-RS ports flips every other pilot; w_t = +1 for
+  // ports 1000-1003.
+  const float sr = odd ? -dr : dr, si = odd ? -di : di;
+#pragma unroll 1
+  for (uint32_t port = 0; port != P; ++port) {
+#pragma unroll
+    for (int g = 0; g != (L + 1) / 2; ++g) {
+      float accr, acci;
+      cmul_ref(dr, di, w[2 * (port * L + 2 * g)], w[2 * (port * L + 2 * g) + 1], accr, acci);
+      if (2 * g + 1 < L) {
+        float pr, pi;
+        cmul_ref(sr, si, w[2 * (port * L + 2 * g + 1)], w[2 * (port * L + 2 * g + 1) + 1], pr, pi);
+        accr = __fadd_rn(accr, pr);
+        acci = __fadd_rn(acci, pi);
+      }
+      out[port * port_stride + g] = pack_cbf16(accr, acci);
+    }
+  }
+}
 
-  // Pilot r(n) uses c(2n), c(2n+1); PRB prb holds n = 6*(prb - ref) .. +5, i.e. sequence bits 12*(prb - ref) .. +11.
-  const uint32_t bit_first = 12u * (wk.prb_begin - pd.dmrs_ref_rb);
-  const uint32_t bit_end   = 12u * (wk.prb_end - pd.dmrs_ref_rb);
-  const uint32_t w0        = bit_first >> 5;
-  const uint32_t nwords    = ((bit_end + 31u) >> 5) - w0;
-  gold_generate_wave(p.gold, p.x1_words, pd.dmrs_c_init[wk.symbol], w0, nwords, gold, lane);
-
-  const float    a          = pd.dmrs_amplitude;
-  const uint32_t nof_items  = (wk.prb_end - wk.prb_begin) * 6u;
-  const size_t   grid_base  = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
-  const uint32_t nof_groups = (L + 1u) >> 1;
+template <int L>
+__device__ __forceinline__ void dmrs_items(const PdschLaunch& p, PduRef pd, const DmrsWork& wk,
+                                           uint32_t* __restrict__ d_grid, uint32_t lane)
+{
+  const uint32_t  P       = pd.nof_ports;
+  const uint32_t  ordinal = __popc(pd.dmrs_symbol_mask & ((1u << wk.symbol) - 1u));
+  const uint32_t* seq     = p.scr + pd.dmrs_seq_offset + ordinal * pd.dmrs_seq_words;
+  const float     a       = pd.dmrs_amplitude;
+  const uint32_t  nof_items = (wk.prb_end - wk.prb_begin) * 6u;
+  const size_t    port_stride = (size_t)NRPHY_NSYMB * p.grid_nof_subc;
+  uint32_t*       row = d_grid + (size_t)pd.grid_index * p.grid_nof_ports * port_stride + (size_t)wk.symbol * p.grid_nof_subc;
   for (uint32_t item = lane; item < nof_items; item += WAVE) {
     const uint32_t prb = wk.prb_begin + item / 6u;
     const uint32_t kp  = item % 6u;
     if (!((pd.prb_mask[prb >> 5] >> (prb & 31u)) & 1u)) {
       continue;
     }
-    const uint32_t bit = 12u * (prb - pd.dmrs_ref_rb) + 2u * kp - 32u * w0;
-    const uint32_t c0  = (gold[bit >> 5] >> (31u - (bit & 31u))) & 1u;
-    const uint32_t c1  = (gold[(bit + 1u) >> 5] >> (31u - ((bit + 1u) & 31u))) & 1u;
-    const float    dr  = c0 ? -a : a;
-    const float    di  = c1 ? -a : a;
-    const float*   w   = p.weights + pd.dmrs_weights_offset;
-    if (pd.nof_prg > 1) {
+    // Pilot r(n) uses c(2n), c(2n+1); PRB prb holds n = 6 (prb - ref) .. +5: an even bit and its neighbour.
+    const uint32_t bit  = 12u * (prb - pd.dmrs_ref_rb) + 2u * kp;
+    const uint32_t word = seq[bit >> 5] << (bit & 31u);
+    const float    dr   = (word & 0x80000000u) ? -a : a;
+    const float    di   = (word & 0x40000000u) ? -a : a;
+    uint32_t*      out  = row + 12u * prb + 2u * kp;
+    if (pd.nof_prg == 1) {
+      dmrs_precode<L>(dr, di, (kp & 1u) != 0, P, to_constant(p.weights + pd.dmrs_weights_offset), out, port_stride);
+    } else {
       uint32_t prg = (12u * prb) / pd.prg_size_subc;
       prg          = prg >= pd.nof_prg ? pd.nof_prg - 1 : prg;
-      w += 2u * prg * P * L;
+      dmrs_precode<L>(dr, di, (kp & 1u) != 0, P, p.weights + pd.dmrs_weights_offset + 2u * prg * P * L, out,
+                      port_stride);
     }
-    for (uint32_t group = 0; group != nof_groups; ++group) {
-      const uint32_t subc = 12u * prb + group + 2u * kp;
-      for (uint32_t port = 0; port != P; ++port) {
-        float accr = 0.f, acci = 0.f;
-        for (uint32_t j = 2u * group; j != 2u * group + 2u && j != L; ++j) {
-          // CDM: w_f = {+1, -1} on odd DM-RS ports flips every other pilot; w_t = +1 for ports 1000-1003.
-          const float sign = ((j & 1u) && (kp & 1u)) ? -1.f : 1.f;
-          float       pr, pi;
-          cmul_ref(sign * dr, sign * di, w[2 * (port * L + j)], w[2 * (port * L + j) + 1], pr, pi);
-          if (j == 2u * group) {
-            accr = pr;
-            acci = pi;
-          } else {
-            accr = __fadd_rn(accr, pr);
-            acci = __fadd_rn(acci, pi);
-          }
-        }
-        d_grid[grid_base + ((size_t)port * NRPHY_NSYMB + wk.symbol) * p.grid_nof_subc + subc] =
-            pack_cbf16(accr, acci);
-      }
-    }
+  }
+}
+
+__device__ __forceinline__ void dmrs_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid,
+                                          uint32_t lane)
+{
+  const auto*    wkc = to_constant(&p.dmrs_work[item_index]);
+  const DmrsWork wk  = {wkc->pdu, wkc->symbol, wkc->prb_begin, wkc->prb_end};
+  PduRef         pd  = *to_constant(&p.pdus[wk.pdu]);
+  switch (pd.nof_layers) { // wave-uniform
+    case 1:
+      dmrs_items<1>(p, pd, wk, d_grid, lane);
+      break;
+    case 2:
+      dmrs_items<2>(p, pd, wk, d_grid, lane);
+      break;
+    case 3:
+      dmrs_items<3>(p, pd, wk, d_grid, lane);
+      break;
+    default:
+      dmrs_items<4>(p, pd, wk, d_grid, lane);
+      break;
   }
 }
 
@@ -615,7 +648,7 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
   if (blockIdx.x >= p.n_work) { // wave-uniform
     const uint32_t extra = blockIdx.x - p.n_work;
     if (extra < p.n_dmrs_in_launch) {
-      dmrs_wave(p, extra, d_grid, dyn_lds, lane);
+      dmrs_wave(p, extra, d_grid, lane);
     } else {
       zero_wave(p, extra - p.n_dmrs_in_launch, d_grid, lane);
     }
@@ -631,10 +664,16 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
   const uint32_t      zc = pd.zc, kb = pd.kb;
 
   // 1. Segmentation + CRC attachment (the graph rows ride along: their loads overlap the transport block's).
+  if (p.profile_stage == 5) {
+    return;
+  }
   stage_graph(&p.graphs[pd.graph], pd.nof_rows, sh.graph, lane);
+  if (p.profile_stage == 6) {
+    return;
+  }
   const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
   build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), &p.tb_crc[wk.pdu], p.gold, &sh,
-                  total_words, lane);
+                  total_words, lane, p.profile_stage);
 
   if (p.profile_stage == 1) {
     return;
@@ -694,8 +733,7 @@ hipError_t launch_codeblocks(const PdschLaunch& p, const uint8_t* d_tb, uint32_t
 
 __global__ __launch_bounds__(WAVE) void dmrs_kernel(PdschLaunch p, uint32_t* __restrict__ d_grid)
 {
-  __shared__ uint32_t gold[DMRS_GOLD_WORDS];
-  dmrs_wave(p, blockIdx.x, d_grid, gold, threadIdx.x);
+  dmrs_wave(p, blockIdx.x, d_grid, threadIdx.x);
 }
 
 hipError_t launch_dmrs(const PdschLaunch& p, uint32_t* d_grid, hipStream_t stream)
