@@ -193,6 +193,34 @@ void build_gold_tables(GoldTables& t, std::vector<uint32_t>& x1_words)
     }
     t.crc24b_table[b] = r & (top - 1);
   }
+  {
+    auto mulx = [&](uint32_t a, unsigned e) { // a x^e mod g
+      for (unsigned s = 0; s != e; ++s) {
+        a <<= 1;
+        if (a & top) {
+          a ^= poly;
+        }
+      }
+      return a;
+    };
+    for (unsigned m = 0; m != CRC_POW_WORDS; ++m) {
+      for (unsigned n = 0; n != 6; ++n) {
+        uint32_t e = mulx(t.crc24b_pow32[m], 4 * n); // x^(32 m + 4 n)
+        // (v x^(4n)) x^(32m) for the 16 values of v, from the four single-bit products.
+        uint32_t bit[4];
+        for (unsigned k = 0; k != 4; ++k) {
+          bit[k] = mulx(e, k);
+        }
+        for (uint32_t nib = 0; nib != 16; ++nib) {
+          uint32_t acc = 0;
+          for (unsigned k = 0; k != 4; ++k) {
+            acc ^= ((nib >> k) & 1U) ? bit[k] : 0U;
+          }
+          t.crc24b_mul[m][n][nib] = acc;
+        }
+      }
+    }
+  }
   // Modulation tables: d = (1-2b0)[2^(h-1) - (1-2b2)[2^(h-2) - ...]] on the even bits, same on the odd bits for
   // the imaginary part (TS 38.211 Sections 5.1.3-5.1.6), h = Qm / 2.
   for (unsigned q = 0; q != 4; ++q) {

@@ -42,7 +42,10 @@ struct GoldTables {
   // sequence bits are linear in the state, so 31 lanes produce the 31 seed words of the word recurrence in parallel.
   uint32_t x2_head[32][32];
   uint32_t crc24b_pow32[CRC_POW_WORDS]; // x^(32 m) mod g_CRC24B(x): places a lane's partial CB-CRC
-  uint32_t crc24b_table[256];           // byte table of CRC24B
+  uint32_t crc24b_table[256];           // byte table of CRC24B: (b x^24) mod g
+  // crc24b_mul[m][n][v] = (v x^(4n)) x^(32 m) mod g: a lane's partial CB-CRC times x^(32 m), one look-up per nibble
+  // of the partial instead of a 24-step shift-and-add multiplication.
+  uint32_t crc24b_mul[CRC_POW_WORDS][6][16];
   // Modulation tables (TS 38.211 Section 5.1): qam_lut[Qm/2 - 1][index of Qm bits, first bit in the MSB] = the
   // un-normalised odd-integer symbol of the reference's ci8 table, as floats (re, im).
   float2 qam_lut[4][256];

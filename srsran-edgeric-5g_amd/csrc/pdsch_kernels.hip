@@ -203,10 +203,16 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
       }
       reg = crc_update_word(reg, word, sh->st->lut.crc_table, crc24b());
     }
-    if (b < nw && reg != 0) {
-      reg = crc_mulmod(reg, tables->crc24b_pow32[nw - b], crc24b());
+    // The lane's partial times x^(32 (nw - b)): six independent table look-ups (one per nibble).
+    uint32_t part = 0;
+    {
+      const uint32_t m = nw - b;
+#pragma unroll
+      for (uint32_t k = 0; k != 6; ++k) {
+        part ^= tables->crc24b_mul[m][k][(reg >> (4u * k)) & 15u];
+      }
     }
-    uint32_t crc = wave_xor(reg);
+    uint32_t crc = wave_xor(part);
     if (lane == 0) {
       or_bits_lds(sh->lin, n, crc << 8, 24);
     }
