@@ -115,6 +115,22 @@ __device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b, CrcPoly c
   return r;
 }
 
+// a * b mod poly for a below 2^order and any 32-bit polynomial b (Horner over the bits of b).
+__device__ __forceinline__ uint32_t crc_mulmod32(uint32_t a, uint32_t b, CrcPoly c)
+{
+  uint32_t top = 1u << c.order, r = 0;
+  for (int i = 31; i >= 0; --i) {
+    r <<= 1;
+    if (r & top) {
+      r ^= c.poly;
+    }
+    if ((b >> i) & 1u) {
+      r ^= a;
+    }
+  }
+  return r;
+}
+
 // x^e mod poly.
 __device__ __forceinline__ uint32_t crc_xpow(uint32_t e, CrcPoly c)
 {
@@ -223,28 +239,43 @@ __device__ inline void gold_generate_wave(const GoldTables* gold, const uint32_t
   wave_sync();
 }
 
-// Whole-sequence generator for one PDU, executed by a 256-thread workgroup: c(n) for n in [0, 32 * nwords) into
-// global memory.  Wave 0 seeds as above (jump to Nc, 31 parallel words).  Squaring the characteristic polynomial
-// 5 + j times lifts the recurrence to
+// Sequence generator for a 256-thread workgroup: c(n) for n in [32 first_word, 32 (first_word + nwords)) into global
+// memory (out[0] is word first_word).  Wave 0 seeds as above (jump to Nc + 32 first_word, 31 parallel words).
+// Squaring the characteristic polynomial 5 + j times lifts the recurrence to
 //   W[k] = W[k - 28 m] ^ W[k - 29 m] ^ W[k - 30 m] ^ W[k - 31 m],   m = 2^j,
 // which yields 28 m new words in parallel from 31 m known ones: the level rises as the known prefix grows, and from
-// m = 64 on every step produces 1792 words from a 4096-word LDS ring.  Per PDU this costs an order of magnitude fewer
-// instructions than generating each codeblock's slice in its own wave.
+// m = 64 on every step produces 1792 words from a 4096-word LDS ring.  The steps synchronise on LDS only; the x1
+// words of a block are requested one step before they are needed and the block is written out one step after it was
+// computed, so no step waits for global memory.
 constexpr uint32_t GOLD_RING_WORDS = 4096;
 constexpr uint32_t GOLD_MAX_LEVEL  = 64;
 
+// Workgroup barrier that orders LDS accesses only (a __syncthreads() would also drain the global loads and stores).
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <uint32_t NT>
 __device__ inline void gold_sequence_workgroup(const GoldTables* gold, const uint32_t* x1_words, uint32_t c_init,
-                                               uint32_t nwords, uint32_t* __restrict__ out, uint32_t* ring,
-                                               uint32_t tid, uint32_t nthreads)
+                                               uint32_t first_word, uint32_t nwords, uint32_t* __restrict__ out,
+                                               uint32_t* ring, uint32_t tid)
 {
   constexpr uint32_t MASK = GOLD_RING_WORDS - 1;
+  constexpr uint32_t PER  = (28u * GOLD_MAX_LEVEL + NT - 1u) / NT; // words per thread and step at the top level
   const uint32_t     lane = tid & (WAVE - 1);
+  if (nwords == 0) { // workgroup-uniform
+    return;
+  }
   if (tid < WAVE) {
-    uint32_t state = c_init & 0x7FFFFFFFu;
-    // Nc = 1600 = 2^6 + 2^9 + 2^10.
-    state = gold_matvec(gold->x2_jump[6], state, lane);
-    state = gold_matvec(gold->x2_jump[9], state, lane);
-    state = gold_matvec(gold->x2_jump[10], state, lane);
+    uint32_t       state  = c_init & 0x7FFFFFFFu;
+    const uint32_t offset = 1600u + 32u * first_word;
+#pragma unroll 1
+    for (uint32_t k = 0; k != GOLD_JUMP_BITS; ++k) {
+      if ((offset >> k) & 1u) { // wave-uniform
+        state = gold_matvec(gold->x2_jump[k], state, lane);
+      }
+    }
     if (lane < 31u) {
       uint32_t word = 0;
 #pragma unroll 8
@@ -252,27 +283,62 @@ __device__ inline void gold_sequence_workgroup(const GoldTables* gold, const uin
         word |= (__popc(gold->x2_head[t][lane] & state) & 1u) << (31u - t);
       }
       ring[lane] = word;
-      if (lane < nwords) {
-        out[lane] = word ^ x1_words[lane];
-      }
     }
   }
-  __syncthreads();
+  lds_barrier();
+  // The block computed last and its x1 words: written out while the next block is being computed.
+  uint32_t pw[PER], px[PER];
+  uint32_t pbeg = 0, pend = nwords < 31u ? nwords : 31u;
+#pragma unroll
+  for (uint32_t i = 0; i != PER; ++i) {
+    const uint32_t k = tid + i * NT;
+    pw[i]            = (k < pend) ? ring[k] : 0u;
+    px[i]            = (k < pend) ? x1_words[first_word + k] : 0u;
+  }
   uint32_t m = 1;
   for (uint32_t have = 31; have < nwords;) { // workgroup-uniform
     while (m < GOLD_MAX_LEVEL && have >= 62u * m) {
       m *= 2u;
     }
     const uint32_t end = have + 28u * m < nwords ? have + 28u * m : nwords;
-    for (uint32_t k = have + tid; k < end; k += nthreads) {
-      const uint32_t w = ring[(k - 28u * m) & MASK] ^ ring[(k - 29u * m) & MASK] ^ ring[(k - 30u * m) & MASK] ^
-                         ring[(k - 31u * m) & MASK];
-      ring[k & MASK] = w;
-      out[k]         = w ^ x1_words[k];
+    uint32_t       cw[PER], cx[PER];
+#pragma unroll
+    for (uint32_t i = 0; i != PER; ++i) {
+      const uint32_t k = have + tid + i * NT;
+      cx[i]            = (k < end) ? x1_words[first_word + k] : 0u;
     }
-    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i != PER; ++i) {
+      const uint32_t k = have + tid + i * NT;
+      cw[i]            = 0;
+      if (k < end) {
+        cw[i] = ring[(k - 28u * m) & MASK] ^ ring[(k - 29u * m) & MASK] ^ ring[(k - 30u * m) & MASK] ^
+                ring[(k - 31u * m) & MASK];
+        ring[k & MASK] = cw[i];
+      }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i != PER; ++i) {
+      const uint32_t k = pbeg + tid + i * NT;
+      if (k < pend) {
+        out[k] = pw[i] ^ px[i];
+      }
+      pw[i] = cw[i];
+      px[i] = cx[i];
+    }
+    pbeg = have;
+    pend = end;
+    lds_barrier();
     have = end;
   }
+#pragma unroll
+  for (uint32_t i = 0; i != PER; ++i) {
+    const uint32_t k = pbeg + tid + i * NT;
+    if (k < pend) {
+      out[k] = pw[i] ^ px[i];
+    }
+  }
+  lds_barrier(); // the ring is reused by the caller's next sequence
 }
 
 // round-to-nearest-even float -> bf16 exactly as the reference stores the grid

@@ -147,6 +147,60 @@ void mat_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) // out = a * b
   std::memcpy(out, tmp, sizeof(tmp));
 }
 
+// GF(2)[x] / g arithmetic of the transport-block CRC polynomials (order 24 or 16, `poly` with its leading term).
+struct CrcField {
+  uint32_t poly, order;
+  uint32_t mul(uint32_t a, uint32_t b) const // a below 2^order, b any 32-bit polynomial
+  {
+    const uint32_t top = 1U << order;
+    uint32_t       r   = 0;
+    for (int k = 31; k >= 0; --k) {
+      r <<= 1;
+      if (r & top) {
+        r ^= poly;
+      }
+      if ((b >> k) & 1U) {
+        r ^= a;
+      }
+    }
+    return r;
+  }
+  uint32_t xpow(int64_t e) const // x^e mod g; g(0) = 1 makes x invertible: x^-1 = (g - 1) / x
+  {
+    uint32_t base = (e >= 0) ? 2U : (poly >> 1);
+    uint64_t n    = (uint64_t)(e >= 0 ? e : -e);
+    uint32_t r    = 1;
+    while (n) {
+      if (n & 1U) {
+        r = mul(r, base);
+      }
+      base = mul(base, base);
+      n >>= 1;
+    }
+    return r;
+  }
+};
+const CrcField CRC24A_FIELD = {0x1864CFBU, 24};
+const CrcField CRC16_FIELD  = {0x11021U, 16};
+
+void build_tbcrc_tables(TbCrcTables& t)
+{
+  const CrcField* field[2] = {&CRC24A_FIELD, &CRC16_FIELD};
+  for (unsigned s = 0; s != 2; ++s) {
+    const CrcField& f  = *field[s];
+    const uint32_t  y1 = f.xpow(32 * 256), y2 = f.xpow(32 * 64);
+    for (unsigned k = 0; k != 4; ++k) {
+      for (uint32_t b = 0; b != 256; ++b) {
+        t.y1[s][k][b] = f.mul(y1, b << (8 * k));
+        t.y2[s][k][b] = f.mul(y2, b << (8 * k));
+      }
+    }
+    for (unsigned l = 0; l != 64; ++l) {
+      t.lane[s][l] = f.xpow(32 * (63 - (int)l));
+    }
+  }
+}
+
 void build_gold_tables(GoldTables& t, std::vector<uint32_t>& x1_words)
 {
   std::memset(&t, 0, sizeof(t));
@@ -273,6 +327,7 @@ struct nrphy_ctx {
   hipStream_t  stream   = nullptr;
   LiftedGraph* d_graphs = nullptr;
   GoldTables*  d_gold   = nullptr;
+  TbCrcTables* d_tbcrc  = nullptr;
   uint32_t*    d_x1     = nullptr;
   float2*      d_twiddle[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // 128 .. 4096
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
@@ -291,7 +346,6 @@ struct nrphy_pdsch_plan {
   uint16_t*             d_re_table = nullptr;
   uint32_t*             d_tb_crc = nullptr;
   CrcWork*              d_crc_work = nullptr;
-  uint32_t*             d_crc_pow = nullptr;
   ZeroWork*             d_zero_work = nullptr;
   ZeroSeg*              d_zero_segs = nullptr;
   uint32_t*             d_scr = nullptr;    // scrambling sequences, rewritten by every run's prologue
@@ -617,7 +671,10 @@ extern "C" int nrphy_create(nrphy_ctx_t** out, int device_id)
   std::vector<uint32_t> x1;
   build_gold_tables(gold, x1);
   ctx->graphs = graphs;
-  if (upload(&ctx->d_graphs, graphs.data(), graphs.size() * sizeof(LiftedGraph)) != hipSuccess ||
+  std::vector<TbCrcTables> tbcrc(1);
+  build_tbcrc_tables(tbcrc[0]);
+  if (upload(&ctx->d_tbcrc, tbcrc.data(), sizeof(TbCrcTables)) != hipSuccess ||
+      upload(&ctx->d_graphs, graphs.data(), graphs.size() * sizeof(LiftedGraph)) != hipSuccess ||
       upload(&ctx->d_gold, &gold, sizeof(gold)) != hipSuccess ||
       upload(&ctx->d_x1, x1.data(), x1.size() * sizeof(uint32_t)) != hipSuccess) {
     nrphy_destroy(ctx);
@@ -635,6 +692,7 @@ extern "C" int nrphy_destroy(nrphy_ctx_t* ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipFree(ctx->d_graphs);
   (void)hipFree(ctx->d_gold);
+  (void)hipFree(ctx->d_tbcrc);
   (void)hipFree(ctx->d_x1);
   for (float2* t : ctx->d_twiddle) {
     (void)hipFree(t);
@@ -726,8 +784,6 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   std::vector<DmrsWork> dmrs;
   std::vector<CrcWork>  crc_work;
   std::vector<std::vector<uint32_t>> pdus_of_grid(nof_grids);
-  std::vector<uint32_t> crc_pow;
-  std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint32_t>> crc_pow_index; // (bytes, order) -> (offset, chunk)
   std::vector<float>    weights;
   std::vector<uint16_t> re_table;
   std::vector<uint8_t>  mask(grid_nof_subc);
@@ -880,58 +936,13 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
       plan->dmrs_separate = true; // data is mapped on RE that also carry DM-RS: the reference lets DM-RS win
     }
     pdus_of_grid[g].push_back(i);
-    // TB-CRC work: ~64 bytes per thread; the per-thread factors x^(8 * bytes after the chunk) are shared by every
-    // PDU with the same transport block size.
+    // TB-CRC work: one workgroup per 16 KiB region of the transport block.
     {
-      const uint32_t n = pdu.tb_size_bytes, order = d.nof_tb_crc_bits;
-      auto           it = crc_pow_index.find({n, order});
-      if (it == crc_pow_index.end()) {
-        const uint32_t threads = divide_ceil(divide_ceil(n, TB_CRC_CHUNK_BYTES), 256) * 256;
-        const uint32_t chunk   = TB_CRC_CHUNK_BYTES;
-        const uint32_t poly = (order == 16) ? 0x11021U : 0x1864CFBU, top = 1U << order;
-        auto mulmod = [&](uint32_t a, uint32_t b) {
-          uint32_t r = 0;
-          for (int k = (int)order - 1; k >= 0; --k) {
-            r <<= 1;
-            if (r & top) {
-              r ^= poly;
-            }
-            if ((b >> k) & 1U) {
-              r ^= a;
-            }
-          }
-          return r;
-        };
-        auto xpow_bytes = [&](uint32_t nbytes) { // x^(8 nbytes) mod poly
-          uint32_t r = 1;
-          for (uint32_t k = 0; k != 8 * nbytes; ++k) {
-            r <<= 1;
-            if (r & top) {
-              r ^= poly;
-            }
-          }
-          return r;
-        };
-        const uint32_t offset   = (uint32_t)crc_pow.size();
-        const uint32_t nonempty = divide_ceil(n, chunk);
-        crc_pow.resize(offset + threads, 0);
-        const uint32_t xchunk = xpow_bytes(chunk);
-        uint32_t       pw     = 1; // thread nonempty-1 has nothing after it
-        crc_pow[offset + nonempty - 1] = pw;
-        if (nonempty > 1) {
-          pw                              = xpow_bytes(n - (nonempty - 1) * chunk); // bytes of the last chunk
-          crc_pow[offset + nonempty - 2] = pw;
-          for (int g = (int)nonempty - 3; g >= 0; --g) {
-            pw                   = mulmod(pw, xchunk);
-            crc_pow[offset + g] = pw;
-          }
-        }
-        it = crc_pow_index.insert({{n, order}, {offset, chunk}}).first;
-      }
-      const uint32_t offset = it->second.first, chunk = it->second.second;
-      const uint32_t threads = divide_ceil(divide_ceil(n, TB_CRC_CHUNK_BYTES), 256) * 256;
-      for (uint32_t t0 = 0; t0 < threads && t0 * chunk < n; t0 += 256) {
-        crc_work.push_back({i, t0, chunk, offset});
+      const CrcField& f = (d.nof_tb_crc_bits == 16) ? CRC16_FIELD : CRC24A_FIELD;
+      const uint32_t  n = pdu.tb_size_bytes;
+      for (uint32_t region = 0; region * TB_CRC_REGION_BYTES < n; ++region) {
+        const int64_t region_end = (int64_t)(region + 1) * TB_CRC_REGION_BYTES;
+        crc_work.push_back({i, region, f.xpow((int64_t)f.order + 8 * ((int64_t)n - region_end)), 0});
       }
     }
     // Work items: every codeblock owns a whole number of RE (rm_length is a multiple of nof_layers * Qm).
@@ -1037,7 +1048,6 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   plan->n_dmrs  = (uint32_t)dmrs.size();
   plan->n_crc_work = (uint32_t)crc_work.size();
   if (upload(&plan->d_crc_work, crc_work.data(), crc_work.size() * sizeof(CrcWork)) != hipSuccess ||
-      upload(&plan->d_crc_pow, crc_pow.data(), crc_pow.size() * sizeof(uint32_t)) != hipSuccess ||
       upload(&plan->d_pdus, plan->pdus.data(), plan->pdus.size() * sizeof(PduDev)) != hipSuccess ||
       upload(&plan->d_work, work.data(), work.size() * sizeof(CbWork)) != hipSuccess ||
       upload(&plan->d_dmrs, dmrs.data(), dmrs.size() * sizeof(DmrsWork)) != hipSuccess ||
@@ -1070,7 +1080,6 @@ extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
   (void)hipFree(plan->d_re_table);
   (void)hipFree(plan->d_tb_crc);
   (void)hipFree(plan->d_crc_work);
-  (void)hipFree(plan->d_crc_pow);
   (void)hipFree(plan->d_zero_work);
   (void)hipFree(plan->d_zero_segs);
   (void)hipFree(plan->d_scr);
@@ -1109,7 +1118,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.work           = plan->d_work;
   p.dmrs_work      = plan->d_dmrs;
   p.crc_work       = plan->d_crc_work;
-  p.crc_pow        = plan->d_crc_pow;
+  p.tbcrc          = ctx->d_tbcrc;
   p.n_crc_work     = plan->n_crc_work;
   p.weights        = plan->d_weights;
   p.re_table       = plan->d_re_table;

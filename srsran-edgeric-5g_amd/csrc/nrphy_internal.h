@@ -34,6 +34,8 @@ struct LiftedGraph {
 constexpr int GOLD_JUMP_BITS  = 24;
 constexpr int GOLD_X1_WORDS   = 1 << 16; // x1(n + 1600) for n < 2^21 bits, MSB-first words
 
+constexpr uint32_t SCR_PARTS = 4; // workgroups sharing the scrambling sequence of one PDU (prologue)
+
 constexpr int CRC_POW_WORDS = 288;     // >= 8448 / 32 + 1
 
 struct GoldTables {
@@ -116,7 +118,18 @@ struct CbWork {
 
 // One workgroup of the DM-RS kernel: OFDM symbol `symbol` of PDU `pdu`.
 constexpr int DMRS_PRB_CHUNK = 32; // PRBs per DM-RS wavefront
-constexpr uint32_t TB_CRC_CHUNK_BYTES = 64; // transport-block bytes per TB-CRC thread (upper bound)
+// Transport-block CRC: one 256-thread workgroup reduces a 16 KiB region of the transport block.
+constexpr uint32_t TB_CRC_REGION_WORDS = 4096;
+constexpr uint32_t TB_CRC_REGION_BYTES = 4 * TB_CRC_REGION_WORDS;
+
+// Tables of the transport-block CRC, per polynomial ([0] CRC24A, [1] CRC16).  Thread t of a workgroup owns the words
+// t, t + 256, ... of the region and runs Horner's rule in y1 = x^(32 * 256); 64 lanes then fold the 256 partials with
+// y2 = x^(32 * 64).  y[k][b] = (b x^(8k)) y mod g, so that a 32-bit partial advances with four independent look-ups.
+struct TbCrcTables {
+  uint32_t y1[2][4][256];
+  uint32_t y2[2][4][256];
+  uint32_t lane[2][64]; // x^(32 (63 - l)) mod g
+};
 
 struct DmrsWork {
   uint32_t pdu;
@@ -125,13 +138,15 @@ struct DmrsWork {
   uint32_t prb_end;
 };
 
-// One 256-thread workgroup of the TB-CRC kernel: threads [thread_begin, thread_begin + 256) of the PDU's split;
-// thread g reduces bytes [g * chunk, (g+1) * chunk) and scales by crc_pow[pow_offset + g] = x^(8 * bytes after).
+// One 256-thread workgroup of the TB-CRC role: region `region` (16 KiB) of the PDU's transport block.  The region
+// is reduced as if the transport block were zero-extended to the region's end; `factor` = x^(order + 8 (bytes - region
+// end)) mod g (a negative exponent for the last region: x is invertible mod g) turns that into the region's share of
+// the CRC.
 struct CrcWork {
   uint32_t pdu;
-  uint32_t thread_begin;
-  uint32_t chunk;      // bytes per thread, multiple of 4
-  uint32_t pow_offset; // into the plan's crc_pow table
+  uint32_t region;
+  uint32_t factor;
+  uint32_t pad_;
 };
 
 // Grid words no PDU of the plan maps must read as zero (resource_grid::set_all_zero in the reference).  Instead of
@@ -161,7 +176,7 @@ struct PdschLaunch {
   const CbWork*      work;
   const DmrsWork*    dmrs_work;
   const CrcWork*     crc_work;
-  const uint32_t*    crc_pow;
+  const TbCrcTables* tbcrc;
   uint32_t           n_crc_work;
   const float*       weights;
   const uint16_t*    re_table;

@@ -17,95 +17,111 @@
 namespace nrphy {
 
 // ================================================================================================================
+// Prologue: per-PDU work the codeblock waves consume.
+//
 // Transport block CRC (TS 38.212 Section 5.1; reference: ldpc_segmenter_impl.cpp:126, crc_calculator_lut_impl.cpp).
-// CRC(M) = sum_t CRC(chunk_t) * x^(8 * bytes after chunk_t) mod g(x): the chunks are independent, the combine is an
-// XOR, so a transport block is spread over as many 256-thread workgroups as it takes to give each thread ~64 bytes.
+// A CRC is the remainder of a polynomial, so it splits: the transport block is cut into 16 KiB regions (one
+// workgroup each, any number per PDU, combined with an atomic XOR); inside a region thread t owns the words
+// t, t + 256, ... (coalesced loads straight from HBM, no staging) and evaluates them with Horner's rule in
+// y1 = x^(32 * 256) -- the same recurrence in every thread, four independent table look-ups per word; the 256
+// partials are the words of a 256-word message that one wavefront folds the same way with y2 = x^(32 * 64), and
+// only those 64 lanes pay for a multiplication by a per-lane constant.
+//
+// Scrambling and DM-RS sequences: see gold_sequence_workgroup().
 // ================================================================================================================
-constexpr int      TB_CRC_THREADS     = 256;
-constexpr uint32_t TB_CRC_CHUNK_WORDS = TB_CRC_CHUNK_BYTES / 4; // words per thread (the plan uses exactly this chunk)
+constexpr int TB_CRC_THREADS = 256;
+static_assert(TB_CRC_REGION_WORDS == 16 * TB_CRC_THREADS, "sixteen words per thread");
 
-static_assert(TB_CRC_THREADS * (TB_CRC_CHUNK_WORDS + 1) >= GOLD_RING_WORDS, "the Gold ring reuses the CRC staging area");
+// reg * y mod g for a 32-bit partial, y's table in LDS: tab[k * 256 + b] = (b x^(8k)) y mod g.
+__device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t reg)
+{
+  return tab[reg & 0xFFu] ^ tab[256u + ((reg >> 8) & 0xFFu)] ^ tab[512u + ((reg >> 16) & 0xFFu)] ^ tab[768u + (reg >> 24)];
+}
 
-// Blocks [0, n_pdu): scrambling sequence of one PDU (TS 38.211 Section 7.3.1.1; reference:
-// pdsch_modulator_impl.cpp:43-60 runs the generator once per codeword too).  Blocks [n_pdu, n_pdu + n_crc_work):
+// Blocks [0, SCR_PARTS n_pdu): scrambling sequence (a quarter each) and DM-RS sequences of one PDU (TS 38.211 Sections 7.3.1.1, 7.4.1.1.1;
+// reference: pdsch_modulator_impl.cpp:43-60, dmrs_pdsch_processor_impl.cpp:84-106).  The blocks after them:
 // transport-block CRC.
 __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
 {
-  __shared__ uint32_t table[256];
-  __shared__ uint32_t partial[TB_CRC_THREADS / WAVE];
-  // The workgroup's 16 KiB of the transport block, staged with coalesced loads; thread t then walks words
-  // [17 t, 17 t + 16): the odd stride keeps the 64 lanes on different banks.
-  __shared__ uint32_t stage[TB_CRC_THREADS * (TB_CRC_CHUNK_WORDS + 1)];
+  __shared__ uint32_t lds[GOLD_RING_WORDS]; // Gold ring, or the CRC role's two tables and partials
+  static_assert(GOLD_RING_WORDS >= 2 * 1024 + TB_CRC_THREADS, "LDS of the CRC role");
+  const uint32_t tid = threadIdx.x;
 
-  if (blockIdx.x < p.n_pdu) { // workgroup-uniform; first in the grid: these have the longest dependent chain
-    PduRef pd = *to_constant(&p.pdus[blockIdx.x]);
-    gold_sequence_workgroup(p.gold, p.x1_words, pd.c_init, pd.scr_words, p.scr + pd.scr_offset, stage, threadIdx.x,
-                            TB_CRC_THREADS);
-    // ... and the DM-RS sequence of every DM-RS symbol (dmrs_pdsch_processor_impl.cpp:84-106), from bit 0 to the
-    // last allocated PRB.
-    uint32_t* seq = p.scr + pd.dmrs_seq_offset;
-    for (uint32_t mask = pd.dmrs_symbol_mask; mask != 0; mask &= mask - 1u) { // workgroup-uniform
-      const uint32_t l = (uint32_t)__ffs(mask) - 1u;
-      gold_sequence_workgroup(p.gold, p.x1_words, pd.dmrs_c_init[l], pd.dmrs_seq_words, seq, stage, threadIdx.x,
-                              TB_CRC_THREADS);
-      seq += pd.dmrs_seq_words;
+  if (blockIdx.x < p.n_pdu * SCR_PARTS) { // workgroup-uniform; first in the grid: the longest dependent chains
+    if (p.profile_stage == 8) {
+      return;
+    }
+    const uint32_t part = blockIdx.x % SCR_PARTS;
+    PduRef         pd   = *to_constant(&p.pdus[blockIdx.x / SCR_PARTS]);
+    // This workgroup's quarter of the scrambling sequence: the generator jumps straight to its first word.
+    const uint32_t chunk = (pd.scr_words + SCR_PARTS - 1u) / SCR_PARTS;
+    const uint32_t first = part * chunk < pd.scr_words ? part * chunk : pd.scr_words;
+    const uint32_t count = pd.scr_words - first < chunk ? pd.scr_words - first : chunk;
+    gold_sequence_workgroup<TB_CRC_THREADS>(p.gold, p.x1_words, pd.c_init, first, count, p.scr + pd.scr_offset + first,
+                                            lds, tid);
+    // The DM-RS sequences, from bit 0 to the last allocated PRB, dealt out over the PDU's workgroups.
+    uint32_t ordinal = 0;
+    for (uint32_t mask = pd.dmrs_symbol_mask; mask != 0; mask &= mask - 1u, ++ordinal) { // workgroup-uniform
+      if (ordinal % SCR_PARTS == part) {
+        const uint32_t l = (uint32_t)__ffs(mask) - 1u;
+        gold_sequence_workgroup<TB_CRC_THREADS>(p.gold, p.x1_words, pd.dmrs_c_init[l], 0, pd.dmrs_seq_words,
+                                                p.scr + pd.dmrs_seq_offset + ordinal * pd.dmrs_seq_words, lds, tid);
+      }
     }
     return;
   }
-  const auto*     wkc = to_constant(&p.crc_work[blockIdx.x - p.n_pdu]);
-  const CrcWork   wk  = {wkc->pdu, wkc->thread_begin, wkc->chunk, wkc->pow_offset};
-  PduRef          pd  = *to_constant(&p.pdus[wk.pdu]);
-  const uint32_t  tid = threadIdx.x;
-  const CrcPoly   c   = (pd.tb_crc_bits == 16) ? crc16() : crc24a();
+
+  if (p.profile_stage == 9) {
+    return;
+  }
+  const auto*     wkc = to_constant(&p.crc_work[blockIdx.x - p.n_pdu * SCR_PARTS]);
+  const uint32_t  wk_pdu = wkc->pdu, wk_region = wkc->region, wk_factor = wkc->factor;
+  PduRef          pd  = *to_constant(&p.pdus[wk_pdu]);
+  const uint32_t  sel = (pd.tb_crc_bits == 16) ? 1u : 0u;
+  const CrcPoly   c   = sel ? crc16() : crc24a();
   const uint32_t  n   = pd.tb_bytes;
-  const uint32_t* w   = reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset);
+  const uint32_t* tbw = reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset);
+  uint32_t*       y1  = lds;
+  uint32_t*       y2  = lds + 1024;
+  uint32_t*       msg = lds + 2048;
 
-  table[tid] = crc_table_entry(tid, c);
-  const uint32_t word0  = wk.thread_begin * TB_CRC_CHUNK_WORDS; // first word of the workgroup's region
-  const uint32_t nwords = (n + 3u) >> 2;                        // words holding transport block bytes
+  // The region's words (zero beyond the transport block, bytes beyond its end masked off).
+  const uint32_t nwords = (n + 3u) >> 2;
+  const uint32_t word0  = wk_region * TB_CRC_REGION_WORDS + tid;
+  uint32_t       w[16];
 #pragma unroll
-  for (uint32_t it = 0; it != TB_CRC_CHUNK_WORDS; ++it) {
-    const uint32_t i  = it * TB_CRC_THREADS + tid; // word within the region: consecutive lanes, consecutive words
-    const uint32_t gw = word0 + i;
-    const uint32_t v  = (gw < nwords) ? be_word(w, gw) : 0u;
-    stage[(i / TB_CRC_CHUNK_WORDS) * (TB_CRC_CHUNK_WORDS + 1) + (i % TB_CRC_CHUNK_WORDS)] = v;
+  for (int i = 0; i != 16; ++i) {
+    const uint32_t idx = word0 + (uint32_t)i * TB_CRC_THREADS;
+    w[i]               = (idx < nwords) ? be_word(tbw, idx) : 0u;
+    if ((n & 3u) != 0 && idx + 1u == nwords) {
+      w[i] &= 0xFFFFFFFFu << (8u * (4u - (n & 3u)));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k != 4; ++k) {
+    y1[k * 256 + tid] = p.tbcrc->y1[sel][k][tid];
+    y2[k * 256 + tid] = p.tbcrc->y2[sel][k][tid];
   }
   __syncthreads();
-
-  const uint32_t g     = wk.thread_begin + tid;
-  const uint32_t begin = g * TB_CRC_CHUNK_BYTES;
-  uint32_t       reg   = 0;
-  if (begin < n) {
-    const uint32_t  len  = (n - begin < TB_CRC_CHUNK_BYTES) ? n - begin : TB_CRC_CHUNK_BYTES;
-    const uint32_t* mine = &stage[tid * (TB_CRC_CHUNK_WORDS + 1)];
-    const uint32_t  nfull = len >> 2;
-    for (uint32_t i = 0; i != nfull; ++i) {
-      reg = crc_update_word(reg, mine[i], table, c);
-    }
-    const uint32_t tail = len & 3u;
-    if (tail) {
-      // The last word is only partially inside the transport block: shift its bytes in one by one.
-      const uint32_t word = mine[nfull];
-      const uint32_t mask = (1u << c.order) - 1u, sh = c.order - 8u;
-      for (uint32_t k = 0; k != tail; ++k) {
-        uint32_t byte = (word >> (24 - 8 * k)) & 0xFFu;
-        uint32_t idx  = ((reg >> sh) ^ byte) & 0xFFu;
-        reg           = ((reg << 8) & mask) ^ table[idx];
-      }
-    }
-    reg = crc_mulmod(reg, p.crc_pow[wk.pow_offset + g], c);
+  uint32_t reg = w[0];
+#pragma unroll
+  for (int i = 1; i != 16; ++i) {
+    reg = crc_advance(y1, reg) ^ w[i];
   }
-  reg = wave_xor(reg);
-  if ((tid & (WAVE - 1)) == 0) {
-    partial[tid / WAVE] = reg;
-  }
+  msg[tid] = reg;
   __syncthreads();
-  if (tid == 0) {
-    uint32_t crc = 0;
-    for (int i = 0; i != TB_CRC_THREADS / WAVE; ++i) {
-      crc ^= partial[i];
+  if (tid < WAVE) {
+    uint32_t r = msg[tid];
+#pragma unroll
+    for (int j = 1; j != 4; ++j) {
+      r = crc_advance(y2, r) ^ msg[tid + WAVE * j];
     }
-    atomicXor(&p.tb_crc[wk.pdu], crc); // the accumulator was cleared by the previous run (or at plan creation)
+    r = crc_mulmod32(p.tbcrc->lane[sel][tid], r, c);
+    r = wave_xor(r);
+    if (tid == 0) {
+      // The accumulator was cleared by the previous run (or at plan creation).
+      atomicXor(&p.tb_crc[wk_pdu], crc_mulmod(r, wk_factor, c));
+    }
   }
 }
 
@@ -114,7 +130,8 @@ hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, hipStream_
   if (p.n_crc_work + p.n_pdu == 0) {
     return hipSuccess;
   }
-  hipLaunchKernelGGL(prologue_kernel, dim3(p.n_crc_work + p.n_pdu), dim3(TB_CRC_THREADS), 0, stream, p, d_tb);
+  hipLaunchKernelGGL(prologue_kernel, dim3(p.n_crc_work + p.n_pdu * SCR_PARTS), dim3(TB_CRC_THREADS), 0, stream, p,
+                     d_tb);
   return hipGetLastError();
 }
 
