@@ -33,10 +33,14 @@ __device__ __forceinline__ uint32_t topmask(uint32_t n)
 }
 
 // 32 bits starting at bit `pos` of the MSB-first bit array `a` (reads words pos/32 and pos/32 + 1).
+// Both words come from one unconditional two-dword load (ds_read2_b32 / global_load_dwordx2): written as two scalar
+// loads, the compiler guards the second one with a divergent branch on pos % 32 != 0.
+typedef uint32_t u32x2_unaligned __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ uint32_t ext32(const uint32_t* a, uint32_t pos)
 {
-  uint32_t w = pos >> 5, sh = pos & 31u;
-  return __funnelshift_l(a[w + 1], a[w], sh);
+  const u32x2_unaligned v  = *reinterpret_cast<const u32x2_unaligned*>(a + (pos >> 5));
+  const uint32_t        sh = pos & 31u;
+  return (v.x << sh) | ((v.y >> 1) >> (31u - sh)); // upper word of (v.x : v.y) << sh, sh = 0 included
 }
 
 // Big-endian 32-bit load from a byte stream viewed as words: word i = bytes 4i..4i+3, first byte in the MSBs.

@@ -668,6 +668,9 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
   sh.graph = sh.symb + p.lds_symb_words;
   sh.st    = &st;
   const uint32_t      lane = threadIdx.x;
+  if (p.profile_stage == 10) {
+    return;
+  }
   if (blockIdx.x >= p.n_work) { // wave-uniform
     const uint32_t extra = blockIdx.x - p.n_work;
     if (extra < p.n_dmrs_in_launch) {
@@ -681,7 +684,16 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
   if (blockIdx.x * WAVE < p.n_pdu && blockIdx.x * WAVE + lane < p.n_pdu) {
     p.tb_crc_next[blockIdx.x * WAVE + lane] = 0u;
   }
-  const auto*         wkc  = to_constant(&p.work[blockIdx.x]);
+  // Workgroups go to the eight XCDs round-robin (block b runs on XCD b % 8).  Give each XCD a contiguous run of work
+  // items, so that codeblocks which share cache lines -- neighbours in the transport block and in the grid rows --
+  // meet in one L2 instead of leaving partial lines in two.
+  uint32_t item = blockIdx.x;
+  {
+    const uint32_t xcd = blockIdx.x & 7u, turn = blockIdx.x >> 3;
+    const uint32_t q = p.n_work >> 3, r = p.n_work & 7u;
+    item = xcd * q + (xcd < r ? xcd : r) + turn;
+  }
+  const auto*         wkc  = to_constant(&p.work[item]);
   const CbWork        wk   = {wkc->pdu, wkc->cb, wkc->re_begin, wkc->re_count};
   PduRef              pd   = *to_constant(&p.pdus[wk.pdu]);
   const uint32_t      zc = pd.zc, kb = pd.kb;
