@@ -66,9 +66,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--slots", type=int, default=1024, help="slots per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="2: the batch is processed as two half-batches on two HIP streams, staggered so that the "
-                         "memory-bound OFDM launch of one half overlaps the VALU-bound PDSCH launches of the other")
     args = ap.parse_args()
 
     import torch
@@ -101,29 +98,9 @@ def main():
     d_slot = torch.tensor([i % 2 for i in range(slots)], dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
 
-    if args.streams == 2:
-        half = slots // 2
-        plan_a = lib.PdschPlan(ctx, pdus[:half], [i * stride for i in range(half)], list(range(half)), half,
-                               nof_ports, nof_subc)
-        plan_b = lib.PdschPlan(ctx, pdus[half:], [i * stride for i in range(slots - half)],
-                               list(range(slots - half)), slots - half, nof_ports, nof_subc)
-        s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
-        ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
-
-        def step():
-            # PDSCH(A) -> [OFDM(A) || PDSCH(B)] -> [OFDM(B) || PDSCH(A) of the next step]
-            s_a.wait_event(ev_b)
-            plan_a.run(d_tb[:half], d_grid[:half], zero_grids=True, stream=s_a.cuda_stream)
-            ev_a.record(s_a)
-            oplan.run(half, d_grid[:half], d_iq[:half], d_slot_index=d_slot[:half], stream=s_a.cuda_stream)
-            s_b.wait_event(ev_a)
-            plan_b.run(d_tb[half:], d_grid[half:], zero_grids=True, stream=s_b.cuda_stream)
-            ev_b.record(s_b)
-            oplan.run(slots - half, d_grid[half:], d_iq[half:], d_slot_index=d_slot[half:], stream=s_b.cuda_stream)
-    else:
-        def step():
-            plan.run(d_tb, d_grid, zero_grids=True)
-            oplan.run(slots, d_grid, d_iq, d_slot_index=d_slot)
+    def step():
+        plan.run(d_tb, d_grid, zero_grids=True)
+        oplan.run(slots, d_grid, d_iq, d_slot_index=d_slot)
 
     def barrier():
         if dist is not None:
@@ -132,9 +109,8 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx.synchronize()
-    timed_plan = plan_a if args.streams == 2 else plan
-    timed_plan.enable_timing(args.steps)
-    oplan.enable_timing(args.steps * args.streams)
+    plan.enable_timing(args.steps)
+    oplan.enable_timing(args.steps)
     barrier()
     torch.cuda.synchronize()
     ctx.synchronize()
@@ -150,7 +126,7 @@ def main():
     total_slots, total_samples, dt = backends.pkg.sharding.aggregate(
         dist, torch.device("cuda", local_rank), slots * args.steps, slots * args.steps * samples_per_slot, dt)
 
-    (ms_crc, ms_cb, ms_dmrs, ms_run), _ = timed_plan.kernel_times()
+    (ms_crc, ms_cb, ms_dmrs, ms_run), _ = plan.kernel_times()
     ms_ofdm, _ = oplan.kernel_time()
 
     if rank == 0:

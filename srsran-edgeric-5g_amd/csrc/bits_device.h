@@ -299,47 +299,58 @@ __device__ inline void gold_sequence_workgroup(const GoldTables* gold, const uin
     pw[i]            = (k < pend) ? ring[k] : 0u;
     px[i]            = (k < pend) ? x1_words[first_word + k] : 0u;
   }
-  uint32_t m = 1;
-  for (uint32_t have = 31; have < nwords;) { // workgroup-uniform
+  // One step: request the x1 words of the next block, compute the block into `nw`, write out the previous block
+  // (`ow`, `ox`: its x1 words were requested a step ago).  The two register sets swap roles from step to step --
+  // copying them would make every step wait for the loads it has just issued.
+  uint32_t m = 1, have = 31;
+  auto step = [&](uint32_t (&nw)[PER], uint32_t (&nx)[PER], const uint32_t (&ow)[PER], const uint32_t (&ox)[PER]) {
     while (m < GOLD_MAX_LEVEL && have >= 62u * m) {
       m *= 2u;
     }
     const uint32_t end = have + 28u * m < nwords ? have + 28u * m : nwords;
-    uint32_t       cw[PER], cx[PER];
 #pragma unroll
     for (uint32_t i = 0; i != PER; ++i) {
       const uint32_t k = have + tid + i * NT;
-      cx[i]            = (k < end) ? x1_words[first_word + k] : 0u;
+      nx[i]            = (k < end) ? x1_words[first_word + k] : 0u;
     }
 #pragma unroll
     for (uint32_t i = 0; i != PER; ++i) {
       const uint32_t k = have + tid + i * NT;
-      cw[i]            = 0;
+      nw[i]            = 0;
       if (k < end) {
-        cw[i] = ring[(k - 28u * m) & MASK] ^ ring[(k - 29u * m) & MASK] ^ ring[(k - 30u * m) & MASK] ^
+        nw[i] = ring[(k - 28u * m) & MASK] ^ ring[(k - 29u * m) & MASK] ^ ring[(k - 30u * m) & MASK] ^
                 ring[(k - 31u * m) & MASK];
-        ring[k & MASK] = cw[i];
+        ring[k & MASK] = nw[i];
       }
     }
 #pragma unroll
     for (uint32_t i = 0; i != PER; ++i) {
       const uint32_t k = pbeg + tid + i * NT;
       if (k < pend) {
-        out[k] = pw[i] ^ px[i];
+        out[k] = ow[i] ^ ox[i];
       }
-      pw[i] = cw[i];
-      px[i] = cx[i];
     }
     pbeg = have;
     pend = end;
     lds_barrier();
     have = end;
+  };
+  uint32_t qw[PER], qx[PER];
+  bool     in_q = false; // which register set holds the block that is still to be written out
+  while (have < nwords) { // workgroup-uniform
+    step(qw, qx, pw, px);
+    in_q = true;
+    if (have >= nwords) {
+      break;
+    }
+    step(pw, px, qw, qx);
+    in_q = false;
   }
 #pragma unroll
   for (uint32_t i = 0; i != PER; ++i) {
     const uint32_t k = pbeg + tid + i * NT;
     if (k < pend) {
-      out[k] = pw[i] ^ px[i];
+      out[k] = in_q ? (qw[i] ^ qx[i]) : (pw[i] ^ px[i]);
     }
   }
   lds_barrier(); // the ring is reused by the caller's next sequence

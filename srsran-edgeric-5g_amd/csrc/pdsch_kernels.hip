@@ -563,6 +563,7 @@ __device__ __forceinline__ void dmrs_precode(float dr, float di, bool odd, uint3
   const float sr = odd ? -dr : dr, si = odd ? -di : di;
 #pragma unroll 1
   for (uint32_t port = 0; port != P; ++port) {
+    uint32_t word[(L + 1) / 2];
 #pragma unroll
     for (int g = 0; g != (L + 1) / 2; ++g) {
       float accr, acci;
@@ -573,7 +574,14 @@ __device__ __forceinline__ void dmrs_precode(float dr, float di, bool odd, uint3
         accr = __fadd_rn(accr, pr);
         acci = __fadd_rn(acci, pi);
       }
-      out[port * port_stride + g] = pack_cbf16(accr, acci);
+      word[g] = pack_cbf16(accr, acci);
+    }
+    // Both CDM groups of a pilot position are neighbours in the grid (subcarriers 2k', 2k' + 1, 8-byte aligned): one
+    // 8-byte store per lane makes the wave's store contiguous instead of every other word.
+    if ((L + 1) / 2 == 2) {
+      *reinterpret_cast<uint2*>(out + port * port_stride) = make_uint2(word[0], word[(L + 1) / 2 - 1]);
+    } else {
+      out[port * port_stride] = word[0];
     }
   }
 }
