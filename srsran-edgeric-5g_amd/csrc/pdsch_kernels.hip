@@ -147,7 +147,6 @@ struct CbStatic {
     uint32_t crc_table[256]; // CRC24B byte table while the codeblock is built ...
     float2   qam[256];       // ... then the modulation table (index = Qm bits, value = ci8 symbol as floats)
   } lut;
-  float w[2 * NRPHY_MAX_PORTS * NRPHY_MAX_LAYERS]; // wideband precoding weights [port][layer] (re, im)
 };
 
 struct CbShared {
@@ -408,22 +407,26 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   const size_t   grid_base = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
   const uint64_t cw_bit0 = pd.cw_bit_offset + g.cw_cb + (uint64_t)wk.re_begin * LQ;
   const uint32_t* __restrict__ scr = p.scr + pd.scr_offset;
-  bool           any_table = false;
+  // The OFDM symbol of the chunk's first RE, found once; the loop below only checks (on the scalar unit) whether the
+  // next 64 RE stay inside the current symbol and walks on when they do not.
+  const uint32_t re0   = re_cb + wk.re_begin;
+  uint32_t       l_cur = 0;
 #pragma unroll
-  for (int l = 0; l != NRPHY_NSYMB; ++l) {
-    any_table |= pd.sym_kind[l] == SYM_TABLE;
+  for (int l = 1; l != NRPHY_NSYMB; ++l) {
+    l_cur += (re0 >= pd.sym_re_start[l]) ? 1u : 0u;
   }
+  uint32_t cur_start = pd.sym_re_start[l_cur], cur_end = pd.sym_re_start[l_cur + 1u];
+  // Wideband precoding (the common case): the weights are wave-uniform, scalar loads put them in SGPRs.
+  const float NRPHY_CONSTANT* wuni = to_constant(wbase);
 
   for (uint32_t r0 = 0; r0 < wk.re_count; r0 += WAVE) { // r0 is wave-uniform
     const uint32_t r = r0 + lane;
-    // OFDM symbol of the first and last RE of this 64-lane group (scalar): almost always the same one.
-    const uint32_t re_first = re_cb + wk.re_begin + r0;
+    const uint32_t re_first = re0 + r0;
     const uint32_t re_last  = re_first + ((wk.re_count - r0 < WAVE ? wk.re_count - r0 : WAVE) - 1u);
-    uint32_t       l_first = 0, l_last = 0;
-#pragma unroll
-    for (int l = 1; l != NRPHY_NSYMB; ++l) {
-      l_first += (re_first >= pd.sym_re_start[l]) ? 1u : 0u;
-      l_last += (re_last >= pd.sym_re_start[l]) ? 1u : 0u;
+    while (re_first >= cur_end && l_cur + 1u < NRPHY_NSYMB) { // wave-uniform; skips symbols without data RE
+      ++l_cur;
+      cur_start = cur_end;
+      cur_end   = pd.sym_re_start[l_cur + 1u];
     }
     if (r >= wk.re_count) {
       continue;
@@ -450,9 +453,12 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
     // RE position: OFDM symbol from the per-symbol prefix counts, subcarrier from the symbol's pattern.
     const uint32_t re_pdu = re_first + lane;
     uint32_t       l_sym, subc;
-    if (l_first == l_last) {
-      l_sym = l_first;
-      subc  = pd.sym_arg[l_first] + (re_pdu - pd.sym_re_start[l_first]);
+    if (re_last < cur_end) { // wave-uniform: the whole group lies in the current symbol
+      l_sym = l_cur;
+      subc  = pd.sym_arg[l_cur] + (re_pdu - cur_start);
+      if (pd.sym_kind[l_cur] == SYM_TABLE) {
+        subc = (uint32_t)p.re_table[subc];
+      }
     } else {
       uint32_t start = 0, arg = pd.sym_arg[0];
       l_sym          = 0;
@@ -464,9 +470,9 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
         arg   = ge ? pd.sym_arg[l] : arg;
       }
       subc = arg + (re_pdu - start);
-    }
-    if (any_table && pd.sym_kind[l_sym] == SYM_TABLE) {
-      subc = (uint32_t)p.re_table[subc];
+      if (pd.sym_kind[l_sym] == SYM_TABLE) {
+        subc = (uint32_t)p.re_table[subc];
+      }
     }
     // Modulation (table lookup) + layer mapping + precoding
     // (resource_grid_mapper_impl.cpp:279-437, channel_precoder_avx2.cpp:214-342).
@@ -479,19 +485,21 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
     // Two copies of the port loop on purpose: one pointer that may address LDS or global memory would be a generic
     // pointer and every weight read a flat load.
     if (one_prg) {
-      // Wideband precoding (the common case): weights in LDS, every lane reads the same words (broadcast).
-#pragma unroll 1
-      for (uint32_t port = 0; port != P; ++port) {
-        float accr, acci;
-        cmul_ref(x[0].x, x[0].y, sh.st->w[2 * port * L], sh.st->w[2 * port * L + 1], accr, acci);
+      // Port loop unrolled with wave-uniform guards so that every weight has a fixed scalar register.
 #pragma unroll
-        for (int l = 1; l != L; ++l) {
-          float pr, pi;
-          cmul_ref(x[l].x, x[l].y, sh.st->w[2 * (port * L + l)], sh.st->w[2 * (port * L + l) + 1], pr, pi);
-          accr = __fadd_rn(accr, pr);
-          acci = __fadd_rn(acci, pi);
+      for (uint32_t port = 0; port != NRPHY_MAX_PORTS; ++port) {
+        if (port < P) {
+          float accr, acci;
+          cmul_ref(x[0].x, x[0].y, wuni[2 * port * L], wuni[2 * port * L + 1], accr, acci);
+#pragma unroll
+          for (int l = 1; l != L; ++l) {
+            float pr, pi;
+            cmul_ref(x[l].x, x[l].y, wuni[2 * (port * L + l)], wuni[2 * (port * L + l) + 1], pr, pi);
+            accr = __fadd_rn(accr, pr);
+            acci = __fadd_rn(acci, pi);
+          }
+          out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = pack_cbf16(accr, acci);
         }
-        out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = pack_cbf16(accr, acci);
       }
     } else {
       uint32_t prg = subc / pd.prg_size_subc;
@@ -734,11 +742,6 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
   g.E     = is_long ? pd.e_long : pd.e_short;
   g.cw_cb = is_long ? pd.n_short * pd.e_short + (wk.cb - pd.n_short) * pd.e_long : wk.cb * pd.e_short;
   g.bit0  = g.cw_cb + wk.re_begin * lq;
-  if (lane < 2 * pd.nof_ports * pd.nof_layers) {
-    st.w[lane] = p.weights[pd.weights_offset + lane];
-  }
-  wave_sync();
-
   if (p.profile_stage == 3) {
     return;
   }
