@@ -64,7 +64,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--slots", type=int, default=1024, help="slots per GPU per step")
+    ap.add_argument("--slots", type=int, default=1024, help="slots (config 4: cell-slots) per GPU per step")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4],
+                    help="BASELINE config: 3 = the headline workload (default); 2 and 4 are secondary measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -84,18 +86,44 @@ def main():
 
     ctx = lib.Context(local_rank)
     slots = args.slots
-    pdu0, nof_ports, nof_subc, ofdm = cases.baseline_config(3)
-    d0 = lib.derive(pdu0)
-    pdus = [cases.baseline_config(3, slot_index=i % 20)[0] for i in range(slots)]
-    stride = (pdu0.tb_size_bytes + 255) & ~255
+    if args.config == 4:
+        # four cells x four UEs (68 PRB each, QPSK / 16 / 64 / 256-QAM): one grid per cell-slot, four PDUs per grid
+        pdus, grid_of = [], []
+        for i in range(slots):
+            cell, nof_ports, nof_subc = cases.mixed_cell(i % 4, slot_index=(i // 4) % 20)
+            pdus += cell
+            grid_of += [i] * len(cell)
+        ofdm = cases.baseline_config(3)[3]
+        workload = ("BASELINE config 4: 100 MHz cell-slots, 4 cells x 4 UEs (68 PRB each; QPSK 120, 16-QAM 658, "
+                    "64-QAM 873, 256-QAM 948; 4 layers) + 4-port OFDM")
+    else:
+        nof_ports, nof_subc, ofdm = cases.baseline_config(args.config)[1:]
+        pdus = [cases.baseline_config(args.config, slot_index=i % (20 if args.config == 3 else 10))[0]
+                for i in range(slots)]
+        grid_of = list(range(slots))
+        d0 = lib.derive(pdus[0])
+        workload = {
+            3: "BASELINE config 3: 100 MHz (FFT 4096, 30 kHz SCS, 273 PRB grid) 4-layer 256-QAM R=948/1024 full-TBS "
+               "PDSCH (TBS %d bit, %d CB, BG1 Zc %d) + 4-port OFDM",
+            2: "BASELINE config 2: 20 MHz (FFT 2048, 15 kHz SCS, 106 PRB) 2-layer 64-QAM R=873/1024 PDSCH "
+               "(TBS %d bit, %d CB, BG1 Zc %d) + 2-port OFDM",
+        }[args.config] % (8 * pdus[0].tb_size_bytes, d0["nof_codeblocks"], d0["lifting_size"])
+    pdu0 = pdus[0]
+    tb_strides = [(q.tb_size_bytes + 255) & ~255 for q in pdus]
+    tb_offsets = [0]
+    for st in tb_strides[:-1]:
+        tb_offsets.append(tb_offsets[-1] + st)
+    tb_total = tb_offsets[-1] + tb_strides[-1]
+    tb_bytes_per_step = sum(q.tb_size_bytes for q in pdus)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
-    d_tb = torch.randint(0, 256, (slots, stride), dtype=torch.uint8, device="cuda", generator=gen)
-    plan = lib.PdschPlan(ctx, pdus, [i * stride for i in range(slots)], list(range(slots)), slots, nof_ports, nof_subc)
+    d_tb = torch.randint(0, 256, (tb_total,), dtype=torch.uint8, device="cuda", generator=gen)
+    plan = lib.PdschPlan(ctx, pdus, tb_offsets, grid_of, slots, nof_ports, nof_subc)
     oplan = lib.OfdmPlan(ctx, ofdm, nof_ports)
     d_grid = torch.zeros((slots, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
     d_iq = torch.zeros((slots, nof_ports, oplan.slot_stride, 2), dtype=torch.float32, device="cuda")
-    d_slot = torch.tensor([i % 2 for i in range(slots)], dtype=torch.int32, device="cuda")
+    sps = 2 if args.config != 2 else 1  # slots per subframe
+    d_slot = torch.tensor([i % sps for i in range(slots)], dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
 
     def step():
@@ -133,13 +161,14 @@ def main():
         # Algorithmic bytes per slot: TB read + grid written once (incl. zeros) +
         # grid read by the OFDM modulator + IQ write.
         grid_bytes = nof_ports * 14 * nof_subc * 4
-        alg_pdsch = pdu0.tb_size_bytes + grid_bytes
+        alg_pdsch = tb_bytes_per_step / slots + grid_bytes
         alg_ofdm = grid_bytes + samples_per_slot * 8
+        ofdm_name = "ofdm_kernel<%d>" % ofdm.dft_size
         kernels = {
             # name: (avg ms per launch, algorithmic bytes per launch)
-            "ofdm_kernel<4096>": (ms_ofdm, slots * alg_ofdm),
+            ofdm_name: (ms_ofdm, slots * alg_ofdm),
             # The codeblock launch also carries the DM-RS and zero-fill waves: it writes every grid word exactly once.
-            "codeblock_kernel": (ms_cb, slots * (pdu0.tb_size_bytes + grid_bytes)),
+            "codeblock_kernel": (ms_cb, tb_bytes_per_step + slots * grid_bytes),
         }
         dom = max(kernels, key=lambda k: kernels[k][0])
         traffic = None
@@ -147,7 +176,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("slots") == slots and dom in tj.get("hbm_bytes_per_launch", {}):
+                if args.config == 3 and tj.get("slots") == slots and dom in tj.get("hbm_bytes_per_launch", {}):
                     traffic = tj["hbm_bytes_per_launch"][dom]
             except Exception:
                 traffic = None
@@ -174,9 +203,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 bit-packed GF(2) + bf16 grid + f32 IQ",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: 100 MHz (FFT 4096, 30 kHz SCS, 273 PRB grid) 4-layer 256-QAM "
-                                   "R=948/1024 full-TBS PDSCH (TBS 868584 bit, 104 CB, BG1 Zc 384) + 4-port OFDM",
-                       "slots_per_gpu_per_step": slots, "parallelism": "slot-sharded x%d, no data-path collective" % world},
+            "config": {"workload": workload, "slots_per_gpu_per_step": slots, "parallelism": "slot-sharded x%d, no data-path collective" % world},
             "iq_gsamples_per_sec": round(total_samples / dt / 1e9, 3),
             "whole_path_hbm_frac": round(total_slots * (alg_pdsch + alg_ofdm) / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
             "kernel_ms": {"prologue_tbcrc_scrambling_seq": round(ms_crc, 4), "codeblock_dmrs_zerofill": round(ms_cb, 4),
@@ -187,14 +214,19 @@ def main():
         # Sanity: slot 0 of the last step against the CPU oracle (checker only, outside the timed region).
         try:
             o = backends.oracle()
-            tb0 = d_tb[0, : pdu0.tb_size_bytes].cpu().numpy()
-            want = o.pdsch_process(pdus[0], tb0, nof_ports, nof_subc)
+            want = None
+            for k, q in enumerate(pdus):  # the PDUs of grid 0 map disjoint RE: their grids OR together
+                if grid_of[k] != 0:
+                    break
+                tbk = d_tb[tb_offsets[k]: tb_offsets[k] + q.tb_size_bytes].cpu().numpy()
+                part = o.pdsch_process(q, tbk, nof_ports, nof_subc)
+                want = part if want is None else np.bitwise_or(want, part)
             got = d_grid[0].cpu().numpy().view(np.uint16).reshape(want.shape)
             out["verified_vs_oracle"] = bool(np.array_equal(got, want))
         except Exception as e:  # the oracle is optional at bench time
             out["verified_vs_oracle"] = "unavailable: %s" % e
-        if world == 1 and not args.no_cpu_baseline:
-            tb_host = d_tb[0, : pdu0.tb_size_bytes].cpu().numpy().copy()
+        if world == 1 and not args.no_cpu_baseline and args.config == 3:
+            tb_host = d_tb[: pdu0.tb_size_bytes].cpu().numpy().copy()
             out["cpu_baseline"] = cpu_baseline(pdus[0], tb_host, nof_ports, nof_subc, ofdm)
         print(json.dumps(out), flush=True)
     if dist is not None:

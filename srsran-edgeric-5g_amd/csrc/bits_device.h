@@ -202,45 +202,43 @@ __device__ __forceinline__ uint32_t gold_matvec(const uint32_t* rows, uint32_t s
   return (uint32_t)__ballot(bit != 0) & 0x7FFFFFFFu;
 }
 
-__device__ inline void gold_generate_wave(const GoldTables* gold, const uint32_t* x1_words, uint32_t c_init,
-                                          uint32_t first_word, uint32_t nwords, uint32_t* out, uint32_t lane)
+// Orders the LDS traffic among the lanes of one wavefront when the workgroup has several (no s_barrier: the waves of
+// the caller run different amounts of work).  LDS operations of a wave complete in order.
+__device__ __forceinline__ void wave_lds_fence()
 {
-  uint32_t state  = c_init & 0x7FFFFFFFu;
-  uint32_t offset = 1600u + 32u * first_word;
-  // Row `lane` of every jump matrix first (independent loads, one latency), then the dependent mat-vec chain.
-  uint32_t jump_row[GOLD_JUMP_BITS];
-#pragma unroll
-  for (int k = 0; k != GOLD_JUMP_BITS; ++k) {
-    jump_row[k] = gold->x2_jump[k][lane & 31u];
-  }
-#pragma unroll
-  for (int k = 0; k != GOLD_JUMP_BITS; ++k) {
-    if ((offset >> k) & 1u) { // wave-uniform
-      uint32_t bit = (lane < 31u) ? (__popc(jump_row[k] & state) & 1u) : 0u;
-      state        = (uint32_t)__ballot(bit != 0) & 0x7FFFFFFFu;
-    }
-  }
-  // The first 31 words are linear in the state: lane w evaluates the 32 parities of word w.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// Short sequence (DM-RS: at most a few hundred words) generated by ONE wavefront: c(n) for n in [0, 32 nwords) into
+// global memory, steps 1-3 of the scheme above, `scratch` = nwords words of LDS private to the wave.
+__device__ inline void gold_sequence_wave(const GoldTables* gold, const uint32_t* x1_words, uint32_t c_init,
+                                          uint32_t nwords, uint32_t* __restrict__ out, uint32_t* scratch,
+                                          uint32_t lane)
+{
+  uint32_t state = c_init & 0x7FFFFFFFu;
+  // Nc = 1600 = 2^6 + 2^9 + 2^10.
+  state = gold_matvec(gold->x2_jump[6], state, lane);
+  state = gold_matvec(gold->x2_jump[9], state, lane);
+  state = gold_matvec(gold->x2_jump[10], state, lane);
   if (lane < 31u && lane < nwords) {
     uint32_t word = 0;
 #pragma unroll 8
     for (uint32_t t = 0; t != 32; ++t) {
       word |= (__popc(gold->x2_head[t][lane] & state) & 1u) << (31u - t);
     }
-    out[lane] = word;
+    scratch[lane] = word;
   }
-  wave_sync();
-  for (uint32_t base = 31; base < nwords; base += 28) {
-    uint32_t k = base + lane;
+  wave_lds_fence();
+  for (uint32_t base = 31; base < nwords; base += 28) { // wave-uniform
+    const uint32_t k = base + lane;
     if (lane < 28u && k < nwords) {
-      out[k] = out[k - 28] ^ out[k - 29] ^ out[k - 30] ^ out[k - 31];
+      scratch[k] = scratch[k - 28] ^ scratch[k - 29] ^ scratch[k - 30] ^ scratch[k - 31];
     }
-    wave_sync();
+    wave_lds_fence();
   }
   for (uint32_t k = lane; k < nwords; k += WAVE) {
-    out[k] ^= x1_words[first_word + k];
+    out[k] = scratch[k] ^ x1_words[k];
   }
-  wave_sync();
 }
 
 // Sequence generator for a 256-thread workgroup: c(n) for n in [32 first_word, 32 (first_word + nwords)) into global

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <new>
 #include <vector>
@@ -346,6 +347,8 @@ struct nrphy_pdsch_plan {
   uint16_t*             d_re_table = nullptr;
   uint32_t*             d_tb_crc = nullptr;
   CrcWork*              d_crc_work = nullptr;
+  ScrWork*              d_scr_work = nullptr;
+  uint32_t              n_scr_work = 0;
   ZeroWork*             d_zero_work = nullptr;
   ZeroSeg*              d_zero_segs = nullptr;
   uint32_t*             d_scr = nullptr;    // scrambling sequences, rewritten by every run's prologue
@@ -783,6 +786,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   std::vector<CbWork>   work;
   std::vector<DmrsWork> dmrs;
   std::vector<CrcWork>  crc_work;
+  std::vector<ScrWork>  scr_work;
   std::vector<std::vector<uint32_t>> pdus_of_grid(nof_grids);
   std::vector<float>    weights;
   std::vector<uint16_t> re_table;
@@ -911,6 +915,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     }
     // DM-RS (dmrs_pdsch_processor_impl.cpp:84-106).
     pd.dmrs_symbol_mask = pdu.dmrs_symbol_mask;
+    pd.dmrs_zero_other_group = (pdu.nof_cdm_groups_without_data == 2 && (pdu.nof_layers + 1) / 2 == 1) ? 1U : 0U;
     pd.dmrs_ref_rb      = (pdu.ref_point == 1) ? pdu.bwp_start_rb : 0;
     {
       const float amp   = std::pow(10.0F, -pdu.ratio_pdsch_dmrs_to_sss_dB / 20.0F);
@@ -969,6 +974,13 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     pd.dmrs_seq_offset = (uint32_t)plan->scr_words;
     pd.dmrs_seq_words  = (12U * (pd.end_prb - pd.dmrs_ref_rb) + 31U) / 32U + 1U;
     plan->scr_words += ((uint64_t)pd.dmrs_seq_words * (unsigned)__builtin_popcount(pdu.dmrs_symbol_mask) + 3U) & ~3ULL;
+    {
+      const uint32_t parts = std::min<uint32_t>(SCR_PARTS, std::max<uint32_t>(1, pd.scr_words >> 11));
+      const uint32_t chunk = divide_ceil(pd.scr_words, parts);
+      for (uint32_t first = 0, k = 0; first < pd.scr_words; first += chunk, ++k) {
+        scr_work.push_back({i, first, std::min(chunk, pd.scr_words - first), k == 0 ? 1U : 0U});
+      }
+    }
     plan->n_cb += d.nof_codeblocks;
     plan->cw_offset.push_back(cw_bits);
     cw_bits += (d.codeword_bits + 31U) & ~31ULL;
@@ -982,7 +994,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   std::vector<ZeroWork> zero_work;
   std::vector<ZeroSeg>  zero_segs;
   {
-    std::map<std::vector<uint64_t>, std::pair<uint32_t, uint32_t>> seen; // segment list -> (begin, count)
+    std::map<std::vector<uint64_t>, std::array<uint32_t, 3>> seen; // segment list -> (begin, count, long runs)
     std::vector<uint8_t>  cov((size_t)NRPHY_NSYMB * grid_nof_subc);
     std::vector<uint64_t> key;
     for (uint32_t g = 0; g != nof_grids; ++g) {
@@ -1000,7 +1012,9 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
               row[k] |= mask[k];
             }
             if ((pdu.dmrs_symbol_mask >> l) & 1U) {
-              const unsigned groups = (pdu.nof_layers + 1) / 2;
+              // RE of a CDM group that is reserved (no data) but carries no pilots of this PDU are zeroed by the
+              // DM-RS waves themselves (dmrs_zero_other_group): as zero-fill work they would be 1-RE segments.
+              const unsigned groups = (pdu.nof_cdm_groups_without_data == 2) ? 2 : (pdu.nof_layers + 1) / 2;
               for (unsigned prb = 0; 12 * prb < grid_nof_subc; ++prb) {
                 if (mask_test(pdu.prb_mask, prb)) {
                   for (unsigned k = 0; k != 12; ++k) {
@@ -1032,13 +1046,21 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
         }
         auto it = seen.find(key);
         if (it == seen.end()) {
+          // Long runs first (the wave clears each one together), then the short ones (one lane per run).
           const uint32_t begin = (uint32_t)zero_segs.size();
-          for (uint64_t v : key) {
-            zero_segs.push_back({(uint16_t)(v >> 32), (uint16_t)((v >> 16) & 0xFFFF), (uint16_t)(v & 0xFFFF), 0});
+          uint32_t       nof_long = 0;
+          for (int pass = 0; pass != 2; ++pass) {
+            for (uint64_t v : key) {
+              const bool is_long = (v & 0xFFFF) >= ZERO_LONG_RUN;
+              if (is_long == (pass == 0)) {
+                zero_segs.push_back({(uint16_t)(v >> 32), (uint16_t)((v >> 16) & 0xFFFF), (uint16_t)(v & 0xFFFF), 0});
+                nof_long += is_long ? 1U : 0U;
+              }
+            }
           }
-          it = seen.insert({key, {begin, (uint32_t)key.size()}}).first;
+          it = seen.insert({key, {begin, (uint32_t)key.size(), nof_long}}).first;
         }
-        zero_work.push_back({g, port, it->second.first, it->second.second});
+        zero_work.push_back({g, port, it->second[0], it->second[1], it->second[2]});
       }
     }
   }
@@ -1047,7 +1069,9 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   plan->n_work  = (uint32_t)work.size();
   plan->n_dmrs  = (uint32_t)dmrs.size();
   plan->n_crc_work = (uint32_t)crc_work.size();
+  plan->n_scr_work = (uint32_t)scr_work.size();
   if (upload(&plan->d_crc_work, crc_work.data(), crc_work.size() * sizeof(CrcWork)) != hipSuccess ||
+      upload(&plan->d_scr_work, scr_work.data(), scr_work.size() * sizeof(ScrWork)) != hipSuccess ||
       upload(&plan->d_pdus, plan->pdus.data(), plan->pdus.size() * sizeof(PduDev)) != hipSuccess ||
       upload(&plan->d_work, work.data(), work.size() * sizeof(CbWork)) != hipSuccess ||
       upload(&plan->d_dmrs, dmrs.data(), dmrs.size() * sizeof(DmrsWork)) != hipSuccess ||
@@ -1080,6 +1104,7 @@ extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
   (void)hipFree(plan->d_re_table);
   (void)hipFree(plan->d_tb_crc);
   (void)hipFree(plan->d_crc_work);
+  (void)hipFree(plan->d_scr_work);
   (void)hipFree(plan->d_zero_work);
   (void)hipFree(plan->d_zero_segs);
   (void)hipFree(plan->d_scr);
@@ -1118,6 +1143,8 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.work           = plan->d_work;
   p.dmrs_work      = plan->d_dmrs;
   p.crc_work       = plan->d_crc_work;
+  p.scr_work       = plan->d_scr_work;
+  p.n_scr_work     = plan->n_scr_work;
   p.tbcrc          = ctx->d_tbcrc;
   p.n_crc_work     = plan->n_crc_work;
   p.weights        = plan->d_weights;

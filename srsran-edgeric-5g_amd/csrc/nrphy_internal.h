@@ -98,6 +98,7 @@ struct PduDev {
   uint32_t sym_arg[NRPHY_NSYMB];
   // DM-RS
   uint32_t dmrs_symbol_mask;
+  uint32_t dmrs_zero_other_group; // 1: CDM group 1 is reserved but unused by this PDU -> the DM-RS waves write its zeros
   uint32_t dmrs_c_init[NRPHY_NSYMB];
   uint32_t dmrs_ref_rb;
   uint32_t dmrs_seq_offset; // word offset of the DM-RS sequences (one per DM-RS symbol, in symbol order)
@@ -138,6 +139,16 @@ struct DmrsWork {
   uint32_t prb_end;
 };
 
+// One 256-thread workgroup of the sequence role: words [first, first + count) of the PDU's scrambling sequence; the
+// PDU's first workgroup also generates its DM-RS sequences.  Long sequences are split over up to SCR_PARTS workgroups
+// (seeding a generator costs about as much as 2,000 words, so short ones are not).
+struct ScrWork {
+  uint32_t pdu;
+  uint32_t first;
+  uint32_t count;
+  uint32_t with_dmrs;
+};
+
 // One 256-thread workgroup of the TB-CRC role: region `region` (16 KiB) of the PDU's transport block.  The region
 // is reduced as if the transport block were zero-extended to the region's end; `factor` = x^(order + 8 (bytes - region
 // end)) mod g (a negative exponent for the last region: x is invertible mod g) turns that into the region's share of
@@ -158,11 +169,13 @@ struct ZeroSeg {
   uint16_t count;
   uint16_t pad_;
 };
+constexpr uint32_t ZERO_LONG_RUN = 32; // runs at least this long are cleared by the whole wave, shorter ones by one lane
 struct ZeroWork {
   uint32_t grid;
   uint32_t port;
   uint32_t seg_begin;
-  uint32_t seg_count;
+  uint32_t seg_count; // segments [seg_begin, seg_begin + seg_count): the first seg_long of them are long runs
+  uint32_t seg_long;
 };
 
 struct PdschLaunch {
@@ -176,6 +189,8 @@ struct PdschLaunch {
   const CbWork*      work;
   const DmrsWork*    dmrs_work;
   const CrcWork*     crc_work;
+  const ScrWork*     scr_work;
+  uint32_t           n_scr_work;
   const TbCrcTables* tbcrc;
   uint32_t           n_crc_work;
   const float*       weights;

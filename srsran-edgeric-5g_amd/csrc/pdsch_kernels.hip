@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t re
   return tab[reg & 0xFFu] ^ tab[256u + ((reg >> 8) & 0xFFu)] ^ tab[512u + ((reg >> 16) & 0xFFu)] ^ tab[768u + (reg >> 24)];
 }
 
-// Blocks [0, SCR_PARTS n_pdu): scrambling sequence (a quarter each) and DM-RS sequences of one PDU (TS 38.211 Sections 7.3.1.1, 7.4.1.1.1;
+// Blocks [0, n_scr_work): a share of the scrambling sequence of one PDU, and its DM-RS sequences (TS 38.211 Sections 7.3.1.1, 7.4.1.1.1;
 // reference: pdsch_modulator_impl.cpp:43-60, dmrs_pdsch_processor_impl.cpp:84-106).  The blocks after them:
 // transport-block CRC.
 __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
@@ -47,25 +47,30 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   static_assert(GOLD_RING_WORDS >= 2 * 1024 + TB_CRC_THREADS, "LDS of the CRC role");
   const uint32_t tid = threadIdx.x;
 
-  if (blockIdx.x < p.n_pdu * SCR_PARTS) { // workgroup-uniform; first in the grid: the longest dependent chains
+  if (blockIdx.x < p.n_scr_work) { // workgroup-uniform; first in the grid: the longest dependent chains
     if (p.profile_stage == 8) {
       return;
     }
-    const uint32_t part = blockIdx.x % SCR_PARTS;
-    PduRef         pd   = *to_constant(&p.pdus[blockIdx.x / SCR_PARTS]);
-    // This workgroup's quarter of the scrambling sequence: the generator jumps straight to its first word.
-    const uint32_t chunk = (pd.scr_words + SCR_PARTS - 1u) / SCR_PARTS;
-    const uint32_t first = part * chunk < pd.scr_words ? part * chunk : pd.scr_words;
-    const uint32_t count = pd.scr_words - first < chunk ? pd.scr_words - first : chunk;
+    const auto*    swc   = to_constant(&p.scr_work[blockIdx.x]);
+    const uint32_t first = swc->first, count = swc->count;
+    const bool     with_dmrs = swc->with_dmrs != 0;
+    PduRef         pd    = *to_constant(&p.pdus[swc->pdu]);
     gold_sequence_workgroup<TB_CRC_THREADS>(p.gold, p.x1_words, pd.c_init, first, count, p.scr + pd.scr_offset + first,
                                             lds, tid);
-    // The DM-RS sequences, from bit 0 to the last allocated PRB, dealt out over the PDU's workgroups.
-    uint32_t ordinal = 0;
-    for (uint32_t mask = pd.dmrs_symbol_mask; mask != 0; mask &= mask - 1u, ++ordinal) { // workgroup-uniform
-      if (ordinal % SCR_PARTS == part) {
-        const uint32_t l = (uint32_t)__ffs(mask) - 1u;
-        gold_sequence_workgroup<TB_CRC_THREADS>(p.gold, p.x1_words, pd.dmrs_c_init[l], 0, pd.dmrs_seq_words,
-                                                p.scr + pd.dmrs_seq_offset + ordinal * pd.dmrs_seq_words, lds, tid);
+    // The DM-RS sequences, from bit 0 to the last allocated PRB: short, so one wave generates one (the four waves of
+    // the PDU's first workgroup take the DM-RS symbols in turn, each with its own quarter of the LDS as scratch).
+    if (with_dmrs) {
+      const uint32_t wave = tid / WAVE, lane = tid % WAVE;
+      static_assert(GOLD_RING_WORDS / (TB_CRC_THREADS / WAVE) >= 1024, "DM-RS scratch per wave");
+      if (pd.dmrs_seq_words <= 1024u) {
+        uint32_t ordinal = 0;
+        for (uint32_t mask = pd.dmrs_symbol_mask; mask != 0; mask &= mask - 1u, ++ordinal) { // uniform
+          if (ordinal % (TB_CRC_THREADS / WAVE) == wave) {
+            const uint32_t l = (uint32_t)__ffs(mask) - 1u;
+            gold_sequence_wave(p.gold, p.x1_words, pd.dmrs_c_init[l], pd.dmrs_seq_words,
+                               p.scr + pd.dmrs_seq_offset + ordinal * pd.dmrs_seq_words, lds + wave * 1024u, lane);
+          }
+        }
       }
     }
     return;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   if (p.profile_stage == 9) {
     return;
   }
-  const auto*     wkc = to_constant(&p.crc_work[blockIdx.x - p.n_pdu * SCR_PARTS]);
+  const auto*     wkc = to_constant(&p.crc_work[blockIdx.x - p.n_scr_work]);
   const uint32_t  wk_pdu = wkc->pdu, wk_region = wkc->region, wk_factor = wkc->factor;
   PduRef          pd  = *to_constant(&p.pdus[wk_pdu]);
   const uint32_t  sel = (pd.tb_crc_bits == 16) ? 1u : 0u;
@@ -127,11 +132,10 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
 
 hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream)
 {
-  if (p.n_crc_work + p.n_pdu == 0) {
+  if (p.n_crc_work + p.n_scr_work == 0) {
     return hipSuccess;
   }
-  hipLaunchKernelGGL(prologue_kernel, dim3(p.n_crc_work + p.n_pdu * SCR_PARTS), dim3(TB_CRC_THREADS), 0, stream, p,
-                     d_tb);
+  hipLaunchKernelGGL(prologue_kernel, dim3(p.n_crc_work + p.n_scr_work), dim3(TB_CRC_THREADS), 0, stream, p, d_tb);
   return hipGetLastError();
 }
 
@@ -564,7 +568,7 @@ __device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, PduRef pd
 // (constant address space = scalar loads for wideband precoding, global memory per lane otherwise).
 template <int L, typename W>
 __device__ __forceinline__ void dmrs_precode(float dr, float di, bool odd, uint32_t P, W w, uint32_t* out,
-                                             size_t port_stride)
+                                             size_t port_stride, bool zero_other_group)
 {
   // CDM (TS 38.211 Table 7.4.1.1.2-1): w_f = {+1, -1} on odd DM-RS ports flips every other pilot; w_t = +1 for
   // ports 1000-1003.
@@ -588,6 +592,8 @@ __device__ __forceinline__ void dmrs_precode(float dr, float di, bool odd, uint3
     // 8-byte store per lane makes the wave's store contiguous instead of every other word.
     if ((L + 1) / 2 == 2) {
       *reinterpret_cast<uint2*>(out + port * port_stride) = make_uint2(word[0], word[(L + 1) / 2 - 1]);
+    } else if (zero_other_group) { // wave-uniform: the reserved, pilot-less neighbour RE is zero
+      *reinterpret_cast<uint2*>(out + port * port_stride) = make_uint2(word[0], 0u);
     } else {
       out[port * port_stride] = word[0];
     }
@@ -618,12 +624,13 @@ __device__ __forceinline__ void dmrs_items(const PdschLaunch& p, PduRef pd, cons
     const float    di   = (word & 0x40000000u) ? -a : a;
     uint32_t*      out  = row + 12u * prb + 2u * kp;
     if (pd.nof_prg == 1) {
-      dmrs_precode<L>(dr, di, (kp & 1u) != 0, P, to_constant(p.weights + pd.dmrs_weights_offset), out, port_stride);
+      dmrs_precode<L>(dr, di, (kp & 1u) != 0, P, to_constant(p.weights + pd.dmrs_weights_offset), out, port_stride,
+                      pd.dmrs_zero_other_group != 0);
     } else {
       uint32_t prg = (12u * prb) / pd.prg_size_subc;
       prg          = prg >= pd.nof_prg ? pd.nof_prg - 1 : prg;
       dmrs_precode<L>(dr, di, (kp & 1u) != 0, P, p.weights + pd.dmrs_weights_offset + 2u * prg * P * L, out,
-                      port_stride);
+                      port_stride, pd.dmrs_zero_other_group != 0);
     }
   }
 }
@@ -654,13 +661,20 @@ __device__ __forceinline__ void dmrs_wave(const PdschLaunch& p, uint32_t item_in
 __device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid, uint32_t lane)
 {
   const auto*    wkc  = to_constant(&p.zero_work[item_index]);
-  const ZeroWork wk   = {wkc->grid, wkc->port, wkc->seg_begin, wkc->seg_count};
-  uint32_t*      base = d_grid + ((size_t)wk.grid * p.grid_nof_ports + wk.port) * NRPHY_NSYMB * p.grid_nof_subc;
-  for (uint32_t i = 0; i != wk.seg_count; ++i) {
-    const auto*   sgc = to_constant(&p.zero_segs[wk.seg_begin + i]);
-    const ZeroSeg sg  = {sgc->symbol, sgc->k0, sgc->count, 0};
-    uint32_t*     row = base + (size_t)sg.symbol * p.grid_nof_subc + sg.k0;
-    for (uint32_t k = lane; k < sg.count; k += WAVE) {
+  const uint32_t seg_begin = wkc->seg_begin, seg_count = wkc->seg_count, seg_long = wkc->seg_long;
+  uint32_t*      base = d_grid + ((size_t)wkc->grid * p.grid_nof_ports + wkc->port) * NRPHY_NSYMB * p.grid_nof_subc;
+  for (uint32_t i = 0; i != seg_long; ++i) { // long runs: the wave clears each one together
+    const auto*    sgc   = to_constant(&p.zero_segs[seg_begin + i]);
+    const uint32_t count = sgc->count;
+    uint32_t*      row   = base + (size_t)sgc->symbol * p.grid_nof_subc + sgc->k0;
+    for (uint32_t k = lane; k < count; k += WAVE) {
+      row[k] = 0u;
+    }
+  }
+  for (uint32_t i = seg_long + lane; i < seg_count; i += WAVE) { // short runs (reserved-RE combs): one lane per run
+    const ZeroSeg  sg  = p.zero_segs[seg_begin + i];
+    uint32_t*      row = base + (size_t)sg.symbol * p.grid_nof_subc + sg.k0;
+    for (uint32_t k = 0; k != sg.count; ++k) {
       row[k] = 0u;
     }
   }
