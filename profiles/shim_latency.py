@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Through-the-shim timing: the host-span entry points the reference's adaptors call, one PDU /
+one slot at a time with host buffers -- plan creation, H2D, kernels, D2H and synchronisation included.
+Usage (GPU box, repository root): python3 profiles/shim_latency.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import backends
+    import cases
+    lib = backends.pkg.lib
+    ctx = lib.Context(0)
+    rng = np.random.default_rng(0)
+    for cfg in (1, 2, 3):
+        pdu, ports, subc, ofdm = cases.baseline_config(cfg)
+        tb = cases.random_tb(rng, pdu)
+        oplan = lib.OfdmPlan(ctx, ofdm, ports)
+        grid = ctx.pdsch_process_host(pdu, tb, ports, subc)
+        for _ in range(3):
+            ctx.pdsch_process_host(pdu, tb, ports, subc, grid=grid)
+            oplan.modulate_slot_host(grid, 0)
+        n = 50
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ctx.pdsch_process_host(pdu, tb, ports, subc, grid=grid)
+        t1 = time.perf_counter()
+        for _ in range(n):
+            oplan.modulate_slot_host(grid, 0)
+        t2 = time.perf_counter()
+        ms_p, ms_o = 1e3 * (t1 - t0) / n, 1e3 * (t2 - t1) / n
+        print("config %d: pdsch_process_host %.3f ms/PDU, ofdm modulate_slot_host (all ports) %.3f ms/slot -> %.0f slots/s "
+              "through the shim, one slot in flight" % (cfg, ms_p, ms_o, 1e3 / (ms_p + ms_o)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -193,6 +193,16 @@ class OfdmPlan:
                                                             out.ctypes.data, n), "nrphy_ofdm_modulate_symbol_host")
         return out
 
+    def modulate_slot_host(self, grid, slot_index, out=None):
+        """ofdm_slot_modulator::modulate for every port of one host grid: [nof_ports][slot samples] complex64."""
+        grid = np.ascontiguousarray(grid, dtype=np.uint16)
+        n = slot_size(self.cfg, slot_index)
+        if out is None:
+            out = np.zeros((self.nof_ports, n), np.complex64)
+        _check(self.ctx.lib.nrphy_ofdm_modulate_slot_host(self.handle, grid.ctypes.data, slot_index, out.ctypes.data),
+               "nrphy_ofdm_modulate_slot_host")
+        return out
+
     def close(self):
         if self.handle:
             self.ctx.lib.nrphy_ofdm_plan_destroy(self.handle)
