@@ -234,7 +234,9 @@ int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uin
 
 /* dft_processor::run (R/include/srsran/phy/generic_functions/dft_processor.h:34-73; generic impl
  * dft_processor_generic_impl.cpp:14-218).  Unnormalised DFT of `size` complex floats, `batch` of them
- * back to back.  inverse != 0 uses exp(+j...).  Sizes: powers of two 128..4096 (more in later rounds). */
+ * back to back.  inverse != 0 uses exp(+j...).  Sizes: 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072,
+ * 4096 (the reference's generic implementation also has 4608, 6144 and larger ones, used by PRACH and
+ * wider carriers: later rounds). */
 int nrphy_dft_run(nrphy_ctx_t* ctx, uint32_t size, int inverse, uint32_t batch, const float* d_in, float* d_out,
                   void* stream);
 /* Host-span form of dft_processor::run for one transform (blocking). */

@@ -330,7 +330,7 @@ struct nrphy_ctx {
   GoldTables*  d_gold   = nullptr;
   TbCrcTables* d_tbcrc  = nullptr;
   uint32_t*    d_x1     = nullptr;
-  float2*      d_twiddle[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // 128 .. 4096
+  float2*      d_twiddle[10] = {}; // one table per supported DFT size (twiddle_slot)
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
 };
 
@@ -733,6 +733,14 @@ int twiddle_slot(uint32_t size)
       return 4;
     case 4096:
       return 5;
+    case 384:
+      return 6;
+    case 768:
+      return 7;
+    case 1536:
+      return 8;
+    case 3072:
+      return 9;
     default:
       return -1;
   }

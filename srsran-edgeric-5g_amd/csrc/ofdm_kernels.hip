@@ -183,6 +183,76 @@ struct Butterfly<SIGN, 16> {
   }
 };
 
+// Radix 3: y0 = a0 + (a1 + a2), y1,2 = a0 - (a1 + a2) / 2 +- SIGN j (sqrt(3) / 2) (a1 - a2).
+template <int SIGN>
+__device__ __forceinline__ void dft3(cf& a0, cf& a1, cf& a2)
+{
+  constexpr float s = 0.86602540378443864676f;
+  const cf        t = cadd(a1, a2), d = csub(a1, a2);
+  const cf        u = a0 - 0.5f * t, v = s * d;
+  a0                = cadd(a0, t);
+  a1                = add_sjb<SIGN>(u, v);
+  a2                = sub_sjb<SIGN>(u, v);
+}
+template <int SIGN>
+struct Butterfly<SIGN, 3> {
+  static __device__ __forceinline__ void run(cf (&a)[3]) { dft3<SIGN>(a[0], a[1], a[2]); }
+};
+template <int SIGN>
+struct Butterfly<SIGN, 6> {
+  // 6 = 2 x 3: X[k1 + 2 k2] = sum_{n2<3} W6^(n2 k1) W3^(n2 k2) [ sum_{n1<2} x[3 n1 + n2] W2^(n1 k1) ].
+  static __device__ __forceinline__ void run(cf (&a)[6])
+  {
+    constexpr float s = 0.86602540378443864676f;
+    dft2<SIGN>(a[0], a[3]);
+    dft2<SIGN>(a[1], a[4]);
+    dft2<SIGN>(a[2], a[5]);
+    a[4] = cmul_uniform(a[4], make_cf(0.5f, SIGN * s));  // W6^1
+    a[5] = cmul_uniform(a[5], make_cf(-0.5f, SIGN * s)); // W6^2
+    dft3<SIGN>(a[0], a[1], a[2]); // k1 = 0: X[0], X[2], X[4]
+    dft3<SIGN>(a[3], a[4], a[5]); // k1 = 1: X[1], X[3], X[5]
+    const cf x1 = a[3], x2 = a[1], x3 = a[4], x4 = a[2];
+    a[1] = x1;
+    a[2] = x2;
+    a[3] = x3;
+    a[4] = x4;
+  }
+};
+template <int SIGN>
+struct Butterfly<SIGN, 12> {
+  // 12 = 4 x 3: X[k1 + 4 k2] = sum_{n2<3} W12^(n2 k1) W3^(n2 k2) [ sum_{n1<4} x[3 n1 + n2] W4^(n1 k1) ].
+  static __device__ __forceinline__ void run(cf (&a)[12])
+  {
+    constexpr float s = 0.86602540378443864676f;
+    dft4<SIGN>(a[0], a[3], a[6], a[9]);
+    dft4<SIGN>(a[1], a[4], a[7], a[10]);
+    dft4<SIGN>(a[2], a[5], a[8], a[11]);
+    // Twiddles W12^(n2 k1) on a[3 k1 + n2].
+    a[4]  = cmul_uniform(a[4], make_cf(s, SIGN * 0.5f));    // 1*1
+    a[5]  = cmul_uniform(a[5], make_cf(0.5f, SIGN * s));    // 2*1
+    a[7]  = cmul_uniform(a[7], make_cf(0.5f, SIGN * s));    // 1*2
+    a[8]  = cmul_uniform(a[8], make_cf(-0.5f, SIGN * s));   // 2*2
+    a[10] = cmul_uniform(a[10], make_cf(0.f, (float)SIGN)); // 1*3: SIGN j
+    a[11] = make_cf(-a[11].x, -a[11].y);                    // 2*3: -1
+    dft3<SIGN>(a[0], a[1], a[2]);   // k1 = 0: X[0], X[4], X[8]
+    dft3<SIGN>(a[3], a[4], a[5]);   // k1 = 1: X[1], X[5], X[9]
+    dft3<SIGN>(a[6], a[7], a[8]);   // k1 = 2: X[2], X[6], X[10]
+    dft3<SIGN>(a[9], a[10], a[11]); // k1 = 3: X[3], X[7], X[11]
+    cf x[12];
+#pragma unroll
+    for (int k1 = 0; k1 != 4; ++k1) {
+#pragma unroll
+      for (int k2 = 0; k2 != 3; ++k2) {
+        x[k1 + 4 * k2] = a[3 * k1 + k2];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k != 12; ++k) {
+      a[k] = x[k];
+    }
+  }
+};
+
 // a[j] *= b^j for j = 1..R-1.  Powers are built from b^2, b^4, b^8 (squarings) so that every power is at most
 // three multiplications deep (a few ulp), and applied at once to keep few values live.
 template <int R>
@@ -230,6 +300,11 @@ template <> struct Plan<1024> { static constexpr int R0 = 16, R1 = 16, R2 = 4, T
 template <> struct Plan<512>  { static constexpr int R0 = 16, R1 = 16, R2 = 2, T = 64; };
 template <> struct Plan<256>  { static constexpr int R0 = 16, R1 = 16, R2 = 1, T = 64; };
 template <> struct Plan<128>  { static constexpr int R0 = 16, R1 = 8, R2 = 1, T = 64; };
+// 3 * 2^k (the 23.04 MHz family of sampling rates): the factor 3 (x 1, 2, 4) is the last, twiddle-free stage.
+template <> struct Plan<3072> { static constexpr int R0 = 16, R1 = 16, R2 = 12, T = 256; };
+template <> struct Plan<1536> { static constexpr int R0 = 16, R1 = 16, R2 = 6, T = 128; };
+template <> struct Plan<768>  { static constexpr int R0 = 16, R1 = 16, R2 = 3, T = 64; };
+template <> struct Plan<384>  { static constexpr int R0 = 16, R1 = 8, R2 = 3, T = 64; };
 
 // Input index k-th element of the first-stage butterfly of thread `tid`: x[tid + k * N / R0].
 template <int N>
@@ -250,10 +325,10 @@ __device__ __forceinline__ TwiddleBase<N> load_twiddle_base(const float2* __rest
   using P = Plan<N>;
   TwiddleBase<N> t;
   // Stage 0: S = 1, p = butterfly index = tid (threads beyond N/R0 butterflies are idle in that stage).
-  const float2 w0 = tw[tid & (N - 1)];
+  const float2 w0 = tw[tid % N];
   // Stage 1: S = R0, p = b / R0 for butterfly b = tid (+ it*T); only the first iteration's base is kept here, the
   // others are derived in the stage (see stage_lds).
-  const float2 w1 = tw[((tid / P::R0) * P::R0) & (N - 1)];
+  const float2 w1 = tw[((tid / P::R0) * P::R0) % N];
   t.b0            = make_cf(w0.x, SIGN < 0 ? -w0.y : w0.y);
   t.b1            = make_cf(w1.x, SIGN < 0 ? -w1.y : w1.y);
   return t;
@@ -304,10 +379,10 @@ __device__ __forceinline__ void stage_lds(cf* lds, const float2* __restrict__ tw
     if (NB % T == 0 || b < NB) {
       uint32_t p = b / S, q = b % S;
       Butterfly<SIGN, R>::run(a[it]);
-      if (n1 > 1) {
+      if constexpr (n1 > 1) {
         cf bs = base;
         if (it > 0) { // p differs per iteration: fetch this iteration's base (rare plans only)
-          const float2 w = tw[(p * S) & (N - 1)];
+          const float2 w = tw[(p * S) % N];
           bs             = make_cf(w.x, SIGN < 0 ? -w.y : w.y);
         }
         apply_twiddle_powers<R>(bs, a[it]);
@@ -372,7 +447,12 @@ __device__ __forceinline__ void load_symbol_row(uint32_t (&raw)[Plan<N>::R0], co
       const_cast<uint32_t*>(row), 0, (int)((p.probe & 2u) ? 0u : p.rg_size * 4u), 0x00020000);
 #pragma unroll
   for (int k = 0; k != Plan<N>::R0; ++k) {
-    const uint32_t off = (t4 + (uint32_t)k * (N / Plan<N>::R0) * 4u) & (4u * N - 1u);
+    uint32_t off = t4 + (uint32_t)k * (N / Plan<N>::R0) * 4u; // byte offset of element (i + rg / 2) mod N
+    if ((N & (N - 1)) == 0) {
+      off &= 4u * N - 1u;
+    } else {
+      off = off >= 4u * N ? off - 4u * N : off;
+    }
     raw[k]             = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
   }
 }
@@ -458,6 +538,14 @@ hipError_t launch_ofdm(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* 
   switch (p.dft_size) {
     case 4096:
       return launch_ofdm_n<4096>(p, nof_grids, d_grid, d_slot_index, d_iq, stream);
+    case 3072:
+      return launch_ofdm_n<3072>(p, nof_grids, d_grid, d_slot_index, d_iq, stream);
+    case 1536:
+      return launch_ofdm_n<1536>(p, nof_grids, d_grid, d_slot_index, d_iq, stream);
+    case 768:
+      return launch_ofdm_n<768>(p, nof_grids, d_grid, d_slot_index, d_iq, stream);
+    case 384:
+      return launch_ofdm_n<384>(p, nof_grids, d_grid, d_slot_index, d_iq, stream);
     case 2048:
       return launch_ofdm_n<2048>(p, nof_grids, d_grid, d_slot_index, d_iq, stream);
     case 1024:
@@ -510,7 +598,8 @@ static hipError_t launch_dft_n(int inverse, uint32_t batch, const float2* tw, co
 
 bool dft_size_supported(uint32_t size)
 {
-  return size == 128 || size == 256 || size == 512 || size == 1024 || size == 2048 || size == 4096;
+  return size == 128 || size == 256 || size == 512 || size == 1024 || size == 2048 || size == 4096 || size == 384 ||
+         size == 768 || size == 1536 || size == 3072;
 }
 
 hipError_t launch_dft(uint32_t size, int inverse, uint32_t batch, const float2* tw, const float2* d_in, float2* d_out,
@@ -522,6 +611,14 @@ hipError_t launch_dft(uint32_t size, int inverse, uint32_t batch, const float2* 
   switch (size) {
     case 4096:
       return launch_dft_n<4096>(inverse, batch, tw, d_in, d_out, stream);
+    case 3072:
+      return launch_dft_n<3072>(inverse, batch, tw, d_in, d_out, stream);
+    case 1536:
+      return launch_dft_n<1536>(inverse, batch, tw, d_in, d_out, stream);
+    case 768:
+      return launch_dft_n<768>(inverse, batch, tw, d_in, d_out, stream);
+    case 384:
+      return launch_dft_n<384>(inverse, batch, tw, d_in, d_out, stream);
     case 2048:
       return launch_dft_n<2048>(inverse, batch, tw, d_in, d_out, stream);
     case 1024:

@@ -86,7 +86,10 @@ np.savez_compressed(os.path.join(HERE, "pdsch_processor.npz"), **golden)
 rng = np.random.default_rng(38211)
 og = {}
 for name, (mu, bw, n, fc, slot) in {"n4096": (1, 273, 4096, 3.5e9, 1), "n2048": (0, 106, 2048, 2.4e9, 0),
-                                    "n1024": (0, 52, 1024, 2.4e9, 0)}.items():
+                                    "n1024": (0, 52, 1024, 2.4e9, 0),
+                                    # the 3 * 2^k sizes of the 23.04 MHz family of sampling rates
+                                    "n1536": (0, 106, 1536, 2.4e9, 0), "n3072": (1, 217, 3072, 3.5e9, 0),
+                                    "n768": (0, 52, 768, 2.4e9, 0), "n384": (0, 25, 384, 2.4e9, 0)}.items():
     cfg = abi.OfdmConfig(mu, bw, n, 0, 1.0 / np.sqrt(n), fc)
     grid = (rng.standard_normal((1, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
     iq = r.ofdm_slot(cfg, grid, slot)

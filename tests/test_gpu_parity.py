@@ -278,7 +278,7 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
-@pytest.mark.parametrize("size", [128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("size", [128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096])
 @pytest.mark.parametrize("inverse", [0, 1])
 def test_dft_vs_oracle(gpu_ctx, oracle, size, inverse):
     import torch
@@ -296,7 +296,7 @@ def test_dft_vs_oracle(gpu_ctx, oracle, size, inverse):
         assert rel_err(out[i], want) < 1e-5   # north-star tolerance; reference test uses MSE < 1e-6 / peak < 1e-3
 
 
-@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024"])
+@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024", "n1536", "n3072", "n768", "n384"])
 def test_ofdm_modulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
     import torch
     g = np.load(os.path.join(cases.GOLDEN, "ofdm_modulator.npz"))

@@ -56,7 +56,7 @@ def test_oracle_pdsch_processor_golden(oracle):
             assert np.array_equal(g32[p][g["%s_p%d_idx" % (name, p)]], g["%s_p%d_val" % (name, p)]), (name, p)
 
 
-@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024"])
+@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024", "n1536", "n3072", "n768", "n384"])
 def test_oracle_ofdm_golden(oracle, name):
     g = np.load(os.path.join(cases.GOLDEN, "ofdm_modulator.npz"))
     mu, bw, n, fc, slot = g[name + "_cfg"]
