@@ -232,6 +232,26 @@ int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, u
  * nof_ports x nrphy_ofdm_slot_size(cfg, slot_index) complex samples, port after port (blocking). */
 int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t slot_index, float* iq);
 
+/* ---- receive side of seam C ("next" row): OFDM demodulator ---------------
+ * Replaces ofdm_symbol_demodulator::demodulate / ofdm_slot_demodulator::demodulate
+ * (R/include/srsran/phy/lower/modulation/ofdm_demodulator.h; impl
+ * R/lib/phy/lower/modulation/ofdm_demodulator_impl.cpp:98-171) for every port of nof_grids slots:
+ * d_iq [grid][port][slot_stride] complex float (the layout nrphy_ofdm_run writes) -> d_grid
+ * [grid][port][14][12*bw_rb] cbf16.  The plan's configuration doubles as ofdm_demodulator_configuration
+ * (numerology, bw_rb, dft_size, cp, scale, center_freq_hz); window_offset is its
+ * nof_samples_window_offset (must be below the shortest cyclic prefix).  slot_index as in nrphy_ofdm_run. */
+int nrphy_ofdm_demod_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const float* d_iq, const uint32_t* slot_index,
+                         uint32_t window_offset, void* d_grid, void* stream);
+/* Host-span whole-slot form: iq holds nof_ports x nrphy_ofdm_slot_size(cfg, slot_index) complex samples,
+ * port after port; grid receives [nof_ports][14][12*bw_rb] cbf16 (blocking). */
+int nrphy_ofdm_demodulate_slot_host(nrphy_ofdm_plan_t* plan, const float* iq, uint32_t slot_index,
+                                    uint32_t window_offset, void* grid);
+/* Host-span form of ofdm_symbol_demodulator::demodulate for one symbol of one port: input = the symbol's
+ * cyclic prefix + dft_size samples, symbol_index counted within the subframe; grid_row receives the
+ * 12*bw_rb cbf16 values of that OFDM symbol (blocking). */
+int nrphy_ofdm_demodulate_symbol_host(nrphy_ofdm_plan_t* plan, const float* input, uint32_t input_size,
+                                      uint32_t symbol_index, uint32_t window_offset, void* grid_row);
+
 /* dft_processor::run (R/include/srsran/phy/generic_functions/dft_processor.h:34-73; generic impl
  * dft_processor_generic_impl.cpp:14-218).  Unnormalised DFT of `size` complex floats, `batch` of them
  * back to back.  inverse != 0 uses exp(+j...).  Sizes: 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072,

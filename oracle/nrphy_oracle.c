@@ -1103,6 +1103,60 @@ int oracle_ofdm_modulate_slot(const nrphy_ofdm_config_t* c, const uint16_t* grid
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* OFDM demodulator (R/lib/phy/lower/modulation/ofdm_demodulator_impl.cpp:98-171): per symbol skip the  */
+/* cyclic prefix minus the window offset, direct DFT, x (receive phase compensation x scale)            */
+/* [phase_compensation_lut.h:49-82 with is_tx = false], x exp(+j 2 pi window_offset i / N) when the     */
+/* window is advanced, top bins -> lower half of the grid, bins from DC -> upper half, stored as cbf16. */
+/* iq: [nof_ports][slot_size] complex float, grid: [nof_ports][14][12*bw_rb] (re, im) bf16.            */
+/* ------------------------------------------------------------------------------------------------ */
+int oracle_ofdm_demodulate_slot(const nrphy_ofdm_config_t* c, const float* iq, uint32_t nof_ports,
+                                uint32_t slot_index, uint32_t window_offset, uint16_t* grid)
+{
+  unsigned N = c->dft_size, rg = 12 * c->bw_rb, nsymb = c->cp ? 12 : 14;
+  if (N <= rg || window_offset >= (144 * N) / 2048) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  unsigned slot_size = oracle_ofdm_slot_size(c, slot_index);
+  double   srate     = 15000.0 * (double)(1U << c->numerology) * (double)N;
+  float*   out       = (float*)malloc(sizeof(float) * 2 * N);
+  for (uint32_t port = 0; port != nof_ports; ++port) {
+    const float* x = iq + 2 * (size_t)port * slot_size;
+    for (unsigned l = 0; l != nsymb; ++l) {
+      unsigned sym = nsymb * slot_index + l;
+      unsigned cp  = cp_length(c, sym);
+      unsigned offset = 0;
+      for (unsigned s = 0; s <= sym; ++s) {
+        offset += cp_length(c, s);
+        if (s != sym) {
+          offset += N;
+        }
+      }
+      double phase = 2.0 * M_PI * c->center_freq_hz * ((double)offset / srate);
+      float  cr = (float)cos(phase) * c->scale, ci = (float)sin(phase) * c->scale;
+      oracle_dft(N, 0, x + 2 * (cp - window_offset), out);
+      uint16_t* g = grid + 2 * (((size_t)port * 14 + l) * rg);
+      for (unsigned k = 0; k != rg; ++k) {
+        unsigned bin = (k < rg / 2) ? N - rg / 2 + k : k - rg / 2;
+        float    xr = out[2 * bin], xi = out[2 * bin + 1];
+        float    yr = xr * cr - xi * ci, yi = xr * ci + xi * cr;
+        if (window_offset != 0) {
+          float omega = (float)window_offset * (float)(2.0 * M_PI) / (float)N;
+          float wr = cosf(omega * (float)bin), wi = sinf(omega * (float)bin);
+          float tr = yr * wr - yi * wi, ti = yr * wi + yi * wr;
+          yr = tr;
+          yi = ti;
+        }
+        g[2 * k]     = to_bf16(yr);
+        g[2 * k + 1] = to_bf16(yi);
+      }
+      x += 2 * (cp + N);
+    }
+  }
+  free(out);
+  return (int)slot_size;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* CPU baseline ("port"): T threads x reps slots, one processor instance per thread                   */
 /* (scheme of R/tests/benchmarks/phy/upper/channel_processors/pdsch_processor_benchmark.cpp:684-737).   */
 /* ------------------------------------------------------------------------------------------------ */

@@ -43,6 +43,8 @@ int oracle_pdsch_process(const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb, uint16
 int      oracle_dft(uint32_t n, int inverse, const float* in, float* out);
 uint32_t oracle_ofdm_symbol_size(const nrphy_ofdm_config_t* cfg, uint32_t symbol_index);
 uint32_t oracle_ofdm_slot_size(const nrphy_ofdm_config_t* cfg, uint32_t slot_index);
+int oracle_ofdm_demodulate_slot(const nrphy_ofdm_config_t* cfg, const float* iq, uint32_t nof_ports,
+                                uint32_t slot_index, uint32_t window_offset, uint16_t* grid);
 int oracle_ofdm_modulate_slot(const nrphy_ofdm_config_t* cfg, const uint16_t* grid, uint32_t nof_ports,
                               uint32_t slot_index, float* iq);
 /* CPU baseline: threads workers x reps slots (PDSCH, + OFDM when ofdm != NULL); returns seconds. */

@@ -11,6 +11,7 @@
 #include "lib/phy/generic_functions/dft_processor_generic_impl.h"
 #include "lib/phy/generic_functions/precoding/channel_precoder_avx2.h"
 #include "lib/phy/generic_functions/precoding/channel_precoder_generic.h"
+#include "lib/phy/lower/modulation/ofdm_demodulator_impl.h"
 #include "lib/phy/lower/modulation/ofdm_modulator_impl.h"
 #include "lib/phy/support/resource_grid_impl.h"
 #include "lib/phy/upper/channel_coding/crc_calculator_lut_impl.h"
@@ -581,6 +582,43 @@ int ref_ofdm_modulate_slot(const nrphy_ofdm_config_t* c,
                  p,
                  slot_index);
   }
+  return static_cast<int>(slot_size);
+}
+
+// ofdm_slot_demodulator::demodulate of every port of one slot: iq_in [nof_ports][slot_size] complex float ->
+// grid_out [nof_ports][14][12*bw_rb] cbf16 raw.  Returns the slot size in samples, or < 0.
+int ref_ofdm_demodulate_slot(const nrphy_ofdm_config_t* c,
+                             const float*               iq_in,
+                             unsigned                   nof_ports,
+                             unsigned                   slot_index,
+                             unsigned                   window_offset,
+                             uint16_t*                  grid_out)
+{
+  unsigned           nof_subc = c->bw_rb * 12;
+  resource_grid_impl grid(nof_ports, 14, nof_subc, make_precoder(0));
+  grid.set_all_zero();
+  dft_processor::configuration dft_cfg;
+  dft_cfg.size = c->dft_size;
+  dft_cfg.dir  = dft_processor::direction::DIRECT;
+  ofdm_demodulator_common_configuration common;
+  common.dft = std::make_unique<dft_processor_generic_impl>(dft_cfg);
+  ofdm_demodulator_configuration cfg;
+  cfg.numerology                = c->numerology;
+  cfg.bw_rb                     = c->bw_rb;
+  cfg.dft_size                  = c->dft_size;
+  cfg.cp                        = c->cp ? cyclic_prefix::EXTENDED : cyclic_prefix::NORMAL;
+  cfg.nof_samples_window_offset = window_offset;
+  cfg.scale                     = c->scale;
+  cfg.center_freq_hz            = c->center_freq_hz;
+  ofdm_slot_demodulator_impl demod(common, cfg);
+  unsigned                   slot_size = demod.get_slot_size(slot_index);
+  for (unsigned p = 0; p != nof_ports; ++p) {
+    demod.demodulate(grid.get_writer(),
+                     span<const cf_t>(reinterpret_cast<const cf_t*>(iq_in) + static_cast<size_t>(p) * slot_size, slot_size),
+                     p,
+                     slot_index);
+  }
+  copy_grid_out(grid_out, grid.get_reader(), nof_ports, nof_subc);
   return static_cast<int>(slot_size);
 }
 

@@ -217,6 +217,9 @@ def declare(lib, prefix="nrphy_"):
     sig("dft_run", i32, vp, u32, i32, u32, vp, vp, vp)
     sig("dft_run_host", i32, vp, u32, i32, vp, vp)
     sig("ofdm_modulate_slot_host", i32, vp, vp, u32, vp)
+    sig("ofdm_demod_run", i32, vp, u32, vp, vp, u32, vp, vp)
+    sig("ofdm_demodulate_slot_host", i32, vp, vp, u32, u32, vp)
+    sig("ofdm_demodulate_symbol_host", i32, vp, vp, u32, u32, u32, vp)
     return lib
 
 
@@ -230,4 +233,5 @@ ABI_SYMBOLS = [
     "nrphy_ofdm_plan_enable_timing", "nrphy_ofdm_plan_kernel_time", "nrphy_pdsch_process_host", "nrphy_ldpc_encode", "nrphy_ofdm_plan_create",
     "nrphy_ofdm_plan_destroy", "nrphy_ofdm_plan_slot_stride", "nrphy_ofdm_run",
     "nrphy_ofdm_modulate_symbol_host", "nrphy_ofdm_modulate_slot_host", "nrphy_dft_run", "nrphy_dft_run_host",
+    "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",
 ]

@@ -24,6 +24,7 @@
 #include "srsran/phy/generic_functions/dft_processor.h"
 #include "srsran/phy/generic_functions/generic_functions_factories.h"
 #include "srsran/phy/lower/modulation/modulation_factories.h"
+#include "srsran/phy/lower/modulation/ofdm_demodulator.h"
 #include "srsran/phy/lower/modulation/ofdm_modulator.h"
 #include "srsran/phy/support/resource_grid_mapper.h"
 #include "srsran/phy/support/resource_grid_reader.h"
@@ -427,6 +428,90 @@ public:
 private:
   std::shared_ptr<context> ctx;
   unsigned                 nof_ports;
+};
+
+/// ofdm_symbol_demodulator / ofdm_slot_demodulator over the host-span demodulator entry points (receive side,
+/// ofdm_demodulator_impl.cpp).  One plan with a single port: the reference calls per port.
+class ofdm_demodulator_adaptor_base
+{
+protected:
+  ofdm_demodulator_adaptor_base(std::shared_ptr<context> ctx_, const srsran::ofdm_demodulator_configuration& config) :
+    ctx(std::move(ctx_)), window_offset(config.nof_samples_window_offset)
+  {
+    cfg.numerology     = config.numerology;
+    cfg.bw_rb          = config.bw_rb;
+    cfg.dft_size       = config.dft_size;
+    cfg.cp             = (config.cp == srsran::cyclic_prefix::NORMAL) ? 0 : 1;
+    cfg.scale          = config.scale;
+    cfg.center_freq_hz = config.center_freq_hz;
+    int rc             = nrphy_ofdm_plan_create(ctx->get(), &cfg, 1, &plan);
+    srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_plan_create failed: {}", nrphy_strerror(rc));
+    staging.resize(static_cast<size_t>(NRPHY_NSYMB) * cfg.bw_rb * srsran::NRE);
+  }
+  ~ofdm_demodulator_adaptor_base() { nrphy_ofdm_plan_destroy(plan); }
+
+  std::shared_ptr<context>     ctx;
+  nrphy_ofdm_config_t          cfg;
+  nrphy_ofdm_plan_t*           plan = nullptr;
+  unsigned                     window_offset;
+  std::vector<srsran::cbf16_t> staging;
+};
+
+class ofdm_symbol_demodulator_adaptor : public srsran::ofdm_symbol_demodulator, private ofdm_demodulator_adaptor_base
+{
+public:
+  ofdm_symbol_demodulator_adaptor(std::shared_ptr<context> ctx_, const srsran::ofdm_demodulator_configuration& config) :
+    ofdm_demodulator_adaptor_base(std::move(ctx_), config)
+  {
+  }
+  unsigned get_symbol_size(unsigned symbol_index) const override { return nrphy_ofdm_symbol_size(&cfg, symbol_index); }
+  void demodulate(srsran::resource_grid_writer& grid, srsran::span<const srsran::cf_t> input, unsigned port_index, unsigned symbol_index) override
+  {
+    using namespace srsran;
+    unsigned nof_subc = cfg.bw_rb * NRE;
+    int      rc       = nrphy_ofdm_demodulate_symbol_host(plan, reinterpret_cast<const float*>(input.data()), input.size(),
+                                               symbol_index, window_offset, staging.data());
+    srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_demodulate_symbol_host failed: {}", nrphy_strerror(rc));
+    grid.put(port_index, symbol_index % NRPHY_NSYMB, 0, 1, span<const cbf16_t>(staging.data(), nof_subc));
+  }
+};
+
+class ofdm_slot_demodulator_adaptor : public srsran::ofdm_slot_demodulator, private ofdm_demodulator_adaptor_base
+{
+public:
+  ofdm_slot_demodulator_adaptor(std::shared_ptr<context> ctx_, const srsran::ofdm_demodulator_configuration& config) :
+    ofdm_demodulator_adaptor_base(std::move(ctx_), config)
+  {
+  }
+  unsigned get_slot_size(unsigned slot_index) const override { return nrphy_ofdm_slot_size(&cfg, slot_index); }
+  void demodulate(srsran::resource_grid_writer& grid, srsran::span<const srsran::cf_t> input, unsigned port_index, unsigned slot_index) override
+  {
+    using namespace srsran;
+    srsran_assert(input.size() == get_slot_size(slot_index), "Invalid input size.");
+    unsigned nof_subc = cfg.bw_rb * NRE;
+    int rc = nrphy_ofdm_demodulate_slot_host(plan, reinterpret_cast<const float*>(input.data()), slot_index, window_offset, staging.data());
+    srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_demodulate_slot_host failed: {}", nrphy_strerror(rc));
+    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+      grid.put(port_index, l, 0, 1, span<const cbf16_t>(&staging[static_cast<size_t>(l) * nof_subc], nof_subc));
+    }
+  }
+};
+
+class ofdm_demodulator_factory_adaptor : public srsran::ofdm_demodulator_factory
+{
+public:
+  explicit ofdm_demodulator_factory_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
+  std::unique_ptr<srsran::ofdm_symbol_demodulator> create_ofdm_symbol_demodulator(const srsran::ofdm_demodulator_configuration& config) override
+  {
+    return std::make_unique<ofdm_symbol_demodulator_adaptor>(ctx, config);
+  }
+  std::unique_ptr<srsran::ofdm_slot_demodulator> create_ofdm_slot_demodulator(const srsran::ofdm_demodulator_configuration& config) override
+  {
+    return std::make_unique<ofdm_slot_demodulator_adaptor>(ctx, config);
+  }
+
+private:
+  std::shared_ptr<context> ctx;
 };
 
 /// dft_processor over nrphy_dft_run_host (owns its input/output buffers like the reference's implementations).

@@ -367,6 +367,7 @@ struct nrphy_ofdm_plan {
   nrphy_ofdm_config_t cfg;
   uint32_t            nof_ports = 0, nsymb = 14, slot_stride = 0, nsym_subframe = 0;
   float2*             d_phase = nullptr;
+  float2*             d_phase_rx = nullptr; // demodulator: conjugate phase x scale (phase_compensation_lut, is_tx = false)
   uint32_t*           d_cp = nullptr;
   uint32_t*           d_off = nullptr;
   std::vector<uint32_t> cp, off;
@@ -1369,7 +1370,7 @@ extern "C" int nrphy_ofdm_plan_create(nrphy_ctx_t* ctx, const nrphy_ofdm_config_
   plan->slot_stride   = nrphy_ofdm_slot_size(cfg, 0);
   // Phase compensation (TS 38.211 Section 5.4; phase_compensation_lut.h:49-82) times the scale.
   const double        srate = 15000.0 * (double)(1U << cfg->numerology) * (double)cfg->dft_size;
-  std::vector<float2> phase(plan->nsym_subframe);
+  std::vector<float2> phase(plan->nsym_subframe), phase_rx(plan->nsym_subframe);
   plan->cp.resize(plan->nsym_subframe);
   plan->off.resize(plan->nsym_subframe);
   unsigned offset = 0, in_slot = 0;
@@ -1382,12 +1383,14 @@ extern "C" int nrphy_ofdm_plan_create(nrphy_ctx_t* ctx, const nrphy_ofdm_config_
     const double ph = -2.0 * M_PI * cfg->center_freq_hz * ((double)offset / srate);
     const float  pr = (float)std::cos(ph), pi = (float)std::sin(ph);
     phase[s]        = make_float2(pr * cfg->scale, pi * cfg->scale);
+    phase_rx[s]     = make_float2(pr * cfg->scale, -pi * cfg->scale);
     plan->cp[s]     = cp;
     plan->off[s]    = in_slot;
     in_slot += cp + cfg->dft_size;
     offset += cfg->dft_size;
   }
   if (upload(&plan->d_phase, phase.data(), phase.size() * sizeof(float2)) != hipSuccess ||
+      upload(&plan->d_phase_rx, phase_rx.data(), phase_rx.size() * sizeof(float2)) != hipSuccess ||
       upload(&plan->d_cp, plan->cp.data(), plan->cp.size() * sizeof(uint32_t)) != hipSuccess ||
       upload(&plan->d_off, plan->off.data(), plan->off.size() * sizeof(uint32_t)) != hipSuccess) {
     nrphy_ofdm_plan_destroy(plan);
@@ -1404,6 +1407,7 @@ extern "C" int nrphy_ofdm_plan_destroy(nrphy_ofdm_plan_t* plan)
   }
   (void)hipSetDevice(plan->ctx->device);
   (void)hipFree(plan->d_phase);
+  (void)hipFree(plan->d_phase_rx);
   (void)hipFree(plan->d_cp);
   (void)hipFree(plan->d_off);
   for (hipEvent_t e : plan->events) {
@@ -1451,6 +1455,117 @@ extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const
     HIP_TRY(hipEventRecord(ev[1], s));
   }
   return NRPHY_OK;
+}
+
+extern "C" int nrphy_ofdm_demod_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const float* d_iq,
+                                    const uint32_t* slot_index, uint32_t window_offset, void* d_grid, void* stream)
+{
+  // ofdm_demodulator_impl.cpp:58-63: the window offset must stay inside the shortest cyclic prefix.
+  if (plan == nullptr || d_grid == nullptr || d_iq == nullptr ||
+      window_offset >= (144U * plan->cfg.dft_size) / 2048U) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  nrphy_ctx* ctx = plan->ctx;
+  OfdmLaunch p;
+  p.dft_size    = plan->cfg.dft_size;
+  p.rg_size     = 12 * plan->cfg.bw_rb;
+  p.nof_ports   = plan->nof_ports;
+  p.nsymb       = plan->nsymb;
+  p.slot_stride = plan->slot_stride;
+  p.twiddle     = get_twiddle(ctx, plan->cfg.dft_size);
+  p.phase       = plan->d_phase_rx;
+  p.cp_len      = plan->d_cp;
+  p.sym_offset  = plan->d_off;
+  p.probe       = 0;
+  HIP_TRY(launch_ofdm_demod(p, nof_grids, (const float2*)d_iq, slot_index, window_offset, (uint32_t*)d_grid,
+                            stream ? (hipStream_t)stream : ctx->stream));
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ofdm_demodulate_slot_host(nrphy_ofdm_plan_t* plan, const float* iq, uint32_t slot_index,
+                                               uint32_t window_offset, void* grid)
+{
+  if (plan == nullptr || iq == nullptr || grid == nullptr || slot_index >= (1U << plan->cfg.numerology)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  nrphy_ctx*   ctx        = plan->ctx;
+  const size_t grid_words = (size_t)plan->nof_ports * NRPHY_NSYMB * 12 * plan->cfg.bw_rb;
+  const size_t slot_size  = nrphy_ofdm_slot_size(&plan->cfg, slot_index);
+  uint32_t *   d_grid = nullptr, *d_slot = nullptr;
+  float2*      d_iq   = nullptr;
+  int          rc     = NRPHY_ERR_DEVICE;
+  do {
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&d_grid, grid_words * 4) != hipSuccess ||
+        hipMalloc((void**)&d_iq, (size_t)plan->nof_ports * plan->slot_stride * sizeof(float2)) != hipSuccess ||
+        upload(&d_slot, &slot_index, sizeof(slot_index)) != hipSuccess) {
+      break;
+    }
+    bool ok = true;
+    for (uint32_t port = 0; port != plan->nof_ports && ok; ++port) { // host: ports back to back, slot_size each
+      ok = hipMemcpy(d_iq + (size_t)port * plan->slot_stride, iq + 2 * (size_t)port * slot_size,
+                     slot_size * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) {
+      break;
+    }
+    rc = nrphy_ofdm_demod_run(plan, 1, (const float*)d_iq, d_slot, window_offset, d_grid, ctx->stream);
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(grid, d_grid, grid_words * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    rc = NRPHY_OK;
+  } while (false);
+  (void)hipFree(d_grid);
+  (void)hipFree(d_iq);
+  (void)hipFree(d_slot);
+  return rc;
+}
+
+extern "C" int nrphy_ofdm_demodulate_symbol_host(nrphy_ofdm_plan_t* plan, const float* input, uint32_t input_size,
+                                                 uint32_t symbol_index, uint32_t window_offset, void* grid_row)
+{
+  if (plan == nullptr || input == nullptr || grid_row == nullptr || symbol_index >= plan->nsym_subframe ||
+      input_size != plan->cp[symbol_index] + plan->cfg.dft_size) { // ofdm_demodulator_impl.cpp:110-118
+    return NRPHY_ERR_ARGUMENT;
+  }
+  // One symbol of one port: the samples are placed where the slot kernel expects them (the other symbols of the
+  // staging slot transform zeros), the symbol's row is read back.
+  nrphy_ctx*     ctx  = plan->ctx;
+  const uint32_t rg   = 12 * plan->cfg.bw_rb;
+  const uint32_t slot = symbol_index / plan->nsymb, l = symbol_index % plan->nsymb;
+  const size_t   iq_samples = (size_t)plan->nof_ports * plan->slot_stride;
+  uint32_t *     d_grid = nullptr, *d_slot = nullptr;
+  float2*        d_iq   = nullptr;
+  int            rc     = NRPHY_ERR_DEVICE;
+  do {
+    if (hipSetDevice(ctx->device) != hipSuccess ||
+        hipMalloc((void**)&d_grid, (size_t)plan->nof_ports * NRPHY_NSYMB * rg * 4) != hipSuccess ||
+        hipMalloc((void**)&d_iq, iq_samples * sizeof(float2)) != hipSuccess ||
+        hipMemset(d_iq, 0, iq_samples * sizeof(float2)) != hipSuccess ||
+        hipMemcpy(d_iq + plan->off[symbol_index], input, (size_t)input_size * sizeof(float2),
+                  hipMemcpyHostToDevice) != hipSuccess ||
+        upload(&d_slot, &slot, sizeof(slot)) != hipSuccess) {
+      break;
+    }
+    rc = nrphy_ofdm_demod_run(plan, 1, (const float*)d_iq, d_slot, window_offset, d_grid, ctx->stream);
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(grid_row, d_grid + (size_t)l * rg, (size_t)rg * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    rc = NRPHY_OK;
+  } while (false);
+  (void)hipFree(d_grid);
+  (void)hipFree(d_iq);
+  (void)hipFree(d_slot);
+  return rc;
 }
 
 extern "C" int nrphy_ofdm_plan_enable_timing(nrphy_ofdm_plan_t* plan, uint32_t max_runs)

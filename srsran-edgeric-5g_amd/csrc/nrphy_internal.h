@@ -234,6 +234,10 @@ struct OfdmLaunch {
 };
 hipError_t launch_ofdm(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* d_grid, const uint32_t* d_slot_index,
                        float2* d_iq, hipStream_t stream);
+// OFDM demodulation (the receive-side mirror of launch_ofdm): `p.phase` is the receive table (conjugate phase x scale),
+// window_offset = nof_samples_window_offset of the reference's demodulator configuration.
+hipError_t launch_ofdm_demod(const OfdmLaunch& p, uint32_t nof_grids, const float2* d_iq, const uint32_t* d_slot_index,
+                             uint32_t window_offset, uint32_t* d_grid, hipStream_t stream);
 hipError_t launch_dft(uint32_t size, int inverse, uint32_t batch, const float2* twiddle_fwd_inv, const float2* d_in,
                       float2* d_out, hipStream_t stream);
 bool       dft_size_supported(uint32_t size);

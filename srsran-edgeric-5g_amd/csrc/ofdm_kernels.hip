@@ -562,6 +562,106 @@ hipError_t launch_ofdm(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* 
 }
 
 // ================================================================================================================
+// OFDM demodulator: the receive-side mirror of ofdm_kernel.  Replaces ofdm_symbol_demodulator_impl::demodulate and
+// ofdm_slot_demodulator_impl::demodulate (R/lib/phy/lower/modulation/ofdm_demodulator_impl.cpp:98-171): skip the
+// cyclic prefix (minus the window offset), direct DFT, phase compensation x scale (x the window-offset phase ramp),
+// top bins -> lower half of the grid, bins from DC -> upper half, stored as cbf16 (round to nearest even, what
+// resource_grid_writer::put does with complex floats).
+// ================================================================================================================
+template <int N>
+__global__ __launch_bounds__(Plan<N>::T) void ofdm_demod_kernel(OfdmLaunch p, const float2* __restrict__ d_iq,
+                                                                const uint32_t* __restrict__ d_slot_index,
+                                                                uint32_t window_offset, uint32_t* __restrict__ d_grid)
+{
+  __shared__ cf  lds[N + N / 16 + 16];
+  const uint32_t tid  = threadIdx.x;
+  const uint32_t l    = blockIdx.x;
+  const uint32_t gp   = blockIdx.z * p.nof_ports + blockIdx.y; // grid * nof_ports + port
+  const uint32_t slot = d_slot_index ? to_constant(d_slot_index)[blockIdx.z] : 0u;
+  const uint32_t sym  = slot * p.nsymb + l; // symbol index within the subframe
+  const uint32_t cp   = to_constant(p.cp_len)[sym];
+  const cf       ph   = make_cf(to_constant(p.phase)[sym].x, to_constant(p.phase)[sym].y);
+  const uint32_t half = p.rg_size >> 1;
+
+  // The symbol's N samples after the cyclic prefix, straight into the registers of the first stage.
+  const float2* in = d_iq + (size_t)gp * p.slot_stride + to_constant(p.sym_offset)[sym] + (cp - window_offset);
+  const __amdgpu_buffer_rsrc_t rsrc_in =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(in), 0, (int)(N * 8u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
+      d_grid + ((size_t)gp * NRPHY_NSYMB + l) * p.rg_size, 0, (int)(p.rg_size * 4u), 0x00020000);
+  const TwiddleBase<N> tb = load_twiddle_base<-1, N>(p.twiddle, tid);
+  cf                   cur[Plan<N>::R0];
+#pragma unroll
+  for (int k = 0; k != Plan<N>::R0; ++k) {
+    const u32x2_t raw = __builtin_amdgcn_raw_buffer_load_b64(
+        rsrc_in, (int)((tid + (uint32_t)k * (N / Plan<N>::R0)) * 8u), 0, 0);
+    cur[k] = make_cf(__uint_as_float(raw.x), __uint_as_float(raw.y));
+  }
+  auto store = [&](uint32_t q, auto base, auto, cf v) {
+    constexpr uint32_t B   = decltype(base)::value;
+    const uint32_t     idx = q + B;
+    cf                 y   = cmul_uniform(v, ph);
+    if (window_offset != 0) { // wave-uniform: exp(+j 2 pi window_offset idx / N)
+      const float2 w = p.twiddle[(idx * window_offset) % N];
+      y              = cmul(y, make_cf(w.x, w.y));
+    }
+    // Bin -> subcarrier; bins of the guard band get an offset the range check drops.
+    uint32_t k = 0xFFFFFFu;
+    if (idx < half) {
+      k = idx + half;
+    } else if (idx >= N - half) {
+      k = idx - (N - half);
+    }
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t b = __builtin_convertvector(y, bf16x2_t);
+    __builtin_amdgcn_raw_buffer_store_b32(*reinterpret_cast<const uint32_t*>(&b), rsrc_out, (int)(k * 4u), 0, 0);
+  };
+  fft_from_registers<-1, N>(cur, tb, lds, p.twiddle, tid, store);
+}
+
+template <int N>
+static hipError_t launch_ofdm_demod_n(const OfdmLaunch& p, uint32_t nof_grids, const float2* d_iq,
+                                      const uint32_t* d_slot_index, uint32_t window_offset, uint32_t* d_grid,
+                                      hipStream_t stream)
+{
+  hipLaunchKernelGGL((ofdm_demod_kernel<N>), dim3(p.nsymb, p.nof_ports, nof_grids), dim3(Plan<N>::T), 0, stream, p,
+                     d_iq, d_slot_index, window_offset, d_grid);
+  return hipGetLastError();
+}
+
+hipError_t launch_ofdm_demod(const OfdmLaunch& p, uint32_t nof_grids, const float2* d_iq, const uint32_t* d_slot_index,
+                             uint32_t window_offset, uint32_t* d_grid, hipStream_t stream)
+{
+  if (nof_grids == 0) {
+    return hipSuccess;
+  }
+  switch (p.dft_size) {
+    case 4096:
+      return launch_ofdm_demod_n<4096>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 3072:
+      return launch_ofdm_demod_n<3072>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 2048:
+      return launch_ofdm_demod_n<2048>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 1536:
+      return launch_ofdm_demod_n<1536>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 1024:
+      return launch_ofdm_demod_n<1024>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 768:
+      return launch_ofdm_demod_n<768>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 512:
+      return launch_ofdm_demod_n<512>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 384:
+      return launch_ofdm_demod_n<384>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 256:
+      return launch_ofdm_demod_n<256>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 128:
+      return launch_ofdm_demod_n<128>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+// ================================================================================================================
 // Plain batched DFT (dft_processor): one workgroup per transform.
 // ================================================================================================================
 template <int SIGN, int N>

@@ -193,6 +193,28 @@ class OfdmPlan:
                                                             out.ctypes.data, n), "nrphy_ofdm_modulate_symbol_host")
         return out
 
+    def demod_run(self, nof_grids, d_iq, d_grid, d_slot_index=None, window_offset=0, stream=None):
+        """ofdm_slot_demodulator::demodulate for every port of nof_grids slots (device buffers)."""
+        _check(self.ctx.lib.nrphy_ofdm_demod_run(self.handle, nof_grids, _dptr(d_iq), _dptr(d_slot_index),
+                                                 window_offset, _dptr(d_grid), stream), "nrphy_ofdm_demod_run")
+
+    def demodulate_slot_host(self, iq, slot_index, window_offset=0):
+        """Host-span form: iq [nof_ports][slot samples] complex64 -> grid [nof_ports][14][12*bw_rb][2] uint16."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        grid = np.zeros((self.nof_ports, 14, 12 * self.cfg.bw_rb, 2), np.uint16)
+        _check(self.ctx.lib.nrphy_ofdm_demodulate_slot_host(self.handle, iq.ctypes.data, slot_index, window_offset,
+                                                            grid.ctypes.data), "nrphy_ofdm_demodulate_slot_host")
+        return grid
+
+    def demodulate_symbol_host(self, samples, symbol_index, window_offset=0):
+        """ofdm_symbol_demodulator::demodulate for one symbol of one port -> [12*bw_rb][2] uint16."""
+        samples = np.ascontiguousarray(samples, dtype=np.complex64)
+        row = np.zeros((12 * self.cfg.bw_rb, 2), np.uint16)
+        _check(self.ctx.lib.nrphy_ofdm_demodulate_symbol_host(self.handle, samples.ctypes.data, samples.size,
+                                                              symbol_index, window_offset, row.ctypes.data),
+               "nrphy_ofdm_demodulate_symbol_host")
+        return row
+
     def modulate_slot_host(self, grid, slot_index, out=None):
         """ofdm_slot_modulator::modulate for every port of one host grid: [nof_ports][slot samples] complex64."""
         grid = np.ascontiguousarray(grid, dtype=np.uint16)

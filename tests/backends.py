@@ -218,6 +218,15 @@ class CpuBackend:
         assert n > 0, n
         return iq.reshape(-1)[: nof_ports * n].reshape(nof_ports, n).copy()
 
+    def ofdm_demod_slot(self, cfg, iq, slot_index=0, window_offset=0):
+        """iq: [nof_ports][slot_size] complex64 -> grid [nof_ports][14][12*bw_rb][2] uint16 (raw bf16)."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        nof_ports = iq.shape[0]
+        grid = np.zeros((nof_ports, 14, 12 * cfg.bw_rb, 2), np.uint16)
+        n = self._f("ofdm_demodulate_slot")(C.byref(cfg), _ptr(iq), nof_ports, slot_index, window_offset, _ptr(grid))
+        assert n == iq.shape[1], (n, iq.shape)
+        return grid
+
     def codebook(self, kind, a=0, b=0, c=0):
         assert self.is_ref
         w = np.zeros((4, 4, 2), np.float32)

@@ -97,4 +97,18 @@ for name, (mu, bw, n, fc, slot) in {"n4096": (1, 273, 4096, 3.5e9, 1), "n2048": 
     og[name + "_iq"] = iq
     og[name + "_cfg"] = np.array([mu, bw, n, fc, slot], dtype=np.float64)
 np.savez_compressed(os.path.join(HERE, "ofdm_modulator.npz"), **og)
+
+# 5. OFDM demodulator ("next" row, PUSCH receive side): random IQ -> reference grid (cbf16), with and without a DFT
+#    window offset.
+rng = np.random.default_rng(38212)
+dg = {}
+for name, (mu, bw, n, fc, slot, wo) in {"d4096": (1, 273, 4096, 3.5e9, 1, 0), "d2048w": (0, 106, 2048, 2.4e9, 0, 9),
+                                        "d1536": (0, 106, 1536, 2.4e9, 0, 0), "d512w": (0, 25, 512, 2.4e9, 0, 3)}.items():
+    cfg = abi.OfdmConfig(mu, bw, n, 0, 1.0 / np.sqrt(n), fc)
+    size = backends.pkg.lib.slot_size(cfg, slot)
+    iq = (rng.standard_normal((2, size)) + 1j * rng.standard_normal((2, size))).astype(np.complex64)
+    dg[name + "_iq"] = iq
+    dg[name + "_grid"] = r.ofdm_demod_slot(cfg, iq, slot, wo)
+    dg[name + "_cfg"] = np.array([mu, bw, n, fc, slot, wo], dtype=np.float64)
+np.savez_compressed(os.path.join(HERE, "ofdm_demodulator.npz"), **dg)
 print("golden vectors written to", HERE)

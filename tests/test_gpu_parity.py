@@ -329,6 +329,76 @@ def test_ofdm_modulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
     plan.close()
 
 
+def bf16_to_f32(raw):
+    return (raw.astype(np.uint32) << 16).view(np.float32)
+
+
+def assert_bf16_grids_close(got, want, min_exact=0.99):
+    """cbf16 grids out of different float FFTs: at most one bf16 ulp apart, almost all identical."""
+    a, b = bf16_to_f32(got), bf16_to_f32(want)
+    scale = np.abs(b).max()
+    assert np.all(np.abs(a - b) <= np.maximum(np.abs(b), 1e-3 * scale) * 2.0 ** -7)
+    assert np.mean(got == want) >= min_exact
+
+
+@pytest.mark.parametrize("name", ["d4096", "d2048w", "d1536", "d512w"])
+def test_ofdm_demodulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
+    """Receive side of seam C (ofdm_slot_demodulator): device path against the oracle and the reference's output."""
+    import torch
+    g = np.load(os.path.join(cases.GOLDEN, "ofdm_demodulator.npz"))
+    mu, bw, n, fc, slot, wo = g[name + "_cfg"]
+    slot, wo = int(slot), int(wo)
+    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), 0, 1.0 / np.sqrt(n), float(fc))
+    iq = g[name + "_iq"]
+    nof_ports = iq.shape[0]
+    plan = lib.OfdmPlan(gpu_ctx, cfg, nof_ports)
+    # Two slots in one launch (the second one with the ports swapped) in the layout nrphy_ofdm_run writes.
+    buf = np.zeros((2, nof_ports, plan.slot_stride), np.complex64)
+    buf[0, :, : iq.shape[1]] = iq
+    buf[1, :, : iq.shape[1]] = iq[::-1]
+    d_grid = torch.zeros((2, nof_ports, 14, int(bw) * 12), dtype=torch.int32, device="cuda")
+    d_slot = dev(np.array([slot, slot], np.uint32).view(np.int32))
+    torch.cuda.synchronize()
+    plan.demod_run(2, dev(buf.view(np.float32)), d_grid, d_slot_index=d_slot, window_offset=wo)
+    gpu_ctx.synchronize()
+    got = d_grid.cpu().numpy().view(np.uint16).reshape(2, nof_ports, 14, int(bw) * 12, 2)
+    want = oracle.ofdm_demod_slot(cfg, iq, slot, wo)
+    assert_bf16_grids_close(got[0], want)
+    assert_bf16_grids_close(got[1], want[::-1])
+    assert_bf16_grids_close(got[0], g[name + "_grid"])   # the reference's own output
+    # Host-span entry point (ofdm_slot_demodulator::demodulate semantics).
+    assert np.array_equal(plan.demodulate_slot_host(iq, slot, wo), got[0])
+    # Host-span single-symbol entry point (ofdm_symbol_demodulator::demodulate semantics).
+    sym = 14 * slot + 5
+    start = sum(lib.symbol_size(cfg, 14 * slot + l) for l in range(5))
+    row = plan.demodulate_symbol_host(iq[0, start: start + lib.symbol_size(cfg, sym)], sym, wo)
+    assert np.array_equal(row, got[0, 0, 5])
+    # A window offset beyond the shortest cyclic prefix is rejected (ofdm_demodulator_impl.cpp:58-63).
+    assert gpu_ctx.lib.nrphy_ofdm_demod_run(plan.handle, 1, d_grid.data_ptr(), None, (144 * int(n)) // 2048,
+                                            d_grid.data_ptr(), None) == abi.ERR_ARGUMENT
+    plan.close()
+
+
+def test_ofdm_modulate_demodulate_round_trip(gpu_ctx):
+    """Transmit and receive chains back to back on the device: the grid comes back up to bf16 rounding."""
+    import torch
+    rng = np.random.default_rng(5)
+    n, bw, slots = 2048, 106, 3
+    cfg = abi.OfdmConfig(0, bw, n, 0, 1.0 / np.sqrt(n), 2.6e9)
+    grid = (rng.standard_normal((slots, 2, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    plan = lib.OfdmPlan(gpu_ctx, cfg, 2)
+    d_grid = dev(grid.view(np.uint32).view(np.int32))
+    d_iq = torch.zeros((slots, 2, plan.slot_stride, 2), dtype=torch.float32, device="cuda")
+    d_back = torch.zeros_like(d_grid)
+    torch.cuda.synchronize()
+    plan.run(slots, d_grid, d_iq)
+    plan.demod_run(slots, d_iq, d_back)
+    gpu_ctx.synchronize()
+    back = d_back.cpu().numpy().view(np.uint16).reshape(grid.shape)
+    assert_bf16_grids_close(back, grid, min_exact=0.9)
+    plan.close()
+
+
 def test_end_to_end_slot_batch(gpu_ctx, oracle):
     """PDSCH + OFDM chained on the device for a small batch of config-2 slots, against the oracle chain."""
     import torch

@@ -17,6 +17,7 @@ import backends
 import cases
 
 abi = backends.abi
+lib = backends.pkg.lib
 
 LIFTING_SIZES = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52,
                  56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128, 144, 160, 176, 192, 208, 224, 240, 256, 288, 320, 352,
@@ -65,6 +66,45 @@ def test_oracle_ofdm_golden(oracle, name):
     want = g[name + "_iq"]
     # The reference's own tolerance is |err| / sqrt(N) < 5e-5 (ofdm_modulator_vectortest.cpp:30); ours: 1e-5 relative.
     assert np.abs(iq - want).max() / np.abs(want).max() < 1e-5
+
+
+def bf16_to_f32(raw):
+    return (raw.astype(np.uint32) << 16).view(np.float32)
+
+
+def assert_bf16_grids_close(got, want, min_exact=0.99):
+    """cbf16 grids that went through different float FFTs: at most one bf16 ulp apart, almost all identical."""
+    a, b = bf16_to_f32(got), bf16_to_f32(want)
+    scale = np.abs(b).max()
+    assert np.all(np.abs(a - b) <= np.maximum(np.abs(b), 1e-3 * scale) * 2.0 ** -7)
+    assert np.mean(got == want) >= min_exact
+
+
+@pytest.mark.parametrize("case", [(1, 273, 4096, 3.5e9, 1, 0), (0, 106, 2048, 2.4e9, 0, 9), (0, 52, 1024, 2.4e9, 0, 0),
+                                  (0, 106, 1536, 2.4e9, 0, 5), (1, 51, 768, 3.6e9, 1, 0), (0, 25, 512, 2.4e9, 0, 3)])
+def test_oracle_ofdm_demodulator_vs_reference(oracle, ref, case):
+    """ofdm_slot_demodulator_impl (compiled reference) against the C restatement on random IQ, and the
+    modulate -> demodulate round trip of ofdm_modulator_unittest / ofdm_demodulator_unittest style."""
+    if ref is None:
+        pytest.skip("compiled reference not available")
+    mu, bw, n, fc, slot, wo = case
+    rng = np.random.default_rng(n + wo)
+    cfg = abi.OfdmConfig(mu, bw, n, 0, 1.0 / np.sqrt(n), fc)
+    size = lib.slot_size(cfg, slot)
+    iq = (rng.standard_normal((2, size)) + 1j * rng.standard_normal((2, size))).astype(np.complex64)
+    assert_bf16_grids_close(oracle.ofdm_demod_slot(cfg, iq, slot, wo), ref.ofdm_demod_slot(cfg, iq, slot, wo))
+    # Round trip: a bf16 grid modulated and demodulated with scales whose product is 1 / N comes back (bf16 rounding).
+    grid = (rng.standard_normal((1, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    back = oracle.ofdm_demod_slot(cfg, oracle.ofdm_slot(cfg, grid, slot), slot, 0)
+    assert_bf16_grids_close(back, grid, min_exact=0.9)
+
+
+@pytest.mark.parametrize("name", ["d4096", "d2048w", "d1536", "d512w"])
+def test_oracle_ofdm_demodulator_golden(oracle, name):
+    g = np.load(os.path.join(cases.GOLDEN, "ofdm_demodulator.npz"))
+    mu, bw, n, fc, slot, wo = g[name + "_cfg"]
+    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), 0, 1.0 / np.sqrt(n), float(fc))
+    assert_bf16_grids_close(oracle.ofdm_demod_slot(cfg, g[name + "_iq"], int(slot), int(wo)), g[name + "_grid"])
 
 
 def test_baseline_config_derived_values(oracle):
