@@ -11,6 +11,7 @@
 #include <cstring>
 #include <array>
 #include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -321,6 +322,47 @@ hipError_t upload(T** dptr, const void* src, size_t bytes)
   return hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
 }
 
+// All tables of a plan in ONE device allocation filled by ONE copy (a plan of a single PDU used to spend most of its
+// creation time in a dozen hipMalloc / hipMemcpy pairs).  add() registers a table; commit() allocates, copies and
+// points every registered device pointer into the block, followed by `scratch_bytes` of uninitialised device memory.
+class DeviceArena
+{
+public:
+  template <typename T>
+  void add(T** dptr, const void* src, size_t bytes)
+  {
+    items.push_back({(void**)dptr, src, bytes, total});
+    total += (bytes + 255) & ~(size_t)255;
+  }
+  hipError_t commit(void** base, size_t scratch_bytes, void** scratch)
+  {
+    std::vector<uint8_t> staging(std::max<size_t>(total, 256), 0);
+    for (const Item& it : items) {
+      if (it.bytes != 0) {
+        std::memcpy(&staging[it.offset], it.src, it.bytes);
+      }
+    }
+    hipError_t e = hipMalloc(base, staging.size() + scratch_bytes);
+    if (e != hipSuccess) {
+      return e;
+    }
+    for (const Item& it : items) {
+      *it.dptr = (uint8_t*)*base + it.offset;
+    }
+    *scratch = (uint8_t*)*base + staging.size();
+    return hipMemcpy(*base, staging.data(), staging.size(), hipMemcpyHostToDevice);
+  }
+
+private:
+  struct Item {
+    void**      dptr;
+    const void* src;
+    size_t      bytes, offset;
+  };
+  std::vector<Item> items;
+  size_t            total = 0;
+};
+
 } // namespace
 
 struct nrphy_ctx {
@@ -332,7 +374,32 @@ struct nrphy_ctx {
   uint32_t*    d_x1     = nullptr;
   float2*      d_twiddle[10] = {}; // one table per supported DFT size (twiddle_slot)
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
+  // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
+  std::mutex host_mutex;
+  void*      scratch[6]       = {};
+  size_t     scratch_bytes[6] = {};
 };
+
+namespace {
+
+// Staging buffer `slot` of the context with room for `bytes` (reallocated only when it has to grow).
+enum ScratchSlot { SCRATCH_TB = 0, SCRATCH_GRID, SCRATCH_CW_RM, SCRATCH_CW_SCR, SCRATCH_IQ, SCRATCH_SMALL };
+void* ctx_scratch(nrphy_ctx* ctx, ScratchSlot slot, size_t bytes)
+{
+  if (bytes > ctx->scratch_bytes[slot]) {
+    (void)hipFree(ctx->scratch[slot]);
+    ctx->scratch[slot]       = nullptr;
+    ctx->scratch_bytes[slot] = 0;
+    const size_t want        = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
+    if (hipMalloc(&ctx->scratch[slot], want) != hipSuccess) {
+      return nullptr;
+    }
+    ctx->scratch_bytes[slot] = want;
+  }
+  return ctx->scratch[slot];
+}
+
+} // namespace
 
 struct nrphy_pdsch_plan {
   nrphy_ctx*            ctx = nullptr;
@@ -340,6 +407,7 @@ struct nrphy_pdsch_plan {
   std::vector<uint64_t> cw_offset;
   uint64_t              cw_bits = 0;
   uint32_t              nof_grids = 0, grid_nof_ports = 0, grid_nof_subc = 0;
+  void*                 d_arena = nullptr; // the one device allocation every d_* pointer below points into
   PduDev*               d_pdus = nullptr;
   CbWork*               d_work = nullptr;
   DmrsWork*             d_dmrs = nullptr;
@@ -697,6 +765,9 @@ extern "C" int nrphy_destroy(nrphy_ctx_t* ctx)
   (void)hipFree(ctx->d_graphs);
   (void)hipFree(ctx->d_gold);
   (void)hipFree(ctx->d_tbcrc);
+  for (void* b : ctx->scratch) {
+    (void)hipFree(b);
+  }
   (void)hipFree(ctx->d_x1);
   for (float2* t : ctx->d_twiddle) {
     (void)hipFree(t);
@@ -772,6 +843,31 @@ const float2* get_twiddle(nrphy_ctx* ctx, uint32_t size)
 // ================================================================================================================
 // PDSCH plan
 // ================================================================================================================
+namespace {
+
+// Everything the RE mapping of a PDU depends on (data_re_mask + the DM-RS comb): PDUs of a batch that repeat an
+// allocation share its tables instead of rebuilding them.
+void append_allocation_signature(const nrphy_pdsch_pdu_t& pdu, std::vector<uint64_t>& sig)
+{
+  sig.insert(sig.end(), std::begin(pdu.prb_mask), std::end(pdu.prb_mask));
+  sig.push_back(((uint64_t)pdu.start_symbol_index << 48) | ((uint64_t)pdu.nof_symbols << 40) |
+                ((uint64_t)pdu.nof_cdm_groups_without_data << 36) | ((uint64_t)pdu.nof_layers << 32) |
+                pdu.dmrs_symbol_mask);
+  sig.push_back(((uint64_t)pdu.bwp_start_rb << 32) | ((uint64_t)pdu.bwp_size_rb << 8) | pdu.nof_reserved);
+  for (unsigned r = 0; r != pdu.nof_reserved; ++r) {
+    sig.insert(sig.end(), std::begin(pdu.reserved[r].prb_mask), std::end(pdu.reserved[r].prb_mask));
+    sig.push_back(((uint64_t)pdu.reserved[r].re_mask << 32) | pdu.reserved[r].symbol_mask);
+  }
+}
+
+struct ReMapping {
+  uint32_t sym_re_start[NRPHY_NSYMB + 1];
+  uint32_t sym_kind[NRPHY_NSYMB];
+  uint32_t sym_arg[NRPHY_NSYMB];
+};
+
+} // namespace
+
 extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
                                        const uint64_t* tb_offset, const uint32_t* grid_index, uint32_t nof_grids,
                                        uint32_t grid_nof_ports, uint32_t grid_nof_subc, nrphy_pdsch_plan_t** out)
@@ -795,6 +891,8 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   std::vector<CbWork>   work;
   std::vector<DmrsWork> dmrs;
   std::vector<CrcWork>  crc_work;
+  std::vector<uint64_t> remap_sig;
+  std::map<std::vector<uint64_t>, ReMapping> remap_cache;
   std::vector<ScrWork>  scr_work;
   std::vector<std::vector<uint32_t>> pdus_of_grid(nof_grids);
   std::vector<float>    weights;
@@ -818,39 +916,54 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     }
     PduDev pd;
     std::memset(&pd, 0, sizeof(pd));
-    // RE mapping tables.
+    // RE mapping tables (shared by the PDUs of the batch that repeat this allocation).
     unsigned nof_re = 0;
-    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
-      pd.sym_re_start[l] = nof_re;
-      data_re_mask(pdu, l, mask);
-      list.clear();
-      for (unsigned k = 0; k != grid_nof_subc; ++k) {
-        if (mask[k]) {
-          list.push_back((uint16_t)k);
-        }
-      }
-      if (list.empty()) {
-        pd.sym_kind[l] = SYM_NONE;
-      } else if ((unsigned)(list.back() - list.front()) + 1 == list.size()) {
-        pd.sym_kind[l] = SYM_CONTIGUOUS;
-        pd.sym_arg[l]  = list.front();
-      } else {
-        pd.sym_kind[l] = SYM_TABLE;
-        pd.sym_arg[l]  = (uint32_t)re_table.size();
-        // Reuse the previous symbol's list when identical (the common case).
-        for (unsigned lp = 0; lp != l; ++lp) {
-          if (pd.sym_kind[lp] == SYM_TABLE && pd.sym_re_start[lp + 1] - pd.sym_re_start[lp] == list.size() &&
-              std::equal(list.begin(), list.end(), re_table.begin() + pd.sym_arg[lp])) {
-            pd.sym_arg[l] = pd.sym_arg[lp];
-            break;
+    remap_sig.clear();
+    append_allocation_signature(pdu, remap_sig);
+    auto cached = remap_cache.find(remap_sig);
+    if (cached != remap_cache.end()) {
+      std::memcpy(pd.sym_re_start, cached->second.sym_re_start, sizeof(pd.sym_re_start));
+      std::memcpy(pd.sym_kind, cached->second.sym_kind, sizeof(pd.sym_kind));
+      std::memcpy(pd.sym_arg, cached->second.sym_arg, sizeof(pd.sym_arg));
+      nof_re = pd.sym_re_start[NRPHY_NSYMB];
+    } else {
+      for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+        pd.sym_re_start[l] = nof_re;
+        data_re_mask(pdu, l, mask);
+        list.clear();
+        for (unsigned k = 0; k != grid_nof_subc; ++k) {
+          if (mask[k]) {
+            list.push_back((uint16_t)k);
           }
         }
-        if (pd.sym_arg[l] == re_table.size()) {
-          re_table.insert(re_table.end(), list.begin(), list.end());
+        if (list.empty()) {
+          pd.sym_kind[l] = SYM_NONE;
+        } else if ((unsigned)(list.back() - list.front()) + 1 == list.size()) {
+          pd.sym_kind[l] = SYM_CONTIGUOUS;
+          pd.sym_arg[l]  = list.front();
+        } else {
+          pd.sym_kind[l] = SYM_TABLE;
+          pd.sym_arg[l]  = (uint32_t)re_table.size();
+          // Reuse the previous symbol's list when identical (the common case).
+          for (unsigned lp = 0; lp != l; ++lp) {
+            if (pd.sym_kind[lp] == SYM_TABLE && pd.sym_re_start[lp + 1] - pd.sym_re_start[lp] == list.size() &&
+                std::equal(list.begin(), list.end(), re_table.begin() + pd.sym_arg[lp])) {
+              pd.sym_arg[l] = pd.sym_arg[lp];
+              break;
+            }
+          }
+          if (pd.sym_arg[l] == re_table.size()) {
+            re_table.insert(re_table.end(), list.begin(), list.end());
+          }
         }
+        nof_re += (unsigned)list.size();
+        pd.sym_re_start[l + 1] = nof_re;
       }
-      nof_re += (unsigned)list.size();
-      pd.sym_re_start[l + 1] = nof_re;
+      ReMapping m;
+      std::memcpy(m.sym_re_start, pd.sym_re_start, sizeof(m.sym_re_start));
+      std::memcpy(m.sym_kind, pd.sym_kind, sizeof(m.sym_kind));
+      std::memcpy(m.sym_arg, pd.sym_arg, sizeof(m.sym_arg));
+      remap_cache.insert({remap_sig, m});
     }
     if (nof_re == 0) {
       status = NRPHY_ERR_INVALID_PDU;
@@ -1005,9 +1118,27 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   {
     std::map<std::vector<uint64_t>, std::array<uint32_t, 3>> seen; // segment list -> (begin, count, long runs)
     std::vector<uint8_t>  cov((size_t)NRPHY_NSYMB * grid_nof_subc);
-    std::vector<uint64_t> key;
+    std::vector<uint64_t> key, sig;
+    std::map<std::vector<uint64_t>, std::array<uint32_t, 3>> by_signature; // allocation -> (begin, count, long runs)
     for (uint32_t g = 0; g != nof_grids; ++g) {
       for (uint32_t port = 0; port != grid_nof_ports; ++port) {
+        // Everything the coverage of this (grid, port) depends on: grids that repeat an allocation (the normal case
+        // in a batch of slots) reuse its segment list without rebuilding the RE masks.
+        sig.clear();
+        for (uint32_t i : pdus_of_grid[g]) {
+          const nrphy_pdsch_pdu_t& pdu = pdus[i];
+          if (port >= pdu.nof_ports) {
+            continue;
+          }
+          append_allocation_signature(pdu, sig);
+        }
+        auto known = by_signature.find(sig);
+        if (known != by_signature.end()) {
+          if (known->second[1] != 0) {
+            zero_work.push_back({g, port, known->second[0], known->second[1], known->second[2]});
+          }
+          continue;
+        }
         std::fill(cov.begin(), cov.end(), 0);
         for (uint32_t i : pdus_of_grid[g]) {
           const nrphy_pdsch_pdu_t& pdu = pdus[i];
@@ -1051,6 +1182,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
           }
         }
         if (key.empty()) {
+          by_signature.insert({sig, {0, 0, 0}});
           continue;
         }
         auto it = seen.find(key);
@@ -1069,6 +1201,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
           }
           it = seen.insert({key, {begin, (uint32_t)key.size(), nof_long}}).first;
         }
+        by_signature.insert({sig, it->second});
         zero_work.push_back({g, port, it->second[0], it->second[1], it->second[2]});
       }
     }
@@ -1079,20 +1212,26 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   plan->n_dmrs  = (uint32_t)dmrs.size();
   plan->n_crc_work = (uint32_t)crc_work.size();
   plan->n_scr_work = (uint32_t)scr_work.size();
-  if (upload(&plan->d_crc_work, crc_work.data(), crc_work.size() * sizeof(CrcWork)) != hipSuccess ||
-      upload(&plan->d_scr_work, scr_work.data(), scr_work.size() * sizeof(ScrWork)) != hipSuccess ||
-      upload(&plan->d_pdus, plan->pdus.data(), plan->pdus.size() * sizeof(PduDev)) != hipSuccess ||
-      upload(&plan->d_work, work.data(), work.size() * sizeof(CbWork)) != hipSuccess ||
-      upload(&plan->d_dmrs, dmrs.data(), dmrs.size() * sizeof(DmrsWork)) != hipSuccess ||
-      upload(&plan->d_weights, weights.data(), weights.size() * sizeof(float)) != hipSuccess ||
-      upload(&plan->d_re_table, re_table.data(), re_table.size() * sizeof(uint16_t)) != hipSuccess ||
-      upload(&plan->d_zero_work, zero_work.data(), zero_work.size() * sizeof(ZeroWork)) != hipSuccess ||
-      upload(&plan->d_zero_segs, zero_segs.data(), zero_segs.size() * sizeof(ZeroSeg)) != hipSuccess ||
-      hipMalloc((void**)&plan->d_scr, sizeof(uint32_t) * std::max<uint64_t>(4, plan->scr_words)) != hipSuccess ||
-      hipMalloc((void**)&plan->d_tb_crc, 2 * sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size())) != hipSuccess ||
-      hipMemset(plan->d_tb_crc, 0, 2 * sizeof(uint32_t) * std::max<size_t>(1, plan->pdus.size())) != hipSuccess) {
-    nrphy_pdsch_plan_destroy(plan);
-    return NRPHY_ERR_DEVICE;
+  {
+    const size_t         n_acc = std::max<size_t>(1, plan->pdus.size());
+    std::vector<uint32_t> zero_acc(2 * n_acc, 0); // the two TB-CRC accumulators start cleared
+    DeviceArena          arena;
+    arena.add(&plan->d_crc_work, crc_work.data(), crc_work.size() * sizeof(CrcWork));
+    arena.add(&plan->d_scr_work, scr_work.data(), scr_work.size() * sizeof(ScrWork));
+    arena.add(&plan->d_pdus, plan->pdus.data(), plan->pdus.size() * sizeof(PduDev));
+    arena.add(&plan->d_work, work.data(), work.size() * sizeof(CbWork));
+    arena.add(&plan->d_dmrs, dmrs.data(), dmrs.size() * sizeof(DmrsWork));
+    arena.add(&plan->d_weights, weights.data(), weights.size() * sizeof(float));
+    arena.add(&plan->d_re_table, re_table.data(), re_table.size() * sizeof(uint16_t));
+    arena.add(&plan->d_zero_work, zero_work.data(), zero_work.size() * sizeof(ZeroWork));
+    arena.add(&plan->d_zero_segs, zero_segs.data(), zero_segs.size() * sizeof(ZeroSeg));
+    arena.add(&plan->d_tb_crc, zero_acc.data(), zero_acc.size() * sizeof(uint32_t));
+    void* scratch = nullptr;
+    if (arena.commit(&plan->d_arena, sizeof(uint32_t) * std::max<uint64_t>(4, plan->scr_words), &scratch) != hipSuccess) {
+      nrphy_pdsch_plan_destroy(plan);
+      return NRPHY_ERR_DEVICE;
+    }
+    plan->d_scr = (uint32_t*)scratch;
   }
   // The dynamic LDS of the codeblock launch also serves the DM-RS waves it may carry.
   plan->lds_lin_words = std::max<uint32_t>(plan->lds_lin_words, 64);
@@ -1106,17 +1245,7 @@ extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
     return NRPHY_OK;
   }
   (void)hipSetDevice(plan->ctx->device);
-  (void)hipFree(plan->d_pdus);
-  (void)hipFree(plan->d_work);
-  (void)hipFree(plan->d_dmrs);
-  (void)hipFree(plan->d_weights);
-  (void)hipFree(plan->d_re_table);
-  (void)hipFree(plan->d_tb_crc);
-  (void)hipFree(plan->d_crc_work);
-  (void)hipFree(plan->d_scr_work);
-  (void)hipFree(plan->d_zero_work);
-  (void)hipFree(plan->d_zero_segs);
-  (void)hipFree(plan->d_scr);
+  (void)hipFree(plan->d_arena);
   for (hipEvent_t e : plan->events) {
     (void)hipEventDestroy(e);
   }
@@ -1276,21 +1405,23 @@ extern "C" int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_
   const size_t tb_alloc   = ((size_t)pdu->tb_size_bytes + 7) & ~(size_t)3;
   const size_t grid_bytes = (size_t)grid_nof_ports * NRPHY_NSYMB * grid_nof_subc * 4;
   const size_t cw_bytes   = (size_t)(plan->cw_bits / 8);
-  uint8_t *    d_tb = nullptr, *d_grid = nullptr, *d_rm = nullptr, *d_scr = nullptr;
+  std::lock_guard<std::mutex> lock(ctx->host_mutex);
+  uint8_t* d_tb   = (uint8_t*)ctx_scratch(ctx, SCRATCH_TB, tb_alloc);
+  uint8_t* d_grid = grid ? (uint8_t*)ctx_scratch(ctx, SCRATCH_GRID, grid_bytes) : nullptr;
+  uint8_t* d_rm   = cw_rm ? (uint8_t*)ctx_scratch(ctx, SCRATCH_CW_RM, cw_bytes) : nullptr;
+  uint8_t* d_scr  = cw_scrambled ? (uint8_t*)ctx_scratch(ctx, SCRATCH_CW_SCR, cw_bytes) : nullptr;
   rc = NRPHY_ERR_DEVICE;
   do {
-    if (hipMalloc((void**)&d_tb, tb_alloc) != hipSuccess || hipMemset(d_tb, 0, tb_alloc) != hipSuccess ||
-        hipMemcpy(d_tb, tb, pdu->tb_size_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    if (d_tb == nullptr || (grid && d_grid == nullptr) || (cw_rm && d_rm == nullptr) ||
+        (cw_scrambled && d_scr == nullptr)) {
       break;
     }
-    if (grid && (hipMalloc((void**)&d_grid, grid_bytes) != hipSuccess ||
-                 hipMemcpy(d_grid, grid, grid_bytes, hipMemcpyHostToDevice) != hipSuccess)) {
+    // The transport block is readable to the next multiple of 4: clear the tail word, then the bytes.
+    if (hipMemsetAsync(d_tb + (tb_alloc - 8), 0, 8, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_tb, tb, pdu->tb_size_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
       break;
     }
-    if (cw_rm && hipMalloc((void**)&d_rm, cw_bytes) != hipSuccess) {
-      break;
-    }
-    if (cw_scrambled && hipMalloc((void**)&d_scr, cw_bytes) != hipSuccess) {
+    if (grid && hipMemcpyAsync(d_grid, grid, grid_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
       break;
     }
     rc = nrphy_pdsch_run(plan, d_tb, d_grid, d_rm, d_scr, 0, ctx->stream);
@@ -1298,27 +1429,23 @@ extern "C" int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_
       break;
     }
     rc = NRPHY_ERR_DEVICE;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-      break;
-    }
     nrphy_pdsch_derived_t d;
     nrphy_pdsch_derive(pdu, &d);
     const size_t cw_out = (d.codeword_bits + 7) / 8;
-    if (grid && hipMemcpy(grid, d_grid, grid_bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (grid && hipMemcpyAsync(grid, d_grid, grid_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
       break;
     }
-    if (cw_rm && hipMemcpy(cw_rm, d_rm, cw_out, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (cw_rm && hipMemcpyAsync(cw_rm, d_rm, cw_out, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
       break;
     }
-    if (cw_scrambled && hipMemcpy(cw_scrambled, d_scr, cw_out, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (cw_scrambled && hipMemcpyAsync(cw_scrambled, d_scr, cw_out, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+      break;
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
       break;
     }
     rc = NRPHY_OK;
   } while (false);
-  (void)hipFree(d_tb);
-  (void)hipFree(d_grid);
-  (void)hipFree(d_rm);
-  (void)hipFree(d_scr);
   nrphy_pdsch_plan_destroy(plan);
   return rc;
 }
@@ -1489,23 +1616,22 @@ extern "C" int nrphy_ofdm_demodulate_slot_host(nrphy_ofdm_plan_t* plan, const fl
     return NRPHY_ERR_ARGUMENT;
   }
   nrphy_ctx*   ctx        = plan->ctx;
+  std::lock_guard<std::mutex> lock(ctx->host_mutex);
   const size_t grid_words = (size_t)plan->nof_ports * NRPHY_NSYMB * 12 * plan->cfg.bw_rb;
   const size_t slot_size  = nrphy_ofdm_slot_size(&plan->cfg, slot_index);
   uint32_t *   d_grid = nullptr, *d_slot = nullptr;
   float2*      d_iq   = nullptr;
   int          rc     = NRPHY_ERR_DEVICE;
   do {
-    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&d_grid, grid_words * 4) != hipSuccess ||
-        hipMalloc((void**)&d_iq, (size_t)plan->nof_ports * plan->slot_stride * sizeof(float2)) != hipSuccess ||
-        upload(&d_slot, &slot_index, sizeof(slot_index)) != hipSuccess) {
+    if (hipSetDevice(ctx->device) != hipSuccess || (d_grid = (uint32_t*)ctx_scratch(ctx, SCRATCH_GRID, grid_words * 4)) == nullptr ||
+        (d_iq = (float2*)ctx_scratch(ctx, SCRATCH_IQ, (size_t)plan->nof_ports * plan->slot_stride * sizeof(float2))) == nullptr ||
+        (d_slot = (uint32_t*)ctx_scratch(ctx, SCRATCH_SMALL, 16)) == nullptr ||
+        hipMemcpy(d_slot, &slot_index, sizeof(slot_index), hipMemcpyHostToDevice) != hipSuccess) {
       break;
     }
-    bool ok = true;
-    for (uint32_t port = 0; port != plan->nof_ports && ok; ++port) { // host: ports back to back, slot_size each
-      ok = hipMemcpy(d_iq + (size_t)port * plan->slot_stride, iq + 2 * (size_t)port * slot_size,
-                     slot_size * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
-    }
-    if (!ok) {
+    // Host: ports back to back, slot_size samples each; device: slot_stride apart.
+    if (hipMemcpy2D(d_iq, (size_t)plan->slot_stride * sizeof(float2), iq, slot_size * sizeof(float2),
+                    slot_size * sizeof(float2), plan->nof_ports, hipMemcpyHostToDevice) != hipSuccess) {
       break;
     }
     rc = nrphy_ofdm_demod_run(plan, 1, (const float*)d_iq, d_slot, window_offset, d_grid, ctx->stream);
@@ -1519,9 +1645,6 @@ extern "C" int nrphy_ofdm_demodulate_slot_host(nrphy_ofdm_plan_t* plan, const fl
     }
     rc = NRPHY_OK;
   } while (false);
-  (void)hipFree(d_grid);
-  (void)hipFree(d_iq);
-  (void)hipFree(d_slot);
   return rc;
 }
 
@@ -1535,6 +1658,7 @@ extern "C" int nrphy_ofdm_demodulate_symbol_host(nrphy_ofdm_plan_t* plan, const 
   // One symbol of one port: the samples are placed where the slot kernel expects them (the other symbols of the
   // staging slot transform zeros), the symbol's row is read back.
   nrphy_ctx*     ctx  = plan->ctx;
+  std::lock_guard<std::mutex> lock(ctx->host_mutex);
   const uint32_t rg   = 12 * plan->cfg.bw_rb;
   const uint32_t slot = symbol_index / plan->nsymb, l = symbol_index % plan->nsymb;
   const size_t   iq_samples = (size_t)plan->nof_ports * plan->slot_stride;
@@ -1543,12 +1667,13 @@ extern "C" int nrphy_ofdm_demodulate_symbol_host(nrphy_ofdm_plan_t* plan, const 
   int            rc     = NRPHY_ERR_DEVICE;
   do {
     if (hipSetDevice(ctx->device) != hipSuccess ||
-        hipMalloc((void**)&d_grid, (size_t)plan->nof_ports * NRPHY_NSYMB * rg * 4) != hipSuccess ||
-        hipMalloc((void**)&d_iq, iq_samples * sizeof(float2)) != hipSuccess ||
+        (d_grid = (uint32_t*)ctx_scratch(ctx, SCRATCH_GRID, (size_t)plan->nof_ports * NRPHY_NSYMB * rg * 4)) == nullptr ||
+        (d_iq = (float2*)ctx_scratch(ctx, SCRATCH_IQ, iq_samples * sizeof(float2))) == nullptr ||
         hipMemset(d_iq, 0, iq_samples * sizeof(float2)) != hipSuccess ||
         hipMemcpy(d_iq + plan->off[symbol_index], input, (size_t)input_size * sizeof(float2),
                   hipMemcpyHostToDevice) != hipSuccess ||
-        upload(&d_slot, &slot, sizeof(slot)) != hipSuccess) {
+        (d_slot = (uint32_t*)ctx_scratch(ctx, SCRATCH_SMALL, 16)) == nullptr ||
+        hipMemcpy(d_slot, &slot, sizeof(slot), hipMemcpyHostToDevice) != hipSuccess) {
       break;
     }
     rc = nrphy_ofdm_demod_run(plan, 1, (const float*)d_iq, d_slot, window_offset, d_grid, ctx->stream);
@@ -1562,9 +1687,6 @@ extern "C" int nrphy_ofdm_demodulate_symbol_host(nrphy_ofdm_plan_t* plan, const 
     }
     rc = NRPHY_OK;
   } while (false);
-  (void)hipFree(d_grid);
-  (void)hipFree(d_iq);
-  (void)hipFree(d_slot);
   return rc;
 }
 
@@ -1614,6 +1736,7 @@ extern "C" int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const vo
     return NRPHY_ERR_ARGUMENT;
   }
   nrphy_ctx*   ctx        = plan->ctx;
+  std::lock_guard<std::mutex> lock(ctx->host_mutex);
   const size_t grid_words = (size_t)plan->nof_ports * NRPHY_NSYMB * 12 * plan->cfg.bw_rb;
   const size_t iq_samples = (size_t)plan->nof_ports * plan->slot_stride;
   uint32_t *   d_grid = nullptr, *d_slot = nullptr;
@@ -1621,10 +1744,11 @@ extern "C" int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const vo
   const uint32_t slot = symbol_index / plan->nsymb;
   int            rc   = NRPHY_ERR_DEVICE;
   do {
-    if (hipMalloc((void**)&d_grid, grid_words * 4) != hipSuccess ||
+    if ((d_grid = (uint32_t*)ctx_scratch(ctx, SCRATCH_GRID, grid_words * 4)) == nullptr ||
         hipMemcpy(d_grid, grid, grid_words * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc((void**)&d_iq, iq_samples * sizeof(float2)) != hipSuccess ||
-        upload(&d_slot, &slot, sizeof(slot)) != hipSuccess) {
+        (d_iq = (float2*)ctx_scratch(ctx, SCRATCH_IQ, iq_samples * sizeof(float2))) == nullptr ||
+        (d_slot = (uint32_t*)ctx_scratch(ctx, SCRATCH_SMALL, 16)) == nullptr ||
+        hipMemcpy(d_slot, &slot, sizeof(slot), hipMemcpyHostToDevice) != hipSuccess) {
       break;
     }
     rc = nrphy_ofdm_run(plan, 1, d_grid, d_slot, (float*)d_iq, ctx->stream);
@@ -1641,9 +1765,6 @@ extern "C" int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const vo
     }
     rc = NRPHY_OK;
   } while (false);
-  (void)hipFree(d_grid);
-  (void)hipFree(d_iq);
-  (void)hipFree(d_slot);
   return rc;
 }
 
@@ -1698,6 +1819,7 @@ extern "C" int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void
     return NRPHY_ERR_ARGUMENT;
   }
   nrphy_ctx*     ctx        = plan->ctx;
+  std::lock_guard<std::mutex> lock(ctx->host_mutex);
   const size_t   grid_words = (size_t)plan->nof_ports * NRPHY_NSYMB * 12 * plan->cfg.bw_rb;
   const size_t   iq_samples = (size_t)plan->nof_ports * plan->slot_stride;
   const uint32_t slot_size  = nrphy_ofdm_slot_size(&plan->cfg, slot_index);
@@ -1705,10 +1827,11 @@ extern "C" int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void
   float2*        d_iq   = nullptr;
   int            rc     = NRPHY_ERR_DEVICE;
   do {
-    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&d_grid, grid_words * 4) != hipSuccess ||
+    if (hipSetDevice(ctx->device) != hipSuccess || (d_grid = (uint32_t*)ctx_scratch(ctx, SCRATCH_GRID, grid_words * 4)) == nullptr ||
         hipMemcpy(d_grid, grid, grid_words * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc((void**)&d_iq, iq_samples * sizeof(float2)) != hipSuccess ||
-        upload(&d_slot, &slot_index, sizeof(slot_index)) != hipSuccess) {
+        (d_iq = (float2*)ctx_scratch(ctx, SCRATCH_IQ, iq_samples * sizeof(float2))) == nullptr ||
+        (d_slot = (uint32_t*)ctx_scratch(ctx, SCRATCH_SMALL, 16)) == nullptr ||
+        hipMemcpy(d_slot, &slot_index, sizeof(slot_index), hipMemcpyHostToDevice) != hipSuccess) {
       break;
     }
     rc = nrphy_ofdm_run(plan, 1, d_grid, d_slot, (float*)d_iq, ctx->stream);
@@ -1719,17 +1842,11 @@ extern "C" int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
       break;
     }
-    bool ok = true;
-    for (uint32_t port = 0; port != plan->nof_ports && ok; ++port) {
-      ok = hipMemcpy(iq + 2 * (size_t)port * slot_size, d_iq + (size_t)port * plan->slot_stride,
-                     (size_t)slot_size * sizeof(float2), hipMemcpyDeviceToHost) == hipSuccess;
-    }
-    if (ok) {
+    // Ports back to back on the host, slot_stride apart on the device: one strided copy.
+    if (hipMemcpy2D(iq, (size_t)slot_size * sizeof(float2), d_iq, (size_t)plan->slot_stride * sizeof(float2),
+                    (size_t)slot_size * sizeof(float2), plan->nof_ports, hipMemcpyDeviceToHost) == hipSuccess) {
       rc = NRPHY_OK;
     }
   } while (false);
-  (void)hipFree(d_grid);
-  (void)hipFree(d_iq);
-  (void)hipFree(d_slot);
   return rc;
 }
