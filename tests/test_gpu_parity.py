@@ -426,6 +426,33 @@ def test_end_to_end_slot_batch(gpu_ctx, oracle):
         assert rel_err(iq[i], want) < 1e-5
 
 
+def test_host_span_calls_from_several_threads(gpu_ctx, oracle):
+    """The reference runs one processor instance per worker thread; the adaptors of all of them share one context.
+    Host-span calls (shared staging buffers, one stream) must serialise correctly."""
+    import threading
+    rng = np.random.default_rng(99)
+    jobs = []
+    for cfg in (1, 2, 1, 2):
+        pdu, nof_ports, nof_subc, _ = cases.baseline_config(cfg, slot_index=len(jobs))
+        tb = cases.random_tb(rng, pdu)
+        jobs.append((pdu, tb, nof_ports, nof_subc, oracle.pdsch_process(pdu, tb, nof_ports, nof_subc)))
+    errors = []
+
+    def worker(job):
+        pdu, tb, nof_ports, nof_subc, want = job
+        for _ in range(5):
+            got = gpu_ctx.pdsch_process_host(pdu, tb, nof_ports, nof_subc)
+            if not np.array_equal(got, want):
+                errors.append("mismatch")
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+
+
 def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
     """The host-span entry points the srsRAN adaptors call (dft_processor::run, ofdm_slot_modulator::modulate)."""
     rng = np.random.default_rng(77)
