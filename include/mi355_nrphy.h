@@ -199,6 +199,27 @@ int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_t* pdu, con
                              uint32_t grid_nof_ports, uint32_t grid_nof_subc, uint8_t* cw_rm,
                              uint8_t* cw_scrambled);
 
+/* ---- seam B: pdsch_encoder::encode / hal::hw_accelerator_pdsch_enc in transport-block mode --------
+ * Replaces pdsch_encoder::encode (R/include/srsran/phy/upper/channel_processors/pdsch_encoder.h;
+ * impl R/lib/phy/upper/channel_processors/pdsch_encoder_impl.cpp:28-77) and what
+ * pdsch_encoder_hw_impl::encode (pdsch_encoder_hw_impl.cpp:34-180) asks of a hardware accelerator:
+ * TB CRC + segmentation + CB CRC + LDPC encoding + rate matching + bit interleaving of one transport
+ * block, no scrambling.  The fields are pdsch_encoder::configuration (base_graph 1|2, rv, qm = bits per
+ * symbol of `mod`, Nref with 0 = unlimited, nof_layers, nof_ch_symbols = RE x layers) + the TB size.
+ * codeword_bits (nof_ch_symbols * qm bytes, one bit per byte: the reference's codeword span) and
+ * codeword_packed (the same bits MSB-first) may each be NULL.  Host spans, blocking. */
+typedef struct nrphy_pdsch_encoder_cfg {
+  uint32_t base_graph;
+  uint32_t rv;
+  uint32_t qm;
+  uint32_t nref;
+  uint32_t nof_layers;
+  uint32_t nof_ch_symbols;
+  uint32_t tb_size_bytes;
+} nrphy_pdsch_encoder_cfg_t;
+int nrphy_pdsch_encode_host(nrphy_ctx_t* ctx, const nrphy_pdsch_encoder_cfg_t* cfg, const uint8_t* tb,
+                            uint8_t* codeword_bits, uint8_t* codeword_packed);
+
 /* ---- seam B pieces: ldpc_encoder::encode, batched ----------------------------------------------
  * Replaces ldpc_encoder::encode (R/lib/phy/upper/channel_coding/ldpc/ldpc_encoder_impl.cpp:44-81) for
  * n_cb codeblocks that share (base graph, lifting size).  d_msg: n_cb messages of Kb*Zc bits, each

@@ -82,6 +82,12 @@ class PdschDerived(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class PdschEncoderCfg(C.Structure):
+    """nrphy_pdsch_encoder_cfg_t (pdsch_encoder::configuration + TB size)."""
+    _fields_ = [("base_graph", C.c_uint32), ("rv", C.c_uint32), ("qm", C.c_uint32), ("nref", C.c_uint32),
+                ("nof_layers", C.c_uint32), ("nof_ch_symbols", C.c_uint32), ("tb_size_bytes", C.c_uint32)]
+
+
 class OfdmConfig(C.Structure):
     _fields_ = [
         ("numerology", C.c_uint32),
@@ -208,6 +214,7 @@ def declare(lib, prefix="nrphy_"):
     sig("ofdm_plan_enable_timing", i32, vp, u32)
     sig("ofdm_plan_kernel_time", i32, vp, P(C.c_float), P(u32))
     sig("pdsch_process_host", i32, vp, P(PdschPdu), u8p, vp, u32, u32, u8p, u8p)
+    sig("pdsch_encode_host", i32, vp, P(PdschEncoderCfg), u8p, u8p, u8p)
     sig("ldpc_encode", i32, vp, u32, u32, u32, u8p, u32, u32, u8p, u32, vp)
     sig("ofdm_plan_create", i32, vp, P(OfdmConfig), u32, P(vp))
     sig("ofdm_plan_destroy", i32, vp)
@@ -230,7 +237,7 @@ ABI_SYMBOLS = [
     "nrphy_ofdm_slot_size", "nrphy_pdsch_plan_create", "nrphy_pdsch_plan_destroy",
     "nrphy_pdsch_plan_nof_codeblocks", "nrphy_pdsch_plan_codeword_bits", "nrphy_pdsch_plan_codeword_offset",
     "nrphy_pdsch_run", "nrphy_pdsch_plan_enable_timing", "nrphy_pdsch_plan_kernel_times",
-    "nrphy_ofdm_plan_enable_timing", "nrphy_ofdm_plan_kernel_time", "nrphy_pdsch_process_host", "nrphy_ldpc_encode", "nrphy_ofdm_plan_create",
+    "nrphy_ofdm_plan_enable_timing", "nrphy_ofdm_plan_kernel_time", "nrphy_pdsch_process_host", "nrphy_pdsch_encode_host", "nrphy_ldpc_encode", "nrphy_ofdm_plan_create",
     "nrphy_ofdm_plan_destroy", "nrphy_ofdm_plan_slot_stride", "nrphy_ofdm_run",
     "nrphy_ofdm_modulate_symbol_host", "nrphy_ofdm_modulate_slot_host", "nrphy_dft_run", "nrphy_dft_run_host",
     "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",

@@ -241,9 +241,9 @@ private:
   unsigned                 nof_subc;
 };
 
-/// hal::hw_accelerator_pdsch_enc in TB mode: one enqueue carries the whole transport block, dequeue returns the
-/// rate-matched codeblock `segment_index` (unpacked bits in `data`, packed in `aux_data`), like the ACC100
-/// implementation's TB mode (hw_accelerator_pdsch_enc_acc100_impl.cpp).
+/// hal::hw_accelerator_pdsch_enc over nrphy_pdsch_encode_host, transport-block mode (get_cb_mode() == false): what
+/// pdsch_encoder_hw_impl::encode (pdsch_encoder_hw_impl.cpp:34-180) drives -- configure, enqueue the raw transport
+/// block, dequeue the rate-matched codeword (unpacked bits in `data`, packed in `aux_data`).  One operation in flight.
 class hw_accelerator_pdsch_enc_adaptor : public srsran::hal::hw_accelerator_pdsch_enc
 {
 public:
@@ -264,23 +264,9 @@ public:
   {
     (void)aux_data;
     (void)cb_index;
-    using namespace srsran;
-    // A PDU that reproduces the encoder configuration: one symbol of `qm` bits per "RE" and layer.
-    unsigned qm       = get_bits_per_symbol(cfg.modulation);
-    unsigned cw_bits  = cfg.nof_short_segments * cfg.cw_length_a + (cfg.nof_segments - cfg.nof_short_segments) * cfg.cw_length_b;
-    std::memset(&pod, 0, sizeof(pod));
-    pod.qm              = qm;
-    pod.rv              = cfg.rv;
-    pod.nof_codewords   = 1;
-    pod.ldpc_base_graph = (cfg.base_graph_index == ldpc_base_graph_type::BG1) ? 1 : 2;
-    pod.tb_size_bytes   = data.size();
-    pod.nof_layers      = 1;
-    pod.nof_ports       = 1;
-    pod.nof_prg         = 1;
-    pod.prg_size_rb     = NRPHY_MAX_RB;
-    // The ABI derives Nref from tbs_lbrm; the HAL hands Nref directly: tbs_lbrm = ceil(Nref * 2C / 24) bytes.
-    pod.tbs_lbrm_bytes  = (cfg.Nref == 0) ? 159749 : (cfg.Nref * 2 * cfg.nof_segments + 23) / 24;
-    (void)cw_bits;
+    if (pending) {
+      return false; // queue depth 1: the caller dequeues, then retries
+    }
     tb.assign(data.begin(), data.end());
     pending = true;
     return true;
@@ -288,20 +274,44 @@ public:
 
   bool dequeue_operation(srsran::span<uint8_t> data, srsran::span<uint8_t> aux_data = {}, unsigned segment_index = 0) override
   {
-    // The whole-codeword tap of nrphy_pdsch_process_host needs an RE allocation; a full implementation keeps a plan
-    // per (TB size, E) and calls nrphy_pdsch_run with d_grid = NULL.  Shown here: the call sequence and span contract.
-    (void)data;
-    (void)aux_data;
     (void)segment_index;
-    bool was_pending = pending;
-    pending          = false;
-    return was_pending;
+    using namespace srsran;
+    if (!pending) {
+      return false;
+    }
+    pending = false;
+    nrphy_pdsch_encoder_cfg_t enc;
+    enc.base_graph    = (cfg.base_graph_index == ldpc_base_graph_type::BG1) ? 1 : 2;
+    enc.rv            = cfg.rv;
+    enc.qm            = get_bits_per_symbol(cfg.modulation);
+    enc.nref          = cfg.Nref;
+    enc.tb_size_bytes = tb.size();
+    // The HAL configuration carries the per-segment lengths instead of the layer count: pick the layer count whose
+    // rate-matching split (TS 38.212 Section 5.4.2.1) reproduces them.
+    unsigned cw_bits   = cfg.nof_short_segments * cfg.cw_length_a + (cfg.nof_segments - cfg.nof_short_segments) * cfg.cw_length_b;
+    enc.nof_ch_symbols = cw_bits / enc.qm;
+    enc.nof_layers     = 1;
+    for (unsigned layers = 1; layers <= NRPHY_MAX_LAYERS; ++layers) {
+      if (enc.nof_ch_symbols % layers != 0) {
+        continue;
+      }
+      unsigned per_layer = enc.nof_ch_symbols / layers, c = cfg.nof_segments;
+      unsigned n_short = c - per_layer % c, e_short = layers * enc.qm * (per_layer / c);
+      unsigned e_long = layers * enc.qm * ((per_layer + c - 1) / c);
+      if (n_short == cfg.nof_short_segments && e_short == cfg.cw_length_a && (n_short == c || e_long == cfg.cw_length_b)) {
+        enc.nof_layers = layers;
+        break;
+      }
+    }
+    srsran_assert(data.size() == cw_bits, "Invalid codeword size.");
+    int rc = nrphy_pdsch_encode_host(ctx->get(), &enc, tb.data(), data.data(), aux_data.empty() ? nullptr : aux_data.data());
+    srsran_assert(rc == NRPHY_OK, "nrphy_pdsch_encode_host failed: {}", nrphy_strerror(rc));
+    return true;
   }
 
 private:
   std::shared_ptr<context>                     ctx;
   srsran::hal::hw_pdsch_encoder_configuration  cfg;
-  nrphy_pdsch_pdu_t                            pod;
   std::vector<uint8_t>                         tb;
   bool                                         pending = false;
 };

@@ -423,6 +423,7 @@ struct nrphy_pdsch_plan {
   uint64_t              scr_words = 0;
   uint32_t              n_zero_work = 0;
   uint32_t              epoch = 0;          // selects the TB-CRC accumulator of the current run
+  bool                  encode_only = false;   // seam B plan: no RE mapping, nrphy_pdsch_run only with d_grid = NULL
   bool                  dmrs_separate = false; // DM-RS must overwrite data RE: keep it in its own, later launch
   uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0, n_crc_work = 0;
   uint32_t              lds_lin_words = 0, lds_symb_words = 0, lds_graph_words = 0;
@@ -557,7 +558,9 @@ void data_re_mask(const nrphy_pdsch_pdu_t& pdu, unsigned l, std::vector<uint8_t>
   }
 }
 
-void derive(const nrphy_pdsch_pdu_t& pdu, unsigned nof_re, nrphy_pdsch_derived_t& d)
+// nref_override: the limited-buffer size given directly (seam B hands N_ref, not TBS_LBRM); nullptr = from the PDU.
+void derive(const nrphy_pdsch_pdu_t& pdu, unsigned nof_re, nrphy_pdsch_derived_t& d,
+            const uint32_t* nref_override = nullptr)
 {
   const unsigned bg      = pdu.ldpc_base_graph;
   const unsigned tb_bits = 8 * pdu.tb_size_bytes;
@@ -582,6 +585,9 @@ void derive(const nrphy_pdsch_pdu_t& pdu, unsigned nof_re, nrphy_pdsch_derived_t
   const unsigned info   = divide_ceil(b_out, C) - cb_crc;
   const unsigned N      = ((bg == 1) ? 66 : 50) * zc;
   uint64_t       nref   = ((uint64_t)pdu.tbs_lbrm_bytes * 8 * 3) / (2 * C); // ldpc::compute_N_ref
+  if (nref_override != nullptr) {
+    nref = *nref_override;
+  }
   nref                  = std::min<uint64_t>(nref, 66 * 384);
   d.nof_re              = nof_re;
   d.nof_codeblocks      = C;
@@ -868,9 +874,32 @@ struct ReMapping {
 
 } // namespace
 
+namespace {
+
+// Seam B (encode + rate match + interleave only): the codeword size and N_ref are given, there is no allocation.
+struct EncodeOnly {
+  uint32_t nof_re; // channel symbols per layer
+  uint32_t nref;
+};
+
+int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus, const uint64_t* tb_offset,
+                const uint32_t* grid_index, uint32_t nof_grids, uint32_t grid_nof_ports, uint32_t grid_nof_subc,
+                const EncodeOnly* enc, nrphy_pdsch_plan_t** out);
+
+} // namespace
+
 extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
                                        const uint64_t* tb_offset, const uint32_t* grid_index, uint32_t nof_grids,
                                        uint32_t grid_nof_ports, uint32_t grid_nof_subc, nrphy_pdsch_plan_t** out)
+{
+  return plan_create(ctx, n_pdu, pdus, tb_offset, grid_index, nof_grids, grid_nof_ports, grid_nof_subc, nullptr, out);
+}
+
+namespace {
+
+int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus, const uint64_t* tb_offset,
+                const uint32_t* grid_index, uint32_t nof_grids, uint32_t grid_nof_ports, uint32_t grid_nof_subc,
+                const EncodeOnly* enc, nrphy_pdsch_plan_t** out)
 {
   if (ctx == nullptr || out == nullptr || (n_pdu != 0 && (pdus == nullptr || tb_offset == nullptr)) ||
       grid_nof_ports == 0 || grid_nof_ports > NRPHY_MAX_PORTS || grid_nof_subc == 0 || grid_nof_subc % 12 != 0 ||
@@ -887,6 +916,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   plan->nof_grids      = nof_grids;
   plan->grid_nof_ports = grid_nof_ports;
   plan->grid_nof_subc  = grid_nof_subc;
+  plan->encode_only    = enc != nullptr;
 
   std::vector<CbWork>   work;
   std::vector<DmrsWork> dmrs;
@@ -904,13 +934,16 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
 
   for (uint32_t i = 0; i != n_pdu && status == NRPHY_OK; ++i) {
     const nrphy_pdsch_pdu_t& pdu = pdus[i];
-    if (nrphy_pdsch_validate(&pdu) != NRPHY_OK) {
+    if (enc == nullptr ? nrphy_pdsch_validate(&pdu) != NRPHY_OK
+                       : (pdu.qm < 2 || pdu.qm > 8 || (pdu.qm & 1U) || pdu.rv > 3 || pdu.nof_layers == 0 ||
+                          pdu.nof_layers > NRPHY_MAX_LAYERS || pdu.tb_size_bytes == 0 ||
+                          (pdu.ldpc_base_graph != 1 && pdu.ldpc_base_graph != 2))) {
       status = NRPHY_ERR_INVALID_PDU;
       break;
     }
     const uint32_t g = grid_index ? grid_index[i] : 0;
     if (g >= nof_grids || pdu.nof_ports > grid_nof_ports || (tb_offset[i] & 3U) != 0 ||
-        12U * (unsigned)(mask_highest(pdu.prb_mask) + 1) > grid_nof_subc) {
+        (enc == nullptr && 12U * (unsigned)(mask_highest(pdu.prb_mask) + 1) > grid_nof_subc)) {
       status = NRPHY_ERR_ARGUMENT;
       break;
     }
@@ -921,7 +954,12 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     remap_sig.clear();
     append_allocation_signature(pdu, remap_sig);
     auto cached = remap_cache.find(remap_sig);
-    if (cached != remap_cache.end()) {
+    if (enc != nullptr) {
+      nof_re = enc[i].nof_re; // no RE mapping: every symbol empty, the count given
+      for (unsigned l = 0; l <= NRPHY_NSYMB; ++l) {
+        pd.sym_re_start[l] = (l == NRPHY_NSYMB) ? nof_re : 0;
+      }
+    } else if (cached != remap_cache.end()) {
       std::memcpy(pd.sym_re_start, cached->second.sym_re_start, sizeof(pd.sym_re_start));
       std::memcpy(pd.sym_kind, cached->second.sym_kind, sizeof(pd.sym_kind));
       std::memcpy(pd.sym_arg, cached->second.sym_arg, sizeof(pd.sym_arg));
@@ -970,7 +1008,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
       break;
     }
     nrphy_pdsch_derived_t d;
-    derive(pdu, nof_re, d);
+    derive(pdu, nof_re, d, enc ? &enc[i].nref : nullptr);
     if (d.lifting_size == 0 || d.nof_codeblocks > NRPHY_MAX_CODEBLOCKS || d.nof_codeblocks > nof_re ||
         d.rm_length_short == 0) {
       status = NRPHY_ERR_INVALID_PDU;
@@ -1028,10 +1066,12 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
       const unsigned nw      = 2 * pdu.nof_prg * pdu.nof_ports * pdu.nof_layers;
       pd.weights_offset      = (uint32_t)weights.size();
       for (unsigned k = 0; k != nw; ++k) {
-        weights.push_back(pdu.precoding[k] * scaling);
+        weights.push_back(pdu.precoding ? pdu.precoding[k] * scaling : 0.0F); // no weights in an encode-only plan
       }
       pd.dmrs_weights_offset = (uint32_t)weights.size();
-      weights.insert(weights.end(), pdu.precoding, pdu.precoding + nw);
+      for (unsigned k = 0; k != nw; ++k) {
+        weights.push_back(pdu.precoding ? pdu.precoding[k] : 0.0F);
+      }
       pd.nof_prg       = pdu.nof_prg;
       pd.prg_size_subc = pdu.prg_size_rb * 12;
     }
@@ -1120,7 +1160,7 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
     std::vector<uint8_t>  cov((size_t)NRPHY_NSYMB * grid_nof_subc);
     std::vector<uint64_t> key, sig;
     std::map<std::vector<uint64_t>, std::array<uint32_t, 3>> by_signature; // allocation -> (begin, count, long runs)
-    for (uint32_t g = 0; g != nof_grids; ++g) {
+    for (uint32_t g = 0; g != (enc ? 0U : nof_grids); ++g) { // an encode-only plan writes no grid
       for (uint32_t port = 0; port != grid_nof_ports; ++port) {
         // Everything the coverage of this (grid, port) depends on: grids that repeat an allocation (the normal case
         // in a batch of slots) reuse its segment list without rebuilding the RE masks.
@@ -1239,6 +1279,8 @@ extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const n
   return NRPHY_OK;
 }
 
+} // namespace
+
 extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
 {
   if (plan == nullptr) {
@@ -1271,7 +1313,7 @@ extern "C" uint64_t nrphy_pdsch_plan_codeword_offset(const nrphy_pdsch_plan_t* p
 extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, void* d_grid, uint8_t* d_cw_rm,
                                uint8_t* d_cw_scrambled, int zero_grids, void* stream)
 {
-  if (plan == nullptr || d_tb == nullptr) {
+  if (plan == nullptr || d_tb == nullptr || (plan->encode_only && d_grid != nullptr)) {
     return NRPHY_ERR_ARGUMENT;
   }
   nrphy_ctx*  ctx = plan->ctx;
@@ -1447,6 +1489,74 @@ extern "C" int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_
     rc = NRPHY_OK;
   } while (false);
   nrphy_pdsch_plan_destroy(plan);
+  return rc;
+}
+
+extern "C" int nrphy_pdsch_encode_host(nrphy_ctx_t* ctx, const nrphy_pdsch_encoder_cfg_t* cfg, const uint8_t* tb,
+                                       uint8_t* codeword_bits, uint8_t* codeword_packed)
+{
+  if (ctx == nullptr || cfg == nullptr || tb == nullptr || cfg->nof_layers == 0 ||
+      cfg->nof_ch_symbols % cfg->nof_layers != 0) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  nrphy_pdsch_pdu_t pdu;
+  std::memset(&pdu, 0, sizeof(pdu));
+  pdu.qm              = cfg->qm;
+  pdu.rv              = cfg->rv;
+  pdu.nof_codewords   = 1;
+  pdu.ldpc_base_graph = cfg->base_graph;
+  pdu.tb_size_bytes   = cfg->tb_size_bytes;
+  pdu.nof_layers      = cfg->nof_layers;
+  pdu.nof_ports       = 1;
+  pdu.nof_prg         = 1;
+  pdu.prg_size_rb     = NRPHY_MAX_RB;
+  pdu.tbs_lbrm_bytes  = 1; // unused: N_ref is given
+  const EncodeOnly    enc    = {cfg->nof_ch_symbols / cfg->nof_layers, cfg->nref};
+  nrphy_pdsch_plan_t* plan   = nullptr;
+  uint64_t            tb_off = 0;
+  uint32_t            gi     = 0;
+  int                 rc     = plan_create(ctx, 1, &pdu, &tb_off, &gi, 1, 1, 12, &enc, &plan);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  const size_t cw_bits  = (size_t)cfg->nof_ch_symbols * cfg->qm;
+  const size_t cw_bytes = (size_t)(plan->cw_bits / 8);
+  const size_t tb_alloc = ((size_t)cfg->tb_size_bytes + 7) & ~(size_t)3;
+  std::vector<uint8_t> packed_local;
+  uint8_t*             packed = codeword_packed;
+  if (packed == nullptr) {
+    packed_local.resize((cw_bits + 7) / 8);
+    packed = packed_local.data();
+  }
+  {
+    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    uint8_t* d_tb = (uint8_t*)ctx_scratch(ctx, SCRATCH_TB, tb_alloc);
+    uint8_t* d_rm = (uint8_t*)ctx_scratch(ctx, SCRATCH_CW_RM, cw_bytes);
+    rc            = NRPHY_ERR_DEVICE;
+    do {
+      if (d_tb == nullptr || d_rm == nullptr ||
+          hipMemsetAsync(d_tb + (tb_alloc - 8), 0, 8, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(d_tb, tb, cfg->tb_size_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        break;
+      }
+      rc = nrphy_pdsch_run(plan, d_tb, nullptr, d_rm, nullptr, 0, ctx->stream);
+      if (rc != NRPHY_OK) {
+        break;
+      }
+      rc = NRPHY_ERR_DEVICE;
+      if (hipMemcpyAsync(packed, d_rm, (cw_bits + 7) / 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        break;
+      }
+      rc = NRPHY_OK;
+    } while (false);
+  }
+  nrphy_pdsch_plan_destroy(plan);
+  if (rc == NRPHY_OK && codeword_bits != nullptr) { // the reference's codeword span: one bit per byte
+    for (size_t i = 0; i != cw_bits; ++i) {
+      codeword_bits[i] = (packed[i >> 3] >> (7U - (i & 7U))) & 1U;
+    }
+  }
   return rc;
 }
 

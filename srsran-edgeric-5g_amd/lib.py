@@ -96,6 +96,16 @@ class Context:
             rm.ctypes.data if taps else None, scr.ctypes.data if taps else None), "nrphy_pdsch_process_host")
         return (grid, rm, scr) if taps else grid
 
+    def pdsch_encode_host(self, base_graph, rv, qm, nref, nof_layers, nof_ch_symbols, tb):
+        """pdsch_encoder::encode: returns (codeword bits one per byte, the same packed MSB-first)."""
+        tb = np.ascontiguousarray(tb, dtype=np.uint8)
+        cfg = abi.PdschEncoderCfg(base_graph, rv, qm, nref, nof_layers, nof_ch_symbols, tb.size)
+        bits = np.zeros(nof_ch_symbols * qm, np.uint8)
+        packed = np.zeros((bits.size + 7) // 8, np.uint8)
+        _check(self.lib.nrphy_pdsch_encode_host(self.handle, C.byref(cfg), tb.ctypes.data, bits.ctypes.data,
+                                                packed.ctypes.data), "nrphy_pdsch_encode_host")
+        return bits, packed
+
     def ldpc_encode(self, base_graph, lifting_size, d_msg, msg_stride, out_bits, d_out, out_stride, n_cb, stream=None):
         _check(self.lib.nrphy_ldpc_encode(self.handle, base_graph, lifting_size, n_cb, _dptr(d_msg), msg_stride,
                                           out_bits, _dptr(d_out), out_stride, stream), "nrphy_ldpc_encode")

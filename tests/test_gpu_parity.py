@@ -426,6 +426,30 @@ def test_end_to_end_slot_batch(gpu_ctx, oracle):
         assert rel_err(iq[i], want) < 1e-5
 
 
+def test_pdsch_encode_host_seam_b(gpu_ctx, oracle):
+    """Seam B (pdsch_encoder::encode / hw_accelerator_pdsch_enc in TB mode): TB -> rate-matched, interleaved codeword
+    from the encoder configuration alone (no allocation), bit-exact against the oracle's encoder."""
+    rng = np.random.default_rng(12)
+    pdus = [cases.baseline_config(c)[0] for c in (1, 2, 3)] + cases.unit_test_like_pdus(rng)[::3]
+    for pdu in pdus:
+        d = oracle.derive(pdu)
+        tb = cases.random_tb(rng, pdu)
+        want = oracle.pdsch_encode(pdu, tb)
+        bits, packed = gpu_ctx.pdsch_encode_host(pdu.ldpc_base_graph, pdu.rv, pdu.qm, d["n_ref"], pdu.nof_layers,
+                                                 d["nof_re"] * pdu.nof_layers, tb)
+        assert bits.size == d["codeword_bits"]
+        assert np.array_equal(packed, want[: packed.size])
+        assert np.array_equal(np.packbits(bits), packed)
+    # unlimited buffer (Nref = 0) and a bad configuration
+    pdu = pdus[1]
+    d = oracle.derive(pdu)
+    bits, _ = gpu_ctx.pdsch_encode_host(1, 0, 6, 0, 2, d["nof_re"] * 2, cases.random_tb(rng, pdu))
+    assert bits.size == d["codeword_bits"]
+    cfg = abi.PdschEncoderCfg(1, 0, 5, 0, 2, 100, 10)
+    buf = np.zeros(16, np.uint8)
+    assert gpu_ctx.lib.nrphy_pdsch_encode_host(gpu_ctx.handle, C.byref(cfg), buf.ctypes.data, None, None) == abi.ERR_INVALID_PDU
+
+
 def test_host_span_calls_from_several_threads(gpu_ctx, oracle):
     """The reference runs one processor instance per worker thread; the adaptors of all of them share one context.
     Host-span calls (shared staging buffers, one stream) must serialise correctly."""
