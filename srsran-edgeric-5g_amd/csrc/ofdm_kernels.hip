@@ -390,7 +390,11 @@ __device__ __forceinline__ void stage_lds(cf* lds, const float2* __restrict__ tw
       if constexpr (LAST) {
         // The last stage has S * R = N, hence p = 0: output index = q + S * j, a per-thread part and a constant.
         static_assert(S * R == N, "last stage");
-        static_for<R>([&](auto J) { store(q, Const<S * decltype(J)::value>{}, Const<S>{}, a[it][decltype(J)::value]); });
+        if constexpr (std::is_invocable_v<Store, uint32_t, Const<S>, cf(&)[R]>) {
+          store(q, Const<S>{}, a[it]); // the sink takes the thread's R outputs together (it may pair them up)
+        } else {
+          static_for<R>([&](auto J) { store(q, Const<S * decltype(J)::value>{}, Const<S>{}, a[it][decltype(J)::value]); });
+        }
       } else {
 #pragma unroll
         for (int j = 0; j != R; ++j) {
@@ -428,9 +432,11 @@ __device__ __forceinline__ void fft_from_registers(cf (&a)[Plan<N>::R0], const T
 // ================================================================================================================
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-// Cache policy of the IQ stores.  Non-temporal (aux = 2) was measured: +6 % in the arithmetic-free probe
-// (profiles/probes/stream_mix.hip, 16-byte stores) but -7 % in this kernel with its 8-byte stores; default it is.
-constexpr int AUX_NT = 0;
+// Cache policy of the IQ stores: non-temporal.  The samples are not read again on the device; measured over the whole
+// step (A/B on one box, 60 steps): the kernel itself is unchanged within noise (16-byte stores, 0.55 vs 0.55 ms on that
+// box) but the PDSCH launches that follow run 4 % faster (0.63 -> 0.61 ms) because 2 GB of IQ no longer pass through
+// the caches.  (With 8-byte stores and the earlier, arithmetic-bound kernel non-temporal stores cost 7 %.)
+constexpr int AUX_NT = 2;
 
 // blockIdx = (symbol group, port, grid): no index arithmetic to undo, every per-symbol quantity is wave-uniform and
 // lives in SGPRs.  A workgroup modulates SPW consecutive symbols of its (grid, port); the row of the next symbol is
@@ -439,6 +445,72 @@ constexpr int AUX_NT = 0;
 // grid half -> top bins, upper half -> bins from DC, guard bins zero) is j = (i + rg_size / 2) mod N and the
 // hardware range check supplies the zeros of the guard bins.  The output goes through a second descriptor with the
 // constant part of every address in the scalar offset.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// The value lane ^ 1 holds (DPP quad_perm [1, 0, 3, 2]).
+__device__ __forceinline__ cf from_neighbour(cf v)
+{
+  const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0xB1, 0xF, 0xF, true);
+  const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0xB1, 0xF, 0xF, true);
+  return make_cf(__int_as_float(x), __int_as_float(y));
+}
+
+// Output side of ofdm_kernel: phase compensation x scale, then the symbol and its cyclic prefix (the tail of the
+// symbol, ofdm_modulator_impl.cpp:92-99) through the buffer descriptor `rsrc` whose record 0 is the first sample of
+// the prefix.  A thread of the last stage holds outputs q + S j; neighbouring lanes hold neighbouring samples, so lane
+// pairs swap half of their outputs and every lane writes 16-byte pairs of consecutive samples (the arithmetic-free
+// probe of this traffic shape streams 2.5 % faster with 16-byte stores).  The prefix never exceeds N / 4 (extended
+// CP), so only the outputs of the last quarter test for it.
+template <int N>
+struct IqSink {
+  __amdgpu_buffer_rsrc_t rsrc;
+  cf                     ph;
+  uint32_t               cp;
+
+  __device__ __forceinline__ void prefix_copy(uint32_t i, u32x2_t d) const
+  {
+    if (i >= N - cp) {
+      __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)((i - (N - cp)) * 8u), 0, AUX_NT);
+    }
+  }
+
+  // One output: idx = q + B.
+  template <uint32_t B, uint32_t S>
+  __device__ __forceinline__ void operator()(uint32_t q, Const<B>, Const<S>, cf v) const
+  {
+    const cf      y = cmul_uniform(v, ph);
+    const u32x2_t d = {__float_as_uint(y.x), __float_as_uint(y.y)};
+    __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)(q * 8u), (int)((cp + B) * 8u), AUX_NT);
+    if constexpr (B + S > N - N / 4) {
+      prefix_copy(q + B, d);
+    }
+  }
+
+  // The thread's R outputs idx = q + S j at once.
+  template <uint32_t S, int R>
+  __device__ __forceinline__ void operator()(uint32_t q, Const<S>, cf (&a)[R]) const
+  {
+    const bool     odd  = (q & 1u) != 0;
+    const uint32_t voff = ((q & ~1u) + (odd ? S : 0u)) * 8u; // even lanes write pair j0 = 2i, odd lanes j1 = 2i + 1
+    static_for<R / 2>([&](auto I) {
+      constexpr uint32_t j0   = 2 * decltype(I)::value;
+      const cf           keep = odd ? a[j0 + 1] : a[j0];
+      const cf           recv = from_neighbour(odd ? a[j0] : a[j0 + 1]);
+      const cf           y0 = cmul_uniform(odd ? recv : keep, ph), y1 = cmul_uniform(odd ? keep : recv, ph);
+      const u32x4_t      d  = {__float_as_uint(y0.x), __float_as_uint(y0.y), __float_as_uint(y1.x), __float_as_uint(y1.y)};
+      __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)voff, (int)((cp + S * j0) * 8u), AUX_NT);
+      if constexpr (S * (j0 + 2) > N - N / 4) {
+        const uint32_t i = (q & ~1u) + S * (odd ? j0 + 1 : j0);
+        prefix_copy(i, u32x2_t{d.x, d.y});
+        prefix_copy(i + 1u, u32x2_t{d.z, d.w});
+      }
+    });
+    if constexpr (R % 2 != 0) { // the odd one out (radix 3) goes alone
+      (*this)(q, Const<S * (R - 1)>{}, Const<S>{}, a[R - 1]);
+    }
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void load_symbol_row(uint32_t (&raw)[Plan<N>::R0], const OfdmLaunch& p,
                                                 const uint32_t* row, uint32_t t4)
@@ -493,20 +565,7 @@ __global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const ui
     const cf       ph  = make_cf(to_constant(p.phase)[sym].x, to_constant(p.phase)[sym].y);
     const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
         iq + to_constant(p.sym_offset)[sym], 0, (int)((p.probe & 1u) ? 0u : (N + cp) * 8u), 0x00020000);
-    // Phase compensation x scale, then the cyclic prefix is the tail of the symbol (ofdm_modulator_impl.cpp:92-99).
-    // The cyclic prefix never exceeds N / 4 (extended CP), so only the outputs of the last quarter test for it.
-    auto store = [&](uint32_t q, auto base, auto span, cf v) {
-      constexpr uint32_t B = decltype(base)::value, S = decltype(span)::value;
-      const cf           y = cmul_uniform(v, ph);
-      const u32x2_t      d = {__float_as_uint(y.x), __float_as_uint(y.y)};
-      __builtin_amdgcn_raw_buffer_store_b64(d, rsrc_out, (int)(q * 8u), (int)((cp + B) * 8u), AUX_NT);
-      if constexpr (B + S > N - N / 4) {
-        const uint32_t i = q + B;
-        if (i >= N - cp) {
-          __builtin_amdgcn_raw_buffer_store_b64(d, rsrc_out, (int)((i - (N - cp)) * 8u), 0, AUX_NT);
-        }
-      }
-    };
+    const IqSink<N> store = {rsrc_out, ph, cp};
     fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
   }
 }
