@@ -117,7 +117,10 @@ def main():
     tb_bytes_per_step = sum(q.tb_size_bytes for q in pdus)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
-    d_tb = torch.randint(0, 256, (tb_total,), dtype=torch.uint8, device="cuda", generator=gen)
+    # Four sets of transport blocks taken in turn (0.45 GB at the default size): a step never finds its input in the
+    # memory-side cache because an earlier step read the same bytes.
+    tb_sets = [torch.randint(0, 256, (tb_total,), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(4)]
+    d_tb = tb_sets[0]
     plan = lib.PdschPlan(ctx, pdus, tb_offsets, grid_of, slots, nof_ports, nof_subc)
     oplan = lib.OfdmPlan(ctx, ofdm, nof_ports)
     d_grid = torch.zeros((slots, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
@@ -126,9 +129,12 @@ def main():
     d_slot = torch.tensor([i % sps for i in range(slots)], dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
 
+    step_no = [0]
+
     def step():
-        plan.run(d_tb, d_grid, zero_grids=True)
+        plan.run(tb_sets[step_no[0] % len(tb_sets)], d_grid, zero_grids=True)
         oplan.run(slots, d_grid, d_iq, d_slot_index=d_slot)
+        step_no[0] += 1
 
     def barrier():
         if dist is not None:
@@ -218,7 +224,8 @@ def main():
             for k, q in enumerate(pdus):  # the PDUs of grid 0 map disjoint RE: their grids OR together
                 if grid_of[k] != 0:
                     break
-                tbk = d_tb[tb_offsets[k]: tb_offsets[k] + q.tb_size_bytes].cpu().numpy()
+                last = tb_sets[(step_no[0] - 1) % len(tb_sets)]
+                tbk = last[tb_offsets[k]: tb_offsets[k] + q.tb_size_bytes].cpu().numpy()
                 part = o.pdsch_process(q, tbk, nof_ports, nof_subc)
                 want = part if want is None else np.bitwise_or(want, part)
             got = d_grid[0].cpu().numpy().view(np.uint16).reshape(want.shape)
