@@ -343,6 +343,15 @@ __device__ __forceinline__ uint32_t pack_cbf16(float re, float im)
   return *reinterpret_cast<uint32_t*>(&b);
 }
 
+// Data RE go to the grid with non-temporal stores: 0.75 GB per 1024 slots that this kernel never reads back would
+// otherwise displace the transport blocks, sequences and tables it does read.  Measured (A/B on one box): codeblock
+// launch 0.486 -> 0.427 ms, whole step +7 %.  The same policy on the DM-RS / zero-fill stores, on the loads of the
+// transport block or of the scrambling words, or on the prologue's sequence stores did not pay (0 ... -4 %).
+__device__ __forceinline__ void grid_store(uint32_t* p, uint32_t v)
+{
+  __builtin_nontemporal_store(v, p);
+}
+
 struct ChunkGeom {
   uint32_t E;      // rate-matched length of the codeblock
   uint32_t cw_cb;  // first codeword bit of the codeblock
@@ -502,7 +511,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
             accr = __fadd_rn(accr, pr);
             acci = __fadd_rn(acci, pi);
           }
-          out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = pack_cbf16(accr, acci);
+          grid_store(&out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc], pack_cbf16(accr, acci));
         }
       }
     } else {
@@ -520,7 +529,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
           accr = __fadd_rn(accr, pr);
           acci = __fadd_rn(acci, pi);
         }
-        out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc] = pack_cbf16(accr, acci);
+        grid_store(&out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc], pack_cbf16(accr, acci));
       }
     }
   }
