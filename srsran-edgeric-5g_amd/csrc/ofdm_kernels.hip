@@ -432,11 +432,11 @@ __device__ __forceinline__ void fft_from_registers(cf (&a)[Plan<N>::R0], const T
 // ================================================================================================================
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-// Cache policy of the IQ stores: non-temporal.  The samples are not read again on the device; measured over the whole
-// step (A/B on one box, 60 steps): the kernel itself is unchanged within noise (16-byte stores, 0.55 vs 0.55 ms on that
-// box) but the PDSCH launches that follow run 4 % faster (0.63 -> 0.61 ms) because 2 GB of IQ no longer pass through
-// the caches.  (With 8-byte stores and the earlier, arithmetic-bound kernel non-temporal stores cost 7 %.)
-constexpr int AUX_NT = 2;
+// Cache policy of the IQ stores: non-temporal + sc1 (buffer aux bits 1 and 4).  The samples are not read again on the
+// device.  Measured over the whole step (A/B on one box, 60 steps, 16-byte stores): default policy 0.52 ms, nt 0.47-0.50,
+// nt + sc1 0.45 ms (6.1 TB/s); with nt the PDSCH launches that follow also run 4 % faster because 2 GB of IQ no longer
+// pass through the caches.  nt + sc0 and nt + sc0 + sc1 were in between, sc0 + sc1 without nt slower.
+constexpr int AUX_NT = 18;
 
 // blockIdx = (symbol group, port, grid): no index arithmetic to undo, every per-symbol quantity is wave-uniform and
 // lives in SGPRs.  A workgroup modulates SPW consecutive symbols of its (grid, port); the row of the next symbol is
