@@ -24,10 +24,12 @@ __device__ __forceinline__ uint32_t rot_word(const uint32_t* a, uint32_t base, u
   uint32_t start = s + 32u * j;
   start          = start >= zc ? start - zc : start;
   if (ALIGNED) {
+    // Both words are always read and combined without a branch (the shift differs from lane to lane; a guarded
+    // second read would be a divergent branch per edge).
     const uint32_t wpb = zc >> 5, bw = base >> 5;
-    const uint32_t w0 = start >> 5, sh = start & 31u;
+    const uint32_t w0 = start >> 5, sh = s & 31u;
     const uint32_t w1 = (w0 + 1u == wpb) ? 0u : w0 + 1u;
-    return __funnelshift_l(a[bw + w1], a[bw + w0], sh);
+    return (a[bw + w0] << sh) | ((a[bw + w1] >> 1) >> (31u - sh));
   }
   uint32_t n_valid = zc - 32u * j;
   n_valid          = n_valid > 32u ? 32u : n_valid;
@@ -84,7 +86,7 @@ __device__ __forceinline__ uint32_t row_word(const uint32_t* gbuf, const uint32_
   uint32_t acc = 0;
   for (uint32_t e = gbuf[m], end = gbuf[m + 1]; e != end; ++e) {
     uint32_t edge = gbuf[LDPC_GRAPH_ROWPTR + e];
-    acc ^= rot_word<ALIGNED>(lin, (edge >> 16) * zc, zc, edge & 0xFFFFu, j);
+    acc ^= rot_word<ALIGNED>(lin, edge >> 16, zc, edge & 0xFFFFu, j);
   }
   return acc;
 }

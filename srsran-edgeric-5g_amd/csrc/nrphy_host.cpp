@@ -112,7 +112,7 @@ void build_lifted_graph(unsigned bg, unsigned zc, LiftedGraph& g)
       } else if (col >= kb + 4) {
         continue; // the identity column of an extension row is its own parity block
       }
-      g.edge[count++] = (col << 16) | shift;
+      g.edge[count++] = ((col * zc) << 16) | shift; // bit offset of the block in the codeblock (< 2^16), lifted shift
     }
   }
   for (unsigned m = rows; m != MAX_BG_ROWS + 2; ++m) {

@@ -13,7 +13,7 @@ namespace nrphy {
 // One lifted graph per (base graph, lifting size): 2 x 51 graphs, built once per context from the
 // 3GPP TS 38.212 Tables 5.3.2-2/-3 edge list (nr_ldpc_bg.inc).  The role of the reference's
 // ldpc_graph_impl array (R/lib/phy/upper/channel_coding/ldpc/ldpc_graph_impl.cpp:29-65), laid out for the GPU:
-// per check row a contiguous run of packed edges (column << 16 | shift), the identity column of extension rows
+// per check row a contiguous run of packed edges (column * Zc << 16 | shift), the identity column of extension rows
 // dropped, plus the three numbers that describe the dual-diagonal core (see ldpc_device.h).
 constexpr int NOF_LIFTING_SIZES = 51;
 constexpr int NOF_GRAPHS        = 2 * NOF_LIFTING_SIZES;
@@ -26,7 +26,7 @@ struct LiftedGraph {
   uint16_t core_s0;                  // shift of (row 0, column Kb)
   uint16_t core_s3;                  // shift of (row 3, column Kb)
   uint16_t core_mid;                 // 1: row 1 has the third edge of column Kb (BG1); 2: row 2 (BG2)
-  uint32_t edge[MAX_BG_EDGES];       // column << 16 | lifted shift; core rows: systematic columns only
+  uint32_t edge[MAX_BG_EDGES];       // (column * Zc) << 16 | lifted shift; core rows: systematic columns only
 };
 
 // ---- Gold sequence tables -----------------------------------------------------------------------------------
