@@ -311,16 +311,24 @@ __device__ __forceinline__ uint32_t rm_gather32(const RmIndex& r, const uint32_t
 
 // 8x8 bit-matrix transposition of the 64-bit word (hi:lo), rows = bytes (most significant first), columns = bits
 // (most significant first): three rounds of masked swaps (Hacker's Delight 7-3), on 32-bit halves.
+// Bits of a where m is set, bits of b elsewhere (one v_bfi_b32).
+__device__ __forceinline__ uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b)
+{
+  return (a & m) | (b & ~m);
+}
+
 __device__ __forceinline__ void transpose8x8(uint32_t& hi, uint32_t& lo)
 {
-  hi = (hi & 0xAA55AA55u) | ((hi & 0x00AA00AAu) << 7) | ((hi >> 7) & 0x00AA00AAu);
-  lo = (lo & 0xAA55AA55u) | ((lo & 0x00AA00AAu) << 7) | ((lo >> 7) & 0x00AA00AAu);
-  hi = (hi & 0xCCCC3333u) | ((hi & 0x0000CCCCu) << 14) | ((hi >> 14) & 0x0000CCCCu);
-  lo = (lo & 0xCCCC3333u) | ((lo & 0x0000CCCCu) << 14) | ((lo >> 14) & 0x0000CCCCu);
-  uint32_t nhi = (hi & 0xF0F0F0F0u) | ((lo & 0xF0F0F0F0u) >> 4);
-  uint32_t nlo = (lo & 0x0F0F0F0Fu) | ((hi & 0x0F0F0F0Fu) << 4);
-  hi           = nhi;
-  lo           = nlo;
+  // Each round keeps the bits under one mask, takes the left-shifted word under a second one and the right-shifted
+  // word elsewhere (the three masks partition the word): two shifts and two bit-selects.
+  hi = bit_select(0xAA55AA55u, hi, bit_select(0x55005500u, hi << 7, hi >> 7));
+  lo = bit_select(0xAA55AA55u, lo, bit_select(0x55005500u, lo << 7, lo >> 7));
+  hi = bit_select(0xCCCC3333u, hi, bit_select(0x33330000u, hi << 14, hi >> 14));
+  lo = bit_select(0xCCCC3333u, lo, bit_select(0x33330000u, lo << 14, lo >> 14));
+  const uint32_t nhi = bit_select(0xF0F0F0F0u, hi, lo >> 4);
+  const uint32_t nlo = bit_select(0x0F0F0F0Fu, lo, hi << 4);
+  hi                 = nhi;
+  lo                 = nlo;
 }
 
 // x * w evaluated like the reference's SIMD precoder (channel_precoder_avx2.cpp:51-56):
