@@ -32,16 +32,17 @@ def test_pod_layout_matches_header():
     src = r'''#include "mi355_nrphy.h"
 #include <stdio.h>
 #include <stddef.h>
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(nrphy_pdsch_pdu_t), offsetof(nrphy_pdsch_pdu_t, prb_mask),
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(nrphy_pdsch_pdu_t), offsetof(nrphy_pdsch_pdu_t, prb_mask),
  offsetof(nrphy_pdsch_pdu_t, reserved), offsetof(nrphy_pdsch_pdu_t, precoding), sizeof(nrphy_re_pattern_t),
- sizeof(nrphy_pdsch_derived_t), sizeof(nrphy_ofdm_config_t));return 0;}'''
+ sizeof(nrphy_pdsch_derived_t), sizeof(nrphy_ofdm_config_t), sizeof(nrphy_pdsch_encoder_cfg_t));return 0;}'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(backends.ROOT, "include"), os.path.join(d, "t.c"), "-o",
                         os.path.join(d, "t")], check=True, timeout=120)
         out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, timeout=60).stdout.split()
     want = [C.sizeof(abi.PdschPdu), abi.PdschPdu.prb_mask.offset, abi.PdschPdu.reserved.offset,
-            abi.PdschPdu.precoding.offset, C.sizeof(abi.RePattern), C.sizeof(abi.PdschDerived), C.sizeof(abi.OfdmConfig)]
+            abi.PdschPdu.precoding.offset, C.sizeof(abi.RePattern), C.sizeof(abi.PdschDerived), C.sizeof(abi.OfdmConfig),
+            C.sizeof(abi.PdschEncoderCfg)]
     assert [int(x) for x in out] == want
 
 
