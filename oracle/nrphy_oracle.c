@@ -1103,6 +1103,202 @@ int oracle_ofdm_modulate_slot(const nrphy_ofdm_config_t* c, const uint16_t* grid
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* LDPC decoder: layered scaled min-sum on int8 log-likelihood ratios                                  */
+/* (R/lib/phy/upper/channel_coding/ldpc/ldpc_decoder_impl.cpp:60-318, ldpc_decoder_generic.cpp:30-128,   */
+/*  LLR arithmetic R/lib/phy/upper/log_likelihood_ratio.cpp:37-87).                                    */
+/* llr: nof_llr soft bits of the codeblock WITHOUT its first 2*Zc (punctured) bits, as the rate          */
+/* dematcher delivers them.  message_bits: Kb*Zc hard bits, one per byte.  crc_poly_id: 0 = no early     */
+/* stop, else the polynomial of oracle_crc_bits checked over the first Kb*Zc - nof_filler bits.          */
+/* ------------------------------------------------------------------------------------------------ */
+#define LLR_MAX_VALUE 120
+#define LLR_INF_VALUE 127
+
+static int llr_isinf(int v)
+{
+  return v > LLR_MAX_VALUE || v < -LLR_MAX_VALUE;
+}
+
+static int llr_special_sum(int a, int b, int* out)
+{
+  if (a == -b) {
+    *out = 0;
+    return 1;
+  }
+  if (llr_isinf(a)) {
+    *out = a;
+    return 1;
+  }
+  if (llr_isinf(b)) {
+    *out = b;
+    return 1;
+  }
+  return 0;
+}
+
+static int llr_add(int a, int b) /* saturating sum */
+{
+  int r;
+  if (llr_special_sum(a, b, &r)) {
+    return r;
+  }
+  r = a + b;
+  return r > LLR_MAX_VALUE ? LLR_MAX_VALUE : (r < -LLR_MAX_VALUE ? -LLR_MAX_VALUE : r);
+}
+
+static int llr_promotion_sum(int a, int b) /* beyond the range the bit becomes certain */
+{
+  int r;
+  if (llr_special_sum(a, b, &r)) {
+    return r;
+  }
+  r = a + b;
+  return r > LLR_MAX_VALUE ? LLR_INF_VALUE : (r < -LLR_MAX_VALUE ? -LLR_INF_VALUE : r);
+}
+
+int oracle_ldpc_decode(uint32_t bg, uint32_t zc, uint32_t nof_filler, uint32_t crc_poly_id, uint32_t max_iterations,
+                       float scaling_factor, const int8_t* llr, uint32_t nof_llr, uint8_t* message_bits)
+{
+  const nr_ldpc_edge_t* edges   = (bg == 1) ? NR_LDPC_BG1_EDGES : NR_LDPC_BG2_EDGES;
+  const unsigned        n_edges = (bg == 1) ? NR_LDPC_BG1_NOF_EDGES : NR_LDPC_BG2_NOF_EDGES;
+  const unsigned        bg_k = (bg == 1) ? 22 : 10, n_full = (bg == 1) ? 68 : 52, n_short = n_full - 2;
+  const unsigned        n_hr = bg_k + 4, bg_m = n_full - bg_k;
+  const int             ils  = lifting_set_index(zc);
+  const unsigned        K    = bg_k * zc;
+  if (ils < 0 || nof_llr > n_short * zc || nof_llr < K + 2 * zc || max_iterations == 0 ||
+      !(scaling_factor > 0.f && scaling_factor < 1.f)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  /* Last non-zero soft bit (ldpc_decoder_impl.cpp:88-97). */
+  unsigned input_size = nof_llr;
+  while (input_size != 0 && llr[input_size - 1] == 0) {
+    --input_size;
+  }
+  if (input_size == 0) {
+    if (crc_poly_id == 0) {
+      memset(message_bits, 1, K);
+    }
+    return 0;
+  }
+  int8_t* soft = (int8_t*)calloc((size_t)n_full * zc, 1);
+  int8_t* v2c  = (int8_t*)calloc((size_t)(n_hr + 1) * zc, 1);
+  int8_t* c2v  = (int8_t*)calloc((size_t)bg_m * (n_hr + 1) * zc, 1);
+  uint8_t init[46];
+  memset(init, 0, sizeof(init));
+  /* load_soft_bits (:128-164): whole nodes clamped to +-64, the tail copied as it is, two punctured nodes first. */
+  {
+    unsigned full = nof_llr / zc;
+    for (unsigned i = 0; i != full * zc; ++i) {
+      int v            = llr[i];
+      soft[2 * zc + i] = (int8_t)(v > 64 ? 64 : (v < -64 ? -64 : v));
+    }
+    for (unsigned i = full * zc; i != nof_llr; ++i) {
+      soft[2 * zc + i] = llr[i];
+    }
+  }
+  unsigned cb_len = input_size + 2 * zc;
+  if (cb_len < K + 4 * zc) {
+    cb_len = K + 4 * zc;
+  }
+  if (cb_len % zc != 0) {
+    cb_len = (cb_len / zc + 1) * zc;
+  }
+  const unsigned nof_layers = cb_len / zc - bg_k;
+  int            result     = 0;
+  int8_t         min1[384], min2[384];
+  uint8_t        min_idx[384], sign_prod[384];
+  for (unsigned it = 0; it != max_iterations && result == 0; ++it) {
+    for (unsigned m = 0; m != nof_layers; ++m) {
+      /* Edges of check row m in adjacency order (ascending variable index). */
+      unsigned first = 0, deg = 0;
+      for (unsigned e = 0; e != n_edges; ++e) {
+        if (edges[e].row == m) {
+          if (deg == 0) {
+            first = e;
+          }
+          ++deg;
+        }
+      }
+      /* Variable-to-check messages (:166-212): slot = variable index, every extension variable in slot n_hr. */
+      for (unsigned t = 0; t != deg; ++t) {
+        unsigned var = edges[first + t].col, slot = var < n_hr ? var : n_hr;
+        for (unsigned j = 0; j != zc; ++j) {
+          int s = soft[var * zc + j];
+          v2c[slot * zc + j] =
+              (int8_t)(init[m] ? llr_add(s, -(int)c2v[((size_t)m * (n_hr + 1) + slot) * zc + j]) : s);
+        }
+      }
+      /* Two smallest magnitudes and the sign product per check (ldpc_decoder_generic.cpp:44-67). */
+      for (unsigned j = 0; j != zc; ++j) {
+        min1[j]      = LLR_MAX_VALUE;
+        min2[j]      = LLR_MAX_VALUE;
+        min_idx[j]   = 0;
+        sign_prod[j] = 0;
+      }
+      for (unsigned t = 0; t != deg; ++t) {
+        unsigned var = edges[first + t].col, slot = var < n_hr ? var : n_hr;
+        unsigned shift = edges[first + t].shift[ils] % zc;
+        for (unsigned j = 0; j != zc; ++j) {
+          int v = v2c[slot * zc + (j + shift) % zc];
+          int a = v < 0 ? -v : v;
+          int is_min = a < min1[j];
+          int new2   = is_min ? min1[j] : a;
+          if (a < min2[j]) {
+            min2[j] = (int8_t)new2;
+          }
+          if (is_min) {
+            min1[j]    = (int8_t)a;
+            min_idx[j] = (uint8_t)t;
+          }
+          sign_prod[j] ^= (v >= 0) ? 0U : 1U;
+        }
+      }
+      /* Check-to-variable messages (:82-107) and soft-bit update (:109-121, ldpc_decoder_impl.cpp:231-245). */
+      for (unsigned t = 0; t != deg; ++t) {
+        unsigned var = edges[first + t].col, slot = var < n_hr ? var : n_hr;
+        unsigned shift = edges[first + t].shift[ils] % zc;
+        for (unsigned j = 0; j != zc; ++j) {
+          unsigned k = (j + zc - shift) % zc;
+          int      v = (t != min_idx[k]) ? min1[k] : min2[k];
+          if (!llr_isinf(v)) {
+            v = (int)roundf((float)v * scaling_factor);
+          }
+          int vc   = v2c[slot * zc + j];
+          int sign = sign_prod[k] ^ ((vc >= 0) ? 0U : 1U);
+          v        = sign ? -(v < 0 ? -v : v) : (v < 0 ? -v : v);
+          c2v[((size_t)m * (n_hr + 1) + slot) * zc + j] = (int8_t)v;
+          soft[var * zc + j]                            = (int8_t)llr_promotion_sum(v, vc);
+        }
+      }
+      init[m] = 1;
+    }
+    if (crc_poly_id != 0) {
+      int ok = 1;
+      for (unsigned i = 0; i != K; ++i) {
+        message_bits[i] = soft[i] <= 0;
+        ok &= soft[i] != 0;
+      }
+      if (ok) {
+        uint8_t* packed = (uint8_t*)calloc((K + 7) / 8, 1);
+        pack_bits(packed, message_bits, K - nof_filler);
+        if (oracle_crc_bits(crc_poly_id, packed, K - nof_filler) == 0) {
+          result = (int)it + 1;
+        }
+        free(packed);
+      }
+    }
+  }
+  if (crc_poly_id == 0) {
+    for (unsigned i = 0; i != K; ++i) {
+      message_bits[i] = soft[i] <= 0;
+    }
+  }
+  free(soft);
+  free(v2c);
+  free(c2v);
+  return result;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* OFDM demodulator (R/lib/phy/lower/modulation/ofdm_demodulator_impl.cpp:98-171): per symbol skip the  */
 /* cyclic prefix minus the window offset, direct DFT, x (receive phase compensation x scale)            */
 /* [phase_compensation_lut.h:49-82 with is_tx = false], x exp(+j 2 pi window_offset i / N) when the     */

@@ -12,6 +12,8 @@
 #include "lib/phy/generic_functions/precoding/channel_precoder_avx2.h"
 #include "lib/phy/generic_functions/precoding/channel_precoder_generic.h"
 #include "lib/phy/lower/modulation/ofdm_demodulator_impl.h"
+#include "lib/phy/upper/channel_coding/ldpc/ldpc_decoder_avx2.h"
+#include "lib/phy/upper/channel_coding/ldpc/ldpc_decoder_generic.h"
 #include "lib/phy/lower/modulation/ofdm_modulator_impl.h"
 #include "lib/phy/support/resource_grid_impl.h"
 #include "lib/phy/upper/channel_coding/crc_calculator_lut_impl.h"
@@ -583,6 +585,52 @@ int ref_ofdm_modulate_slot(const nrphy_ofdm_config_t* c,
                  slot_index);
   }
   return static_cast<int>(slot_size);
+}
+
+// ldpc_decoder::decode (generic or AVX2 implementation) of one codeblock: llr = nof_llr soft bits (the codeblock without
+// its first 2*Zc bits), message_bits = Kb*Zc hard bits one per byte.  crc_poly_id: 0 none, 16 CRC16, 0x24A, 0x24B.
+// Returns the iteration count when the CRC passed, 0 otherwise.
+int ref_ldpc_decode(uint32_t      bg,
+                    uint32_t      zc,
+                    uint32_t      nof_filler,
+                    uint32_t      crc_poly_id,
+                    uint32_t      max_iterations,
+                    float         scaling_factor,
+                    const int8_t* llr,
+                    uint32_t      nof_llr,
+                    uint8_t*      message_bits,
+                    int           simd)
+{
+  std::unique_ptr<ldpc_decoder> dec;
+  if (simd) {
+    dec = std::make_unique<ldpc_decoder_avx2>();
+  } else {
+    dec = std::make_unique<ldpc_decoder_generic>();
+  }
+  ldpc_decoder::configuration cfg;
+  cfg.block_conf.tb_common.base_graph       = (bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+  cfg.block_conf.tb_common.lifting_size     = static_cast<ldpc::lifting_size_t>(zc);
+  cfg.block_conf.cb_specific.nof_filler_bits = nof_filler;
+  cfg.block_conf.cb_specific.nof_crc_bits   = (crc_poly_id == 16) ? 16 : 24;
+  cfg.algorithm_conf.max_iterations         = max_iterations;
+  cfg.algorithm_conf.scaling_factor         = scaling_factor;
+  std::unique_ptr<crc_calculator> crc;
+  if (crc_poly_id != 0) {
+    crc = std::make_unique<crc_calculator_lut_impl>(crc_poly_id == 16      ? crc_generator_poly::CRC16
+                                                    : crc_poly_id == 0x24B ? crc_generator_poly::CRC24B
+                                                                           : crc_generator_poly::CRC24A);
+  }
+  unsigned                          K = ((bg == 1) ? 22 : 10) * zc;
+  std::vector<log_likelihood_ratio> in(nof_llr);
+  for (unsigned i = 0; i != nof_llr; ++i) {
+    in[i] = log_likelihood_ratio(llr[i]);
+  }
+  dynamic_bit_buffer      out(K);
+  std::optional<unsigned> r = dec->decode(out, in, crc.get(), cfg);
+  for (unsigned i = 0; i != K; ++i) {
+    message_bits[i] = out.extract(i, 1);
+  }
+  return r.has_value() ? static_cast<int>(r.value()) : 0;
 }
 
 // ofdm_slot_demodulator::demodulate of every port of one slot: iq_in [nof_ports][slot_size] complex float ->

@@ -110,6 +110,15 @@ class CpuBackend:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         return int(self._f("crc")(poly, _ptr(data), data.size))
 
+    def crc_bits(self, poly, bits):
+        """CRC of a bit string given one bit per byte (oracle only)."""
+        assert not self.is_ref
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        packed = np.packbits(bits)
+        f = self._f("crc_bits")
+        f.restype = C.c_uint32
+        return int(f(C.c_uint32(poly), _ptr(packed), C.c_uint32(bits.size)))
+
     def validate(self, pdu):
         return int(self._f("pdsch_validate")(C.byref(pdu)))
 
@@ -217,6 +226,18 @@ class CpuBackend:
         n = self._f("ofdm_modulate_slot")(C.byref(cfg), _ptr(grid), nof_ports, slot_index, _ptr(iq))
         assert n > 0, n
         return iq.reshape(-1)[: nof_ports * n].reshape(nof_ports, n).copy()
+
+    def ldpc_decode(self, bg, zc, nof_filler, crc_poly_id, max_iterations, scaling, llr, simd=0):
+        """ldpc_decoder::decode: llr int8 (codeblock without its first 2*Zc bits) -> (iterations or 0, Kb*Zc bits)."""
+        llr = np.ascontiguousarray(llr, dtype=np.int8)
+        bits = np.zeros((22 if bg == 1 else 10) * zc, np.uint8)
+        f = self._f("ldpc_decode")
+        f.restype = C.c_int
+        args = [C.c_uint32(bg), C.c_uint32(zc), C.c_uint32(nof_filler), C.c_uint32(crc_poly_id),
+                C.c_uint32(max_iterations), C.c_float(scaling), _ptr(llr), C.c_uint32(llr.size), _ptr(bits)]
+        if self.is_ref:
+            args.append(C.c_int(simd))
+        return int(f(*args)), bits
 
     def ofdm_demod_slot(self, cfg, iq, slot_index=0, window_offset=0):
         """iq: [nof_ports][slot_size] complex64 -> grid [nof_ports][14][12*bw_rb][2] uint16 (raw bf16)."""
