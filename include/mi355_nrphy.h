@@ -253,6 +253,36 @@ int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, u
  * nof_ports x nrphy_ofdm_slot_size(cfg, slot_index) complex samples, port after port (blocking). */
 int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t slot_index, float* iq);
 
+/* ---- receive side ("next" row): LDPC decoder ------------------------------
+ * Replaces ldpc_decoder::decode (R/include/srsran/phy/upper/channel_coding/ldpc/ldpc_decoder.h;
+ * impl R/lib/phy/upper/channel_coding/ldpc/ldpc_decoder_impl.cpp:60-126 with the message kernels of
+ * ldpc_decoder_generic.cpp:30-128): layered scaled min-sum on int8 log-likelihood ratios (finite range
+ * +-120, +-127 = certain), early stop when the hard bits pass the CRC.  The fields are
+ * ldpc_decoder::configuration: codeblock metadata (base graph, lifting size, filler bits, CRC) and
+ * algorithm details (max_iterations, scaling_factor in (0, 1)).  crc_poly: 0 = no early stop, 16 =
+ * CRC16, 0x24A = CRC24A, 0x24B = CRC24B.  nof_llr soft bits per codeblock: the codeblock without its
+ * first 2*Zc (punctured) bits, as the rate dematcher delivers it, between (Kb + 2) * Zc and
+ * (N_full - 2) * Zc of them.  Results are bit-identical to the reference's generic implementation; its
+ * AVX2 implementation uses other intermediate arithmetic and agrees only once both have converged. */
+typedef struct nrphy_ldpc_decoder_cfg {
+  uint32_t base_graph;
+  uint32_t lifting_size;
+  uint32_t nof_filler_bits;
+  uint32_t crc_poly;
+  uint32_t nof_llr;
+  uint32_t max_iterations;
+  float    scaling_factor;
+} nrphy_ldpc_decoder_cfg_t;
+/* n_cb codeblocks that share the configuration.  d_llr: codeblock i at i * llr_stride_bytes.  d_out:
+ * the Kb*Zc hard bits of codeblock i, packed MSB first, at i * out_stride_bytes.  d_iterations (may be
+ * NULL): per codeblock the iteration after which the CRC passed, 0 when it did not (or no CRC given). */
+int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb, const int8_t* d_llr,
+                      uint32_t llr_stride_bytes, uint8_t* d_out, uint32_t out_stride_bytes, uint32_t* d_iterations,
+                      void* stream);
+/* Host-span form for one codeblock (blocking). */
+int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, const int8_t* llr,
+                           uint8_t* message_packed, uint32_t* iterations);
+
 /* ---- receive side of seam C ("next" row): OFDM demodulator ---------------
  * Replaces ofdm_symbol_demodulator::demodulate / ofdm_slot_demodulator::demodulate
  * (R/include/srsran/phy/lower/modulation/ofdm_demodulator.h; impl

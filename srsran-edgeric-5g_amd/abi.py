@@ -88,6 +88,13 @@ class PdschEncoderCfg(C.Structure):
                 ("nof_layers", C.c_uint32), ("nof_ch_symbols", C.c_uint32), ("tb_size_bytes", C.c_uint32)]
 
 
+class LdpcDecoderCfg(C.Structure):
+    """nrphy_ldpc_decoder_cfg_t (ldpc_decoder::configuration + number of soft bits)."""
+    _fields_ = [("base_graph", C.c_uint32), ("lifting_size", C.c_uint32), ("nof_filler_bits", C.c_uint32),
+                ("crc_poly", C.c_uint32), ("nof_llr", C.c_uint32), ("max_iterations", C.c_uint32),
+                ("scaling_factor", C.c_float)]
+
+
 class OfdmConfig(C.Structure):
     _fields_ = [
         ("numerology", C.c_uint32),
@@ -227,6 +234,8 @@ def declare(lib, prefix="nrphy_"):
     sig("ofdm_demod_run", i32, vp, u32, vp, vp, u32, vp, vp)
     sig("ofdm_demodulate_slot_host", i32, vp, vp, u32, u32, vp)
     sig("ofdm_demodulate_symbol_host", i32, vp, vp, u32, u32, u32, vp)
+    sig("ldpc_decode", i32, vp, P(LdpcDecoderCfg), u32, vp, u32, vp, u32, vp, vp)
+    sig("ldpc_decode_host", i32, vp, P(LdpcDecoderCfg), vp, u8p, P(u32))
     return lib
 
 
@@ -241,4 +250,5 @@ ABI_SYMBOLS = [
     "nrphy_ofdm_plan_destroy", "nrphy_ofdm_plan_slot_stride", "nrphy_ofdm_run",
     "nrphy_ofdm_modulate_symbol_host", "nrphy_ofdm_modulate_slot_host", "nrphy_dft_run", "nrphy_dft_run_host",
     "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",
+    "nrphy_ldpc_decode", "nrphy_ldpc_decode_host",
 ]

@@ -373,17 +373,19 @@ struct nrphy_ctx {
   TbCrcTables* d_tbcrc  = nullptr;
   uint32_t*    d_x1     = nullptr;
   float2*      d_twiddle[10] = {}; // one table per supported DFT size (twiddle_slot)
+  DecoderGraph* d_dec_graph[NOF_GRAPHS] = {}; // decoder graphs, built on first use
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
   // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
   std::mutex host_mutex;
-  void*      scratch[6]       = {};
-  size_t     scratch_bytes[6] = {};
+  void*      scratch[7]       = {};
+  size_t     scratch_bytes[7] = {};
 };
 
 namespace {
 
 // Staging buffer `slot` of the context with room for `bytes` (reallocated only when it has to grow).
-enum ScratchSlot { SCRATCH_TB = 0, SCRATCH_GRID, SCRATCH_CW_RM, SCRATCH_CW_SCR, SCRATCH_IQ, SCRATCH_SMALL };
+enum ScratchSlot { SCRATCH_TB = 0, SCRATCH_GRID, SCRATCH_CW_RM, SCRATCH_CW_SCR, SCRATCH_IQ, SCRATCH_SMALL,
+                   SCRATCH_DECODER };
 void* ctx_scratch(nrphy_ctx* ctx, ScratchSlot slot, size_t bytes)
 {
   if (bytes > ctx->scratch_bytes[slot]) {
@@ -773,6 +775,9 @@ extern "C" int nrphy_destroy(nrphy_ctx_t* ctx)
   (void)hipFree(ctx->d_tbcrc);
   for (void* b : ctx->scratch) {
     (void)hipFree(b);
+  }
+  for (DecoderGraph* g : ctx->d_dec_graph) {
+    (void)hipFree(g);
   }
   (void)hipFree(ctx->d_x1);
   for (float2* t : ctx->d_twiddle) {
@@ -1557,6 +1562,132 @@ extern "C" int nrphy_pdsch_encode_host(nrphy_ctx_t* ctx, const nrphy_pdsch_encod
       codeword_bits[i] = (packed[i >> 3] >> (7U - (i & 7U))) & 1U;
     }
   }
+  return rc;
+}
+
+namespace {
+
+// Decoder graph of (base graph, lifting size): all edges of TS 38.212 Tables 5.3.2-2/-3, row by row.
+const DecoderGraph* get_decoder_graph(nrphy_ctx* ctx, unsigned bg, unsigned zc)
+{
+  const int pos = lifting_position(zc);
+  if (pos < 0) {
+    return nullptr;
+  }
+  const unsigned slot = (bg - 1) * NOF_LIFTING_SIZES + (unsigned)pos;
+  if (ctx->d_dec_graph[slot] == nullptr) {
+    std::vector<DecoderGraph> g(1);
+    std::memset(&g[0], 0, sizeof(DecoderGraph));
+    const nr_ldpc_edge_t* edges   = (bg == 1) ? NR_LDPC_BG1_EDGES : NR_LDPC_BG2_EDGES;
+    const unsigned        n_edges = (bg == 1) ? NR_LDPC_BG1_NOF_EDGES : NR_LDPC_BG2_NOF_EDGES;
+    const unsigned        rows    = (bg == 1) ? 46 : 42;
+    const int             ils     = lifting_set_index(zc);
+    unsigned              count   = 0;
+    for (unsigned m = 0; m != rows; ++m) {
+      g[0].row_ptr[m] = (uint16_t)count;
+      for (unsigned e = 0; e != n_edges; ++e) {
+        if (edges[e].row == m) {
+          g[0].edge[count++] = ((uint32_t)edges[e].col << 16) | (edges[e].shift[ils] % zc);
+        }
+      }
+    }
+    for (unsigned m = rows; m != MAX_BG_ROWS + 2; ++m) {
+      g[0].row_ptr[m] = (uint16_t)count;
+    }
+    if (upload(&ctx->d_dec_graph[slot], g.data(), sizeof(DecoderGraph)) != hipSuccess) {
+      return nullptr;
+    }
+  }
+  return ctx->d_dec_graph[slot];
+}
+
+} // namespace
+
+extern "C" int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb,
+                                 const int8_t* d_llr, uint32_t llr_stride_bytes, uint8_t* d_out,
+                                 uint32_t out_stride_bytes, uint32_t* d_iterations, void* stream)
+{
+  if (ctx == nullptr || cfg == nullptr || d_llr == nullptr || d_out == nullptr ||
+      (cfg->base_graph != 1 && cfg->base_graph != 2) || cfg->max_iterations == 0 ||
+      !(cfg->scaling_factor > 0.0F && cfg->scaling_factor < 1.0F) ||
+      (cfg->crc_poly != 0 && cfg->crc_poly != 16 && cfg->crc_poly != 0x24A && cfg->crc_poly != 0x24B)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const unsigned bg_k = (cfg->base_graph == 1) ? 22 : 10, n_full = (cfg->base_graph == 1) ? 68 : 52;
+  const unsigned zc = cfg->lifting_size, K = bg_k * zc;
+  // ldpc_decoder_impl.cpp:70-86: between the message plus two blocks and the whole (shortened) codeblock.
+  if (lifting_position(zc) < 0 || cfg->nof_llr < K + 2 * zc || cfg->nof_llr > (n_full - 2) * zc ||
+      cfg->nof_filler_bits >= K || llr_stride_bytes < cfg->nof_llr || out_stride_bytes < (K + 7) / 8) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  LdpcDecodeLaunch p;
+  p.graph = get_decoder_graph(ctx, cfg->base_graph, zc);
+  if (p.graph == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  p.zc             = zc;
+  p.bg_k           = bg_k;
+  p.nof_nodes      = std::max<uint32_t>(divide_ceil(cfg->nof_llr, zc) + 2, bg_k + 4);
+  p.nof_layers_max = p.nof_nodes - bg_k;
+  p.nof_llr        = cfg->nof_llr;
+  p.llr_stride     = llr_stride_bytes;
+  p.out_stride     = out_stride_bytes;
+  p.nof_filler     = cfg->nof_filler_bits;
+  p.crc_order      = (cfg->crc_poly == 0) ? 0 : (cfg->crc_poly == 16 ? 16 : 24);
+  p.crc_poly       = (cfg->crc_poly == 16) ? 0x11021U : (cfg->crc_poly == 0x24B ? 0x1800063U : 0x1864CFBU);
+  p.max_iterations = cfg->max_iterations;
+  p.scaling_factor = cfg->scaling_factor;
+  p.llr            = d_llr;
+  p.out            = d_out;
+  p.iterations     = d_iterations;
+  {
+    // Check records: context-owned, grow-only (a first call with a larger batch allocates; not stream-ordered).
+    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    p.scratch = (uint2*)ctx_scratch(ctx, SCRATCH_DECODER, (size_t)n_cb * p.nof_layers_max * zc * sizeof(uint2));
+  }
+  if (p.scratch == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  HIP_TRY(launch_ldpc_decode(p, n_cb, stream ? (hipStream_t)stream : ctx->stream));
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, const int8_t* llr,
+                                      uint8_t* message_packed, uint32_t* iterations)
+{
+  if (ctx == nullptr || cfg == nullptr || llr == nullptr || message_packed == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const unsigned K     = ((cfg->base_graph == 1) ? 22U : 10U) * cfg->lifting_size;
+  int8_t*        d_llr = nullptr;
+  uint8_t*       d_out = nullptr;
+  int            rc    = NRPHY_ERR_DEVICE;
+  do {
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&d_llr, cfg->nof_llr + 16) != hipSuccess ||
+        hipMalloc((void**)&d_out, (K + 7) / 8 + 16) != hipSuccess ||
+        hipMemcpy(d_llr, llr, cfg->nof_llr, hipMemcpyHostToDevice) != hipSuccess) {
+      break;
+    }
+    uint32_t* d_it = (uint32_t*)(d_out + (((K + 7) / 8 + 3) & ~3U));
+    rc = nrphy_ldpc_decode(ctx, cfg, 1, d_llr, cfg->nof_llr, d_out, (K + 7) / 8, d_it, ctx->stream);
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    uint32_t it = 0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(message_packed, d_out, (K + 7) / 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&it, d_it, sizeof(it), hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    if (iterations) {
+      *iterations = it;
+    }
+    rc = NRPHY_OK;
+  } while (false);
+  (void)hipFree(d_llr);
+  (void)hipFree(d_out);
   return rc;
 }
 

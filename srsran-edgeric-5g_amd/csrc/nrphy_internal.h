@@ -219,6 +219,28 @@ hipError_t launch_ldpc_encode(const LiftedGraph* graphs, uint32_t graph, uint32_
                               const uint8_t* d_msg, uint32_t msg_stride, uint32_t out_bits, uint8_t* d_out,
                               uint32_t out_stride, hipStream_t stream);
 
+// ---- LDPC decoder ("next" row, receive side) -------------------------------------------------------------------
+// The whole lifted graph of one (base graph, lifting size) for the decoder: every edge of every check row in
+// adjacency order (ascending variable index, the order that breaks ties between equal minima).
+struct DecoderGraph {
+  uint16_t row_ptr[MAX_BG_ROWS + 2];
+  uint32_t edge[MAX_BG_EDGES]; // variable node << 16 | lifted shift
+};
+
+struct LdpcDecodeLaunch {
+  const DecoderGraph* graph;
+  const int8_t*       llr;        // per codeblock: nof_llr soft bits (the codeblock without its first 2 Zc bits)
+  uint2*              scratch;    // per codeblock: nof_layers_max * Zc check records of 8 bytes
+  uint8_t*            out;        // per codeblock: Kb * Zc hard bits, packed MSB first
+  uint32_t*           iterations; // per codeblock: iterations until the CRC passed, 0 = it did not (may be null)
+  uint32_t            zc, bg_k, nof_nodes, nof_layers_max;
+  uint32_t            nof_llr, llr_stride, out_stride, nof_filler;
+  uint32_t            crc_poly, crc_order; // order 0: no early stop
+  uint32_t            max_iterations;
+  float               scaling_factor;
+};
+hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStream_t stream);
+
 // ---- OFDM ---------------------------------------------------------------------------------------------------
 struct OfdmLaunch {
   uint32_t       dft_size;

@@ -110,6 +110,23 @@ class Context:
         _check(self.lib.nrphy_ldpc_encode(self.handle, base_graph, lifting_size, n_cb, _dptr(d_msg), msg_stride,
                                           out_bits, _dptr(d_out), out_stride, stream), "nrphy_ldpc_encode")
 
+    def ldpc_decode(self, cfg, n_cb, d_llr, llr_stride, d_out, out_stride, d_iterations=None, stream=None):
+        """ldpc_decoder::decode for n_cb codeblocks resident in HBM (cfg: abi.LdpcDecoderCfg)."""
+        _check(self.lib.nrphy_ldpc_decode(self.handle, C.byref(cfg), n_cb, _dptr(d_llr), llr_stride, _dptr(d_out),
+                                          out_stride, _dptr(d_iterations) if d_iterations is not None else None,
+                                          stream), "nrphy_ldpc_decode")
+
+    def ldpc_decode_host(self, base_graph, lifting_size, nof_filler, crc_poly, max_iterations, scaling, llr):
+        """ldpc_decoder::decode on host spans: returns (iterations or 0, Kb*Zc hard bits one per byte)."""
+        llr = np.ascontiguousarray(llr, dtype=np.int8)
+        cfg = abi.LdpcDecoderCfg(base_graph, lifting_size, nof_filler, crc_poly, llr.size, max_iterations, scaling)
+        k = (22 if base_graph == 1 else 10) * lifting_size
+        packed = np.zeros((k + 7) // 8, np.uint8)
+        it = C.c_uint32(0)
+        _check(self.lib.nrphy_ldpc_decode_host(self.handle, C.byref(cfg), llr.ctypes.data, packed.ctypes.data,
+                                               C.byref(it)), "nrphy_ldpc_decode_host")
+        return int(it.value), np.unpackbits(packed)[:k]
+
     def dft(self, size, inverse, batch, d_in, d_out, stream=None):
         _check(self.lib.nrphy_dft_run(self.handle, size, int(inverse), batch, _dptr(d_in), _dptr(d_out), stream),
                "nrphy_dft_run")

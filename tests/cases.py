@@ -87,3 +87,38 @@ def unit_test_like_pdus(rng):
 
 def random_tb(rng, pdu):
     return rng.integers(0, 256, pdu.tb_size_bytes, dtype=np.uint8)
+
+
+# ---- LDPC decoder ("next" row) -------------------------------------------------------------------------
+def make_ldpc_llrs(oracle, rng, bg, zc, nof_llr, crc_poly_id, nof_filler, amplitude, sigma):
+    """A valid codeblock (random payload + CRC + filler zeros) encoded by the oracle, turned into noisy int8 LLRs."""
+    kb = 22 if bg == 1 else 10
+    K = kb * zc
+    crc_len = 16 if crc_poly_id == 16 else 24
+    payload = rng.integers(0, 2, K - nof_filler - crc_len, dtype=np.uint8)
+    crc = oracle.crc_bits(crc_poly_id, payload)
+    msg = np.concatenate([payload, [(crc >> (crc_len - 1 - i)) & 1 for i in range(crc_len)],
+                          np.zeros(nof_filler, np.uint8)]).astype(np.uint8)
+    cb = oracle.ldpc_encode(bg, zc, np.packbits(msg), nof_llr)
+    bits = np.unpackbits(cb)[:nof_llr].astype(np.float64)
+    llr = (1.0 - 2.0 * bits) * amplitude + rng.normal(0.0, sigma, nof_llr)
+    return msg, np.clip(np.rint(llr), -120, 120).astype(np.int8)
+
+
+LDPC_DECODE_CASES = [
+    # bg, zc, nof_llr (in units of zc beyond K: total = K + extra * zc + tail), extra, tail, crc, filler, amp, sigma
+    (1, 384, 4, 0, 0x24B, 72, 24, 0),      # config-3 codeblock, noiseless, high rate (four layers)
+    (1, 384, 4, 120, 0x24B, 72, 20, 9),    # partial last node, noise
+    (1, 384, 12, 0, 0x24B, 0, 16, 10),
+    (1, 128, 44, 0, 0x24A, 40, 10, 7),     # full base graph 1, low rate
+    (2, 352, 6, 33, 0x24B, 24, 14, 8),     # config-4 QPSK user: BG2
+    (2, 144, 40, 0, 16, 104, 8, 6),        # config 1: BG2, CRC16, every layer
+    (2, 6, 10, 3, 16, 2, 30, 12),          # tiny lifting size
+    (1, 384, 6, 0, 0x24B, 72, 6, 9),       # too noisy: must fail the CRC after max_iterations
+]
+
+
+def ldpc_decode_nof_llr(case):
+    bg, zc, extra, tail = case[:4]
+    kb = 22 if bg == 1 else 10
+    return max(kb * zc + extra * zc + tail - 2 * zc, kb * zc + 2 * zc)

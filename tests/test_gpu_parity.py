@@ -494,3 +494,99 @@ def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
         assert gpu_ctx.lib.nrphy_ofdm_modulate_slot_host(plan.handle, grid.ctypes.data, slot, iq.ctypes.data) == 0
         assert rel_err(iq, oracle.ofdm_slot(cfg, grid, slot)) < 1e-5
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LDPC decoder ("next" row, receive side): bit-exact hard bits and iteration counts against the oracle, which is pinned
+# to the reference's generic decoder (tests/test_oracle.py)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", cases.LDPC_DECODE_CASES)
+def test_ldpc_decoder_vs_oracle(gpu_ctx, oracle, case):
+    bg, zc, extra, tail, crc_id, filler, amp, sigma = case
+    rng = np.random.default_rng(zc * 1000 + extra)
+    nof_llr = cases.ldpc_decode_nof_llr(case)
+    msg, llr = cases.make_ldpc_llrs(oracle, rng, bg, zc, nof_llr, crc_id, filler, amp, sigma)
+    for crc in (crc_id, 0):
+        for iters in (1, 3, 8):
+            it_o, bits_o = oracle.ldpc_decode(bg, zc, filler, crc, iters, 0.8, llr)
+            it_g, bits_g = gpu_ctx.ldpc_decode_host(bg, zc, filler, crc, iters, 0.8, llr)
+            assert it_g == it_o, (crc, iters)
+            assert np.array_equal(bits_g, bits_o), (crc, iters, int(np.count_nonzero(bits_g != bits_o)))
+    # other scaling factors, saturated and "certain" inputs
+    hard = llr.copy()
+    hard[::7] = np.where(hard[::7] >= 0, 127, -127)
+    hard[5::11] = 0
+    for scaling in (0.5, 0.75, 0.95):
+        it_o, bits_o = oracle.ldpc_decode(bg, zc, filler, crc_id, 6, scaling, hard)
+        it_g, bits_g = gpu_ctx.ldpc_decode_host(bg, zc, filler, crc_id, 6, scaling, hard)
+        assert it_g == it_o and np.array_equal(bits_g, bits_o), scaling
+    # all-zero input: nothing to decode (ldpc_decoder_impl.cpp:88-97)
+    zero = np.zeros(nof_llr, np.int8)
+    assert gpu_ctx.ldpc_decode_host(bg, zc, filler, crc_id, 8, 0.8, zero)[0] == 0
+    it, bits = gpu_ctx.ldpc_decode_host(bg, zc, filler, 0, 8, 0.8, zero)
+    assert it == 0 and bits.all()
+
+
+def test_ldpc_decoder_batch_and_argument_checks(gpu_ctx, oracle):
+    """A batch of codeblocks of one configuration resident in HBM, each with its own noise; strides; refusals."""
+    import torch
+    bg, zc, filler, crc_id = 1, 384, 72, 0x24B
+    nof_llr, n_cb = 22 * 384 + 4 * 384 - 2 * 384 + 200, 24
+    rng = np.random.default_rng(4242)
+    stride = nof_llr + 57
+    llrs = np.zeros((n_cb, stride), np.int8)
+    want = []
+    for i in range(n_cb):
+        _, llr = cases.make_ldpc_llrs(oracle, rng, bg, zc, nof_llr, crc_id, filler, 20, 6 + i % 6)
+        llrs[i, :nof_llr] = llr
+        llrs[i, nof_llr:] = 99  # must never be read
+        want.append(oracle.ldpc_decode(bg, zc, filler, crc_id, 6, 0.8, llr))
+    k = 22 * zc
+    out = torch.zeros((n_cb, k // 8 + 8), dtype=torch.uint8, device="cuda")
+    its = torch.full((n_cb,), 77, dtype=torch.int32, device="cuda")
+    cfg = abi.LdpcDecoderCfg(bg, zc, filler, crc_id, nof_llr, 6, 0.8)
+    gpu_ctx.ldpc_decode(cfg, n_cb, dev(llrs), stride, out, out.shape[1], its)
+    torch.cuda.synchronize()
+    got_bits = np.unpackbits(out.cpu().numpy()[:, : k // 8], axis=1)
+    for i in range(n_cb):
+        assert int(its[i]) == want[i][0], i
+        assert np.array_equal(got_bits[i], want[i][1]), i
+    assert {w[0] for w in want} != {0}, "the batch should hold codeblocks that converge"
+    llr0 = llrs[0, :nof_llr]
+    for bad in [dict(base_graph=3), dict(lifting_size=17), dict(max_iterations=0), dict(scaling_factor=1.0),
+                dict(crc_poly=5), dict(nof_llr=22 * 384), dict(nof_filler_bits=22 * 384)]:
+        c = abi.LdpcDecoderCfg(bg, zc, filler, crc_id, nof_llr, 6, 0.8)
+        for name, value in bad.items():
+            setattr(c, name, value)
+        packed = np.zeros(k // 8, np.uint8)
+        rc = gpu_ctx.lib.nrphy_ldpc_decode_host(gpu_ctx.handle, C.byref(c), llr0.ctypes.data, packed.ctypes.data, None)
+        assert rc == abi.ERR_ARGUMENT, bad
+
+
+def test_ldpc_encode_decode_round_trip_full_size(gpu_ctx, oracle):
+    """Size-independent property at the config-3 shape: every codeblock the GPU encoder produces, with errors inside the
+    code's reach, decodes back to its message (encode -> corrupt -> decode)."""
+    import torch
+    bg, zc, n_cb = 1, 384, 104
+    k, e = 22 * zc, 8960
+    rng = np.random.default_rng(31)
+    msgs = rng.integers(0, 2, (n_cb, k), dtype=np.uint8)
+    msgs[:, k - 72:] = 0
+    for i in range(n_cb):
+        crc = oracle.crc_bits(0x24B, msgs[i, : k - 72 - 24])
+        msgs[i, k - 96: k - 72] = [(crc >> (23 - b)) & 1 for b in range(24)]
+    d_msg = dev(np.packbits(msgs, axis=1))
+    d_cb = torch.zeros((n_cb, (e + 7) // 8), dtype=torch.uint8, device="cuda")
+    gpu_ctx.ldpc_encode(bg, zc, d_msg, d_msg.shape[1], e, d_cb, d_cb.shape[1], n_cb)
+    torch.cuda.synchronize()
+    bits = np.unpackbits(d_cb.cpu().numpy(), axis=1)[:, :e].astype(np.float64)
+    llr = (1.0 - 2.0 * bits) * 24 + rng.normal(0.0, 9.0, bits.shape)
+    llr = np.clip(np.rint(llr), -120, 120).astype(np.int8)
+    assert np.count_nonzero((llr < 0) != (bits > 0)) > 100, "the channel should flip some bits"
+    out = torch.zeros((n_cb, k // 8), dtype=torch.uint8, device="cuda")
+    its = torch.zeros((n_cb,), dtype=torch.int32, device="cuda")
+    cfg = abi.LdpcDecoderCfg(bg, zc, 72, 0x24B, e, 10, 0.8)
+    gpu_ctx.ldpc_decode(cfg, n_cb, dev(llr), e, out, k // 8, its)
+    torch.cuda.synchronize()
+    assert int(its.min()) >= 1
+    assert np.array_equal(np.unpackbits(out.cpu().numpy(), axis=1)[:, : k - 72], msgs[:, : k - 72])

@@ -107,35 +107,7 @@ def test_oracle_ofdm_demodulator_golden(oracle, name):
     assert_bf16_grids_close(oracle.ofdm_demod_slot(cfg, g[name + "_iq"], int(slot), int(wo)), g[name + "_grid"])
 
 
-def make_ldpc_llrs(oracle, rng, bg, zc, nof_llr, crc_poly_id, nof_filler, amplitude, sigma):
-    """A valid codeblock (random payload + CRC + filler zeros) encoded by the oracle, turned into noisy int8 LLRs."""
-    kb = 22 if bg == 1 else 10
-    K = kb * zc
-    crc_len = 16 if crc_poly_id == 16 else 24
-    payload = rng.integers(0, 2, K - nof_filler - crc_len, dtype=np.uint8)
-    crc = oracle.crc_bits(crc_poly_id, payload)
-    msg = np.concatenate([payload, [(crc >> (crc_len - 1 - i)) & 1 for i in range(crc_len)],
-                          np.zeros(nof_filler, np.uint8)]).astype(np.uint8)
-    cb = oracle.ldpc_encode(bg, zc, np.packbits(msg), nof_llr)
-    bits = np.unpackbits(cb)[:nof_llr].astype(np.float64)
-    llr = (1.0 - 2.0 * bits) * amplitude + rng.normal(0.0, sigma, nof_llr)
-    return msg, np.clip(np.rint(llr), -120, 120).astype(np.int8)
-
-
-LDPC_DECODE_CASES = [
-    # bg, zc, nof_llr (in units of zc beyond K: total = K + extra * zc + tail), extra, tail, crc, filler, amp, sigma
-    (1, 384, 4, 0, 0x24B, 72, 24, 0),      # config-3 codeblock, noiseless, high rate (four layers)
-    (1, 384, 4, 120, 0x24B, 72, 20, 9),    # partial last node, noise
-    (1, 384, 12, 0, 0x24B, 0, 16, 10),
-    (1, 128, 44, 0, 0x24A, 40, 10, 7),     # full base graph 1, low rate
-    (2, 352, 6, 33, 0x24B, 24, 14, 8),     # config-4 QPSK user: BG2
-    (2, 144, 40, 0, 16, 104, 8, 6),        # config 1: BG2, CRC16, every layer
-    (2, 6, 10, 3, 16, 2, 30, 12),          # tiny lifting size
-    (1, 384, 6, 0, 0x24B, 72, 6, 9),       # too noisy: must fail the CRC after max_iterations
-]
-
-
-@pytest.mark.parametrize("case", LDPC_DECODE_CASES)
+@pytest.mark.parametrize("case", cases.LDPC_DECODE_CASES)
 def test_oracle_ldpc_decoder_vs_reference(oracle, ref, case):
     """Layered scaled min-sum against the C restatement.  The oracle follows ldpc_decoder_generic: identical hard bits and
     iteration counts, with and without CRC early stop.  The reference's AVX2 decoder uses different intermediate
@@ -143,10 +115,8 @@ def test_oracle_ldpc_decoder_vs_reference(oracle, ref, case):
     then); it is only required to deliver the same message once both have passed the CRC."""
     bg, zc, extra, tail, crc_id, filler, amp, sigma = case
     rng = np.random.default_rng(zc * 1000 + extra)
-    kb = 22 if bg == 1 else 10
-    nof_llr = kb * zc + extra * zc + tail - 2 * zc
-    nof_llr = max(nof_llr, kb * zc + 2 * zc)
-    msg, llr = make_ldpc_llrs(oracle, rng, bg, zc, nof_llr, crc_id, filler, amp, sigma)
+    nof_llr = cases.ldpc_decode_nof_llr(case)
+    msg, llr = cases.make_ldpc_llrs(oracle, rng, bg, zc, nof_llr, crc_id, filler, amp, sigma)
     for crc in (crc_id, 0):
         for iters in (1, 8):
             it_o, bits_o = oracle.ldpc_decode(bg, zc, filler, crc, iters, 0.8, llr)
