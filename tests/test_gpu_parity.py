@@ -583,10 +583,13 @@ def test_ldpc_encode_decode_round_trip_full_size(gpu_ctx, oracle):
     llr = (1.0 - 2.0 * bits) * 24 + rng.normal(0.0, 9.0, bits.shape)
     llr = np.clip(np.rint(llr), -120, 120).astype(np.int8)
     assert np.count_nonzero((llr < 0) != (bits > 0)) > 100, "the channel should flip some bits"
+    # the rate dematcher hands over the whole circular buffer: what was not transmitted is zero
+    nof_llr = 66 * zc
+    llr = np.concatenate([llr, np.zeros((n_cb, nof_llr - e), np.int8)], axis=1)
     out = torch.zeros((n_cb, k // 8), dtype=torch.uint8, device="cuda")
     its = torch.zeros((n_cb,), dtype=torch.int32, device="cuda")
-    cfg = abi.LdpcDecoderCfg(bg, zc, 72, 0x24B, e, 10, 0.8)
-    gpu_ctx.ldpc_decode(cfg, n_cb, dev(llr), e, out, k // 8, its)
+    cfg = abi.LdpcDecoderCfg(bg, zc, 72, 0x24B, nof_llr, 10, 0.8)
+    gpu_ctx.ldpc_decode(cfg, n_cb, dev(llr), nof_llr, out, k // 8, its)
     torch.cuda.synchronize()
     assert int(its.min()) >= 1
     assert np.array_equal(np.unpackbits(out.cpu().numpy(), axis=1)[:, : k - 72], msgs[:, : k - 72])
