@@ -51,6 +51,22 @@ def main():
         res[label] = {"ms": ms, "codeblocks_per_s": n_cb / ms * 1e3, "slots_per_s": n_slots / ms * 1e3,
                       "info_gbps": n_cb * (k - 24) / ms * 1e-6, "mean_iterations": float(its.float().mean())}
     # without a CRC in the random messages early stop never fires: the second leg is the CRC cost on top
+    # CPU context: the reference's own decoder (oracle/_ref, AVX2 and generic) on a few of the same codeblocks, 1 thread
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    try:
+        import backends
+        ref = backends.ref()
+        if ref is None:
+            raise RuntimeError("oracle/_ref not built")
+        for simd, label in ((1, "reference_avx2"), (0, "reference_generic")):
+            t0, n = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 2.0:
+                ref.ldpc_decode(bg, zc, 0, 0, iters, 0.8, llr[n % n_cb], simd=simd)
+                n += 1
+            dt = time.perf_counter() - t0
+            res[label] = {"codeblocks_per_s": n / dt, "info_gbps": n * (k - 24) / dt * 1e-9, "threads": 1}
+    except Exception as e:  # the compiled reference is optional here
+        res["reference"] = "unavailable: %s" % e
     print(json.dumps({"n_slots": n_slots, "n_cb": n_cb, "max_iterations": iters, **res}))
 
 

@@ -6,14 +6,14 @@
 // R/lib/phy/upper/log_likelihood_ratio.cpp:37-87) bit for bit: same clamps, same saturating / promoting sums, same
 // tie-breaking of the two minima, same rounding of the scaled magnitude, same early stop on the CRC.
 //
-// One workgroup per codeblock, thread j owns lifted position j of every block (Zc <= 384 threads).  The soft bits and
-// the variable-to-check messages of the layer in flight live in LDS.  The check-to-variable messages are kept in the
-// compressed form the min-sum rule allows -- per lifted check its two scaled magnitudes, the edge holding the minimum
-// and one sign bit per edge: 8 bytes instead of up to 20 -- in a global scratch area (mostly L2).  A layer is
-//   1. v2c[edge][j]  = soft[var][j] - c2v(edge)[j]          (c2v rebuilt from the record of check (j - shift) mod Zc)
-//   2. min-sum over the rotated v2c of check j               -> new record of check j
-//   3. soft[var][j]  = c2v(edge)[j] (+) v2c[edge][j]          (promotion sum)
-// with two workgroup barriers.
+// One workgroup per codeblock, thread j owns lifted check j of every layer (Zc <= 384 threads).  The soft bits live in
+// LDS.  Check j of a layer reads the soft bit of each neighbour at its rotated position (j + shift) mod Zc, subtracts
+// its own previous message, runs the min-sum rule and writes the new soft bit back to the same place: within a layer
+// every (variable, position) pair belongs to exactly one check, so a layer needs no exchange buffer and one barrier.
+// The check-to-variable messages are kept in the compressed form the min-sum rule allows -- per lifted check its two
+// scaled magnitudes, the edge holding the minimum and one sign bit per edge: 8 bytes instead of up to 19 -- read and
+// written only by the thread that owns the check (coalesced, L2 resident; the next layer's record is prefetched).
+// This is the reference's arithmetic re-indexed by check instead of by variable position; the values are the same.
 #include "bits_device.h"
 
 namespace nrphy {
@@ -21,86 +21,215 @@ namespace nrphy {
 constexpr int LLR_MAX_V = 120;
 constexpr int LLR_INF_V = 127;
 
-__device__ __forceinline__ bool llr_isinf(int v)
+// ---- LLR arithmetic -------------------------------------------------------------------------------------------------
+// The check-to-variable magnitudes are finite by construction: the two minima start at LLR_MAX and only shrink
+// (ldpc_decoder_generic.cpp:88-107), and the scaling factor is below one.  With a finite message c the rules of
+// log_likelihood_ratio.cpp:37-87 reduce to: "a - c" clamps to +-LLR_MAX unless the soft bit a is infinite, which then
+// stays; "c + v" promotes a sum beyond +-LLR_MAX to infinity, and an infinite v stays (the "a == -b gives 0" case is
+// what the plain sum yields anyway).  Infinite soft bits are kept as exactly +-LLR_INFTY (normalised on load; any value
+// beyond +-LLR_MAX behaves the same in every rule, and only hard bits leave the kernel).  Everything is written with
+// median / min / max / bit-field operations: no compare-and-select pairs, which cost wait states on gfx950.
+__device__ __forceinline__ int med3(int x, int lo, int hi)
 {
-  return v > LLR_MAX_V || v < -LLR_MAX_V;
+  return max(lo, min(x, hi)); // v_med3_i32
+}
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
-// Saturating (PROMOTE = false) or promoting (PROMOTE = true) LLR sum.
-template <bool PROMOTE>
-__device__ __forceinline__ int llr_sum(int a, int b)
+// Variable-to-check message a - c.  An infinite soft bit yields a value far beyond the finite range with the sign of
+// a (+-384 on top): never a minimum, the right sign, and llr_add_promote() turns it back into +-LLR_INFTY.
+__device__ __forceinline__ int llr_sub(int a, int c)
 {
-  if (a == -b) {
-    return 0;
-  }
-  if (llr_isinf(a)) {
-    return a;
-  }
-  if (llr_isinf(b)) {
-    return b;
-  }
-  const int r   = a + b;
-  const int top = PROMOTE ? LLR_INF_V : LLR_MAX_V;
-  return r > LLR_MAX_V ? top : (r < -LLR_MAX_V ? -top : r);
+  const int d   = med3(a - c, -LLR_MAX_V, LLR_MAX_V);
+  const int big = a - med3(a, -LLR_MAX_V - 1, LLR_MAX_V + 1); // 0, or +-6 for +-127
+  return (big << 6) + d;
+}
+// New soft bit c + v, promoting.
+__device__ __forceinline__ int llr_add_promote(int c, int v)
+{
+  const int r = c + v;
+  const int e = med3(r, -LLR_MAX_V - 1, LLR_MAX_V + 1), f = med3(r, -LLR_MAX_V, LLR_MAX_V);
+  return e + 6 * (e - f); // +-121 -> +-127
 }
 
-// c2v message of edge t at a position served by check record `rec` (lo: min1 | min2 << 8 | idx << 16, hi: signs).
-__device__ __forceinline__ int c2v_value(uint2 rec, uint32_t t)
+// Check record: lo = min1 | min2 << 8 | index of the minimum << 16 (scaled magnitudes, index 0xFF: none), hi = one sign
+// bit per edge, edge t of a degree-DEG check at bit DEG - 1 - t.
+template <uint32_t DEG>
+struct CheckMessages {
+  int      m1, m2;
+  uint32_t hot, signs;
+  __device__ __forceinline__ explicit CheckMessages(uint2 rec) :
+    m1((int)(rec.x & 0xFFu)), m2((int)((rec.x >> 8) & 0xFFu)), signs(rec.y)
+  {
+    const uint32_t idx = rec.x >> 16;
+    hot                = idx < 32u ? 1u << idx : 0u;
+  }
+  __device__ __forceinline__ int operator()(uint32_t t) const
+  {
+    const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)hot, t, 1);             // all ones on the minimum's edge
+    const int      mag = (int)((sel & (uint32_t)m2) | (~sel & (uint32_t)m1));         // v_bfi_b32
+    const int      sgn = __builtin_amdgcn_sbfe((int)signs, DEG - 1u - t, 1);          // 0 or -1
+    return (mag ^ sgn) - sgn;
+  }
+};
+
+// One lifted check of degree DEG: reads the soft bits of its neighbours, returns its new record, writes them back.
+// jm = j - Zc (wraps): min(j + shift, jm + shift) = (j + shift) mod Zc.
+template <uint32_t DEG>
+__device__ __forceinline__ uint2 process_check(int8_t* soft, const uint8_t* scaled, const NRPHY_CONSTANT uint32_t* edge,
+                                               uint32_t zc, uint32_t j, uint32_t jm, uint2 old_rec)
 {
-  const int m1 = (int)(int8_t)(rec.x & 0xFFu), m2 = (int)(int8_t)((rec.x >> 8) & 0xFFu);
-  const int v  = (t != ((rec.x >> 16) & 0xFFu)) ? m1 : m2;
-  return ((rec.y >> t) & 1u) ? -v : v;
+  uint32_t addr[DEG];
+  int      v[DEG];
+#pragma unroll
+  for (uint32_t t = 0; t != DEG; ++t) {
+    const uint32_t e = edge[t], shift = e & 0xFFFFu;
+    addr[t]          = (e >> 16) * zc + min(j + shift, jm + shift);
+  }
+#pragma unroll
+  for (uint32_t t = 0; t != DEG; ++t) {
+    v[t] = soft[addr[t]];
+  }
+  const CheckMessages<DEG> old(old_rec);
+  // two smallest magnitudes as keys (magnitude << 8 | edge): ties go to the earlier edge as in the reference's strict
+  // comparison; an untouched first key (index 0xFF) means both minima are LLR_MAX and the owner does not matter
+  uint32_t key1 = ((uint32_t)LLR_MAX_V << 8) | 0xFFu, key2 = key1, neg = 0;
+#pragma unroll
+  for (uint32_t t = 0; t != DEG; ++t) {
+    const int x = llr_sub(v[t], old(t));
+    v[t]        = x;
+    const uint32_t key = ((uint32_t)max(x, -x) << 8) | t;
+    key2               = med3_u32(key, key1, key2);
+    key1               = min(key, key1);
+    neg                = __builtin_amdgcn_alignbit(neg, (uint32_t)x, 31); // neg << 1 | sign
+  }
+  // scale_llr (ldpc_decoder_generic.cpp:69-79) through the table of round(m * scaling_factor)
+  const uint32_t s1    = scaled[key1 >> 8], s2 = scaled[key2 >> 8];
+  const uint32_t signs = (__popc(neg) & 1u) ? (neg ^ ((1u << DEG) - 1u)) : neg;
+  const uint2    mine  = make_uint2(s1 | (s2 << 8) | ((key1 & 0xFFu) << 16), signs);
+  const CheckMessages<DEG> now(mine);
+#pragma unroll
+  for (uint32_t t = 0; t != DEG; ++t) {
+    soft[addr[t]] = (int8_t)llr_add_promote(now(t), v[t]);
+  }
+  return mine;
 }
 
-__global__ __launch_bounds__(384) void ldpc_decode_kernel(LdpcDecodeLaunch p)
+// One soft bit as it enters the decoder (ldpc_decoder_impl.cpp:128-164): whole nodes are clamped to +-64, the tail
+// is taken as is (infinities normalised, see above).
+__device__ __forceinline__ int load_soft(int v, bool whole_node)
+{
+  const int t = v > LLR_MAX_V ? LLR_INF_V : (v < -LLR_MAX_V ? -LLR_INF_V : v);
+  return whole_node ? med3(v, -64, 64) : t;
+}
+
+// Hard bits [32 w, 32 w + 32) of the soft bits (MSB first); zero_seen: an undecided one among the first `limit`.
+__device__ __forceinline__ uint32_t hard_word(const int8_t* soft, uint32_t w, uint32_t limit, bool& zero_seen)
+{
+  const uint4    lo = *reinterpret_cast<const uint4*>(soft + 32u * w);
+  const uint4    hi = *reinterpret_cast<const uint4*>(soft + 32u * w + 16u);
+  const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t       word = 0, zeros = 0;
+#pragma unroll
+  for (uint32_t i = 0; i != 32; ++i) {
+    const int v = (int)(int8_t)(x[i >> 2] >> (8u * (i & 3u)));
+    word |= (v <= 0 ? 1u : 0u) << (31u - i);
+    zeros |= (v == 0 ? 1u : 0u) << (31u - i);
+  }
+  const uint32_t valid = limit > 32u * w ? topmask(limit - 32u * w < 32u ? limit - 32u * w : 32u) : 0u;
+  zero_seen |= (zeros & valid) != 0;
+  return word;
+}
+
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5))) void ldpc_decode_kernel(LdpcDecodeLaunch p)
 {
   extern __shared__ __attribute__((aligned(16))) int8_t dec_lds[];
-  const uint32_t zc = p.zc, j = threadIdx.x;
-  const uint32_t n_hr = p.bg_k + 4u;
-  int8_t*        soft = dec_lds;                                 // [n_nodes][zc]
-  int8_t*        v2c  = dec_lds + (size_t)p.nof_nodes * zc;      // [n_hr + 1][zc]
-  uint32_t*      crcw = reinterpret_cast<uint32_t*>(v2c + (size_t)(n_hr + 1u) * zc + 16u); // packed hard bits
-  crcw                = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(crcw) + 15u) & ~(uintptr_t)15u);
   __shared__ uint32_t s_flag[4];
+  __shared__ uint8_t  s_scaled[128];
+  const uint32_t zc = p.zc, j = threadIdx.x;
+  int8_t*        soft = dec_lds; // [nof_nodes][zc] (+ 32 bytes of slack for the word reads of the last hard bits)
 
-  const auto*   graph = to_constant(p.graph); // wave-uniform reads: scalar loads
-  const int8_t* llr = p.llr + (size_t)blockIdx.x * p.llr_stride;
-  uint2*        rec = p.scratch + (size_t)blockIdx.x * p.nof_layers_max * zc;
+  const auto*   graph  = to_constant(p.graph); // wave-uniform reads: scalar loads
+  const int8_t* llr    = p.llr + (size_t)blockIdx.x * p.llr_stride;
+  uint2*        rec    = p.scratch + (size_t)blockIdx.x * p.nof_layers_max * zc;
   const bool    active = j < zc;
 
-  // load_soft_bits (ldpc_decoder_impl.cpp:128-164): two punctured nodes, whole nodes clamped to +-64, the tail as is.
-  // The last non-zero soft bit decides how many layers take part (:88-116).
-  uint32_t last_nz = 0;
-  if (active) {
-    const uint32_t full = p.nof_llr / zc;
-    for (uint32_t n = 0; n != p.nof_nodes; ++n) {
-      int v = 0;
-      if (n >= 2u) {
-        const uint32_t i = (n - 2u) * zc + j;
-        if (i < p.nof_llr) {
-          v = llr[i];
-          if (v != 0) {
-            last_nz = i + 1u;
-          }
-          if (n - 2u < full) {
-            v = v > 64 ? 64 : (v < -64 ? -64 : v);
-          }
-        }
+  // load_soft_bits (ldpc_decoder_impl.cpp:128-164): two punctured nodes, then the input.  The last non-zero soft bit
+  // decides how many layers take part (:88-116).
+  uint32_t       last_nz   = 0;
+  const uint32_t T         = blockDim.x;
+  const uint32_t clamp_end = (p.nof_llr / zc) * zc; // whole nodes
+  const uint32_t lds_bytes = p.nof_nodes * zc + 48u;
+  for (uint32_t i = j; i < 2u * zc; i += T) {
+    soft[i] = 0;
+  }
+  for (uint32_t i = 2u * zc + p.nof_llr + j; i < lds_bytes; i += T) {
+    soft[i] = 0;
+  }
+  if (((reinterpret_cast<uintptr_t>(llr) | zc) & 3u) == 0) {
+    // four soft bits per lane and load
+    const uint32_t  nd  = p.nof_llr >> 2;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(llr);
+    uint32_t*       dst = reinterpret_cast<uint32_t*>(soft + 2u * zc);
+#pragma unroll 4
+    for (uint32_t d = j; d < nd; d += T) {
+      const uint32_t x = src[d];
+      if (x != 0) {
+        last_nz = max(last_nz, 4u * d + 4u - ((uint32_t)__clz(x) >> 3));
       }
-      soft[n * zc + j] = (int8_t)v;
+      uint32_t y = 0;
+#pragma unroll
+      for (uint32_t b = 0; b != 4; ++b) {
+        const int v = load_soft((int)(int8_t)(x >> (8u * b)), 4u * d + b < clamp_end);
+        y |= ((uint32_t)v & 0xFFu) << (8u * b);
+      }
+      dst[d] = y;
     }
+    const uint32_t i = 4u * nd + j;
+    if (i < p.nof_llr) {
+      const int v = llr[i];
+      last_nz     = v != 0 ? max(last_nz, i + 1u) : last_nz;
+      soft[2u * zc + i] = (int8_t)load_soft(v, i < clamp_end);
+    }
+  } else {
+#pragma unroll 4
+    for (uint32_t i = j; i < p.nof_llr; i += T) {
+      const int v = llr[i];
+      last_nz     = v != 0 ? max(last_nz, i + 1u) : last_nz;
+      soft[2u * zc + i] = (int8_t)load_soft(v, i < clamp_end);
+    }
+  }
+  if (j <= (uint32_t)LLR_MAX_V) {
+    s_scaled[j] = (uint8_t)roundf((float)j * p.scaling_factor); // rounded half away from zero
   }
   if (j < 4) {
     s_flag[j] = 0;
   }
   __syncthreads();
-  if (active && last_nz != 0) {
+  if (last_nz != 0) {
     atomicMax(&s_flag[0], last_nz);
   }
   __syncthreads();
   const uint32_t input_size = s_flag[0];
   const uint32_t K          = p.bg_k * zc;
+  const uint32_t nw_k       = (K + 31u) >> 5;
   uint32_t       iterations = 0;
+
+  // Early stop: the message is a multiple of the generator polynomial.  Thread w owns hard-bit word w; its weight
+  // x^(bits after the word) mod g comes from the host.
+  const CrcPoly  crc    = {p.crc_poly, p.crc_order};
+  const uint32_t n_msg  = K - p.nof_filler;
+  uint32_t       w_bits = 0, w_factor = 0;
+  if (p.crc_order != 0 && 32u * j < n_msg) {
+    w_bits   = n_msg - 32u * j < 32u ? n_msg - 32u * j : 32u;
+    w_factor = p.crc_weight[j];
+  }
+  const uint32_t jm = j - zc;
+
   if (input_size != 0) { // workgroup-uniform
     uint32_t cb_len = input_size + 2u * zc;
     cb_len          = cb_len < K + 4u * zc ? K + 4u * zc : cb_len;
@@ -108,135 +237,78 @@ __global__ __launch_bounds__(384) void ldpc_decode_kernel(LdpcDecodeLaunch p)
     const uint32_t nof_layers = cb_len / zc - p.bg_k;
 
     for (uint32_t it = 0; it != p.max_iterations && iterations == 0; ++it) {
+      uint2 next = make_uint2(0, 0);
+      if (it != 0 && active) {
+        next = rec[j];
+      }
       for (uint32_t m = 0; m != nof_layers; ++m) {
         const uint32_t e0 = graph->row_ptr[m], deg = graph->row_ptr[m + 1u] - e0;
-        uint2*         layer_rec = rec + (size_t)m * zc;
-        // 1. variable-to-check messages
-        if (active) {
-          for (uint32_t t = 0; t != deg; ++t) {
-            const uint32_t edge = graph->edge[e0 + t], var = edge >> 16, shift = edge & 0xFFFFu;
-            const uint32_t slot = var < n_hr ? var : n_hr;
-            int            s    = soft[var * zc + j];
-            if (it != 0) {
-              uint32_t k = j + zc - shift;
-              k          = k >= zc ? k - zc : k;
-              s          = llr_sum<false>(s, -c2v_value(layer_rec[k], t));
-            }
-            v2c[slot * zc + j] = (int8_t)s;
-          }
+        const uint2    old = next;
+        if (it != 0 && active && m + 1u != nof_layers) {
+          next = rec[(size_t)(m + 1u) * zc + j];
         }
-        __syncthreads();
-        // 2. two smallest magnitudes, their owner, the sign product; the record of check j
-        uint2 mine = make_uint2(0, 0);
         if (active) {
-          int      min1 = LLR_MAX_V, min2 = LLR_MAX_V;
-          uint32_t idx = 0, neg = 0;
-          for (uint32_t t = 0; t != deg; ++t) {
-            const uint32_t edge = graph->edge[e0 + t], var = edge >> 16, shift = edge & 0xFFFFu;
-            const uint32_t slot = var < n_hr ? var : n_hr;
-            uint32_t       k    = j + shift;
-            k                   = k >= zc ? k - zc : k;
-            const int  v        = v2c[slot * zc + k];
-            const int  a        = v < 0 ? -v : v;
-            const bool is_min   = a < min1;
-            const int  new2     = is_min ? min1 : a;
-            min2                = (a < min2) ? new2 : min2;
-            idx                 = is_min ? t : idx;
-            min1                = is_min ? a : min1;
-            neg |= (v < 0 ? 1u : 0u) << t;
+          const auto* edge = graph->edge + e0;
+                    uint2       mine;
+          switch (deg) { // every row degree of the two base graphs
+            case 3: mine = process_check<3>(soft, s_scaled, edge, zc, j, jm, old); break;
+            case 4: mine = process_check<4>(soft, s_scaled, edge, zc, j, jm, old); break;
+            case 5: mine = process_check<5>(soft, s_scaled, edge, zc, j, jm, old); break;
+            case 6: mine = process_check<6>(soft, s_scaled, edge, zc, j, jm, old); break;
+            case 7: mine = process_check<7>(soft, s_scaled, edge, zc, j, jm, old); break;
+            case 8: mine = process_check<8>(soft, s_scaled, edge, zc, j, jm, old); break;
+            case 9: mine = process_check<9>(soft, s_scaled, edge, zc, j, jm, old); break;
+            case 10: mine = process_check<10>(soft, s_scaled, edge, zc, j, jm, old); break;
+            default: mine = process_check<19>(soft, s_scaled, edge, zc, j, jm, old); break;
           }
-          // scale_llr (ldpc_decoder_generic.cpp:69-79): infinities pass, the rest is rounded half away from zero
-          const int s1 = llr_isinf(min1) ? min1 : (int)roundf((float)min1 * p.scaling_factor);
-          const int s2 = llr_isinf(min2) ? min2 : (int)roundf((float)min2 * p.scaling_factor);
-          // sign of the message on edge t = product of all signs x the sign of that edge's own input
-          const uint32_t all = (deg >= 32u) ? 0xFFFFFFFFu : ((1u << deg) - 1u);
-          const uint32_t signs = (__popc(neg) & 1u) ? (neg ^ all) : neg;
-          mine = make_uint2((uint32_t)(s1 & 0xFF) | ((uint32_t)(s2 & 0xFF) << 8) | (idx << 16), signs);
-          layer_rec[j] = mine;
+          rec[(size_t)m * zc + j] = mine;
         }
-        __threadfence_block();
-        __syncthreads();
-        // 3. soft bits
-        if (active) {
-          for (uint32_t t = 0; t != deg; ++t) {
-            const uint32_t edge = graph->edge[e0 + t], var = edge >> 16, shift = edge & 0xFFFFu;
-            const uint32_t slot = var < n_hr ? var : n_hr;
-            uint32_t       k    = j + zc - shift;
-            k                   = k >= zc ? k - zc : k;
-            const int c         = c2v_value(layer_rec[k], t);
-            soft[var * zc + j]  = (int8_t)llr_sum<true>(c, (int)v2c[slot * zc + j]);
-          }
-        }
+        lds_barrier();
       }
       // Early stop (ldpc_decoder_impl.cpp:118-126): every hard bit decided and the CRC of the significant bits zero.
       if (p.crc_order != 0) {
-        __syncthreads();
         if (j < 2) {
           s_flag[1 + j] = 0;
         }
-        __syncthreads();
-        const uint32_t n   = K - p.nof_filler;
-        const uint32_t pad = (32u - (n & 31u)) & 31u, nw = (n + pad) >> 5;
-        bool           zero_seen = false;
-        for (uint32_t w = j; w < nw; w += blockDim.x) { // word w holds message bits [32 w - pad, 32 w - pad + 32)
-          uint32_t word = 0;
-          for (uint32_t b = 0; b != 32; ++b) {
-            const int32_t i = (int32_t)(32u * w + b) - (int32_t)pad;
-            if (i >= 0) {
-              const int s = soft[i];
-              zero_seen |= s == 0;
-              word |= (s <= 0 ? 1u : 0u) << (31u - b);
-            }
+        lds_barrier();
+        bool     zero_seen = false;
+        uint32_t part      = 0;
+        if (j < nw_k) {
+          const uint32_t word = hard_word(soft, j, K, zero_seen);
+          if (w_bits != 0) {
+            part = crc_mulmod32(w_factor, word >> (32u - w_bits), crc);
           }
-          crcw[w] = word;
         }
-        // zeros among the filler bits count too (get_hard_bits looks at all Kb * Zc soft bits)
-        for (uint32_t i = n + j; i < K; i += blockDim.x) {
-          zero_seen |= soft[i] == 0;
+        for (int o = WAVE / 2; o != 0; o >>= 1) {
+          part ^= __shfl_xor(part, o);
+        }
+        if ((j & (WAVE - 1)) == 0 && part != 0) {
+          atomicXor(&s_flag[2], part);
         }
         if (zero_seen) {
           atomicOr(&s_flag[1], 1u);
         }
-        __syncthreads();
-        if (j < WAVE) { // the first wavefront divides the packed message by the generator polynomial
-          const CrcPoly c   = {p.crc_poly, p.crc_order};
-          uint32_t      reg = 0;
-          if (j == 0) {
-            const uint32_t mask = (1u << c.order) - 1u, top = 1u << c.order;
-            for (uint32_t w = 0; w != nw; ++w) {
-              const uint32_t word = crcw[w];
-              for (int b = 31; b >= 0; --b) {
-                reg = (reg << 1) | ((word >> b) & 1u);
-                if (reg & top) {
-                  reg ^= c.poly;
-                }
-              }
-            }
-            reg &= mask;
-            s_flag[2] = reg;
-          }
-        }
-        __syncthreads();
+        lds_barrier();
         if (s_flag[1] == 0 && s_flag[2] == 0) {
           iterations = it + 1u;
         }
+        lds_barrier(); // the flags are cleared again at the top of the next check
       }
     }
-  } else if (p.crc_order == 0 && active) {
-    // All-zero input and nobody to tell: every bit one (ldpc_decoder_impl.cpp:91-96); soft <= 0 yields exactly that.
   }
-  __syncthreads();
-  // Hard bits of the message, packed MSB first.
+  // Hard bits of the message, packed MSB first (all-zero input: soft <= 0 everywhere, every bit one as in
+  // ldpc_decoder_impl.cpp:91-96).
   uint8_t* out = p.out + (size_t)blockIdx.x * p.out_stride;
-  for (uint32_t byte = j; byte < (K + 7u) / 8u; byte += blockDim.x) {
-    uint32_t v = 0;
-    for (uint32_t b = 0; b != 8; ++b) {
-      const uint32_t i = 8u * byte + b;
-      if (i < K) {
-        v |= (soft[i] <= 0 ? 1u : 0u) << (7u - b);
+  if (j < nw_k) {
+    bool           unused = false;
+    const uint32_t word   = hard_word(soft, j, K, unused) & topmask(K - 32u * j < 32u ? K - 32u * j : 32u);
+    const uint32_t nbytes = (K + 7u) / 8u;
+#pragma unroll
+    for (uint32_t b = 0; b != 4; ++b) {
+      if (4u * j + b < nbytes) {
+        out[4u * j + b] = (uint8_t)(word >> (24u - 8u * b));
       }
     }
-    out[byte] = (uint8_t)v;
   }
   if (j == 0 && p.iterations) {
     p.iterations[blockIdx.x] = iterations;
@@ -245,8 +317,7 @@ __global__ __launch_bounds__(384) void ldpc_decode_kernel(LdpcDecodeLaunch p)
 
 size_t ldpc_decode_lds_bytes(const LdpcDecodeLaunch& p)
 {
-  const size_t K = (size_t)p.bg_k * p.zc;
-  return (size_t)p.nof_nodes * p.zc + (size_t)(p.bg_k + 5u) * p.zc + 32u + 4u * ((K + 31u) / 32u + 2u) + 16u;
+  return (((size_t)p.nof_nodes * p.zc + 15u) & ~(size_t)15u) + 48u;
 }
 
 hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStream_t stream)

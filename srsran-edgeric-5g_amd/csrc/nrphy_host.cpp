@@ -374,6 +374,7 @@ struct nrphy_ctx {
   uint32_t*    d_x1     = nullptr;
   float2*      d_twiddle[10] = {}; // one table per supported DFT size (twiddle_slot)
   DecoderGraph* d_dec_graph[NOF_GRAPHS] = {}; // decoder graphs, built on first use
+  std::map<uint64_t, uint32_t*> d_dec_crc;     // early-stop CRC weights per (polynomial, message length)
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
   // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
   std::mutex host_mutex;
@@ -778,6 +779,9 @@ extern "C" int nrphy_destroy(nrphy_ctx_t* ctx)
   }
   for (DecoderGraph* g : ctx->d_dec_graph) {
     (void)hipFree(g);
+  }
+  for (auto& kv : ctx->d_dec_crc) {
+    (void)hipFree(kv.second);
   }
   (void)hipFree(ctx->d_x1);
   for (float2* t : ctx->d_twiddle) {
@@ -1594,11 +1598,42 @@ const DecoderGraph* get_decoder_graph(nrphy_ctx* ctx, unsigned bg, unsigned zc)
     for (unsigned m = rows; m != MAX_BG_ROWS + 2; ++m) {
       g[0].row_ptr[m] = (uint16_t)count;
     }
+    for (unsigned m = 0; m != rows; ++m) {
+      // the kernel is specialised for the row degrees the two base graphs have
+      const unsigned deg = g[0].row_ptr[m + 1] - g[0].row_ptr[m];
+      if (!((deg >= 3 && deg <= 10) || deg == 19)) {
+        return nullptr;
+      }
+    }
     if (upload(&ctx->d_dec_graph[slot], g.data(), sizeof(DecoderGraph)) != hipSuccess) {
       return nullptr;
     }
   }
   return ctx->d_dec_graph[slot];
+}
+
+// Early-stop weights: word w of the n-bit message (32 bits, the last one n mod 32) is followed by n - 32 w - bits(w)
+// bits; the message is a multiple of the generator g iff the sum of word(w) * x^(that) vanishes mod g.
+const uint32_t* get_decoder_crc_weights(nrphy_ctx* ctx, uint32_t poly, uint32_t order, uint32_t n_msg)
+{
+  const uint64_t key = ((uint64_t)poly << 32) | n_msg;
+  auto           it  = ctx->d_dec_crc.find(key);
+  if (it != ctx->d_dec_crc.end()) {
+    return it->second;
+  }
+  const CrcField        field = {poly, order};
+  const uint32_t        nw    = (n_msg + 31) / 32;
+  std::vector<uint32_t> w(nw);
+  for (uint32_t i = 0; i != nw; ++i) {
+    const uint32_t bits = std::min<uint32_t>(32, n_msg - 32 * i);
+    w[i]                = field.xpow((int64_t)n_msg - 32 * i - bits);
+  }
+  uint32_t* d = nullptr;
+  if (upload(&d, w.data(), nw * sizeof(uint32_t)) != hipSuccess) {
+    return nullptr;
+  }
+  ctx->d_dec_crc[key] = d;
+  return d;
 }
 
 } // namespace
@@ -1622,7 +1657,10 @@ extern "C" int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_
   }
   HIP_TRY(hipSetDevice(ctx->device));
   LdpcDecodeLaunch p;
-  p.graph = get_decoder_graph(ctx, cfg->base_graph, zc);
+  {
+    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    p.graph = get_decoder_graph(ctx, cfg->base_graph, zc);
+  }
   if (p.graph == nullptr) {
     return NRPHY_ERR_DEVICE;
   }
@@ -1641,12 +1679,16 @@ extern "C" int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_
   p.llr            = d_llr;
   p.out            = d_out;
   p.iterations     = d_iterations;
+  p.crc_weight     = nullptr;
   {
     // Check records: context-owned, grow-only (a first call with a larger batch allocates; not stream-ordered).
     std::lock_guard<std::mutex> lock(ctx->host_mutex);
     p.scratch = (uint2*)ctx_scratch(ctx, SCRATCH_DECODER, (size_t)n_cb * p.nof_layers_max * zc * sizeof(uint2));
+    if (p.crc_order != 0) {
+      p.crc_weight = get_decoder_crc_weights(ctx, p.crc_poly, p.crc_order, K - cfg->nof_filler_bits);
+    }
   }
-  if (p.scratch == nullptr) {
+  if (p.scratch == nullptr || (p.crc_order != 0 && p.crc_weight == nullptr)) {
     return NRPHY_ERR_DEVICE;
   }
   HIP_TRY(launch_ldpc_decode(p, n_cb, stream ? (hipStream_t)stream : ctx->stream));

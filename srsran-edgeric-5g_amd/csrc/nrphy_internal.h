@@ -233,6 +233,7 @@ struct LdpcDecodeLaunch {
   uint2*              scratch;    // per codeblock: nof_layers_max * Zc check records of 8 bytes
   uint8_t*            out;        // per codeblock: Kb * Zc hard bits, packed MSB first
   uint32_t*           iterations; // per codeblock: iterations until the CRC passed, 0 = it did not (may be null)
+  const uint32_t*     crc_weight; // per 32-bit word of the message: x^(bits after the word) mod the CRC polynomial
   uint32_t            zc, bg_k, nof_nodes, nof_layers_max;
   uint32_t            nof_llr, llr_stride, out_stride, nof_filler;
   uint32_t            crc_poly, crc_order; // order 0: no early stop
