@@ -1155,6 +1155,95 @@ static int llr_promotion_sum(int a, int b) /* beyond the range the bit becomes c
   return r > LLR_MAX_VALUE ? LLR_INF_VALUE : (r < -LLR_MAX_VALUE ? -LLR_INF_VALUE : r);
 }
 
+/* ---- LDPC rate dematcher ("next" row, receive side) ----------------------------------------------------------------
+ * ldpc_rate_dematcher_impl::rate_dematch (R/lib/phy/upper/channel_coding/ldpc/ldpc_rate_dematcher_impl.cpp:43-103):
+ * undo the bit interleaver (:202-256), then walk the circular buffer from k0 the way the rate matcher read it
+ * (allot_llrs, :118-200), skipping the filler bits, wrapping at the (Nref-limited) buffer length.  With new data the
+ * first visit of a position copies, every later visit adds with the saturating LLR sum; without, every visit adds to
+ * what the soft buffer held.  Filler bits become +infinity (new data only).
+ *
+ * The walk below keeps the reference's order of operations including what it leaves untouched: with new data it
+ * clears [0, k0) of the systematic part, the stretch after the last written position only when the input ended
+ * before the first wrap -- and then counted from the END of the full-length block (which differs from "the rest of
+ * the buffer" when Nref shortens it) -- and nothing between the systematic part and a k0 beyond it.  Whatever is not
+ * mentioned keeps its old content, so out is an in/out argument in every mode. */
+int oracle_ldpc_rate_dematch(uint32_t bg, uint32_t zc, uint32_t rv, uint32_t qm, uint32_t nref, uint32_t nof_filler,
+                             int new_data, const int8_t* in, uint32_t e, int8_t* out)
+{
+  static const double shift_bg1[4] = {0, 17, 33, 56}, shift_bg2[4] = {0, 13, 25, 43};
+  const uint32_t      n_short = (bg == 1) ? 66 : 50, bg_k = (bg == 1) ? 22 : 10;
+  const uint32_t      block_length = n_short * zc;
+  const uint32_t      buffer_length = (nref > 0 && nref < block_length) ? nref : block_length;
+  const uint32_t      nof_systematic = (bg_k - 2) * zc;
+  if (rv > 3 || qm == 0 || e % qm != 0 || nof_filler >= nof_systematic || buffer_length <= nof_systematic) {
+    return -1;
+  }
+  const uint32_t nof_info = nof_systematic - nof_filler;
+  const double   frac     = (((bg == 1) ? shift_bg1 : shift_bg2)[rv] * buffer_length) / block_length;
+  const uint32_t k0       = (uint32_t)((uint16_t)floor(frac)) * zc;
+
+  /* deinterleave: row j of the Qm x (E / Qm) table is the j-th bit of every symbol */
+  int8_t* seq = (int8_t*)malloc(e ? e : 1);
+  if (qm == 1) {
+    memcpy(seq, in, e);
+  } else {
+    const uint32_t cols = e / qm;
+    for (uint32_t i = 0; i != cols; ++i) {
+      for (uint32_t j = 0; j != qm; ++j) {
+        seq[cols * j + i] = in[i * qm + j];
+      }
+    }
+  }
+
+  int      copying = new_data != 0;
+  uint32_t pos = k0, taken = 0;
+  while (taken != e) {
+    uint32_t left = e - taken;
+    if (pos < nof_info) { /* information bits up to the first filler bit */
+      uint32_t n = nof_info - pos < left ? nof_info - pos : left;
+      if (copying) {
+        memset(out, 0, pos);
+        memcpy(out + pos, seq + taken, n);
+      } else {
+        for (uint32_t i = 0; i != n; ++i) {
+          out[pos + i] = (int8_t)llr_add(seq[taken + i], out[pos + i]); /* operator+ adds the left operand to the right */
+        }
+      }
+      pos += n;
+      taken += n;
+      left -= n;
+    } else if (copying) {
+      memset(out, 0, nof_info);
+    }
+    if (copying) {
+      memset(out + nof_info, LLR_INF_VALUE, nof_filler);
+    }
+    if (pos < nof_systematic) {
+      pos = nof_systematic;
+    }
+    { /* parity bits up to the end of the buffer */
+      uint32_t n = buffer_length - pos < left ? buffer_length - pos : left;
+      if (copying) {
+        memcpy(out + pos, seq + taken, n);
+      } else {
+        for (uint32_t i = 0; i != n; ++i) {
+          out[pos + i] = (int8_t)llr_add(seq[taken + i], out[pos + i]); /* operator+ adds the left operand to the right */
+        }
+      }
+      pos = (pos + n) % buffer_length;
+      taken += n;
+    }
+    if (taken != e) {
+      copying = 0; /* after the first wrap everything is combined */
+    }
+  }
+  if (copying && pos != 0) {
+    memset(out + block_length - (buffer_length - pos), 0, buffer_length - pos);
+  }
+  free(seq);
+  return 0;
+}
+
 int oracle_ldpc_decode(uint32_t bg, uint32_t zc, uint32_t nof_filler, uint32_t crc_poly_id, uint32_t max_iterations,
                        float scaling_factor, const int8_t* llr, uint32_t nof_llr, uint8_t* message_bits)
 {

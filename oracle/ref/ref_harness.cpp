@@ -21,6 +21,8 @@
 #include "lib/phy/upper/channel_coding/ldpc/ldpc_encoder_generic.h"
 #include "lib/phy/upper/channel_coding/ldpc/ldpc_graph_impl.h"
 #include "lib/phy/upper/channel_coding/ldpc/ldpc_luts_impl.h"
+#include "lib/phy/upper/channel_coding/ldpc/ldpc_rate_dematcher_avx2_impl.h"
+#include "lib/phy/upper/channel_coding/ldpc/ldpc_rate_dematcher_impl.h"
 #include "lib/phy/upper/channel_coding/ldpc/ldpc_rate_matcher_impl.h"
 #include "lib/phy/upper/channel_coding/ldpc/ldpc_segmenter_impl.h"
 #include "lib/phy/upper/channel_modulation/modulation_mapper_lut_impl.h"
@@ -631,6 +633,48 @@ int ref_ldpc_decode(uint32_t      bg,
     message_bits[i] = out.extract(i, 1);
   }
   return r.has_value() ? static_cast<int>(r.value()) : 0;
+}
+
+// ldpc_rate_dematcher::rate_dematch (generic or AVX2 implementation) of one codeblock.  out: the soft buffer of
+// block_length = N - 2*Zc LLRs, read and written (HARQ combining unless new_data); in: E rate-matched LLRs.
+int ref_ldpc_rate_dematch(uint32_t      bg,
+                          uint32_t      zc,
+                          uint32_t      rv,
+                          uint32_t      qm,
+                          uint32_t      nref,
+                          uint32_t      nof_filler,
+                          int           new_data,
+                          const int8_t* in,
+                          uint32_t      e,
+                          int8_t*       out,
+                          int           simd)
+{
+  std::unique_ptr<ldpc_rate_dematcher> dm;
+  if (simd) {
+    dm = std::make_unique<ldpc_rate_dematcher_avx2_impl>();
+  } else {
+    dm = std::make_unique<ldpc_rate_dematcher_impl>();
+  }
+  codeblock_metadata cfg         = {};
+  cfg.tb_common.base_graph       = (bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+  cfg.tb_common.lifting_size     = static_cast<ldpc::lifting_size_t>(zc);
+  cfg.tb_common.rv               = rv;
+  cfg.tb_common.mod              = to_mod(qm);
+  cfg.tb_common.Nref             = nref;
+  cfg.cb_specific.nof_filler_bits = nof_filler;
+  unsigned                          block_length = ((bg == 1) ? 66 : 50) * zc;
+  std::vector<log_likelihood_ratio> vin(e), vout(block_length);
+  for (unsigned i = 0; i != e; ++i) {
+    vin[i] = log_likelihood_ratio(in[i]);
+  }
+  for (unsigned i = 0; i != block_length; ++i) {
+    vout[i] = log_likelihood_ratio(out[i]);
+  }
+  dm->rate_dematch(vout, vin, new_data != 0, cfg);
+  for (unsigned i = 0; i != block_length; ++i) {
+    out[i] = static_cast<int8_t>(vout[i].to_int());
+  }
+  return 0;
 }
 
 // ofdm_slot_demodulator::demodulate of every port of one slot: iq_in [nof_ports][slot_size] complex float ->

@@ -239,6 +239,20 @@ class CpuBackend:
             args.append(C.c_int(simd))
         return int(f(*args)), bits
 
+    def ldpc_rate_dematch(self, bg, zc, rv, qm, nref, nof_filler, new_data, llr_in, soft_buffer, simd=0):
+        """ldpc_rate_dematcher::rate_dematch: returns the updated soft buffer ((66 or 50) * Zc int8, copy)."""
+        llr_in = np.ascontiguousarray(llr_in, dtype=np.int8)
+        out = np.array(soft_buffer, dtype=np.int8, copy=True)
+        assert out.size == (66 if bg == 1 else 50) * zc
+        args = [C.c_uint32(bg), C.c_uint32(zc), C.c_uint32(rv), C.c_uint32(qm), C.c_uint32(nref),
+                C.c_uint32(nof_filler), C.c_int(int(new_data)), _ptr(llr_in), C.c_uint32(llr_in.size), _ptr(out)]
+        if self.is_ref:
+            args.append(C.c_int(simd))
+        f = self._f("ldpc_rate_dematch")
+        f.restype = C.c_int
+        assert f(*args) == 0
+        return out
+
     def ofdm_demod_slot(self, cfg, iq, slot_index=0, window_offset=0):
         """iq: [nof_ports][slot_size] complex64 -> grid [nof_ports][14][12*bw_rb][2] uint16 (raw bf16)."""
         iq = np.ascontiguousarray(iq, dtype=np.complex64)

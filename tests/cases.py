@@ -122,3 +122,20 @@ def ldpc_decode_nof_llr(case):
     bg, zc, extra, tail = case[:4]
     kb = 22 if bg == 1 else 10
     return max(kb * zc + extra * zc + tail - 2 * zc, kb * zc + 2 * zc)
+
+
+# ---- LDPC rate dematcher ("next" row) ------------------------------------------------------------------
+# (bg, zc, rm_length, rv, qm, nref, nof_filler).  The first 25 are the configurations of the reference's
+# ldpc_rate_matcher_test_data.h (BG1, Zc = 14, N = 924, N_ref = 700 when limited-buffer rate matching is on); its
+# ldpc_rm_test.cpp runs the dematcher on each of them.  The rest are the shapes of BASELINE configs 1-4 and corner
+# cases: repetition (E > N), k0 beyond the systematic part, input ending inside the systematic part.
+_REF_RM = [(277, 0, 1, 0, 0), (554, 1, 2, 700, 28), (924, 2, 4, 0, 28), (4620, 3, 6, 0, 0), (9240, 0, 8, 700, 0),
+           (208, 1, 4, 700, 0), (420, 0, 6, 0, 12), (700, 3, 1, 700, 12), (3500, 2, 2, 700, 0), (7000, 1, 1, 0, 12),
+           (924, 0, 2, 0, 0), (3500, 0, 4, 700, 12), (696, 1, 8, 0, 12), (3500, 1, 1, 700, 0), (276, 2, 6, 700, 28),
+           (420, 2, 1, 700, 0), (9240, 2, 2, 0, 28), (210, 3, 2, 700, 0), (552, 3, 4, 0, 28), (7000, 3, 4, 700, 0),
+           (924, 1, 6, 0, 28), (6996, 1, 6, 700, 0), (272, 2, 8, 0, 28), (416, 3, 8, 700, 0), (4616, 0, 8, 0, 28)]
+LDPC_DEMATCH_CASES = [(1, 14, e, rv, qm, nref, nf) for e, rv, qm, nref, nf in _REF_RM] + [
+    (1, 384, 8992, 0, 8, 18432, 72), (1, 384, 8960, 0, 8, 0, 72), (1, 384, 9804, 2, 6, 0, 80),
+    (2, 144, 11232, 0, 2, 0, 104), (2, 352, 5000, 3, 4, 8000, 24), (1, 16, 2000, 1, 2, 0, 5),
+    (2, 7, 2304, 3, 2, 0, 30), (1, 384, 60, 0, 6, 0, 72), (1, 384, 30000, 3, 8, 0, 0), (2, 384, 19200, 1, 4, 0, 0),
+]

@@ -134,6 +134,43 @@ def test_oracle_ldpc_decoder_vs_reference(oracle, ref, case):
     assert ref.ldpc_decode(bg, zc, filler, crc_id, 8, 0.8, zero)[0] == 0
 
 
+@pytest.mark.parametrize("case", cases.LDPC_DEMATCH_CASES)
+def test_oracle_ldpc_rate_dematcher_vs_reference(oracle, ref, case):
+    """Rate dematcher against the compiled reference: new data and HARQ combining, arbitrary int8 soft bits (infinities
+    included) against the generic implementation bit for bit.  The reference's AVX2 implementation saturates an
+    infinite operand like a finite one, so it is compared on finite inputs only."""
+    bg, zc, e, rv, qm, nref, nf = case
+    rng = np.random.default_rng(e * 7 + rv)
+    n = (66 if bg == 1 else 50) * zc
+    for finite in (False, True):
+        lim = 120 if finite else 127
+        llr = rng.integers(-lim, lim + 1, e).astype(np.int8)
+        llr[rng.integers(0, e, e // 10)] = 0
+        old = rng.integers(-lim, lim + 1, n).astype(np.int8)
+        for new_data in (1, 0):
+            want = ref.ldpc_rate_dematch(bg, zc, rv, qm, nref, nf, new_data, llr, old, simd=0)
+            got = oracle.ldpc_rate_dematch(bg, zc, rv, qm, nref, nf, new_data, llr, old)
+            assert np.array_equal(got, want), (finite, new_data, int(np.count_nonzero(got != want)))
+            if finite:
+                avx = ref.ldpc_rate_dematch(bg, zc, rv, qm, nref, nf, new_data, llr, old, simd=1)
+                if new_data:
+                    # the filler bits are the only infinities the AVX2 path meets: it may only differ where a wrap adds to them
+                    nof_sys = ((22 if bg == 1 else 10) - 2) * zc
+                    keep = np.ones(n, bool)
+                    keep[nof_sys - nf:nof_sys] = False
+                    assert np.array_equal(avx[keep], want[keep])
+    # the reference's own test property (ldpc_rm_test.cpp:183-211): match -> LLR -> dematch -> hard -> match is the identity
+    cb = rng.integers(0, 2, n, dtype=np.uint8)
+    nof_sys = ((22 if bg == 1 else 10) - 2) * zc
+    cb[nof_sys - nf:nof_sys] = 0
+    matched = np.unpackbits(oracle.rate_match(bg, zc, rv, qm, nref, nf, np.packbits(cb), e))[:e]
+    soft = oracle.ldpc_rate_dematch(bg, zc, rv, qm, nref, nf, 1, (1 - 2 * matched.astype(np.int8)), np.zeros(n, np.int8))
+    hard = (soft < 0).astype(np.uint8)
+    again = np.unpackbits(oracle.rate_match(bg, zc, rv, qm, nref, nf, np.packbits(hard), e))[:e]
+    assert np.array_equal(again, matched)
+    assert np.all(soft[nof_sys - nf:nof_sys] == 127)
+
+
 def test_baseline_config_derived_values(oracle):
     """The derived sizes SURVEY.md section 8d lists for the BASELINE configs."""
     d = oracle.derive(cases.baseline_config(3)[0])
