@@ -253,6 +253,37 @@ int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, u
  * nof_ports x nrphy_ofdm_slot_size(cfg, slot_index) complex samples, port after port (blocking). */
 int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t slot_index, float* iq);
 
+/* ---- receive side ("next" row): LDPC rate dematcher --------------------------
+ * Replaces ldpc_rate_dematcher::rate_dematch (R/include/srsran/phy/upper/channel_coding/ldpc/
+ * ldpc_rate_dematcher.h; impl R/lib/phy/upper/channel_coding/ldpc/ldpc_rate_dematcher_impl.cpp:43-256):
+ * rm_length soft bits as received -> the codeblock's soft buffer of (66 or 50) * Zc int8 LLRs (the
+ * codeblock without its first 2*Zc bits), which the LDPC decoder reads.  new_data != 0: first
+ * transmission, the buffer is rebuilt (filler bits +infinity = 127, bits not received 0); otherwise the
+ * soft bits are added to what the buffer holds (HARQ combining, saturating LLR sum).  The fields are
+ * those of codeblock_metadata the reference reads: tb_common {base_graph, lifting_size, rv, mod (as bits
+ * per symbol, 1 = BPSK), Nref} and cb_specific.nof_filler_bits, plus the input length.  Results are
+ * those of the reference's generic implementation bit for bit, including which soft bits it leaves
+ * untouched (so the buffer is an in/out argument in both modes); its AVX2 implementation treats an
+ * infinite soft bit like a finite one when combining. */
+typedef struct nrphy_ldpc_rate_dematcher_cfg {
+  uint32_t base_graph;
+  uint32_t lifting_size;
+  uint32_t rv;
+  uint32_t qm;
+  uint32_t nref;
+  uint32_t nof_filler_bits;
+  uint32_t rm_length;
+} nrphy_ldpc_rate_dematcher_cfg_t;
+/* n_cb codeblocks that share the configuration: input i at d_in + i * in_stride_bytes, soft buffer i at
+ * d_soft + i * soft_stride_bytes.  NRPHY_ERR_CAPACITY: more repetition than the kernel's operation
+ * list holds (rm_length of many times the buffer length). */
+int nrphy_ldpc_rate_dematch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg, uint32_t n_cb,
+                            const int8_t* d_in, uint32_t in_stride_bytes, int8_t* d_soft, uint32_t soft_stride_bytes,
+                            int new_data, void* stream);
+/* Host-span form for one codeblock (blocking); soft_buffer is read and written. */
+int nrphy_ldpc_rate_dematch_host(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg, const int8_t* in,
+                                 int8_t* soft_buffer, int new_data);
+
 /* ---- receive side ("next" row): LDPC decoder ------------------------------
  * Replaces ldpc_decoder::decode (R/include/srsran/phy/upper/channel_coding/ldpc/ldpc_decoder.h;
  * impl R/lib/phy/upper/channel_coding/ldpc/ldpc_decoder_impl.cpp:60-126 with the message kernels of

@@ -95,6 +95,12 @@ class LdpcDecoderCfg(C.Structure):
                 ("scaling_factor", C.c_float)]
 
 
+class LdpcRateDematcherCfg(C.Structure):
+    """nrphy_ldpc_rate_dematcher_cfg_t (the codeblock_metadata fields the rate dematcher reads + input length)."""
+    _fields_ = [("base_graph", C.c_uint32), ("lifting_size", C.c_uint32), ("rv", C.c_uint32), ("qm", C.c_uint32),
+                ("nref", C.c_uint32), ("nof_filler_bits", C.c_uint32), ("rm_length", C.c_uint32)]
+
+
 class OfdmConfig(C.Structure):
     _fields_ = [
         ("numerology", C.c_uint32),
@@ -236,6 +242,8 @@ def declare(lib, prefix="nrphy_"):
     sig("ofdm_demodulate_symbol_host", i32, vp, vp, u32, u32, u32, vp)
     sig("ldpc_decode", i32, vp, P(LdpcDecoderCfg), u32, vp, u32, vp, u32, vp, vp)
     sig("ldpc_decode_host", i32, vp, P(LdpcDecoderCfg), vp, u8p, P(u32))
+    sig("ldpc_rate_dematch", i32, vp, P(LdpcRateDematcherCfg), u32, vp, u32, vp, u32, i32, vp)
+    sig("ldpc_rate_dematch_host", i32, vp, P(LdpcRateDematcherCfg), vp, vp, i32)
     return lib
 
 
@@ -250,5 +258,5 @@ ABI_SYMBOLS = [
     "nrphy_ofdm_plan_destroy", "nrphy_ofdm_plan_slot_stride", "nrphy_ofdm_run",
     "nrphy_ofdm_modulate_symbol_host", "nrphy_ofdm_modulate_slot_host", "nrphy_dft_run", "nrphy_dft_run_host",
     "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",
-    "nrphy_ldpc_decode", "nrphy_ldpc_decode_host",
+    "nrphy_ldpc_decode", "nrphy_ldpc_decode_host", "nrphy_ldpc_rate_dematch", "nrphy_ldpc_rate_dematch_host",
 ]

@@ -1571,6 +1571,135 @@ extern "C" int nrphy_pdsch_encode_host(nrphy_ctx_t* ctx, const nrphy_pdsch_encod
 
 namespace {
 
+// The walk of ldpc_rate_dematcher_impl::allot_llrs (ldpc_rate_dematcher_impl.cpp:118-200) over the soft buffer, with
+// the data taken out: which ranges it clears, fills, copies into and adds to, in its order.  Returns false when the
+// list does not fit (extreme repetition).
+bool build_dematch_ops(DematchLaunch& p, unsigned block_length, unsigned buffer_length, unsigned k0,
+                       unsigned nof_systematic, unsigned nof_filler, unsigned e, bool new_data)
+{
+  const unsigned nof_info = nof_systematic - nof_filler;
+  bool           copying  = new_data, ok = true;
+  unsigned       pos = k0, taken = 0;
+  p.n_ops = 0;
+  auto emit = [&](uint32_t kind, unsigned begin, unsigned count, unsigned src) {
+    if (count == 0) {
+      return;
+    }
+    if (p.n_ops == MAX_DEMATCH_OPS) {
+      ok = false;
+      return;
+    }
+    p.ops[p.n_ops++] = {kind, begin, count, src};
+  };
+  while (taken != e && ok) {
+    unsigned left = e - taken;
+    if (pos < nof_info) {
+      const unsigned n = std::min(nof_info - pos, left);
+      if (copying) {
+        emit(DEMATCH_ZERO, 0, pos, 0);
+      }
+      emit(copying ? DEMATCH_COPY : DEMATCH_COMBINE, pos, n, taken);
+      pos += n;
+      taken += n;
+      left -= n;
+    } else if (copying) {
+      emit(DEMATCH_ZERO, 0, nof_info, 0);
+    }
+    if (copying) {
+      emit(DEMATCH_FILL, nof_info, nof_filler, 0);
+    }
+    pos = std::max(pos, nof_systematic);
+    const unsigned n = std::min(buffer_length - pos, left);
+    emit(copying ? DEMATCH_COPY : DEMATCH_COMBINE, pos, n, taken);
+    pos = (pos + n) % buffer_length;
+    taken += n;
+    if (taken != e) {
+      copying = false;
+    }
+  }
+  if (copying && pos != 0) {
+    // the reference clears this many soft bits at the end of the full-length block, wherever the buffer ends
+    emit(DEMATCH_ZERO, block_length - (buffer_length - pos), buffer_length - pos, 0);
+  }
+  return ok;
+}
+
+} // namespace
+
+extern "C" int nrphy_ldpc_rate_dematch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg, uint32_t n_cb,
+                                       const int8_t* d_in, uint32_t in_stride_bytes, int8_t* d_soft,
+                                       uint32_t soft_stride_bytes, int new_data, void* stream)
+{
+  if (ctx == nullptr || cfg == nullptr || d_in == nullptr || d_soft == nullptr ||
+      (cfg->base_graph != 1 && cfg->base_graph != 2) || cfg->rv > 3 || lifting_position(cfg->lifting_size) < 0 ||
+      (cfg->qm != 1 && cfg->qm != 2 && cfg->qm != 4 && cfg->qm != 6 && cfg->qm != 8) || cfg->rm_length == 0 ||
+      cfg->rm_length % cfg->qm != 0) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  static const double shift_bg1[4] = {0, 17, 33, 56}, shift_bg2[4] = {0, 13, 25, 43};
+  const unsigned      zc = cfg->lifting_size, n_short = (cfg->base_graph == 1) ? 66 : 50;
+  const unsigned      block_length   = n_short * zc;
+  const unsigned      buffer_length  = (cfg->nref > 0 && cfg->nref < block_length) ? cfg->nref : block_length;
+  const unsigned      nof_systematic = (((cfg->base_graph == 1) ? 22 : 10) - 2) * zc;
+  if (cfg->nof_filler_bits >= nof_systematic || buffer_length <= nof_systematic || in_stride_bytes < cfg->rm_length ||
+      soft_stride_bytes < block_length) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  // ldpc_rate_dematcher_impl.cpp:94-95: k0 of TS 38.212 Table 5.4.2.1-2 in double precision
+  const double   frac = (((cfg->base_graph == 1) ? shift_bg1 : shift_bg2)[cfg->rv] * buffer_length) / block_length;
+  const unsigned k0   = (unsigned)((uint16_t)std::floor(frac)) * zc;
+  DematchLaunch  p;
+  if (!build_dematch_ops(p, block_length, buffer_length, k0, nof_systematic, cfg->nof_filler_bits, cfg->rm_length,
+                         new_data != 0)) {
+    return NRPHY_ERR_CAPACITY;
+  }
+  p.in           = d_in;
+  p.out          = d_soft;
+  p.in_stride    = in_stride_bytes;
+  p.out_stride   = soft_stride_bytes;
+  p.block_length = block_length;
+  p.qm           = cfg->qm;
+  p.cols         = cfg->rm_length / cfg->qm;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(launch_ldpc_dematch(p, n_cb, stream ? (hipStream_t)stream : ctx->stream));
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ldpc_rate_dematch_host(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg,
+                                            const int8_t* in, int8_t* soft_buffer, int new_data)
+{
+  if (ctx == nullptr || cfg == nullptr || in == nullptr || soft_buffer == nullptr ||
+      (cfg->base_graph != 1 && cfg->base_graph != 2)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const unsigned block_length = ((cfg->base_graph == 1) ? 66U : 50U) * cfg->lifting_size;
+  int8_t *       d_in = nullptr, *d_soft = nullptr;
+  int            rc = NRPHY_ERR_DEVICE;
+  do {
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&d_in, cfg->rm_length + 16) != hipSuccess ||
+        hipMalloc((void**)&d_soft, block_length + 16) != hipSuccess ||
+        hipMemcpy(d_in, in, cfg->rm_length, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_soft, soft_buffer, block_length, hipMemcpyHostToDevice) != hipSuccess) {
+      break;
+    }
+    rc = nrphy_ldpc_rate_dematch(ctx, cfg, 1, d_in, cfg->rm_length, d_soft, block_length, new_data, ctx->stream);
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(soft_buffer, d_soft, block_length, hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    rc = NRPHY_OK;
+  } while (false);
+  (void)hipFree(d_in);
+  (void)hipFree(d_soft);
+  return rc;
+}
+
+namespace {
+
 // Decoder graph of (base graph, lifting size): all edges of TS 38.212 Tables 5.3.2-2/-3, row by row.
 const DecoderGraph* get_decoder_graph(nrphy_ctx* ctx, unsigned bg, unsigned zc)
 {

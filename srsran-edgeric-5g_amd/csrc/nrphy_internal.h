@@ -242,6 +242,22 @@ struct LdpcDecodeLaunch {
 };
 hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStream_t stream);
 
+// ---- LDPC rate dematcher ("next" row, receive side) ---------------------------------------------------------------
+enum DematchKind : uint32_t { DEMATCH_ZERO = 0, DEMATCH_FILL, DEMATCH_COPY, DEMATCH_COMBINE };
+// One step of the reference's walk over the soft buffer: positions [begin, begin + count) are cleared, set to
+// +infinity, or take / add elements [src, src + count) of the deinterleaved input.
+struct DematchOp {
+  uint32_t kind, begin, count, src;
+};
+constexpr uint32_t MAX_DEMATCH_OPS = 60;
+struct DematchLaunch {
+  const int8_t* in;  // per codeblock: rm_length soft bits as received
+  int8_t*       out; // per codeblock: the soft buffer, block_length soft bits
+  uint32_t      in_stride, out_stride, block_length, qm, cols, n_ops;
+  DematchOp     ops[MAX_DEMATCH_OPS];
+};
+hipError_t launch_ldpc_dematch(const DematchLaunch& p, uint32_t n_cb, hipStream_t stream);
+
 // ---- OFDM ---------------------------------------------------------------------------------------------------
 struct OfdmLaunch {
   uint32_t       dft_size;

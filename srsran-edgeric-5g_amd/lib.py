@@ -110,6 +110,20 @@ class Context:
         _check(self.lib.nrphy_ldpc_encode(self.handle, base_graph, lifting_size, n_cb, _dptr(d_msg), msg_stride,
                                           out_bits, _dptr(d_out), out_stride, stream), "nrphy_ldpc_encode")
 
+    def ldpc_rate_dematch(self, cfg, n_cb, d_in, in_stride, d_soft, soft_stride, new_data, stream=None):
+        """ldpc_rate_dematcher::rate_dematch for n_cb codeblocks resident in HBM (cfg: abi.LdpcRateDematcherCfg)."""
+        _check(self.lib.nrphy_ldpc_rate_dematch(self.handle, C.byref(cfg), n_cb, _dptr(d_in), in_stride, _dptr(d_soft),
+                                                soft_stride, int(new_data), stream), "nrphy_ldpc_rate_dematch")
+
+    def ldpc_rate_dematch_host(self, base_graph, lifting_size, rv, qm, nref, nof_filler, new_data, llr_in, soft_buffer):
+        """ldpc_rate_dematcher::rate_dematch on host spans: returns the updated soft buffer (copy)."""
+        llr_in = np.ascontiguousarray(llr_in, dtype=np.int8)
+        out = np.array(soft_buffer, dtype=np.int8, copy=True)
+        cfg = abi.LdpcRateDematcherCfg(base_graph, lifting_size, rv, qm, nref, nof_filler, llr_in.size)
+        _check(self.lib.nrphy_ldpc_rate_dematch_host(self.handle, C.byref(cfg), llr_in.ctypes.data, out.ctypes.data,
+                                                     int(new_data)), "nrphy_ldpc_rate_dematch_host")
+        return out
+
     def ldpc_decode(self, cfg, n_cb, d_llr, llr_stride, d_out, out_stride, d_iterations=None, stream=None):
         """ldpc_decoder::decode for n_cb codeblocks resident in HBM (cfg: abi.LdpcDecoderCfg)."""
         _check(self.lib.nrphy_ldpc_decode(self.handle, C.byref(cfg), n_cb, _dptr(d_llr), llr_stride, _dptr(d_out),

@@ -593,3 +593,68 @@ def test_ldpc_encode_decode_round_trip_full_size(gpu_ctx, oracle):
     torch.cuda.synchronize()
     assert int(its.min()) >= 1
     assert np.array_equal(np.unpackbits(out.cpu().numpy(), axis=1)[:, : k - 72], msgs[:, : k - 72])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LDPC rate dematcher ("next" row, receive side): bit-exact soft buffers against the oracle (pinned to the reference's
+# generic implementation in tests/test_oracle.py), new data and HARQ combining
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", cases.LDPC_DEMATCH_CASES)
+def test_ldpc_rate_dematcher_vs_oracle(gpu_ctx, oracle, case):
+    bg, zc, e, rv, qm, nref, nf = case
+    rng = np.random.default_rng(e * 7 + rv)
+    n = (66 if bg == 1 else 50) * zc
+    llr = rng.integers(-127, 128, e).astype(np.int8)
+    llr[rng.integers(0, e, e // 10)] = 0
+    old = rng.integers(-127, 128, n).astype(np.int8)
+    for new_data in (1, 0):
+        want = oracle.ldpc_rate_dematch(bg, zc, rv, qm, nref, nf, new_data, llr, old)
+        got = gpu_ctx.ldpc_rate_dematch_host(bg, zc, rv, qm, nref, nf, new_data, llr, old)
+        assert np.array_equal(got, want), (new_data, int(np.count_nonzero(got != want)))
+    # a second transmission on top of the first (rv cycling as HARQ does)
+    soft = gpu_ctx.ldpc_rate_dematch_host(bg, zc, rv, qm, nref, nf, 1, llr, old)
+    want = oracle.ldpc_rate_dematch(bg, zc, rv, qm, nref, nf, 1, llr, old)
+    for rv2 in (2, 3, 1):
+        llr2 = rng.integers(-120, 121, e).astype(np.int8)
+        soft = gpu_ctx.ldpc_rate_dematch_host(bg, zc, rv2, qm, nref, nf, 0, llr2, soft)
+        want = oracle.ldpc_rate_dematch(bg, zc, rv2, qm, nref, nf, 0, llr2, want)
+        assert np.array_equal(soft, want), rv2
+
+
+def test_ldpc_rate_dematch_then_decode_batch(gpu_ctx, oracle):
+    """The receive chain on a config-3 slot resident in HBM: 104 codeblocks rate matched by the oracle, noisy LLRs, GPU rate
+    dematcher into soft buffers with a padded stride, GPU decoder on the soft buffers; every codeblock comes back."""
+    import torch
+    pdu, nof_ports, nof_subc, _ = cases.baseline_config(3)
+    d = oracle.derive(pdu)
+    bg, zc, nf, n_cb = 1, d["lifting_size"], d["nof_filler_bits"], 8
+    e, k, n = d["rm_length_short"], 22 * d["lifting_size"], 66 * d["lifting_size"]
+    rng = np.random.default_rng(17)
+    msgs, llrs = [], np.zeros((n_cb, e + 32), np.int8)
+    for i in range(n_cb):
+        payload = rng.integers(0, 2, k - nf - 24, dtype=np.uint8)
+        crc = oracle.crc_bits(0x24B, payload)
+        msg = np.concatenate([payload, [(crc >> (23 - b)) & 1 for b in range(24)], np.zeros(nf, np.uint8)]).astype(np.uint8)
+        cb = oracle.ldpc_encode(bg, zc, np.packbits(msg), n)
+        rm = np.unpackbits(oracle.rate_match(bg, zc, 0, 8, 0, nf, cb, e))[:e]
+        llrs[i, :e] = np.clip(np.rint((1.0 - 2.0 * rm) * 24 + rng.normal(0, 8.0, e)), -120, 120).astype(np.int8)
+        msgs.append(msg)
+    stride = n + 64
+    soft = torch.full((n_cb, stride), 55, dtype=torch.int8, device="cuda")
+    dcfg = abi.LdpcRateDematcherCfg(bg, zc, 0, 8, 0, nf, e)
+    gpu_ctx.ldpc_rate_dematch(dcfg, n_cb, dev(llrs), llrs.shape[1], soft, stride, True)
+    torch.cuda.synchronize()
+    soft_host = soft.cpu().numpy()
+    for i in range(n_cb):
+        want = oracle.ldpc_rate_dematch(bg, zc, 0, 8, 0, nf, 1, llrs[i, :e], np.full(n, 55, np.int8))
+        assert np.array_equal(soft_host[i, :n], want), i
+    assert np.all(soft_host[:, n:] == 55), "nothing beyond a codeblock's soft buffer may be written"
+    out = torch.zeros((n_cb, k // 8), dtype=torch.uint8, device="cuda")
+    its = torch.zeros((n_cb,), dtype=torch.int32, device="cuda")
+    gpu_ctx.ldpc_decode(abi.LdpcDecoderCfg(bg, zc, nf, 0x24B, n, 8, 0.8), n_cb, soft, stride, out, k // 8, its)
+    torch.cuda.synchronize()
+    bits = np.unpackbits(out.cpu().numpy(), axis=1)
+    for i in range(n_cb):
+        it_o, bits_o = oracle.ldpc_decode(bg, zc, nf, 0x24B, 8, 0.8, soft_host[i, :n])
+        assert int(its[i]) == it_o >= 1 and np.array_equal(bits[i], bits_o)
+        assert np.array_equal(bits[i, : k - nf], msgs[i][: k - nf])
