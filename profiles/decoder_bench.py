@@ -50,6 +50,23 @@ def main():
         ms = a.elapsed_time(b) / reps
         res[label] = {"ms": ms, "codeblocks_per_s": n_cb / ms * 1e3, "slots_per_s": n_slots / ms * 1e3,
                       "info_gbps": n_cb * (k - 24) / ms * 1e-6, "mean_iterations": float(its.float().mean())}
+    # rate dematcher in front (256-QAM, rv 0, new data, then a retransmission combined into the same soft buffers)
+    rm_in = torch.from_numpy(np.ascontiguousarray(llr[:, :e])).cuda()
+    soft = torch.zeros((n_cb, nof_llr), dtype=torch.int8, device="cuda")
+    dcfg = abi.LdpcRateDematcherCfg(bg, zc, 0, 8, 0, 72, e)
+    for new_data, label in ((True, "rate_dematch_new_data"), (False, "rate_dematch_combine")):
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            ctx.ldpc_rate_dematch(dcfg, n_cb, rm_in, e, soft, nof_llr, new_data, stream.cuda_stream)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(5):
+                ctx.ldpc_rate_dematch(dcfg, n_cb, rm_in, e, soft, nof_llr, new_data, stream.cuda_stream)
+            b.record(stream)
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 5
+        gb = n_cb * (e + nof_llr * (1 if new_data else 2)) * 1e-9
+        res[label] = {"ms": ms, "codeblocks_per_s": n_cb / ms * 1e3, "algorithmic_GBps": gb / ms * 1e3}
     # without a CRC in the random messages early stop never fires: the second leg is the CRC cost on top
     # CPU context: the reference's own decoder (oracle/_ref, AVX2 and generic) on a few of the same codeblocks, 1 thread
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

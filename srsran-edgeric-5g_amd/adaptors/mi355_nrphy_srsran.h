@@ -27,6 +27,7 @@
 #include "srsran/phy/lower/modulation/ofdm_demodulator.h"
 #include "srsran/phy/lower/modulation/ofdm_modulator.h"
 #include "srsran/phy/support/resource_grid_mapper.h"
+#include "srsran/phy/upper/channel_coding/channel_coding_factories.h"
 #include "srsran/phy/support/resource_grid_reader.h"
 #include "srsran/phy/support/resource_grid_writer.h"
 #include "srsran/phy/upper/channel_processors/channel_processor_factories.h"
@@ -559,15 +560,131 @@ public:
     switch (config.size) {
       case 128:
       case 256:
+      case 384:
       case 512:
+      case 768:
       case 1024:
+      case 1536:
       case 2048:
+      case 3072:
       case 4096:
         return std::make_unique<dft_processor_adaptor>(ctx, config);
       default:
         return nullptr;
     }
   }
+
+private:
+  std::shared_ptr<context> ctx;
+};
+
+// ---- receive side ("next" row): LDPC rate dematcher and decoder ----------------------------------------------------
+// Drop-ins for create_ldpc_rate_dematcher_factory_sw / create_ldpc_decoder_factory_sw
+// (R/include/srsran/phy/upper/channel_coding/channel_coding_factories.h:52-77): one codeblock per call on host spans,
+// the calling convention of pusch_codeblock_decoder (R/lib/phy/upper/channel_processors/pusch/pusch_codeblock_decoder.cpp).
+// A device-resident receive chain calls nrphy_ldpc_rate_dematch / nrphy_ldpc_decode on whole batches instead.
+class ldpc_rate_dematcher_adaptor : public srsran::ldpc_rate_dematcher
+{
+public:
+  explicit ldpc_rate_dematcher_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
+  void rate_dematch(srsran::span<srsran::log_likelihood_ratio>       output,
+                    srsran::span<const srsran::log_likelihood_ratio> input,
+                    bool                                             new_data,
+                    const srsran::codeblock_metadata&                cfg) override
+  {
+    using namespace srsran;
+    // As the reference, the base graph and the lifting size follow from the soft-buffer length (66 Zc or 50 Zc).
+    nrphy_ldpc_rate_dematcher_cfg_t c = {};
+    c.base_graph                      = (output.size() % 66 == 0) ? 1 : 2;
+    c.lifting_size                    = output.size() / ((c.base_graph == 1) ? 66 : 50);
+    c.rv                              = cfg.tb_common.rv;
+    c.qm                              = get_bits_per_symbol(cfg.tb_common.mod);
+    c.nref                            = cfg.tb_common.Nref;
+    c.nof_filler_bits                 = cfg.cb_specific.nof_filler_bits;
+    c.rm_length                       = input.size();
+    static_assert(sizeof(log_likelihood_ratio) == sizeof(int8_t), "LLRs are plain int8");
+    int rc = nrphy_ldpc_rate_dematch_host(ctx->get(), &c, reinterpret_cast<const int8_t*>(input.data()),
+                                          reinterpret_cast<int8_t*>(output.data()), new_data ? 1 : 0);
+    srsran_assert(rc == NRPHY_OK, "nrphy_ldpc_rate_dematch_host failed: {}", nrphy_strerror(rc));
+  }
+
+private:
+  std::shared_ptr<context> ctx;
+};
+
+class ldpc_rate_dematcher_factory_adaptor : public srsran::ldpc_rate_dematcher_factory
+{
+public:
+  explicit ldpc_rate_dematcher_factory_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
+  std::unique_ptr<srsran::ldpc_rate_dematcher> create() override
+  {
+    return std::make_unique<ldpc_rate_dematcher_adaptor>(ctx);
+  }
+
+private:
+  std::shared_ptr<context> ctx;
+};
+
+class ldpc_decoder_adaptor : public srsran::ldpc_decoder
+{
+public:
+  explicit ldpc_decoder_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
+  std::optional<unsigned> decode(srsran::bit_buffer&                              output,
+                                 srsran::span<const srsran::log_likelihood_ratio> input,
+                                 srsran::crc_calculator*                          crc,
+                                 const configuration&                             cfg) override
+  {
+    using namespace srsran;
+    nrphy_ldpc_decoder_cfg_t c = {};
+    c.base_graph               = (cfg.block_conf.tb_common.base_graph == ldpc_base_graph_type::BG1) ? 1 : 2;
+    c.lifting_size             = cfg.block_conf.tb_common.lifting_size;
+    c.nof_filler_bits          = cfg.block_conf.cb_specific.nof_filler_bits;
+    c.nof_llr                  = input.size();
+    c.max_iterations           = cfg.algorithm_conf.max_iterations;
+    c.scaling_factor           = cfg.algorithm_conf.scaling_factor;
+    c.crc_poly                 = 0;
+    if (crc != nullptr) {
+      switch (crc->get_generator_poly()) {
+        case crc_generator_poly::CRC16:
+          c.crc_poly = 16;
+          break;
+        case crc_generator_poly::CRC24A:
+          c.crc_poly = 0x24A;
+          break;
+        case crc_generator_poly::CRC24B:
+          c.crc_poly = 0x24B;
+          break;
+        default:
+          srsran_assert(false, "CRC polynomial not used for LDPC codeblocks.");
+      }
+    }
+    const unsigned k = ((c.base_graph == 1) ? 22 : 10) * c.lifting_size;
+    packed.resize((k + 7) / 8);
+    uint32_t iterations = 0;
+    int rc = nrphy_ldpc_decode_host(ctx->get(), &c, reinterpret_cast<const int8_t*>(input.data()), packed.data(), &iterations);
+    srsran_assert(rc == NRPHY_OK, "nrphy_ldpc_decode_host failed: {}", nrphy_strerror(rc));
+    // output holds the message without (or with) its filler bits: the first output.size() hard bits
+    const unsigned nbits = std::min<unsigned>(output.size(), k);
+    for (unsigned i = 0; i < nbits; i += 8) {
+      unsigned n = std::min(8U, nbits - i);
+      output.insert(static_cast<uint8_t>(packed[i / 8] >> (8 - n)), i, n);
+    }
+    if (crc != nullptr && iterations != 0) {
+      return iterations;
+    }
+    return std::nullopt;
+  }
+
+private:
+  std::shared_ptr<context> ctx;
+  std::vector<uint8_t>     packed;
+};
+
+class ldpc_decoder_factory_adaptor : public srsran::ldpc_decoder_factory
+{
+public:
+  explicit ldpc_decoder_factory_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
+  std::unique_ptr<srsran::ldpc_decoder> create() override { return std::make_unique<ldpc_decoder_adaptor>(ctx); }
 
 private:
   std::shared_ptr<context> ctx;
