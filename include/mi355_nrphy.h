@@ -275,8 +275,8 @@ typedef struct nrphy_ldpc_rate_dematcher_cfg {
   uint32_t rm_length;
 } nrphy_ldpc_rate_dematcher_cfg_t;
 /* n_cb codeblocks that share the configuration: input i at d_in + i * in_stride_bytes, soft buffer i at
- * d_soft + i * soft_stride_bytes.  NRPHY_ERR_CAPACITY: more repetition than the kernel's operation
- * list holds (rm_length of many times the buffer length). */
+ * d_soft + i * soft_stride_bytes.  Asynchronous on `stream`, except for extreme repetition (rm_length of
+ * dozens of buffer lengths), where the call synchronises the device to upload a longer operation list. */
 int nrphy_ldpc_rate_dematch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg, uint32_t n_cb,
                             const int8_t* d_in, uint32_t in_stride_bytes, int8_t* d_soft, uint32_t soft_stride_bytes,
                             int new_data, void* stream);

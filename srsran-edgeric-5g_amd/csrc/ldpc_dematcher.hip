@@ -15,14 +15,22 @@
 namespace nrphy {
 
 // Element s of the deinterleaved input: row j = s / cols of the Qm x cols table is bit j of every symbol
-// (ldpc_rate_dematcher_impl.cpp:202-213).
-__device__ __forceinline__ int dematch_fetch(const int8_t* in, uint32_t s, uint32_t qm, uint32_t cols)
+// (ldpc_rate_dematcher_impl.cpp:202-213).  s / cols through the float reciprocal with a correction step (s < 2^24).
+__device__ __forceinline__ int dematch_fetch(const int8_t* in, uint32_t s, uint32_t qm, uint32_t cols, float rcp_cols)
 {
   if (qm == 1) {
     return in[s];
   }
-  const uint32_t j = s / cols, i = s - j * cols;
-  return in[i * qm + j];
+  uint32_t j = (uint32_t)((float)s * rcp_cols);
+  int32_t  i = (int32_t)(s - j * cols);
+  if (i < 0) {
+    i += (int32_t)cols;
+    --j;
+  } else if (i >= (int32_t)cols) {
+    i -= (int32_t)cols;
+    ++j;
+  }
+  return in[(uint32_t)i * qm + j];
 }
 
 // in + old as log_likelihood_ratio::operator+ evaluates it (log_likelihood_ratio.cpp:37-80): opposite values cancel,
@@ -35,28 +43,23 @@ __device__ __forceinline__ int dematch_sum(int in, int old)
   return in == -old ? 0 : r;
 }
 
-template <uint32_t VEC>
-__global__ __launch_bounds__(256) void ldpc_dematch_kernel(DematchLaunch p)
+// Applies, in order, every operation that covers soft bits [first, first + VEC) of one codeblock.  `in` is the
+// codeblock's input, in global memory or staged in LDS.
+// old: what the buffer holds there (a dword of four soft bits, or one soft bit).  EXT: the operation list is in global
+// memory (p.ops_ext) instead of the kernel argument.
+template <uint32_t VEC, bool EXT>
+__device__ __forceinline__ void dematch_positions(const DematchLaunch& p, const int8_t* in, int8_t* out_row, uint32_t first,
+                                                  uint32_t old, float rcp_cols)
 {
-  const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
-  if (first >= p.block_length) {
-    return;
-  }
-  const int8_t* in  = p.in + (size_t)blockIdx.y * p.in_stride;
-  int8_t*       out = p.out + (size_t)blockIdx.y * p.out_stride + first;
-  int           v[VEC];
-  if (VEC == 4) {
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(out);
+  int8_t* out = out_row + first;
+  int     v[VEC];
 #pragma unroll
-    for (uint32_t i = 0; i != VEC; ++i) {
-      v[i] = (int)(int8_t)(w >> (8u * i));
-    }
-  } else {
-    v[0] = out[0];
+  for (uint32_t i = 0; i != VEC; ++i) {
+    v[i] = (int)(int8_t)(old >> (8u * i));
   }
   bool touched = false;
   for (uint32_t k = 0; k != p.n_ops; ++k) {
-    const DematchOp op = p.ops[k];
+    const DematchOp op = EXT ? p.ops_ext[k] : p.ops[k];
     if (first + VEC <= op.begin || first >= op.begin + op.count) {
       continue;
     }
@@ -73,10 +76,10 @@ __global__ __launch_bounds__(256) void ldpc_dematch_kernel(DematchLaunch p)
             v[i] = 127; // LLR_INFINITY: a filler bit is a certain zero
             break;
           case DEMATCH_COPY:
-            v[i] = dematch_fetch(in, op.src + (q - op.begin), p.qm, p.cols);
+            v[i] = dematch_fetch(in, op.src + (q - op.begin), p.qm, p.cols, rcp_cols);
             break;
           default:
-            v[i] = dematch_sum(dematch_fetch(in, op.src + (q - op.begin), p.qm, p.cols), v[i]);
+            v[i] = dematch_sum(dematch_fetch(in, op.src + (q - op.begin), p.qm, p.cols, rcp_cols), v[i]);
             break;
         }
       }
@@ -97,19 +100,89 @@ __global__ __launch_bounds__(256) void ldpc_dematch_kernel(DematchLaunch p)
   }
 }
 
+// General form: the input is gathered from global memory (any alignment, any length).
+template <uint32_t VEC, bool EXT>
+__global__ __launch_bounds__(256) void ldpc_dematch_kernel(DematchLaunch p)
+{
+  const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (first >= p.block_length) {
+    return;
+  }
+  int8_t*        out_row = p.out + (size_t)blockIdx.y * p.out_stride;
+  const uint32_t old     = VEC == 4 ? *reinterpret_cast<const uint32_t*>(out_row + first) : (uint32_t)(uint8_t)out_row[first];
+  dematch_positions<VEC, EXT>(p, p.in + (size_t)blockIdx.y * p.in_stride, out_row, first, old, 1.0f / (float)p.cols);
+}
+
+// One workgroup per codeblock: the input is read once, coalesced, into LDS; the strided reads of the deinterleaver
+// then stay on chip.
+constexpr uint32_t DEMATCH_LDS_THREADS = 1024;
+constexpr uint32_t DEMATCH_LDS_ROUNDS  = 7; // 66 * 384 soft bits / (1024 threads * 4)
+
+template <bool EXT>
+__global__ __launch_bounds__(DEMATCH_LDS_THREADS) void ldpc_dematch_lds_kernel(DematchLaunch p)
+{
+  extern __shared__ __attribute__((aligned(16))) int8_t staged[];
+  const int8_t*  in = p.in + (size_t)blockIdx.x * p.in_stride;
+  const uint32_t e  = p.cols * p.qm;
+  if (((reinterpret_cast<uintptr_t>(in)) & 3u) == 0) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in);
+    uint32_t*       dst = reinterpret_cast<uint32_t*>(staged);
+    for (uint32_t i = threadIdx.x; i < e / 4u; i += blockDim.x) {
+      dst[i] = src[i];
+    }
+    for (uint32_t i = (e & ~3u) + threadIdx.x; i < e; i += blockDim.x) {
+      staged[i] = in[i];
+    }
+  } else {
+    for (uint32_t i = threadIdx.x; i < e; i += blockDim.x) {
+      staged[i] = in[i];
+    }
+  }
+  // what the soft buffer holds: all loads of this thread in flight while the input is being staged
+  int8_t*  out_row = p.out + (size_t)blockIdx.x * p.out_stride;
+  uint32_t old[DEMATCH_LDS_ROUNDS];
+#pragma unroll
+  for (uint32_t r = 0; r != DEMATCH_LDS_ROUNDS; ++r) {
+    const uint32_t first = (r * DEMATCH_LDS_THREADS + threadIdx.x) * 4u;
+    old[r]               = first < p.block_length ? *reinterpret_cast<const uint32_t*>(out_row + first) : 0u;
+  }
+  __syncthreads();
+  const float rcp_cols = 1.0f / (float)p.cols;
+#pragma unroll
+  for (uint32_t r = 0; r != DEMATCH_LDS_ROUNDS; ++r) {
+    const uint32_t first = (r * DEMATCH_LDS_THREADS + threadIdx.x) * 4u;
+    if (first < p.block_length) {
+      dematch_positions<4, EXT>(p, staged, out_row, first, old[r], rcp_cols);
+    }
+  }
+}
+
+template <bool EXT>
+static void launch_dematch_variant(const DematchLaunch& p, uint32_t n_cb, hipStream_t stream)
+{
+  // four soft bits per thread when every codeblock row is dword aligned (block lengths are multiples of 4 only for even Zc)
+  const bool     vec4 = ((reinterpret_cast<uintptr_t>(p.out) | p.out_stride | p.block_length) & 3u) == 0;
+  const uint32_t e    = p.cols * p.qm;
+  if (vec4 && e <= 60u * 1024u) {
+    hipLaunchKernelGGL(ldpc_dematch_lds_kernel<EXT>, dim3(n_cb), dim3(DEMATCH_LDS_THREADS), (e + 15u) & ~15u, stream, p);
+  } else if (vec4) {
+    const uint32_t blocks = (p.block_length / 4 + 255) / 256;
+    hipLaunchKernelGGL((ldpc_dematch_kernel<4, EXT>), dim3(blocks, n_cb), dim3(256), 0, stream, p);
+  } else {
+    const uint32_t blocks = (p.block_length + 255) / 256;
+    hipLaunchKernelGGL((ldpc_dematch_kernel<1, EXT>), dim3(blocks, n_cb), dim3(256), 0, stream, p);
+  }
+}
+
 hipError_t launch_ldpc_dematch(const DematchLaunch& p, uint32_t n_cb, hipStream_t stream)
 {
   if (n_cb == 0 || p.n_ops == 0) {
     return hipSuccess;
   }
-  // four soft bits per thread when every codeblock row is dword aligned (block lengths are multiples of 4 only for even Zc)
-  const bool vec4 = ((reinterpret_cast<uintptr_t>(p.out) | p.out_stride | p.block_length) & 3u) == 0;
-  if (vec4) {
-    const uint32_t blocks = (p.block_length / 4 + 255) / 256;
-    hipLaunchKernelGGL(ldpc_dematch_kernel<4>, dim3(blocks, n_cb), dim3(256), 0, stream, p);
+  if (p.ops_ext != nullptr) {
+    launch_dematch_variant<true>(p, n_cb, stream);
   } else {
-    const uint32_t blocks = (p.block_length + 255) / 256;
-    hipLaunchKernelGGL(ldpc_dematch_kernel<1>, dim3(blocks, n_cb), dim3(256), 0, stream, p);
+    launch_dematch_variant<false>(p, n_cb, stream);
   }
   return hipGetLastError();
 }

@@ -378,15 +378,15 @@ struct nrphy_ctx {
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
   // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
   std::mutex host_mutex;
-  void*      scratch[7]       = {};
-  size_t     scratch_bytes[7] = {};
+  void*      scratch[8]       = {};
+  size_t     scratch_bytes[8] = {};
 };
 
 namespace {
 
 // Staging buffer `slot` of the context with room for `bytes` (reallocated only when it has to grow).
 enum ScratchSlot { SCRATCH_TB = 0, SCRATCH_GRID, SCRATCH_CW_RM, SCRATCH_CW_SCR, SCRATCH_IQ, SCRATCH_SMALL,
-                   SCRATCH_DECODER };
+                   SCRATCH_DECODER, SCRATCH_DEMATCH_OPS };
 void* ctx_scratch(nrphy_ctx* ctx, ScratchSlot slot, size_t bytes)
 {
   if (bytes > ctx->scratch_bytes[slot]) {
@@ -1573,25 +1573,19 @@ namespace {
 
 // The walk of ldpc_rate_dematcher_impl::allot_llrs (ldpc_rate_dematcher_impl.cpp:118-200) over the soft buffer, with
 // the data taken out: which ranges it clears, fills, copies into and adds to, in its order.  Returns false when the
-// list does not fit (extreme repetition).
-bool build_dematch_ops(DematchLaunch& p, unsigned block_length, unsigned buffer_length, unsigned k0,
+void build_dematch_ops(std::vector<DematchOp>& ops, unsigned block_length, unsigned buffer_length, unsigned k0,
                        unsigned nof_systematic, unsigned nof_filler, unsigned e, bool new_data)
 {
   const unsigned nof_info = nof_systematic - nof_filler;
-  bool           copying  = new_data, ok = true;
+  bool           copying  = new_data;
   unsigned       pos = k0, taken = 0;
-  p.n_ops = 0;
+  ops.clear();
   auto emit = [&](uint32_t kind, unsigned begin, unsigned count, unsigned src) {
-    if (count == 0) {
-      return;
+    if (count != 0) {
+      ops.push_back({kind, begin, count, src});
     }
-    if (p.n_ops == MAX_DEMATCH_OPS) {
-      ok = false;
-      return;
-    }
-    p.ops[p.n_ops++] = {kind, begin, count, src};
   };
-  while (taken != e && ok) {
+  while (taken != e) {
     unsigned left = e - taken;
     if (pos < nof_info) {
       const unsigned n = std::min(nof_info - pos, left);
@@ -1621,7 +1615,6 @@ bool build_dematch_ops(DematchLaunch& p, unsigned block_length, unsigned buffer_
     // the reference clears this many soft bits at the end of the full-length block, wherever the buffer ends
     emit(DEMATCH_ZERO, block_length - (buffer_length - pos), buffer_length - pos, 0);
   }
-  return ok;
 }
 
 } // namespace
@@ -1633,7 +1626,7 @@ extern "C" int nrphy_ldpc_rate_dematch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_d
   if (ctx == nullptr || cfg == nullptr || d_in == nullptr || d_soft == nullptr ||
       (cfg->base_graph != 1 && cfg->base_graph != 2) || cfg->rv > 3 || lifting_position(cfg->lifting_size) < 0 ||
       (cfg->qm != 1 && cfg->qm != 2 && cfg->qm != 4 && cfg->qm != 6 && cfg->qm != 8) || cfg->rm_length == 0 ||
-      cfg->rm_length % cfg->qm != 0) {
+      cfg->rm_length > 35 * 8448 /* ldpc::MAX_CODEBLOCK_RM_SIZE */ || cfg->rm_length % cfg->qm != 0) {
     return NRPHY_ERR_ARGUMENT;
   }
   static const double shift_bg1[4] = {0, 17, 33, 56}, shift_bg2[4] = {0, 13, 25, 43};
@@ -1648,10 +1641,26 @@ extern "C" int nrphy_ldpc_rate_dematch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_d
   // ldpc_rate_dematcher_impl.cpp:94-95: k0 of TS 38.212 Table 5.4.2.1-2 in double precision
   const double   frac = (((cfg->base_graph == 1) ? shift_bg1 : shift_bg2)[cfg->rv] * buffer_length) / block_length;
   const unsigned k0   = (unsigned)((uint16_t)std::floor(frac)) * zc;
-  DematchLaunch  p;
-  if (!build_dematch_ops(p, block_length, buffer_length, k0, nof_systematic, cfg->nof_filler_bits, cfg->rm_length,
-                         new_data != 0)) {
-    return NRPHY_ERR_CAPACITY;
+  DematchLaunch          p;
+  std::vector<DematchOp> ops;
+  build_dematch_ops(ops, block_length, buffer_length, k0, nof_systematic, cfg->nof_filler_bits, cfg->rm_length,
+                    new_data != 0);
+  HIP_TRY(hipSetDevice(ctx->device));
+  p.n_ops   = (uint32_t)ops.size();
+  p.ops_ext = nullptr;
+  if (ops.size() <= MAX_DEMATCH_OPS) {
+    std::copy(ops.begin(), ops.end(), p.ops);
+  } else {
+    // Heavy repetition (rm_length of dozens of buffer lengths): the list goes through device memory.  This path
+    // copies synchronously and waits for earlier launches that may still read the previous list.
+    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    HIP_TRY(hipDeviceSynchronize());
+    DematchOp* d_ops = (DematchOp*)ctx_scratch(ctx, SCRATCH_DEMATCH_OPS, ops.size() * sizeof(DematchOp));
+    if (d_ops == nullptr) {
+      return NRPHY_ERR_DEVICE;
+    }
+    HIP_TRY(hipMemcpy(d_ops, ops.data(), ops.size() * sizeof(DematchOp), hipMemcpyHostToDevice));
+    p.ops_ext = d_ops;
   }
   p.in           = d_in;
   p.out          = d_soft;
@@ -1660,7 +1669,6 @@ extern "C" int nrphy_ldpc_rate_dematch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_d
   p.block_length = block_length;
   p.qm           = cfg->qm;
   p.cols         = cfg->rm_length / cfg->qm;
-  HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(launch_ldpc_dematch(p, n_cb, stream ? (hipStream_t)stream : ctx->stream));
   return NRPHY_OK;
 }

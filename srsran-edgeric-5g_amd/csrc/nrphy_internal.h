@@ -254,7 +254,8 @@ struct DematchLaunch {
   const int8_t* in;  // per codeblock: rm_length soft bits as received
   int8_t*       out; // per codeblock: the soft buffer, block_length soft bits
   uint32_t      in_stride, out_stride, block_length, qm, cols, n_ops;
-  DematchOp     ops[MAX_DEMATCH_OPS];
+  const DematchOp* ops_ext; // the list in device memory when it has more than MAX_DEMATCH_OPS entries, else null
+  DematchOp        ops[MAX_DEMATCH_OPS];
 };
 hipError_t launch_ldpc_dematch(const DematchLaunch& p, uint32_t n_cb, hipStream_t stream);
 

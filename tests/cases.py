@@ -138,4 +138,5 @@ LDPC_DEMATCH_CASES = [(1, 14, e, rv, qm, nref, nf) for e, rv, qm, nref, nf in _R
     (1, 384, 8992, 0, 8, 18432, 72), (1, 384, 8960, 0, 8, 0, 72), (1, 384, 9804, 2, 6, 0, 80),
     (2, 144, 11232, 0, 2, 0, 104), (2, 352, 5000, 3, 4, 8000, 24), (1, 16, 2000, 1, 2, 0, 5),
     (2, 7, 2304, 3, 2, 0, 30), (1, 384, 60, 0, 6, 0, 72), (1, 384, 30000, 3, 8, 0, 0), (2, 384, 19200, 1, 4, 0, 0),
+    (1, 384, 65536, 2, 8, 0, 16), (2, 30, 64000, 0, 4, 0, 0),
 ]
