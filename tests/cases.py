@@ -140,3 +140,29 @@ LDPC_DEMATCH_CASES = [(1, 14, e, rv, qm, nref, nf) for e, rv, qm, nref, nf in _R
     (2, 7, 2304, 3, 2, 0, 30), (1, 384, 60, 0, 6, 0, 72), (1, 384, 30000, 3, 8, 0, 0), (2, 384, 19200, 1, 4, 0, 0),
     (1, 384, 65536, 2, 8, 0, 16), (2, 30, 64000, 0, 4, 0, 0),
 ]
+
+
+# ---- precoding shapes with exact zeros (signed-zero products in the layer sum) ----------------------------
+def diagonal_precoding_variants():
+    """[(name, weights [1][P][L] complex64)]: diagonal matrices with real / imaginary / complex entries, one off-diagonal
+    entry, a permutation, a zero on the diagonal -- sums in which most products are signed zeros."""
+    out = []
+    d = np.zeros((1, 4, 4), np.complex64)
+    for i, v in enumerate((0.5, -0.5, 0.5j, -0.5j)):
+        d[0, i, i] = v
+    out.append(("rotated", d))
+    d = np.zeros((1, 4, 4), np.complex64)
+    for i in range(4):
+        d[0, i, i] = 0.70710678
+    d[0, 2, 2] = (1 + 1j) * 0.5
+    out.append(("complex_entry", d))
+    d = np.eye(4, dtype=np.complex64)[None].copy()
+    d[0, 1, 3] = 1e-3
+    out.append(("off_diagonal", d))
+    out.append(("permutation", np.eye(4, dtype=np.complex64)[[1, 0, 3, 2]][None].copy()))
+    d = np.eye(4, dtype=np.complex64)[None].copy()
+    d[0, 3, 3] = 0
+    out.append(("zero_on_diagonal", d))
+    d = -np.eye(2, dtype=np.complex64)[None].copy()
+    out.append(("two_layers_negative", d))
+    return out

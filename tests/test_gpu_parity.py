@@ -131,6 +131,21 @@ def test_pdsch_unit_test_like_pdus(gpu_ctx, oracle):
         assert sha(grid) == str(g[name + "_grid_sha"]), name
 
 
+def test_pdsch_diagonal_precoding_variants(gpu_ctx, oracle):
+    """Weight matrices full of exact zeros: the layer sum then adds signed zeros, whose sign survives into the bf16 grid
+    when a port's sum is zero; the grid must stay bit-exact."""
+    rng = np.random.default_rng(606)
+    for name, w in cases.diagonal_precoding_variants():
+        layers = w.shape[2]
+        for qm in (2, 8):
+            nre = 30 * 12 * 12
+            tb_bits = oracle.tbs(12, 12, 0, qm, 700.0 if qm == 8 else 400.0, layers, 30)
+            pdu = abi.make_pdu(bwp_size_rb=30, qm=qm, dmrs_symbols=(2, 11), prb_start=0, prb_count=30, start_symbol=1,
+                               nof_symbols=13, precoding=w, tb_size_bytes=tb_bits // 8, ratio_data_dB=1.5,
+                               nof_cdm_groups_without_data=2, scrambling_id=77, n_id=5, rnti=4321)
+            run_single(gpu_ctx, oracle, pdu, cases.random_tb(rng, pdu), w.shape[1], 30 * 12)
+
+
 def edge_case_pdus():
     rng = np.random.default_rng(99)
     w22 = (rng.standard_normal((3, 2, 2, 2)) * 0.5).astype(np.float32)       # 3 PRGs, complex random weights

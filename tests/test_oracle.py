@@ -171,6 +171,23 @@ def test_oracle_ldpc_rate_dematcher_vs_reference(oracle, ref, case):
     assert np.all(soft[nof_sys - nf:nof_sys] == 127)
 
 
+def test_oracle_vs_ref_diagonal_precoding_variants(oracle, ref):
+    """Weight matrices full of exact zeros (signed-zero products in the layer sum), oracle against the compiled reference
+    (its three processors, AVX2 and generic precoders): bit-exact grids."""
+    rng = np.random.default_rng(607)
+    for name, w in cases.diagonal_precoding_variants():
+        layers = w.shape[2]
+        tb_bits = oracle.tbs(12, 12, 0, 8, 700.0, layers, 30)
+        pdu = abi.make_pdu(bwp_size_rb=30, qm=8, dmrs_symbols=(2, 11), prb_start=0, prb_count=30, start_symbol=1,
+                           nof_symbols=13, precoding=w, tb_size_bytes=tb_bits // 8, ratio_data_dB=1.5,
+                           nof_cdm_groups_without_data=2, scrambling_id=77, n_id=5, rnti=4321)
+        tb = cases.random_tb(rng, pdu)
+        want = oracle.pdsch_process(pdu, tb, w.shape[1], 30 * 12)
+        for impl in range(3):
+            got = ref.pdsch_process(pdu, tb, w.shape[1], 30 * 12, impl=impl)
+            assert np.array_equal(got, want), (name, impl)
+
+
 def test_baseline_config_derived_values(oracle):
     """The derived sizes SURVEY.md section 8d lists for the BASELINE configs."""
     d = oracle.derive(cases.baseline_config(3)[0])
