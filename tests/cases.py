@@ -166,3 +166,27 @@ def diagonal_precoding_variants():
     d = -np.eye(2, dtype=np.complex64)[None].copy()
     out.append(("two_layers_negative", d))
     return out
+
+
+LIFTING_SIZES = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52,
+                 56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128, 144, 160, 176, 192, 208, 224, 240, 256, 288, 320, 352,
+                 384]
+
+
+def ldpc_dec_test_lengths(bg, zc):
+    """create_range(min_cb_length, max_cb_length, 3) of the reference's ldpc_enc_dec_test.cpp:237-252."""
+    lo, hi = ((24, 66) if bg == 1 else (12, 50))
+    lo, hi = lo * zc, hi * zc
+    step = (hi - lo) // 3
+    return list(range(lo, hi, step)) + [hi]
+
+
+def noiseless_llrs(oracle, rng, bg, zc, nof_filler, length):
+    """A random message (filler bits at the end of it), its codeblock as LLRs of amplitude 10, fillers +10 as the
+    reference's LDPCDecTest maps them (ldpc_enc_dec_test.cpp:60-64).  Returns (message bits, llrs)."""
+    kb = 22 if bg == 1 else 10
+    msg = rng.integers(0, 2, kb * zc, dtype=np.uint8)
+    if nof_filler:
+        msg[-nof_filler:] = 0
+    cb = np.unpackbits(oracle.ldpc_encode(bg, zc, np.packbits(msg), length))[:length]
+    return msg, (10 * (1 - 2 * cb.astype(np.int8))).astype(np.int8)

@@ -17,9 +17,7 @@ abi = backends.abi
 lib = backends.pkg.lib
 pytestmark = pytest.mark.gpu
 
-LIFTING_SIZES = [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52,
-                 56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128, 144, 160, 176, 192, 208, 224, 240, 256, 288, 320, 352,
-                 384]
+LIFTING_SIZES = cases.LIFTING_SIZES
 
 
 def sha(a):
@@ -540,6 +538,33 @@ def test_ldpc_decoder_vs_oracle(gpu_ctx, oracle, case):
     assert gpu_ctx.ldpc_decode_host(bg, zc, filler, crc_id, 8, 0.8, zero)[0] == 0
     it, bits = gpu_ctx.ldpc_decode_host(bg, zc, filler, 0, 8, 0.8, zero)
     assert it == 0 and bits.all()
+
+
+@pytest.mark.parametrize("bg", [1, 2])
+def test_ldpc_decoder_reference_unit_tests_all_graphs(gpu_ctx, oracle, bg):
+    """The reference's LDPCDecTest / ZeroLLR / AlmostZeroLLR (ldpc_enc_dec_test.cpp:287-358) through the C ABI: all 51
+    lifting sizes, noiseless codeblocks at the test's four lengths, no CRC, 6 iterations; bit-exact with the oracle too."""
+    rng = np.random.default_rng(300 + bg)
+    for zc in LIFTING_SIZES:
+        for length in cases.ldpc_dec_test_lengths(bg, zc):
+            msg, llr = cases.noiseless_llrs(oracle, rng, bg, zc, zc // 3, length)
+            it, bits = gpu_ctx.ldpc_decode_host(bg, zc, zc // 3, 0, 6, 0.8, llr)
+            assert it == 0 and np.array_equal(bits, msg), (zc, length)
+        full = (66 if bg == 1 else 50) * zc
+        zero = np.zeros(full, np.int8)
+        it, bits = gpu_ctx.ldpc_decode_host(bg, zc, 0, 0, 6, 0.8, zero)
+        assert it == 0 and bits.all()
+        for i in range((24 if bg == 1 else 12) * zc + 2, full, 3):
+            zero[i] = 1 if i % 2 == 0 else -1
+        it, bits = gpu_ctx.ldpc_decode_host(bg, zc, 0, 0, 6, 0.8, zero)
+        assert bits.all()
+        # a noisy codeblock per lifting size against the oracle, with the CRC that size would carry
+        crc_id = 16 if (22 if bg == 1 else 10) * zc < 3824 else 0x24A
+        if (22 if bg == 1 else 10) * zc - zc // 3 > 40:
+            _, noisy = cases.make_ldpc_llrs(oracle, rng, bg, zc, full - 2 * zc, crc_id, zc // 3, 12, 5)
+            want = oracle.ldpc_decode(bg, zc, zc // 3, crc_id, 6, 0.8, noisy)
+            got = gpu_ctx.ldpc_decode_host(bg, zc, zc // 3, crc_id, 6, 0.8, noisy)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]), zc
 
 
 def test_ldpc_decoder_batch_and_argument_checks(gpu_ctx, oracle):

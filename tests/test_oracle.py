@@ -188,6 +188,34 @@ def test_oracle_vs_ref_diagonal_precoding_variants(oracle, ref):
             assert np.array_equal(got, want), (name, impl)
 
 
+@pytest.mark.parametrize("bg", [1, 2])
+def test_oracle_ldpc_decoder_reference_unit_tests(oracle, ref, bg):
+    """The reference's LDPCDecTest / LDPCDecTestZeroLLR / LDPCDecTestAlmostZeroLLR (ldpc_enc_dec_test.cpp:287-358) on
+    the restatement: every lifting size, noiseless codeblocks at the test's four lengths decode to the message in the
+    default 6 iterations without a CRC; all-zero and almost-zero inputs give all ones.  Every fourth lifting size is
+    also compared bit for bit with the compiled reference's generic decoder."""
+    rng = np.random.default_rng(300 + bg)
+    kb = 22 if bg == 1 else 10
+    for n, zc in enumerate(cases.LIFTING_SIZES):
+        for length in cases.ldpc_dec_test_lengths(bg, zc):
+            msg, llr = cases.noiseless_llrs(oracle, rng, bg, zc, zc // 3, length)
+            it, bits = oracle.ldpc_decode(bg, zc, zc // 3, 0, 6, 0.8, llr)
+            assert it == 0 and np.array_equal(bits, msg), (zc, length)
+            if n % 4 == 0:
+                assert np.array_equal(ref.ldpc_decode(bg, zc, zc // 3, 0, 6, 0.8, llr, simd=0)[1], bits)
+        full = (66 if bg == 1 else 50) * zc
+        zero = np.zeros(full, np.int8)
+        it, bits = oracle.ldpc_decode(bg, zc, 0, 0, 6, 0.8, zero)
+        assert it == 0 and bits.all()
+        lo = (24 if bg == 1 else 12) * zc
+        for i in range(lo + 2, full, 3):
+            zero[i] = 1 if i % 2 == 0 else -1
+        assert oracle.ldpc_decode(bg, zc, 0, 0, 6, 0.8, zero)[1].all()
+        if n % 4 == 0:
+            assert ref.ldpc_decode(bg, zc, 0, 0, 6, 0.8, zero, simd=0)[1].all()
+    assert kb * zc == bits.size
+
+
 def test_baseline_config_derived_values(oracle):
     """The derived sizes SURVEY.md section 8d lists for the BASELINE configs."""
     d = oracle.derive(cases.baseline_config(3)[0])
