@@ -314,6 +314,17 @@ int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
 int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, const int8_t* llr,
                            uint8_t* message_packed, uint32_t* iterations);
 
+/* One codeblock through rate dematcher and decoder, host spans, one round trip: the operation of the
+ * per-codeblock accelerator seam hal::hw_accelerator_pusch_dec::{configure,enqueue,dequeue}_operation +
+ * read_operation_outputs (R/include/srsran/hal/phy/upper/channel_processors/pusch/hw_accelerator_pusch_dec.h:
+ * 36-110; caller R/lib/phy/upper/channel_processors/pusch/pusch_decoder_hw_impl.cpp:180-345).  llr: the
+ * dm->rm_length soft bits of the codeblock; soft_buffer: its HARQ buffer of (66 or 50) * Zc LLRs, read
+ * and written; message_packed: Kb * Zc hard bits; *iterations: as nrphy_ldpc_decode.  crc_poly 0 runs
+ * max_iterations without a check. */
+int nrphy_pusch_decode_codeblock_host(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* dm, uint32_t crc_poly,
+                                      uint32_t max_iterations, float scaling_factor, const int8_t* llr,
+                                      int8_t* soft_buffer, int new_data, uint8_t* message_packed, uint32_t* iterations);
+
 /* ---- receive side of seam C ("next" row): OFDM demodulator ---------------
  * Replaces ofdm_symbol_demodulator::demodulate / ofdm_slot_demodulator::demodulate
  * (R/include/srsran/phy/lower/modulation/ofdm_demodulator.h; impl

@@ -244,6 +244,7 @@ def declare(lib, prefix="nrphy_"):
     sig("ldpc_decode_host", i32, vp, P(LdpcDecoderCfg), vp, u8p, P(u32))
     sig("ldpc_rate_dematch", i32, vp, P(LdpcRateDematcherCfg), u32, vp, u32, vp, u32, i32, vp)
     sig("ldpc_rate_dematch_host", i32, vp, P(LdpcRateDematcherCfg), vp, vp, i32)
+    sig("pusch_decode_codeblock_host", i32, vp, P(LdpcRateDematcherCfg), u32, u32, C.c_float, vp, vp, i32, u8p, P(u32))
     return lib
 
 
@@ -259,4 +260,5 @@ ABI_SYMBOLS = [
     "nrphy_ofdm_modulate_symbol_host", "nrphy_ofdm_modulate_slot_host", "nrphy_dft_run", "nrphy_dft_run_host",
     "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",
     "nrphy_ldpc_decode", "nrphy_ldpc_decode_host", "nrphy_ldpc_rate_dematch", "nrphy_ldpc_rate_dematch_host",
+    "nrphy_pusch_decode_codeblock_host",
 ]

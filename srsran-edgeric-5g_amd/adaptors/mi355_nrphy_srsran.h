@@ -21,6 +21,8 @@
 
 #include "srsran/hal/phy/upper/channel_processors/hw_accelerator_pdsch_enc.h"
 #include "srsran/hal/phy/upper/channel_processors/hw_accelerator_pdsch_enc_factory.h"
+#include "srsran/hal/phy/upper/channel_processors/pusch/hw_accelerator_pusch_dec.h"
+#include "srsran/hal/phy/upper/channel_processors/pusch/hw_accelerator_pusch_dec_factory.h"
 #include "srsran/phy/generic_functions/dft_processor.h"
 #include "srsran/phy/generic_functions/generic_functions_factories.h"
 #include "srsran/phy/lower/modulation/modulation_factories.h"
@@ -685,6 +687,132 @@ class ldpc_decoder_factory_adaptor : public srsran::ldpc_decoder_factory
 public:
   explicit ldpc_decoder_factory_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
   std::unique_ptr<srsran::ldpc_decoder> create() override { return std::make_unique<ldpc_decoder_adaptor>(ctx); }
+
+private:
+  std::shared_ptr<context> ctx;
+};
+
+// hal::hw_accelerator_pusch_dec in codeblock mode (hw_accelerator_pusch_dec.h:36-110): the drop-in for the bbdev
+// accelerator that pusch_decoder_hw_impl drives (pusch_decoder_hw_impl.cpp:180-345).  An operation = rate dematching
+// of one codeblock into its HARQ buffer + LDPC decoding.  The soft buffers live with the caller
+// (is_external_harq_supported() == false): enqueue receives the previous soft bits, dequeue returns the updated ones.
+class hw_accelerator_pusch_dec_adaptor : public srsran::hal::hw_accelerator_pusch_dec
+{
+public:
+  explicit hw_accelerator_pusch_dec_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
+
+  void reserve_queue() override {}
+  void free_queue() override {}
+  void free_harq_context_entry(unsigned absolute_cb_id) override { (void)absolute_cb_id; }
+  bool is_external_harq_supported() const override { return false; }
+
+  void configure_operation(const srsran::hal::hw_pusch_decoder_configuration& config, unsigned cb_index = 0) override
+  {
+    slot(cb_index).cfg = config;
+  }
+
+  bool enqueue_operation(srsran::span<const int8_t> data, srsran::span<const int8_t> soft_data = {}, unsigned cb_index = 0) override
+  {
+    using namespace srsran;
+    operation& op = slot(cb_index);
+    if (op.pending) {
+      return false;
+    }
+    const hal::hw_pusch_decoder_configuration& cfg = op.cfg;
+    nrphy_ldpc_rate_dematcher_cfg_t            dm  = {};
+    dm.base_graph      = (cfg.base_graph_index == ldpc_base_graph_type::BG1) ? 1 : 2;
+    dm.lifting_size    = cfg.lifting_size;
+    dm.rv              = cfg.rv;
+    dm.qm              = get_bits_per_symbol(cfg.modulation);
+    dm.nref            = cfg.Nref;
+    dm.nof_filler_bits = cfg.nof_filler_bits;
+    dm.rm_length       = data.size();
+    const unsigned n = ((dm.base_graph == 1) ? 66 : 50) * dm.lifting_size, k = ((dm.base_graph == 1) ? 22 : 10) * dm.lifting_size;
+    op.soft.assign(n, 0);
+    if (!soft_data.empty()) {
+      std::memcpy(op.soft.data(), soft_data.data(), std::min<size_t>(n, soft_data.size()));
+    }
+    op.message.assign((k + 7) / 8, 0);
+    uint32_t crc_poly = 0;
+    if (cfg.use_early_stop) {
+      crc_poly = (cfg.cb_crc_type == hal::hw_dec_cb_crc_type::CRC16) ? 16 : (cfg.cb_crc_type == hal::hw_dec_cb_crc_type::CRC24A) ? 0x24A : 0x24B;
+    }
+    uint32_t iterations = 0;
+    int      rc = nrphy_pusch_decode_codeblock_host(ctx->get(), &dm, crc_poly, cfg.max_nof_ldpc_iterations, 0.8F, data.data(),
+                                               op.soft.data(), cfg.new_data ? 1 : 0, op.message.data(), &iterations);
+    srsran_assert(rc == NRPHY_OK, "nrphy_pusch_decode_codeblock_host failed: {}", nrphy_strerror(rc));
+    op.out.nof_ldpc_iterations = (iterations != 0) ? iterations : cfg.max_nof_ldpc_iterations;
+    // Without early stop the decoder did not look at the CRC: divide the payload + CRC by the generator here.
+    op.out.CRC_pass = (iterations != 0) || (!cfg.use_early_stop && crc_is_zero(op.message, cfg));
+    op.pending      = true;
+    return true;
+  }
+
+  bool dequeue_operation(srsran::span<uint8_t> data, srsran::span<int8_t> soft_data = {}, unsigned segment_index = 0) override
+  {
+    operation& op = slot(segment_index);
+    if (!op.pending) {
+      return false;
+    }
+    std::memcpy(data.data(), op.message.data(), std::min<size_t>(data.size(), op.message.size()));
+    if (!soft_data.empty()) {
+      std::memcpy(soft_data.data(), op.soft.data(), std::min<size_t>(soft_data.size(), op.soft.size()));
+    }
+    op.pending = false;
+    return true;
+  }
+
+  void read_operation_outputs(srsran::hal::hw_pusch_decoder_outputs& out, unsigned cb_index = 0, unsigned absolute_cb_id = 0) override
+  {
+    (void)absolute_cb_id;
+    out = slot(cb_index).out;
+  }
+
+private:
+  struct operation {
+    srsran::hal::hw_pusch_decoder_configuration cfg = {};
+    srsran::hal::hw_pusch_decoder_outputs       out = {};
+    std::vector<int8_t>                         soft;
+    std::vector<uint8_t>                        message;
+    bool                                        pending = false;
+  };
+  operation& slot(unsigned cb_index)
+  {
+    if (ops.size() <= cb_index) {
+      ops.resize(cb_index + 1);
+    }
+    return ops[cb_index];
+  }
+  // Remainder of the message without its filler bits modulo the codeblock CRC polynomial (the early-stop criterion
+  // of ldpc_decoder_impl.cpp:118-126).
+  static bool crc_is_zero(const std::vector<uint8_t>& message, const srsran::hal::hw_pusch_decoder_configuration& cfg)
+  {
+    using namespace srsran;
+    const unsigned order = (cfg.cb_crc_type == hal::hw_dec_cb_crc_type::CRC16) ? 16 : 24;
+    const uint32_t poly  = (cfg.cb_crc_type == hal::hw_dec_cb_crc_type::CRC16) ? 0x11021U : (cfg.cb_crc_type == hal::hw_dec_cb_crc_type::CRC24A) ? 0x1864CFBU : 0x1800063U;
+    const unsigned nbits = ((cfg.base_graph_index == ldpc_base_graph_type::BG1) ? 22 : 10) * cfg.lifting_size - cfg.nof_filler_bits;
+    uint32_t       reg   = 0;
+    for (unsigned i = 0; i != nbits && i / 8 < message.size(); ++i) {
+      reg = (reg << 1) | ((message[i / 8] >> (7 - i % 8)) & 1U);
+      if (reg & (1U << order)) {
+        reg ^= poly;
+      }
+    }
+    return reg == 0;
+  }
+
+  std::shared_ptr<context> ctx;
+  std::vector<operation>   ops;
+};
+
+class hw_accelerator_pusch_dec_factory_adaptor : public srsran::hal::hw_accelerator_pusch_dec_factory
+{
+public:
+  explicit hw_accelerator_pusch_dec_factory_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
+  std::unique_ptr<srsran::hal::hw_accelerator_pusch_dec> create() override
+  {
+    return std::make_unique<hw_accelerator_pusch_dec_adaptor>(ctx);
+  }
 
 private:
   std::shared_ptr<context> ctx;

@@ -378,15 +378,16 @@ struct nrphy_ctx {
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
   // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
   std::mutex host_mutex;
-  void*      scratch[8]       = {};
-  size_t     scratch_bytes[8] = {};
+  std::mutex host_call_mutex; // serialises host-span calls that are built from device-pointer calls taking host_mutex
+  void*      scratch[9]       = {};
+  size_t     scratch_bytes[9] = {};
 };
 
 namespace {
 
 // Staging buffer `slot` of the context with room for `bytes` (reallocated only when it has to grow).
 enum ScratchSlot { SCRATCH_TB = 0, SCRATCH_GRID, SCRATCH_CW_RM, SCRATCH_CW_SCR, SCRATCH_IQ, SCRATCH_SMALL,
-                   SCRATCH_DECODER, SCRATCH_DEMATCH_OPS };
+                   SCRATCH_DECODER, SCRATCH_DEMATCH_OPS, SCRATCH_RX };
 void* ctx_scratch(nrphy_ctx* ctx, ScratchSlot slot, size_t bytes)
 {
   if (bytes > ctx->scratch_bytes[slot]) {
@@ -1868,6 +1869,62 @@ extern "C" int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder
   (void)hipFree(d_llr);
   (void)hipFree(d_out);
   return rc;
+}
+
+// One codeblock through rate dematcher and decoder with one round trip over the link: what a per-codeblock
+// accelerator interface (hal::hw_accelerator_pusch_dec) asks for.
+extern "C" int nrphy_pusch_decode_codeblock_host(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* dm,
+                                                 uint32_t crc_poly, uint32_t max_iterations, float scaling_factor,
+                                                 const int8_t* llr, int8_t* soft_buffer, int new_data,
+                                                 uint8_t* message_packed, uint32_t* iterations)
+{
+  if (ctx == nullptr || dm == nullptr || llr == nullptr || soft_buffer == nullptr || message_packed == nullptr ||
+      (dm->base_graph != 1 && dm->base_graph != 2) || lifting_position(dm->lifting_size) < 0) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const unsigned zc = dm->lifting_size, n = ((dm->base_graph == 1) ? 66U : 50U) * zc;
+  const unsigned k = ((dm->base_graph == 1) ? 22U : 10U) * zc, kbytes = (k + 7) / 8;
+  const size_t   off_soft = ((size_t)dm->rm_length + 63) & ~(size_t)63, off_out = off_soft + (((size_t)n + 63) & ~(size_t)63);
+  const size_t   off_it = off_out + (((size_t)kbytes + 63) & ~(size_t)63);
+  std::lock_guard<std::mutex> host_lock(ctx->host_call_mutex);
+  HIP_TRY(hipSetDevice(ctx->device));
+  uint8_t* base = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    base = (uint8_t*)ctx_scratch(ctx, SCRATCH_RX, off_it + 64);
+  }
+  if (base == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  HIP_TRY(hipMemcpyAsync(base, llr, dm->rm_length, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(base + off_soft, soft_buffer, n, hipMemcpyHostToDevice, ctx->stream));
+  int rc = nrphy_ldpc_rate_dematch(ctx, dm, 1, (const int8_t*)base, dm->rm_length, (int8_t*)(base + off_soft), n, new_data,
+                                   ctx->stream);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  nrphy_ldpc_decoder_cfg_t dec;
+  dec.base_graph      = dm->base_graph;
+  dec.lifting_size    = zc;
+  dec.nof_filler_bits = dm->nof_filler_bits;
+  dec.crc_poly        = crc_poly;
+  dec.nof_llr         = n;
+  dec.max_iterations  = max_iterations;
+  dec.scaling_factor  = scaling_factor;
+  rc = nrphy_ldpc_decode(ctx, &dec, 1, (const int8_t*)(base + off_soft), n, base + off_out, kbytes,
+                         (uint32_t*)(base + off_it), ctx->stream);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  uint32_t it = 0;
+  HIP_TRY(hipMemcpyAsync(soft_buffer, base + off_soft, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(message_packed, base + off_out, kbytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&it, base + off_it, sizeof(it), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (iterations) {
+    *iterations = it;
+  }
+  return NRPHY_OK;
 }
 
 extern "C" int nrphy_ldpc_encode(nrphy_ctx_t* ctx, uint32_t base_graph, uint32_t lifting_size, uint32_t n_cb,

@@ -124,6 +124,22 @@ class Context:
                                                      int(new_data)), "nrphy_ldpc_rate_dematch_host")
         return out
 
+    def pusch_decode_codeblock_host(self, base_graph, lifting_size, rv, qm, nref, nof_filler, crc_poly, max_iterations,
+                                    scaling, new_data, llr_in, soft_buffer):
+        """Rate dematcher + decoder of one codeblock on host spans (the hw_accelerator_pusch_dec operation):
+        returns (iterations or 0, Kb*Zc hard bits, updated soft buffer)."""
+        llr_in = np.ascontiguousarray(llr_in, dtype=np.int8)
+        soft = np.array(soft_buffer, dtype=np.int8, copy=True)
+        cfg = abi.LdpcRateDematcherCfg(base_graph, lifting_size, rv, qm, nref, nof_filler, llr_in.size)
+        k = (22 if base_graph == 1 else 10) * lifting_size
+        packed = np.zeros((k + 7) // 8, np.uint8)
+        it = C.c_uint32(0)
+        _check(self.lib.nrphy_pusch_decode_codeblock_host(self.handle, C.byref(cfg), crc_poly, max_iterations, scaling,
+                                                          llr_in.ctypes.data, soft.ctypes.data, int(new_data),
+                                                          packed.ctypes.data, C.byref(it)),
+               "nrphy_pusch_decode_codeblock_host")
+        return int(it.value), np.unpackbits(packed)[:k], soft
+
     def ldpc_decode(self, cfg, n_cb, d_llr, llr_stride, d_out, out_stride, d_iterations=None, stream=None):
         """ldpc_decoder::decode for n_cb codeblocks resident in HBM (cfg: abi.LdpcDecoderCfg)."""
         _check(self.lib.nrphy_ldpc_decode(self.handle, C.byref(cfg), n_cb, _dptr(d_llr), llr_stride, _dptr(d_out),

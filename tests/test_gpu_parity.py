@@ -698,3 +698,36 @@ def test_ldpc_rate_dematch_then_decode_batch(gpu_ctx, oracle):
         it_o, bits_o = oracle.ldpc_decode(bg, zc, nf, 0x24B, 8, 0.8, soft_host[i, :n])
         assert int(its[i]) == it_o >= 1 and np.array_equal(bits[i], bits_o)
         assert np.array_equal(bits[i, : k - nf], msgs[i][: k - nf])
+
+
+def test_pusch_decode_codeblock_host_harq(gpu_ctx, oracle):
+    """The per-codeblock accelerator operation (rate dematcher + decoder, host spans): a first transmission too noisy
+    to decode, then retransmissions with other redundancy versions combined into the same soft buffer until the CRC
+    passes -- every step bit-exact with the oracle's dematcher and decoder run one after the other."""
+    rng = np.random.default_rng(909)
+    for bg, zc, qm, e, nf, crc_id in ((1, 384, 8, 8960, 72, 0x24B), (2, 144, 2, 2000, 104, 16), (1, 64, 4, 1800, 0, 0x24A)):
+        kb, n = (22, 66 * zc) if bg == 1 else (10, 50 * zc)
+        k = kb * zc
+        crc_len = 16 if crc_id == 16 else 24
+        payload = rng.integers(0, 2, k - nf - crc_len, dtype=np.uint8)
+        crc = oracle.crc_bits(crc_id, payload)
+        msg = np.concatenate([payload, [(crc >> (crc_len - 1 - i)) & 1 for i in range(crc_len)],
+                              np.zeros(nf, np.uint8)]).astype(np.uint8)
+        cb = oracle.ldpc_encode(bg, zc, np.packbits(msg), n)
+        soft_gpu = rng.integers(-120, 121, n).astype(np.int8)  # stale content: rv 0 as new data rebuilds the whole buffer
+        soft_cpu = soft_gpu.copy()
+        decoded = False
+        for tx, rv in enumerate((0, 2, 3, 1)):
+            tx_bits = np.unpackbits(oracle.rate_match(bg, zc, rv, qm, 0, nf, cb, e))[:e]
+            llr = np.clip(np.rint((1.0 - 2.0 * tx_bits) * 8 + rng.normal(0, 7.0, e)), -120, 120).astype(np.int8)
+            soft_cpu = oracle.ldpc_rate_dematch(bg, zc, rv, qm, 0, nf, tx == 0, llr, soft_cpu)
+            it_o, bits_o = oracle.ldpc_decode(bg, zc, nf, crc_id, 6, 0.8, soft_cpu)
+            it_g, bits_g, soft_gpu = gpu_ctx.pusch_decode_codeblock_host(bg, zc, rv, qm, 0, nf, crc_id, 6, 0.8, tx == 0,
+                                                                        llr, soft_gpu)
+            assert np.array_equal(soft_gpu, soft_cpu), (zc, tx)
+            assert it_g == it_o and np.array_equal(bits_g, bits_o), (zc, tx)
+            if it_g:
+                assert np.array_equal(bits_g[: k - nf], msg[: k - nf])
+                decoded = True
+                break
+        assert decoded, "HARQ combining of four transmissions should decode (%d, %d)" % (bg, zc)
