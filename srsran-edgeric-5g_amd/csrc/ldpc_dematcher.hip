@@ -116,43 +116,83 @@ __global__ __launch_bounds__(256) void ldpc_dematch_kernel(DematchLaunch p)
 // One workgroup per codeblock: the input is read once, coalesced, into LDS; the strided reads of the deinterleaver
 // then stay on chip.
 constexpr uint32_t DEMATCH_LDS_THREADS = 1024;
-constexpr uint32_t DEMATCH_LDS_ROUNDS  = 7; // 66 * 384 soft bits / (1024 threads * 4)
 
+// One workgroup per codeblock, everything on chip: the input and the soft buffer are read once, coalesced, into LDS;
+// the operations run one after the other over their own ranges (no per-position range tests, the strided reads of the
+// deinterleaver stay in LDS); the soft buffer is written back once.  Soft bits no operation covers are written back
+// unchanged.
 template <bool EXT>
 __global__ __launch_bounds__(DEMATCH_LDS_THREADS) void ldpc_dematch_lds_kernel(DematchLaunch p)
 {
-  extern __shared__ __attribute__((aligned(16))) int8_t staged[];
-  const int8_t*  in = p.in + (size_t)blockIdx.x * p.in_stride;
-  const uint32_t e  = p.cols * p.qm;
-  if (((reinterpret_cast<uintptr_t>(in)) & 3u) == 0) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(in);
-    uint32_t*       dst = reinterpret_cast<uint32_t*>(staged);
-    for (uint32_t i = threadIdx.x; i < e / 4u; i += blockDim.x) {
+  extern __shared__ __attribute__((aligned(16))) int8_t dematch_lds[];
+  const uint32_t e      = p.cols * p.qm;
+  int8_t*        staged = dematch_lds;                       // [e]
+  int8_t*        soft   = dematch_lds + ((e + 15u) & ~15u);  // [block_length]
+  const int8_t*  in      = p.in + (size_t)blockIdx.x * p.in_stride;
+  int8_t*        out_row = p.out + (size_t)blockIdx.x * p.out_stride;
+  const uint32_t T = blockDim.x, tid = threadIdx.x;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(out_row); // dword aligned (checked by the launcher)
+    uint32_t*       dst = reinterpret_cast<uint32_t*>(soft);
+    for (uint32_t i = tid; i < p.block_length / 4u; i += T) {
       dst[i] = src[i];
     }
-    for (uint32_t i = (e & ~3u) + threadIdx.x; i < e; i += blockDim.x) {
+  }
+  if ((reinterpret_cast<uintptr_t>(in) & 3u) == 0) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in);
+    uint32_t*       dst = reinterpret_cast<uint32_t*>(staged);
+    for (uint32_t i = tid; i < e / 4u; i += T) {
+      dst[i] = src[i];
+    }
+    for (uint32_t i = (e & ~3u) + tid; i < e; i += T) {
       staged[i] = in[i];
     }
   } else {
-    for (uint32_t i = threadIdx.x; i < e; i += blockDim.x) {
+    for (uint32_t i = tid; i < e; i += T) {
       staged[i] = in[i];
     }
   }
-  // what the soft buffer holds: all loads of this thread in flight while the input is being staged
-  int8_t*  out_row = p.out + (size_t)blockIdx.x * p.out_stride;
-  uint32_t old[DEMATCH_LDS_ROUNDS];
-#pragma unroll
-  for (uint32_t r = 0; r != DEMATCH_LDS_ROUNDS; ++r) {
-    const uint32_t first = (r * DEMATCH_LDS_THREADS + threadIdx.x) * 4u;
-    old[r]               = first < p.block_length ? *reinterpret_cast<const uint32_t*>(out_row + first) : 0u;
-  }
   __syncthreads();
   const float rcp_cols = 1.0f / (float)p.cols;
-#pragma unroll
-  for (uint32_t r = 0; r != DEMATCH_LDS_ROUNDS; ++r) {
-    const uint32_t first = (r * DEMATCH_LDS_THREADS + threadIdx.x) * 4u;
-    if (first < p.block_length) {
-      dematch_positions<4, EXT>(p, staged, out_row, first, old[r], rcp_cols);
+  for (uint32_t k = 0; k != p.n_ops; ++k) { // workgroup-uniform
+    const DematchOp op  = EXT ? p.ops_ext[k] : p.ops[k];
+    int8_t*         dst = soft + op.begin;
+    switch (op.kind) {
+      case DEMATCH_ZERO:
+      case DEMATCH_FILL: {
+        const int8_t   value = op.kind == DEMATCH_ZERO ? 0 : 127; // LLR_INFINITY: a filler bit is a certain zero
+        const uint32_t head  = min(op.count, (4u - (op.begin & 3u)) & 3u); // bytes up to the first aligned dword
+        const uint32_t words = (op.count - head) >> 2;
+        if (tid < head) {
+          dst[tid] = value;
+        }
+        uint32_t* dst32 = reinterpret_cast<uint32_t*>(dst + head);
+        for (uint32_t q = tid; q < words; q += T) {
+          dst32[q] = 0x01010101u * (uint32_t)(uint8_t)value;
+        }
+        for (uint32_t q = head + 4u * words + tid; q < op.count; q += T) {
+          dst[q] = value;
+        }
+        break;
+      }
+      case DEMATCH_COPY:
+        for (uint32_t q = tid; q < op.count; q += T) {
+          dst[q] = (int8_t)dematch_fetch(staged, op.src + q, p.qm, p.cols, rcp_cols);
+        }
+        break;
+      default:
+        for (uint32_t q = tid; q < op.count; q += T) {
+          dst[q] = (int8_t)dematch_sum(dematch_fetch(staged, op.src + q, p.qm, p.cols, rcp_cols), dst[q]);
+        }
+        break;
+    }
+    lds_barrier();
+  }
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(soft);
+    uint32_t*       dst = reinterpret_cast<uint32_t*>(out_row);
+    for (uint32_t i = tid; i < p.block_length / 4u; i += T) {
+      dst[i] = src[i];
     }
   }
 }
@@ -163,8 +203,9 @@ static void launch_dematch_variant(const DematchLaunch& p, uint32_t n_cb, hipStr
   // four soft bits per thread when every codeblock row is dword aligned (block lengths are multiples of 4 only for even Zc)
   const bool     vec4 = ((reinterpret_cast<uintptr_t>(p.out) | p.out_stride | p.block_length) & 3u) == 0;
   const uint32_t e    = p.cols * p.qm;
-  if (vec4 && e <= 60u * 1024u) {
-    hipLaunchKernelGGL(ldpc_dematch_lds_kernel<EXT>, dim3(n_cb), dim3(DEMATCH_LDS_THREADS), (e + 15u) & ~15u, stream, p);
+  const uint32_t lds  = ((e + 15u) & ~15u) + ((p.block_length + 15u) & ~15u);
+  if (vec4 && lds <= 64u * 1024u) {
+    hipLaunchKernelGGL(ldpc_dematch_lds_kernel<EXT>, dim3(n_cb), dim3(DEMATCH_LDS_THREADS), lds, stream, p);
   } else if (vec4) {
     const uint32_t blocks = (p.block_length / 4 + 255) / 256;
     hipLaunchKernelGGL((ldpc_dematch_kernel<4, EXT>), dim3(blocks, n_cb), dim3(256), 0, stream, p);
