@@ -63,7 +63,7 @@ typedef struct nrphy_pdsch_pdu {
   uint32_t rnti;
   uint32_t bwp_start_rb;
   uint32_t bwp_size_rb;
-  uint32_t cp;               /* 0 = normal (the only one the reference's processor handles with 14 symbols) */
+  uint32_t cp;               /* 0 = normal (14 symbols per slot), 1 = extended (12; grid rows 12 and 13 stay zero) */
   uint32_t qm;               /* bits per symbol of codeword 0: 2 QPSK, 4 16QAM, 6 64QAM, 8 256QAM */
   uint32_t rv;               /* redundancy version 0..3 */
   uint32_t nof_codewords;    /* must be 1 (validator) */
@@ -120,7 +120,7 @@ typedef struct nrphy_ofdm_config {
   uint32_t numerology;
   uint32_t bw_rb;
   uint32_t dft_size;
-  uint32_t cp;        /* 0 normal, 1 extended */
+  uint32_t cp;        /* 0 normal, 1 extended (12 symbols per slot, each with a cyclic prefix of dft_size / 4) */
   float    scale;
   double   center_freq_hz;
 } nrphy_ofdm_config_t;

@@ -160,8 +160,11 @@ pdsch_processor::pdu_t to_pdu(const nrphy_pdsch_pdu_t& in)
   }
   pdu.n_id      = in.n_id;
   pdu.ref_point = in.ref_point ? pdsch_processor::pdu_t::PRB0 : pdsch_processor::pdu_t::CRB0;
-  pdu.dmrs_symbol_mask.resize(14);
-  for (unsigned l = 0; l != 14; ++l) {
+  // The validator wants a mask as long as the slot (12 symbols with extended cyclic prefix); a bit beyond it makes the
+  // PDU invalid, which a 14-bit mask reproduces.
+  const unsigned mask_size = (in.cp && (in.dmrs_symbol_mask >> 12) == 0) ? 12 : 14;
+  pdu.dmrs_symbol_mask.resize(mask_size);
+  for (unsigned l = 0; l != mask_size; ++l) {
     if ((in.dmrs_symbol_mask >> l) & 1U) {
       pdu.dmrs_symbol_mask.set(l);
     }

@@ -183,7 +183,7 @@ public:
     alloc.re_mask  = ~re_prb_mask();
     alloc.symbols.fill(pdu.start_symbol_index, pdu.start_symbol_index + pdu.nof_symbols);
     std::vector<cbf16_t> packed(nof_subc);
-    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+    for (unsigned l = 0, nsymb = get_nsymb_per_slot(pdu.cp); l != nsymb; ++l) {
       bounded_bitset<MAX_RB * NRE> mask(nof_subc);
       alloc.get_inclusion_mask(mask, l);
       reserved.get_exclusion_mask(mask, l);
@@ -362,11 +362,12 @@ public:
       std::fill(output.begin(), output.end(), cf_t());
       return;
     }
-    unsigned slot = symbol_index / NRPHY_NSYMB, l = symbol_index % NRPHY_NSYMB;
+    const unsigned nsymb = cfg.cp ? 12 : 14; // symbols per slot; the staging grid keeps NRPHY_NSYMB rows per port
+    unsigned       slot = symbol_index / nsymb, l = symbol_index % nsymb;
     if (&grid != cached_grid || slot != cached_slot || (l == 0 && port_index == 0)) {
       unsigned nof_subc = cfg.bw_rb * NRE;
       for (unsigned port = 0; port != nof_ports; ++port) {
-        for (unsigned sym = 0; sym != NRPHY_NSYMB; ++sym) {
+        for (unsigned sym = 0; sym != nsymb; ++sym) {
           span<const cbf16_t> view = grid.get_view(port, sym);
           std::memcpy(&staging[(static_cast<size_t>(port) * NRPHY_NSYMB + sym) * nof_subc], view.data(), nof_subc * sizeof(cbf16_t));
         }
@@ -380,7 +381,7 @@ public:
     }
     unsigned offset = 0;
     for (unsigned sym = 0; sym != l; ++sym) {
-      offset += get_symbol_size(slot * NRPHY_NSYMB + sym);
+      offset += get_symbol_size(slot * nsymb + sym);
     }
     std::memcpy(output.data(), &iq[static_cast<size_t>(port_index) * slot_size + offset], output.size() * sizeof(cf_t));
   }
@@ -401,28 +402,29 @@ class ofdm_slot_modulator_adaptor : public srsran::ofdm_slot_modulator
 {
 public:
   ofdm_slot_modulator_adaptor(std::shared_ptr<context> ctx_, const srsran::ofdm_modulator_configuration& config, unsigned nof_ports_) :
-    symbol_modulator(std::move(ctx_), config, nof_ports_)
+    symbol_modulator(std::move(ctx_), config, nof_ports_), nsymb(srsran::get_nsymb_per_slot(config.cp))
   {
   }
   unsigned get_slot_size(unsigned slot_index) const override
   {
     unsigned n = 0;
-    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
-      n += symbol_modulator.get_symbol_size(NRPHY_NSYMB * slot_index + l);
+    for (unsigned l = 0; l != nsymb; ++l) {
+      n += symbol_modulator.get_symbol_size(nsymb * slot_index + l);
     }
     return n;
   }
   void modulate(srsran::span<srsran::cf_t> output, const srsran::resource_grid_reader& grid, unsigned port_index, unsigned slot_index) override
   {
-    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) { // ofdm_modulator_impl.cpp:115-139
-      unsigned size = symbol_modulator.get_symbol_size(NRPHY_NSYMB * slot_index + l);
-      symbol_modulator.modulate(output.first(size), grid, port_index, NRPHY_NSYMB * slot_index + l);
+    for (unsigned l = 0; l != nsymb; ++l) { // ofdm_modulator_impl.cpp:115-139
+      unsigned size = symbol_modulator.get_symbol_size(nsymb * slot_index + l);
+      symbol_modulator.modulate(output.first(size), grid, port_index, nsymb * slot_index + l);
       output = output.last(output.size() - size);
     }
   }
 
 private:
   ofdm_symbol_modulator_adaptor symbol_modulator;
+  unsigned                      nsymb;
 };
 
 class ofdm_modulator_factory_adaptor : public srsran::ofdm_modulator_factory
@@ -485,7 +487,7 @@ public:
     int      rc       = nrphy_ofdm_demodulate_symbol_host(plan, reinterpret_cast<const float*>(input.data()), input.size(),
                                                symbol_index, window_offset, staging.data());
     srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_demodulate_symbol_host failed: {}", nrphy_strerror(rc));
-    grid.put(port_index, symbol_index % NRPHY_NSYMB, 0, 1, span<const cbf16_t>(staging.data(), nof_subc));
+    grid.put(port_index, symbol_index % (cfg.cp ? 12 : 14), 0, 1, span<const cbf16_t>(staging.data(), nof_subc));
   }
 };
 
@@ -504,7 +506,7 @@ public:
     unsigned nof_subc = cfg.bw_rb * NRE;
     int rc = nrphy_ofdm_demodulate_slot_host(plan, reinterpret_cast<const float*>(input.data()), slot_index, window_offset, staging.data());
     srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_demodulate_slot_host failed: {}", nrphy_strerror(rc));
-    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+    for (unsigned l = 0, nsymb = cfg.cp ? 12 : 14; l != nsymb; ++l) {
       grid.put(port_index, l, 0, 1, span<const cbf16_t>(&staging[static_cast<size_t>(l) * nof_subc], nof_subc));
     }
   }

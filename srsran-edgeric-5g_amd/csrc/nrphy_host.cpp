@@ -513,7 +513,7 @@ extern "C" int nrphy_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
   }
   if ((pdu->qm != 2 && pdu->qm != 4 && pdu->qm != 6 && pdu->qm != 8) || pdu->rv > 3 ||
       (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->tb_size_bytes == 0 || pdu->nof_prg == 0 ||
-      pdu->prg_size_rb == 0 || pdu->precoding == nullptr || pdu->cp != 0) {
+      pdu->prg_size_rb == 0 || pdu->precoding == nullptr || pdu->cp > 1) {
     return NRPHY_ERR_INVALID_PDU;
   }
   return NRPHY_OK;
@@ -1094,6 +1094,8 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
       pd.dmrs_amplitude = (float)(M_SQRT1_2 * (double)amp);
     }
     for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+      // 14 symbols per slot also with extended cyclic prefix: the reference takes get_nsymb_per_slot(NORMAL) here
+      // (dmrs_pdsch_processor_impl.cpp:95), and a drop-in has to produce the same pilots.
       const uint64_t a  = (uint64_t)(14 * pdu.slot_index + l + 1) * (2 * pdu.scrambling_id + 1);
       pd.dmrs_c_init[l] = (uint32_t)(((a << 17) + (2 * pdu.scrambling_id + (pdu.n_scid ? 1 : 0))) & 0x7FFFFFFFULL);
       if ((pdu.dmrs_symbol_mask >> l) & 1U) {
@@ -1953,7 +1955,7 @@ extern "C" int nrphy_ofdm_plan_create(nrphy_ctx_t* ctx, const nrphy_ofdm_config_
                                       nrphy_ofdm_plan_t** out)
 {
   if (ctx == nullptr || cfg == nullptr || out == nullptr || nof_ports == 0 || cfg->numerology > 4 ||
-      !dft_size_supported(cfg->dft_size) || cfg->dft_size <= 12 * cfg->bw_rb || cfg->bw_rb == 0 || cfg->cp != 0 ||
+      !dft_size_supported(cfg->dft_size) || cfg->dft_size <= 12 * cfg->bw_rb || cfg->bw_rb == 0 || cfg->cp > 1 ||
       !std::isnormal(cfg->scale)) {
     return NRPHY_ERR_ARGUMENT;
   }
@@ -1969,8 +1971,8 @@ extern "C" int nrphy_ofdm_plan_create(nrphy_ctx_t* ctx, const nrphy_ofdm_config_
   plan->ctx           = ctx;
   plan->cfg           = *cfg;
   plan->nof_ports     = nof_ports;
-  plan->nsymb         = 14;
-  plan->nsym_subframe = 14U << cfg->numerology;
+  plan->nsymb         = cfg->cp ? 12 : 14; // get_nsymb_per_slot (cyclic_prefix.h:108-114)
+  plan->nsym_subframe = plan->nsymb << cfg->numerology;
   plan->slot_stride   = nrphy_ofdm_slot_size(cfg, 0);
   // Phase compensation (TS 38.211 Section 5.4; phase_compensation_lut.h:49-82) times the scale.
   const double        srate = 15000.0 * (double)(1U << cfg->numerology) * (double)cfg->dft_size;
@@ -2116,8 +2118,11 @@ extern "C" int nrphy_ofdm_demodulate_slot_host(nrphy_ofdm_plan_t* plan, const fl
       break;
     }
     rc = NRPHY_ERR_DEVICE;
+    // Only the symbols a slot has (12 with extended cyclic prefix) are written, as by the reference's demodulator.
+    const size_t port_bytes = (size_t)NRPHY_NSYMB * 12 * plan->cfg.bw_rb * 4;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-        hipMemcpy(grid, d_grid, grid_words * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        hipMemcpy2D(grid, port_bytes, d_grid, port_bytes, (size_t)plan->nsymb * 12 * plan->cfg.bw_rb * 4,
+                    plan->nof_ports, hipMemcpyDeviceToHost) != hipSuccess) {
       break;
     }
     rc = NRPHY_OK;

@@ -190,3 +190,21 @@ def noiseless_llrs(oracle, rng, bg, zc, nof_filler, length):
         msg[-nof_filler:] = 0
     cb = np.unpackbits(oracle.ldpc_encode(bg, zc, np.packbits(msg), length))[:length]
     return msg, (10 * (1 - 2 * cb.astype(np.int8))).astype(np.int8)
+
+
+# ---- extended cyclic prefix (12 symbols per slot; the reference's validator and processors accept it) ---------
+def extended_cp_pdus(tbs):
+    """[(pdu, nof_ports, nof_subc)] with cp = 1: every modulation, 1-4 layers, DM-RS on several of the 12 symbols,
+    allocations ending on the last symbol.  tbs: a TBS calculator (oracle.tbs)."""
+    out = []
+    for layers, qm, dmrs, start, nsym, slot in ((1, 2, (2, 9), 1, 11, 3), (2, 6, (2,), 0, 12, 0), (4, 8, (3, 7, 11), 2, 10, 7),
+                                                (3, 4, (0, 6), 0, 9, 19)):
+        n_prb = 30
+        dmrs_per_prb = 6 * len(dmrs) * 2
+        tb_bits = tbs(nsym, dmrs_per_prb, 0, qm, 600.0, layers, n_prb)
+        pdu = abi.make_pdu(bwp_size_rb=n_prb, qm=qm, dmrs_symbols=dmrs, prb_start=0, prb_count=n_prb, start_symbol=start,
+                           nof_symbols=nsym, precoding=abi.identity_precoding(layers), tb_size_bytes=tb_bits // 8, cp=1,
+                           slot_index=slot, scrambling_id=9 + layers, n_id=3, rnti=77, n_scid=layers & 1,
+                           base_graph=1 if qm > 2 else 2)
+        out.append((pdu, layers, n_prb * 12))
+    return out

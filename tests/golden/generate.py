@@ -96,6 +96,15 @@ for name, (mu, bw, n, fc, slot) in {"n4096": (1, 273, 4096, 3.5e9, 1), "n2048": 
     og[name + "_grid"] = grid
     og[name + "_iq"] = iq
     og[name + "_cfg"] = np.array([mu, bw, n, fc, slot], dtype=np.float64)
+# extended cyclic prefix (12 symbols per slot, 60 kHz SCS: the numerology-2 rows of ofdm_modulator_test_data.h); own
+# generator so that the vectors above do not change
+rng = np.random.default_rng(38213)
+for name, (mu, bw, n, fc, slot) in {"x512": (2, 24, 512, 3.5e9, 3), "x2048": (2, 96, 2048, 28e9, 0)}.items():
+    cfg = abi.OfdmConfig(mu, bw, n, 1, 1.0 / np.sqrt(n), fc)
+    grid = (rng.standard_normal((1, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    og[name + "_grid"] = grid
+    og[name + "_iq"] = r.ofdm_slot(cfg, grid, slot)
+    og[name + "_cfg"] = np.array([mu, bw, n, fc, slot, 1], dtype=np.float64)
 np.savez_compressed(os.path.join(HERE, "ofdm_modulator.npz"), **og)
 
 # 5. OFDM demodulator ("next" row, PUSCH receive side): random IQ -> reference grid (cbf16), with and without a DFT
@@ -110,5 +119,13 @@ for name, (mu, bw, n, fc, slot, wo) in {"d4096": (1, 273, 4096, 3.5e9, 1, 0), "d
     dg[name + "_iq"] = iq
     dg[name + "_grid"] = r.ofdm_demod_slot(cfg, iq, slot, wo)
     dg[name + "_cfg"] = np.array([mu, bw, n, fc, slot, wo], dtype=np.float64)
+rng = np.random.default_rng(38214)
+for name, (mu, bw, n, fc, slot, wo) in {"dx1024w": (2, 48, 1024, 3.5e9, 1, 7)}.items():
+    cfg = abi.OfdmConfig(mu, bw, n, 1, 1.0 / np.sqrt(n), fc)
+    size = backends.pkg.lib.slot_size(cfg, slot)
+    iq = (rng.standard_normal((2, size)) + 1j * rng.standard_normal((2, size))).astype(np.complex64)
+    dg[name + "_iq"] = iq
+    dg[name + "_grid"] = r.ofdm_demod_slot(cfg, iq, slot, wo)
+    dg[name + "_cfg"] = np.array([mu, bw, n, fc, slot, wo, 1], dtype=np.float64)
 np.savez_compressed(os.path.join(HERE, "ofdm_demodulator.npz"), **dg)
 print("golden vectors written to", HERE)

@@ -144,6 +144,27 @@ def test_pdsch_diagonal_precoding_variants(gpu_ctx, oracle):
             run_single(gpu_ctx, oracle, pdu, cases.random_tb(rng, pdu), w.shape[1], 30 * 12)
 
 
+def test_pdsch_extended_cyclic_prefix(gpu_ctx, oracle):
+    """Extended cyclic prefix end to end: PDSCH grid and codeword bit-exact, then the 12-symbol OFDM slot."""
+    import torch
+    rng = np.random.default_rng(1212)
+    for pdu, nof_ports, nof_subc in cases.extended_cp_pdus(oracle.tbs):
+        assert gpu_ctx.lib.nrphy_pdsch_validate(C.byref(pdu)) == 0
+        grid, _ = run_single(gpu_ctx, oracle, pdu, cases.random_tb(rng, pdu), nof_ports, nof_subc)
+        cfg = abi.OfdmConfig(2, nof_subc // 12, 512, 1, 0.05, 3.5e9)
+        plan = lib.OfdmPlan(gpu_ctx, cfg, nof_ports)
+        slot = pdu.slot_index % 4
+        iq = plan.modulate_slot_host(grid, slot)
+        want = oracle.ofdm_slot(cfg, grid, slot)
+        assert iq.shape == want.shape and iq.shape[1] == 12 * (512 + 128)
+        assert rel_err(iq, want) < 1e-5
+        plan.close()
+    bad = cases.extended_cp_pdus(oracle.tbs)[0][0]
+    bad.dmrs_symbol_mask |= 1 << 12
+    bad.nof_symbols = 13
+    assert gpu_ctx.lib.nrphy_pdsch_validate(C.byref(bad)) == abi.ERR_INVALID_PDU
+
+
 def edge_case_pdus():
     rng = np.random.default_rng(99)
     w22 = (rng.standard_normal((3, 2, 2, 2)) * 0.5).astype(np.float32)       # 3 PRGs, complex random weights
@@ -309,12 +330,14 @@ def test_dft_vs_oracle(gpu_ctx, oracle, size, inverse):
         assert rel_err(out[i], want) < 1e-5   # north-star tolerance; reference test uses MSE < 1e-6 / peak < 1e-3
 
 
-@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024", "n1536", "n3072", "n768", "n384"])
+@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024", "n1536", "n3072", "n768", "n384", "x512", "x2048"])
 def test_ofdm_modulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
     import torch
     g = np.load(os.path.join(cases.GOLDEN, "ofdm_modulator.npz"))
-    mu, bw, n, fc, slot = g[name + "_cfg"]
-    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), 0, 1.0 / np.sqrt(n), float(fc))
+    mu, bw, n, fc, slot = g[name + "_cfg"][:5]
+    ext = int(g[name + "_cfg"][5]) if len(g[name + "_cfg"]) > 5 else 0   # x...: extended cyclic prefix, 12 symbols
+    nsymb = 12 if ext else 14
+    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), ext, 1.0 / np.sqrt(n), float(fc))
     grid = g[name + "_grid"]
     plan = lib.OfdmPlan(gpu_ctx, cfg, 1)
     assert plan.slot_stride == lib.slot_size(cfg, 0)
@@ -329,15 +352,17 @@ def test_ofdm_modulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
     assert rel_err(iq[: len(want)], g[name + "_iq"][0]) < 1e-5   # reference output (its own test allows 5e-5)
     # Structure checks of ofdm_modulator_unittest.cpp: the cyclic prefix repeats the symbol tail.
     off = 0
-    for l in range(14):
-        size = lib.symbol_size(cfg, 14 * int(slot) + l)
+    for l in range(nsymb):
+        size = lib.symbol_size(cfg, nsymb * int(slot) + l)
         cp = size - int(n)
+        assert cp == (int(n) // 4 if ext else cp)
         assert np.array_equal(iq[off: off + cp], iq[off + int(n): off + size])
         off += size
+    assert off == len(want)
     # Host-span single-symbol entry point (ofdm_symbol_modulator::modulate semantics).
-    sym = 14 * int(slot) + 3
+    sym = nsymb * int(slot) + 3
     one = plan.modulate_symbol_host(grid, 0, sym)
-    start = sum(lib.symbol_size(cfg, 14 * int(slot) + l) for l in range(3))
+    start = sum(lib.symbol_size(cfg, nsymb * int(slot) + l) for l in range(3))
     assert np.array_equal(one, iq[start: start + len(one)])
     plan.close()
 
@@ -354,14 +379,15 @@ def assert_bf16_grids_close(got, want, min_exact=0.99):
     assert np.mean(got == want) >= min_exact
 
 
-@pytest.mark.parametrize("name", ["d4096", "d2048w", "d1536", "d512w"])
+@pytest.mark.parametrize("name", ["d4096", "d2048w", "d1536", "d512w", "dx1024w"])
 def test_ofdm_demodulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
     """Receive side of seam C (ofdm_slot_demodulator): device path against the oracle and the reference's output."""
     import torch
     g = np.load(os.path.join(cases.GOLDEN, "ofdm_demodulator.npz"))
-    mu, bw, n, fc, slot, wo = g[name + "_cfg"]
+    mu, bw, n, fc, slot, wo = g[name + "_cfg"][:6]
+    ext = int(g[name + "_cfg"][6]) if len(g[name + "_cfg"]) > 6 else 0   # dx...: extended cyclic prefix
     slot, wo = int(slot), int(wo)
-    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), 0, 1.0 / np.sqrt(n), float(fc))
+    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), ext, 1.0 / np.sqrt(n), float(fc))
     iq = g[name + "_iq"]
     nof_ports = iq.shape[0]
     plan = lib.OfdmPlan(gpu_ctx, cfg, nof_ports)
@@ -382,12 +408,14 @@ def test_ofdm_demodulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
     # Host-span entry point (ofdm_slot_demodulator::demodulate semantics).
     assert np.array_equal(plan.demodulate_slot_host(iq, slot, wo), got[0])
     # Host-span single-symbol entry point (ofdm_symbol_demodulator::demodulate semantics).
-    sym = 14 * slot + 5
-    start = sum(lib.symbol_size(cfg, 14 * slot + l) for l in range(5))
+    nsymb = 12 if ext else 14
+    sym = nsymb * slot + 5
+    start = sum(lib.symbol_size(cfg, nsymb * slot + l) for l in range(5))
     row = plan.demodulate_symbol_host(iq[0, start: start + lib.symbol_size(cfg, sym)], sym, wo)
     assert np.array_equal(row, got[0, 0, 5])
     # A window offset beyond the shortest cyclic prefix is rejected (ofdm_demodulator_impl.cpp:58-63).
-    assert gpu_ctx.lib.nrphy_ofdm_demod_run(plan.handle, 1, d_grid.data_ptr(), None, (144 * int(n)) // 2048,
+    shortest_cp = int(n) // 4 if ext else ((144 >> int(mu)) * int(n) * (1 << int(mu))) // 2048
+    assert gpu_ctx.lib.nrphy_ofdm_demod_run(plan.handle, 1, d_grid.data_ptr(), None, shortest_cp,
                                             d_grid.data_ptr(), None) == abi.ERR_ARGUMENT
     plan.close()
 

@@ -57,11 +57,12 @@ def test_oracle_pdsch_processor_golden(oracle):
             assert np.array_equal(g32[p][g["%s_p%d_idx" % (name, p)]], g["%s_p%d_val" % (name, p)]), (name, p)
 
 
-@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024", "n1536", "n3072", "n768", "n384"])
+@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024", "n1536", "n3072", "n768", "n384", "x512", "x2048"])
 def test_oracle_ofdm_golden(oracle, name):
     g = np.load(os.path.join(cases.GOLDEN, "ofdm_modulator.npz"))
-    mu, bw, n, fc, slot = g[name + "_cfg"]
-    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), 0, 1.0 / np.sqrt(n), float(fc))
+    mu, bw, n, fc, slot = g[name + "_cfg"][:5]
+    ext = int(g[name + "_cfg"][5]) if len(g[name + "_cfg"]) > 5 else 0   # x...: extended cyclic prefix, 12 symbols
+    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), ext, 1.0 / np.sqrt(n), float(fc))
     iq = oracle.ofdm_slot(cfg, g[name + "_grid"], int(slot))
     want = g[name + "_iq"]
     # The reference's own tolerance is |err| / sqrt(N) < 5e-5 (ofdm_modulator_vectortest.cpp:30); ours: 1e-5 relative.
@@ -81,29 +82,34 @@ def assert_bf16_grids_close(got, want, min_exact=0.99):
 
 
 @pytest.mark.parametrize("case", [(1, 273, 4096, 3.5e9, 1, 0), (0, 106, 2048, 2.4e9, 0, 9), (0, 52, 1024, 2.4e9, 0, 0),
-                                  (0, 106, 1536, 2.4e9, 0, 5), (1, 51, 768, 3.6e9, 1, 0), (0, 25, 512, 2.4e9, 0, 3)])
+                                  (0, 106, 1536, 2.4e9, 0, 5), (1, 51, 768, 3.6e9, 1, 0), (0, 25, 512, 2.4e9, 0, 3),
+                                  (2, 48, 1024, 3.5e9, 2, 11, 1), (2, 192, 4096, 28e9, 1, 0, 1)])
 def test_oracle_ofdm_demodulator_vs_reference(oracle, ref, case):
     """ofdm_slot_demodulator_impl (compiled reference) against the C restatement on random IQ, and the
     modulate -> demodulate round trip of ofdm_modulator_unittest / ofdm_demodulator_unittest style."""
     if ref is None:
         pytest.skip("compiled reference not available")
-    mu, bw, n, fc, slot, wo = case
+    mu, bw, n, fc, slot, wo = case[:6]
+    ext = case[6] if len(case) > 6 else 0   # extended cyclic prefix
     rng = np.random.default_rng(n + wo)
-    cfg = abi.OfdmConfig(mu, bw, n, 0, 1.0 / np.sqrt(n), fc)
+    cfg = abi.OfdmConfig(mu, bw, n, ext, 1.0 / np.sqrt(n), fc)
     size = lib.slot_size(cfg, slot)
     iq = (rng.standard_normal((2, size)) + 1j * rng.standard_normal((2, size))).astype(np.complex64)
     assert_bf16_grids_close(oracle.ofdm_demod_slot(cfg, iq, slot, wo), ref.ofdm_demod_slot(cfg, iq, slot, wo))
     # Round trip: a bf16 grid modulated and demodulated with scales whose product is 1 / N comes back (bf16 rounding).
     grid = (rng.standard_normal((1, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    if ext:
+        grid[:, 12:] = 0   # a slot has 12 symbols: grid rows 12 and 13 are neither sent nor received
     back = oracle.ofdm_demod_slot(cfg, oracle.ofdm_slot(cfg, grid, slot), slot, 0)
     assert_bf16_grids_close(back, grid, min_exact=0.9)
 
 
-@pytest.mark.parametrize("name", ["d4096", "d2048w", "d1536", "d512w"])
+@pytest.mark.parametrize("name", ["d4096", "d2048w", "d1536", "d512w", "dx1024w"])
 def test_oracle_ofdm_demodulator_golden(oracle, name):
     g = np.load(os.path.join(cases.GOLDEN, "ofdm_demodulator.npz"))
-    mu, bw, n, fc, slot, wo = g[name + "_cfg"]
-    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), 0, 1.0 / np.sqrt(n), float(fc))
+    mu, bw, n, fc, slot, wo = g[name + "_cfg"][:6]
+    ext = int(g[name + "_cfg"][6]) if len(g[name + "_cfg"]) > 6 else 0
+    cfg = abi.OfdmConfig(int(mu), int(bw), int(n), ext, 1.0 / np.sqrt(n), float(fc))
     assert_bf16_grids_close(oracle.ofdm_demod_slot(cfg, g[name + "_iq"], int(slot), int(wo)), g[name + "_grid"])
 
 
@@ -214,6 +220,23 @@ def test_oracle_ldpc_decoder_reference_unit_tests(oracle, ref, bg):
         if n % 4 == 0:
             assert ref.ldpc_decode(bg, zc, 0, 0, 6, 0.8, zero, simd=0)[1].all()
     assert kb * zc == bits.size
+
+
+def test_oracle_vs_ref_extended_cyclic_prefix_pdsch(oracle, ref):
+    """PDSCH with extended cyclic prefix (12 symbols per slot: DM-RS c_init, symbol bounds): validator and grid against
+    the reference's three processors; a DM-RS symbol beyond the slot is refused by both."""
+    rng = np.random.default_rng(1212)
+    for pdu, nof_ports, nof_subc in cases.extended_cp_pdus(oracle.tbs):
+        assert oracle.validate(pdu) == 0 and ref.validate(pdu) == 0
+        tb = cases.random_tb(rng, pdu)
+        want = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc)
+        assert not want[:, 12:].any(), "symbols 12 and 13 do not exist with extended cyclic prefix"
+        for impl in range(3):
+            assert np.array_equal(ref.pdsch_process(pdu, tb, nof_ports, nof_subc, impl=impl), want), impl
+    bad = cases.extended_cp_pdus(oracle.tbs)[0][0]
+    bad.dmrs_symbol_mask |= 1 << 12
+    bad.nof_symbols = 13
+    assert oracle.validate(bad) != 0 and ref.validate(bad) != 0
 
 
 def test_baseline_config_derived_values(oracle):
@@ -332,9 +355,12 @@ def test_oracle_vs_ref_dft_and_ofdm(oracle, ref):
         for inv in (0, 1):
             a, b = oracle.dft(x, inv), ref.dft(x, inv)
             assert np.abs(a - b).max() / np.abs(b).max() < 2e-6
-    for mu, bw, n, fc, slot in ((1, 273, 4096, 3.5e9, 0), (1, 273, 4096, 3.5e9, 1), (0, 52, 1024, 2.4e9, 0), (0, 106, 2048, 0.0, 0),
-                                (2, 24, 512, 28e9, 3)):
-        cfg = abi.OfdmConfig(mu, bw, n, 0, 0.37, fc)
+    # the last five: the extended-cyclic-prefix rows of the reference's ofdm_modulator_test_data.h (numerology 2)
+    for mu, bw, n, fc, slot, ext in ((1, 273, 4096, 3.5e9, 0, 0), (1, 273, 4096, 3.5e9, 1, 0), (0, 52, 1024, 2.4e9, 0, 0),
+                                     (0, 106, 2048, 0.0, 0, 0), (2, 24, 512, 28e9, 3, 0), (2, 12, 256, 3.5e9, 0, 1),
+                                     (2, 24, 512, 3.5e9, 1, 1), (2, 48, 1024, 3.5e9, 2, 1), (2, 96, 2048, 28e9, 3, 1),
+                                     (2, 192, 4096, 28e9, 0, 1)):
+        cfg = abi.OfdmConfig(mu, bw, n, ext, 0.37, fc)
         grid = (rng.standard_normal((2, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
         a, b = oracle.ofdm_slot(cfg, grid, slot), ref.ofdm_slot(cfg, grid, slot)
         assert a.shape == b.shape
