@@ -759,3 +759,55 @@ def test_pusch_decode_codeblock_host_harq(gpu_ctx, oracle):
                 decoded = True
                 break
         assert decoded, "HARQ combining of four transmissions should decode (%d, %d)" % (bg, zc)
+
+
+def test_device_entry_points_in_a_hip_graph(gpu_ctx, oracle):
+    """nrphy_pdsch_run / nrphy_ofdm_run neither allocate nor synchronise, so a step can be captured in a hipGraph and
+    replayed on new transport blocks.  The plan alternates two TB-CRC accumulators from run to run, so a graph holds an
+    even number of runs of a plan (two here)."""
+    import torch
+    pdu, nof_ports, nof_subc, ocfg = cases.baseline_config(2)
+    slots = 3
+    pdus = [cases.baseline_config(2, slot_index=i)[0] for i in range(slots)]
+    tb_bytes = (pdu.tb_size_bytes + 3) & ~3
+    plan = lib.PdschPlan(gpu_ctx, pdus, [i * tb_bytes for i in range(slots)], list(range(slots)), slots, nof_ports, nof_subc)
+    oplan = lib.OfdmPlan(gpu_ctx, ocfg, nof_ports)
+    d_tb = [torch.zeros(slots * tb_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    d_grid = [torch.zeros((slots, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda") for _ in range(2)]
+    d_iq = [torch.zeros((slots, nof_ports, oplan.slot_stride, 2), dtype=torch.float32, device="cuda") for _ in range(2)]
+    d_slot = dev(np.zeros(slots, np.int32))
+    rng = np.random.default_rng(5150)
+
+    def two_steps(stream):
+        for k in range(2):
+            plan.run(d_tb[k], d_grid[k], zero_grids=True, stream=stream)
+            oplan.run(slots, d_grid[k], d_iq[k], d_slot_index=d_slot, stream=stream)
+
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        two_steps(s.cuda_stream)   # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        two_steps(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        tbs = []
+        for k in range(2):
+            h = np.zeros(slots * tb_bytes, np.uint8)
+            for i in range(slots):
+                h[i * tb_bytes: i * tb_bytes + pdu.tb_size_bytes] = cases.random_tb(rng, pdu)
+            d_tb[k].copy_(torch.from_numpy(h))
+            tbs.append(h)
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in range(2):
+            for i in (0, slots - 1):
+                grid = d_grid[k][i].cpu().numpy().view(np.uint16).reshape(nof_ports, 14, nof_subc, 2)
+                tb = tbs[k][i * tb_bytes: i * tb_bytes + pdu.tb_size_bytes]
+                assert np.array_equal(grid, oracle.pdsch_process(pdus[i], tb, nof_ports, nof_subc)), (k, i)
+                iq = d_iq[k][i].cpu().numpy().view(np.complex64).reshape(nof_ports, -1)
+                want = oracle.ofdm_slot(ocfg, grid, 0)
+                assert rel_err(iq[:, : want.shape[1]], want) < 1e-5
+    plan.close()
+    oplan.close()
