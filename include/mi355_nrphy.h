@@ -325,6 +325,42 @@ int nrphy_pusch_decode_codeblock_host(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_de
                                       uint32_t max_iterations, float scaling_factor, const int8_t* llr,
                                       int8_t* soft_buffer, int new_data, uint8_t* message_packed, uint32_t* iterations);
 
+/* ---- receive side ("next" row): PUSCH (UL-SCH) decoder, transport-block level ----
+ * Replaces pusch_decoder::new_data ... on_end_softbits (R/include/srsran/phy/upper/channel_processors/pusch/
+ * pusch_decoder.h; impl R/lib/phy/upper/channel_processors/pusch/pusch_decoder_impl.cpp:94-497 with
+ * ldpc_segmenter_rx and pusch_codeblock_decoder.cpp:28-71) for a batch of transport blocks that share one
+ * configuration, everything resident in HBM: segmentation of the codeword LLRs, rate dematching of every
+ * codeblock into its HARQ soft buffer, LDPC decoding of the codeblocks whose CRC has not passed yet,
+ * concatenation, transport-block CRC.  The fields are pusch_decoder::configuration (base_graph, rv, mod,
+ * Nref, nof_layers, nof_ldpc_iterations, use_early_stop, new_data) plus the transport-block size and the
+ * number of channel symbols (codeword soft bits / bits per symbol). */
+typedef struct nrphy_pusch_decoder_cfg {
+  uint32_t base_graph;
+  uint32_t qm;
+  uint32_t rv;
+  uint32_t nof_layers;
+  uint32_t nref;            /* limited-buffer size N_ref in bits, 0 = none */
+  uint32_t tb_size_bytes;
+  uint32_t nof_ch_symbols;  /* G / qm */
+  uint32_t max_iterations;
+  uint32_t use_early_stop;
+  uint32_t new_data;
+} nrphy_pusch_decoder_cfg_t;
+/* HARQ state the caller keeps per batch between transmissions (sizes from nrphy_pusch_decoder_sizes):
+ * d_soft  = n_tb * soft_bytes_per_tb  int8 soft buffers, [tb][codeblock][(66 or 50) * Zc];
+ * d_state = n_tb-dependent codeblock state (CRC flags, decoded messages, iteration counts), state_bytes(n_tb).
+ * Neither needs initialising before a new_data call. */
+int nrphy_pusch_decoder_sizes(const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb, uint64_t* soft_bytes_per_tb,
+                              uint64_t* state_bytes, uint32_t* nof_codeblocks);
+/* d_llr: codeword LLRs of transport block i at i * llr_stride_bytes (nof_ch_symbols * qm of them, in the
+ * order the demodulator delivers them).  d_tb: transport block i at i * tb_stride_bytes (written whenever
+ * all its codeblock CRCs pass; valid when its tb_crc_ok is 1).  d_result: 4 words per transport block --
+ * tb_crc_ok, codeblocks whose CRC passed, sum and maximum of the LDPC iterations of the codeblocks decoded
+ * in this call (a failed decode counts max_iterations).  Asynchronous on `stream`. */
+int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb, const int8_t* d_llr,
+                             uint64_t llr_stride_bytes, int8_t* d_soft, uint8_t* d_state, uint8_t* d_tb,
+                             uint32_t tb_stride_bytes, uint32_t* d_result, void* stream);
+
 /* ---- receive side of seam C ("next" row): OFDM demodulator ---------------
  * Replaces ofdm_symbol_demodulator::demodulate / ofdm_slot_demodulator::demodulate
  * (R/include/srsran/phy/lower/modulation/ofdm_demodulator.h; impl

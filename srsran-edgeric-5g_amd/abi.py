@@ -101,6 +101,13 @@ class LdpcRateDematcherCfg(C.Structure):
                 ("nref", C.c_uint32), ("nof_filler_bits", C.c_uint32), ("rm_length", C.c_uint32)]
 
 
+class PuschDecoderCfg(C.Structure):
+    """nrphy_pusch_decoder_cfg_t (pusch_decoder::configuration + TB size + number of channel symbols)."""
+    _fields_ = [("base_graph", C.c_uint32), ("qm", C.c_uint32), ("rv", C.c_uint32), ("nof_layers", C.c_uint32),
+                ("nref", C.c_uint32), ("tb_size_bytes", C.c_uint32), ("nof_ch_symbols", C.c_uint32),
+                ("max_iterations", C.c_uint32), ("use_early_stop", C.c_uint32), ("new_data", C.c_uint32)]
+
+
 class OfdmConfig(C.Structure):
     _fields_ = [
         ("numerology", C.c_uint32),
@@ -244,6 +251,8 @@ def declare(lib, prefix="nrphy_"):
     sig("ldpc_decode_host", i32, vp, P(LdpcDecoderCfg), vp, u8p, P(u32))
     sig("ldpc_rate_dematch", i32, vp, P(LdpcRateDematcherCfg), u32, vp, u32, vp, u32, i32, vp)
     sig("ldpc_rate_dematch_host", i32, vp, P(LdpcRateDematcherCfg), vp, vp, i32)
+    sig("pusch_decoder_sizes", i32, P(PuschDecoderCfg), u32, P(u64), P(u64), P(u32))
+    sig("pusch_decode_batch", i32, vp, P(PuschDecoderCfg), u32, vp, u64, vp, vp, vp, u32, vp, vp)
     sig("pusch_decode_codeblock_host", i32, vp, P(LdpcRateDematcherCfg), u32, u32, C.c_float, vp, vp, i32, u8p, P(u32))
     return lib
 
@@ -260,5 +269,5 @@ ABI_SYMBOLS = [
     "nrphy_ofdm_modulate_symbol_host", "nrphy_ofdm_modulate_slot_host", "nrphy_dft_run", "nrphy_dft_run_host",
     "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",
     "nrphy_ldpc_decode", "nrphy_ldpc_decode_host", "nrphy_ldpc_rate_dematch", "nrphy_ldpc_rate_dematch_host",
-    "nrphy_pusch_decode_codeblock_host",
+    "nrphy_pusch_decode_codeblock_host", "nrphy_pusch_decoder_sizes", "nrphy_pusch_decode_batch",
 ]

@@ -153,6 +153,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5))) void l
   const uint32_t zc = p.zc, j = threadIdx.x;
   int8_t*        soft = dec_lds; // [nof_nodes][zc] (+ 32 bytes of slack for the word reads of the last hard bits)
 
+  if (p.skip != nullptr && p.skip[blockIdx.x] != 0) { // workgroup-uniform: decoded in an earlier transmission
+    return;
+  }
   const auto*   graph  = to_constant(p.graph); // wave-uniform reads: scalar loads
   const int8_t* llr    = p.llr + (size_t)blockIdx.x * p.llr_stride;
   uint2*        rec    = p.scratch + (size_t)blockIdx.x * p.nof_layers_max * zc;
@@ -266,7 +269,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5))) void l
         lds_barrier();
       }
       // Early stop (ldpc_decoder_impl.cpp:118-126): every hard bit decided and the CRC of the significant bits zero.
-      if (p.crc_order != 0) {
+      // crc_at_end (pusch_codeblock_decoder.cpp:59-68): no check until the last iteration, then the CRC alone decides.
+      if (p.crc_order != 0 && (!p.crc_at_end || it + 1u == p.max_iterations)) {
         if (j < 2) {
           s_flag[1 + j] = 0;
         }
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5))) void l
           atomicOr(&s_flag[1], 1u);
         }
         lds_barrier();
-        if (s_flag[1] == 0 && s_flag[2] == 0) {
+        if ((s_flag[1] == 0 || p.crc_at_end) && s_flag[2] == 0) {
           iterations = it + 1u;
         }
         lds_barrier(); // the flags are cleared again at the top of the next check
@@ -312,6 +316,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5))) void l
   }
   if (j == 0 && p.iterations) {
     p.iterations[blockIdx.x] = iterations;
+  }
+  if (j == 0 && p.ok_flags && iterations != 0) {
+    p.ok_flags[blockIdx.x] = 1;
   }
 }
 

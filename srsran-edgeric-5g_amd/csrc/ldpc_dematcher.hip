@@ -108,9 +108,10 @@ __global__ __launch_bounds__(256) void ldpc_dematch_kernel(DematchLaunch p)
   if (first >= p.block_length) {
     return;
   }
-  int8_t*        out_row = p.out + (size_t)blockIdx.y * p.out_stride;
+  int8_t*        out_row = p.out + (size_t)blockIdx.z * p.out_stride_outer + (size_t)blockIdx.y * p.out_stride;
   const uint32_t old     = VEC == 4 ? *reinterpret_cast<const uint32_t*>(out_row + first) : (uint32_t)(uint8_t)out_row[first];
-  dematch_positions<VEC, EXT>(p, p.in + (size_t)blockIdx.y * p.in_stride, out_row, first, old, 1.0f / (float)p.cols);
+  dematch_positions<VEC, EXT>(p, p.in + (size_t)blockIdx.z * p.in_stride_outer + (size_t)blockIdx.y * p.in_stride, out_row,
+                              first, old, 1.0f / (float)p.cols);
 }
 
 // One workgroup per codeblock: the input is read once, coalesced, into LDS; the strided reads of the deinterleaver
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(DEMATCH_LDS_THREADS) void ldpc_dematch_lds_kernel(D
   const uint32_t e      = p.cols * p.qm;
   int8_t*        staged = dematch_lds;                       // [e]
   int8_t*        soft   = dematch_lds + ((e + 15u) & ~15u);  // [block_length]
-  const int8_t*  in      = p.in + (size_t)blockIdx.x * p.in_stride;
-  int8_t*        out_row = p.out + (size_t)blockIdx.x * p.out_stride;
+  const int8_t*  in      = p.in + (size_t)blockIdx.y * p.in_stride_outer + (size_t)blockIdx.x * p.in_stride;
+  int8_t*        out_row = p.out + (size_t)blockIdx.y * p.out_stride_outer + (size_t)blockIdx.x * p.out_stride;
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(out_row); // dword aligned (checked by the launcher)
@@ -198,32 +199,32 @@ __global__ __launch_bounds__(DEMATCH_LDS_THREADS) void ldpc_dematch_lds_kernel(D
 }
 
 template <bool EXT>
-static void launch_dematch_variant(const DematchLaunch& p, uint32_t n_cb, hipStream_t stream)
+static void launch_dematch_variant(const DematchLaunch& p, uint32_t n_cb, uint32_t n_outer, hipStream_t stream)
 {
   // four soft bits per thread when every codeblock row is dword aligned (block lengths are multiples of 4 only for even Zc)
-  const bool     vec4 = ((reinterpret_cast<uintptr_t>(p.out) | p.out_stride | p.block_length) & 3u) == 0;
+  const bool     vec4 = ((reinterpret_cast<uintptr_t>(p.out) | p.out_stride | p.out_stride_outer | p.block_length) & 3u) == 0;
   const uint32_t e    = p.cols * p.qm;
   const uint32_t lds  = ((e + 15u) & ~15u) + ((p.block_length + 15u) & ~15u);
   if (vec4 && lds <= 64u * 1024u) {
-    hipLaunchKernelGGL(ldpc_dematch_lds_kernel<EXT>, dim3(n_cb), dim3(DEMATCH_LDS_THREADS), lds, stream, p);
+    hipLaunchKernelGGL(ldpc_dematch_lds_kernel<EXT>, dim3(n_cb, n_outer), dim3(DEMATCH_LDS_THREADS), lds, stream, p);
   } else if (vec4) {
     const uint32_t blocks = (p.block_length / 4 + 255) / 256;
-    hipLaunchKernelGGL((ldpc_dematch_kernel<4, EXT>), dim3(blocks, n_cb), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((ldpc_dematch_kernel<4, EXT>), dim3(blocks, n_cb, n_outer), dim3(256), 0, stream, p);
   } else {
     const uint32_t blocks = (p.block_length + 255) / 256;
-    hipLaunchKernelGGL((ldpc_dematch_kernel<1, EXT>), dim3(blocks, n_cb), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((ldpc_dematch_kernel<1, EXT>), dim3(blocks, n_cb, n_outer), dim3(256), 0, stream, p);
   }
 }
 
-hipError_t launch_ldpc_dematch(const DematchLaunch& p, uint32_t n_cb, hipStream_t stream)
+hipError_t launch_ldpc_dematch(const DematchLaunch& p, uint32_t n_cb, hipStream_t stream, uint32_t n_outer)
 {
-  if (n_cb == 0 || p.n_ops == 0) {
+  if (n_cb == 0 || n_outer == 0 || p.n_ops == 0) {
     return hipSuccess;
   }
   if (p.ops_ext != nullptr) {
-    launch_dematch_variant<true>(p, n_cb, stream);
+    launch_dematch_variant<true>(p, n_cb, n_outer, stream);
   } else {
-    launch_dematch_variant<false>(p, n_cb, stream);
+    launch_dematch_variant<false>(p, n_cb, n_outer, stream);
   }
   return hipGetLastError();
 }

@@ -1620,11 +1620,26 @@ void build_dematch_ops(std::vector<DematchOp>& ops, unsigned block_length, unsig
   }
 }
 
+// n_outer groups (transport blocks) of n_cb codeblocks: codeblock (g, i) reads d_in + g * in_outer + i * in_stride and
+// owns the soft buffer d_soft + g * soft_outer + i * soft_stride.
+int rate_dematch_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg, uint32_t n_cb, uint32_t n_outer,
+                       const int8_t* d_in, uint32_t in_stride_bytes, size_t in_outer, int8_t* d_soft,
+                       uint32_t soft_stride_bytes, size_t soft_outer, int new_data, void* stream);
+
 } // namespace
 
 extern "C" int nrphy_ldpc_rate_dematch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg, uint32_t n_cb,
                                        const int8_t* d_in, uint32_t in_stride_bytes, int8_t* d_soft,
                                        uint32_t soft_stride_bytes, int new_data, void* stream)
+{
+  return rate_dematch_batch(ctx, cfg, n_cb, 1, d_in, in_stride_bytes, 0, d_soft, soft_stride_bytes, 0, new_data, stream);
+}
+
+namespace {
+
+int rate_dematch_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg, uint32_t n_cb, uint32_t n_outer,
+                       const int8_t* d_in, uint32_t in_stride_bytes, size_t in_outer, int8_t* d_soft,
+                       uint32_t soft_stride_bytes, size_t soft_outer, int new_data, void* stream)
 {
   if (ctx == nullptr || cfg == nullptr || d_in == nullptr || d_soft == nullptr ||
       (cfg->base_graph != 1 && cfg->base_graph != 2) || cfg->rv > 3 || lifting_position(cfg->lifting_size) < 0 ||
@@ -1672,9 +1687,16 @@ extern "C" int nrphy_ldpc_rate_dematch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_d
   p.block_length = block_length;
   p.qm           = cfg->qm;
   p.cols         = cfg->rm_length / cfg->qm;
-  HIP_TRY(launch_ldpc_dematch(p, n_cb, stream ? (hipStream_t)stream : ctx->stream));
+  p.in_stride_outer  = (uint32_t)in_outer;
+  p.out_stride_outer = (uint32_t)soft_outer;
+  if (in_outer > 0xFFFFFFFFULL || soft_outer > 0xFFFFFFFFULL) {
+    return NRPHY_ERR_CAPACITY;
+  }
+  HIP_TRY(launch_ldpc_dematch(p, n_cb, stream ? (hipStream_t)stream : ctx->stream, n_outer));
   return NRPHY_OK;
 }
+
+} // namespace
 
 extern "C" int nrphy_ldpc_rate_dematch_host(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg,
                                             const int8_t* in, int8_t* soft_buffer, int new_data)
@@ -1778,9 +1800,26 @@ const uint32_t* get_decoder_crc_weights(nrphy_ctx* ctx, uint32_t poly, uint32_t 
 
 } // namespace
 
+namespace {
+// skip / ok_flags: per-codeblock HARQ state of a transport-block decoder; crc_at_end: no early stop.
+int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb, const int8_t* d_llr,
+                      uint32_t llr_stride_bytes, uint8_t* d_out, uint32_t out_stride_bytes, uint32_t* d_iterations,
+                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* stream);
+} // namespace
+
 extern "C" int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb,
                                  const int8_t* d_llr, uint32_t llr_stride_bytes, uint8_t* d_out,
                                  uint32_t out_stride_bytes, uint32_t* d_iterations, void* stream)
+{
+  return ldpc_decode_batch(ctx, cfg, n_cb, d_llr, llr_stride_bytes, d_out, out_stride_bytes, d_iterations, nullptr,
+                           nullptr, false, stream);
+}
+
+namespace {
+
+int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb, const int8_t* d_llr,
+                      uint32_t llr_stride_bytes, uint8_t* d_out, uint32_t out_stride_bytes, uint32_t* d_iterations,
+                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* stream)
 {
   if (ctx == nullptr || cfg == nullptr || d_llr == nullptr || d_out == nullptr ||
       (cfg->base_graph != 1 && cfg->base_graph != 2) || cfg->max_iterations == 0 ||
@@ -1819,6 +1858,9 @@ extern "C" int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_
   p.llr            = d_llr;
   p.out            = d_out;
   p.iterations     = d_iterations;
+  p.skip           = d_skip;
+  p.ok_flags       = d_ok_flags;
+  p.crc_at_end     = crc_at_end ? 1U : 0U;
   p.crc_weight     = nullptr;
   {
     // Check records: context-owned, grow-only (a first call with a larger batch allocates; not stream-ordered).
@@ -1834,6 +1876,8 @@ extern "C" int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_
   HIP_TRY(launch_ldpc_decode(p, n_cb, stream ? (hipStream_t)stream : ctx->stream));
   return NRPHY_OK;
 }
+
+} // namespace
 
 extern "C" int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, const int8_t* llr,
                                       uint8_t* message_packed, uint32_t* iterations)
@@ -1926,6 +1970,148 @@ extern "C" int nrphy_pusch_decode_codeblock_host(nrphy_ctx_t* ctx, const nrphy_l
   if (iterations) {
     *iterations = it;
   }
+  return NRPHY_OK;
+}
+
+// ================================================================================================================
+// PUSCH decoder, transport-block level
+// ================================================================================================================
+namespace {
+
+struct PuschLayout {
+  nrphy_pdsch_derived_t d;
+  uint32_t              msg_stride; // bytes per decoded message
+  uint64_t              off_ok, off_skip, off_iter, off_msg, state_bytes;
+};
+
+bool pusch_layout(const nrphy_pusch_decoder_cfg_t& cfg, uint32_t n_tb, PuschLayout& l)
+{
+  if ((cfg.base_graph != 1 && cfg.base_graph != 2) || (cfg.qm != 1 && cfg.qm != 2 && cfg.qm != 4 && cfg.qm != 6 && cfg.qm != 8) ||
+      cfg.rv > 3 || cfg.nof_layers == 0 || cfg.nof_layers > NRPHY_MAX_LAYERS || cfg.tb_size_bytes == 0 ||
+      cfg.nof_ch_symbols == 0 || cfg.nof_ch_symbols % cfg.nof_layers != 0 || cfg.max_iterations == 0) {
+    return false;
+  }
+  // Segmentation is the transmitter's (ldpc_segmenter_rx_impl mirrors ldpc_segmenter_tx): reuse its derivation.
+  nrphy_pdsch_pdu_t pdu;
+  std::memset(&pdu, 0, sizeof(pdu));
+  pdu.ldpc_base_graph = cfg.base_graph;
+  pdu.tb_size_bytes   = cfg.tb_size_bytes;
+  pdu.rv              = cfg.rv;
+  pdu.nof_layers      = cfg.nof_layers;
+  pdu.qm              = cfg.qm;
+  const uint32_t nref = cfg.nref;
+  derive(pdu, cfg.nof_ch_symbols / cfg.nof_layers, l.d, &nref);
+  if (l.d.lifting_size == 0 || l.d.nof_codeblocks == 0 || l.d.nof_codeblocks > NRPHY_MAX_CODEBLOCKS ||
+      l.d.rm_length_short == 0) {
+    return false;
+  }
+  const uint64_t n_cb = (uint64_t)n_tb * l.d.nof_codeblocks;
+  l.msg_stride        = ((l.d.segment_length + 7) / 8 + 8 + 15) & ~15U;
+  l.off_ok            = 0;
+  l.off_skip          = (n_cb + 63) & ~(uint64_t)63;
+  l.off_iter          = 2 * l.off_skip;
+  l.off_msg           = (l.off_iter + 4 * n_cb + 63) & ~(uint64_t)63;
+  l.state_bytes       = l.off_msg + n_cb * l.msg_stride;
+  return true;
+}
+
+} // namespace
+
+extern "C" int nrphy_pusch_decoder_sizes(const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb, uint64_t* soft_bytes_per_tb,
+                                         uint64_t* state_bytes, uint32_t* nof_codeblocks)
+{
+  PuschLayout l;
+  if (cfg == nullptr || !pusch_layout(*cfg, n_tb, l)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (soft_bytes_per_tb) {
+    *soft_bytes_per_tb = (uint64_t)l.d.nof_codeblocks * l.d.full_length;
+  }
+  if (state_bytes) {
+    *state_bytes = l.state_bytes;
+  }
+  if (nof_codeblocks) {
+    *nof_codeblocks = l.d.nof_codeblocks;
+  }
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb,
+                                        const int8_t* d_llr, uint64_t llr_stride_bytes, int8_t* d_soft, uint8_t* d_state,
+                                        uint8_t* d_tb, uint32_t tb_stride_bytes, uint32_t* d_result, void* stream)
+{
+  PuschLayout l;
+  if (ctx == nullptr || cfg == nullptr || d_llr == nullptr || d_soft == nullptr || d_state == nullptr || d_tb == nullptr ||
+      d_result == nullptr || !pusch_layout(*cfg, n_tb, l) || tb_stride_bytes < cfg->tb_size_bytes ||
+      llr_stride_bytes < (uint64_t)cfg->nof_ch_symbols * cfg->qm) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (n_tb == 0) {
+    return NRPHY_OK;
+  }
+  const nrphy_pdsch_derived_t& d = l.d;
+  const uint32_t               C = d.nof_codeblocks, N = d.full_length;
+  const uint64_t               n_cb = (uint64_t)n_tb * C;
+  hipStream_t                  s    = stream ? (hipStream_t)stream : ctx->stream;
+  uint8_t *                    ok = d_state + l.off_ok, *skip = d_state + l.off_skip, *msg = d_state + l.off_msg;
+  uint32_t*                    iter = (uint32_t*)(d_state + l.off_iter);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (cfg->new_data) { // a fresh soft buffer has no codeblock CRC flags
+    HIP_TRY(hipMemsetAsync(ok, 0, n_cb, s));
+  }
+  HIP_TRY(hipMemcpyAsync(skip, ok, n_cb, hipMemcpyDeviceToDevice, s));
+  // Rate dematching of every codeblock, also of those decoded earlier (pusch_decoder_impl.cpp:340-350): the short
+  // segments, then the long ones.
+  nrphy_ldpc_rate_dematcher_cfg_t dm;
+  dm.base_graph      = cfg->base_graph;
+  dm.lifting_size    = d.lifting_size;
+  dm.rv              = cfg->rv;
+  dm.qm              = cfg->qm;
+  dm.nref            = d.n_ref;
+  dm.nof_filler_bits = d.nof_filler_bits;
+  const uint32_t n_short = d.nof_short_segments;
+  int            rc      = NRPHY_OK;
+  if (n_short != 0) {
+    dm.rm_length = d.rm_length_short;
+    rc = rate_dematch_batch(ctx, &dm, n_short, n_tb, d_llr, d.rm_length_short, llr_stride_bytes, d_soft, N, (size_t)C * N,
+                            cfg->new_data, s);
+  }
+  if (rc == NRPHY_OK && n_short != C) {
+    dm.rm_length = d.rm_length_long;
+    rc = rate_dematch_batch(ctx, &dm, C - n_short, n_tb, d_llr + (size_t)n_short * d.rm_length_short, d.rm_length_long,
+                            llr_stride_bytes, d_soft + (size_t)n_short * N, N, (size_t)C * N, cfg->new_data, s);
+  }
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  // Decoding of the codeblocks whose CRC has not passed yet (pusch_codeblock_decoder.cpp:36-71): CRC24B per codeblock,
+  // the transport block's own CRC when it is a single codeblock.
+  nrphy_ldpc_decoder_cfg_t dec;
+  dec.base_graph      = cfg->base_graph;
+  dec.lifting_size    = d.lifting_size;
+  dec.nof_filler_bits = d.nof_filler_bits;
+  dec.crc_poly        = (C > 1) ? 0x24B : (d.nof_tb_crc_bits == 16 ? 16 : 0x24A);
+  dec.nof_llr         = N;
+  dec.max_iterations  = cfg->max_iterations;
+  dec.scaling_factor  = 0.8F; // ldpc_decoder::configuration::algorithm_details default, which pusch_codeblock_decoder keeps
+  rc = ldpc_decode_batch(ctx, &dec, (uint32_t)n_cb, d_soft, N, msg, l.msg_stride, iter, skip, ok, cfg->use_early_stop == 0, s);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  PuschAssembleLaunch a;
+  a.cb_msg         = msg;
+  a.cb_ok          = ok;
+  a.cb_iter        = iter;
+  a.skipped        = skip;
+  a.tb             = d_tb;
+  a.result         = d_result;
+  a.C              = C;
+  a.msg_stride     = l.msg_stride;
+  a.tb_stride      = tb_stride_bytes;
+  a.tb_bytes       = cfg->tb_size_bytes;
+  a.cb_info_bits   = d.cb_info_bits;
+  a.max_iterations = cfg->max_iterations;
+  HIP_TRY(launch_pusch_assemble(a, n_tb, s));
   return NRPHY_OK;
 }
 

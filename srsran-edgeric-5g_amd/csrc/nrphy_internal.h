@@ -234,6 +234,9 @@ struct LdpcDecodeLaunch {
   uint8_t*            out;        // per codeblock: Kb * Zc hard bits, packed MSB first
   uint32_t*           iterations; // per codeblock: iterations until the CRC passed, 0 = it did not (may be null)
   const uint32_t*     crc_weight; // per 32-bit word of the message: x^(bits after the word) mod the CRC polynomial
+  const uint8_t*      skip;       // per codeblock (may be null): non-zero = leave it alone (decoded earlier)
+  uint8_t*            ok_flags;   // per codeblock (may be null): set to 1 when the CRC passed
+  uint32_t            crc_at_end; // 1: check the CRC once, after max_iterations (no early stop)
   uint32_t            zc, bg_k, nof_nodes, nof_layers_max;
   uint32_t            nof_llr, llr_stride, out_stride, nof_filler;
   uint32_t            crc_poly, crc_order; // order 0: no early stop
@@ -254,10 +257,23 @@ struct DematchLaunch {
   const int8_t* in;  // per codeblock: rm_length soft bits as received
   int8_t*       out; // per codeblock: the soft buffer, block_length soft bits
   uint32_t      in_stride, out_stride, block_length, qm, cols, n_ops;
+  uint32_t      in_stride_outer, out_stride_outer; // a second batch dimension (transport blocks of codeblocks)
   const DematchOp* ops_ext; // the list in device memory when it has more than MAX_DEMATCH_OPS entries, else null
   DematchOp        ops[MAX_DEMATCH_OPS];
 };
-hipError_t launch_ldpc_dematch(const DematchLaunch& p, uint32_t n_cb, hipStream_t stream);
+hipError_t launch_ldpc_dematch(const DematchLaunch& p, uint32_t n_cb, hipStream_t stream, uint32_t n_outer = 1);
+
+// ---- PUSCH decoder: transport-block assembly ("next" row, receive side) --------------------------------------------
+struct PuschAssembleLaunch {
+  const uint8_t* cb_msg;      // [n_tb][C][msg_stride] decoded messages, packed MSB first
+  uint8_t*       cb_ok;       // [n_tb][C] codeblock CRC flags (cleared when the transport-block CRC fails)
+  const uint32_t* cb_iter;    // [n_tb][C] iterations of this call's decodes (0: failed or skipped)
+  const uint8_t* skipped;     // [n_tb][C] 1 where this call did not run the decoder (CRC ok since an earlier transmission)
+  uint8_t*       tb;          // [n_tb][tb_stride] transport blocks out
+  uint32_t*      result;      // [n_tb][4]: tb_crc_ok, codeblocks with CRC ok, sum and max of iterations over decoded codeblocks
+  uint32_t       C, msg_stride, tb_stride, tb_bytes, cb_info_bits, max_iterations;
+};
+hipError_t launch_pusch_assemble(const PuschAssembleLaunch& p, uint32_t n_tb, hipStream_t stream);
 
 // ---- OFDM ---------------------------------------------------------------------------------------------------
 struct OfdmLaunch {

@@ -1,0 +1,123 @@
+// Transport-block side of the PUSCH decoder for gfx950 (MI355X) ("next" row).
+//
+// Replaces the tail of pusch_decoder_impl (R/lib/phy/upper/channel_processors/pusch/pusch_decoder_impl.cpp:386-497):
+// once every codeblock of a transport block has passed its CRC, concatenate_codeblocks() copies the data bits of the
+// codeblocks into the transport block and the CRC24A of the block is compared with the checksum the last codeblock
+// carries; if it fails every codeblock flag is cleared again (one of them was a false positive).  A single-codeblock
+// transport block is its codeblock.  Statistics as pusch_decoder_result: codeblocks decoded, iterations (a failed
+// decode counts with the maximum).
+//
+// One workgroup per transport block.  Thread t assembles a contiguous run of transport-block bytes straight from the
+// decoded messages, runs the CRC over it with a byte table in LDS and shifts its remainder to the end of the block
+// (x^(8 * bytes behind the run) mod g); the workgroup XORs the pieces.
+#include "bits_device.h"
+
+namespace nrphy {
+
+constexpr uint32_t ASSEMBLE_THREADS = 256;
+
+// Eight message bits starting at bit s (MSB-first packed bytes; reads one byte beyond the one holding bit s).
+__device__ __forceinline__ uint32_t message_bits8(const uint8_t* m, uint32_t s)
+{
+  const uint32_t w = ((uint32_t)m[s >> 3] << 8) | m[(s >> 3) + 1u];
+  return (w >> (8u - (s & 7u))) & 0xFFu;
+}
+
+// Byte i of the concatenated data bits: codeblock r holds bits [r * info, (r + 1) * info) of the stream.
+__device__ __forceinline__ uint32_t stream_byte(const uint8_t* msgs, uint32_t msg_stride, uint32_t info, uint32_t i)
+{
+  const uint32_t pos = 8u * i, r = pos / info, s = pos - r * info;
+  const uint8_t* m   = msgs + (size_t)r * msg_stride;
+  uint32_t       b   = message_bits8(m, s);
+  if (s + 8u > info) { // the byte straddles two codeblocks
+    const uint32_t n1 = info - s;
+    b                 = (b & (0xFFu << (8u - n1)) & 0xFFu) | (message_bits8(m + msg_stride, 0) >> n1);
+  }
+  return b;
+}
+
+__global__ __launch_bounds__(ASSEMBLE_THREADS) void pusch_assemble_kernel(PuschAssembleLaunch p)
+{
+  __shared__ uint32_t s_table[256];
+  __shared__ uint32_t s_acc[4]; // codeblocks ok, iteration sum, iteration max, CRC remainder
+  const uint32_t tb = blockIdx.x, tid = threadIdx.x, C = p.C;
+  uint8_t*       cb_ok = p.cb_ok + (size_t)tb * C;
+  const uint8_t* msgs  = p.cb_msg + (size_t)tb * C * p.msg_stride;
+  const CrcPoly  g     = crc24a();
+  { // CRC24A byte table: remainder of b(x) * x^24
+    uint32_t r = tid << 16;
+    for (int k = 0; k != 8; ++k) {
+      r = (r & 0x800000u) ? ((r << 1) ^ g.poly) : (r << 1);
+    }
+    s_table[tid] = r & 0xFFFFFFu;
+  }
+  if (tid < 4) {
+    s_acc[tid] = 0;
+  }
+  __syncthreads();
+  for (uint32_t r = tid; r < C; r += ASSEMBLE_THREADS) {
+    const bool ok = cb_ok[r] != 0;
+    if (ok) {
+      atomicAdd(&s_acc[0], 1u);
+    }
+    if (p.skipped[(size_t)tb * C + r] == 0) { // the decoder ran on this codeblock in this call
+      const uint32_t it = p.cb_iter[(size_t)tb * C + r];
+      const uint32_t n  = (ok && it != 0) ? it : p.max_iterations;
+      atomicAdd(&s_acc[1], n);
+      atomicMax(&s_acc[2], n);
+    }
+  }
+  __syncthreads();
+  const uint32_t n_ok   = s_acc[0];
+  bool           tb_ok  = false;
+  uint8_t*       out    = p.tb + (size_t)tb * p.tb_stride;
+  if (n_ok == C) { // workgroup-uniform
+    if (C == 1) {
+      tb_ok = true;
+      for (uint32_t i = tid; i < p.tb_bytes; i += ASSEMBLE_THREADS) {
+        out[i] = msgs[i];
+      }
+    } else {
+      const uint32_t chunk = (p.tb_bytes + ASSEMBLE_THREADS - 1) / ASSEMBLE_THREADS;
+      const uint32_t begin = min(tid * chunk, p.tb_bytes), end = min(begin + chunk, p.tb_bytes);
+      uint32_t       crc   = 0;
+      for (uint32_t i = begin; i != end; ++i) {
+        const uint32_t b = stream_byte(msgs, p.msg_stride, p.cb_info_bits, i);
+        out[i]           = (uint8_t)b;
+        crc              = ((crc << 8) ^ s_table[((crc >> 16) ^ b) & 0xFFu]) & 0xFFFFFFu;
+      }
+      if (crc != 0) {
+        atomicXor(&s_acc[3], crc_mulmod(crc, crc_xpow(8u * (p.tb_bytes - end), g), g));
+      }
+      __syncthreads();
+      uint32_t checksum = 0;
+      for (uint32_t k = 0; k != 3; ++k) {
+        checksum = (checksum << 8) | stream_byte(msgs, p.msg_stride, p.cb_info_bits, p.tb_bytes + k);
+      }
+      tb_ok = s_acc[3] == checksum;
+      if (!tb_ok) { // a codeblock CRC was a false positive: every codeblock is decoded again next time
+        for (uint32_t r = tid; r < C; r += ASSEMBLE_THREADS) {
+          cb_ok[r] = 0;
+        }
+      }
+    }
+  }
+  if (tid == 0) {
+    uint32_t* res = p.result + 4u * (size_t)tb;
+    res[0]        = tb_ok ? 1u : 0u;
+    res[1]        = n_ok;
+    res[2]        = s_acc[1];
+    res[3]        = s_acc[2];
+  }
+}
+
+hipError_t launch_pusch_assemble(const PuschAssembleLaunch& p, uint32_t n_tb, hipStream_t stream)
+{
+  if (n_tb == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(pusch_assemble_kernel, dim3(n_tb), dim3(ASSEMBLE_THREADS), 0, stream, p);
+  return hipGetLastError();
+}
+
+} // namespace nrphy

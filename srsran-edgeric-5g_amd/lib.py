@@ -140,6 +140,19 @@ class Context:
                "nrphy_pusch_decode_codeblock_host")
         return int(it.value), np.unpackbits(packed)[:k], soft
 
+    def pusch_decoder_sizes(self, cfg, n_tb):
+        """(soft-buffer bytes per transport block, state bytes of the batch, codeblocks per transport block)."""
+        soft, state, ncb = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        _check(self.lib.nrphy_pusch_decoder_sizes(C.byref(cfg), n_tb, C.byref(soft), C.byref(state), C.byref(ncb)),
+               "nrphy_pusch_decoder_sizes")
+        return int(soft.value), int(state.value), int(ncb.value)
+
+    def pusch_decode_batch(self, cfg, n_tb, d_llr, llr_stride, d_soft, d_state, d_tb, tb_stride, d_result, stream=None):
+        """pusch_decoder for n_tb transport blocks of one configuration, everything resident in HBM."""
+        _check(self.lib.nrphy_pusch_decode_batch(self.handle, C.byref(cfg), n_tb, _dptr(d_llr), llr_stride, _dptr(d_soft),
+                                                 _dptr(d_state), _dptr(d_tb), tb_stride, _dptr(d_result), stream),
+               "nrphy_pusch_decode_batch")
+
     def ldpc_decode(self, cfg, n_cb, d_llr, llr_stride, d_out, out_stride, d_iterations=None, stream=None):
         """ldpc_decoder::decode for n_cb codeblocks resident in HBM (cfg: abi.LdpcDecoderCfg)."""
         _check(self.lib.nrphy_ldpc_decode(self.handle, C.byref(cfg), n_cb, _dptr(d_llr), llr_stride, _dptr(d_out),

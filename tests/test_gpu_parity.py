@@ -811,3 +811,102 @@ def test_device_entry_points_in_a_hip_graph(gpu_ctx, oracle):
                 assert rel_err(iq[:, : want.shape[1]], want) < 1e-5
     plan.close()
     oplan.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PUSCH decoder at transport-block level ("next" row): segmentation, rate dematching, decoding, concatenation, TB CRC
+# ---------------------------------------------------------------------------------------------------------------------
+def pusch_decode_expected(oracle, d, cfg, llr, soft, cb_ok, cb_msg):
+    """pusch_decoder_impl restated on the oracle's codeblock functions (pusch_decoder_impl.cpp:318-497): updates soft /
+    cb_ok / cb_msg in place, returns (tb_crc_ok, codeblocks ok, iteration sum, iteration max, transport block or None)."""
+    bg, zc, C, n = cfg.base_graph, d["lifting_size"], d["nof_codeblocks"], d["full_length"]
+    k, nf, info = d["segment_length"], d["nof_filler_bits"], d["cb_info_bits"]
+    crc_id = 0x24B if C > 1 else (16 if d["nof_tb_crc_bits"] == 16 else 0x24A)
+    if cfg.new_data:
+        cb_ok[:] = 0
+    offset, it_sum, it_max = 0, 0, 0
+    for r in range(C):
+        e = d["rm_length_short"] if r < d["nof_short_segments"] else d["rm_length_long"]
+        soft[r] = oracle.ldpc_rate_dematch(bg, zc, cfg.rv, cfg.qm, d["n_ref"], nf, cfg.new_data, llr[offset: offset + e], soft[r])
+        offset += e
+        if cb_ok[r]:
+            continue
+        it, bits = oracle.ldpc_decode(bg, zc, nf, crc_id, cfg.max_iterations, 0.8, soft[r])
+        cb_msg[r] = bits
+        cb_ok[r] = 1 if it else 0
+        it_sum += it if it else cfg.max_iterations
+        it_max = max(it_max, it if it else cfg.max_iterations)
+    n_ok = int(cb_ok.sum())
+    tb, tb_ok = None, False
+    tb_bits = 8 * cfg.tb_size_bytes
+    if n_ok == C:
+        if C == 1:
+            tb_ok, tb = True, np.packbits(cb_msg[0][:tb_bits])
+        else:
+            stream = np.concatenate([cb_msg[r][:info] for r in range(C)])[: tb_bits + 24]
+            tb = np.packbits(stream[:tb_bits])
+            checksum = int("".join(map(str, stream[tb_bits:])), 2)
+            tb_ok = oracle.crc(0x24A, tb) == checksum
+            if not tb_ok:
+                cb_ok[:] = 0
+    return tb_ok, n_ok, it_sum, it_max, tb
+
+
+@pytest.mark.parametrize("shape", ["cfg2", "cfg1", "bg2_multi"])
+def test_pusch_decoder_transport_blocks_harq(gpu_ctx, oracle, shape):
+    """Two transport blocks through the whole receive-side coding chain on the GPU, twice (rv 0 as new data at an SNR
+    where some codeblocks fail, then rv 2 combined): soft buffers, codeblock flags, iteration statistics and transport
+    blocks against pusch_decoder_impl restated on the oracle; the transmit side is the oracle's PDSCH encoder."""
+    import torch
+    rng = np.random.default_rng({"cfg2": 21, "cfg1": 22, "bg2_multi": 23}[shape])
+    if shape == "cfg2":
+        pdu, nof_ports, nof_subc, _ = cases.baseline_config(2)
+        amp, sigma = 10.0, 5.0
+    elif shape == "cfg1":
+        pdu, nof_ports, nof_subc, _ = cases.baseline_config(1)
+        amp, sigma = 4.0, 7.0
+    else:
+        tb_bits = oracle.tbs(12, 12, 0, 2, 400.0, 2, 100)
+        pdu = abi.make_pdu(bwp_size_rb=100, qm=2, dmrs_symbols=(2,), prb_start=0, prb_count=100, start_symbol=0, nof_symbols=14,
+                           precoding=abi.identity_precoding(2), tb_size_bytes=tb_bits // 8, base_graph=2, rnti=9, n_id=1)
+        nof_ports, nof_subc = 2, 1200
+        amp, sigma = 6.0, 6.0
+    d = oracle.derive(pdu)
+    n_tb, C, n = 2, d["nof_codeblocks"], d["full_length"]
+    G = d["codeword_bits"]
+    cfgs = [abi.PuschDecoderCfg(pdu.ldpc_base_graph, pdu.qm, rv, pdu.nof_layers, d["n_ref"], pdu.tb_size_bytes,
+                                G // pdu.qm, 6, 1, 1 if i == 0 else 0) for i, rv in enumerate((0, 2))]
+    soft_bytes, state_bytes, ncb = gpu_ctx.pusch_decoder_sizes(cfgs[0], n_tb)
+    assert (soft_bytes, ncb) == (C * n, C)
+    d_soft = torch.full((n_tb, soft_bytes), 33, dtype=torch.int8, device="cuda")     # stale content on purpose
+    d_state = torch.full((state_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
+    d_tb = torch.zeros((n_tb, pdu.tb_size_bytes + 5), dtype=torch.uint8, device="cuda")
+    d_res = torch.zeros((n_tb, 4), dtype=torch.int32, device="cuda")
+    tbs = [cases.random_tb(rng, pdu) for _ in range(n_tb)]
+    soft = [np.full((C, n), 33, np.int8) for _ in range(n_tb)]
+    cb_ok = [np.full(C, 1, np.uint8) for _ in range(n_tb)]     # garbage flags: new data must clear them
+    cb_msg = [np.zeros((C, d["segment_length"]), np.uint8) for _ in range(n_tb)]
+    stride = G + 13
+    seen_partial = False
+    for tx, cfg in enumerate(cfgs):
+        llrs = np.zeros((n_tb, stride), np.int8)
+        for i in range(n_tb):
+            pdu.rv = cfg.rv
+            _, rm, _ = oracle.pdsch_process(pdu, tbs[i], nof_ports, nof_subc, taps=True, codeword_bits=G)
+            bits = np.unpackbits(rm)[:G].astype(np.float64)
+            llrs[i, :G] = np.clip(np.rint((1 - 2 * bits) * amp + rng.normal(0, sigma, G)), -120, 120).astype(np.int8)
+        pdu.rv = 0
+        gpu_ctx.pusch_decode_batch(cfg, n_tb, dev(llrs), stride, d_soft, d_state, d_tb, d_tb.shape[1], d_res)
+        torch.cuda.synchronize()
+        res = d_res.cpu().numpy()
+        got_soft = d_soft.cpu().numpy().reshape(n_tb, C, n)
+        for i in range(n_tb):
+            tb_ok, n_ok, it_sum, it_max, tb = pusch_decode_expected(oracle, d, cfg, llrs[i, :G], soft[i], cb_ok[i], cb_msg[i])
+            assert np.array_equal(got_soft[i], soft[i]), (tx, i)
+            assert tuple(res[i]) == (int(tb_ok), n_ok, it_sum, it_max), (tx, i, res[i], (tb_ok, n_ok, it_sum, it_max))
+            if tb_ok:
+                assert np.array_equal(d_tb[i].cpu().numpy()[: pdu.tb_size_bytes], tb)
+                assert np.array_equal(tb, tbs[i])
+            seen_partial |= 0 < n_ok < C or (tx == 0 and not tb_ok)
+    assert all(int(r[0]) == 1 for r in res), "the retransmission should complete every transport block"
+    assert seen_partial, "the first transmission should leave work for the second (pick a lower SNR)"
