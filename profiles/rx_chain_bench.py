@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Secondary measurement, BASELINE config 5 ("PUSCH receive path add-on: OFDM demod + LDPC min-sum decode, 8 iterations,
-100 MHz, 1 MI355X"): the three receive-side kernels built so far on one batch of slots, inputs resident in HBM.
-A step = OFDM demodulation of `slots` 100 MHz slots (4 receive ports) + rate dematching and decoding of the 104
-codeblocks (BG1, Zc 384, 256-QAM, E = 8960) each slot's transport block has.  Equalisation and soft demodulation sit
-between the two in a real receiver and are not built; the LLRs are synthetic noisy codewords of the GPU encoder.
+100 MHz, 1 MI355X"): the receive-side kernels built so far on one batch of slots, everything resident in HBM.
+A step = OFDM demodulation of `slots` 100 MHz slots (4 receive ports) + the transport-block decoder on the config-3
+transport block of each slot (nrphy_pusch_decode_batch: rate dematching of its 104 codeblocks, LDPC decoding with
+CRC24B early stop, concatenation, TB CRC24A).  The transmitter is this library's PDSCH path (its rate-matched codeword
+tap); equalisation and soft demodulation, which sit between the two in a receiver, are not built: the LLRs are the
+codeword bits through a BPSK-like AWGN map.  Every decoded transport block is compared with what was sent.
 Prints one JSON line in bench.py's schema.  Usage (GPU box, repository root):
-python3 profiles/rx_chain_bench.py [--slots 64] [--iterations 8] [--steps 10]"""
+python3 profiles/rx_chain_bench.py [--slots 64] [--iterations 8] [--steps 10] [--sigma 7.0]"""
 import argparse
 import json
 import os
@@ -23,70 +25,63 @@ def main():
     ap.add_argument("--iterations", type=int, default=8)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sigma", type=float, default=7.0)
     args = ap.parse_args()
     import torch
     import backends
     import cases
     abi, lib = backends.abi, backends.pkg.lib
     ctx = lib.Context(0)
-    _, ports, subc, ocfg = cases.baseline_config(3)
-    plan = lib.OfdmPlan(ctx, ocfg, ports)
+    pdu, ports, subc, ocfg = cases.baseline_config(3)
     slots = args.slots
-    bg, zc, e, nf = 1, 384, 8960, 72
-    k, n, n_cb = 22 * zc, 66 * zc, 104 * slots
-    rng = np.random.default_rng(5)
-    # valid codeblocks (CRC24B) so that early stop fires as it does on a live link
-    oracle = backends.oracle()
-    base = []
-    for _ in range(8):
-        payload = rng.integers(0, 2, k - nf - 24, dtype=np.uint8)
-        crc = oracle.crc_bits(0x24B, payload)
-        base.append(np.packbits(np.concatenate([payload, [(crc >> (23 - b)) & 1 for b in range(24)],
-                                                np.zeros(nf, np.uint8)]).astype(np.uint8)))
-    msgs = np.stack([base[i % 8] for i in range(n_cb)])
-    d_msg = torch.from_numpy(msgs).cuda()
-    enc_bits = e + nf + 8  # rate matching skips the filler bits
-    d_cb = torch.zeros((n_cb, (enc_bits + 7) // 8), dtype=torch.uint8, device="cuda")
-    ctx.ldpc_encode(bg, zc, d_msg, k // 8, enc_bits, d_cb, d_cb.shape[1], n_cb)
+    d = lib.derive(pdu)
+    G, C, tb_size = d["codeword_bits"], d["nof_codeblocks"], pdu.tb_size_bytes
+    # transmit side: the PDSCH plan with its rate-matched (pre-scrambling) codeword tap
+    pdus = [cases.baseline_config(3, slot_index=i % 20)[0] for i in range(slots)]
+    tb_stride = (tb_size + 3) & ~3
+    plan = lib.PdschPlan(ctx, pdus, [i * tb_stride for i in range(slots)], list(range(slots)), slots, ports, subc)
+    d_tb = torch.randint(0, 256, (slots, tb_stride), dtype=torch.uint8, device="cuda")
+    d_cw = torch.zeros((plan.codeword_bits + 7) // 8 + 64, dtype=torch.uint8, device="cuda")
+    plan.run(d_tb.reshape(-1), None, d_cw_rm=d_cw)
+    ctx.synchronize()
     torch.cuda.synchronize()
-    cb = np.unpackbits(d_cb.cpu().numpy(), axis=1)
-    nof_sys = 20 * zc
-    bits = np.concatenate([cb[:, : nof_sys - nf], cb[:, nof_sys:]], axis=1)[:, :e].astype(np.float32)
-    # the rate matcher's bit interleaver is undone by the dematcher: interleave here the way the transmitter does
-    cols = e // 8
-    tx = bits.reshape(n_cb, 8, cols).transpose(0, 2, 1).reshape(n_cb, e)
-    llr = np.clip(np.rint((1 - 2 * tx) * 20 + rng.normal(0, 7.0, tx.shape)), -120, 120).astype(np.int8)
+    offs = [plan.codeword_offset(i) for i in range(slots)]
+    assert all(o % 8 == 0 for o in offs)
+    cw = d_cw.cpu().numpy()
+    bits = np.stack([np.unpackbits(cw[o // 8: o // 8 + (G + 7) // 8])[:G] for o in offs]).astype(np.float32)
+    rng = np.random.default_rng(5)
+    llr = np.clip(np.rint((1 - 2 * bits) * 20 + rng.normal(0, args.sigma, bits.shape)), -120, 120).astype(np.int8)
     d_llr = torch.from_numpy(llr).cuda()
-    d_soft = torch.zeros((n_cb, n), dtype=torch.int8, device="cuda")
-    d_out = torch.zeros((n_cb, k // 8), dtype=torch.uint8, device="cuda")
-    d_its = torch.zeros((n_cb,), dtype=torch.int32, device="cuda")
-    d_iq = torch.randn((slots, ports, plan.slot_stride, 2), dtype=torch.float32, device="cuda")
+    cfg = abi.PuschDecoderCfg(pdu.ldpc_base_graph, pdu.qm, 0, pdu.nof_layers, d["n_ref"], tb_size, G // pdu.qm,
+                              args.iterations, 1, 1)
+    soft_bytes, state_bytes, ncb = ctx.pusch_decoder_sizes(cfg, slots)
+    d_soft = torch.zeros((slots, soft_bytes), dtype=torch.int8, device="cuda")
+    d_state = torch.zeros((state_bytes,), dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros((slots, tb_stride), dtype=torch.uint8, device="cuda")
+    d_res = torch.zeros((slots, 4), dtype=torch.int32, device="cuda")
+    oplan = lib.OfdmPlan(ctx, ocfg, ports)
+    d_iq = torch.randn((slots, ports, oplan.slot_stride, 2), dtype=torch.float32, device="cuda")
     d_grid = torch.zeros((slots, ports, 14, subc), dtype=torch.int32, device="cuda")
     d_slot = torch.tensor([i % 2 for i in range(slots)], dtype=torch.int32, device="cuda")
-    dm = abi.LdpcRateDematcherCfg(bg, zc, 0, 8, 0, nf, e)
-    dec = abi.LdpcDecoderCfg(bg, zc, nf, 0x24B, n, args.iterations, 0.8)
     s = torch.cuda.Stream()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    kernel_ms = {"ofdm_demod": 0.0, "rate_dematch": 0.0, "ldpc_decode": 0.0}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 
     def step(timed):
         if timed:
             ev[0].record(s)
-        plan.demod_run(slots, d_iq, d_grid, d_slot_index=d_slot, stream=s.cuda_stream)
+        oplan.demod_run(slots, d_iq, d_grid, d_slot_index=d_slot, stream=s.cuda_stream)
         if timed:
             ev[1].record(s)
-        ctx.ldpc_rate_dematch(dm, n_cb, d_llr, e, d_soft, n, True, s.cuda_stream)
+        ctx.pusch_decode_batch(cfg, slots, d_llr, G, d_soft, d_state, d_out, tb_stride, d_res, s.cuda_stream)
         if timed:
             ev[2].record(s)
-        ctx.ldpc_decode(dec, n_cb, d_soft, n, d_out, k // 8, d_its, s.cuda_stream)
-        if timed:
-            ev[3].record(s)
 
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
-    assert int(d_its.min()) >= 1, "every codeblock must decode at this SNR"
-    assert np.array_equal(d_out.cpu().numpy()[:16], msgs[:16]), "decoded messages differ from what was sent"
+    res = d_res.cpu().numpy()
+    assert res[:, 0].all(), "every transport block must decode at this SNR (%d of %d did)" % (int(res[:, 0].sum()), slots)
+    assert torch.equal(d_out[:, :tb_size], d_tb[:, :tb_size]), "decoded transport blocks differ from what was sent"
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(s)
     for _ in range(args.steps):
@@ -96,20 +91,21 @@ def main():
     ms = a.elapsed_time(b) / args.steps
     step(True)
     torch.cuda.synchronize()
-    for i, name in enumerate(kernel_ms):
-        kernel_ms[name] = ev[i].elapsed_time(ev[i + 1])
-    alg = n_cb * (n + k // 8)  # decoder: soft buffer in, packed message out
+    kernel_ms = {"ofdm_demod": ev[0].elapsed_time(ev[1]), "pusch_decode_batch": ev[1].elapsed_time(ev[2])}
+    n_cb = slots * C
+    alg = n_cb * d["full_length"] + slots * tb_size  # decoder: soft buffers in, transport blocks out
     print(json.dumps({
         "metric": "pusch_rx_slots_per_second", "value": slots / ms * 1e3, "unit": "slots/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int8 LLR / f32 IQ", "data": "synthetic",
-        "config": {"workload": "BASELINE config 5: OFDM demod (4096, 273 PRB, %d ports) + LDPC rate dematch + decode, "
-                               "104 CB/slot BG1 Zc384 E8960, max %d iterations, CRC24B early stop" % (ports, args.iterations),
-                   "slots_per_step": slots, "codeblocks_per_step": n_cb},
-        "kernel_ms": kernel_ms, "mean_iterations": float(d_its.float().mean()),
-        "info_gbps": n_cb * (k - nf - 24) / ms * 1e-6,
-        "roofline": {"bound": "hbm", "kernel": "ldpc_decode_kernel", "achieved": alg / kernel_ms["ldpc_decode"] * 1e-6,
-                     "peak": 8000.0, "unit": "GB/s", "frac": alg / kernel_ms["ldpc_decode"] * 1e-6 / 8000.0,
+        "config": {"workload": "BASELINE config 5: OFDM demod (4096, 273 PRB, %d ports) + UL-SCH decoder (rate dematch, LDPC "
+                               "max %d iterations with CRC24B early stop, concatenation, TB CRC) on config-3 transport "
+                               "blocks (868584 bit, 104 CB, BG1 Zc384)" % (ports, args.iterations),
+                   "slots_per_step": slots, "codeblocks_per_step": n_cb, "noise_sigma_over_amplitude": args.sigma / 20},
+        "kernel_ms": kernel_ms, "mean_iterations": float(res[:, 2].sum()) / n_cb, "tb_crc_ok": int(res[:, 0].sum()),
+        "info_gbps": slots * tb_size * 8 / ms * 1e-6,
+        "roofline": {"bound": "hbm", "kernel": "ldpc_decode_kernel", "achieved": alg / kernel_ms["pusch_decode_batch"] * 1e-6,
+                     "peak": 8000.0, "unit": "GB/s", "frac": alg / kernel_ms["pusch_decode_batch"] * 1e-6 / 8000.0,
                      "traffic": None, "note": "VALU-issue bound, see DESIGN.md section 5"},
     }))
 

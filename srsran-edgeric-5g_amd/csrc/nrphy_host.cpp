@@ -375,6 +375,7 @@ struct nrphy_ctx {
   float2*      d_twiddle[10] = {}; // one table per supported DFT size (twiddle_slot)
   DecoderGraph* d_dec_graph[NOF_GRAPHS] = {}; // decoder graphs, built on first use
   std::map<uint64_t, uint32_t*> d_dec_crc;     // early-stop CRC weights per (polynomial, message length)
+  std::map<uint32_t, uint32_t*> d_tb_crc_w;    // transport-block CRC weights of the PUSCH assembly kernel per block size
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
   // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
   std::mutex host_mutex;
@@ -782,6 +783,9 @@ extern "C" int nrphy_destroy(nrphy_ctx_t* ctx)
     (void)hipFree(g);
   }
   for (auto& kv : ctx->d_dec_crc) {
+    (void)hipFree(kv.second);
+  }
+  for (auto& kv : ctx->d_tb_crc_w) {
     (void)hipFree(kv.second);
   }
   (void)hipFree(ctx->d_x1);
@@ -2099,6 +2103,26 @@ extern "C" int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_deco
     return rc;
   }
   PuschAssembleLaunch a;
+  a.crc_weight = nullptr;
+  if (C > 1) {
+    // weights of the assembly kernel's per-thread CRC pieces (pusch_decoder.hip): fixed by the block size
+    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    auto                        it = ctx->d_tb_crc_w.find(cfg->tb_size_bytes);
+    if (it == ctx->d_tb_crc_w.end()) {
+      const uint32_t        piece = divide_ceil(cfg->tb_size_bytes, PUSCH_ASSEMBLE_THREADS);
+      std::vector<uint32_t> w(PUSCH_ASSEMBLE_THREADS);
+      for (uint32_t t = 0; t != PUSCH_ASSEMBLE_THREADS; ++t) {
+        const uint32_t end = std::min<uint32_t>(std::min<uint32_t>(t * piece, cfg->tb_size_bytes) + piece, cfg->tb_size_bytes);
+        w[t]               = CRC24A_FIELD.xpow(8 * (int64_t)(cfg->tb_size_bytes - end));
+      }
+      uint32_t* d_w = nullptr;
+      if (upload(&d_w, w.data(), w.size() * sizeof(uint32_t)) != hipSuccess) {
+        return NRPHY_ERR_DEVICE;
+      }
+      it = ctx->d_tb_crc_w.emplace(cfg->tb_size_bytes, d_w).first;
+    }
+    a.crc_weight = it->second;
+  }
   a.cb_msg         = msg;
   a.cb_ok          = ok;
   a.cb_iter        = iter;
