@@ -27,6 +27,11 @@
 #include "lib/phy/upper/channel_coding/ldpc/ldpc_segmenter_impl.h"
 #include "lib/phy/upper/channel_modulation/modulation_mapper_lut_impl.h"
 #include "lib/phy/upper/channel_processors/pdsch_encoder_impl.h"
+#include "lib/phy/upper/channel_processors/pusch/pusch_codeblock_decoder.h"
+#include "lib/phy/upper/channel_processors/pusch/pusch_decoder_impl.h"
+#include "srsran/phy/upper/channel_processors/pusch/pusch_decoder_notifier.h"
+#include "srsran/phy/upper/channel_processors/pusch/pusch_decoder_result.h"
+#include "srsran/phy/upper/rx_buffer_pool.h"
 #include "lib/phy/upper/channel_processors/pdsch_modulator_impl.h"
 #include "lib/phy/upper/channel_processors/pdsch_processor_concurrent_impl.h"
 #include "lib/phy/upper/channel_processors/pdsch_processor_impl.h"
@@ -677,6 +682,103 @@ int ref_ldpc_rate_dematch(uint32_t      bg,
   for (unsigned i = 0; i != block_length; ++i) {
     out[i] = static_cast<int8_t>(vout[i].to_int());
   }
+  return 0;
+}
+
+// pusch_decoder_impl (generic rate dematcher and LDPC decoder underneath) on one transport block, with the HARQ state
+// kept in a reference rx_buffer_pool between calls: harq_id names the soft buffer (0..7); new_data starts it afresh.
+// llr: the nof_llr = G codeword soft bits.  tb_out: tb_size_bytes.  result[4]: tb_crc_ok, decoder observations
+// (codeblocks decoded in this call), sum and maximum of their iteration counts.  Returns 0, or < 0 when no buffer.
+namespace {
+struct pusch_notifier : pusch_decoder_notifier {
+  pusch_decoder_result result;
+  bool                 done = false;
+  void                 on_sch_data(const pusch_decoder_result& r) override
+  {
+    result = r;
+    done   = true;
+  }
+};
+std::unique_ptr<rx_buffer_pool_controller>& pusch_pool()
+{
+  static std::unique_ptr<rx_buffer_pool_controller> pool;
+  if (!pool) {
+    rx_buffer_pool_config cfg;
+    cfg.max_codeblock_size   = ldpc::MAX_CODEBLOCK_SIZE;
+    cfg.nof_buffers          = 8;
+    cfg.nof_codeblocks       = 8 * 170;
+    cfg.expire_timeout_slots = 100000;
+    cfg.external_soft_bits   = false;
+    pool                     = create_rx_buffer_pool(cfg);
+  }
+  return pool;
+}
+} // namespace
+
+int ref_pusch_decode(uint32_t      bg,
+                     uint32_t      qm,
+                     uint32_t      rv,
+                     uint32_t      nof_layers,
+                     uint32_t      nref,
+                     uint32_t      tb_size_bytes,
+                     uint32_t      max_iterations,
+                     int           use_early_stop,
+                     int           new_data,
+                     uint32_t      harq_id,
+                     uint32_t      nof_codeblocks,
+                     const int8_t* llr,
+                     uint32_t      nof_llr,
+                     uint8_t*      tb_out,
+                     uint32_t*     result)
+{
+  auto make_crcs = [](auto& set) {
+    set.crc16  = std::make_unique<crc_calculator_lut_impl>(crc_generator_poly::CRC16);
+    set.crc24A = std::make_unique<crc_calculator_lut_impl>(crc_generator_poly::CRC24A);
+    set.crc24B = std::make_unique<crc_calculator_lut_impl>(crc_generator_poly::CRC24B);
+  };
+  pusch_codeblock_decoder::sch_crc cb_crcs;
+  make_crcs(cb_crcs);
+  std::vector<std::unique_ptr<pusch_codeblock_decoder>> instances;
+  instances.push_back(std::make_unique<pusch_codeblock_decoder>(
+      std::make_unique<ldpc_rate_dematcher_impl>(), std::make_unique<ldpc_decoder_generic>(), cb_crcs));
+  auto decoder_pool = std::make_shared<pusch_decoder_impl::codeblock_decoder_pool>(std::move(instances));
+  pusch_decoder_impl::sch_crc tb_crcs;
+  make_crcs(tb_crcs);
+  pusch_decoder_impl decoder(
+      ldpc_segmenter_impl::create_ldpc_segmenter_impl_rx(), decoder_pool, std::move(tb_crcs), nullptr, 275, 4);
+
+  unique_rx_buffer buffer = pusch_pool()->get_pool().reserve(
+      slot_point(1, 0), trx_buffer_identifier(0x4601, static_cast<uint8_t>(harq_id)), nof_codeblocks, new_data != 0);
+  if (!buffer.is_valid()) {
+    return -1;
+  }
+  pusch_decoder::configuration cfg;
+  cfg.base_graph          = (bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+  cfg.rv                  = rv;
+  cfg.mod                 = to_mod(qm);
+  cfg.Nref                = nref;
+  cfg.nof_layers          = nof_layers;
+  cfg.nof_ldpc_iterations = max_iterations;
+  cfg.use_early_stop      = use_early_stop != 0;
+  cfg.new_data            = new_data != 0;
+  std::vector<uint8_t>              tb(tb_size_bytes);
+  std::vector<log_likelihood_ratio> soft(nof_llr);
+  for (unsigned i = 0; i != nof_llr; ++i) {
+    soft[i] = log_likelihood_ratio(llr[i]);
+  }
+  pusch_notifier        notifier;
+  pusch_decoder_buffer& in = decoder.new_data(tb, std::move(buffer), notifier, cfg);
+  in.on_new_softbits(soft);
+  in.on_end_softbits();
+  if (!notifier.done) {
+    return -2;
+  }
+  std::memcpy(tb_out, tb.data(), tb_size_bytes);
+  const auto& st = notifier.result.ldpc_decoder_stats;
+  result[0]      = notifier.result.tb_crc_ok ? 1 : 0;
+  result[1]      = static_cast<uint32_t>(st.get_nof_observations());
+  result[2]      = static_cast<uint32_t>(std::lround(st.get_mean() * st.get_nof_observations()));
+  result[3]      = st.get_nof_observations() ? st.get_max() : 0;
   return 0;
 }
 

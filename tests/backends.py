@@ -253,6 +253,22 @@ class CpuBackend:
         assert f(*args) == 0
         return out
 
+    def pusch_decode(self, cfg, harq_id, nof_codeblocks, llr):
+        """pusch_decoder_impl of the compiled reference on one transport block (HARQ state kept in the reference's
+        rx_buffer_pool under harq_id): returns (tb_crc_ok, decoder runs, iteration sum, iteration max, tb bytes)."""
+        assert self.is_ref
+        llr = np.ascontiguousarray(llr, dtype=np.int8)
+        tb = np.zeros(cfg.tb_size_bytes, np.uint8)
+        res = np.zeros(4, np.uint32)
+        f = self._f("pusch_decode")
+        f.restype = C.c_int
+        rc = f(C.c_uint32(cfg.base_graph), C.c_uint32(cfg.qm), C.c_uint32(cfg.rv), C.c_uint32(cfg.nof_layers),
+               C.c_uint32(cfg.nref), C.c_uint32(cfg.tb_size_bytes), C.c_uint32(cfg.max_iterations),
+               C.c_int(cfg.use_early_stop), C.c_int(cfg.new_data), C.c_uint32(harq_id), C.c_uint32(nof_codeblocks),
+               _ptr(llr), C.c_uint32(llr.size), _ptr(tb), _ptr(res))
+        assert rc == 0, rc
+        return bool(res[0]), int(res[1]), int(res[2]), int(res[3]), tb
+
     def ofdm_demod_slot(self, cfg, iq, slot_index=0, window_offset=0):
         """iq: [nof_ports][slot_size] complex64 -> grid [nof_ports][14][12*bw_rb][2] uint16 (raw bf16)."""
         iq = np.ascontiguousarray(iq, dtype=np.complex64)

@@ -208,3 +208,59 @@ def extended_cp_pdus(tbs):
                            base_graph=1 if qm > 2 else 2)
         out.append((pdu, layers, n_prb * 12))
     return out
+
+
+# ---- PUSCH decoder at transport-block level ("next" row) ------------------------------------------------
+def pusch_decoder_shape(oracle, shape):
+    """(pdu of the transmit side, nof_ports, nof_subc, LLR amplitude, noise sigma): the noise is set where the first
+    transmission leaves codeblocks undecoded and the second (rv 2, combined) completes the transport block."""
+    if shape == "cfg2":
+        pdu, nof_ports, nof_subc, _ = baseline_config(2)
+        return pdu, nof_ports, nof_subc, 10.0, 5.0
+    if shape == "cfg1":
+        pdu, nof_ports, nof_subc, _ = baseline_config(1)
+        return pdu, nof_ports, nof_subc, 4.0, 7.0
+    tb_bits = oracle.tbs(12, 12, 0, 2, 400.0, 2, 100)
+    pdu = abi.make_pdu(bwp_size_rb=100, qm=2, dmrs_symbols=(2,), prb_start=0, prb_count=100, start_symbol=0, nof_symbols=14,
+                       precoding=abi.identity_precoding(2), tb_size_bytes=tb_bits // 8, base_graph=2, rnti=9, n_id=1)
+    return pdu, 2, 1200, 6.0, 6.0
+
+
+def pusch_decode_expected(oracle, d, cfg, llr, soft, cb_ok, cb_msg):
+    """pusch_decoder_impl restated on the oracle's codeblock functions (pusch_decoder_impl.cpp:318-497): updates soft /
+    cb_ok / cb_msg in place, returns (tb_crc_ok, codeblocks ok, iteration sum, iteration max, transport block or None)."""
+    bg, zc, C, n = cfg.base_graph, d["lifting_size"], d["nof_codeblocks"], d["full_length"]
+    k, nf, info = d["segment_length"], d["nof_filler_bits"], d["cb_info_bits"]
+    crc_id = 0x24B if C > 1 else (16 if d["nof_tb_crc_bits"] == 16 else 0x24A)
+    if cfg.new_data:
+        cb_ok[:] = 0
+    offset, it_sum, it_max = 0, 0, 0
+    for r in range(C):
+        e = d["rm_length_short"] if r < d["nof_short_segments"] else d["rm_length_long"]
+        soft[r] = oracle.ldpc_rate_dematch(bg, zc, cfg.rv, cfg.qm, d["n_ref"], nf, cfg.new_data, llr[offset: offset + e], soft[r])
+        offset += e
+        if cb_ok[r]:
+            continue
+        if cfg.use_early_stop:
+            it, bits = oracle.ldpc_decode(bg, zc, nf, crc_id, cfg.max_iterations, 0.8, soft[r])
+        else:  # pusch_codeblock_decoder.cpp:59-68: all iterations, then the CRC of the bits without the filler
+            _, bits = oracle.ldpc_decode(bg, zc, nf, 0, cfg.max_iterations, 0.8, soft[r])
+            it = cfg.max_iterations if oracle.crc_bits(crc_id, bits[: k - nf]) == 0 else 0
+        cb_msg[r] = bits
+        cb_ok[r] = 1 if it else 0
+        it_sum += it if it else cfg.max_iterations
+        it_max = max(it_max, it if it else cfg.max_iterations)
+    n_ok = int(cb_ok.sum())
+    tb, tb_ok = None, False
+    tb_bits = 8 * cfg.tb_size_bytes
+    if n_ok == C:
+        if C == 1:
+            tb_ok, tb = True, np.packbits(cb_msg[0][:tb_bits])
+        else:
+            stream = np.concatenate([cb_msg[r][:info] for r in range(C)])[: tb_bits + 24]
+            tb = np.packbits(stream[:tb_bits])
+            checksum = int("".join(map(str, stream[tb_bits:])), 2)
+            tb_ok = oracle.crc(0x24A, tb) == checksum
+            if not tb_ok:
+                cb_ok[:] = 0
+    return tb_ok, n_ok, it_sum, it_max, tb

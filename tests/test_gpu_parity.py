@@ -816,66 +816,20 @@ def test_device_entry_points_in_a_hip_graph(gpu_ctx, oracle):
 # ---------------------------------------------------------------------------------------------------------------------
 # PUSCH decoder at transport-block level ("next" row): segmentation, rate dematching, decoding, concatenation, TB CRC
 # ---------------------------------------------------------------------------------------------------------------------
-def pusch_decode_expected(oracle, d, cfg, llr, soft, cb_ok, cb_msg):
-    """pusch_decoder_impl restated on the oracle's codeblock functions (pusch_decoder_impl.cpp:318-497): updates soft /
-    cb_ok / cb_msg in place, returns (tb_crc_ok, codeblocks ok, iteration sum, iteration max, transport block or None)."""
-    bg, zc, C, n = cfg.base_graph, d["lifting_size"], d["nof_codeblocks"], d["full_length"]
-    k, nf, info = d["segment_length"], d["nof_filler_bits"], d["cb_info_bits"]
-    crc_id = 0x24B if C > 1 else (16 if d["nof_tb_crc_bits"] == 16 else 0x24A)
-    if cfg.new_data:
-        cb_ok[:] = 0
-    offset, it_sum, it_max = 0, 0, 0
-    for r in range(C):
-        e = d["rm_length_short"] if r < d["nof_short_segments"] else d["rm_length_long"]
-        soft[r] = oracle.ldpc_rate_dematch(bg, zc, cfg.rv, cfg.qm, d["n_ref"], nf, cfg.new_data, llr[offset: offset + e], soft[r])
-        offset += e
-        if cb_ok[r]:
-            continue
-        it, bits = oracle.ldpc_decode(bg, zc, nf, crc_id, cfg.max_iterations, 0.8, soft[r])
-        cb_msg[r] = bits
-        cb_ok[r] = 1 if it else 0
-        it_sum += it if it else cfg.max_iterations
-        it_max = max(it_max, it if it else cfg.max_iterations)
-    n_ok = int(cb_ok.sum())
-    tb, tb_ok = None, False
-    tb_bits = 8 * cfg.tb_size_bytes
-    if n_ok == C:
-        if C == 1:
-            tb_ok, tb = True, np.packbits(cb_msg[0][:tb_bits])
-        else:
-            stream = np.concatenate([cb_msg[r][:info] for r in range(C)])[: tb_bits + 24]
-            tb = np.packbits(stream[:tb_bits])
-            checksum = int("".join(map(str, stream[tb_bits:])), 2)
-            tb_ok = oracle.crc(0x24A, tb) == checksum
-            if not tb_ok:
-                cb_ok[:] = 0
-    return tb_ok, n_ok, it_sum, it_max, tb
-
-
 @pytest.mark.parametrize("shape", ["cfg2", "cfg1", "bg2_multi"])
-def test_pusch_decoder_transport_blocks_harq(gpu_ctx, oracle, shape):
+@pytest.mark.parametrize("early_stop", [1, 0])
+def test_pusch_decoder_transport_blocks_harq(gpu_ctx, oracle, shape, early_stop):
     """Two transport blocks through the whole receive-side coding chain on the GPU, twice (rv 0 as new data at an SNR
     where some codeblocks fail, then rv 2 combined): soft buffers, codeblock flags, iteration statistics and transport
     blocks against pusch_decoder_impl restated on the oracle; the transmit side is the oracle's PDSCH encoder."""
     import torch
     rng = np.random.default_rng({"cfg2": 21, "cfg1": 22, "bg2_multi": 23}[shape])
-    if shape == "cfg2":
-        pdu, nof_ports, nof_subc, _ = cases.baseline_config(2)
-        amp, sigma = 10.0, 5.0
-    elif shape == "cfg1":
-        pdu, nof_ports, nof_subc, _ = cases.baseline_config(1)
-        amp, sigma = 4.0, 7.0
-    else:
-        tb_bits = oracle.tbs(12, 12, 0, 2, 400.0, 2, 100)
-        pdu = abi.make_pdu(bwp_size_rb=100, qm=2, dmrs_symbols=(2,), prb_start=0, prb_count=100, start_symbol=0, nof_symbols=14,
-                           precoding=abi.identity_precoding(2), tb_size_bytes=tb_bits // 8, base_graph=2, rnti=9, n_id=1)
-        nof_ports, nof_subc = 2, 1200
-        amp, sigma = 6.0, 6.0
+    pdu, nof_ports, nof_subc, amp, sigma = cases.pusch_decoder_shape(oracle, shape)
     d = oracle.derive(pdu)
     n_tb, C, n = 2, d["nof_codeblocks"], d["full_length"]
     G = d["codeword_bits"]
     cfgs = [abi.PuschDecoderCfg(pdu.ldpc_base_graph, pdu.qm, rv, pdu.nof_layers, d["n_ref"], pdu.tb_size_bytes,
-                                G // pdu.qm, 6, 1, 1 if i == 0 else 0) for i, rv in enumerate((0, 2))]
+                                G // pdu.qm, 6, early_stop, 1 if i == 0 else 0) for i, rv in enumerate((0, 2))]
     soft_bytes, state_bytes, ncb = gpu_ctx.pusch_decoder_sizes(cfgs[0], n_tb)
     assert (soft_bytes, ncb) == (C * n, C)
     d_soft = torch.full((n_tb, soft_bytes), 33, dtype=torch.int8, device="cuda")     # stale content on purpose
@@ -901,7 +855,7 @@ def test_pusch_decoder_transport_blocks_harq(gpu_ctx, oracle, shape):
         res = d_res.cpu().numpy()
         got_soft = d_soft.cpu().numpy().reshape(n_tb, C, n)
         for i in range(n_tb):
-            tb_ok, n_ok, it_sum, it_max, tb = pusch_decode_expected(oracle, d, cfg, llrs[i, :G], soft[i], cb_ok[i], cb_msg[i])
+            tb_ok, n_ok, it_sum, it_max, tb = cases.pusch_decode_expected(oracle, d, cfg, llrs[i, :G], soft[i], cb_ok[i], cb_msg[i])
             assert np.array_equal(got_soft[i], soft[i]), (tx, i)
             assert tuple(res[i]) == (int(tb_ok), n_ok, it_sum, it_max), (tx, i, res[i], (tb_ok, n_ok, it_sum, it_max))
             if tb_ok:

@@ -239,6 +239,39 @@ def test_oracle_vs_ref_extended_cyclic_prefix_pdsch(oracle, ref):
     assert oracle.validate(bad) != 0 and ref.validate(bad) != 0
 
 
+@pytest.mark.parametrize("shape", ["cfg2", "cfg1", "bg2_multi"])
+@pytest.mark.parametrize("early_stop", [1, 0])
+def test_pusch_decoder_restatement_vs_reference(oracle, ref, shape, early_stop):
+    """The transport-block decoder the GPU tests compare with (cases.pusch_decode_expected: pusch_decoder_impl restated on
+    the oracle's codeblock functions) against the compiled reference's pusch_decoder_impl with its rx_buffer_pool, generic
+    rate dematcher and generic LDPC decoder: two HARQ transmissions (rv 0 new data, rv 2 combined), same CRC verdict,
+    number of decoder runs, iteration sum and maximum, and transport block."""
+    rng = np.random.default_rng({"cfg2": 21, "cfg1": 22, "bg2_multi": 23}[shape] + early_stop)
+    pdu, nof_ports, nof_subc, amp, sigma = cases.pusch_decoder_shape(oracle, shape)
+    d = oracle.derive(pdu)
+    C, n, G = d["nof_codeblocks"], d["full_length"], d["codeword_bits"]
+    tb = cases.random_tb(rng, pdu)
+    soft = np.zeros((C, n), np.int8)
+    cb_ok = np.ones(C, np.uint8)
+    cb_msg = np.zeros((C, d["segment_length"]), np.uint8)
+    harq_id = {"cfg2": 1, "cfg1": 2, "bg2_multi": 3}[shape] + 4 * early_stop
+    for tx, rv in enumerate((0, 2)):
+        cfg = abi.PuschDecoderCfg(pdu.ldpc_base_graph, pdu.qm, rv, pdu.nof_layers, d["n_ref"], pdu.tb_size_bytes, G // pdu.qm, 6,
+                                  early_stop, 1 if tx == 0 else 0)
+        pdu.rv = rv
+        _, rm, _ = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc, taps=True, codeword_bits=G)
+        pdu.rv = 0
+        bits = np.unpackbits(rm)[:G].astype(np.float64)
+        llr = np.clip(np.rint((1 - 2 * bits) * amp + rng.normal(0, sigma, G)), -120, 120).astype(np.int8)
+        skipped = int(cb_ok.sum()) if tx else 0
+        tb_ok, n_ok, it_sum, it_max, got_tb = cases.pusch_decode_expected(oracle, d, cfg, llr, soft, cb_ok, cb_msg)
+        r_ok, r_runs, r_sum, r_max, r_tb = ref.pusch_decode(cfg, harq_id, C, llr)
+        assert (r_ok, r_runs, r_sum, r_max) == (tb_ok, C - skipped, it_sum, it_max), (tx, (r_ok, r_runs, r_sum, r_max))
+        if tb_ok:
+            assert np.array_equal(r_tb, got_tb) and np.array_equal(got_tb, tb)
+    assert tb_ok
+
+
 def test_baseline_config_derived_values(oracle):
     """The derived sizes SURVEY.md section 8d lists for the BASELINE configs."""
     d = oracle.derive(cases.baseline_config(3)[0])
