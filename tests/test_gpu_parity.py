@@ -864,3 +864,49 @@ def test_pusch_decoder_transport_blocks_harq(gpu_ctx, oracle, shape, early_stop)
             seen_partial |= 0 < n_ok < C or (tx == 0 and not tb_ok)
     assert all(int(r[0]) == 1 for r in res), "the retransmission should complete every transport block"
     assert seen_partial, "the first transmission should leave work for the second (pick a lower SNR)"
+
+
+def test_transmit_receive_loop_full_size(gpu_ctx):
+    """Size-independent property at the BASELINE config-3 shape: transport blocks -> GPU PDSCH encoder chain (rate-matched
+    codeword tap) -> noisy LLRs -> GPU UL-SCH decoder (rate dematcher, LDPC, concatenation, CRC24A) give the transport
+    blocks back, a first transmission that is too noisy included (HARQ retransmission with rv 3 completes it)."""
+    import torch
+    pdu, nof_ports, nof_subc, _ = cases.baseline_config(3)
+    slots = 4
+    d = lib.derive(pdu)
+    G, tb_size = d["codeword_bits"], pdu.tb_size_bytes
+    tb_stride = (tb_size + 3) & ~3
+    d_tb = torch.randint(0, 256, (slots, tb_stride), dtype=torch.uint8, device="cuda")
+    rng = np.random.default_rng(808)
+    cfg0 = abi.PuschDecoderCfg(pdu.ldpc_base_graph, pdu.qm, 0, pdu.nof_layers, d["n_ref"], tb_size, G // pdu.qm, 8, 1, 1)
+    soft_bytes, state_bytes, _ = gpu_ctx.pusch_decoder_sizes(cfg0, slots)
+    d_soft = torch.zeros((slots, soft_bytes), dtype=torch.int8, device="cuda")
+    d_state = torch.zeros((state_bytes,), dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros((slots, tb_stride), dtype=torch.uint8, device="cuda")
+    d_res = torch.zeros((slots, 4), dtype=torch.int32, device="cuda")
+    first_ok = None
+    for tx, (rv, sigma) in enumerate(((0, 11.0), (3, 9.0))):
+        pdus = []
+        for i in range(slots):
+            p = cases.baseline_config(3, slot_index=i)[0]
+            p.rv = rv
+            pdus.append(p)
+        plan = lib.PdschPlan(gpu_ctx, pdus, [i * tb_stride for i in range(slots)], list(range(slots)), slots, nof_ports, nof_subc)
+        d_cw = torch.zeros((plan.codeword_bits + 7) // 8 + 64, dtype=torch.uint8, device="cuda")
+        plan.run(d_tb.reshape(-1), None, d_cw_rm=d_cw)
+        gpu_ctx.synchronize()
+        cw = d_cw.cpu().numpy()
+        offs = [plan.codeword_offset(i) for i in range(slots)]
+        bits = np.stack([np.unpackbits(cw[o // 8: o // 8 + (G + 7) // 8])[:G] for o in offs]).astype(np.float32)
+        llr = np.clip(np.rint((1 - 2 * bits) * 20 + rng.normal(0, sigma, bits.shape)), -120, 120).astype(np.int8)
+        cfg = abi.PuschDecoderCfg(pdu.ldpc_base_graph, pdu.qm, rv, pdu.nof_layers, d["n_ref"], tb_size, G // pdu.qm, 8, 1,
+                                  1 if tx == 0 else 0)
+        gpu_ctx.pusch_decode_batch(cfg, slots, dev(llr), G, d_soft, d_state, d_out, tb_stride, d_res)
+        torch.cuda.synchronize()
+        res = d_res.cpu().numpy()
+        if tx == 0:
+            first_ok = res[:, 0].copy()
+        plan.close()
+    assert not first_ok.all(), "the first transmission should fail for some transport blocks (raise its noise)"
+    assert res[:, 0].all(), res
+    assert torch.equal(d_out[:, :tb_size], d_tb[:, :tb_size])
