@@ -253,6 +253,44 @@ int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, u
  * nof_ports x nrphy_ofdm_slot_size(cfg, slot_index) complex samples, port after port (blocking). */
 int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t slot_index, float* iq);
 
+/* ---- other downlink grid writers ("next" row): NZP-CSI-RS generator -----------
+ * Replaces nzp_csi_rs_generator::map (R/include/srsran/phy/upper/signal_processors/nzp_csi_rs_generator.h:
+ * 39-90; impl R/lib/phy/upper/signal_processors/nzp_csi_rs_generator_impl.cpp:96-352 with the RE patterns of
+ * R/lib/ran/csi_rs/csi_rs_pattern.cpp and resource_grid_mapper_impl::map, resource_grid_mapper_impl.cpp:
+ * 150-277).  The fields are nzp_csi_rs_generator::config_t.  Rows 1 to 5 of TS 38.211 Table 7.4.1.5.3-1 (1, 1,
+ * 2, 4, 4 ports: what a grid of NRPHY_MAX_PORTS ports can carry); density and CDM type must be the ones the
+ * row allows.  Every CDM group writes its resource elements on ALL ports of the precoding (zeros where the
+ * weights are zero), as the reference does. */
+typedef struct nrphy_csi_rs_cfg {
+  uint32_t slot_index;       /* slot within the frame */
+  uint32_t cp;               /* 0 normal, 1 extended */
+  uint32_t start_rb;
+  uint32_t nof_rb;
+  uint32_t row;              /* csi_rs_mapping_table_row, 1..5 */
+  uint32_t nof_k_ref;
+  uint32_t k_ref[6];         /* freq_allocation_ref_idx */
+  uint32_t symbol_l0;
+  uint32_t symbol_l1;        /* unused by rows 1..5 */
+  uint32_t cdm;              /* csi_rs_cdm_type: 0 no_CDM, 1 fd_CDM2 */
+  uint32_t density;          /* csi_rs_freq_density_type: 0 dot5_even_RB, 1 dot5_odd_RB, 2 one, 3 three */
+  uint32_t scrambling_id;
+  float    amplitude;
+  uint32_t nof_ports;        /* ports of the row = ports and layers of the precoding */
+  uint32_t prg_size_rb;
+  uint32_t nof_prg;          /* must be 1: the reference's generator only handles wideband precoding */
+  const float* precoding;    /* [nof_ports][nof_ports] complex: coefficient(layer, port) at [port][layer] */
+} nrphy_csi_rs_cfg_t;
+/* NRPHY_OK when the configuration is one this library maps (the reference's validator accepts everything). */
+int nrphy_csi_rs_validate(const nrphy_csi_rs_cfg_t* cfg);
+/* n signals into device grids ([grid][port][14][subc] cbf16): signal i into grid grid_index[i].  The
+ * configurations are copied at the call (host pointers, like PDUs at plan creation); asynchronous on
+ * `stream` afterwards. */
+int nrphy_csi_rs_map(nrphy_ctx_t* ctx, uint32_t n, const nrphy_csi_rs_cfg_t* cfgs, const uint32_t* grid_index,
+                     void* d_grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc, void* stream);
+/* One signal into a host grid [nof_ports][14][nof_subc] cbf16 (read and written; blocking). */
+int nrphy_csi_rs_map_host(nrphy_ctx_t* ctx, const nrphy_csi_rs_cfg_t* cfg, void* grid, uint32_t nof_ports,
+                          uint32_t nof_subc);
+
 /* ---- receive side ("next" row): LDPC rate dematcher --------------------------
  * Replaces ldpc_rate_dematcher::rate_dematch (R/include/srsran/phy/upper/channel_coding/ldpc/
  * ldpc_rate_dematcher.h; impl R/lib/phy/upper/channel_coding/ldpc/ldpc_rate_dematcher_impl.cpp:43-256):

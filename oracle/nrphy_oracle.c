@@ -819,6 +819,143 @@ static void put_dmrs(const nrphy_pdsch_pdu_t* pdu, uint16_t* grid, unsigned nof_
   }
 }
 
+/* ---- NZP-CSI-RS ("next" row) ---------------------------------------------------------------
+ * nzp_csi_rs_generator_impl::map (R/lib/phy/upper/signal_processors/nzp_csi_rs_generator_impl.cpp:96-352), the RE
+ * patterns of get_csi_rs_pattern (R/lib/ran/csi_rs/csi_rs_pattern.cpp: rows 1-5 of TS 38.211 Table 7.4.1.5.3-1) and
+ * the generic branch of resource_grid_mapper_impl::map (resource_grid_mapper_impl.cpp:150-277).
+ * Per CDM group: one QPSK sequence per OFDM symbol of the group (c_init of TS 38.211 Section 7.4.1.5.2, the elements
+ * below the first occupied PRB skipped), the group's second port is the first with every other element negated
+ * (FD-CDM2), the group is precoded onto all ports and written over whatever the grid holds there. */
+#define CSI_DENSITY_DOT5_EVEN 0
+#define CSI_DENSITY_DOT5_ODD 1
+#define CSI_DENSITY_ONE 2
+#define CSI_DENSITY_THREE 3
+
+int oracle_csi_rs_validate(const nrphy_csi_rs_cfg_t* c)
+{
+  static const unsigned row_ports[6] = {0, 1, 1, 2, 4, 4};
+  if (c == NULL || c->row < 1 || c->row > 5 || c->nof_k_ref != 1 || c->cp > 1 || c->nof_rb == 0 ||
+      c->nof_ports != row_ports[c->row] || c->precoding == NULL || c->nof_prg != 1 || c->prg_size_rb == 0 ||
+      c->start_rb + c->nof_rb > NRPHY_MAX_RB) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  unsigned nsymb = c->cp ? 12 : 14, k0 = c->k_ref[0];
+  switch (c->row) { /* the assertions of mapping_row_1 .. mapping_row_5 */
+    case 1:
+      return (k0 <= 3 && c->density == CSI_DENSITY_THREE && c->cdm == 0 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
+    case 2:
+      return (k0 < 12 && c->density != CSI_DENSITY_THREE && c->cdm == 0 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
+    case 3:
+      return (k0 < 11 && c->density != CSI_DENSITY_THREE && c->cdm == 1 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
+    case 4:
+      return (k0 < 9 && c->density == CSI_DENSITY_ONE && c->cdm == 1 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
+    default:
+      return (k0 < 11 && c->density == CSI_DENSITY_ONE && c->cdm == 1 && c->symbol_l0 + 1 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
+  }
+}
+
+int oracle_csi_rs_map(const nrphy_csi_rs_cfg_t* c, uint16_t* grid, uint32_t nof_ports, uint32_t nof_subc)
+{
+  if (oracle_csi_rs_validate(c) != NRPHY_OK || nof_ports < c->nof_ports || nof_subc < 12 * (c->start_rb + c->nof_rb)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const unsigned group_size = c->cdm ? 2 : 1, nof_groups = c->nof_ports / group_size;
+  const int      half = c->density == CSI_DENSITY_DOT5_EVEN || c->density == CSI_DENSITY_DOT5_ODD;
+  /* PRB range and stride (build_re_patterns) */
+  unsigned rb_begin = c->start_rb, rb_end = c->start_rb + c->nof_rb, rb_stride = half ? 2 : 1;
+  if (half && (((c->start_rb % 2) != 0) == (c->density == CSI_DENSITY_DOT5_EVEN))) {
+    ++rb_begin;
+  }
+  /* sequence elements below the first occupied PRB (get_nof_skipped_elements) and per symbol (get_seq_len) */
+  unsigned first_prb = c->start_rb;
+  if (c->density == CSI_DENSITY_DOT5_EVEN) {
+    first_prb = c->start_rb + c->start_rb % 2;
+  } else if (c->density == CSI_DENSITY_DOT5_ODD) {
+    first_prb = c->start_rb + (1 - c->start_rb % 2);
+  }
+  unsigned advance = 0;
+  if (c->density == CSI_DENSITY_THREE) {
+    advance = 3 * first_prb;
+  } else if (c->density == CSI_DENSITY_ONE) {
+    advance = (c->row == 2) ? first_prb : 2 * first_prb;
+  } else {
+    advance = (c->row == 2) ? first_prb / 2 : first_prb;
+  }
+  unsigned seq_len = c->nof_rb;
+  if (half) {
+    seq_len /= 2;
+    if (c->nof_rb % 2 != 0 && (((c->start_rb % 2) != 0) == (c->density == CSI_DENSITY_DOT5_ODD))) {
+      ++seq_len;
+    }
+  } else if (c->density == CSI_DENSITY_THREE) {
+    seq_len *= 3;
+  }
+  if (c->cdm) {
+    seq_len *= 2;
+  }
+  const unsigned nsymb     = c->cp ? 12 : 14;
+  const float    amplitude = (float)(M_SQRT1_2 * (double)c->amplitude);
+  float*         seq       = (float*)malloc(sizeof(float) * 2 * (seq_len ? seq_len : 1));
+  for (unsigned g = 0; g != nof_groups; ++g) {
+    /* k_bar / l_bar of the group's first port (mapping_row_n) and its RE mask within a PRB */
+    unsigned k_bar = c->k_ref[0], l_bar = c->symbol_l0, re_mask = 0;
+    if (c->row == 4) {
+      k_bar += 2 * g;
+    } else if (c->row == 5) {
+      l_bar += g;
+    }
+    if (c->row == 1) {
+      re_mask = (1U << k_bar) | (1U << (k_bar + 4)) | (1U << (k_bar + 8));
+    } else if (c->cdm == 0) {
+      re_mask = 1U << k_bar;
+    } else {
+      re_mask = 3U << k_bar;
+    }
+    /* one symbol per group for these rows */
+    const unsigned l      = l_bar;
+    const uint32_t c_init = (uint32_t)((1024ULL * (nsymb * c->slot_index + l + 1) * (2 * c->scrambling_id + 1) + c->scrambling_id) & 0x7FFFFFFFULL);
+    oracle_prg_generate_float(c_init, 2 * advance, amplitude, seq, 2 * seq_len);
+    unsigned m = 0; /* element of the sequence = RE of the pattern in ascending subcarrier order */
+    for (unsigned prb = rb_begin; prb < rb_end; prb += rb_stride) {
+      for (unsigned k = 0; k != 12; ++k) {
+        if (!((re_mask >> k) & 1U)) {
+          continue;
+        }
+        const unsigned subc = 12 * prb + k;
+        /* one PRG: the generator builds the group's precoding with a single PRG (nzp_csi_rs_generator_impl.cpp:259) */
+        const float*   w    = c->precoding;
+        for (unsigned port = 0; port != c->nof_ports; ++port) {
+          float accr = 0, acci = 0;
+          for (unsigned j = 0; j != group_size; ++j) {
+            const unsigned layer = g * group_size + j;
+            const float    sign  = (j == 1 && (m & 1U)) ? -1.0F : 1.0F; /* fd_cdm2_table: w_f = {+1, -1} */
+            float          pr, pi;
+            cmul_fmaddsub(sign * seq[2 * m], sign * seq[2 * m + 1], w[2 * (port * c->nof_ports + layer)],
+                          w[2 * (port * c->nof_ports + layer) + 1], &pr, &pi);
+            if (j == 0) {
+              accr = pr;
+              acci = pi;
+            } else {
+              accr += pr;
+              acci += pi;
+            }
+          }
+          size_t o    = 2 * (((size_t)port * 14 + l) * nof_subc + subc);
+          grid[o]     = to_bf16(accr);
+          grid[o + 1] = to_bf16(acci);
+        }
+        ++m;
+      }
+    }
+    if (m != seq_len) { /* the reference asserts that the pattern consumes the whole sequence */
+      free(seq);
+      return NRPHY_ERR_ARGUMENT;
+    }
+  }
+  free(seq);
+  return NRPHY_OK;
+}
+
 int oracle_pdsch_process(const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb, uint16_t* grid, uint32_t nof_ports,
                          uint32_t nof_subc, uint8_t* cw_rm, uint8_t* cw_scrambled)
 {

@@ -44,6 +44,9 @@ int      oracle_dft(uint32_t n, int inverse, const float* in, float* out);
 /* LDPC decoder ("next" row, receive side): returns the iteration count (>= 1) when the CRC passed, 0 otherwise. */
 int oracle_ldpc_decode(uint32_t bg, uint32_t zc, uint32_t nof_filler, uint32_t crc_poly_id, uint32_t max_iterations,
                        float scaling_factor, const int8_t* llr, uint32_t nof_llr, uint8_t* message_bits);
+/* NZP-CSI-RS generator ("next" row, section 8f-2): writes the signal's RE into grid [nof_ports][14][nof_subc] cbf16. */
+int oracle_csi_rs_validate(const nrphy_csi_rs_cfg_t* cfg);
+int oracle_csi_rs_map(const nrphy_csi_rs_cfg_t* cfg, uint16_t* grid, uint32_t nof_ports, uint32_t nof_subc);
 /* LDPC rate dematcher ("next" row): out = soft buffer of (66 or 50) * Zc LLRs, read and written. */
 int oracle_ldpc_rate_dematch(uint32_t bg, uint32_t zc, uint32_t rv, uint32_t qm, uint32_t nref, uint32_t nof_filler,
                              int new_data, const int8_t* in, uint32_t e, int8_t* out);

@@ -39,6 +39,7 @@
 #include "lib/phy/upper/channel_processors/pdsch_processor_validator_impl.h"
 #include "lib/phy/upper/sequence_generators/pseudo_random_generator_impl.h"
 #include "lib/phy/upper/signal_processors/dmrs_pdsch_processor_impl.h"
+#include "lib/phy/upper/signal_processors/nzp_csi_rs_generator_impl.h"
 #include "srsran/ran/precoding/precoding_codebooks.h"
 #include "srsran/ran/sch/tbs_calculator.h"
 #include "srsran/srsvec/bit.h"
@@ -780,6 +781,48 @@ int ref_pusch_decode(uint32_t      bg,
   result[2]      = static_cast<uint32_t>(std::lround(st.get_mean() * st.get_nof_observations()));
   result[3]      = st.get_nof_observations() ? st.get_max() : 0;
   return 0;
+}
+
+// nzp_csi_rs_generator_impl::map into a grid that already holds `grid_io` ([nof_ports][14][nof_subc] cbf16 raw): what the
+// signal overwrites and what it leaves alone are both visible.  simd: 0 generic precoder, 1 AVX2.
+int ref_csi_rs_map(const nrphy_csi_rs_cfg_t* c, uint16_t* grid_io, unsigned nof_ports, unsigned nof_subc, int simd)
+{
+  resource_grid_impl grid(nof_ports, 14, nof_subc, make_precoder(simd));
+  grid.set_all_zero();
+  for (unsigned p = 0; p != nof_ports; ++p) {
+    for (unsigned l = 0; l != 14; ++l) {
+      const cbf16_t* row = reinterpret_cast<const cbf16_t*>(grid_io) + (static_cast<size_t>(p) * 14 + l) * nof_subc;
+      grid.get_writer().put(p, l, 0, 1, span<const cbf16_t>(row, nof_subc));
+    }
+  }
+  nzp_csi_rs_generator::config_t cfg;
+  cfg.slot                     = slot_point(4, 0, c->slot_index);
+  cfg.cp                       = c->cp ? cyclic_prefix::EXTENDED : cyclic_prefix::NORMAL;
+  cfg.start_rb                 = c->start_rb;
+  cfg.nof_rb                   = c->nof_rb;
+  cfg.csi_rs_mapping_table_row = c->row;
+  for (unsigned i = 0; i != c->nof_k_ref; ++i) {
+    cfg.freq_allocation_ref_idx.push_back(c->k_ref[i]);
+  }
+  cfg.symbol_l0     = c->symbol_l0;
+  cfg.symbol_l1     = c->symbol_l1;
+  cfg.cdm           = static_cast<csi_rs_cdm_type>(c->cdm);
+  cfg.freq_density  = static_cast<csi_rs_freq_density_type>(c->density);
+  cfg.scrambling_id = c->scrambling_id;
+  cfg.amplitude     = c->amplitude;
+  cfg.precoding     = precoding_configuration(c->nof_ports, c->nof_ports, c->nof_prg, c->prg_size_rb);
+  for (unsigned g = 0; g != c->nof_prg; ++g) {
+    for (unsigned p = 0; p != c->nof_ports; ++p) {
+      for (unsigned l = 0; l != c->nof_ports; ++l) {
+        const float* w = c->precoding + 2 * ((g * c->nof_ports + p) * c->nof_ports + l);
+        cfg.precoding.set_coefficient(cf_t(w[0], w[1]), l, p, g);
+      }
+    }
+  }
+  nzp_csi_rs_generator_impl generator(std::make_unique<pseudo_random_generator_impl>());
+  generator.map(grid.get_mapper(), cfg);
+  copy_grid_out(grid_io, grid.get_reader(), nof_ports, nof_subc);
+  return NRPHY_OK;
 }
 
 // ofdm_slot_demodulator::demodulate of every port of one slot: iq_in [nof_ports][slot_size] complex float ->

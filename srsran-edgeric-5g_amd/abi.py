@@ -108,6 +108,40 @@ class PuschDecoderCfg(C.Structure):
                 ("max_iterations", C.c_uint32), ("use_early_stop", C.c_uint32), ("new_data", C.c_uint32)]
 
 
+class CsiRsCfg(C.Structure):
+    """nrphy_csi_rs_cfg_t (nzp_csi_rs_generator::config_t)."""
+    _fields_ = [("slot_index", C.c_uint32), ("cp", C.c_uint32), ("start_rb", C.c_uint32), ("nof_rb", C.c_uint32),
+                ("row", C.c_uint32), ("nof_k_ref", C.c_uint32), ("k_ref", C.c_uint32 * 6), ("symbol_l0", C.c_uint32),
+                ("symbol_l1", C.c_uint32), ("cdm", C.c_uint32), ("density", C.c_uint32), ("scrambling_id", C.c_uint32),
+                ("amplitude", C.c_float), ("nof_ports", C.c_uint32), ("prg_size_rb", C.c_uint32), ("nof_prg", C.c_uint32),
+                ("precoding", C.POINTER(C.c_float))]
+
+
+CSI_DENSITY = {"dot5_even": 0, "dot5_odd": 1, "one": 2, "three": 3}
+CSI_ROW_PORTS = {1: 1, 2: 1, 3: 2, 4: 4, 5: 4}
+
+
+def make_csi_rs(*, row, start_rb, nof_rb, k0, l0, density, slot_index=0, cp=0, scrambling_id=0, amplitude=1.0,
+                precoding=None, prg_size_rb=MAX_RB):
+    """Builds a CsiRsCfg for rows 1-5; ``precoding`` [nof_prg][ports][ports] complex64 (default identity).  The weight
+    array is attached to the struct (``_keepalive``)."""
+    ports = CSI_ROW_PORTS[row]
+    if precoding is None:
+        precoding = np.eye(ports, dtype=np.complex64)[None]
+    w = np.ascontiguousarray(np.asarray(precoding, dtype=np.complex64)).view(np.float32).reshape(-1)
+    c = CsiRsCfg()
+    c.slot_index, c.cp, c.start_rb, c.nof_rb, c.row = slot_index, cp, start_rb, nof_rb, row
+    c.nof_k_ref, c.symbol_l0, c.symbol_l1 = 1, l0, 0
+    c.k_ref[0] = k0
+    c.cdm = 0 if row in (1, 2) else 1
+    c.density = CSI_DENSITY[density]
+    c.scrambling_id, c.amplitude, c.nof_ports = scrambling_id, amplitude, ports
+    c.prg_size_rb, c.nof_prg = prg_size_rb, np.asarray(precoding).shape[0]
+    c._keepalive = w
+    c.precoding = w.ctypes.data_as(C.POINTER(C.c_float))
+    return c
+
+
 class OfdmConfig(C.Structure):
     _fields_ = [
         ("numerology", C.c_uint32),
@@ -251,6 +285,9 @@ def declare(lib, prefix="nrphy_"):
     sig("ldpc_decode_host", i32, vp, P(LdpcDecoderCfg), vp, u8p, P(u32))
     sig("ldpc_rate_dematch", i32, vp, P(LdpcRateDematcherCfg), u32, vp, u32, vp, u32, i32, vp)
     sig("ldpc_rate_dematch_host", i32, vp, P(LdpcRateDematcherCfg), vp, vp, i32)
+    sig("csi_rs_validate", i32, P(CsiRsCfg))
+    sig("csi_rs_map", i32, vp, u32, P(CsiRsCfg), P(u32), vp, u32, u32, vp)
+    sig("csi_rs_map_host", i32, vp, P(CsiRsCfg), vp, u32, u32)
     sig("pusch_decoder_sizes", i32, P(PuschDecoderCfg), u32, P(u64), P(u64), P(u32))
     sig("pusch_decode_batch", i32, vp, P(PuschDecoderCfg), u32, vp, u64, vp, vp, vp, u32, vp, vp)
     sig("pusch_decode_codeblock_host", i32, vp, P(LdpcRateDematcherCfg), u32, u32, C.c_float, vp, vp, i32, u8p, P(u32))
@@ -270,4 +307,5 @@ ABI_SYMBOLS = [
     "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",
     "nrphy_ldpc_decode", "nrphy_ldpc_decode_host", "nrphy_ldpc_rate_dematch", "nrphy_ldpc_rate_dematch_host",
     "nrphy_pusch_decode_codeblock_host", "nrphy_pusch_decoder_sizes", "nrphy_pusch_decode_batch",
+    "nrphy_csi_rs_validate", "nrphy_csi_rs_map", "nrphy_csi_rs_map_host",
 ]

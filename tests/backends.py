@@ -253,6 +253,21 @@ class CpuBackend:
         assert f(*args) == 0
         return out
 
+    def csi_rs_map(self, cfg, grid, simd=1):
+        """nzp_csi_rs_generator::map into a copy of grid [nof_ports][14][nof_subc][2] uint16 (raw cbf16)."""
+        out = np.array(grid, dtype=np.uint16, copy=True)
+        nof_ports, _, nof_subc, _ = out.shape
+        args = [C.byref(cfg), _ptr(out), C.c_uint32(nof_ports), C.c_uint32(nof_subc)]
+        if self.is_ref:
+            args.append(C.c_int(simd))
+        rc = self._f("csi_rs_map")(*args)
+        assert rc == 0, rc
+        return out
+
+    def csi_rs_validate(self, cfg):
+        assert not self.is_ref
+        return int(self._f("csi_rs_validate")(C.byref(cfg)))
+
     def pusch_decode(self, cfg, harq_id, nof_codeblocks, llr):
         """pusch_decoder_impl of the compiled reference on one transport block (HARQ state kept in the reference's
         rx_buffer_pool under harq_id): returns (tb_crc_ok, decoder runs, iteration sum, iteration max, tb bytes)."""

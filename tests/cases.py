@@ -264,3 +264,29 @@ def pusch_decode_expected(oracle, d, cfg, llr, soft, cb_ok, cb_msg):
             if not tb_ok:
                 cb_ok[:] = 0
     return tb_ok, n_ok, it_sum, it_max, tb
+
+
+# ---- NZP-CSI-RS ("next" row, section 8f-2) ---------------------------------------------------------------
+def csi_rs_cases(rng):
+    """[(name, cfg, nof_ports, nof_subc)]: rows 1-5 of TS 38.211 Table 7.4.1.5.3-1 with every density the row allows, odd
+    and even first PRBs and PRB counts (the rounding rules of the 0.5 densities), identity and dense (wideband) precoding,
+    both cyclic prefixes."""
+    out = []
+
+    def dense(ports, nof_prg):
+        return ((rng.standard_normal((nof_prg, ports, ports)) + 1j * rng.standard_normal((nof_prg, ports, ports))) / 2).astype(np.complex64)
+
+    for row, densities, k0s in ((1, ("three",), (0, 3)), (2, ("one", "dot5_even", "dot5_odd"), (0, 11)),
+                                (3, ("one", "dot5_even", "dot5_odd"), (0, 10)), (4, ("one",), (0, 8)), (5, ("one",), (2, 10))):
+        ports = abi.CSI_ROW_PORTS[row]
+        for density in densities:
+            for i, (start_rb, nof_rb) in enumerate(((0, 52), (3, 25), (4, 25), (7, 24), (1, 1), (0, 273))):
+                k0 = k0s[i % 2]
+                prg = None if i % 2 == 0 else dense(ports, 1)
+                cfg = abi.make_csi_rs(row=row, start_rb=start_rb, nof_rb=nof_rb, k0=k0, l0=(3 + 2 * i) % 12, density=density,
+                                      slot_index=(5 * i + row) % 20, cp=i % 2 if i != 5 else 0, scrambling_id=(97 * i + row) % 1024,
+                                      amplitude=0.5 + 0.25 * i, precoding=prg,
+                                      prg_size_rb=abi.MAX_RB)
+                nof_subc = 12 * max(52, start_rb + nof_rb)
+                out.append(("row%d_%s_%d" % (row, density, i), cfg, max(ports, 1 + i % 2 * 3), nof_subc))
+    return out

@@ -272,6 +272,21 @@ def test_pusch_decoder_restatement_vs_reference(oracle, ref, shape, early_stop):
     assert tb_ok
 
 
+def test_oracle_nzp_csi_rs_vs_reference(oracle, ref):
+    """NZP-CSI-RS generator (rows 1-5) against the compiled reference's nzp_csi_rs_generator_impl (AVX2 and generic
+    precoders): the signal is mapped into a grid full of other data; every grid word is compared, so both what is written
+    (including the zeros a CDM group writes on the ports it does not use) and what is left alone are checked."""
+    rng = np.random.default_rng(7415)
+    for name, cfg, nof_ports, nof_subc in cases.csi_rs_cases(rng):
+        assert oracle.csi_rs_validate(cfg) == 0, name
+        grid = (rng.standard_normal((nof_ports, 14, nof_subc, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        got = oracle.csi_rs_map(cfg, grid)
+        for simd in (1, 0):
+            want = ref.csi_rs_map(cfg, grid, simd=simd)
+            assert np.array_equal(got, want), (name, simd, int(np.count_nonzero(got != want)))
+        assert np.count_nonzero(got != grid) > 0 or cfg.nof_rb == 1, name   # one PRB at density 0.5 may hold nothing
+
+
 def test_baseline_config_derived_values(oracle):
     """The derived sizes SURVEY.md section 8d lists for the BASELINE configs."""
     d = oracle.derive(cases.baseline_config(3)[0])
