@@ -34,6 +34,8 @@
 #include "srsran/phy/support/resource_grid_writer.h"
 #include "srsran/phy/upper/channel_processors/channel_processor_factories.h"
 #include "srsran/phy/upper/channel_processors/pdsch_processor.h"
+#include "srsran/phy/upper/signal_processors/nzp_csi_rs_generator.h"
+#include "srsran/ran/csi_rs/csi_rs_pattern.h"
 #include "srsran/srsvec/bit.h"
 
 #include <cstring>
@@ -818,6 +820,103 @@ public:
 
 private:
   std::shared_ptr<context> ctx;
+};
+
+// ---- other downlink grid writers ("next" row): NZP-CSI-RS generator -------------------------------------------------
+// Drop-in for create_nzp_csi_rs_generator_factory_sw (R/include/srsran/phy/upper/signal_processors/
+// signal_processor_factories.h) for rows 1-5 of TS 38.211 Table 7.4.1.5.3-1.  Host-span form: the signal is computed
+// into a staging grid and its resource elements are put into the caller's grid through the writer, every CDM group on
+// all ports, as the reference's mapper does.  A device-resident L1 calls nrphy_csi_rs_map on its device grids instead.
+class nzp_csi_rs_generator_adaptor : public srsran::nzp_csi_rs_generator
+{
+public:
+  nzp_csi_rs_generator_adaptor(std::shared_ptr<context> ctx_, writer_resolver resolver_, unsigned nof_ports_, unsigned nof_subc_) :
+    ctx(std::move(ctx_)), resolver(std::move(resolver_)), nof_ports(nof_ports_), nof_subc(nof_subc_),
+    staging(static_cast<size_t>(nof_ports_) * NRPHY_NSYMB * nof_subc_)
+  {
+  }
+
+  void map(srsran::resource_grid_mapper& mapper, const config_t& config) override
+  {
+    using namespace srsran;
+    std::vector<float> weights(2 * config.precoding.get_nof_ports() * config.precoding.get_nof_layers());
+    nrphy_csi_rs_cfg_t c = {};
+    c.slot_index         = config.slot.slot_index();
+    c.cp                 = (config.cp == cyclic_prefix::NORMAL) ? 0 : 1;
+    c.start_rb           = config.start_rb;
+    c.nof_rb             = config.nof_rb;
+    c.row                = config.csi_rs_mapping_table_row;
+    c.nof_k_ref          = config.freq_allocation_ref_idx.size();
+    for (unsigned i = 0; i != c.nof_k_ref && i != 6; ++i) {
+      c.k_ref[i] = config.freq_allocation_ref_idx[i];
+    }
+    c.symbol_l0     = config.symbol_l0;
+    c.symbol_l1     = config.symbol_l1;
+    c.cdm           = static_cast<uint32_t>(config.cdm);
+    c.density       = static_cast<uint32_t>(config.freq_density);
+    c.scrambling_id = config.scrambling_id;
+    c.amplitude     = config.amplitude;
+    c.nof_ports     = config.precoding.get_nof_ports();
+    c.prg_size_rb   = config.precoding.get_prg_size();
+    c.nof_prg       = config.precoding.get_nof_prg();
+    for (unsigned port = 0; port != c.nof_ports; ++port) {
+      for (unsigned layer = 0; layer != config.precoding.get_nof_layers(); ++layer) {
+        cf_t w                                                  = config.precoding.get_coefficient(layer, port, 0);
+        weights[2 * (port * config.precoding.get_nof_layers() + layer)]     = w.real();
+        weights[2 * (port * config.precoding.get_nof_layers() + layer) + 1] = w.imag();
+      }
+    }
+    c.precoding = weights.data();
+    srsran_assert(nrphy_csi_rs_validate(&c) == NRPHY_OK, "CSI-RS configuration outside rows 1-5 / wideband precoding.");
+    std::fill(staging.begin(), staging.end(), cbf16_t());
+    int rc = nrphy_csi_rs_map_host(ctx->get(), &c, staging.data(), nof_ports, nof_subc);
+    srsran_assert(rc == NRPHY_OK, "nrphy_csi_rs_map_host failed: {}", nrphy_strerror(rc));
+
+    // The RE of the signal: the union of the per-port patterns, every one of them written on all precoding ports.
+    csi_rs_pattern_configuration pc;
+    pc.start_rb                 = config.start_rb;
+    pc.nof_rb                   = config.nof_rb;
+    pc.csi_rs_mapping_table_row = config.csi_rs_mapping_table_row;
+    pc.freq_allocation_ref_idx  = config.freq_allocation_ref_idx;
+    pc.symbol_l0                = config.symbol_l0;
+    pc.symbol_l1                = config.symbol_l1;
+    pc.cdm                      = config.cdm;
+    pc.freq_density             = config.freq_density;
+    csi_rs_pattern        pattern = get_csi_rs_pattern(pc);
+    resource_grid_writer& writer  = resolver(mapper);
+    std::vector<cbf16_t>  packed(nof_subc);
+    for (unsigned l = 0, nsymb = get_nsymb_per_slot(config.cp); l != nsymb; ++l) {
+      bounded_bitset<MAX_RB * NRE> mask(nof_subc);
+      for (const csi_rs_pattern_port& port_pattern : pattern.prb_patterns) {
+        if (!port_pattern.symbol_mask.test(l)) {
+          continue;
+        }
+        for (unsigned prb = pattern.rb_begin; prb < pattern.rb_end; prb += pattern.rb_stride) {
+          for (unsigned k = 0; k != NRE; ++k) {
+            if (port_pattern.re_mask.test(k)) {
+              mask.set(NRE * prb + k);
+            }
+          }
+        }
+      }
+      if (mask.none()) {
+        continue;
+      }
+      for (unsigned port = 0; port != c.nof_ports; ++port) {
+        const cbf16_t* row = &staging[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc];
+        unsigned       n   = 0;
+        mask.for_each(0, mask.size(), [&](unsigned k) { packed[n++] = row[k]; });
+        writer.put(port, l, 0, mask, span<const cbf16_t>(packed).first(n));
+      }
+    }
+  }
+
+private:
+  std::shared_ptr<context>     ctx;
+  writer_resolver              resolver;
+  unsigned                     nof_ports;
+  unsigned                     nof_subc;
+  std::vector<srsran::cbf16_t> staging;
 };
 
 } // namespace mi355

@@ -380,15 +380,15 @@ struct nrphy_ctx {
   // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
   std::mutex host_mutex;
   std::mutex host_call_mutex; // serialises host-span calls that are built from device-pointer calls taking host_mutex
-  void*      scratch[9]       = {};
-  size_t     scratch_bytes[9] = {};
+  void*      scratch[10]       = {};
+  size_t     scratch_bytes[10] = {};
 };
 
 namespace {
 
 // Staging buffer `slot` of the context with room for `bytes` (reallocated only when it has to grow).
 enum ScratchSlot { SCRATCH_TB = 0, SCRATCH_GRID, SCRATCH_CW_RM, SCRATCH_CW_SCR, SCRATCH_IQ, SCRATCH_SMALL,
-                   SCRATCH_DECODER, SCRATCH_DEMATCH_OPS, SCRATCH_RX };
+                   SCRATCH_DECODER, SCRATCH_DEMATCH_OPS, SCRATCH_RX, SCRATCH_CSI };
 void* ctx_scratch(nrphy_ctx* ctx, ScratchSlot slot, size_t bytes)
 {
   if (bytes > ctx->scratch_bytes[slot]) {
@@ -2136,6 +2136,173 @@ extern "C" int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_deco
   a.cb_info_bits   = d.cb_info_bits;
   a.max_iterations = cfg->max_iterations;
   HIP_TRY(launch_pusch_assemble(a, n_tb, s));
+  return NRPHY_OK;
+}
+
+// ================================================================================================================
+// NZP-CSI-RS
+// ================================================================================================================
+extern "C" int nrphy_csi_rs_validate(const nrphy_csi_rs_cfg_t* c)
+{
+  static const unsigned row_ports[6] = {0, 1, 1, 2, 4, 4};
+  if (c == nullptr || c->row < 1 || c->row > 5 || c->nof_k_ref != 1 || c->cp > 1 || c->nof_rb == 0 ||
+      c->nof_ports != row_ports[c->row] || c->precoding == nullptr || c->nof_prg != 1 || c->prg_size_rb == 0 ||
+      c->start_rb + c->nof_rb > NRPHY_MAX_RB) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  // The assertions of mapping_row_1 .. mapping_row_5 (csi_rs_pattern.cpp:34-158); densities as csi_rs_freq_density_type.
+  const unsigned nsymb = c->cp ? 12 : 14, k0 = c->k_ref[0];
+  const bool     three = c->density == 3, one = c->density == 2, valid_density = c->density <= 3;
+  bool           ok    = false;
+  switch (c->row) {
+    case 1:
+      ok = k0 <= 3 && three && c->cdm == 0 && c->symbol_l0 < nsymb;
+      break;
+    case 2:
+      ok = k0 < 12 && valid_density && !three && c->cdm == 0 && c->symbol_l0 < nsymb;
+      break;
+    case 3:
+      ok = k0 < 11 && valid_density && !three && c->cdm == 1 && c->symbol_l0 < nsymb;
+      break;
+    case 4:
+      ok = k0 < 9 && one && c->cdm == 1 && c->symbol_l0 < nsymb;
+      break;
+    default:
+      ok = k0 < 11 && one && c->cdm == 1 && c->symbol_l0 + 1 < nsymb;
+      break;
+  }
+  return ok ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
+}
+
+extern "C" int nrphy_csi_rs_map(nrphy_ctx_t* ctx, uint32_t n, const nrphy_csi_rs_cfg_t* cfgs, const uint32_t* grid_index,
+                                void* d_grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc, void* stream)
+{
+  if (ctx == nullptr || (n != 0 && (cfgs == nullptr || d_grid == nullptr))) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  std::vector<CsiRsWork> work;
+  std::vector<float>     weights;
+  for (uint32_t i = 0; i != n; ++i) {
+    const nrphy_csi_rs_cfg_t& c = cfgs[i];
+    if (nrphy_csi_rs_validate(&c) != NRPHY_OK || c.nof_ports > grid_nof_ports || 12 * (c.start_rb + c.nof_rb) > grid_nof_subc) {
+      return NRPHY_ERR_ARGUMENT;
+    }
+    const unsigned group_size = c.cdm ? 2 : 1, nof_groups = c.nof_ports / group_size;
+    const bool     half       = c.density <= 1, even = c.density == 0;
+    // PRB range and stride (build_re_patterns, csi_rs_pattern.cpp:374-392)
+    unsigned rb_begin = c.start_rb, rb_stride = half ? 2 : 1;
+    if (half && (((c.start_rb % 2) != 0) == even)) {
+      ++rb_begin;
+    }
+    // sequence elements below the first occupied PRB and per symbol (nzp_csi_rs_generator_impl.cpp:66-159)
+    unsigned first_prb = c.start_rb;
+    if (half) {
+      first_prb = even ? c.start_rb + c.start_rb % 2 : c.start_rb + (1 - c.start_rb % 2);
+    }
+    unsigned advance = 0;
+    if (c.density == 3) {
+      advance = 3 * first_prb;
+    } else if (c.density == 2) {
+      advance = (c.row == 2) ? first_prb : 2 * first_prb;
+    } else {
+      advance = (c.row == 2) ? first_prb / 2 : first_prb;
+    }
+    unsigned seq_len = c.nof_rb;
+    if (half) {
+      seq_len /= 2;
+      if (c.nof_rb % 2 != 0 && (((c.start_rb % 2) != 0) == !even)) {
+        ++seq_len;
+      }
+    } else if (c.density == 3) {
+      seq_len *= 3;
+    }
+    seq_len *= c.cdm ? 2 : 1;
+    const unsigned nsymb = c.cp ? 12 : 14;
+    for (unsigned g = 0; g != nof_groups; ++g) {
+      CsiRsWork w;
+      unsigned  k_bar = c.k_ref[0], l_bar = c.symbol_l0;
+      if (c.row == 4) {
+        k_bar += 2 * g;
+      } else if (c.row == 5) {
+        l_bar += g;
+      }
+      w.re_mask    = (c.row == 1) ? ((1U << k_bar) | (1U << (k_bar + 4)) | (1U << (k_bar + 8))) : ((c.cdm ? 3U : 1U) << k_bar);
+      w.n_re_prb   = (uint32_t)__builtin_popcount(w.re_mask);
+      w.grid_index = grid_index ? grid_index[i] : 0;
+      w.symbol     = l_bar;
+      w.c_init     = (uint32_t)((1024ULL * (nsymb * c.slot_index + l_bar + 1) * (2 * c.scrambling_id + 1) + c.scrambling_id) & 0x7FFFFFFFULL);
+      w.advance    = advance;
+      w.seq_len    = seq_len;
+      w.rb_begin   = rb_begin;
+      w.rb_stride  = rb_stride;
+      w.nof_ports  = c.nof_ports;
+      w.first_layer = g * group_size;
+      w.group_size  = group_size;
+      w.weights_offset = (uint32_t)weights.size();
+      w.amplitude   = (float)(M_SQRT1_2 * (double)c.amplitude);
+      if (2 * (advance + seq_len) + 32 > 32 * CSI_RS_MAX_SEQ_WORDS) {
+        return NRPHY_ERR_CAPACITY;
+      }
+      work.push_back(w);
+    }
+    weights.insert(weights.end(), c.precoding, c.precoding + 2 * (size_t)c.nof_ports * c.nof_ports);
+  }
+  if (work.empty()) {
+    return NRPHY_OK;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  // Work list and weights go through a context buffer: the copy is ordered on the stream, an earlier launch on another
+  // stream that still reads the buffer is the caller's to order (as for plans).
+  const size_t work_bytes = work.size() * sizeof(CsiRsWork), off_w = (work_bytes + 63) & ~(size_t)63;
+  uint8_t*     base       = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    base = (uint8_t*)ctx_scratch(ctx, SCRATCH_CSI, off_w + weights.size() * sizeof(float));
+  }
+  if (base == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  // pageable host memory: hipMemcpyAsync stages it before returning, the vectors may go out of scope
+  HIP_TRY(hipMemcpyAsync(base, work.data(), work_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(base + off_w, weights.data(), weights.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  CsiRsLaunch p;
+  p.work           = (const CsiRsWork*)base;
+  p.weights        = (const float*)(base + off_w);
+  p.gold           = ctx->d_gold;
+  p.x1_words       = ctx->d_x1;
+  p.grid           = (uint32_t*)d_grid;
+  p.grid_nof_ports = grid_nof_ports;
+  p.grid_nof_subc  = grid_nof_subc;
+  HIP_TRY(launch_csi_rs(p, (uint32_t)work.size(), s));
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_csi_rs_map_host(nrphy_ctx_t* ctx, const nrphy_csi_rs_cfg_t* cfg, void* grid, uint32_t nof_ports,
+                                     uint32_t nof_subc)
+{
+  if (ctx == nullptr || cfg == nullptr || grid == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  std::lock_guard<std::mutex> host_lock(ctx->host_call_mutex);
+  const size_t bytes  = (size_t)nof_ports * NRPHY_NSYMB * nof_subc * 4;
+  void*        d_grid = nullptr;
+  HIP_TRY(hipSetDevice(ctx->device));
+  {
+    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    d_grid = ctx_scratch(ctx, SCRATCH_GRID, bytes);
+  }
+  if (d_grid == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  HIP_TRY(hipMemcpyAsync(d_grid, grid, bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int rc = nrphy_csi_rs_map(ctx, 1, cfg, nullptr, d_grid, nof_ports, nof_subc, ctx->stream);
+  if (rc != NRPHY_OK) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(grid, d_grid, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return NRPHY_OK;
 }
 

@@ -277,6 +277,27 @@ struct PuschAssembleLaunch {
 constexpr uint32_t PUSCH_ASSEMBLE_THREADS = 1024;
 hipError_t launch_pusch_assemble(const PuschAssembleLaunch& p, uint32_t n_tb, hipStream_t stream);
 
+// ---- NZP-CSI-RS ("next" row: other downlink grid writers) -------------------------------------------------------------
+constexpr uint32_t CSI_RS_MAX_SEQ_WORDS = 128; // 2 * (3 * 275 skipped + 3 * 275 used) bits and some
+// One CDM group of one signal (rows 1-5 have one OFDM symbol per group).
+struct CsiRsWork {
+  uint32_t grid_index, symbol, c_init;
+  uint32_t advance, seq_len;          // sequence elements skipped / used
+  uint32_t rb_begin, rb_stride, re_mask, n_re_prb;
+  uint32_t nof_ports, first_layer, group_size;
+  uint32_t weights_offset;            // floats: [nof_ports][nof_ports] complex of the signal
+  float    amplitude;                 // config amplitude / sqrt(2)
+};
+struct CsiRsLaunch {
+  const CsiRsWork*  work;
+  const float*      weights;
+  const GoldTables* gold;
+  const uint32_t*   x1_words;
+  uint32_t*         grid;
+  uint32_t          grid_nof_ports, grid_nof_subc;
+};
+hipError_t launch_csi_rs(const CsiRsLaunch& p, uint32_t n_work, hipStream_t stream);
+
 // ---- OFDM ---------------------------------------------------------------------------------------------------
 struct OfdmLaunch {
   uint32_t       dft_size;

@@ -140,6 +140,21 @@ class Context:
                "nrphy_pusch_decode_codeblock_host")
         return int(it.value), np.unpackbits(packed)[:k], soft
 
+    def csi_rs_map(self, cfgs, grid_indices, d_grid, nof_ports, nof_subc, stream=None):
+        """nzp_csi_rs_generator::map for a batch of signals into device grids [grid][port][14][subc]."""
+        n = len(cfgs)
+        arr = (abi.CsiRsCfg * n)(*cfgs)
+        idx = (C.c_uint32 * n)(*grid_indices)
+        _check(self.lib.nrphy_csi_rs_map(self.handle, n, arr, idx, _dptr(d_grid), nof_ports, nof_subc, stream),
+               "nrphy_csi_rs_map")
+
+    def csi_rs_map_host(self, cfg, grid):
+        """nzp_csi_rs_generator::map into a copy of a host grid [nof_ports][14][nof_subc][2] uint16 (raw cbf16)."""
+        out = np.array(grid, dtype=np.uint16, copy=True)
+        _check(self.lib.nrphy_csi_rs_map_host(self.handle, C.byref(cfg), out.ctypes.data, out.shape[0], out.shape[2]),
+               "nrphy_csi_rs_map_host")
+        return out
+
     def pusch_decoder_sizes(self, cfg, n_tb):
         """(soft-buffer bytes per transport block, state bytes of the batch, codeblocks per transport block)."""
         soft, state, ncb = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)

@@ -910,3 +910,44 @@ def test_transmit_receive_loop_full_size(gpu_ctx):
     assert not first_ok.all(), "the first transmission should fail for some transport blocks (raise its noise)"
     assert res[:, 0].all(), res
     assert torch.equal(d_out[:, :tb_size], d_tb[:, :tb_size])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NZP-CSI-RS generator ("next" row, section 8f-2): bit-exact grids against the oracle (pinned to the reference's
+# nzp_csi_rs_generator_impl in tests/test_oracle.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_nzp_csi_rs_vs_oracle(gpu_ctx, oracle):
+    import torch
+    rng = np.random.default_rng(7415)
+    batch = []
+    for name, cfg, nof_ports, nof_subc in cases.csi_rs_cases(rng):
+        assert gpu_ctx.lib.nrphy_csi_rs_validate(C.byref(cfg)) == 0, name
+        grid = (rng.standard_normal((nof_ports, 14, nof_subc, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        want = oracle.csi_rs_map(cfg, grid)
+        got = gpu_ctx.csi_rs_map_host(cfg, grid)
+        assert np.array_equal(got, want), (name, int(np.count_nonzero(got != want)))
+        if nof_ports == 4 and nof_subc == 624:
+            batch.append((cfg, grid, want))
+    # several signals in one call, two of them into the same grid (disjoint symbols), device-resident grids
+    assert len(batch) >= 4
+    n_grids = len(batch) - 1
+    grids = np.stack([b[1] for b in batch[:n_grids]])
+    idx = list(range(n_grids)) + [0]
+    want0 = oracle.csi_rs_map(batch[-1][0], batch[0][2])
+    d_grid = dev(grids.view(np.uint32).reshape(n_grids, 4, 14, 624).view(np.int32))
+    gpu_ctx.csi_rs_map([b[0] for b in batch], idx, d_grid, 4, 624)
+    gpu_ctx.synchronize()
+    torch.cuda.synchronize()
+    got = d_grid.cpu().numpy().view(np.uint16).reshape(n_grids, 4, 14, 624, 2)
+    assert np.array_equal(got[0], want0)
+    for i in range(1, n_grids):
+        assert np.array_equal(got[i], batch[i][2]), i
+    # refusals: a row beyond 5, a density the row does not allow, per-PRG precoding
+    bad = abi.make_csi_rs(row=4, start_rb=0, nof_rb=52, k0=0, l0=5, density="one")
+    bad.density = abi.CSI_DENSITY["three"]
+    assert gpu_ctx.lib.nrphy_csi_rs_validate(C.byref(bad)) == abi.ERR_ARGUMENT
+    bad = abi.make_csi_rs(row=2, start_rb=0, nof_rb=52, k0=0, l0=5, density="one")
+    bad.nof_prg = 2
+    assert gpu_ctx.lib.nrphy_csi_rs_validate(C.byref(bad)) == abi.ERR_ARGUMENT
+    bad.nof_prg, bad.row = 1, 6
+    assert gpu_ctx.lib.nrphy_csi_rs_validate(C.byref(bad)) == abi.ERR_ARGUMENT
