@@ -253,6 +253,23 @@ int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, u
  * nof_ports x nrphy_ofdm_slot_size(cfg, slot_index) complex samples, port after port (blocking). */
 int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t slot_index, float* iq);
 
+/* ---- device-resident resource grid: sparse writes from the host --------------------------------------
+ * The channels this library does not generate (PDCCH, SSB/PBCH, ...) stay on the CPU; their resource elements
+ * -- a few hundred per slot -- are merged into the grid in HBM with one call per slot instead of moving the
+ * grid.  Counterpart of resource_grid_writer::put(port, l, k_init, mask, symbols)
+ * (R/include/srsran/phy/support/resource_grid_writer.h) for a grid that lives on the device: later entries
+ * win over earlier ones, everything else in the grid is left alone. */
+typedef struct nrphy_grid_re {
+  uint16_t port;
+  uint16_t symbol;
+  uint32_t subc;
+  uint32_t value;  /* cbf16: bf16 real part in the low half, imaginary part in the high half */
+} nrphy_grid_re_t;
+/* d_grid: ONE grid [nof_ports][14][nof_subc] in device memory; entries: host array, copied at the call.
+ * Asynchronous on `stream` afterwards. */
+int nrphy_grid_put(nrphy_ctx_t* ctx, void* d_grid, uint32_t nof_ports, uint32_t nof_subc, uint32_t n,
+                   const nrphy_grid_re_t* entries, void* stream);
+
 /* ---- other downlink grid writers ("next" row): NZP-CSI-RS generator -----------
  * Replaces nzp_csi_rs_generator::map (R/include/srsran/phy/upper/signal_processors/nzp_csi_rs_generator.h:
  * 39-90; impl R/lib/phy/upper/signal_processors/nzp_csi_rs_generator_impl.cpp:96-352 with the RE patterns of

@@ -108,6 +108,11 @@ class PuschDecoderCfg(C.Structure):
                 ("max_iterations", C.c_uint32), ("use_early_stop", C.c_uint32), ("new_data", C.c_uint32)]
 
 
+class GridRe(C.Structure):
+    """nrphy_grid_re_t: one resource element written from the host into a device grid."""
+    _fields_ = [("port", C.c_uint16), ("symbol", C.c_uint16), ("subc", C.c_uint32), ("value", C.c_uint32)]
+
+
 class CsiRsCfg(C.Structure):
     """nrphy_csi_rs_cfg_t (nzp_csi_rs_generator::config_t)."""
     _fields_ = [("slot_index", C.c_uint32), ("cp", C.c_uint32), ("start_rb", C.c_uint32), ("nof_rb", C.c_uint32),
@@ -285,6 +290,7 @@ def declare(lib, prefix="nrphy_"):
     sig("ldpc_decode_host", i32, vp, P(LdpcDecoderCfg), vp, u8p, P(u32))
     sig("ldpc_rate_dematch", i32, vp, P(LdpcRateDematcherCfg), u32, vp, u32, vp, u32, i32, vp)
     sig("ldpc_rate_dematch_host", i32, vp, P(LdpcRateDematcherCfg), vp, vp, i32)
+    sig("grid_put", i32, vp, vp, u32, u32, u32, P(GridRe), vp)
     sig("csi_rs_validate", i32, P(CsiRsCfg))
     sig("csi_rs_map", i32, vp, u32, P(CsiRsCfg), P(u32), vp, u32, u32, vp)
     sig("csi_rs_map_host", i32, vp, P(CsiRsCfg), vp, u32, u32)
@@ -307,5 +313,5 @@ ABI_SYMBOLS = [
     "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",
     "nrphy_ldpc_decode", "nrphy_ldpc_decode_host", "nrphy_ldpc_rate_dematch", "nrphy_ldpc_rate_dematch_host",
     "nrphy_pusch_decode_codeblock_host", "nrphy_pusch_decoder_sizes", "nrphy_pusch_decode_batch",
-    "nrphy_csi_rs_validate", "nrphy_csi_rs_map", "nrphy_csi_rs_map_host",
+    "nrphy_csi_rs_validate", "nrphy_csi_rs_map", "nrphy_csi_rs_map_host", "nrphy_grid_put",
 ]

@@ -71,6 +71,34 @@ __global__ __launch_bounds__(WAVE) void csi_rs_kernel(CsiRsLaunch p)
   }
 }
 
+// Sparse host writes into a device grid (nrphy_grid_put): entry i goes to word (port * 14 + symbol) * nof_subc + subc.
+// Entries are applied in order: when two name the same resource element the later one must win, so every thread looks
+// whether a later entry overwrites its own (the lists are a few hundred entries; duplicates are rare and short-lived).
+__global__ __launch_bounds__(256) void grid_put_kernel(const uint32_t* __restrict__ index, const uint32_t* __restrict__ value,
+                                                       uint32_t n, uint32_t* __restrict__ grid)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) {
+    return;
+  }
+  const uint32_t mine = index[i];
+  for (uint32_t k = i + 1; k < n; ++k) {
+    if (index[k] == mine) {
+      return; // a later entry owns this resource element
+    }
+  }
+  grid[mine] = value[i];
+}
+
+hipError_t launch_grid_put(const uint32_t* d_index, const uint32_t* d_value, uint32_t n, uint32_t* d_grid, hipStream_t stream)
+{
+  if (n == 0) {
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(grid_put_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_index, d_value, n, d_grid);
+  return hipGetLastError();
+}
+
 hipError_t launch_csi_rs(const CsiRsLaunch& p, uint32_t n_work, hipStream_t stream)
 {
   if (n_work == 0) {

@@ -380,15 +380,15 @@ struct nrphy_ctx {
   // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
   std::mutex host_mutex;
   std::mutex host_call_mutex; // serialises host-span calls that are built from device-pointer calls taking host_mutex
-  void*      scratch[10]       = {};
-  size_t     scratch_bytes[10] = {};
+  void*      scratch[11]       = {};
+  size_t     scratch_bytes[11] = {};
 };
 
 namespace {
 
 // Staging buffer `slot` of the context with room for `bytes` (reallocated only when it has to grow).
 enum ScratchSlot { SCRATCH_TB = 0, SCRATCH_GRID, SCRATCH_CW_RM, SCRATCH_CW_SCR, SCRATCH_IQ, SCRATCH_SMALL,
-                   SCRATCH_DECODER, SCRATCH_DEMATCH_OPS, SCRATCH_RX, SCRATCH_CSI };
+                   SCRATCH_DECODER, SCRATCH_DEMATCH_OPS, SCRATCH_RX, SCRATCH_CSI, SCRATCH_PUT };
 void* ctx_scratch(nrphy_ctx* ctx, ScratchSlot slot, size_t bytes)
 {
   if (bytes > ctx->scratch_bytes[slot]) {
@@ -2303,6 +2303,39 @@ extern "C" int nrphy_csi_rs_map_host(nrphy_ctx_t* ctx, const nrphy_csi_rs_cfg_t*
   }
   HIP_TRY(hipMemcpyAsync(grid, d_grid, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_grid_put(nrphy_ctx_t* ctx, void* d_grid, uint32_t nof_ports, uint32_t nof_subc, uint32_t n,
+                              const nrphy_grid_re_t* entries, void* stream)
+{
+  if (ctx == nullptr || d_grid == nullptr || (n != 0 && entries == nullptr)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (n == 0) {
+    return NRPHY_OK;
+  }
+  std::vector<uint32_t> packed(2 * (size_t)n);
+  for (uint32_t i = 0; i != n; ++i) {
+    const nrphy_grid_re_t& e = entries[i];
+    if (e.port >= nof_ports || e.symbol >= NRPHY_NSYMB || e.subc >= nof_subc) {
+      return NRPHY_ERR_ARGUMENT;
+    }
+    packed[i]     = ((uint32_t)e.port * NRPHY_NSYMB + e.symbol) * nof_subc + e.subc;
+    packed[n + i] = e.value;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s    = stream ? (hipStream_t)stream : ctx->stream;
+  uint32_t*   base = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    base = (uint32_t*)ctx_scratch(ctx, SCRATCH_PUT, packed.size() * sizeof(uint32_t));
+  }
+  if (base == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  HIP_TRY(hipMemcpyAsync(base, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_grid_put(base, base + n, n, (uint32_t*)d_grid, s));
   return NRPHY_OK;
 }
 

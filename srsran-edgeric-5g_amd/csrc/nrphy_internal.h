@@ -297,6 +297,7 @@ struct CsiRsLaunch {
   uint32_t          grid_nof_ports, grid_nof_subc;
 };
 hipError_t launch_csi_rs(const CsiRsLaunch& p, uint32_t n_work, hipStream_t stream);
+hipError_t launch_grid_put(const uint32_t* d_index, const uint32_t* d_value, uint32_t n, uint32_t* d_grid, hipStream_t stream);
 
 // ---- OFDM ---------------------------------------------------------------------------------------------------
 struct OfdmLaunch {

@@ -140,6 +140,12 @@ class Context:
                "nrphy_pusch_decode_codeblock_host")
         return int(it.value), np.unpackbits(packed)[:k], soft
 
+    def grid_put(self, d_grid, nof_ports, nof_subc, entries, stream=None):
+        """Sparse host writes into ONE device grid: entries = [(port, symbol, subc, cbf16 word)], later ones win."""
+        n = len(entries)
+        arr = (abi.GridRe * n)(*[abi.GridRe(*e) for e in entries])
+        _check(self.lib.nrphy_grid_put(self.handle, _dptr(d_grid), nof_ports, nof_subc, n, arr, stream), "nrphy_grid_put")
+
     def csi_rs_map(self, cfgs, grid_indices, d_grid, nof_ports, nof_subc, stream=None):
         """nzp_csi_rs_generator::map for a batch of signals into device grids [grid][port][14][subc]."""
         n = len(cfgs)

@@ -951,3 +951,26 @@ def test_nzp_csi_rs_vs_oracle(gpu_ctx, oracle):
     assert gpu_ctx.lib.nrphy_csi_rs_validate(C.byref(bad)) == abi.ERR_ARGUMENT
     bad.nof_prg, bad.row = 1, 6
     assert gpu_ctx.lib.nrphy_csi_rs_validate(C.byref(bad)) == abi.ERR_ARGUMENT
+
+
+def test_grid_put_sparse_host_writes(gpu_ctx):
+    """nrphy_grid_put: resource elements of CPU-generated channels merged into a device grid; later entries win, the
+    rest of the grid is untouched, out-of-range entries are refused."""
+    import torch
+    rng = np.random.default_rng(99)
+    nof_ports, nof_subc = 3, 624
+    grid = rng.integers(0, 2 ** 32, (nof_ports, 14, nof_subc), dtype=np.uint32)
+    d_grid = dev(grid.view(np.int32))
+    entries, want = [], grid.copy()
+    for _ in range(700):
+        e = (int(rng.integers(0, nof_ports)), int(rng.integers(0, 14)), int(rng.integers(0, nof_subc)), int(rng.integers(0, 2 ** 32)))
+        entries.append(e)
+    entries += [entries[5][:3] + (123,), entries[5][:3] + (456,), entries[17][:3] + (789,)]   # duplicates: the last one wins
+    for p, l, k, v in entries:
+        want[p, l, k] = v
+    gpu_ctx.grid_put(d_grid, nof_ports, nof_subc, entries)
+    gpu_ctx.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_grid.cpu().numpy().view(np.uint32), want)
+    bad = (abi.GridRe * 1)(abi.GridRe(nof_ports, 0, 0, 1))
+    assert gpu_ctx.lib.nrphy_grid_put(gpu_ctx.handle, d_grid.data_ptr(), nof_ports, nof_subc, 1, bad, None) == abi.ERR_ARGUMENT
