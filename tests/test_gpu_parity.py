@@ -974,3 +974,28 @@ def test_grid_put_sparse_host_writes(gpu_ctx):
     assert np.array_equal(d_grid.cpu().numpy().view(np.uint32), want)
     bad = (abi.GridRe * 1)(abi.GridRe(nof_ports, 0, 0, 1))
     assert gpu_ctx.lib.nrphy_grid_put(gpu_ctx.handle, d_grid.data_ptr(), nof_ports, nof_subc, 1, bad, None) == abi.ERR_ARGUMENT
+
+
+def test_pdsch_random_pdus(gpu_ctx, oracle):
+    """Fuzz: the 40 random PDUs of tests/test_oracle.py::test_oracle_vs_ref_random_pdus (same seed, so the oracle side of
+    every one of them is pinned to the compiled reference) plus 40 more, codeword taps and grid bit-exact."""
+    rng = np.random.default_rng(20240611)
+    for i, (pdu, nof_ports, nof_subc) in enumerate(cases.random_pdus(oracle.tbs, rng, 40)):
+        if oracle.validate(pdu) != 0:
+            assert gpu_ctx.lib.nrphy_pdsch_validate(C.byref(pdu)) != 0
+            continue
+        run_single(gpu_ctx, oracle, pdu, cases.random_tb(rng, pdu), nof_ports, nof_subc)
+    rng = np.random.default_rng(777)
+    refused = 0
+    for pdu, nof_ports, nof_subc in cases.random_pdus(oracle.tbs, rng, 40):
+        if oracle.validate(pdu) != 0:
+            continue
+        if oracle.derive(pdu)["nof_re"] == 0:
+            # every allocated symbol carries DM-RS on both CDM groups: nothing to transmit on; the reference runs into
+            # its assertions, this library refuses the PDU
+            with pytest.raises(lib.NrphyError):
+                gpu_ctx.pdsch_process_host(pdu, cases.random_tb(rng, pdu), nof_ports, nof_subc)
+            refused += 1
+            continue
+        run_single(gpu_ctx, oracle, pdu, cases.random_tb(rng, pdu), nof_ports, nof_subc)
+    assert refused <= 3

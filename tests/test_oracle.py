@@ -287,6 +287,21 @@ def test_oracle_nzp_csi_rs_vs_reference(oracle, ref):
         assert np.count_nonzero(got != grid) > 0 or cfg.nof_rb == 1, name   # one PRB at density 0.5 may hold nothing
 
 
+def test_oracle_vs_ref_random_pdus(oracle, ref):
+    """Fuzz: 40 PDUs drawn at random within what the validator accepts (cases.random_pdus), oracle against the compiled
+    reference's processors -- the same draw the GPU suite runs against the oracle."""
+    rng = np.random.default_rng(20240611)
+    for i, (pdu, nof_ports, nof_subc) in enumerate(cases.random_pdus(oracle.tbs, rng, 40)):
+        assert oracle.validate(pdu) == ref.validate(pdu), i
+        if oracle.validate(pdu) != 0:
+            continue
+        tb = cases.random_tb(rng, pdu)
+        want = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc)
+        for impl in (0, 1):
+            got = ref.pdsch_process(pdu, tb, nof_ports, nof_subc, impl=impl)
+            assert np.array_equal(got, want), (i, impl, int(np.count_nonzero(got != want)), oracle.derive(pdu))
+
+
 def test_baseline_config_derived_values(oracle):
     """The derived sizes SURVEY.md section 8d lists for the BASELINE configs."""
     d = oracle.derive(cases.baseline_config(3)[0])
