@@ -206,8 +206,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5))) void l
       soft[2u * zc + i] = (int8_t)load_soft(v, i < clamp_end);
     }
   }
-  if (j <= (uint32_t)LLR_MAX_V) {
-    s_scaled[j] = (uint8_t)roundf((float)j * p.scaling_factor); // rounded half away from zero
+  for (uint32_t m = j; m <= (uint32_t)LLR_MAX_V; m += T) { // a workgroup may be a single wavefront (Zc <= 64)
+    s_scaled[m] = (uint8_t)roundf((float)m * p.scaling_factor); // rounded half away from zero
   }
   if (j < 4) {
     s_flag[j] = 0;

@@ -999,3 +999,45 @@ def test_pdsch_random_pdus(gpu_ctx, oracle):
             continue
         run_single(gpu_ctx, oracle, pdu, cases.random_tb(rng, pdu), nof_ports, nof_subc)
     assert refused <= 3
+
+
+def test_receive_side_random_configurations(gpu_ctx, oracle):
+    """Fuzz of the receive-side coding kernels against the oracle: random (base graph, lifting size, lengths, filler bits,
+    CRC, noise, iterations, scaling) for the decoder; random (lifting size, E, rv, modulation, Nref, filler bits, new data
+    or combining, arbitrary int8 contents) for the rate dematcher."""
+    rng = np.random.default_rng(31337)
+    sizes = cases.LIFTING_SIZES
+    for _ in range(30):
+        bg = int(rng.integers(1, 3))
+        zc = int(rng.choice(sizes[8:]))
+        kb, n_short = (22, 66) if bg == 1 else (10, 50)
+        k = kb * zc
+        crc_id = int(rng.choice([16, 0x24A, 0x24B]))
+        crc_len = 16 if crc_id == 16 else 24
+        nf = int(rng.integers(0, max(1, min(k - crc_len - 8, (kb - 2) * zc - 1) // 2)))
+        nof_llr = int(rng.integers(k + 2 * zc - 2 * zc + 2 * zc, n_short * zc + 1))
+        nof_llr = max(nof_llr, k + 2 * zc)
+        amp, sigma = float(rng.uniform(6, 30)), float(rng.uniform(2, 14))
+        _, llr = cases.make_ldpc_llrs(oracle, rng, bg, zc, nof_llr, crc_id, nf, amp, sigma)
+        llr[rng.integers(0, nof_llr, nof_llr // 50)] = 127          # a few certain bits ...
+        llr[rng.integers(0, nof_llr, nof_llr // 50)] = 0            # ... and a few erasures
+        iters, scaling = int(rng.integers(1, 11)), float(rng.choice([0.5, 0.75, 0.8, 0.9]))
+        crc = crc_id if rng.integers(0, 4) else 0
+        want = oracle.ldpc_decode(bg, zc, nf, crc, iters, scaling, llr)
+        got = gpu_ctx.ldpc_decode_host(bg, zc, nf, crc, iters, scaling, llr)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]), (bg, zc, nf, crc, iters, scaling, nof_llr)
+    for _ in range(60):
+        bg = int(rng.integers(1, 3))
+        zc = int(rng.choice(sizes[4:]))
+        n = (66 if bg == 1 else 50) * zc
+        nof_sys = ((22 if bg == 1 else 10) - 2) * zc
+        qm = int(rng.choice([1, 2, 4, 6, 8]))
+        e = qm * int(rng.integers(1, max(2, min(3 * n, 60000) // qm)))
+        nf = int(rng.integers(0, nof_sys // 2))
+        nref = int(rng.choice([0, 0, int(rng.integers(nof_sys + 1, n + 1))]))
+        rv, new_data = int(rng.integers(0, 4)), int(rng.integers(0, 2))
+        llr = rng.integers(-127, 128, e).astype(np.int8)
+        old = rng.integers(-127, 128, n).astype(np.int8)
+        want = oracle.ldpc_rate_dematch(bg, zc, rv, qm, nref, nf, new_data, llr, old)
+        got = gpu_ctx.ldpc_rate_dematch_host(bg, zc, rv, qm, nref, nf, new_data, llr, old)
+        assert np.array_equal(got, want), (bg, zc, e, rv, qm, nref, nf, new_data, int(np.count_nonzero(got != want)))
