@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdlib>
 #include <cstring>
 #include <array>
@@ -445,6 +446,8 @@ struct nrphy_ofdm_plan {
   uint32_t*           d_cp = nullptr;
   uint32_t*           d_off = nullptr;
   std::vector<uint32_t> cp, off;
+  std::map<uint32_t, float2*> d_window_phase; // demodulator: per window offset, built on first use
+  std::mutex          window_mutex;           // guards the map (the host-span entry points already hold ctx->host_mutex)
   std::vector<hipEvent_t> events; // 2 per recorded run
   uint32_t            timed_runs = 0, max_timed_runs = 0;
 };
@@ -2426,6 +2429,9 @@ extern "C" int nrphy_ofdm_plan_destroy(nrphy_ofdm_plan_t* plan)
   (void)hipFree(plan->d_phase_rx);
   (void)hipFree(plan->d_cp);
   (void)hipFree(plan->d_off);
+  for (auto& kv : plan->d_window_phase) {
+    (void)hipFree(kv.second);
+  }
   for (hipEvent_t e : plan->events) {
     (void)hipEventDestroy(e);
   }
@@ -2446,6 +2452,7 @@ extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const
   }
   nrphy_ctx* ctx = plan->ctx;
   OfdmLaunch p;
+  p.window_phase = nullptr;
   p.dft_size    = plan->cfg.dft_size;
   p.rg_size     = 12 * plan->cfg.bw_rb;
   p.nof_ports   = plan->nof_ports;
@@ -2483,6 +2490,7 @@ extern "C" int nrphy_ofdm_demod_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids,
   }
   nrphy_ctx* ctx = plan->ctx;
   OfdmLaunch p;
+  p.window_phase = nullptr;
   p.dft_size    = plan->cfg.dft_size;
   p.rg_size     = 12 * plan->cfg.bw_rb;
   p.nof_ports   = plan->nof_ports;
@@ -2493,6 +2501,30 @@ extern "C" int nrphy_ofdm_demod_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids,
   p.cp_len      = plan->d_cp;
   p.sym_offset  = plan->d_off;
   p.probe       = 0;
+  p.window_phase = nullptr;
+  if (window_offset != 0) {
+    // The reference rotates bin i by std::polar(1.0F, omega * i) with omega = offset * 2 pi / N rounded to float
+    // (ofdm_demodulator_impl.cpp:68-76): omega * i reaches hundreds of radians, so its float rounding shows in the
+    // output (1e-5 of the largest bin); the table is built here with the same arithmetic instead of exactly.
+    std::lock_guard<std::mutex> lock(plan->window_mutex);
+    auto                        it = plan->d_window_phase.find(window_offset);
+    if (it == plan->d_window_phase.end()) {
+      const unsigned      n = plan->cfg.dft_size;
+      std::vector<float2> w(n);
+      const float         omega = static_cast<float>(window_offset) * static_cast<float>(2.0 * M_PI) / static_cast<float>(n);
+      for (unsigned i = 0; i != n; ++i) {
+        const std::complex<float> v = std::polar(1.0F, omega * static_cast<float>(i));
+        w[i]                        = make_float2(v.real(), v.imag());
+      }
+      float2* d_w = nullptr;
+      HIP_TRY(hipSetDevice(ctx->device));
+      if (upload(&d_w, w.data(), w.size() * sizeof(float2)) != hipSuccess) {
+        return NRPHY_ERR_DEVICE;
+      }
+      it = plan->d_window_phase.emplace(window_offset, d_w).first;
+    }
+    p.window_phase = it->second;
+  }
   HIP_TRY(launch_ofdm_demod(p, nof_grids, (const float2*)d_iq, slot_index, window_offset, (uint32_t*)d_grid,
                             stream ? (hipStream_t)stream : ctx->stream));
   return NRPHY_OK;

@@ -308,6 +308,7 @@ struct OfdmLaunch {
   uint32_t       slot_stride; // samples per (grid, port) in the output
   const float2*  twiddle;     // exp(+j 2 pi k / N), k < N
   const float2*  phase;       // [symbols per subframe] phase compensation * scale
+  const float2*  window_phase; // demodulator with a window offset: [dft_size] exp(+j 2 pi offset i / N), else unused
   const uint32_t* cp_len;     // [symbols per subframe]
   const uint32_t* sym_offset; // [symbols per subframe] start of the symbol within its slot (samples)
   uint32_t       probe;       // NRPHY_OFDM_PROBE: timing-only runs with the loads and/or stores range-checked away

@@ -660,8 +660,8 @@ __global__ __launch_bounds__(Plan<N>::T) void ofdm_demod_kernel(OfdmLaunch p, co
     constexpr uint32_t B   = decltype(base)::value;
     const uint32_t     idx = q + B;
     cf                 y   = cmul_uniform(v, ph);
-    if (window_offset != 0) { // wave-uniform: exp(+j 2 pi window_offset idx / N)
-      const float2 w = p.twiddle[(idx * window_offset) % N];
+    if (window_offset != 0) { // wave-uniform: exp(+j 2 pi window_offset idx / N) as the reference rounds it (host table)
+      const float2 w = p.window_phase[idx];
       y              = cmul(y, make_cf(w.x, w.y));
     }
     // Bin -> subcarrier; bins of the guard band get an offset the range check drops.

@@ -414,7 +414,7 @@ def test_ofdm_demodulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
     row = plan.demodulate_symbol_host(iq[0, start: start + lib.symbol_size(cfg, sym)], sym, wo)
     assert np.array_equal(row, got[0, 0, 5])
     # A window offset beyond the shortest cyclic prefix is rejected (ofdm_demodulator_impl.cpp:58-63).
-    shortest_cp = int(n) // 4 if ext else ((144 >> int(mu)) * int(n) * (1 << int(mu))) // 2048
+    shortest_cp = (144 * int(n)) // 2048   # ofdm_demodulator_impl.cpp:63, also with extended cyclic prefix
     assert gpu_ctx.lib.nrphy_ofdm_demod_run(plan.handle, 1, d_grid.data_ptr(), None, shortest_cp,
                                             d_grid.data_ptr(), None) == abi.ERR_ARGUMENT
     plan.close()
@@ -1041,3 +1041,29 @@ def test_receive_side_random_configurations(gpu_ctx, oracle):
         want = oracle.ldpc_rate_dematch(bg, zc, rv, qm, nref, nf, new_data, llr, old)
         got = gpu_ctx.ldpc_rate_dematch_host(bg, zc, rv, qm, nref, nf, new_data, llr, old)
         assert np.array_equal(got, want), (bg, zc, e, rv, qm, nref, nf, new_data, int(np.count_nonzero(got != want)))
+
+
+def test_ofdm_random_configurations(gpu_ctx, oracle):
+    """Fuzz of the OFDM modulator and demodulator against the oracle: random numerology, bandwidth, DFT size, cyclic
+    prefix, centre frequency, scale, slot and (demodulator) window offset, 1-3 ports."""
+    rng = np.random.default_rng(4096)
+    for _ in range(24):
+        n = int(rng.choice([128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]))
+        mu = int(rng.integers(0, 4))
+        ext = int(rng.integers(0, 4) == 0)
+        bw = int(rng.integers(1, min(275, (n - 1) // 12) + 1))
+        ports = int(rng.integers(1, 4))
+        cfg = abi.OfdmConfig(mu, bw, n, ext, float(rng.uniform(0.01, 2.0)), float(rng.choice([0.0, 2.4e9, 3.5e9, 28e9])))
+        slot = int(rng.integers(0, 1 << mu))
+        grid = (rng.standard_normal((ports, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        plan = lib.OfdmPlan(gpu_ctx, cfg, ports)
+        iq = plan.modulate_slot_host(grid, slot)
+        want = oracle.ofdm_slot(cfg, grid, slot)
+        assert iq.shape == want.shape and rel_err(iq, want) < 1e-5, (mu, bw, n, ext, slot)
+        wo = int(rng.integers(0, (144 * n) // 2048))   # the reference bounds the offset by the normal cyclic prefix
+        rx = (rng.standard_normal(want.shape) + 1j * rng.standard_normal(want.shape)).astype(np.complex64)
+        got = plan.demodulate_slot_host(rx, slot, wo)
+        ref_grid = oracle.ofdm_demod_slot(cfg, rx, slot, wo)
+        nsymb = 12 if ext else 14
+        assert_bf16_grids_close(got[:, :nsymb], ref_grid[:, :nsymb])
+        plan.close()
