@@ -1067,3 +1067,41 @@ def test_ofdm_random_configurations(gpu_ctx, oracle):
         nsymb = 12 if ext else 14
         assert_bf16_grids_close(got[:, :nsymb], ref_grid[:, :nsymb])
         plan.close()
+
+
+def test_pdsch_random_pdus_in_one_plan(gpu_ctx, oracle):
+    """Fuzz of the batched path: 32 random PDUs (different allocations, layers, code rates, cyclic prefixes) in ONE plan,
+    each into its own grid of a common shape, run twice on the same grids (the second run must overwrite everything the
+    first one wrote: zero-fill lists, DM-RS and data of a different transport block set)."""
+    import torch
+    rng = np.random.default_rng(90210)
+    drawn = [x for x in cases.random_pdus(oracle.tbs, rng, 36) if oracle.validate(x[0]) == 0 and oracle.derive(x[0])["nof_re"] > 0][:32]
+    nof_ports, nof_subc = 4, max(x[2] for x in drawn)
+    pdus = [x[0] for x in drawn]
+    n = len(pdus)
+    plan = None
+    d_grid = torch.full((n, nof_ports, 14, nof_subc), 0x7FFF7FFF, dtype=torch.int32, device="cuda")
+    for run in range(2):
+        offs, tbs, pos = [], [], 0
+        for p in pdus:
+            tb = cases.random_tb(rng, p)
+            offs.append(pos)
+            tbs.append(tb)
+            pos += (len(tb) + 15) & ~15
+        buf = np.zeros(pos + 16, np.uint8)
+        for o, tb in zip(offs, tbs):
+            buf[o:o + len(tb)] = tb
+        if plan is None:
+            plan = lib.PdschPlan(gpu_ctx, pdus, offs, list(range(n)), n, nof_ports, nof_subc)
+        d_rm = torch.zeros(plan.codeword_bits // 8 + 8, dtype=torch.uint8, device="cuda")
+        plan.run(dev(buf), d_grid, d_cw_rm=d_rm, zero_grids=True)
+        gpu_ctx.synchronize()
+        grids = d_grid.cpu().numpy().view(np.uint16).reshape(n, nof_ports, 14, nof_subc, 2)
+        rm = d_rm.cpu().numpy()
+        for i, p in enumerate(pdus):
+            d = oracle.derive(p)
+            want, orm, _ = oracle.pdsch_process(p, tbs[i], nof_ports, nof_subc, taps=True, codeword_bits=d["codeword_bits"])
+            assert np.array_equal(grids[i], want), (run, i, int(np.count_nonzero(grids[i] != want)))
+            o = plan.codeword_offset(i) // 8
+            assert np.array_equal(rm[o:o + len(orm)], orm), (run, i)
+    plan.close()
