@@ -32,9 +32,12 @@ def test_pod_layout_matches_header():
     src = r'''#include "mi355_nrphy.h"
 #include <stdio.h>
 #include <stddef.h>
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(nrphy_pdsch_pdu_t), offsetof(nrphy_pdsch_pdu_t, prb_mask),
- offsetof(nrphy_pdsch_pdu_t, reserved), offsetof(nrphy_pdsch_pdu_t, precoding), sizeof(nrphy_re_pattern_t),
- sizeof(nrphy_pdsch_derived_t), sizeof(nrphy_ofdm_config_t), sizeof(nrphy_pdsch_encoder_cfg_t));return 0;}'''
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(nrphy_pdsch_pdu_t),
+ offsetof(nrphy_pdsch_pdu_t, prb_mask), offsetof(nrphy_pdsch_pdu_t, reserved), offsetof(nrphy_pdsch_pdu_t, precoding),
+ sizeof(nrphy_re_pattern_t), sizeof(nrphy_pdsch_derived_t), sizeof(nrphy_ofdm_config_t), sizeof(nrphy_pdsch_encoder_cfg_t),
+ sizeof(nrphy_ldpc_decoder_cfg_t), sizeof(nrphy_ldpc_rate_dematcher_cfg_t), sizeof(nrphy_pusch_decoder_cfg_t),
+ sizeof(nrphy_csi_rs_cfg_t), offsetof(nrphy_csi_rs_cfg_t, amplitude), offsetof(nrphy_csi_rs_cfg_t, precoding),
+ sizeof(nrphy_grid_re_t));return 0;}'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(backends.ROOT, "include"), os.path.join(d, "t.c"), "-o",
@@ -42,7 +45,9 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(nrphy_pdsch_pd
         out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, timeout=60).stdout.split()
     want = [C.sizeof(abi.PdschPdu), abi.PdschPdu.prb_mask.offset, abi.PdschPdu.reserved.offset,
             abi.PdschPdu.precoding.offset, C.sizeof(abi.RePattern), C.sizeof(abi.PdschDerived), C.sizeof(abi.OfdmConfig),
-            C.sizeof(abi.PdschEncoderCfg)]
+            C.sizeof(abi.PdschEncoderCfg), C.sizeof(abi.LdpcDecoderCfg), C.sizeof(abi.LdpcRateDematcherCfg),
+            C.sizeof(abi.PuschDecoderCfg), C.sizeof(abi.CsiRsCfg), abi.CsiRsCfg.amplitude.offset,
+            abi.CsiRsCfg.precoding.offset, C.sizeof(abi.GridRe)]
     assert [int(x) for x in out] == want
 
 
