@@ -145,7 +145,7 @@ __device__ __forceinline__ uint32_t hard_word(const int8_t* soft, uint32_t w, ui
   return word;
 }
 
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5))) void ldpc_decode_kernel(LdpcDecodeLaunch p)
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void ldpc_decode_kernel(LdpcDecodeLaunch p)
 {
   extern __shared__ __attribute__((aligned(16))) int8_t dec_lds[];
   __shared__ uint32_t s_flag[4];
