@@ -65,10 +65,19 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--slots", type=int, default=1024, help="slots (config 4: cell-slots) per GPU per step")
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4],
-                    help="BASELINE config: 3 = the headline workload (default); 2 and 4 are secondary measurements")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="BASELINE config: 3 = the headline workload (default); 2, 4 and 5 (receive-side add-on, one GPU) "
+                         "are secondary measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.config == 5:
+        # the receive-side chain has its own script (profiles/rx_chain_bench.py); same JSON schema, one GPU
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import rx_chain_bench
+        sys.argv = [sys.argv[0], "--steps", str(args.steps), "--warmup", str(args.warmup)] + (
+            ["--slots", str(args.slots)] if args.slots != 1024 else [])
+        rx_chain_bench.main()
+        return
 
     import torch
     import backends
