@@ -530,7 +530,7 @@ __device__ __forceinline__ void load_symbol_row(uint32_t (&raw)[Plan<N>::R0], co
 }
 
 template <int N, int SPW>
-__global__ __launch_bounds__(Plan<N>::T) __attribute__((amdgpu_waves_per_eu(4))) void ofdm_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_grid,
+__global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_grid,
                                                           const uint32_t* __restrict__ d_slot_index,
                                                           float2* __restrict__ d_iq)
 {
