@@ -300,8 +300,8 @@ typedef struct nrphy_csi_rs_cfg {
 /* NRPHY_OK when the configuration is one this library maps (the reference's validator accepts everything). */
 int nrphy_csi_rs_validate(const nrphy_csi_rs_cfg_t* cfg);
 /* n signals into device grids ([grid][port][14][subc] cbf16): signal i into grid grid_index[i].  The
- * configurations are copied at the call (host pointers, like PDUs at plan creation); asynchronous on
- * `stream` afterwards. */
+ * configurations are copied at the call (host pointers, like PDUs at plan creation; a copy from pageable
+ * memory, so the call waits for what `stream` holds before it); the kernel itself is asynchronous. */
 int nrphy_csi_rs_map(nrphy_ctx_t* ctx, uint32_t n, const nrphy_csi_rs_cfg_t* cfgs, const uint32_t* grid_index,
                      void* d_grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc, void* stream);
 /* One signal into a host grid [nof_ports][14][nof_subc] cbf16 (read and written; blocking). */
