@@ -1105,3 +1105,60 @@ def test_pdsch_random_pdus_in_one_plan(gpu_ctx, oracle):
             o = plan.codeword_offset(i) // 8
             assert np.array_equal(rm[o:o + len(orm)], orm), (run, i)
     plan.close()
+
+
+def test_pusch_decoder_random_shapes(gpu_ctx, oracle):
+    """Fuzz of the transport-block decoder: random transport-block sizes, base graphs, modulations, layers, limited-buffer
+    sizes and redundancy-version orders, three transmissions each (the first as new data), against the restated
+    pusch_decoder_impl (itself pinned to the compiled reference on fixed shapes)."""
+    import torch
+    rng = np.random.default_rng(5252)
+    done = 0
+    while done < 10:
+        layers, qm = int(rng.integers(1, 5)), int(rng.choice([2, 4, 6, 8]))
+        n_prb, nsym = int(rng.integers(2, 60)), int(rng.integers(6, 14))
+        rate = float(rng.uniform(100, 800))
+        tb_bits = oracle.tbs(nsym, 12, 0, qm, rate, layers, n_prb)
+        if tb_bits < 40 or tb_bits > 120000:
+            continue
+        r = rate / 1024
+        bg = 2 if (tb_bits <= 292 or (tb_bits <= 3824 and r <= 0.67) or r <= 0.25) else 1
+        pdu = abi.make_pdu(bwp_size_rb=n_prb, qm=qm, dmrs_symbols=(2,), prb_start=0, prb_count=n_prb, start_symbol=0,
+                           nof_symbols=nsym, precoding=abi.identity_precoding(layers), tb_size_bytes=tb_bits // 8, base_graph=bg,
+                           tbs_lbrm_bytes=int(rng.choice([3168, 20000, abi.TBS_LBRM_DEFAULT])), nof_cdm_groups_without_data=2)
+        if oracle.validate(pdu) != 0:
+            continue
+        d = oracle.derive(pdu)
+        if d["nof_re"] == 0 or d["nof_codeblocks"] > 12:
+            continue
+        C, n, G = d["nof_codeblocks"], d["full_length"], d["codeword_bits"]
+        tb = cases.random_tb(rng, pdu)
+        cfg0 = abi.PuschDecoderCfg(bg, qm, 0, layers, d["n_ref"], pdu.tb_size_bytes, G // qm, 6, 1, 1)
+        soft_bytes, state_bytes, _ = gpu_ctx.pusch_decoder_sizes(cfg0, 1)
+        d_soft = torch.full((1, soft_bytes), -7, dtype=torch.int8, device="cuda")
+        d_state = torch.full((state_bytes,), 0xA5, dtype=torch.uint8, device="cuda")
+        d_tb = torch.zeros((1, pdu.tb_size_bytes + 3), dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros((1, 4), dtype=torch.int32, device="cuda")
+        soft = np.full((C, n), -7, np.int8)
+        cb_ok = np.ones(C, np.uint8)
+        cb_msg = np.zeros((C, d["segment_length"]), np.uint8)
+        amp = 8.0
+        sigma = float(rng.uniform(3.0, 9.0))
+        early = int(rng.integers(0, 2))
+        for tx, rv in enumerate([0] + [int(x) for x in rng.permutation([1, 2, 3])[:2]]):
+            cfg = abi.PuschDecoderCfg(bg, qm, rv, layers, d["n_ref"], pdu.tb_size_bytes, G // qm, 6, early, 1 if tx == 0 else 0)
+            pdu.rv = rv
+            _, rm, _ = oracle.pdsch_process(pdu, tb, layers, 12 * n_prb, taps=True, codeword_bits=G)
+            pdu.rv = 0
+            bits = np.unpackbits(rm)[:G].astype(np.float64)
+            llr = np.clip(np.rint((1 - 2 * bits) * amp + rng.normal(0, sigma, G)), -120, 120).astype(np.int8)
+            want = cases.pusch_decode_expected(oracle, d, cfg, llr, soft, cb_ok, cb_msg)
+            gpu_ctx.pusch_decode_batch(cfg, 1, dev(llr[None, :]), G, d_soft, d_state, d_tb, d_tb.shape[1], d_res)
+            torch.cuda.synchronize()
+            res = tuple(int(x) for x in d_res.cpu().numpy()[0])
+            assert res == (int(want[0]), want[1], want[2], want[3]), (done, tx, rv, res, want[:4], C, d["lifting_size"])
+            assert np.array_equal(d_soft.cpu().numpy().reshape(C, n), soft), (done, tx)
+            if want[0]:
+                assert np.array_equal(d_tb.cpu().numpy()[0, : pdu.tb_size_bytes], tb)
+                break
+        done += 1
