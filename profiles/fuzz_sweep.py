@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Larger randomised sweeps than the test-suite runs, GPU against the oracle through the C ABI (the numbers DESIGN.md section
+2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [rx] [ofdm] [csi]   (default: all)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import backends  # noqa: E402
+import cases  # noqa: E402
+
+abi, lib = backends.abi, backends.pkg.lib
+o = backends.oracle()
+ctx = lib.Context(0)
+
+
+def f32(raw):
+    return (raw.astype(np.uint32) << 16).view(np.float32)
+
+
+def pdsch():
+    bad = n = 0
+    for seed in range(6):
+        rng = np.random.default_rng(1000 + seed)
+        for pdu, P, S in cases.random_pdus(o.tbs, rng, 80):
+            if o.validate(pdu) != 0 or o.derive(pdu)["nof_re"] == 0:
+                continue
+            tb = cases.random_tb(rng, pdu)
+            d = o.derive(pdu)
+            want, orm, oscr = o.pdsch_process(pdu, tb, P, S, taps=True, codeword_bits=d["codeword_bits"])
+            got, rm, scr = ctx.pdsch_process_host(pdu, tb, P, S, taps=True)
+            n += 1
+            if not (np.array_equal(got, want) and np.array_equal(rm, orm) and np.array_equal(scr, oscr)):
+                bad += 1
+                print("PDSCH MISMATCH seed", seed, d, flush=True)
+    print("pdsch: %d random PDUs, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
+def rx():
+    rng = np.random.default_rng(424242)
+    sizes = cases.LIFTING_SIZES
+    bad = 0
+    for t in range(200):
+        bg = int(rng.integers(1, 3))
+        zc = int(rng.choice(sizes[3:]))
+        kb, n_short = (22, 66) if bg == 1 else (10, 50)
+        k = kb * zc
+        crc_id = int(rng.choice([16, 0x24A, 0x24B]))
+        crc_len = 16 if crc_id == 16 else 24
+        if k - crc_len - 2 <= 0:
+            continue
+        nf = int(rng.integers(0, max(1, min(k - crc_len - 2, (kb - 2) * zc - 1) // 2)))
+        nof_llr = int(rng.integers(k + 2 * zc, n_short * zc + 1))
+        _, llr = cases.make_ldpc_llrs(o, rng, bg, zc, nof_llr, crc_id, nf, float(rng.uniform(6, 30)), float(rng.uniform(2, 14)))
+        llr[rng.integers(0, nof_llr, max(1, nof_llr // 50))] = 127
+        llr[rng.integers(0, nof_llr, max(1, nof_llr // 50))] = 0
+        if t % 7 == 0:
+            llr[rng.integers(0, nof_llr, max(1, nof_llr // 40))] = -127
+        iters, scaling = int(rng.integers(1, 11)), float(rng.choice([0.5, 0.625, 0.75, 0.8, 0.9, 0.99]))
+        crc = crc_id if rng.integers(0, 4) else 0
+        want = o.ldpc_decode(bg, zc, nf, crc, iters, scaling, llr)
+        got = ctx.ldpc_decode_host(bg, zc, nf, crc, iters, scaling, llr)
+        if got[0] != want[0] or not np.array_equal(got[1], want[1]):
+            bad += 1
+            print("DECODER MISMATCH", bg, zc, nf, hex(crc), iters, scaling, nof_llr, flush=True)
+    print("decoder: 200 random configurations, %d mismatches" % bad, flush=True)
+    total = bad
+    bad = 0
+    for t in range(300):
+        bg = int(rng.integers(1, 3))
+        zc = int(rng.choice(sizes))
+        n = (66 if bg == 1 else 50) * zc
+        nof_sys = ((22 if bg == 1 else 10) - 2) * zc
+        qm = int(rng.choice([1, 2, 4, 6, 8]))
+        e = qm * int(rng.integers(1, max(2, min(4 * n, 70000) // qm)))
+        nf = int(rng.integers(0, max(1, nof_sys // 2)))
+        nref = int(rng.choice([0, 0, int(rng.integers(nof_sys + 1, n + 1))]))
+        rv, new_data = int(rng.integers(0, 4)), int(rng.integers(0, 2))
+        llr = rng.integers(-127, 128, e).astype(np.int8)
+        old = rng.integers(-127, 128, n).astype(np.int8)
+        want = o.ldpc_rate_dematch(bg, zc, rv, qm, nref, nf, new_data, llr, old)
+        got = ctx.ldpc_rate_dematch_host(bg, zc, rv, qm, nref, nf, new_data, llr, old)
+        if not np.array_equal(got, want):
+            bad += 1
+            print("DEMATCHER MISMATCH", bg, zc, e, rv, qm, nref, nf, new_data, flush=True)
+    print("rate dematcher: 300 random configurations, %d mismatches" % bad, flush=True)
+    return total + bad
+
+
+def ofdm():
+    rng = np.random.default_rng(8088)
+    bad = 0
+    for t in range(100):
+        n = int(rng.choice([128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]))
+        mu, ext = int(rng.integers(0, 5)), int(rng.integers(0, 4) == 0)
+        bw, ports = int(rng.integers(1, min(275, (n - 1) // 12) + 1)), int(rng.integers(1, 5))
+        cfg = abi.OfdmConfig(mu, bw, n, ext, float(rng.uniform(0.01, 2.0)), float(rng.choice([0.0, 7e8, 2.4e9, 3.5e9, 28e9, 39e9])))
+        slot = int(rng.integers(0, 1 << mu))
+        grid = (rng.standard_normal((ports, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        plan = lib.OfdmPlan(ctx, cfg, ports)
+        iq = plan.modulate_slot_host(grid, slot)
+        want = o.ofdm_slot(cfg, grid, slot)
+        e1 = np.abs(iq - want).max() / np.abs(want).max()
+        wo = int(rng.integers(0, (144 * n) // 2048))
+        rxs = (rng.standard_normal(want.shape) + 1j * rng.standard_normal(want.shape)).astype(np.complex64)
+        got, ref = plan.demodulate_slot_host(rxs, slot, wo), o.ofdm_demod_slot(cfg, rxs, slot, wo)
+        ns = 12 if ext else 14
+        a, b = f32(got[:, :ns]), f32(ref[:, :ns])
+        nb = int((np.abs(a - b) > np.maximum(np.abs(b), 1e-3 * np.abs(b).max()) * 2.0 ** -7).sum())
+        if e1 >= 1e-5 or nb or np.mean(got[:, :ns] == ref[:, :ns]) < 0.99:
+            bad += 1
+            print("OFDM MISMATCH", n, mu, ext, bw, ports, slot, wo, "modulator err %.1e" % e1, "demodulator bad", nb, flush=True)
+        plan.close()
+    print("ofdm: 100 random configurations, %d mismatches" % bad, flush=True)
+    return bad
+
+
+def csi():
+    rng = np.random.default_rng(8088)
+    bad = 0
+    for t in range(200):
+        row = int(rng.integers(1, 6))
+        ports = abi.CSI_ROW_PORTS[row]
+        dens = {1: ["three"], 2: ["one", "dot5_even", "dot5_odd"], 3: ["one", "dot5_even", "dot5_odd"], 4: ["one"], 5: ["one"]}[row]
+        kmax = {1: 3, 2: 11, 3: 10, 4: 8, 5: 10}[row]
+        start = int(rng.integers(0, 200))
+        nrb = int(rng.integers(1, 275 - start))
+        cp = int(rng.integers(0, 2))
+        lmax = (12 if cp else 14) - (2 if row == 5 else 1)
+        w = None
+        if rng.integers(0, 2):
+            w = ((rng.standard_normal((1, ports, ports)) + 1j * rng.standard_normal((1, ports, ports))) / 2).astype(np.complex64)
+        cfg = abi.make_csi_rs(row=row, start_rb=start, nof_rb=nrb, k0=int(rng.integers(0, kmax + 1)), l0=int(rng.integers(0, lmax + 1)),
+                              density=str(rng.choice(dens)), slot_index=int(rng.integers(0, 20)), cp=cp,
+                              scrambling_id=int(rng.integers(0, 1024)), amplitude=float(rng.uniform(0.1, 2)), precoding=w)
+        P, S = int(rng.integers(ports, 5)), 12 * (start + nrb)
+        grid = (rng.standard_normal((P, 14, S, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        if o.csi_rs_validate(cfg) != 0 or ctx.lib.nrphy_csi_rs_validate(C.byref(cfg)) != 0:
+            bad += 1
+            continue
+        if not np.array_equal(ctx.csi_rs_map_host(cfg, grid), o.csi_rs_map(cfg, grid)):
+            bad += 1
+            print("CSI-RS MISMATCH", row, start, nrb, cp, flush=True)
+    print("csi-rs: 200 random configurations, %d mismatches" % bad, flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["pdsch", "rx", "ofdm", "csi"]
+    total = sum({"pdsch": pdsch, "rx": rx, "ofdm": ofdm, "csi": csi}[w]() for w in which)
+    sys.exit(1 if total else 0)
