@@ -270,6 +270,24 @@ typedef struct nrphy_grid_re {
 int nrphy_grid_put(nrphy_ctx_t* ctx, void* d_grid, uint32_t nof_ports, uint32_t nof_subc, uint32_t n,
                    const nrphy_grid_re_t* entries, void* stream);
 
+/* ---- soft-bit descrambling ("next" row, SURVEY.md section 8f-1: the step between the demodulation mapper and the
+ * UL-SCH decoder) -------------------------------------------------------------------------------------------
+ * Replaces pseudo_random_generator::apply_xor(span<log_likelihood_ratio>, span<const log_likelihood_ratio>)
+ * (R/include/srsran/phy/upper/sequence_generators/pseudo_random_generator.h; implementation
+ * R/lib/phy/upper/sequence_generators/pseudo_random_generator_impl.cpp:423-523) after init(c_init), and the same
+ * operation written out in pusch_demodulator_impl (revert_scrambling on the generated sequence,
+ * R/lib/phy/upper/channel_processors/pusch/pusch_demodulator_impl.cpp:38-100, 254-259, one OFDM symbol at a time):
+ * out[i] = c(i) ? -in[i] : in[i] in 8-bit two's complement (-128 stays -128), c = the Gold sequence of TS 38.211
+ * Section 5.2.1 from its first bit.  The UCI placeholder handling of that demodulator is not part of this call.
+ * n_cw codewords of `length` soft bits each, row r at d_in + r * in_stride / d_out + r * out_stride (bytes; in place
+ * is allowed: d_out == d_in), d_c_init: n_cw values IN DEVICE MEMORY (for PUSCH (rnti << 15) + n_id, TS 38.211
+ * Section 6.3.1.1).  length <= 2^21; n_cw <= 65535.  16-byte aligned rows take the wide path.  Asynchronous on
+ * `stream` (NULL: the context's stream); no host memory is touched, so the call can be captured in a hipGraph. */
+int nrphy_llr_descramble(nrphy_ctx_t* ctx, uint32_t n_cw, const uint32_t* d_c_init, uint32_t length, const int8_t* d_in,
+                         size_t in_stride, int8_t* d_out, size_t out_stride, void* stream);
+/* One codeword from and to host memory (blocking; for tests and small cases). */
+int nrphy_llr_descramble_host(nrphy_ctx_t* ctx, uint32_t c_init, uint32_t length, const int8_t* in, int8_t* out);
+
 /* ---- other downlink grid writers ("next" row): NZP-CSI-RS generator -----------
  * Replaces nzp_csi_rs_generator::map (R/include/srsran/phy/upper/signal_processors/nzp_csi_rs_generator.h:
  * 39-90; impl R/lib/phy/upper/signal_processors/nzp_csi_rs_generator_impl.cpp:96-352 with the RE patterns of

@@ -644,6 +644,20 @@ void oracle_prg_apply_xor(uint32_t c_init, uint32_t offset, uint8_t* data, uint3
   }
 }
 
+/* pseudo_random_generator::apply_xor on soft bits (pseudo_random_generator_impl.cpp:423-523): the log-likelihood ratio of
+ * every position whose sequence bit is one changes sign.  The 16-at-a-time path negates in 8-bit two's complement
+ * (-128 stays -128) and the scalar tail multiplies by -1 and narrows again, which is the same value.
+ * pusch_demodulator_impl performs the same operation on the generated sequence (revert_scrambling,
+ * lib/phy/upper/channel_processors/pusch/pusch_demodulator_impl.cpp:38-100, 254-259). */
+void oracle_prg_apply_xor_llr(uint32_t c_init, uint32_t offset, const int8_t* in, int8_t* out, uint32_t n)
+{
+  gold_t g;
+  gold_init(&g, c_init, offset);
+  for (uint32_t i = 0; i != n; ++i) {
+    out[i] = gold_step(&g) ? (int8_t)(uint8_t)(0U - (uint8_t)in[i]) : in[i];
+  }
+}
+
 void oracle_prg_generate_float(uint32_t c_init, uint32_t offset, float value, float* out, uint32_t n)
 {
   gold_t g;

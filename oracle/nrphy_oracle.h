@@ -32,6 +32,7 @@ int oracle_ldpc_encode(uint32_t bg, uint32_t zc, const uint8_t* msg, uint32_t ou
 int oracle_ldpc_rate_match(uint32_t bg, uint32_t zc, uint32_t rv, uint32_t qm, uint32_t nref, uint32_t nof_filler,
                            const uint8_t* in, uint32_t in_bits, uint8_t* out, uint32_t rm_length);
 void  oracle_prg_apply_xor(uint32_t c_init, uint32_t offset, uint8_t* data, uint32_t nbits);
+void  oracle_prg_apply_xor_llr(uint32_t c_init, uint32_t offset, const int8_t* in, int8_t* out, uint32_t n);
 void  oracle_prg_generate_float(uint32_t c_init, uint32_t offset, float value, float* out, uint32_t n);
 float oracle_modulate_ci8(uint32_t qm, const uint8_t* bits, uint32_t nsym, int8_t* out);
 /* pdsch_encoder::encode -> packed rate-matched codeword (codeword_bits bits). */

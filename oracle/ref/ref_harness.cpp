@@ -517,6 +517,17 @@ void ref_prg_apply_xor(unsigned c_init, unsigned offset, uint8_t* data, unsigned
   std::memcpy(data, out.get_buffer().data(), out.get_buffer().size());
 }
 
+// pseudo_random_generator::apply_xor(span<log_likelihood_ratio>, span<const log_likelihood_ratio>) after init + advance.
+void ref_prg_apply_xor_llr(unsigned c_init, unsigned offset, const int8_t* in, int8_t* out, unsigned n)
+{
+  pseudo_random_generator_impl prg;
+  prg.init(c_init);
+  prg.advance(offset);
+  static_assert(sizeof(log_likelihood_ratio) == 1, "one byte per soft bit");
+  prg.apply_xor(span<log_likelihood_ratio>(reinterpret_cast<log_likelihood_ratio*>(out), n),
+                span<const log_likelihood_ratio>(reinterpret_cast<const log_likelihood_ratio*>(in), n));
+}
+
 // pseudo_random_generator::generate(span<float>, value) after init + advance.
 void ref_prg_generate_float(unsigned c_init, unsigned offset, float value, float* out, unsigned n)
 {

@@ -290,6 +290,8 @@ def declare(lib, prefix="nrphy_"):
     sig("ldpc_decode_host", i32, vp, P(LdpcDecoderCfg), vp, u8p, P(u32))
     sig("ldpc_rate_dematch", i32, vp, P(LdpcRateDematcherCfg), u32, vp, u32, vp, u32, i32, vp)
     sig("ldpc_rate_dematch_host", i32, vp, P(LdpcRateDematcherCfg), vp, vp, i32)
+    sig("llr_descramble", i32, vp, u32, vp, u32, vp, C.c_size_t, vp, C.c_size_t, vp)
+    sig("llr_descramble_host", i32, vp, u32, u32, vp, vp)
     sig("grid_put", i32, vp, vp, u32, u32, u32, P(GridRe), vp)
     sig("csi_rs_validate", i32, P(CsiRsCfg))
     sig("csi_rs_map", i32, vp, u32, P(CsiRsCfg), P(u32), vp, u32, u32, vp)
@@ -314,4 +316,5 @@ ABI_SYMBOLS = [
     "nrphy_ldpc_decode", "nrphy_ldpc_decode_host", "nrphy_ldpc_rate_dematch", "nrphy_ldpc_rate_dematch_host",
     "nrphy_pusch_decode_codeblock_host", "nrphy_pusch_decoder_sizes", "nrphy_pusch_decode_batch",
     "nrphy_csi_rs_validate", "nrphy_csi_rs_map", "nrphy_csi_rs_map_host", "nrphy_grid_put",
+    "nrphy_llr_descramble", "nrphy_llr_descramble_host",
 ]

@@ -1738,6 +1738,58 @@ extern "C" int nrphy_ldpc_rate_dematch_host(nrphy_ctx_t* ctx, const nrphy_ldpc_r
   return rc;
 }
 
+extern "C" int nrphy_llr_descramble(nrphy_ctx_t* ctx, uint32_t n_cw, const uint32_t* d_c_init, uint32_t length,
+                                    const int8_t* d_in, size_t in_stride, int8_t* d_out, size_t out_stride, void* stream)
+{
+  if (ctx == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (n_cw == 0 || length == 0) {
+    return NRPHY_OK;
+  }
+  // The x1 table holds the first 2^21 sequence bits (the longest PUSCH / PDSCH codeword is 1.47 Mbit).
+  if (d_c_init == nullptr || d_in == nullptr || d_out == nullptr || length > (uint32_t)GOLD_X1_WORDS * 32U ||
+      (n_cw > 1 && (in_stride < length || out_stride < length)) || n_cw > 65535U) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(launch_llr_descramble(ctx->d_gold, ctx->d_x1, d_c_init, n_cw, length, d_in, in_stride, d_out, out_stride,
+                                stream ? (hipStream_t)stream : ctx->stream));
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_llr_descramble_host(nrphy_ctx_t* ctx, uint32_t c_init, uint32_t length, const int8_t* in, int8_t* out)
+{
+  if (ctx == nullptr || (length != 0 && (in == nullptr || out == nullptr))) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (length == 0) {
+    return NRPHY_OK;
+  }
+  int8_t*   d_buf = nullptr;
+  uint32_t* d_ci  = nullptr;
+  int       rc    = NRPHY_ERR_DEVICE;
+  do {
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&d_buf, (size_t)length + 16) != hipSuccess ||
+        hipMalloc((void**)&d_ci, 16) != hipSuccess || hipMemcpy(d_buf, in, length, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ci, &c_init, sizeof(c_init), hipMemcpyHostToDevice) != hipSuccess) {
+      break;
+    }
+    rc = nrphy_llr_descramble(ctx, 1, d_ci, length, d_buf, length, d_buf, length, ctx->stream); // in place, as the caller does
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(out, d_buf, length, hipMemcpyDeviceToHost) != hipSuccess) {
+      break;
+    }
+    rc = NRPHY_OK;
+  } while (false);
+  (void)hipFree(d_buf);
+  (void)hipFree(d_ci);
+  return rc;
+}
+
 namespace {
 
 // Decoder graph of (base graph, lifting size): all edges of TS 38.212 Tables 5.3.2-2/-3, row by row.

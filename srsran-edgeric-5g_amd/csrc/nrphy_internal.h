@@ -297,6 +297,9 @@ struct CsiRsLaunch {
   uint32_t          grid_nof_ports, grid_nof_subc;
 };
 hipError_t launch_csi_rs(const CsiRsLaunch& p, uint32_t n_work, hipStream_t stream);
+hipError_t launch_llr_descramble(const GoldTables* gold, const uint32_t* x1_words, const uint32_t* d_c_init, uint32_t n_cw,
+                                 uint32_t length, const int8_t* d_in, size_t in_stride, int8_t* d_out, size_t out_stride,
+                                 hipStream_t stream);
 hipError_t launch_grid_put(const uint32_t* d_index, const uint32_t* d_value, uint32_t n, uint32_t* d_grid, hipStream_t stream);
 
 // ---- OFDM ---------------------------------------------------------------------------------------------------

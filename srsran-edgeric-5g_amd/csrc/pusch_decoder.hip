@@ -142,6 +142,85 @@ __global__ __launch_bounds__(ASSEMBLE_THREADS) void pusch_tb_crc_kernel(PuschAss
   }
 }
 
+// ================================================================================================================
+// Descrambling of soft bits: the sign of every log-likelihood ratio whose scrambling bit c(n) is one flips
+// (pseudo_random_generator_impl::apply_xor on log_likelihood_ratio spans, pseudo_random_generator_impl.cpp:423-523;
+// revert_scrambling in pusch_demodulator_impl.cpp:38-100 after the demodulation mapper).  blockIdx.x = chunk of DESCRAMBLE_CHUNK_WORDS x 32
+// soft bits, blockIdx.y = codeword.  The workgroup generates its share of c(n) straight into LDS (jump to the chunk's
+// offset, then the lifted recurrence), then every lane takes 16 soft bits per step: one 16-byte load, the 16 sequence
+// bits spread to byte masks, bytewise two's-complement negation (-128 stays -128 as in the reference's 16-wide path),
+// one 16-byte store.  HBM-bound: one byte read and one written per soft bit.
+// ================================================================================================================
+constexpr uint32_t DESCRAMBLE_CHUNK_WORDS = 2048;
+constexpr uint32_t DESCRAMBLE_THREADS     = 256;
+
+// The four most significant bits of `nibble << 28` spread to byte masks: bit 31 -> byte 0 (lowest address) ... bit 28
+// -> byte 3.
+__device__ __forceinline__ uint32_t byte_masks_msb_first(uint32_t bits4)
+{
+  // bits4 holds the four bits in its low nibble, first soft bit in bit 3.
+  const uint32_t spread = ((bits4 >> 3) & 1u) | (((bits4 >> 2) & 1u) << 8) | (((bits4 >> 1) & 1u) << 16) | ((bits4 & 1u) << 24);
+  return spread * 0xFFu;
+}
+
+// Per byte: m ? -x : x  (m = 0xFF or 0x00 per byte).
+__device__ __forceinline__ uint32_t negate_bytes(uint32_t x, uint32_t m)
+{
+  const uint32_t a = x ^ m, b = m & 0x01010101u;
+  return ((a & 0x7F7F7F7Fu) + b) ^ (a & 0x80808080u); // b < 0x80 per byte: its top bit never takes part
+}
+
+__global__ __launch_bounds__(DESCRAMBLE_THREADS) void llr_descramble_kernel(const GoldTables* gold, const uint32_t* x1_words,
+                                                                            const uint32_t* __restrict__ c_init,
+                                                                            const int8_t* __restrict__ in, size_t in_stride,
+                                                                            int8_t* __restrict__ out, size_t out_stride,
+                                                                            uint32_t length)
+{
+  __shared__ uint32_t ring[GOLD_RING_WORDS];
+  __shared__ uint32_t seq[DESCRAMBLE_CHUNK_WORDS];
+  const uint32_t tid        = threadIdx.x;
+  const uint32_t first_word = blockIdx.x * DESCRAMBLE_CHUNK_WORDS;
+  const uint32_t first      = first_word * 32u;
+  const uint32_t count      = min(length - first, DESCRAMBLE_CHUNK_WORDS * 32u); // soft bits of this chunk (> 0 by the grid)
+  const uint32_t nwords     = (count + 31u) / 32u;
+  gold_sequence_workgroup<DESCRAMBLE_THREADS>(gold, x1_words, to_constant(c_init)[blockIdx.y], first_word, nwords, seq, ring, tid);
+  __syncthreads();
+  const int8_t* src = in + (size_t)blockIdx.y * in_stride + first;
+  int8_t*       dst = out + (size_t)blockIdx.y * out_stride + first;
+  // 16-byte steps need both rows aligned; the chunk offset is a multiple of 64 KiB, so that is a property of the
+  // caller's pointers and strides (workgroup-uniform).
+  const bool     wide   = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15u) == 0;
+  const uint32_t groups = wide ? count / 16u : 0u;
+  for (uint32_t g = tid; g < groups; g += DESCRAMBLE_THREADS) {
+    const uint32_t bits16 = (seq[g >> 1] >> ((g & 1u) ? 0u : 16u)) & 0xFFFFu;
+    const uint4    v      = reinterpret_cast<const uint4*>(src)[g];
+    uint4          r;
+    r.x = negate_bytes(v.x, byte_masks_msb_first(bits16 >> 12));
+    r.y = negate_bytes(v.y, byte_masks_msb_first(bits16 >> 8));
+    r.z = negate_bytes(v.z, byte_masks_msb_first(bits16 >> 4));
+    r.w = negate_bytes(v.w, byte_masks_msb_first(bits16));
+    reinterpret_cast<uint4*>(dst)[g] = r;
+  }
+  for (uint32_t i = groups * 16u + tid; i < count; i += DESCRAMBLE_THREADS) { // ragged end, or unaligned rows
+    const bool flip = ((seq[i >> 5] >> (31u - (i & 31u))) & 1u) != 0;
+    const int8_t x  = src[i];
+    dst[i]          = flip ? (int8_t)(uint8_t)(0u - (uint8_t)x) : x;
+  }
+}
+
+hipError_t launch_llr_descramble(const GoldTables* gold, const uint32_t* x1_words, const uint32_t* d_c_init, uint32_t n_cw,
+                                 uint32_t length, const int8_t* d_in, size_t in_stride, int8_t* d_out, size_t out_stride,
+                                 hipStream_t stream)
+{
+  if (n_cw == 0 || length == 0) {
+    return hipSuccess;
+  }
+  const uint32_t chunks = (length + DESCRAMBLE_CHUNK_WORDS * 32u - 1u) / (DESCRAMBLE_CHUNK_WORDS * 32u);
+  hipLaunchKernelGGL(llr_descramble_kernel, dim3(chunks, n_cw), dim3(DESCRAMBLE_THREADS), 0, stream, gold, x1_words, d_c_init,
+                     d_in, in_stride, d_out, out_stride, length);
+  return hipGetLastError();
+}
+
 hipError_t launch_pusch_assemble(const PuschAssembleLaunch& p, uint32_t n_tb, hipStream_t stream)
 {
   if (n_tb == 0) {

@@ -140,6 +140,19 @@ class Context:
                "nrphy_pusch_decode_codeblock_host")
         return int(it.value), np.unpackbits(packed)[:k], soft
 
+    def llr_descramble(self, d_c_init, n_cw, length, d_in, in_stride, d_out, out_stride, stream=None):
+        """pseudo_random_generator::apply_xor on soft bits for n_cw codewords in device memory (d_c_init: device uint32)."""
+        _check(self.lib.nrphy_llr_descramble(self.handle, n_cw, _dptr(d_c_init), length, _dptr(d_in), in_stride, _dptr(d_out),
+                                             out_stride, stream), "nrphy_llr_descramble")
+
+    def llr_descramble_host(self, c_init, llr):
+        """One codeword of int8 soft bits from host memory; returns the descrambled copy."""
+        llr = np.ascontiguousarray(llr, dtype=np.int8)
+        out = np.empty_like(llr)
+        _check(self.lib.nrphy_llr_descramble_host(self.handle, c_init, llr.size, llr.ctypes.data, out.ctypes.data),
+               "nrphy_llr_descramble_host")
+        return out
+
     def grid_put(self, d_grid, nof_ports, nof_subc, entries, stream=None):
         """Sparse host writes into ONE device grid: entries = [(port, symbol, subc, cbf16 word)], later ones win."""
         n = len(entries)

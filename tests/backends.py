@@ -253,6 +253,15 @@ class CpuBackend:
         assert f(*args) == 0
         return out
 
+    def prg_apply_xor_llr(self, c_init, offset, llr):
+        """pseudo_random_generator::apply_xor on soft bits (sign flips); returns a new int8 array."""
+        llr = np.ascontiguousarray(llr, dtype=np.int8)
+        out = np.empty_like(llr)
+        f = self._f("prg_apply_xor_llr")
+        f.restype = None
+        f(C.c_uint32(c_init), C.c_uint32(offset), _ptr(llr), _ptr(out), C.c_uint32(llr.size))
+        return out
+
     def csi_rs_map(self, cfg, grid, simd=1):
         """nzp_csi_rs_generator::map into a copy of grid [nof_ports][14][nof_subc][2] uint16 (raw cbf16)."""
         out = np.array(grid, dtype=np.uint16, copy=True)

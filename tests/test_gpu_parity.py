@@ -976,6 +976,47 @@ def test_grid_put_sparse_host_writes(gpu_ctx):
     assert gpu_ctx.lib.nrphy_grid_put(gpu_ctx.handle, d_grid.data_ptr(), nof_ports, nof_subc, 1, bad, None) == abi.ERR_ARGUMENT
 
 
+def test_llr_descramble_host_cases(gpu_ctx, oracle):
+    """Soft-bit descrambling, the cases of tests/test_oracle.py::test_oracle_vs_ref_llr_descrambling (oracle pinned to the
+    compiled reference there) plus chunk boundaries of the kernel (65536 soft bits per workgroup) and the longest
+    PUSCH codeword; every int8 value including -128."""
+    rng = np.random.default_rng(44)
+    for c_init, n in ((1 << 15, 256), (0x12345678, 100003), (5, 15), (0x7FFFFFFF, 17), ((0x4601 << 15) + 935, 52416),
+                      (77, 1), (78, 33), (79, 6 * 32 + 5), (80, 65536), (81, 65537), (82, 65535), (83, 2 * 65536 + 16),
+                      (0x7ABCDEF0, 273 * 12 * 14 * 8 * 4), (84, 1 << 21)):
+        llr = rng.integers(-128, 128, n).astype(np.int8)
+        got = gpu_ctx.llr_descramble_host(c_init, llr)
+        assert np.array_equal(got, oracle.prg_apply_xor_llr(c_init, 0, llr)), (c_init, n)
+    assert gpu_ctx.llr_descramble_host(3, np.zeros(0, np.int8)).size == 0
+    one = np.zeros(16, np.int8)
+    assert gpu_ctx.lib.nrphy_llr_descramble_host(gpu_ctx.handle, 1, (1 << 21) + 1, one.ctypes.data, one.ctypes.data) == abi.ERR_ARGUMENT
+
+
+def test_llr_descramble_batch_strided_in_place(gpu_ctx, oracle):
+    """A batch of codewords with their own c_init in device memory: out of place with different strides, in place, rows
+    that are not 16-byte aligned (byte path), and padding between rows left untouched."""
+    import torch
+    rng = np.random.default_rng(45)
+    for n_cw, length, in_stride, out_stride in ((5, 70000, 70016, 70400), (3, 4097, 4099, 4101), (64, 1000, 1008, 1008), (2, 131072, 131072, 131072)):
+        c_init = rng.integers(0, 1 << 31, n_cw).astype(np.uint32)
+        src = rng.integers(-128, 128, (n_cw, in_stride)).astype(np.int8)
+        dst0 = rng.integers(-128, 128, (n_cw, out_stride)).astype(np.int8)
+        d_ci, d_src, d_dst = dev(c_init.view(np.int32)), dev(src), dev(dst0)
+        gpu_ctx.llr_descramble(d_ci, n_cw, length, d_src, in_stride, d_dst, out_stride)
+        gpu_ctx.synchronize()
+        torch.cuda.synchronize()
+        got = d_dst.cpu().numpy()
+        for r in range(n_cw):
+            assert np.array_equal(got[r, :length], oracle.prg_apply_xor_llr(int(c_init[r]), 0, src[r, :length])), (n_cw, length, r)
+        assert np.array_equal(got[:, length:], dst0[:, length:])
+        assert np.array_equal(d_src.cpu().numpy(), src)
+        gpu_ctx.llr_descramble(d_ci, n_cw, length, d_src, in_stride, d_src, in_stride)   # in place
+        gpu_ctx.synchronize()
+        torch.cuda.synchronize()
+        again = d_src.cpu().numpy()
+        assert np.array_equal(again[:, :length], got[:, :length]) and np.array_equal(again[:, length:], src[:, length:])
+
+
 def test_pdsch_random_pdus(gpu_ctx, oracle):
     """Fuzz: the 40 random PDUs of tests/test_oracle.py::test_oracle_vs_ref_random_pdus (same seed, so the oracle side of
     every one of them is pinned to the compiled reference) plus 40 more, codeword taps and grid bit-exact."""

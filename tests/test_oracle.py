@@ -373,6 +373,21 @@ def test_oracle_vs_ref_prg_and_modulation(oracle, ref):
         assert np.array_equal(a, b) and sa == sb
 
 
+def test_oracle_vs_ref_llr_descrambling(oracle, ref):
+    """Soft-bit apply_xor: every int8 value (including -128), lengths around the reference's 16-wide and step sizes."""
+    rng = np.random.default_rng(44)
+    every = np.arange(-128, 128, dtype=np.int8)
+    for c_init, off, n in ((1 << 15, 0, 256), (0x12345678, 777, 100003), (5, 100000, 15), (0x7FFFFFFF, 1, 17),
+                           ((0x4601 << 15) + 935, 0, 52416), (77, 3, 1), (78, 31, 33), (79, 0, 6 * 32 + 5)):
+        llr = rng.integers(-128, 128, n).astype(np.int8)
+        llr[: min(n, 256)] = np.tile(every, 2)[: min(n, 256)][rng.permutation(min(n, 256))] if n >= 256 else llr[: min(n, 256)]
+        want = ref.prg_apply_xor_llr(c_init, off, llr)
+        got = oracle.prg_apply_xor_llr(c_init, off, llr)
+        assert np.array_equal(got, want), (c_init, off, n)
+        assert np.array_equal(np.abs(got.astype(np.int16)), np.abs(llr.astype(np.int16)))
+        assert np.array_equal(oracle.prg_apply_xor_llr(c_init, off, got), llr)  # an involution
+
+
 def test_oracle_vs_ref_pdsch_processor(oracle, ref):
     """Grid bit-exact against the reference's generic, AVX2 and "lite" processors, codeword against pdsch_encoder."""
     import test_gpu_parity
