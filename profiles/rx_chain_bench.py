@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Secondary measurement, BASELINE config 5 ("PUSCH receive path add-on: OFDM demod + LDPC min-sum decode, 8 iterations,
 100 MHz, 1 MI355X"): the receive-side kernels built so far on one batch of slots, everything resident in HBM.
-A step = OFDM demodulation of `slots` 100 MHz slots (4 receive ports) + the transport-block decoder on the config-3
-transport block of each slot (nrphy_pusch_decode_batch: rate dematching of its 104 codeblocks, LDPC decoding with
-CRC24B early stop, concatenation, TB CRC24A).  The transmitter is this library's PDSCH path (its rate-matched codeword
-tap); equalisation and soft demodulation, which sit between the two in a receiver, are not built: the LLRs are the
-codeword bits through a BPSK-like AWGN map.  Every decoded transport block is compared with what was sent.
+A step = OFDM demodulation of `slots` 100 MHz slots (4 receive ports) + soft-bit descrambling (nrphy_llr_descramble)
++ the transport-block decoder on the config-3 transport block of each slot (nrphy_pusch_decode_batch: rate dematching of
+its 104 codeblocks, LDPC decoding with CRC24B early stop, concatenation, TB CRC24A).  The transmitter is this library's
+PDSCH path (its scrambled codeword tap); equalisation and the demodulation mapper, which sit between the two in a
+receiver, are not built: the soft bits are the scrambled codeword bits through a BPSK-like AWGN map.  Every decoded transport block is compared with what was sent.
 Prints one JSON line in bench.py's schema.  Usage (GPU box, repository root):
 python3 profiles/rx_chain_bench.py [--slots 64] [--iterations 8] [--steps 10] [--sigma 7.0]"""
 import argparse
@@ -36,13 +36,13 @@ def main():
     slots = args.slots
     d = lib.derive(pdu)
     G, C, tb_size = d["codeword_bits"], d["nof_codeblocks"], pdu.tb_size_bytes
-    # transmit side: the PDSCH plan with its rate-matched (pre-scrambling) codeword tap
+    # transmit side: the PDSCH plan with its scrambled codeword tap (what the air interface carries)
     pdus = [cases.baseline_config(3, slot_index=i % 20)[0] for i in range(slots)]
     tb_stride = (tb_size + 3) & ~3
     plan = lib.PdschPlan(ctx, pdus, [i * tb_stride for i in range(slots)], list(range(slots)), slots, ports, subc)
     d_tb = torch.randint(0, 256, (slots, tb_stride), dtype=torch.uint8, device="cuda")
     d_cw = torch.zeros((plan.codeword_bits + 7) // 8 + 64, dtype=torch.uint8, device="cuda")
-    plan.run(d_tb.reshape(-1), None, d_cw_rm=d_cw)
+    plan.run(d_tb.reshape(-1), None, d_cw_scr=d_cw)
     ctx.synchronize()
     torch.cuda.synchronize()
     offs = [plan.codeword_offset(i) for i in range(slots)]
@@ -51,7 +51,9 @@ def main():
     bits = np.stack([np.unpackbits(cw[o // 8: o // 8 + (G + 7) // 8])[:G] for o in offs]).astype(np.float32)
     rng = np.random.default_rng(5)
     llr = np.clip(np.rint((1 - 2 * bits) * 20 + rng.normal(0, args.sigma, bits.shape)), -120, 120).astype(np.int8)
-    d_llr = torch.from_numpy(llr).cuda()
+    d_llr_scr = torch.from_numpy(llr).cuda()   # soft bits as the demodulation mapper would hand them over: still scrambled
+    d_llr = torch.empty_like(d_llr_scr)
+    d_c_init = torch.tensor([(p.rnti << 15) + p.n_id for p in pdus], dtype=torch.int32, device="cuda")  # TS 38.211 7.3.1.1, q = 0
     cfg = abi.PuschDecoderCfg(pdu.ldpc_base_graph, pdu.qm, 0, pdu.nof_layers, d["n_ref"], tb_size, G // pdu.qm,
                               args.iterations, 1, 1)
     soft_bytes, state_bytes, ncb = ctx.pusch_decoder_sizes(cfg, slots)
@@ -64,7 +66,7 @@ def main():
     d_grid = torch.zeros((slots, ports, 14, subc), dtype=torch.int32, device="cuda")
     d_slot = torch.tensor([i % 2 for i in range(slots)], dtype=torch.int32, device="cuda")
     s = torch.cuda.Stream()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 
     def step(timed):
         if timed:
@@ -72,9 +74,12 @@ def main():
         oplan.demod_run(slots, d_iq, d_grid, d_slot_index=d_slot, stream=s.cuda_stream)
         if timed:
             ev[1].record(s)
-        ctx.pusch_decode_batch(cfg, slots, d_llr, G, d_soft, d_state, d_out, tb_stride, d_res, s.cuda_stream)
+        ctx.llr_descramble(d_c_init, slots, G, d_llr_scr, G, d_llr, G, s.cuda_stream)
         if timed:
             ev[2].record(s)
+        ctx.pusch_decode_batch(cfg, slots, d_llr, G, d_soft, d_state, d_out, tb_stride, d_res, s.cuda_stream)
+        if timed:
+            ev[3].record(s)
 
     for _ in range(args.warmup):
         step(False)
@@ -91,7 +96,8 @@ def main():
     ms = a.elapsed_time(b) / args.steps
     step(True)
     torch.cuda.synchronize()
-    kernel_ms = {"ofdm_demod": ev[0].elapsed_time(ev[1]), "pusch_decode_batch": ev[1].elapsed_time(ev[2])}
+    kernel_ms = {"ofdm_demod": ev[0].elapsed_time(ev[1]), "llr_descramble": ev[1].elapsed_time(ev[2]),
+                 "pusch_decode_batch": ev[2].elapsed_time(ev[3])}
     n_cb = slots * C
     alg = n_cb * d["full_length"] + slots * tb_size  # decoder: soft buffers in, transport blocks out
     print(json.dumps({
