@@ -89,6 +89,16 @@ def rx():
             bad += 1
             print("DEMATCHER MISMATCH", bg, zc, e, rv, qm, nref, nf, new_data, flush=True)
     print("rate dematcher: 300 random configurations, %d mismatches" % bad, flush=True)
+    total += bad
+    bad = 0
+    for t in range(300):
+        n = int(rng.choice([rng.integers(1, 200), rng.integers(1, 70000), rng.integers(65000, 66100), rng.integers(1, 1 << 21)]))
+        c_init = int(rng.integers(0, 1 << 31))
+        llr = rng.integers(-128, 128, n).astype(np.int8)
+        if not np.array_equal(ctx.llr_descramble_host(c_init, llr), o.prg_apply_xor_llr(c_init, 0, llr)):
+            bad += 1
+            print("DESCRAMBLER MISMATCH", c_init, n, flush=True)
+    print("soft-bit descrambler: 300 random (c_init, length) pairs, %d mismatches" % bad, flush=True)
     return total + bad
 
 
