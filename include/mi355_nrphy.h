@@ -17,7 +17,14 @@
  *    (R/lib/phy/lower/modulation/ofdm_modulator_impl.cpp:115-139).
  *  - Pointers named d_* are device (HBM) pointers valid on the context's device; `stream` is a
  *    hipStream_t passed as void* (NULL = the context's own stream).  Calls that take a stream are
- *    asynchronous with respect to the host and never allocate, so they can be captured in a hipGraph.
+ *    asynchronous with respect to the host.  The plan-based calls (nrphy_pdsch_run, nrphy_ofdm_run,
+ *    nrphy_ofdm_demod_run, nrphy_llr_descramble, nrphy_dft_run) neither allocate nor touch host memory and can be
+ *    captured in a hipGraph, any number of them in any order; the others say what they do at the call.
+ *  - A PDSCH plan owns device scratch that every run rewrites before reading it (sequences, CRC shares): runs of
+ *    ONE plan must be ordered (one stream, or events between streams); different plans may run concurrently.
+ *    Every run is self-contained -- no state is carried from one run of a plan to the next.
+ *  - Host-span entry points (*_host) are blocking and serialised per context (one lock for the whole call);
+ *    they may be called from several threads.
  */
 #ifndef MI355_NRPHY_H
 #define MI355_NRPHY_H
@@ -161,7 +168,8 @@ uint32_t nrphy_ofdm_slot_size(const nrphy_ofdm_config_t* cfg, uint32_t slot_inde
  * A plan holds n_pdu PDUs.  PDU i reads its transport block at d_tb + tb_offset[i] and writes grid
  * number grid_index[i] of a batch of grids with nof_ports x 14 x nof_subc cbf16 each.  Creating a plan
  * validates every PDU (NRPHY_ERR_INVALID_PDU names none; use nrphy_pdsch_validate to find it), derives
- * the per-PDU and per-codeblock descriptors and uploads them; it may be run any number of times. */
+ * the per-PDU and per-codeblock descriptors and uploads them; it may be run any number of times (runs of one plan
+ * ordered with respect to each other, see the conventions above). */
 int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
                             const uint64_t* tb_offset, const uint32_t* grid_index, uint32_t nof_grids,
                             uint32_t grid_nof_ports, uint32_t grid_nof_subc, nrphy_pdsch_plan_t** plan);
@@ -265,7 +273,8 @@ typedef struct nrphy_grid_re {
   uint32_t subc;
   uint32_t value;  /* cbf16: bf16 real part in the low half, imaginary part in the high half */
 } nrphy_grid_re_t;
-/* d_grid: ONE grid [nof_ports][14][nof_subc] in device memory; entries: host array, copied at the call.
+/* d_grid: ONE grid [nof_ports][14][nof_subc] in device memory; entries: host array, copied at the call into a
+ * staging buffer of the call's own (stream-ordered allocation: hipMallocAsync / hipFreeAsync on `stream`).
  * Asynchronous on `stream` afterwards. */
 int nrphy_grid_put(nrphy_ctx_t* ctx, void* d_grid, uint32_t nof_ports, uint32_t nof_subc, uint32_t n,
                    const nrphy_grid_re_t* entries, void* stream);
@@ -318,8 +327,8 @@ typedef struct nrphy_csi_rs_cfg {
 /* NRPHY_OK when the configuration is one this library maps (the reference's validator accepts everything). */
 int nrphy_csi_rs_validate(const nrphy_csi_rs_cfg_t* cfg);
 /* n signals into device grids ([grid][port][14][subc] cbf16): signal i into grid grid_index[i].  The
- * configurations are copied at the call (host pointers, like PDUs at plan creation; a copy from pageable
- * memory, so the call waits for what `stream` holds before it); the kernel itself is asynchronous. */
+ * configurations are copied at the call (host pointers, like PDUs at plan creation) into a staging buffer of
+ * the call's own (stream-ordered allocation on `stream`); the kernel itself is asynchronous. */
 int nrphy_csi_rs_map(nrphy_ctx_t* ctx, uint32_t n, const nrphy_csi_rs_cfg_t* cfgs, const uint32_t* grid_index,
                      void* d_grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc, void* stream);
 /* One signal into a host grid [nof_ports][14][nof_subc] cbf16 (read and written; blocking). */
@@ -348,8 +357,9 @@ typedef struct nrphy_ldpc_rate_dematcher_cfg {
   uint32_t rm_length;
 } nrphy_ldpc_rate_dematcher_cfg_t;
 /* n_cb codeblocks that share the configuration: input i at d_in + i * in_stride_bytes, soft buffer i at
- * d_soft + i * soft_stride_bytes.  Asynchronous on `stream`, except for extreme repetition (rm_length of
- * dozens of buffer lengths), where the call synchronises the device to upload a longer operation list. */
+ * d_soft + i * soft_stride_bytes.  Asynchronous on `stream`; capturable except for extreme repetition
+ * (rm_length of dozens of buffer lengths), where a longer operation list goes through a stream-ordered
+ * allocation of the call's own. */
 int nrphy_ldpc_rate_dematch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg, uint32_t n_cb,
                             const int8_t* d_in, uint32_t in_stride_bytes, int8_t* d_soft, uint32_t soft_stride_bytes,
                             int new_data, void* stream);

@@ -379,17 +379,19 @@ struct nrphy_ctx {
   std::map<uint32_t, uint32_t*> d_tb_crc_w;    // transport-block CRC weights of the PUSCH assembly kernel per block size
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
   // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
-  std::mutex host_mutex;
-  std::mutex host_call_mutex; // serialises host-span calls that are built from device-pointer calls taking host_mutex
-  void*      scratch[11]       = {};
-  size_t     scratch_bytes[11] = {};
+  // One lock for everything context-owned and shared: the staging buffers below and the lazily built tables.  The
+  // host-span entry points (*_host) hold it from their first staging access to their last copy, so two of them never
+  // interleave on a buffer; it is recursive because they are built from device-pointer calls that take it briefly.
+  std::recursive_mutex host_mutex;
+  void*      scratch[8]       = {};
+  size_t     scratch_bytes[8] = {};
 };
 
 namespace {
 
 // Staging buffer `slot` of the context with room for `bytes` (reallocated only when it has to grow).
 enum ScratchSlot { SCRATCH_TB = 0, SCRATCH_GRID, SCRATCH_CW_RM, SCRATCH_CW_SCR, SCRATCH_IQ, SCRATCH_SMALL,
-                   SCRATCH_DECODER, SCRATCH_DEMATCH_OPS, SCRATCH_RX, SCRATCH_CSI, SCRATCH_PUT };
+                   SCRATCH_DECODER, SCRATCH_RX, SCRATCH_COUNT };
 void* ctx_scratch(nrphy_ctx* ctx, ScratchSlot slot, size_t bytes)
 {
   if (bytes > ctx->scratch_bytes[slot]) {
@@ -404,6 +406,34 @@ void* ctx_scratch(nrphy_ctx* ctx, ScratchSlot slot, size_t bytes)
   }
   return ctx->scratch[slot];
 }
+
+// Device staging that lives for ONE call: host-built work lists a kernel of this call reads.  Allocated and released
+// in stream order (hipMallocAsync / hipFreeAsync), so calls in flight on different streams never share a buffer and
+// nothing waits for the device.  Usage: alloc(), copy + launch on the same stream, then the destructor frees.
+class StreamStaging
+{
+public:
+  explicit StreamStaging(hipStream_t s) : stream(s) {}
+  StreamStaging(const StreamStaging&)            = delete;
+  StreamStaging& operator=(const StreamStaging&) = delete;
+  ~StreamStaging()
+  {
+    if (ptr != nullptr) {
+      (void)hipFreeAsync(ptr, stream);
+    }
+  }
+  void* alloc(size_t bytes)
+  {
+    if (hipMallocAsync(&ptr, std::max<size_t>(bytes, 16), stream) != hipSuccess) {
+      ptr = nullptr;
+    }
+    return ptr;
+  }
+
+private:
+  hipStream_t stream;
+  void*       ptr = nullptr;
+};
 
 } // namespace
 
@@ -428,7 +458,6 @@ struct nrphy_pdsch_plan {
   uint32_t*             d_scr = nullptr;    // scrambling sequences, rewritten by every run's prologue
   uint64_t              scr_words = 0;
   uint32_t              n_zero_work = 0;
-  uint32_t              epoch = 0;          // selects the TB-CRC accumulator of the current run
   bool                  encode_only = false;   // seam B plan: no RE mapping, nrphy_pdsch_run only with d_grid = NULL
   bool                  dmrs_separate = false; // DM-RS must overwrite data RE: keep it in its own, later launch
   uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0, n_crc_work = 0;
@@ -1126,6 +1155,12 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
     {
       const CrcField& f = (d.nof_tb_crc_bits == 16) ? CRC16_FIELD : CRC24A_FIELD;
       const uint32_t  n = pdu.tb_size_bytes;
+      pd.crc_first      = (uint32_t)crc_work.size();
+      pd.crc_count      = divide_ceil(n, TB_CRC_REGION_BYTES);
+      if (pd.crc_count > 64) { // one lane of the attaching wave per share
+        status = NRPHY_ERR_INVALID_PDU;
+        break;
+      }
       for (uint32_t region = 0; region * TB_CRC_REGION_BYTES < n; ++region) {
         const int64_t region_end = (int64_t)(region + 1) * TB_CRC_REGION_BYTES;
         crc_work.push_back({i, region, f.xpow((int64_t)f.order + 8 * ((int64_t)n - region_end)), 0});
@@ -1272,8 +1307,6 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
   plan->n_crc_work = (uint32_t)crc_work.size();
   plan->n_scr_work = (uint32_t)scr_work.size();
   {
-    const size_t         n_acc = std::max<size_t>(1, plan->pdus.size());
-    std::vector<uint32_t> zero_acc(2 * n_acc, 0); // the two TB-CRC accumulators start cleared
     DeviceArena          arena;
     arena.add(&plan->d_crc_work, crc_work.data(), crc_work.size() * sizeof(CrcWork));
     arena.add(&plan->d_scr_work, scr_work.data(), scr_work.size() * sizeof(ScrWork));
@@ -1284,13 +1317,16 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
     arena.add(&plan->d_re_table, re_table.data(), re_table.size() * sizeof(uint16_t));
     arena.add(&plan->d_zero_work, zero_work.data(), zero_work.size() * sizeof(ZeroWork));
     arena.add(&plan->d_zero_segs, zero_segs.data(), zero_segs.size() * sizeof(ZeroSeg));
-    arena.add(&plan->d_tb_crc, zero_acc.data(), zero_acc.size() * sizeof(uint32_t));
     void* scratch = nullptr;
-    if (arena.commit(&plan->d_arena, sizeof(uint32_t) * std::max<uint64_t>(4, plan->scr_words), &scratch) != hipSuccess) {
+    // Behind the tables: what every run rewrites before it reads it -- the sequences and the TB-CRC shares.
+    const uint64_t scr_alloc = (std::max<uint64_t>(4, plan->scr_words) + 3U) & ~3ULL;
+    if (arena.commit(&plan->d_arena, sizeof(uint32_t) * (scr_alloc + std::max<size_t>(4, crc_work.size())), &scratch) !=
+        hipSuccess) {
       nrphy_pdsch_plan_destroy(plan);
       return NRPHY_ERR_DEVICE;
     }
-    plan->d_scr = (uint32_t*)scratch;
+    plan->d_scr    = (uint32_t*)scratch;
+    plan->d_tb_crc = plan->d_scr + scr_alloc;
   }
   // The dynamic LDS of the codeblock launch also serves the DM-RS waves it may carry.
   plan->lds_lin_words = std::max<uint32_t>(plan->lds_lin_words, 64);
@@ -1351,11 +1387,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.graphs         = ctx->d_graphs;
   p.gold           = ctx->d_gold;
   p.x1_words       = ctx->d_x1;
-  // Two TB-CRC accumulators alternate between runs: this run XORs into one, its codeblock kernel clears the other.
-  const size_t   n_acc = std::max<size_t>(1, plan->pdus.size());
-  p.tb_crc             = plan->d_tb_crc + (plan->epoch & 1U) * n_acc;
-  p.tb_crc_next        = plan->d_tb_crc + ((plan->epoch + 1U) & 1U) * n_acc;
-  plan->epoch++;
+  p.tb_crc_part        = plan->d_tb_crc;
   const bool merge_dmrs = d_grid != nullptr && !plan->dmrs_separate;
   p.zero_work          = plan->d_zero_work;
   p.zero_segs          = plan->d_zero_segs;
@@ -1466,7 +1498,7 @@ extern "C" int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_
   const size_t tb_alloc   = ((size_t)pdu->tb_size_bytes + 7) & ~(size_t)3;
   const size_t grid_bytes = (size_t)grid_nof_ports * NRPHY_NSYMB * grid_nof_subc * 4;
   const size_t cw_bytes   = (size_t)(plan->cw_bits / 8);
-  std::lock_guard<std::mutex> lock(ctx->host_mutex);
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
   uint8_t* d_tb   = (uint8_t*)ctx_scratch(ctx, SCRATCH_TB, tb_alloc);
   uint8_t* d_grid = grid ? (uint8_t*)ctx_scratch(ctx, SCRATCH_GRID, grid_bytes) : nullptr;
   uint8_t* d_rm   = cw_rm ? (uint8_t*)ctx_scratch(ctx, SCRATCH_CW_RM, cw_bytes) : nullptr;
@@ -1548,7 +1580,7 @@ extern "C" int nrphy_pdsch_encode_host(nrphy_ctx_t* ctx, const nrphy_pdsch_encod
     packed = packed_local.data();
   }
   {
-    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
     uint8_t* d_tb = (uint8_t*)ctx_scratch(ctx, SCRATCH_TB, tb_alloc);
     uint8_t* d_rm = (uint8_t*)ctx_scratch(ctx, SCRATCH_CW_RM, cw_bytes);
     rc            = NRPHY_ERR_DEVICE;
@@ -1671,20 +1703,20 @@ int rate_dematch_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* 
   build_dematch_ops(ops, block_length, buffer_length, k0, nof_systematic, cfg->nof_filler_bits, cfg->rm_length,
                     new_data != 0);
   HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t   s = stream ? (hipStream_t)stream : ctx->stream;
+  StreamStaging staging(s);
   p.n_ops   = (uint32_t)ops.size();
   p.ops_ext = nullptr;
   if (ops.size() <= MAX_DEMATCH_OPS) {
     std::copy(ops.begin(), ops.end(), p.ops);
   } else {
-    // Heavy repetition (rm_length of dozens of buffer lengths): the list goes through device memory.  This path
-    // copies synchronously and waits for earlier launches that may still read the previous list.
-    std::lock_guard<std::mutex> lock(ctx->host_mutex);
-    HIP_TRY(hipDeviceSynchronize());
-    DematchOp* d_ops = (DematchOp*)ctx_scratch(ctx, SCRATCH_DEMATCH_OPS, ops.size() * sizeof(DematchOp));
+    // Heavy repetition (rm_length of dozens of buffer lengths): the list goes through device memory of this call's
+    // own, allocated, filled and released in stream order.
+    DematchOp* d_ops = (DematchOp*)staging.alloc(ops.size() * sizeof(DematchOp));
     if (d_ops == nullptr) {
       return NRPHY_ERR_DEVICE;
     }
-    HIP_TRY(hipMemcpy(d_ops, ops.data(), ops.size() * sizeof(DematchOp), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(d_ops, ops.data(), ops.size() * sizeof(DematchOp), hipMemcpyHostToDevice, s));
     p.ops_ext = d_ops;
   }
   p.in           = d_in;
@@ -1699,7 +1731,7 @@ int rate_dematch_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* 
   if (in_outer > 0xFFFFFFFFULL || soft_outer > 0xFFFFFFFFULL) {
     return NRPHY_ERR_CAPACITY;
   }
-  HIP_TRY(launch_ldpc_dematch(p, n_cb, stream ? (hipStream_t)stream : ctx->stream, n_outer));
+  HIP_TRY(launch_ldpc_dematch(p, n_cb, s, n_outer));
   return NRPHY_OK;
 }
 
@@ -1708,8 +1740,10 @@ int rate_dematch_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* 
 extern "C" int nrphy_ldpc_rate_dematch_host(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* cfg,
                                             const int8_t* in, int8_t* soft_buffer, int new_data)
 {
+  // Everything that sizes a copy below is checked here, before the validating device-pointer call runs.
   if (ctx == nullptr || cfg == nullptr || in == nullptr || soft_buffer == nullptr ||
-      (cfg->base_graph != 1 && cfg->base_graph != 2)) {
+      (cfg->base_graph != 1 && cfg->base_graph != 2) || lifting_position(cfg->lifting_size) < 0 || cfg->rm_length == 0 ||
+      cfg->rm_length > 35 * 8448) {
     return NRPHY_ERR_ARGUMENT;
   }
   const unsigned block_length = ((cfg->base_graph == 1) ? 66U : 50U) * cfg->lifting_size;
@@ -1896,7 +1930,7 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
   HIP_TRY(hipSetDevice(ctx->device));
   LdpcDecodeLaunch p;
   {
-    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
     p.graph = get_decoder_graph(ctx, cfg->base_graph, zc);
   }
   if (p.graph == nullptr) {
@@ -1923,7 +1957,7 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
   p.crc_weight     = nullptr;
   {
     // Check records: context-owned, grow-only (a first call with a larger batch allocates; not stream-ordered).
-    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
     p.scratch = (uint2*)ctx_scratch(ctx, SCRATCH_DECODER, (size_t)n_cb * p.nof_layers_max * zc * sizeof(uint2));
     if (p.crc_order != 0) {
       p.crc_weight = get_decoder_crc_weights(ctx, p.crc_poly, p.crc_order, K - cfg->nof_filler_bits);
@@ -1941,7 +1975,9 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
 extern "C" int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, const int8_t* llr,
                                       uint8_t* message_packed, uint32_t* iterations)
 {
-  if (ctx == nullptr || cfg == nullptr || llr == nullptr || message_packed == nullptr) {
+  if (ctx == nullptr || cfg == nullptr || llr == nullptr || message_packed == nullptr ||
+      (cfg->base_graph != 1 && cfg->base_graph != 2) || lifting_position(cfg->lifting_size) < 0 ||
+      cfg->nof_llr > 66U * cfg->lifting_size) {
     return NRPHY_ERR_ARGUMENT;
   }
   const unsigned K     = ((cfg->base_graph == 1) ? 22U : 10U) * cfg->lifting_size;
@@ -1991,11 +2027,11 @@ extern "C" int nrphy_pusch_decode_codeblock_host(nrphy_ctx_t* ctx, const nrphy_l
   const unsigned k = ((dm->base_graph == 1) ? 22U : 10U) * zc, kbytes = (k + 7) / 8;
   const size_t   off_soft = ((size_t)dm->rm_length + 63) & ~(size_t)63, off_out = off_soft + (((size_t)n + 63) & ~(size_t)63);
   const size_t   off_it = off_out + (((size_t)kbytes + 63) & ~(size_t)63);
-  std::lock_guard<std::mutex> host_lock(ctx->host_call_mutex);
+  std::lock_guard<std::recursive_mutex> host_lock(ctx->host_mutex);
   HIP_TRY(hipSetDevice(ctx->device));
   uint8_t* base = nullptr;
   {
-    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
     base = (uint8_t*)ctx_scratch(ctx, SCRATCH_RX, off_it + 64);
   }
   if (base == nullptr) {
@@ -2161,7 +2197,7 @@ extern "C" int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_deco
   a.crc_weight = nullptr;
   if (C > 1) {
     // weights of the assembly kernel's per-thread CRC pieces (pusch_decoder.hip): fixed by the block size
-    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
     auto                        it = ctx->d_tb_crc_w.find(cfg->tb_size_bytes);
     if (it == ctx->d_tb_crc_w.end()) {
       const uint32_t        piece = divide_ceil(cfg->tb_size_bytes, PUSCH_ASSEMBLE_THREADS);
@@ -2307,14 +2343,10 @@ extern "C" int nrphy_csi_rs_map(nrphy_ctx_t* ctx, uint32_t n, const nrphy_csi_rs
   }
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  // Work list and weights go through a context buffer: the copy is ordered on the stream, an earlier launch on another
-  // stream that still reads the buffer is the caller's to order (as for plans).
-  const size_t work_bytes = work.size() * sizeof(CsiRsWork), off_w = (work_bytes + 63) & ~(size_t)63;
-  uint8_t*     base       = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(ctx->host_mutex);
-    base = (uint8_t*)ctx_scratch(ctx, SCRATCH_CSI, off_w + weights.size() * sizeof(float));
-  }
+  // Work list and weights go through a buffer of this call's own (stream-ordered allocation).
+  const size_t  work_bytes = work.size() * sizeof(CsiRsWork), off_w = (work_bytes + 63) & ~(size_t)63;
+  StreamStaging staging(s);
+  uint8_t*      base = (uint8_t*)staging.alloc(off_w + weights.size() * sizeof(float));
   if (base == nullptr) {
     return NRPHY_ERR_DEVICE;
   }
@@ -2339,12 +2371,12 @@ extern "C" int nrphy_csi_rs_map_host(nrphy_ctx_t* ctx, const nrphy_csi_rs_cfg_t*
   if (ctx == nullptr || cfg == nullptr || grid == nullptr) {
     return NRPHY_ERR_ARGUMENT;
   }
-  std::lock_guard<std::mutex> host_lock(ctx->host_call_mutex);
+  std::lock_guard<std::recursive_mutex> host_lock(ctx->host_mutex);
   const size_t bytes  = (size_t)nof_ports * NRPHY_NSYMB * nof_subc * 4;
   void*        d_grid = nullptr;
   HIP_TRY(hipSetDevice(ctx->device));
   {
-    std::lock_guard<std::mutex> lock(ctx->host_mutex);
+    std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
     d_grid = ctx_scratch(ctx, SCRATCH_GRID, bytes);
   }
   if (d_grid == nullptr) {
@@ -2381,11 +2413,8 @@ extern "C" int nrphy_grid_put(nrphy_ctx_t* ctx, void* d_grid, uint32_t nof_ports
   }
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s    = stream ? (hipStream_t)stream : ctx->stream;
-  uint32_t*   base = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(ctx->host_mutex);
-    base = (uint32_t*)ctx_scratch(ctx, SCRATCH_PUT, packed.size() * sizeof(uint32_t));
-  }
+  StreamStaging staging(s);
+  uint32_t*     base = (uint32_t*)staging.alloc(packed.size() * sizeof(uint32_t));
   if (base == nullptr) {
     return NRPHY_ERR_DEVICE;
   }
@@ -2589,7 +2618,7 @@ extern "C" int nrphy_ofdm_demodulate_slot_host(nrphy_ofdm_plan_t* plan, const fl
     return NRPHY_ERR_ARGUMENT;
   }
   nrphy_ctx*   ctx        = plan->ctx;
-  std::lock_guard<std::mutex> lock(ctx->host_mutex);
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
   const size_t grid_words = (size_t)plan->nof_ports * NRPHY_NSYMB * 12 * plan->cfg.bw_rb;
   const size_t slot_size  = nrphy_ofdm_slot_size(&plan->cfg, slot_index);
   uint32_t *   d_grid = nullptr, *d_slot = nullptr;
@@ -2634,7 +2663,7 @@ extern "C" int nrphy_ofdm_demodulate_symbol_host(nrphy_ofdm_plan_t* plan, const 
   // One symbol of one port: the samples are placed where the slot kernel expects them (the other symbols of the
   // staging slot transform zeros), the symbol's row is read back.
   nrphy_ctx*     ctx  = plan->ctx;
-  std::lock_guard<std::mutex> lock(ctx->host_mutex);
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
   const uint32_t rg   = 12 * plan->cfg.bw_rb;
   const uint32_t slot = symbol_index / plan->nsymb, l = symbol_index % plan->nsymb;
   const size_t   iq_samples = (size_t)plan->nof_ports * plan->slot_stride;
@@ -2712,7 +2741,7 @@ extern "C" int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const vo
     return NRPHY_ERR_ARGUMENT;
   }
   nrphy_ctx*   ctx        = plan->ctx;
-  std::lock_guard<std::mutex> lock(ctx->host_mutex);
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
   const size_t grid_words = (size_t)plan->nof_ports * NRPHY_NSYMB * 12 * plan->cfg.bw_rb;
   const size_t iq_samples = (size_t)plan->nof_ports * plan->slot_stride;
   uint32_t *   d_grid = nullptr, *d_slot = nullptr;
@@ -2795,7 +2824,7 @@ extern "C" int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void
     return NRPHY_ERR_ARGUMENT;
   }
   nrphy_ctx*     ctx        = plan->ctx;
-  std::lock_guard<std::mutex> lock(ctx->host_mutex);
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
   const size_t   grid_words = (size_t)plan->nof_ports * NRPHY_NSYMB * 12 * plan->cfg.bw_rb;
   const size_t   iq_samples = (size_t)plan->nof_ports * plan->slot_stride;
   const uint32_t slot_size  = nrphy_ofdm_slot_size(&plan->cfg, slot_index);

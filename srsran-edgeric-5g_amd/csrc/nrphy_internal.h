@@ -107,6 +107,8 @@ struct PduDev {
   uint32_t prb_mask[2 * NRPHY_PRB_WORDS];
   uint32_t first_prb;
   uint32_t end_prb;
+  uint32_t crc_first;       // the PDU's transport-block CRC shares: tb_crc_part[crc_first .. crc_first + crc_count)
+  uint32_t crc_count;
 };
 
 // One wavefront of the codeblock kernel: RE [re_begin, re_begin + re_count) of codeblock cb of PDU pdu.
@@ -183,7 +185,6 @@ struct PdschLaunch {
   const ZeroSeg*     zero_segs;
   uint32_t           n_zero_work;     // zero-fill waves appended to the codeblock launch (0: caller cleared the grids)
   uint32_t           n_dmrs_in_launch; // DM-RS waves appended to the codeblock launch (0: separate launch)
-  uint32_t*          tb_crc_next;     // the other TB-CRC accumulator, cleared for the next run
   uint32_t*          scr;             // scrambling sequences c(n) of every PDU, MSB-first words (prologue -> codeblocks)
   const PduDev*      pdus;
   const CbWork*      work;
@@ -198,7 +199,7 @@ struct PdschLaunch {
   const LiftedGraph* graphs;
   const GoldTables*  gold;
   const uint32_t*    x1_words;
-  uint32_t*          tb_crc; // [n_pdu]
+  uint32_t*          tb_crc_part; // [n_crc_work] share of every 16 KiB region in its PDU's CRC, rewritten by every run
   uint32_t           n_pdu;
   uint32_t           n_work;
   uint32_t           n_dmrs_work;

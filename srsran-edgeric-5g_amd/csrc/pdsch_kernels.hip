@@ -124,8 +124,9 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
     r = crc_mulmod32(p.tbcrc->lane[sel][tid], r, c);
     r = wave_xor(r);
     if (tid == 0) {
-      // The accumulator was cleared by the previous run (or at plan creation).
-      atomicXor(&p.tb_crc[wk_pdu], crc_mulmod(r, wk_factor, c));
+      // The region's share of the PDU's CRC in a slot of its own: the codeblock wave that attaches the CRC adds the
+      // shares up, so a run neither relies on nor leaves behind any accumulator state.
+      p.tb_crc_part[blockIdx.x - p.n_scr_work] = crc_mulmod(r, wk_factor, c);
     }
   }
 }
@@ -162,7 +163,7 @@ struct CbShared {
 
 // Fills lin with the K bits of codeblock `cb` (payload, TB CRC + zero padding on the last codeblock, CB CRC, filler
 // zeros) and zeroes the parity region up to `total_words`.
-__device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* tbw, const uint32_t* tb_crc_ptr,
+__device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* tbw, const uint32_t* tb_crc_part,
                                        const GoldTables* tables, CbShared* sh, uint32_t total_words, uint32_t lane,
                                        uint32_t profile_stage)
 {
@@ -196,8 +197,11 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
   if (profile_stage == 7) {
     return;
   }
-  if (last && lane == 0) {
-    or_bits_lds(sh->lin, used, *tb_crc_ptr << (32u - pd.tb_crc_bits), pd.tb_crc_bits);
+  if (last) { // wave-uniform: the transport-block CRC = XOR of the shares of its regions (prologue)
+    const uint32_t tb_crc = wave_xor(lane < pd.crc_count ? tb_crc_part[pd.crc_first + lane] : 0u);
+    if (lane == 0) {
+      or_bits_lds(sh->lin, used, tb_crc << (32u - pd.tb_crc_bits), pd.tb_crc_bits);
+    }
   }
   wave_sync();
   if (pd.cb_crc_bits) {
@@ -741,10 +745,6 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
     }
     return;
   }
-  // Clear the other TB-CRC accumulator for the next run (this run reads p.tb_crc only).
-  if (blockIdx.x * WAVE < p.n_pdu && blockIdx.x * WAVE + lane < p.n_pdu) {
-    p.tb_crc_next[blockIdx.x * WAVE + lane] = 0u;
-  }
   // Workgroups go to the eight XCDs round-robin (block b runs on XCD b % 8).  Give each XCD a contiguous run of work
   // items, so that codeblocks which share cache lines -- neighbours in the transport block and in the grid rows --
   // meet in one L2 instead of leaving partial lines in two.
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
     return;
   }
   const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
-  build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), &p.tb_crc[wk.pdu], p.gold, &sh,
+  build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), p.tb_crc_part, p.gold, &sh,
                   total_words, lane, p.profile_stage);
 
   if (p.profile_stage == 1) {

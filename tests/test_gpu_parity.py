@@ -518,6 +518,48 @@ def test_host_span_calls_from_several_threads(gpu_ctx, oracle):
     assert not errors
 
 
+def test_mixed_host_span_calls_from_several_threads(gpu_ctx, oracle):
+    """The downlink processor of the reference dispatches PDSCH, NZP-CSI-RS and the lower PHY's modulator from different
+    threads; their adaptors share one context, whose staging buffers (one grid buffer among them) they all use."""
+    import threading
+    rng = np.random.default_rng(4242)
+    pdu, nof_ports, nof_subc, ocfg = cases.baseline_config(2)
+    tb = cases.random_tb(rng, pdu)
+    want_pdsch = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc)
+    name, ccfg, c_ports, c_subc = next(iter(cases.csi_rs_cases(rng)))
+    cgrid = (rng.standard_normal((c_ports, 14, c_subc, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    want_csi = oracle.csi_rs_map(ccfg, cgrid)
+    oplan = lib.OfdmPlan(gpu_ctx, ocfg, nof_ports)
+    n = lib.slot_size(ocfg, 0)
+    want_iq = oracle.ofdm_slot(ocfg, want_pdsch, 0)
+    errors = []
+
+    def pdsch():
+        for _ in range(8):
+            if not np.array_equal(gpu_ctx.pdsch_process_host(pdu, tb, nof_ports, nof_subc), want_pdsch):
+                errors.append("pdsch")
+
+    def csi():
+        for _ in range(8):
+            if not np.array_equal(gpu_ctx.csi_rs_map_host(ccfg, cgrid), want_csi):
+                errors.append("csi-rs")
+
+    def ofdm():
+        for _ in range(8):
+            iq = np.zeros((nof_ports, n), np.complex64)
+            rc = gpu_ctx.lib.nrphy_ofdm_modulate_slot_host(oplan.handle, want_pdsch.ctypes.data, 0, iq.ctypes.data)
+            if rc != 0 or rel_err(iq, want_iq) > 1e-5:
+                errors.append("ofdm")
+
+    threads = [threading.Thread(target=f) for f in (pdsch, csi, ofdm, pdsch, csi, ofdm)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    oplan.close()
+    assert not errors, sorted(set(errors))
+
+
 def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
     """The host-span entry points the srsRAN adaptors call (dft_processor::run, ofdm_slot_modulator::modulate)."""
     rng = np.random.default_rng(77)
@@ -763,8 +805,7 @@ def test_pusch_decode_codeblock_host_harq(gpu_ctx, oracle):
 
 def test_device_entry_points_in_a_hip_graph(gpu_ctx, oracle):
     """nrphy_pdsch_run / nrphy_ofdm_run neither allocate nor synchronise, so a step can be captured in a hipGraph and
-    replayed on new transport blocks.  The plan alternates two TB-CRC accumulators from run to run, so a graph holds an
-    even number of runs of a plan (two here)."""
+    replayed on new transport blocks (two runs of the plan per graph here)."""
     import torch
     pdu, nof_ports, nof_subc, ocfg = cases.baseline_config(2)
     slots = 3
@@ -811,6 +852,40 @@ def test_device_entry_points_in_a_hip_graph(gpu_ctx, oracle):
                 assert rel_err(iq[:, : want.shape[1]], want) < 1e-5
     plan.close()
     oplan.close()
+
+
+def test_single_run_graph_replay_and_eager_interleaved(gpu_ctx, oracle):
+    """Every run of a plan is self-contained (no TB-CRC state is carried between runs): a graph holding ONE run -- the
+    natural step -- replays correctly any number of times, also with eager runs of the same plan in between."""
+    import torch
+    pdu, nof_ports, nof_subc, _ = cases.baseline_config(2)
+    tb_bytes = (pdu.tb_size_bytes + 3) & ~3
+    plan = lib.PdschPlan(gpu_ctx, [pdu], [0], [0], 1, nof_ports, nof_subc)
+    d_tb = torch.zeros(tb_bytes, dtype=torch.uint8, device="cuda")
+    d_grid = torch.zeros((1, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.run(d_tb, d_grid, zero_grids=True, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        plan.run(d_tb, d_grid, zero_grids=True, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(77)
+    for k in range(5):
+        tb = cases.random_tb(rng, pdu)
+        h = np.zeros(tb_bytes, np.uint8)
+        h[: tb.size] = tb
+        d_tb.copy_(torch.from_numpy(h))
+        if k == 3:  # an eager run between two replays
+            with torch.cuda.stream(s):
+                plan.run(d_tb, d_grid, zero_grids=True, stream=s.cuda_stream)
+            torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        grid = d_grid[0].cpu().numpy().view(np.uint16).reshape(nof_ports, 14, nof_subc, 2)
+        assert np.array_equal(grid, oracle.pdsch_process(pdu, tb, nof_ports, nof_subc)), k
+    plan.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
