@@ -466,9 +466,11 @@ int nrphy_ofdm_demodulate_symbol_host(nrphy_ofdm_plan_t* plan, const float* inpu
 
 /* dft_processor::run (R/include/srsran/phy/generic_functions/dft_processor.h:34-73; generic impl
  * dft_processor_generic_impl.cpp:14-218).  Unnormalised DFT of `size` complex floats, `batch` of them
- * back to back.  inverse != 0 uses exp(+j...).  Sizes: 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072,
- * 4096 (the reference's generic implementation also has 4608, 6144 and larger ones, used by PRACH and
- * wider carriers: later rounds). */
+ * back to back.  inverse != 0 uses exp(+j...).  Sizes: every size of the reference's generic implementation
+ * (dft_processor_generic_impl.cpp:190-208) -- 128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 4608, 6144
+ * (one workgroup per transform, in LDS; these are also the sizes nrphy_ofdm_plan_create accepts) and 9216, 12288,
+ * 18432, 24576, 36864, 49152 (the PRACH sizes: a radix-3/6/12 column pass through a scratch copy of the batch,
+ * allocated and released in stream order by the call, then LDS transforms of 3072 or 4096 points). */
 int nrphy_dft_run(nrphy_ctx_t* ctx, uint32_t size, int inverse, uint32_t batch, const float* d_in, float* d_out,
                   void* stream);
 /* Host-span form of dft_processor::run for one transform (blocking). */

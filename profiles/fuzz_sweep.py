@@ -106,7 +106,7 @@ def ofdm():
     rng = np.random.default_rng(8088)
     bad = 0
     for t in range(100):
-        n = int(rng.choice([128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]))
+        n = int(rng.choice([128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 4608, 6144]))
         mu, ext = int(rng.integers(0, 5)), int(rng.integers(0, 4) == 0)
         bw, ports = int(rng.integers(1, min(275, (n - 1) // 12) + 1)), int(rng.integers(1, 5))
         cfg = abi.OfdmConfig(mu, bw, n, ext, float(rng.uniform(0.01, 2.0)), float(rng.choice([0.0, 7e8, 2.4e9, 3.5e9, 28e9, 39e9])))

@@ -373,7 +373,7 @@ struct nrphy_ctx {
   GoldTables*  d_gold   = nullptr;
   TbCrcTables* d_tbcrc  = nullptr;
   uint32_t*    d_x1     = nullptr;
-  float2*      d_twiddle[10] = {}; // one table per supported DFT size (twiddle_slot)
+  std::map<uint32_t, float2*> d_twiddle; // exp(+j 2 pi k / N) per DFT size, built on first use (under host_mutex)
   DecoderGraph* d_dec_graph[NOF_GRAPHS] = {}; // decoder graphs, built on first use
   std::map<uint64_t, uint32_t*> d_dec_crc;     // early-stop CRC weights per (polynomial, message length)
   std::map<uint32_t, uint32_t*> d_tb_crc_w;    // transport-block CRC weights of the PUSCH assembly kernel per block size
@@ -821,8 +821,8 @@ extern "C" int nrphy_destroy(nrphy_ctx_t* ctx)
     (void)hipFree(kv.second);
   }
   (void)hipFree(ctx->d_x1);
-  for (float2* t : ctx->d_twiddle) {
-    (void)hipFree(t);
+  for (auto& kv : ctx->d_twiddle) {
+    (void)hipFree(kv.second);
   }
   if (ctx->stream) {
     (void)hipStreamDestroy(ctx->stream);
@@ -842,52 +842,28 @@ extern "C" int nrphy_synchronize(nrphy_ctx_t* ctx, void* stream)
 
 namespace {
 
-int twiddle_slot(uint32_t size)
-{
-  switch (size) {
-    case 128:
-      return 0;
-    case 256:
-      return 1;
-    case 512:
-      return 2;
-    case 1024:
-      return 3;
-    case 2048:
-      return 4;
-    case 4096:
-      return 5;
-    case 384:
-      return 6;
-    case 768:
-      return 7;
-    case 1536:
-      return 8;
-    case 3072:
-      return 9;
-    default:
-      return -1;
-  }
-}
-
 // exp(+j 2 pi k / N) computed in double precision and rounded once.
 const float2* get_twiddle(nrphy_ctx* ctx, uint32_t size)
 {
-  int slot = twiddle_slot(size);
-  if (slot < 0) {
+  if (!dft_size_supported(size)) {
     return nullptr;
   }
-  if (ctx->d_twiddle[slot] == nullptr) {
-    std::vector<float2> tw(size);
-    for (uint32_t k = 0; k != size; ++k) {
-      double ang = 2.0 * M_PI * (double)k / (double)size;
-      tw[k]      = make_float2((float)std::cos(ang), (float)std::sin(ang));
-    }
-    if (upload(&ctx->d_twiddle[slot], tw.data(), tw.size() * sizeof(float2)) != hipSuccess) {
-      return nullptr;
-    }
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
+  auto it = ctx->d_twiddle.find(size);
+  if (it != ctx->d_twiddle.end()) {
+    return it->second;
   }
-  return ctx->d_twiddle[slot];
+  std::vector<float2> tw(size);
+  for (uint32_t k = 0; k != size; ++k) {
+    double ang = 2.0 * M_PI * (double)k / (double)size;
+    tw[k]      = make_float2((float)std::cos(ang), (float)std::sin(ang));
+  }
+  float2* d = nullptr;
+  if (upload(&d, tw.data(), tw.size() * sizeof(float2)) != hipSuccess) {
+    return nullptr;
+  }
+  ctx->d_twiddle[size] = d;
+  return d;
 }
 
 } // namespace
@@ -2449,7 +2425,7 @@ extern "C" int nrphy_ofdm_plan_create(nrphy_ctx_t* ctx, const nrphy_ofdm_config_
                                       nrphy_ofdm_plan_t** out)
 {
   if (ctx == nullptr || cfg == nullptr || out == nullptr || nof_ports == 0 || cfg->numerology > 4 ||
-      !dft_size_supported(cfg->dft_size) || cfg->dft_size <= 12 * cfg->bw_rb || cfg->bw_rb == 0 || cfg->cp > 1 ||
+      !dft_size_in_lds(cfg->dft_size) || cfg->dft_size <= 12 * cfg->bw_rb || cfg->bw_rb == 0 || cfg->cp > 1 ||
       !std::isnormal(cfg->scale)) {
     return NRPHY_ERR_ARGUMENT;
   }
@@ -2779,12 +2755,25 @@ extern "C" int nrphy_dft_run(nrphy_ctx_t* ctx, uint32_t size, int inverse, uint3
   if (ctx == nullptr || d_in == nullptr || d_out == nullptr || !dft_size_supported(size)) {
     return NRPHY_ERR_ARGUMENT;
   }
-  const float2* tw = get_twiddle(ctx, size);
-  if (tw == nullptr) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t   s  = stream ? (hipStream_t)stream : ctx->stream;
+  uint32_t      n1 = 1, n2 = size;
+  dft_split(size, &n1, &n2);
+  const float2* tw    = get_twiddle(ctx, size);
+  const float2* tw_n2 = (n1 == 1) ? tw : get_twiddle(ctx, n2);
+  if (tw == nullptr || tw_n2 == nullptr) {
     return NRPHY_ERR_DEVICE;
   }
-  HIP_TRY(launch_dft(size, inverse, batch, tw, (const float2*)d_in, (float2*)d_out,
-                     stream ? (hipStream_t)stream : ctx->stream));
+  // The sizes beyond 6144 take two passes through a scratch copy of the batch (stream-ordered allocation).
+  StreamStaging staging(s);
+  float2*       d_tmp = nullptr;
+  if (n1 != 1 && batch != 0) {
+    d_tmp = (float2*)staging.alloc((size_t)batch * size * sizeof(float2));
+    if (d_tmp == nullptr) {
+      return NRPHY_ERR_DEVICE;
+    }
+  }
+  HIP_TRY(launch_dft(size, inverse, batch, tw, tw_n2, d_tmp, (const float2*)d_in, (float2*)d_out, s));
   return NRPHY_OK;
 }
 

@@ -323,8 +323,17 @@ hipError_t launch_ofdm(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* 
 // window_offset = nof_samples_window_offset of the reference's demodulator configuration.
 hipError_t launch_ofdm_demod(const OfdmLaunch& p, uint32_t nof_grids, const float2* d_iq, const uint32_t* d_slot_index,
                              uint32_t window_offset, uint32_t* d_grid, hipStream_t stream);
-hipError_t launch_dft(uint32_t size, int inverse, uint32_t batch, const float2* twiddle_fwd_inv, const float2* d_in,
-                      float2* d_out, hipStream_t stream);
+// size = n1 * n2: n1 = 1 for the sizes one workgroup transforms in LDS (128 ... 6144, what the OFDM kernels take), else
+// a radix-n1 column pass through global memory in front of n1 LDS transforms of size n2 (9216 ... 49152).
+bool       dft_split(uint32_t size, uint32_t* n1, uint32_t* n2);
 bool       dft_size_supported(uint32_t size);
+inline bool dft_size_in_lds(uint32_t size)
+{
+  uint32_t n1 = 0, n2 = 0;
+  return dft_split(size, &n1, &n2) && n1 == 1;
+}
+// twiddle: exp(+j 2 pi k / size); split sizes also need the table of n2 and `batch` transforms of scratch.
+hipError_t launch_dft(uint32_t size, int inverse, uint32_t batch, const float2* twiddle, const float2* twiddle_n2,
+                      float2* d_tmp, const float2* d_in, float2* d_out, hipStream_t stream);
 
 } // namespace nrphy

@@ -259,27 +259,35 @@ template <int R>
 __device__ __forceinline__ void apply_twiddle_powers(cf b, cf (&a)[R])
 {
   a[1] = cmul(a[1], b);
-  if (R > 2) {
+  if constexpr (R > 2) {
     const cf b2 = cmul(b, b);
     a[2]        = cmul(a[2], b2);
-    a[3]        = cmul(a[3], cmul(b2, b));
-    if (R > 4) {
+    if constexpr (R > 3) {
+      a[3] = cmul(a[3], cmul(b2, b));
+    }
+    if constexpr (R > 4) {
       const cf b4 = cmul(b2, b2);
       a[4]        = cmul(a[4], b4);
-      a[5]        = cmul(a[5], cmul(b4, b));
-      a[6]        = cmul(a[6], cmul(b4, b2));
-      a[7]        = cmul(a[7], cmul(b4, cmul(b2, b)));
-      if (R > 8) {
+      if constexpr (R > 5) {
+        a[5] = cmul(a[5], cmul(b4, b));
+      }
+      if constexpr (R > 6) {
+        a[6] = cmul(a[6], cmul(b4, b2));
+        a[7] = cmul(a[7], cmul(b4, cmul(b2, b)));
+      }
+      if constexpr (R > 8) {
         const cf b8 = cmul(b4, b4);
         a[8]        = cmul(a[8], b8);
         a[9]        = cmul(a[9], cmul(b8, b));
         a[10]       = cmul(a[10], cmul(b8, b2));
         a[11]       = cmul(a[11], cmul(b8, cmul(b2, b)));
-        const cf b12 = cmul(b8, b4);
-        a[12]        = cmul(a[12], b12);
-        a[13]        = cmul(a[13], cmul(b12, b));
-        a[14]        = cmul(a[14], cmul(b12, b2));
-        a[15]        = cmul(a[15], cmul(b12, cmul(b2, b)));
+        if constexpr (R > 12) {
+          const cf b12 = cmul(b8, b4);
+          a[12]        = cmul(a[12], b12);
+          a[13]        = cmul(a[13], cmul(b12, b));
+          a[14]        = cmul(a[14], cmul(b12, b2));
+          a[15]        = cmul(a[15], cmul(b12, cmul(b2, b)));
+        }
       }
     }
   }
@@ -291,20 +299,29 @@ __device__ __forceinline__ uint32_t pad(uint32_t i)
   return i + (i >> 4);
 }
 
-// Radix plans: N = R0 * R1 * R2 (R2 = 1 when two stages suffice), T = threads per transform = N / 16.
+// Radix plans: N = R0 * R1 * R2 * R3 (R2 = 1 when two stages suffice, R3 = 1 when three do), T = threads per
+// transform = N / 16.
+struct ThreeStages {
+  static constexpr int R3 = 1;
+};
 template <int N>
 struct Plan;
-template <> struct Plan<4096> { static constexpr int R0 = 16, R1 = 16, R2 = 16, T = 256; };
-template <> struct Plan<2048> { static constexpr int R0 = 16, R1 = 16, R2 = 8, T = 128; };
-template <> struct Plan<1024> { static constexpr int R0 = 16, R1 = 16, R2 = 4, T = 64; };
-template <> struct Plan<512>  { static constexpr int R0 = 16, R1 = 16, R2 = 2, T = 64; };
-template <> struct Plan<256>  { static constexpr int R0 = 16, R1 = 16, R2 = 1, T = 64; };
-template <> struct Plan<128>  { static constexpr int R0 = 16, R1 = 8, R2 = 1, T = 64; };
+template <> struct Plan<4096> : ThreeStages { static constexpr int R0 = 16, R1 = 16, R2 = 16, T = 256; };
+template <> struct Plan<2048> : ThreeStages { static constexpr int R0 = 16, R1 = 16, R2 = 8, T = 128; };
+template <> struct Plan<1024> : ThreeStages { static constexpr int R0 = 16, R1 = 16, R2 = 4, T = 64; };
+template <> struct Plan<512>  : ThreeStages { static constexpr int R0 = 16, R1 = 16, R2 = 2, T = 64; };
+template <> struct Plan<256>  : ThreeStages { static constexpr int R0 = 16, R1 = 16, R2 = 1, T = 64; };
+template <> struct Plan<128>  : ThreeStages { static constexpr int R0 = 16, R1 = 8, R2 = 1, T = 64; };
 // 3 * 2^k (the 23.04 MHz family of sampling rates): the factor 3 (x 1, 2, 4) is the last, twiddle-free stage.
-template <> struct Plan<3072> { static constexpr int R0 = 16, R1 = 16, R2 = 12, T = 256; };
-template <> struct Plan<1536> { static constexpr int R0 = 16, R1 = 16, R2 = 6, T = 128; };
-template <> struct Plan<768>  { static constexpr int R0 = 16, R1 = 16, R2 = 3, T = 64; };
-template <> struct Plan<384>  { static constexpr int R0 = 16, R1 = 8, R2 = 3, T = 64; };
+template <> struct Plan<3072> : ThreeStages { static constexpr int R0 = 16, R1 = 16, R2 = 12, T = 256; };
+template <> struct Plan<1536> : ThreeStages { static constexpr int R0 = 16, R1 = 16, R2 = 6, T = 128; };
+template <> struct Plan<768>  : ThreeStages { static constexpr int R0 = 16, R1 = 16, R2 = 3, T = 64; };
+template <> struct Plan<384>  : ThreeStages { static constexpr int R0 = 16, R1 = 8, R2 = 3, T = 64; };
+// 6144 = 3 * 2^11 and 4608 = 9 * 2^9 (the next sizes of the reference's generic DFT, dft_processor_generic_impl.cpp:201-202;
+// 6144 is the 15 kHz transform of a 92.16 MHz sampling rate): four stages, still one transform per workgroup in LDS
+// (52 KB / 39 KB); the last, twiddle-free stage is the radix 3.
+template <> struct Plan<6144> { static constexpr int R0 = 16, R1 = 16, R2 = 8, R3 = 3, T = 384; };
+template <> struct Plan<4608> { static constexpr int R0 = 16, R1 = 16, R2 = 6, R3 = 3, T = 288; };
 
 // Input index k-th element of the first-stage butterfly of thread `tid`: x[tid + k * N / R0].
 template <int N>
@@ -316,7 +333,7 @@ __device__ __forceinline__ uint32_t first_stage_index(uint32_t tid, int k)
 // Twiddle bases of a thread: stage s multiplies output j of its butterfly by (w_n^p)^j with w_n^p = tw[p * S].
 template <int N>
 struct TwiddleBase {
-  cf b0, b1; // first and second stage (the last stage of a plan has n1 = 1: no twiddles)
+  cf b0, b1, b2; // first, second and (four-stage plans) third stage; the last stage of a plan has n1 = 1: no twiddles
 };
 
 template <int SIGN, int N>
@@ -331,6 +348,11 @@ __device__ __forceinline__ TwiddleBase<N> load_twiddle_base(const float2* __rest
   const float2 w1 = tw[((tid / P::R0) * P::R0) % N];
   t.b0            = make_cf(w0.x, SIGN < 0 ? -w0.y : w0.y);
   t.b1            = make_cf(w1.x, SIGN < 0 ? -w1.y : w1.y);
+  t.b2            = t.b1;
+  if constexpr (P::R3 != 1) { // stage 2: S = R0 R1
+    const float2 w2 = tw[((tid / (P::R0 * P::R1)) * (P::R0 * P::R1)) % N];
+    t.b2            = make_cf(w2.x, SIGN < 0 ? -w2.y : w2.y);
+  }
   return t;
 }
 
@@ -418,9 +440,13 @@ __device__ __forceinline__ void fft_from_registers(cf (&a)[Plan<N>::R0], const T
   stage_first<SIGN, N>(a, tb.b0, lds, tid);
   if constexpr (P::R2 == 1) {
     stage_lds<SIGN, N, T, P::R1, P::R0, true>(lds, tw, tb.b1, tid, store);
-  } else {
+  } else if constexpr (P::R3 == 1) {
     stage_lds<SIGN, N, T, P::R1, P::R0, false>(lds, tw, tb.b1, tid, no_store);
     stage_lds<SIGN, N, T, P::R2, P::R0 * P::R1, true>(lds, tw, tb.b1, tid, store);
+  } else {
+    stage_lds<SIGN, N, T, P::R1, P::R0, false>(lds, tw, tb.b1, tid, no_store);
+    stage_lds<SIGN, N, T, P::R2, P::R0 * P::R1, false>(lds, tw, tb.b2, tid, no_store);
+    stage_lds<SIGN, N, T, P::R3, P::R0 * P::R1 * P::R2, true>(lds, tw, tb.b2, tid, store);
   }
   __syncthreads(); // the LDS buffer is reused by the next transform of this workgroup
 }
@@ -595,6 +621,10 @@ hipError_t launch_ofdm(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* 
     return hipSuccess;
   }
   switch (p.dft_size) {
+    case 6144:
+      return launch_ofdm_n<6144>(p, nof_grids, d_grid, d_slot_index, d_iq, stream);
+    case 4608:
+      return launch_ofdm_n<4608>(p, nof_grids, d_grid, d_slot_index, d_iq, stream);
     case 4096:
       return launch_ofdm_n<4096>(p, nof_grids, d_grid, d_slot_index, d_iq, stream);
     case 3072:
@@ -695,6 +725,10 @@ hipError_t launch_ofdm_demod(const OfdmLaunch& p, uint32_t nof_grids, const floa
     return hipSuccess;
   }
   switch (p.dft_size) {
+    case 6144:
+      return launch_ofdm_demod_n<6144>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
+    case 4608:
+      return launch_ofdm_demod_n<4608>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
     case 4096:
       return launch_ofdm_demod_n<4096>(p, nof_grids, d_iq, d_slot_index, window_offset, d_grid, stream);
     case 3072:
@@ -721,16 +755,19 @@ hipError_t launch_ofdm_demod(const OfdmLaunch& p, uint32_t nof_grids, const floa
 }
 
 // ================================================================================================================
-// Plain batched DFT (dft_processor): one workgroup per transform.
+// Plain batched DFT (dft_processor): one workgroup per transform.  Output element k of transform t goes to
+// d_out[(t / out_group) * out_group * N + (t % out_group) + k * out_group]: out_group = 1 is the plain layout, the
+// second pass of a large transform interleaves the out_group = N1 sub-transforms of one transform (see below).
 // ================================================================================================================
 template <int SIGN, int N>
 __global__ __launch_bounds__(Plan<N>::T) void dft_kernel(const float2* __restrict__ tw, const float2* __restrict__ d_in,
-                                                         float2* __restrict__ d_out)
+                                                         float2* __restrict__ d_out, uint32_t out_group)
 {
   __shared__ cf     lds[N + N / 16 + 16];
   const uint32_t    tid = threadIdx.x;
+  const uint32_t    big = blockIdx.x / out_group, sub = blockIdx.x - big * out_group;
   const float2*     in  = d_in + (size_t)blockIdx.x * N;
-  float2*           out = d_out + (size_t)blockIdx.x * N;
+  float2*           out = d_out + (size_t)big * out_group * N + sub;
   const TwiddleBase<N> tb = load_twiddle_base<SIGN, N>(tw, tid);
   cf                a[Plan<N>::R0];
 #pragma unroll
@@ -739,58 +776,185 @@ __global__ __launch_bounds__(Plan<N>::T) void dft_kernel(const float2* __restric
     const float2   v = (i < N) ? in[i] : make_float2(0.f, 0.f);
     a[k]             = make_cf(v.x, v.y);
   }
-  auto store = [&](uint32_t q, auto base, auto, cf v) { out[q + decltype(base)::value] = make_float2(v.x, v.y); };
+  auto store = [&](uint32_t q, auto base, auto, cf v) {
+    out[(size_t)(q + decltype(base)::value) * out_group] = make_float2(v.x, v.y);
+  };
   fft_from_registers<SIGN, N>(a, tb, lds, tw, tid, store);
 }
 
 template <int N>
 static hipError_t launch_dft_n(int inverse, uint32_t batch, const float2* tw, const float2* d_in, float2* d_out,
-                               hipStream_t stream)
+                               uint32_t out_group, hipStream_t stream)
 {
   if (inverse) {
-    hipLaunchKernelGGL((dft_kernel<+1, N>), dim3(batch), dim3(Plan<N>::T), 0, stream, tw, d_in, d_out);
+    hipLaunchKernelGGL((dft_kernel<+1, N>), dim3(batch), dim3(Plan<N>::T), 0, stream, tw, d_in, d_out, out_group);
   } else {
-    hipLaunchKernelGGL((dft_kernel<-1, N>), dim3(batch), dim3(Plan<N>::T), 0, stream, tw, d_in, d_out);
+    hipLaunchKernelGGL((dft_kernel<-1, N>), dim3(batch), dim3(Plan<N>::T), 0, stream, tw, d_in, d_out, out_group);
   }
   return hipGetLastError();
 }
 
-bool dft_size_supported(uint32_t size)
+static hipError_t launch_dft_lds(uint32_t size, int inverse, uint32_t batch, const float2* tw, const float2* d_in,
+                                 float2* d_out, uint32_t out_group, hipStream_t stream)
 {
-  return size == 128 || size == 256 || size == 512 || size == 1024 || size == 2048 || size == 4096 || size == 384 ||
-         size == 768 || size == 1536 || size == 3072;
-}
-
-hipError_t launch_dft(uint32_t size, int inverse, uint32_t batch, const float2* tw, const float2* d_in, float2* d_out,
-                      hipStream_t stream)
-{
-  if (batch == 0) {
-    return hipSuccess;
-  }
   switch (size) {
+    case 6144:
+      return launch_dft_n<6144>(inverse, batch, tw, d_in, d_out, out_group, stream);
+    case 4608:
+      return launch_dft_n<4608>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 4096:
-      return launch_dft_n<4096>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<4096>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 3072:
-      return launch_dft_n<3072>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<3072>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 1536:
-      return launch_dft_n<1536>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<1536>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 768:
-      return launch_dft_n<768>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<768>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 384:
-      return launch_dft_n<384>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<384>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 2048:
-      return launch_dft_n<2048>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<2048>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 1024:
-      return launch_dft_n<1024>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<1024>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 512:
-      return launch_dft_n<512>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<512>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 256:
-      return launch_dft_n<256>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<256>(inverse, batch, tw, d_in, d_out, out_group, stream);
     case 128:
-      return launch_dft_n<128>(inverse, batch, tw, d_in, d_out, stream);
+      return launch_dft_n<128>(inverse, batch, tw, d_in, d_out, out_group, stream);
     default:
       return hipErrorInvalidValue;
   }
+}
+
+// ---- transforms that do not fit LDS: 9216 ... 49152 (the PRACH sizes of the reference's generic DFT,
+// dft_processor_generic_impl.cpp:203-208) -----------------------------------------------------------------------------
+// N = N1 * N2 with N1 in {3, 6, 12} and N2 = 3072 or 4096, decimation in time over n = N2 n1 + n2, k = k1 + N1 k2:
+//   X[k1 + N1 k2] = sum_{n2} W_N2^(n2 k2) { W_N^(n2 k1) sum_{n1} x[N2 n1 + n2] W_N1^(n1 k1) }.
+// Pass 1 (this kernel): one thread per n2 takes the N1 inputs N2 apart (coalesced across the wave), runs the radix-N1
+// butterfly in registers, applies W_N^(n2 k1) from the size-N table and writes tmp[k1][n2] (coalesced).  Pass 2: the LDS
+// transform of size N2 over every row of tmp, its output k2 stored at k1 + N1 k2 (dft_kernel with out_group = N1).
+template <int SIGN, int N1>
+__global__ __launch_bounds__(256) void dft_columns_kernel(const float2* __restrict__ tw_n, uint32_t n2_size,
+                                                          const float2* __restrict__ d_in, float2* __restrict__ d_tmp)
+{
+  const uint32_t n2 = blockIdx.x * 256u + threadIdx.x;
+  if (n2 >= n2_size) {
+    return;
+  }
+  const size_t  n   = (size_t)N1 * n2_size;
+  const float2* in  = d_in + (size_t)blockIdx.y * n;
+  float2*       tmp = d_tmp + (size_t)blockIdx.y * n;
+  cf            a[N1];
+#pragma unroll
+  for (int k = 0; k != N1; ++k) {
+    const float2 v = in[n2 + (size_t)k * n2_size];
+    a[k]           = make_cf(v.x, v.y);
+  }
+  Butterfly<SIGN, N1>::run(a);
+#pragma unroll
+  for (int k = 0; k != N1; ++k) {
+    cf v = a[k];
+    if (k != 0) {
+      const float2 w = tw_n[(uint32_t)k * n2]; // k n2 < N: exp(+j 2 pi k n2 / N) from the table, conjugated when direct
+      v              = cmul(v, make_cf(w.x, SIGN < 0 ? -w.y : w.y));
+    }
+    tmp[n2 + (size_t)k * n2_size] = make_float2(v.x, v.y);
+  }
+}
+
+template <int N1>
+static hipError_t launch_dft_columns(int inverse, uint32_t batch, uint32_t n2_size, const float2* tw_n, const float2* d_in,
+                                     float2* d_tmp, hipStream_t stream)
+{
+  const dim3 grid((n2_size + 255u) / 256u, batch);
+  if (inverse) {
+    hipLaunchKernelGGL((dft_columns_kernel<+1, N1>), grid, dim3(256), 0, stream, tw_n, n2_size, d_in, d_tmp);
+  } else {
+    hipLaunchKernelGGL((dft_columns_kernel<-1, N1>), grid, dim3(256), 0, stream, tw_n, n2_size, d_in, d_tmp);
+  }
+  return hipGetLastError();
+}
+
+// The split of a size: n1 = 1 for the sizes one workgroup transforms in LDS.
+bool dft_split(uint32_t size, uint32_t* n1, uint32_t* n2)
+{
+  uint32_t a = 1, b = size;
+  switch (size) {
+    case 128: case 256: case 384: case 512: case 768: case 1024: case 1536: case 2048: case 3072: case 4096: case 4608:
+    case 6144:
+      break;
+    case 9216:
+      a = 3, b = 3072;
+      break;
+    case 12288:
+      a = 3, b = 4096;
+      break;
+    case 18432:
+      a = 6, b = 3072;
+      break;
+    case 24576:
+      a = 6, b = 4096;
+      break;
+    case 36864:
+      a = 12, b = 3072;
+      break;
+    case 49152:
+      a = 12, b = 4096;
+      break;
+    default:
+      return false;
+  }
+  if (n1) {
+    *n1 = a;
+  }
+  if (n2) {
+    *n2 = b;
+  }
+  return true;
+}
+
+bool dft_size_supported(uint32_t size)
+{
+  return dft_split(size, nullptr, nullptr);
+}
+
+// tw: the size's own twiddle table; for a split size also tw_n2 (the table of its LDS factor) and d_tmp, `batch`
+// transforms of scratch.
+hipError_t launch_dft(uint32_t size, int inverse, uint32_t batch, const float2* tw, const float2* tw_n2, float2* d_tmp,
+                      const float2* d_in, float2* d_out, hipStream_t stream)
+{
+  uint32_t n1 = 1, n2 = size;
+  if (!dft_split(size, &n1, &n2)) {
+    return hipErrorInvalidValue;
+  }
+  if (batch == 0) {
+    return hipSuccess;
+  }
+  if (n1 == 1) {
+    return launch_dft_lds(size, inverse, batch, tw, d_in, d_out, 1, stream);
+  }
+  if (tw_n2 == nullptr || d_tmp == nullptr) {
+    return hipErrorInvalidValue;
+  }
+  hipError_t e = hipErrorInvalidValue;
+  switch (n1) {
+    case 3:
+      e = launch_dft_columns<3>(inverse, batch, n2, tw, d_in, d_tmp, stream);
+      break;
+    case 6:
+      e = launch_dft_columns<6>(inverse, batch, n2, tw, d_in, d_tmp, stream);
+      break;
+    case 12:
+      e = launch_dft_columns<12>(inverse, batch, n2, tw, d_in, d_tmp, stream);
+      break;
+    default:
+      break;
+  }
+  if (e != hipSuccess) {
+    return e;
+  }
+  return launch_dft_lds(n2, inverse, batch * n1, tw_n2, d_tmp, d_out, n1, stream);
 }
 
 } // namespace nrphy

@@ -3,7 +3,10 @@
 `make -C oracle ref` from /root/reference).  Run in the build container only; the outputs (small .npz files: inputs +
 expected outputs, never reference source) are committed and travel to the GPU box.
 
-    python tests/golden/generate.py
+    python tests/golden/generate.py [section ...]     (no argument: every section)
+
+Sections: base (the round-1 files: codebooks, ldpc_encoder, pdsch_processor, ofdm_modulator, ofdm_demodulator),
+ofdm_sizes (DFT sizes 4608 / 6144: ofdm_sizes.npz).
 """
 import hashlib
 import os
@@ -22,6 +25,37 @@ assert r is not None, "build oracle/_ref first: make -C oracle ref"
 
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+SECTIONS = sys.argv[1:] or ["base", "ofdm_sizes"]
+
+
+def section_ofdm_sizes():
+    """OFDM modulator / demodulator at the two DFT sizes added in round 2 (15 kHz SCS: 6144 = 92.16 Msps, the size the
+    reference's ofdm_modulator_unittest sweeps; 4608 = 69.12 Msps)."""
+    rng = np.random.default_rng(6144)
+    og = {}
+    for name, (mu, bw, n, fc, slot) in {"n6144": (0, 273, 6144, 3.5e9, 0), "n4608": (0, 270, 4608, 2.4e9, 0)}.items():
+        cfg = abi.OfdmConfig(mu, bw, n, 0, 1.0 / np.sqrt(n), fc)
+        grid = (rng.standard_normal((1, 14, bw * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        og[name + "_grid"] = grid
+        og[name + "_iq"] = r.ofdm_slot(cfg, grid, slot)
+        og[name + "_cfg"] = np.array([mu, bw, n, fc, slot], dtype=np.float64)
+    for name, (mu, bw, n, fc, slot, wo) in {"d6144": (0, 273, 6144, 3.5e9, 0, 0), "d4608w": (0, 270, 4608, 2.4e9, 0, 11)}.items():
+        cfg = abi.OfdmConfig(mu, bw, n, 0, 1.0 / np.sqrt(n), fc)
+        size = backends.pkg.lib.slot_size(cfg, slot)
+        iq = (rng.standard_normal((1, size)) + 1j * rng.standard_normal((1, size))).astype(np.complex64)
+        og[name + "_iq"] = iq
+        og[name + "_grid"] = r.ofdm_demod_slot(cfg, iq, slot, wo)
+        og[name + "_cfg"] = np.array([mu, bw, n, fc, slot, wo], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "ofdm_sizes.npz"), **og)
+
+
+if "ofdm_sizes" in SECTIONS:
+    section_ofdm_sizes()
+if "base" not in SECTIONS:
+    print("golden vectors written to", HERE, SECTIONS)
+    sys.exit(0)
 
 
 # 1. Precoding codebooks the BASELINE configs use.

@@ -312,12 +312,14 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
-@pytest.mark.parametrize("size", [128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096])
+@pytest.mark.parametrize("size", [128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 4608, 6144, 9216, 12288,
+                                  18432, 24576, 36864, 49152])
 @pytest.mark.parametrize("inverse", [0, 1])
 def test_dft_vs_oracle(gpu_ctx, oracle, size, inverse):
+    """Every size of the reference's generic DFT (dft_processor_generic_impl.cpp:190-208), both directions."""
     import torch
     rng = np.random.default_rng(size + inverse)
-    batch = 5
+    batch = 5 if size <= 6144 else 3
     x = (rng.standard_normal((batch, size)) + 1j * rng.standard_normal((batch, size))).astype(np.complex64)
     d_in = dev(x.view(np.float32))
     d_out = torch.zeros_like(d_in)
@@ -330,10 +332,11 @@ def test_dft_vs_oracle(gpu_ctx, oracle, size, inverse):
         assert rel_err(out[i], want) < 1e-5   # north-star tolerance; reference test uses MSE < 1e-6 / peak < 1e-3
 
 
-@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024", "n1536", "n3072", "n768", "n384", "x512", "x2048"])
+@pytest.mark.parametrize("name", ["n4096", "n2048", "n1024", "n1536", "n3072", "n768", "n384", "x512", "x2048", "n6144",
+                                  "n4608"])
 def test_ofdm_modulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
     import torch
-    g = np.load(os.path.join(cases.GOLDEN, "ofdm_modulator.npz"))
+    g = np.load(os.path.join(cases.GOLDEN, "ofdm_sizes.npz" if name in ("n6144", "n4608") else "ofdm_modulator.npz"))
     mu, bw, n, fc, slot = g[name + "_cfg"][:5]
     ext = int(g[name + "_cfg"][5]) if len(g[name + "_cfg"]) > 5 else 0   # x...: extended cyclic prefix, 12 symbols
     nsymb = 12 if ext else 14
@@ -379,11 +382,11 @@ def assert_bf16_grids_close(got, want, min_exact=0.99):
     assert np.mean(got == want) >= min_exact
 
 
-@pytest.mark.parametrize("name", ["d4096", "d2048w", "d1536", "d512w", "dx1024w"])
+@pytest.mark.parametrize("name", ["d4096", "d2048w", "d1536", "d512w", "dx1024w", "d6144", "d4608w"])
 def test_ofdm_demodulator_vs_oracle_and_reference_golden(gpu_ctx, oracle, name):
     """Receive side of seam C (ofdm_slot_demodulator): device path against the oracle and the reference's output."""
     import torch
-    g = np.load(os.path.join(cases.GOLDEN, "ofdm_demodulator.npz"))
+    g = np.load(os.path.join(cases.GOLDEN, "ofdm_sizes.npz" if name in ("d6144", "d4608w") else "ofdm_demodulator.npz"))
     mu, bw, n, fc, slot, wo = g[name + "_cfg"][:6]
     ext = int(g[name + "_cfg"][6]) if len(g[name + "_cfg"]) > 6 else 0   # dx...: extended cyclic prefix
     slot, wo = int(slot), int(wo)
@@ -1164,7 +1167,7 @@ def test_ofdm_random_configurations(gpu_ctx, oracle):
     prefix, centre frequency, scale, slot and (demodulator) window offset, 1-3 ports."""
     rng = np.random.default_rng(4096)
     for _ in range(24):
-        n = int(rng.choice([128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096]))
+        n = int(rng.choice([128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 4608, 6144]))
         mu = int(rng.integers(0, 4))
         ext = int(rng.integers(0, 4) == 0)
         bw = int(rng.integers(1, min(275, (n - 1) // 12) + 1))
