@@ -262,7 +262,7 @@ int nrphy_ofdm_modulate_symbol_host(nrphy_ofdm_plan_t* plan, const void* grid, u
 int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t slot_index, float* iq);
 
 /* ---- device-resident resource grid: sparse writes from the host --------------------------------------
- * The channels this library does not generate (PDCCH, SSB/PBCH, ...) stay on the CPU; their resource elements
+ * The channels this library does not generate (PRS, PT-RS, ...) stay on the CPU; their resource elements
  * -- a few hundred per slot -- are merged into the grid in HBM with one call per slot instead of moving the
  * grid.  Counterpart of resource_grid_writer::put(port, l, k_init, mask, symbols)
  * (R/include/srsran/phy/support/resource_grid_writer.h) for a grid that lives on the device: later entries
@@ -334,6 +334,94 @@ int nrphy_csi_rs_map(nrphy_ctx_t* ctx, uint32_t n, const nrphy_csi_rs_cfg_t* cfg
 /* One signal into a host grid [nof_ports][14][nof_subc] cbf16 (read and written; blocking). */
 int nrphy_csi_rs_map_host(nrphy_ctx_t* ctx, const nrphy_csi_rs_cfg_t* cfg, void* grid, uint32_t nof_ports,
                           uint32_t nof_subc);
+
+/* ---- other downlink grid writers: PDCCH processor ------------------------------------
+ * Replaces pdcch_processor::process (R/include/srsran/phy/upper/channel_processors/pdcch_processor.h:47-151;
+ * impl R/lib/phy/upper/channel_processors/pdcch_processor_impl.cpp:66-118) with everything behind it: the
+ * CCE-to-REG mapping (R/lib/ran/pdcch/cce_to_prb_mapping.cpp), pdcch_encoder_impl (CRC24C with the RNTI mask, polar
+ * interleaver / allocator / encoder / rate matcher: pdcch_encoder_impl.cpp:33-98, channel_coding/polar/), pdcch_modulator_impl
+ * (scrambling, QPSK, precoding, mapping: pdcch_modulator_impl.cpp:30-90) and dmrs_pdcch_processor_impl
+ * (R/lib/phy/upper/signal_processors/dmrs_pdcch_processor_impl.cpp:32-102).  The fields are pdcch_processor::pdu_t:
+ * coreset_description + dci_description.  Precoding has one layer: [nof_prg][nof_ports] complex weights. */
+#define NRPHY_PDCCH_MAX_PAYLOAD 128 /* pdcch_constants::MAX_DCI_PAYLOAD_SIZE */
+typedef struct nrphy_pdcch_pdu {
+  uint32_t slot_index;         /* slot within the radio frame (DM-RS c_init) */
+  uint32_t cp;                 /* 0 normal, 1 extended */
+  /* coreset_description */
+  uint32_t bwp_size_rb;
+  uint32_t bwp_start_rb;
+  uint32_t start_symbol_index;
+  uint32_t duration;           /* 1..3 */
+  uint64_t frequency_resources; /* bit i = PRBs [6i, 6i + 6) of the BWP belong to the CORESET (45 bits) */
+  uint32_t cce_to_reg_mapping; /* 0 CORESET0, 1 non-interleaved, 2 interleaved */
+  uint32_t reg_bundle_size;    /* L, interleaved only */
+  uint32_t interleaver_size;   /* R, interleaved only */
+  uint32_t shift_index;        /* n_shift (interleaved), physical cell id (CORESET0) */
+  /* dci_description */
+  uint32_t rnti;
+  uint32_t n_id_pdcch_dmrs;
+  uint32_t n_id_pdcch_data;
+  uint32_t n_rnti;
+  uint32_t cce_index;
+  uint32_t aggregation_level;  /* 1, 2, 4, 8, 16 */
+  float    dmrs_power_offset_dB;
+  float    data_power_offset_dB;
+  uint32_t payload_size;       /* DCI bits: 12 .. 128 (polar K = payload + 24 in 36 .. 164) */
+  uint8_t  payload[NRPHY_PDCCH_MAX_PAYLOAD]; /* one bit per byte, as the reference passes it */
+  /* precoding_configuration, one layer */
+  uint32_t nof_ports;
+  uint32_t prg_size_rb;
+  uint32_t nof_prg;
+  const float* precoding;      /* host pointer: [nof_prg][nof_ports] complex (re, im) */
+} nrphy_pdcch_pdu_t;
+/* NRPHY_OK when the PDU is one the reference processes without running into its assertions (its validator accepts
+ * everything): duration, aggregation level, payload size, a CCE range inside the CORESET, REG bundles that tile it,
+ * PRGs that cover the allocation exactly. */
+int nrphy_pdcch_validate(const nrphy_pdcch_pdu_t* pdu);
+/* n PDUs into device grids ([grid][port][14][subc] cbf16): PDU i into grid grid_index[i] (NULL: all into grid 0).
+ * Descriptors are copied at the call into a staging buffer of the call's own (stream-ordered allocation); the kernel
+ * is asynchronous on `stream`.  Only the resource elements of the PDCCH and its DM-RS are written. */
+int nrphy_pdcch_process(nrphy_ctx_t* ctx, uint32_t n, const nrphy_pdcch_pdu_t* pdus, const uint32_t* grid_index,
+                        void* d_grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc, void* stream);
+/* One PDU into a host grid [nof_ports][14][nof_subc] cbf16 (read and written; blocking). */
+int nrphy_pdcch_process_host(nrphy_ctx_t* ctx, const nrphy_pdcch_pdu_t* pdu, void* grid, uint32_t nof_ports,
+                             uint32_t nof_subc);
+/* pdcch_encoder::encode (R/include/srsran/phy/upper/channel_processors/pdcch_encoder.h:33-57) alone: payload bits
+ * (one per byte) -> E = rm_length rate-matched bits (one per byte); host spans, blocking. */
+int nrphy_pdcch_encode_host(nrphy_ctx_t* ctx, const uint8_t* payload, uint32_t payload_size, uint32_t rnti,
+                            uint32_t rm_length, uint8_t* encoded);
+
+/* ---- other downlink grid writers: SS/PBCH block processor -----------------------------
+ * Replaces ssb_processor::process (R/include/srsran/phy/upper/channel_processors/ssb_processor.h:35-92; impl
+ * R/lib/phy/upper/channel_processors/ssb_processor_impl.cpp:29-107) with pbch_encoder_impl (payload generation,
+ * scrambling, CRC24C, polar coding, rate matching: pbch_encoder_impl.cpp:38-186), pbch_modulator_impl
+ * (pbch_modulator_impl.cpp:29-109), dmrs_pbch_processor_impl, pss_processor_impl and sss_processor_impl
+ * (R/lib/phy/upper/signal_processors/).  The fields are ssb_processor::pdu_t; the slot is given as numerology, system
+ * frame number and slot within the frame (slot_point). */
+typedef struct nrphy_ssb_pdu {
+  uint32_t numerology;       /* of the slot: 0 = 15 kHz ... */
+  uint32_t sfn;
+  uint32_t slot_index;       /* slot within the radio frame */
+  uint32_t phys_cell_id;     /* 0..1007 */
+  float    beta_pss_dB;      /* PSS power relative to SSS */
+  uint32_t ssb_idx;
+  uint32_t L_max;            /* 4, 8 or 64 */
+  uint32_t common_scs;       /* subCarrierSpacingCommon as a numerology: 0 = 15 kHz, 1 = 30, 2 = 60, 3 = 120 */
+  uint32_t subcarrier_offset; /* k_SSB */
+  uint32_t offset_to_pointA;
+  uint32_t pattern_case;     /* 0..4 = case A..E */
+  uint8_t  bch_payload[32];  /* one bit per byte: 24 MIB bits (+ 8 the encoder regenerates) */
+  uint32_t nof_ports;
+  uint8_t  ports[NRPHY_MAX_PORTS]; /* grid ports that carry the block */
+} nrphy_ssb_pdu_t;
+int nrphy_ssb_validate(const nrphy_ssb_pdu_t* pdu);
+/* n blocks into device grids, as nrphy_pdcch_process. */
+int nrphy_ssb_process(nrphy_ctx_t* ctx, uint32_t n, const nrphy_ssb_pdu_t* pdus, const uint32_t* grid_index, void* d_grid,
+                      uint32_t grid_nof_ports, uint32_t grid_nof_subc, void* stream);
+int nrphy_ssb_process_host(nrphy_ctx_t* ctx, const nrphy_ssb_pdu_t* pdu, void* grid, uint32_t nof_ports,
+                           uint32_t nof_subc);
+/* pbch_encoder::encode alone: the 864 rate-matched bits (one per byte) of the block's PBCH; host span, blocking. */
+int nrphy_pbch_encode_host(nrphy_ctx_t* ctx, const nrphy_ssb_pdu_t* pdu, uint8_t* encoded);
 
 /* ---- receive side ("next" row): LDPC rate dematcher --------------------------
  * Replaces ldpc_rate_dematcher::rate_dematch (R/include/srsran/phy/upper/channel_coding/ldpc/

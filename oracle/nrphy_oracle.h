@@ -48,6 +48,16 @@ int oracle_ldpc_decode(uint32_t bg, uint32_t zc, uint32_t nof_filler, uint32_t c
 /* NZP-CSI-RS generator ("next" row, section 8f-2): writes the signal's RE into grid [nof_ports][14][nof_subc] cbf16. */
 int oracle_csi_rs_validate(const nrphy_csi_rs_cfg_t* cfg);
 int oracle_csi_rs_map(const nrphy_csi_rs_cfg_t* cfg, uint16_t* grid, uint32_t nof_ports, uint32_t nof_subc);
+/* Downlink control side (section 8f-2), oracle/nrphy_oracle_dl.c: polar code construction (returns N, fills the mask of
+ * the K information positions), PDCCH encoder / processor, PBCH encoder / SS/PBCH block processor.  Bit arrays are one
+ * bit per byte; grids [nof_ports][14][nof_subc] cbf16, only the channel's RE are written. */
+int oracle_polar_code(uint32_t K, uint32_t E, uint32_t n_max, uint8_t* k_set_mask);
+int oracle_pdcch_encode(const uint8_t* payload, uint32_t payload_size, uint32_t rnti, uint32_t rm_length, uint8_t* encoded);
+int oracle_pdcch_validate(const nrphy_pdcch_pdu_t* pdu);
+int oracle_pdcch_process(const nrphy_pdcch_pdu_t* pdu, uint16_t* grid, uint32_t nof_ports, uint32_t nof_subc);
+int oracle_ssb_validate(const nrphy_ssb_pdu_t* pdu);
+int oracle_pbch_encode(const nrphy_ssb_pdu_t* pdu, uint8_t* encoded);
+int oracle_ssb_process(const nrphy_ssb_pdu_t* pdu, uint16_t* grid, uint32_t nof_ports, uint32_t nof_subc);
 /* LDPC rate dematcher ("next" row): out = soft buffer of (66 or 50) * Zc LLRs, read and written. */
 int oracle_ldpc_rate_dematch(uint32_t bg, uint32_t zc, uint32_t rv, uint32_t qm, uint32_t nref, uint32_t nof_filler,
                              int new_data, const int8_t* in, uint32_t e, int8_t* out);

@@ -147,6 +147,87 @@ def make_csi_rs(*, row, start_rb, nof_rb, k0, l0, density, slot_index=0, cp=0, s
     return c
 
 
+PDCCH_MAX_PAYLOAD = 128
+
+
+class PdcchPdu(C.Structure):
+    """nrphy_pdcch_pdu_t (pdcch_processor::pdu_t: coreset_description + dci_description)."""
+    _fields_ = [("slot_index", C.c_uint32), ("cp", C.c_uint32), ("bwp_size_rb", C.c_uint32), ("bwp_start_rb", C.c_uint32),
+                ("start_symbol_index", C.c_uint32), ("duration", C.c_uint32), ("frequency_resources", C.c_uint64),
+                ("cce_to_reg_mapping", C.c_uint32), ("reg_bundle_size", C.c_uint32), ("interleaver_size", C.c_uint32),
+                ("shift_index", C.c_uint32), ("rnti", C.c_uint32), ("n_id_pdcch_dmrs", C.c_uint32),
+                ("n_id_pdcch_data", C.c_uint32), ("n_rnti", C.c_uint32), ("cce_index", C.c_uint32),
+                ("aggregation_level", C.c_uint32), ("dmrs_power_offset_dB", C.c_float), ("data_power_offset_dB", C.c_float),
+                ("payload_size", C.c_uint32), ("payload", C.c_uint8 * PDCCH_MAX_PAYLOAD), ("nof_ports", C.c_uint32),
+                ("prg_size_rb", C.c_uint32), ("nof_prg", C.c_uint32), ("precoding", C.POINTER(C.c_float))]
+
+
+CCE_TO_REG = {"coreset0": 0, "non_interleaved": 1, "interleaved": 2}
+
+
+def make_pdcch(*, payload, rnti, cce_index, aggregation_level, duration, frequency_resources=(), mapping="non_interleaved",
+               bwp_start_rb=0, bwp_size_rb=52, start_symbol=0, reg_bundle_size=6, interleaver_size=2, shift_index=0,
+               n_id_dmrs=0, n_id_data=0, n_rnti=0, dmrs_dB=0.0, data_dB=0.0, slot_index=0, cp=0, precoding=None,
+               prg_size_rb=MAX_RB):
+    """Builds a PdcchPdu; ``payload`` = DCI bits, ``frequency_resources`` = indices of the 6-PRB groups of the CORESET,
+    ``precoding`` [nof_prg][nof_ports] complex64 (default: one port, weight 1)."""
+    p = PdcchPdu()
+    p.slot_index, p.cp, p.bwp_size_rb, p.bwp_start_rb = slot_index, cp, bwp_size_rb, bwp_start_rb
+    p.start_symbol_index, p.duration = start_symbol, duration
+    p.frequency_resources = sum(1 << i for i in frequency_resources)
+    p.cce_to_reg_mapping = CCE_TO_REG[mapping]
+    p.reg_bundle_size, p.interleaver_size, p.shift_index = reg_bundle_size, interleaver_size, shift_index
+    p.rnti, p.n_id_pdcch_dmrs, p.n_id_pdcch_data, p.n_rnti = rnti, n_id_dmrs, n_id_data, n_rnti
+    p.cce_index, p.aggregation_level = cce_index, aggregation_level
+    p.dmrs_power_offset_dB, p.data_power_offset_dB = dmrs_dB, data_dB
+    payload = np.asarray(payload, dtype=np.uint8)
+    p.payload_size = payload.size
+    for i, b in enumerate(payload[:PDCCH_MAX_PAYLOAD]):
+        p.payload[i] = int(b)
+    if precoding is None:
+        precoding = np.ones((1, 1), np.complex64)
+    w = np.ascontiguousarray(np.asarray(precoding, dtype=np.complex64))
+    assert w.ndim == 2
+    p.nof_prg, p.nof_ports, p.prg_size_rb = w.shape[0], w.shape[1], prg_size_rb
+    f = w.view(np.float32).reshape(-1)
+    p._keepalive = f
+    p.precoding = f.ctypes.data_as(C.POINTER(C.c_float))
+    return p
+
+
+class SsbPdu(C.Structure):
+    """nrphy_ssb_pdu_t (ssb_processor::pdu_t)."""
+    _fields_ = [("numerology", C.c_uint32), ("sfn", C.c_uint32), ("slot_index", C.c_uint32), ("phys_cell_id", C.c_uint32),
+                ("beta_pss_dB", C.c_float), ("ssb_idx", C.c_uint32), ("L_max", C.c_uint32), ("common_scs", C.c_uint32),
+                ("subcarrier_offset", C.c_uint32), ("offset_to_pointA", C.c_uint32), ("pattern_case", C.c_uint32),
+                ("bch_payload", C.c_uint8 * 32), ("nof_ports", C.c_uint32), ("ports", C.c_uint8 * MAX_PORTS)]
+
+
+SSB_CASE = {"A": 0, "B": 1, "C": 2, "D": 3, "E": 4}
+
+
+def make_ssb(*, pattern_case, ssb_idx, L_max, phys_cell_id, payload, sfn=0, numerology=None, slot_index=None, common_scs=None,
+             subcarrier_offset=0, offset_to_pointA=0, beta_pss_dB=0.0, ports=(0,)):
+    """Builds an SsbPdu; the slot defaults to the one of the first half frame that carries candidate ``ssb_idx``."""
+    case = SSB_CASE[pattern_case]
+    mu = {0: 0, 1: 1, 2: 1, 3: 3, 4: 4}[case] if numerology is None else numerology
+    first = {0: lambda i: (2, 8)[i % 2] + 14 * (i // 2), 1: lambda i: (4, 8, 16, 20)[i % 4] + 28 * (i // 4),
+             2: lambda i: (2, 8)[i % 2] + 14 * (i // 2)}.get(case)
+    p = SsbPdu()
+    p.numerology, p.sfn = mu, sfn
+    p.slot_index = (first(ssb_idx) // 14 if first else 0) if slot_index is None else slot_index
+    p.phys_cell_id, p.beta_pss_dB, p.ssb_idx, p.L_max = phys_cell_id, beta_pss_dB, ssb_idx, L_max
+    p.common_scs = (mu if mu < 4 else 3) if common_scs is None else common_scs
+    p.subcarrier_offset, p.offset_to_pointA, p.pattern_case = subcarrier_offset, offset_to_pointA, case
+    payload = np.asarray(payload, dtype=np.uint8)
+    for i in range(32):
+        p.bch_payload[i] = int(payload[i]) if i < payload.size else 0
+    p.nof_ports = len(ports)
+    for i, q in enumerate(ports):
+        p.ports[i] = q
+    return p
+
+
 class OfdmConfig(C.Structure):
     _fields_ = [
         ("numerology", C.c_uint32),
@@ -296,6 +377,14 @@ def declare(lib, prefix="nrphy_"):
     sig("csi_rs_validate", i32, P(CsiRsCfg))
     sig("csi_rs_map", i32, vp, u32, P(CsiRsCfg), P(u32), vp, u32, u32, vp)
     sig("csi_rs_map_host", i32, vp, P(CsiRsCfg), vp, u32, u32)
+    sig("pdcch_validate", i32, P(PdcchPdu))
+    sig("pdcch_process", i32, vp, u32, P(PdcchPdu), P(u32), vp, u32, u32, vp)
+    sig("pdcch_process_host", i32, vp, P(PdcchPdu), vp, u32, u32)
+    sig("pdcch_encode_host", i32, vp, u8p, u32, u32, u32, u8p)
+    sig("ssb_validate", i32, P(SsbPdu))
+    sig("ssb_process", i32, vp, u32, P(SsbPdu), P(u32), vp, u32, u32, vp)
+    sig("ssb_process_host", i32, vp, P(SsbPdu), vp, u32, u32)
+    sig("pbch_encode_host", i32, vp, P(SsbPdu), u8p)
     sig("pusch_decoder_sizes", i32, P(PuschDecoderCfg), u32, P(u64), P(u64), P(u32))
     sig("pusch_decode_batch", i32, vp, P(PuschDecoderCfg), u32, vp, u64, vp, vp, vp, u32, vp, vp)
     sig("pusch_decode_codeblock_host", i32, vp, P(LdpcRateDematcherCfg), u32, u32, C.c_float, vp, vp, i32, u8p, P(u32))
@@ -317,4 +406,6 @@ ABI_SYMBOLS = [
     "nrphy_pusch_decode_codeblock_host", "nrphy_pusch_decoder_sizes", "nrphy_pusch_decode_batch",
     "nrphy_csi_rs_validate", "nrphy_csi_rs_map", "nrphy_csi_rs_map_host", "nrphy_grid_put",
     "nrphy_llr_descramble", "nrphy_llr_descramble_host",
+    "nrphy_pdcch_validate", "nrphy_pdcch_process", "nrphy_pdcch_process_host", "nrphy_pdcch_encode_host",
+    "nrphy_ssb_validate", "nrphy_ssb_process", "nrphy_ssb_process_host", "nrphy_pbch_encode_host",
 ]

@@ -3,7 +3,7 @@
 // Per-PDU scalar derivation (what pdsch_processor_impl / ldpc_segmenter_impl / ldpc_rate_matcher_impl compute on
 // the CPU before their loops), plan construction and kernel launches.  No compute happens here and there is no CPU
 // fallback: every entry point that produces PHY output needs a HIP device.
-#include "nrphy_internal.h"
+#include "nrphy_host_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -151,40 +151,6 @@ void mat_mul(const uint32_t* a, const uint32_t* b, uint32_t* out) // out = a * b
 }
 
 // GF(2)[x] / g arithmetic of the transport-block CRC polynomials (order 24 or 16, `poly` with its leading term).
-struct CrcField {
-  uint32_t poly, order;
-  uint32_t mul(uint32_t a, uint32_t b) const // a below 2^order, b any 32-bit polynomial
-  {
-    const uint32_t top = 1U << order;
-    uint32_t       r   = 0;
-    for (int k = 31; k >= 0; --k) {
-      r <<= 1;
-      if (r & top) {
-        r ^= poly;
-      }
-      if ((b >> k) & 1U) {
-        r ^= a;
-      }
-    }
-    return r;
-  }
-  uint32_t xpow(int64_t e) const // x^e mod g; g(0) = 1 makes x invertible: x^-1 = (g - 1) / x
-  {
-    uint32_t base = (e >= 0) ? 2U : (poly >> 1);
-    uint64_t n    = (uint64_t)(e >= 0 ? e : -e);
-    uint32_t r    = 1;
-    while (n) {
-      if (n & 1U) {
-        r = mul(r, base);
-      }
-      base = mul(base, base);
-      n >>= 1;
-    }
-    return r;
-  }
-};
-const CrcField CRC24A_FIELD = {0x1864CFBU, 24};
-const CrcField CRC16_FIELD  = {0x11021U, 16};
 
 void build_tbcrc_tables(TbCrcTables& t)
 {
@@ -307,21 +273,6 @@ void build_gold_tables(GoldTables& t, std::vector<uint32_t>& x1_words)
   }
 }
 
-template <typename T>
-hipError_t upload(T** dptr, const void* src, size_t bytes)
-{
-  *dptr = nullptr;
-  if (bytes == 0) {
-    bytes = 16;
-    hipError_t e = hipMalloc((void**)dptr, bytes);
-    return e;
-  }
-  hipError_t e = hipMalloc((void**)dptr, bytes);
-  if (e != hipSuccess) {
-    return e;
-  }
-  return hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
-}
 
 // All tables of a plan in ONE device allocation filled by ONE copy (a plan of a single PDU used to spend most of its
 // creation time in a dozen hipMalloc / hipMemcpy pairs).  add() registers a table; commit() allocates, copies and
@@ -366,74 +317,9 @@ private:
 
 } // namespace
 
-struct nrphy_ctx {
-  int          device   = 0;
-  hipStream_t  stream   = nullptr;
-  LiftedGraph* d_graphs = nullptr;
-  GoldTables*  d_gold   = nullptr;
-  TbCrcTables* d_tbcrc  = nullptr;
-  uint32_t*    d_x1     = nullptr;
-  std::map<uint32_t, float2*> d_twiddle; // exp(+j 2 pi k / N) per DFT size, built on first use (under host_mutex)
-  DecoderGraph* d_dec_graph[NOF_GRAPHS] = {}; // decoder graphs, built on first use
-  std::map<uint64_t, uint32_t*> d_dec_crc;     // early-stop CRC weights per (polynomial, message length)
-  std::map<uint32_t, uint32_t*> d_tb_crc_w;    // transport-block CRC weights of the PUSCH assembly kernel per block size
-  std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)
-  // Device staging of the host-span entry points (*_host): grow-only buffers, one call at a time per context.
-  // One lock for everything context-owned and shared: the staging buffers below and the lazily built tables.  The
-  // host-span entry points (*_host) hold it from their first staging access to their last copy, so two of them never
-  // interleave on a buffer; it is recursive because they are built from device-pointer calls that take it briefly.
-  std::recursive_mutex host_mutex;
-  void*      scratch[8]       = {};
-  size_t     scratch_bytes[8] = {};
-};
 
 namespace {
 
-// Staging buffer `slot` of the context with room for `bytes` (reallocated only when it has to grow).
-enum ScratchSlot { SCRATCH_TB = 0, SCRATCH_GRID, SCRATCH_CW_RM, SCRATCH_CW_SCR, SCRATCH_IQ, SCRATCH_SMALL,
-                   SCRATCH_DECODER, SCRATCH_RX, SCRATCH_COUNT };
-void* ctx_scratch(nrphy_ctx* ctx, ScratchSlot slot, size_t bytes)
-{
-  if (bytes > ctx->scratch_bytes[slot]) {
-    (void)hipFree(ctx->scratch[slot]);
-    ctx->scratch[slot]       = nullptr;
-    ctx->scratch_bytes[slot] = 0;
-    const size_t want        = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
-    if (hipMalloc(&ctx->scratch[slot], want) != hipSuccess) {
-      return nullptr;
-    }
-    ctx->scratch_bytes[slot] = want;
-  }
-  return ctx->scratch[slot];
-}
-
-// Device staging that lives for ONE call: host-built work lists a kernel of this call reads.  Allocated and released
-// in stream order (hipMallocAsync / hipFreeAsync), so calls in flight on different streams never share a buffer and
-// nothing waits for the device.  Usage: alloc(), copy + launch on the same stream, then the destructor frees.
-class StreamStaging
-{
-public:
-  explicit StreamStaging(hipStream_t s) : stream(s) {}
-  StreamStaging(const StreamStaging&)            = delete;
-  StreamStaging& operator=(const StreamStaging&) = delete;
-  ~StreamStaging()
-  {
-    if (ptr != nullptr) {
-      (void)hipFreeAsync(ptr, stream);
-    }
-  }
-  void* alloc(size_t bytes)
-  {
-    if (hipMallocAsync(&ptr, std::max<size_t>(bytes, 16), stream) != hipSuccess) {
-      ptr = nullptr;
-    }
-    return ptr;
-  }
-
-private:
-  hipStream_t stream;
-  void*       ptr = nullptr;
-};
 
 } // namespace
 
@@ -749,12 +635,6 @@ extern "C" uint32_t nrphy_ofdm_slot_size(const nrphy_ofdm_config_t* cfg, uint32_
 // ================================================================================================================
 // Context
 // ================================================================================================================
-#define HIP_TRY(expr)                                                                                                  \
-  do {                                                                                                                 \
-    if ((expr) != hipSuccess) {                                                                                        \
-      return NRPHY_ERR_DEVICE;                                                                                         \
-    }                                                                                                                  \
-  } while (0)
 
 extern "C" int nrphy_create(nrphy_ctx_t** out, int device_id)
 {

@@ -303,6 +303,51 @@ hipError_t launch_llr_descramble(const GoldTables* gold, const uint32_t* x1_word
                                  hipStream_t stream);
 hipError_t launch_grid_put(const uint32_t* d_index, const uint32_t* d_value, uint32_t n, uint32_t* d_grid, hipStream_t stream);
 
+// ---- PDCCH and SS/PBCH block ("next" row: other downlink grid writers) --------------------------------------------------
+// One wavefront per DCI.  Offsets index the launch's shared tables: tab16 (gather table of the polar input, PRB list),
+// bytes (payload bits, one per byte), words (CRC weights), weights (floats).
+struct PdcchWork {
+  uint32_t grid_index;
+  uint32_t A, E, N;        // payload bits, rate-matched bits, polar code length
+  uint32_t mode;           // bit selection: 0 repetition, 1 puncturing, 2 shortening
+  uint32_t rnti, crc_const; // crc_const: the share of the 24 leading ones in the CRC
+  uint32_t c_init_data;
+  uint32_t start_symbol, duration, n_prb, ref_rb, top_prb; // top_prb: highest allocated PRB + 1
+  uint32_t nof_ports, prg_size_subc;
+  uint32_t dmrs_c_init[3];
+  float    data_amp, dmrs_amp;
+  uint32_t weights_offset, src_offset, prb_offset, payload_offset, crcw_offset, enc_offset;
+};
+// One wavefront per SS/PBCH block.
+struct SsbWork {
+  uint32_t grid_index, l0, k0, pci;
+  uint32_t a_bits;     // PBCH payload a_0 .. a_31 after the interleaver G, a_0 in the MSB
+  uint32_t scr_mask;   // positions of a that are scrambled, position 0 in the MSB
+  uint32_t scr_adv;    // M v: offset of the payload scrambling sequence
+  uint32_t ssb_adv;    // (ssb_idx mod 8) * 864: offset of the PBCH scrambling sequence
+  uint32_t dmrs_c_init;
+  uint32_t m_pss, m0, m1;
+  float    pss_amp;
+  uint32_t nof_ports;
+  uint8_t  ports[NRPHY_MAX_PORTS];
+  uint32_t src_offset, crcw_offset, enc_offset;
+};
+struct DlControlLaunch {
+  const PdcchWork*  pdcch;
+  const SsbWork*    ssb;
+  const float*      weights;
+  const uint16_t*   tab16;
+  const uint8_t*    bytes;
+  const uint32_t*   words;
+  const GoldTables* gold;
+  const uint32_t*   x1_words;
+  uint32_t*         grid; // null: encode only
+  uint8_t*          enc;  // null, or the rate-matched bits (one per byte) of every work item at its enc_offset
+  uint32_t          grid_nof_ports, grid_nof_subc;
+};
+hipError_t launch_pdcch(const DlControlLaunch& p, uint32_t n, hipStream_t stream);
+hipError_t launch_ssb(const DlControlLaunch& p, uint32_t n, hipStream_t stream);
+
 // ---- OFDM ---------------------------------------------------------------------------------------------------
 struct OfdmLaunch {
   uint32_t       dft_size;

@@ -174,6 +174,51 @@ class Context:
                "nrphy_csi_rs_map_host")
         return out
 
+    # ---- downlink control channels (pdcch_processor, ssb_processor) --------------------------------------------
+    def pdcch_process(self, pdus, grid_indices, d_grid, nof_ports, nof_subc, stream=None):
+        """pdcch_processor::process for a batch of DCIs into device grids [grid][port][14][subc]."""
+        n = len(pdus)
+        arr = (abi.PdcchPdu * n)(*pdus)
+        idx = (C.c_uint32 * n)(*grid_indices)
+        _check(self.lib.nrphy_pdcch_process(self.handle, n, arr, idx, _dptr(d_grid), nof_ports, nof_subc, stream),
+               "nrphy_pdcch_process")
+
+    def pdcch_process_host(self, pdu, grid):
+        """pdcch_processor::process into a copy of a host grid [nof_ports][14][nof_subc][2] uint16 (raw cbf16)."""
+        out = np.array(grid, dtype=np.uint16, copy=True)
+        _check(self.lib.nrphy_pdcch_process_host(self.handle, C.byref(pdu), out.ctypes.data, out.shape[0], out.shape[2]),
+               "nrphy_pdcch_process_host")
+        return out
+
+    def pdcch_encode_host(self, payload_bits, rnti, rm_length):
+        """pdcch_encoder::encode: payload bits (one per byte) -> rm_length bits (one per byte)."""
+        payload = np.ascontiguousarray(payload_bits, dtype=np.uint8)
+        out = np.zeros(rm_length, np.uint8)
+        _check(self.lib.nrphy_pdcch_encode_host(self.handle, payload.ctypes.data, payload.size, rnti, rm_length,
+                                                out.ctypes.data), "nrphy_pdcch_encode_host")
+        return out
+
+    def ssb_process(self, pdus, grid_indices, d_grid, nof_ports, nof_subc, stream=None):
+        """ssb_processor::process for a batch of SS/PBCH blocks into device grids [grid][port][14][subc]."""
+        n = len(pdus)
+        arr = (abi.SsbPdu * n)(*pdus)
+        idx = (C.c_uint32 * n)(*grid_indices)
+        _check(self.lib.nrphy_ssb_process(self.handle, n, arr, idx, _dptr(d_grid), nof_ports, nof_subc, stream),
+               "nrphy_ssb_process")
+
+    def ssb_process_host(self, pdu, grid):
+        """ssb_processor::process into a copy of a host grid [nof_ports][14][nof_subc][2] uint16 (raw cbf16)."""
+        out = np.array(grid, dtype=np.uint16, copy=True)
+        _check(self.lib.nrphy_ssb_process_host(self.handle, C.byref(pdu), out.ctypes.data, out.shape[0], out.shape[2]),
+               "nrphy_ssb_process_host")
+        return out
+
+    def pbch_encode_host(self, pdu):
+        """pbch_encoder::encode: the 864 rate-matched PBCH bits (one per byte)."""
+        out = np.zeros(864, np.uint8)
+        _check(self.lib.nrphy_pbch_encode_host(self.handle, C.byref(pdu), out.ctypes.data), "nrphy_pbch_encode_host")
+        return out
+
     def pusch_decoder_sizes(self, cfg, n_tb):
         """(soft-buffer bytes per transport block, state bytes of the batch, codeblocks per transport block)."""
         soft, state, ncb = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)

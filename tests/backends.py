@@ -302,6 +302,70 @@ class CpuBackend:
         assert n == iq.shape[1], (n, iq.shape)
         return grid
 
+    # ---- downlink control side (section 8f-2) ---------------------------------------------------------------
+    def polar_code(self, K, E, n_max=9):
+        """polar_code::set -> (N, mask of the K information positions as N bytes)."""
+        mask = np.zeros(1024, np.uint8)
+        f = self._f("polar_code")
+        f.restype = C.c_int
+        n = f(C.c_uint32(K), C.c_uint32(E), C.c_uint32(n_max), _ptr(mask))
+        assert n > 0, n
+        return n, mask[:n].copy()
+
+    def pdcch_encode(self, payload_bits, rnti, rm_length):
+        """pdcch_encoder::encode: payload bits (one per byte) -> rm_length bits (one per byte)."""
+        payload = np.ascontiguousarray(payload_bits, dtype=np.uint8)
+        out = np.zeros(rm_length, np.uint8)
+        f = self._f("pdcch_encode")
+        f.restype = C.c_int
+        rc = f(_ptr(payload), C.c_uint32(payload.size), C.c_uint32(rnti), C.c_uint32(rm_length), _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def pdcch_validate(self, pdu):
+        assert not self.is_ref
+        f = self._f("pdcch_validate")
+        f.restype = C.c_int
+        return int(f(C.byref(pdu)))
+
+    def pdcch_process(self, pdu, grid, simd=1):
+        """pdcch_processor::process into a copy of grid [nof_ports][14][nof_subc][2] uint16 (raw cbf16)."""
+        out = np.array(grid, dtype=np.uint16, copy=True)
+        nof_ports, _, nof_subc, _ = out.shape
+        args = [C.byref(pdu), _ptr(out), C.c_uint32(nof_ports), C.c_uint32(nof_subc)]
+        if self.is_ref:
+            args.append(C.c_int(simd))
+        f = self._f("pdcch_process")
+        f.restype = C.c_int
+        rc = f(*args)
+        assert rc == 0, rc
+        return out
+
+    def ssb_validate(self, pdu):
+        assert not self.is_ref
+        f = self._f("ssb_validate")
+        f.restype = C.c_int
+        return int(f(C.byref(pdu)))
+
+    def pbch_encode(self, pdu):
+        """pbch_encoder::encode -> 864 bits (one per byte)."""
+        out = np.zeros(864, np.uint8)
+        f = self._f("pbch_encode")
+        f.restype = C.c_int
+        rc = f(C.byref(pdu), _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def ssb_process(self, pdu, grid):
+        """ssb_processor::process into a copy of grid [nof_ports][14][nof_subc][2] uint16 (raw cbf16)."""
+        out = np.array(grid, dtype=np.uint16, copy=True)
+        nof_ports, _, nof_subc, _ = out.shape
+        f = self._f("ssb_process")
+        f.restype = C.c_int
+        rc = f(C.byref(pdu), _ptr(out), C.c_uint32(nof_ports), C.c_uint32(nof_subc))
+        assert rc == 0, rc
+        return out
+
     def codebook(self, kind, a=0, b=0, c=0):
         assert self.is_ref
         w = np.zeros((4, 4, 2), np.float32)
@@ -317,8 +381,8 @@ _REF = None
 def build_oracle():
     """Compiles oracle/liboracle.so when missing or stale (gcc, a second or two)."""
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    src = os.path.join(ROOT, "oracle", "nrphy_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(ROOT, "oracle", n) for n in ("nrphy_oracle.c", "nrphy_oracle_dl.c", "nrphy_oracle.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, capture_output=True,
                        timeout=300)
     return so

@@ -345,3 +345,123 @@ def random_pdus(tbs, rng, count):
                            tb_size_bytes=tb_bits // 8, cp=cp)
         out.append((pdu, ports, 12 * (bwp_start + bwp_size)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Downlink control side: random PDCCH and SS/PBCH PDUs within what the validators accept
+# ---------------------------------------------------------------------------------------------------------------------
+def random_pdcch(rng, nof_ports_max=4, nof_rb_grid=52):
+    """One random PDCCH PDU (pdcch_processor::pdu_t) that fits a grid of nof_rb_grid PRBs."""
+    while True:
+        mapping = str(rng.choice(["coreset0", "non_interleaved", "interleaved"]))
+        duration = int(rng.integers(1, 4))
+        al = int(rng.choice([1, 2, 4, 8, 16]))
+        kw = {}
+        if mapping == "coreset0":
+            size = int(rng.choice([24, 48]))
+            if size > nof_rb_grid:
+                continue
+            start = int(rng.integers(0, nof_rb_grid - size + 1))
+            kw.update(bwp_start_rb=start, bwp_size_rb=size, shift_index=int(rng.integers(0, 1008)))
+            n_rb = size
+        else:
+            bwp_start = int(rng.integers(0, 5))
+            n_groups_max = (nof_rb_grid - bwp_start) // 6
+            groups = sorted(rng.choice(n_groups_max, size=int(rng.integers(1, n_groups_max + 1)), replace=False).tolist())
+            kw.update(bwp_start_rb=bwp_start, bwp_size_rb=nof_rb_grid - bwp_start, frequency_resources=groups)
+            n_rb = 6 * len(groups)
+            if mapping == "interleaved":
+                L = int(rng.choice([2, 6] if duration < 3 else [3, 6]))
+                R = int(rng.choice([2, 3, 6]))
+                if (n_rb * duration) % (L * R) != 0 or L % duration != 0:
+                    continue
+                kw.update(reg_bundle_size=L, interleaver_size=R, shift_index=int(rng.integers(0, 275)))
+        n_cce = n_rb * duration // 6
+        if n_cce < al:
+            continue
+        cce = al * int(rng.integers(0, n_cce // al))
+        ports = int(rng.integers(1, nof_ports_max + 1))
+        style = int(rng.integers(0, 3))
+        if style == 0:
+            w, prg = np.ones((1, 1), np.complex64), abi.MAX_RB   # make_wideband(make_single_port())
+        elif style == 1:
+            w = (rng.standard_normal((1, ports)) + 1j * rng.standard_normal((1, ports))).astype(np.complex64)
+            prg = abi.MAX_RB
+        else:
+            w, prg = None, int(rng.choice([2, 4, 8, 16]))
+        pdu = abi.make_pdcch(payload=rng.integers(0, 2, int(rng.integers(12, min(129, 108 * al - 24))), dtype=np.uint8),
+                             rnti=int(rng.integers(0, 65536)),
+                             cce_index=cce, aggregation_level=al, duration=duration, mapping=mapping,
+                             start_symbol=int(rng.integers(0, 14 - duration + 1)), n_id_dmrs=int(rng.integers(0, 65536)),
+                             n_id_data=int(rng.integers(0, 65536)), n_rnti=int(rng.integers(0, 65536)),
+                             dmrs_dB=float(rng.choice([0.0, 3.0, -1.5])), data_dB=float(rng.choice([0.0, -3.0, 1.25])),
+                             slot_index=int(rng.integers(0, 20)), precoding=w if w is not None else np.ones((1, 1), np.complex64),
+                             prg_size_rb=prg if w is not None else abi.MAX_RB, **kw)
+        if w is None:
+            # per-PRG weights: as many PRGs as it takes to cover the highest allocated PRB exactly
+            import backends
+            o = backends.oracle()
+            for nof_prg in range(1, nof_rb_grid // prg + 2):
+                cand = (rng.standard_normal((nof_prg, ports)) + 1j * rng.standard_normal((nof_prg, ports))).astype(np.complex64)
+                pdu2 = abi.make_pdcch(payload=np.frombuffer(bytes(pdu.payload)[: pdu.payload_size], np.uint8), rnti=pdu.rnti,
+                                      cce_index=cce, aggregation_level=al, duration=duration, mapping=mapping,
+                                      start_symbol=pdu.start_symbol_index, n_id_dmrs=pdu.n_id_pdcch_dmrs,
+                                      n_id_data=pdu.n_id_pdcch_data, n_rnti=pdu.n_rnti, dmrs_dB=pdu.dmrs_power_offset_dB,
+                                      data_dB=pdu.data_power_offset_dB, slot_index=pdu.slot_index, precoding=cand,
+                                      prg_size_rb=prg, **kw)
+                if o.pdcch_validate(pdu2) == 0:
+                    return pdu2
+            continue
+        return pdu
+
+
+def random_ssb(rng, nof_rb_grid=52, nof_ports=2):
+    """One random SS/PBCH block PDU (cases A-C, FR1) that fits a grid of nof_rb_grid PRBs."""
+    case = str(rng.choice(["A", "B", "C"]))
+    mu = 0 if case == "A" else 1
+    L_max = int(rng.choice([4, 8]))
+    k_ssb, opa = int(rng.integers(0, 24)), int(rng.integers(0, (nof_rb_grid - 21) * (1 + mu)))
+    if mu == 1:
+        k_ssb, opa = k_ssb & ~1, opa & ~1
+    ports = sorted(rng.choice(nof_ports, size=int(rng.integers(1, nof_ports + 1)), replace=False).tolist())
+    pdu = abi.make_ssb(pattern_case=case, ssb_idx=int(rng.integers(0, L_max)), L_max=L_max, phys_cell_id=int(rng.integers(0, 1008)),
+                       payload=rng.integers(0, 2, 32, dtype=np.uint8), sfn=int(rng.integers(0, 1024)), subcarrier_offset=k_ssb,
+                       offset_to_pointA=opa, beta_pss_dB=float(rng.choice([0.0, 3.0, -3.0])), ports=ports)
+    if rng.integers(0, 2):
+        pdu.slot_index += (10 << mu) // 2   # the same candidate in the second half frame
+    return pdu
+
+
+def pdu_to_arrays(pdu, prefix):
+    """A ctypes PDU (PdcchPdu / SsbPdu) as plain arrays for an .npz fixture: every scalar field, array fields as uint8
+    arrays, the precoding weights (when the PDU has them) as complex64 [nof_prg][nof_ports]."""
+    out = {}
+    for name, ctype in pdu._fields_:
+        v = getattr(pdu, name)
+        if name == "precoding":
+            w = np.ctypeslib.as_array(v, shape=(2 * pdu.nof_prg * pdu.nof_ports,)).copy()
+            out[prefix + name] = w.view(np.complex64).reshape(pdu.nof_prg, pdu.nof_ports)
+        elif hasattr(v, "__len__"):
+            out[prefix + name] = np.array(list(v), dtype=np.uint8)
+        else:
+            out[prefix + name] = np.array(v)
+    return out
+
+
+def pdu_from_arrays(cls, g, prefix):
+    """Inverse of pdu_to_arrays for abi.PdcchPdu / abi.SsbPdu."""
+    import ctypes as C
+    pdu = cls()
+    for name, ctype in cls._fields_:
+        v = g[prefix + name]
+        if name == "precoding":
+            f = np.ascontiguousarray(v, dtype=np.complex64).view(np.float32).reshape(-1)
+            pdu._keepalive = f
+            pdu.precoding = f.ctypes.data_as(C.POINTER(C.c_float))
+        elif v.ndim == 1:
+            arr = getattr(pdu, name)
+            for i, x in enumerate(v):
+                arr[i] = int(x)
+        else:
+            setattr(pdu, name, v.item())
+    return pdu

@@ -6,7 +6,7 @@ expected outputs, never reference source) are committed and travel to the GPU bo
     python tests/golden/generate.py [section ...]     (no argument: every section)
 
 Sections: base (the round-1 files: codebooks, ldpc_encoder, pdsch_processor, ofdm_modulator, ofdm_demodulator),
-ofdm_sizes (DFT sizes 4608 / 6144: ofdm_sizes.npz).
+ofdm_sizes (DFT sizes 4608 / 6144: ofdm_sizes.npz), dl_control (PDCCH and SS/PBCH block processors: dl_control.npz).
 """
 import hashlib
 import os
@@ -27,7 +27,7 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-SECTIONS = sys.argv[1:] or ["base", "ofdm_sizes"]
+SECTIONS = sys.argv[1:] or ["base", "ofdm_sizes", "dl_control"]
 
 
 def section_ofdm_sizes():
@@ -51,8 +51,42 @@ def section_ofdm_sizes():
     np.savez_compressed(os.path.join(HERE, "ofdm_sizes.npz"), **og)
 
 
+def section_dl_control():
+    """PDCCH and SS/PBCH block processors of the compiled reference on seeded PDUs (tests/cases.py generators; the PDUs
+    are stored field by field, so the fixture does not depend on the generators staying the same): encoder outputs and
+    the grid words the processor wrote into an all-zero grid."""
+    import cases
+    rng = np.random.default_rng(38213)
+    g = {}
+    n_pdcch, n_ssb = 24, 12
+    for i in range(n_pdcch):
+        pdu = cases.random_pdcch(rng)
+        grid = r.pdcch_process(pdu, np.zeros((4, 14, 52 * 12, 2), np.uint16), simd=1)
+        assert np.array_equal(grid, r.pdcch_process(pdu, np.zeros((4, 14, 52 * 12, 2), np.uint16), simd=0))
+        g.update(cases.pdu_to_arrays(pdu, "pdcch%02d_" % i))
+        payload = np.array(list(pdu.payload)[: pdu.payload_size], np.uint8)
+        g["pdcch%02d_encoded" % i] = np.packbits(r.pdcch_encode(payload, pdu.rnti, 108 * pdu.aggregation_level))
+        w = grid.view(np.uint32).reshape(-1)
+        idx = np.flatnonzero(w)
+        g["pdcch%02d_idx" % i] = idx.astype(np.uint32)
+        g["pdcch%02d_val" % i] = w[idx]
+    for i in range(n_ssb):
+        pdu = cases.random_ssb(rng, nof_ports=3)
+        grid = r.ssb_process(pdu, np.zeros((3, 14, 52 * 12, 2), np.uint16))
+        g.update(cases.pdu_to_arrays(pdu, "ssb%02d_" % i))
+        g["ssb%02d_encoded" % i] = np.packbits(r.pbch_encode(pdu))
+        w = grid.view(np.uint32).reshape(-1)
+        idx = np.flatnonzero(w)   # the SSS writes -0 imaginary parts: non-zero words, kept
+        g["ssb%02d_idx" % i] = idx.astype(np.uint32)
+        g["ssb%02d_val" % i] = w[idx]
+    g["n_pdcch"], g["n_ssb"] = np.array(n_pdcch), np.array(n_ssb)
+    np.savez_compressed(os.path.join(HERE, "dl_control.npz"), **g)
+
+
 if "ofdm_sizes" in SECTIONS:
     section_ofdm_sizes()
+if "dl_control" in SECTIONS:
+    section_dl_control()
 if "base" not in SECTIONS:
     print("golden vectors written to", HERE, SECTIONS)
     sys.exit(0)

@@ -1031,6 +1031,166 @@ def test_nzp_csi_rs_vs_oracle(gpu_ctx, oracle):
     assert gpu_ctx.lib.nrphy_csi_rs_validate(C.byref(bad)) == abi.ERR_ARGUMENT
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Downlink control channels: PDCCH and SS/PBCH block processors on the device
+# ---------------------------------------------------------------------------------------------------------------------
+def test_pdcch_processor_vs_oracle_and_reference_golden(gpu_ctx, oracle):
+    """pdcch_processor::process through the C ABI: the reference's outputs (tests/golden/dl_control.npz), random PDUs
+    against the oracle in grids full of other data, the encoder alone, and a batch of DCIs into device-resident grids."""
+    import torch
+    import test_oracle
+    g = np.load(os.path.join(cases.GOLDEN, "dl_control.npz"))
+    for i in range(int(g["n_pdcch"])):
+        pdu, enc, grid = test_oracle.dl_control_golden("pdcch", i)
+        assert gpu_ctx.lib.nrphy_pdcch_validate(C.byref(pdu)) == 0, i
+        payload = np.array(list(pdu.payload)[: pdu.payload_size], np.uint8)
+        assert np.array_equal(np.packbits(gpu_ctx.pdcch_encode_host(payload, pdu.rnti, 108 * pdu.aggregation_level)), enc), i
+        assert np.array_equal(gpu_ctx.pdcch_process_host(pdu, np.zeros_like(grid)), grid), i
+    rng = np.random.default_rng(8212)
+    batch = []
+    for i in range(60):
+        pdu = cases.random_pdcch(rng)
+        grid = (rng.standard_normal((4, 14, 52 * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        want = oracle.pdcch_process(pdu, grid)
+        got = gpu_ctx.pdcch_process_host(pdu, grid)
+        assert np.array_equal(got, want), (i, int(np.count_nonzero(got != want)))
+        batch.append((pdu, grid, want))
+    # 60 DCIs in one call: three per grid (their candidates may overlap: each is checked in a grid of its own below, the
+    # shared grids only have to equal the oracle applied in the same order)
+    n_grids = 20
+    grids = np.stack([b[1] for b in batch[:n_grids]])
+    idx = [i % n_grids for i in range(60)]
+    want = grids.copy()
+    for i, (pdu, _, _) in enumerate(batch):
+        want[idx[i]] = oracle.pdcch_process(pdu, want[idx[i]])
+    d_grid = dev(grids.view(np.uint32).reshape(n_grids, 4, 14, 624).view(np.int32))
+    # candidates of one grid can collide; launch them one grid-set at a time so that the order is the oracle's
+    for first in (0, 20, 40):
+        gpu_ctx.pdcch_process([b[0] for b in batch[first: first + 20]], idx[first: first + 20], d_grid, 4, 624)
+    gpu_ctx.synchronize()
+    torch.cuda.synchronize()
+    got = d_grid.cpu().numpy().view(np.uint16).reshape(n_grids, 4, 14, 624, 2)
+    assert np.array_equal(got, want)
+    # refusals: a payload that leaves no room for the CRC (K >= E), a candidate beyond the CORESET, PRGs that do not
+    # cover the allocation, an aggregation level that does not exist
+    ok = abi.make_pdcch(payload=np.zeros(40, np.uint8), rnti=1, cce_index=0, aggregation_level=2, duration=2,
+                        frequency_resources=(0, 1, 2, 3))
+    assert gpu_ctx.lib.nrphy_pdcch_validate(C.byref(ok)) == 0
+    for change in (dict(payload=np.zeros(90, np.uint8), aggregation_level=1), dict(cce_index=7), dict(aggregation_level=3),
+                   dict(prg_size_rb=4), dict(duration=4)):
+        kw = dict(payload=np.zeros(40, np.uint8), rnti=1, cce_index=0, aggregation_level=2, duration=2, frequency_resources=(0, 1, 2, 3))
+        kw.update(change)
+        bad = abi.make_pdcch(**kw)
+        assert gpu_ctx.lib.nrphy_pdcch_validate(C.byref(bad)) == abi.ERR_INVALID_PDU, change
+        assert oracle.pdcch_validate(bad) == abi.ERR_INVALID_PDU, change
+
+
+def test_ssb_processor_vs_oracle_and_reference_golden(gpu_ctx, oracle):
+    """ssb_processor::process through the C ABI: reference outputs, random blocks (cases A-C, both half frames, several
+    ports) and case D with L_max = 64 against the oracle, the PBCH encoder alone, a batch into device grids."""
+    import torch
+    import test_oracle
+    g = np.load(os.path.join(cases.GOLDEN, "dl_control.npz"))
+    for i in range(int(g["n_ssb"])):
+        pdu, enc, grid = test_oracle.dl_control_golden("ssb", i)
+        assert np.array_equal(np.packbits(gpu_ctx.pbch_encode_host(pdu)), enc), i
+        assert np.array_equal(gpu_ctx.ssb_process_host(pdu, np.zeros_like(grid)), grid), i
+    rng = np.random.default_rng(8213)
+    batch = []
+    for i in range(40):
+        pdu = cases.random_ssb(rng, nof_ports=3)
+        grid = (rng.standard_normal((3, 14, 52 * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        want = oracle.ssb_process(pdu, grid)
+        assert np.array_equal(gpu_ctx.pbch_encode_host(pdu), oracle.pbch_encode(pdu)), i
+        got = gpu_ctx.ssb_process_host(pdu, grid)
+        assert np.array_equal(got, want), (i, int(np.count_nonzero(got != want)))
+        batch.append((pdu, grid, want))
+    groups = (0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17, 18)
+    for idx in (0, 13, 37, 63):
+        first = (4, 8, 16, 20)[idx % 4] + 28 * groups[idx // 4]
+        pdu = abi.make_ssb(pattern_case="D", ssb_idx=idx, L_max=64, phys_cell_id=777, payload=rng.integers(0, 2, 32, dtype=np.uint8),
+                           sfn=1000 + idx % 20, numerology=3, slot_index=first // 14, common_scs=3, subcarrier_offset=5,
+                           offset_to_pointA=4, ports=(1,))
+        grid = np.zeros((2, 14, 52 * 12, 2), np.uint16)
+        assert np.array_equal(gpu_ctx.ssb_process_host(pdu, grid), oracle.ssb_process(pdu, grid)), idx
+    grids = np.stack([b[1] for b in batch])
+    d_grid = dev(grids.view(np.uint32).reshape(len(batch), 3, 14, 624).view(np.int32))
+    gpu_ctx.ssb_process([b[0] for b in batch], list(range(len(batch))), d_grid, 3, 624)
+    gpu_ctx.synchronize()
+    torch.cuda.synchronize()
+    got = d_grid.cpu().numpy().view(np.uint16).reshape(len(batch), 3, 14, 624, 2)
+    for i, b in enumerate(batch):
+        assert np.array_equal(got[i], b[2]), i
+    # refusals: a slot that does not hold the candidate, a port beyond the grid, a block beyond the grid
+    pdu = cases.random_ssb(rng, nof_ports=2)
+    pdu.slot_index = (pdu.slot_index + 1) % (10 << pdu.numerology)
+    assert gpu_ctx.lib.nrphy_ssb_validate(C.byref(pdu)) == abi.ERR_INVALID_PDU and oracle.ssb_validate(pdu) == abi.ERR_INVALID_PDU
+    pdu = cases.random_ssb(rng, nof_ports=3)
+    with pytest.raises(lib.NrphyError):
+        gpu_ctx.ssb_process_host(pdu, np.zeros((1, 14, 18 * 12, 2), np.uint16))
+
+
+def test_whole_downlink_slot_in_one_device_grid(gpu_ctx, oracle):
+    """Every downlink grid writer of a slot on the device, in the order the reference's downlink processor applies them
+    (PDCCH, PDSCH with its DM-RS, SS/PBCH block, NZP-CSI-RS): the grid in HBM equals the oracle's grid and the OFDM
+    modulator turns it into IQ without the grid ever visiting the host."""
+    import torch
+    rng = np.random.default_rng(2718)
+    nof_ports, nof_rb = 2, 52
+    nof_subc = 12 * nof_rb
+    w2 = cases.codebook("two_layer_two_ports_0")
+    # PDSCH on symbols 2-13 of PRBs 22-51 (below it the SS/PBCH block: PRBs 0-19 on symbols 2-5; PDCCH on symbols 0-1)
+    tbs = lib.tbs_calculate(12, 12, 0, 4, 490, 2, 30)
+    pdsch = abi.make_pdu(bwp_size_rb=nof_rb, qm=4, rnti=17, n_id=5, dmrs_symbols=(2, 11), prb_start=22, prb_count=30,
+                         start_symbol=2, nof_symbols=12, precoding=w2, tb_size_bytes=tbs // 8, slot_index=0)
+    tb = cases.random_tb(rng, pdsch)
+    pdcch = [abi.make_pdcch(payload=rng.integers(0, 2, 41, dtype=np.uint8), rnti=17, cce_index=0, aggregation_level=4, duration=2,
+                            frequency_resources=tuple(range(8)), mapping="interleaved", reg_bundle_size=6, interleaver_size=2,
+                            shift_index=3, n_id_dmrs=5, n_id_data=5, n_rnti=17, bwp_size_rb=nof_rb,
+                            precoding=np.array([[1.0, 1.0j]], np.complex64) / np.sqrt(2)),
+             abi.make_pdcch(payload=rng.integers(0, 2, 39, dtype=np.uint8), rnti=0xFFFF, cce_index=4, aggregation_level=4, duration=2,
+                            frequency_resources=tuple(range(8)), mapping="interleaved", reg_bundle_size=6, interleaver_size=2,
+                            shift_index=3, n_id_dmrs=5, n_id_data=5, bwp_size_rb=nof_rb)]
+    ssb = abi.make_ssb(pattern_case="A", ssb_idx=0, L_max=4, phys_cell_id=5, payload=rng.integers(0, 2, 32, dtype=np.uint8),
+                       sfn=100, ports=(0,))
+    csi = abi.make_csi_rs(row=3, start_rb=0, nof_rb=nof_rb, k0=4, l0=13, density="one", scrambling_id=5,
+                          precoding=np.eye(2, dtype=np.complex64)[None])
+    # expected: the oracle's writers applied in the same order to one grid
+    want = np.zeros((nof_ports, 14, nof_subc, 2), np.uint16)
+    for p in pdcch:
+        want = oracle.pdcch_process(p, want)
+    pg = oracle.pdsch_process(pdsch, tb, nof_ports, nof_subc)
+    mask = pg.view(np.uint32) != 0
+    want.view(np.uint32)[mask] = pg.view(np.uint32)[mask]
+    want = oracle.ssb_process(ssb, want)
+    want = oracle.csi_rs_map(csi, want)
+    # device: PDSCH plan (zero-fills everything it does not map), then the other writers on the same stream
+    tb_bytes = (pdsch.tb_size_bytes + 3) & ~3
+    h = np.zeros(tb_bytes, np.uint8)
+    h[: tb.size] = tb
+    d_tb = dev(h)
+    d_grid = torch.full((1, nof_ports, 14, nof_subc), -1, dtype=torch.int32, device="cuda")
+    plan = lib.PdschPlan(gpu_ctx, [pdsch], [0], [0], 1, nof_ports, nof_subc)
+    torch.cuda.synchronize()
+    plan.run(d_tb, d_grid, zero_grids=True)
+    gpu_ctx.pdcch_process(pdcch[:1], [0], d_grid, nof_ports, nof_subc)
+    gpu_ctx.pdcch_process(pdcch[1:], [0], d_grid, nof_ports, nof_subc)
+    gpu_ctx.ssb_process([ssb], [0], d_grid, nof_ports, nof_subc)
+    gpu_ctx.csi_rs_map([csi], [0], d_grid, nof_ports, nof_subc)
+    ocfg = abi.OfdmConfig(0, nof_rb, 1024, 0, 1.0 / np.sqrt(1024), 2.4e9)
+    oplan = lib.OfdmPlan(gpu_ctx, ocfg, nof_ports)
+    d_iq = torch.zeros((1, nof_ports, oplan.slot_stride, 2), dtype=torch.float32, device="cuda")
+    oplan.run(1, d_grid, d_iq)
+    gpu_ctx.synchronize()
+    torch.cuda.synchronize()
+    got = d_grid[0].cpu().numpy().view(np.uint16).reshape(nof_ports, 14, nof_subc, 2)
+    assert np.array_equal(got, want), int(np.count_nonzero(got != want))
+    iq = d_iq[0].cpu().numpy().view(np.complex64).reshape(nof_ports, -1)
+    assert rel_err(iq, oracle.ofdm_slot(ocfg, want, 0)) < 1e-5
+    plan.close()
+    oplan.close()
+
+
 def test_grid_put_sparse_host_writes(gpu_ctx):
     """nrphy_grid_put: resource elements of CPU-generated channels merged into a device grid; later entries win, the
     rest of the grid is untouched, out-of-range entries are refused."""

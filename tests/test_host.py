@@ -51,6 +51,42 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %
     assert [int(x) for x in out] == want
 
 
+def test_dl_control_pod_layout_and_validators(oracle):
+    """PDCCH / SS/PBCH PODs: ctypes mirror vs the C compiler's layout; the library's validators (host only, no device)
+    against the oracle's on random and on broken PDUs."""
+    import subprocess
+    import tempfile
+    src = r'''#include "mi355_nrphy.h"
+#include <stdio.h>
+#include <stddef.h>
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(nrphy_pdcch_pdu_t), offsetof(nrphy_pdcch_pdu_t, frequency_resources),
+ offsetof(nrphy_pdcch_pdu_t, payload), offsetof(nrphy_pdcch_pdu_t, precoding), sizeof(nrphy_ssb_pdu_t),
+ offsetof(nrphy_ssb_pdu_t, bch_payload), offsetof(nrphy_ssb_pdu_t, ports));return 0;}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(backends.ROOT, "include"), os.path.join(d, "t.c"), "-o",
+                        os.path.join(d, "t")], check=True, timeout=120)
+        out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, timeout=60).stdout.split()
+    want = [C.sizeof(abi.PdcchPdu), abi.PdcchPdu.frequency_resources.offset, abi.PdcchPdu.payload.offset,
+            abi.PdcchPdu.precoding.offset, C.sizeof(abi.SsbPdu), abi.SsbPdu.bch_payload.offset, abi.SsbPdu.ports.offset]
+    assert [int(x) for x in out] == want
+    h = lib.load()
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        pdu = cases.random_pdcch(rng)
+        field = str(rng.choice(["none", "cce_index", "aggregation_level", "duration", "payload_size", "prg_size_rb", "nof_prg",
+                                "reg_bundle_size", "interleaver_size", "start_symbol_index", "frequency_resources"]))
+        if field != "none":
+            setattr(pdu, field, int(rng.integers(0, 20)))
+        assert h.nrphy_pdcch_validate(C.byref(pdu)) == oracle.pdcch_validate(pdu), field
+        ssb = cases.random_ssb(rng, nof_ports=4)
+        field = str(rng.choice(["none", "slot_index", "ssb_idx", "L_max", "pattern_case", "subcarrier_offset", "common_scs",
+                                "numerology"]))
+        if field != "none":
+            setattr(ssb, field, int(rng.integers(0, 9)))
+        assert h.nrphy_ssb_validate(C.byref(ssb)) == oracle.ssb_validate(ssb), field
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

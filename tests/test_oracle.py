@@ -448,6 +448,98 @@ def test_oracle_vs_ref_dft_and_ofdm(oracle, ref):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# 2b. downlink control side: polar coding, PDCCH, SS/PBCH block
+# ---------------------------------------------------------------------------------------------------------------------
+def test_oracle_vs_ref_polar_code(oracle, ref):
+    """polar_code::set: code length and information set for every downlink (K, E) of the PDCCH lengths and PBCH, plus a
+    sweep over rate-matched lengths that reaches every branch (repetition, shortening, both puncturing bounds)."""
+    for K in range(36, 165):
+        for E in (108, 216, 432, 864, 1728):
+            if K < E:
+                a, b = oracle.polar_code(K, E), ref.polar_code(K, E)
+                assert a[0] == b[0] and np.array_equal(a[1], b[1]), (K, E)
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        K = int(rng.integers(36, 165))
+        E = int(rng.integers(K + 1, 2000))
+        a, b = oracle.polar_code(K, E), ref.polar_code(K, E)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), (K, E)
+
+
+def test_oracle_vs_ref_pdcch_encoder(oracle, ref):
+    """pdcch_encoder_impl (CRC24C + RNTI mask, polar interleaver / allocator / encoder / rate matcher) on random DCIs."""
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        E = int(rng.choice([108, 216, 432, 864, 1728]))
+        A = int(rng.integers(12, min(129, E - 24)))
+        payload, rnti = rng.integers(0, 2, A, dtype=np.uint8), int(rng.integers(0, 65536))
+        assert np.array_equal(oracle.pdcch_encode(payload, rnti, E), ref.pdcch_encode(payload, rnti, E)), (A, E)
+
+
+def test_oracle_vs_ref_pdcch_processor(oracle, ref):
+    """pdcch_processor_impl with both precoders of the reference on random PDUs: the three CCE-to-REG mappings, 1-3
+    symbols, every aggregation level, 1-4 ports, wideband and per-PRG complex weights, power offsets -- into grids
+    full of other data, so that what is left alone is checked too."""
+    rng = np.random.default_rng(3)
+    for i in range(150):
+        pdu = cases.random_pdcch(rng)
+        assert oracle.pdcch_validate(pdu) == 0
+        grid = (rng.standard_normal((4, 14, 52 * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        want = oracle.pdcch_process(pdu, grid)
+        assert np.array_equal(want, ref.pdcch_process(pdu, grid, simd=1)), i
+        assert np.array_equal(want, ref.pdcch_process(pdu, grid, simd=0)), i
+
+
+def test_oracle_vs_ref_ssb_processor(oracle, ref):
+    """pbch_encoder_impl and ssb_processor_impl: pattern cases A-C (L_max 4 / 8, both half frames) and case D with
+    L_max = 64 (block index bits in the payload), several ports."""
+    rng = np.random.default_rng(2)
+    for _ in range(120):
+        pdu = cases.random_ssb(rng, nof_ports=3)
+        assert oracle.ssb_validate(pdu) == 0
+        assert np.array_equal(oracle.pbch_encode(pdu), ref.pbch_encode(pdu))
+        grid = (rng.standard_normal((3, 14, 52 * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        assert np.array_equal(oracle.ssb_process(pdu, grid), ref.ssb_process(pdu, grid))
+    groups = (0, 1, 2, 3, 5, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17, 18)
+    for _ in range(30):
+        idx = int(rng.integers(0, 64))
+        first = (4, 8, 16, 20)[idx % 4] + 28 * groups[idx // 4]
+        pdu = abi.make_ssb(pattern_case="D", ssb_idx=idx, L_max=64, phys_cell_id=int(rng.integers(0, 1008)),
+                           payload=rng.integers(0, 2, 32, dtype=np.uint8), sfn=int(rng.integers(0, 1024)), numerology=3,
+                           slot_index=first // 14, common_scs=3, subcarrier_offset=int(rng.integers(0, 12)),
+                           offset_to_pointA=2 * int(rng.integers(0, 8)), ports=(1,))
+        assert oracle.ssb_validate(pdu) == 0
+        assert np.array_equal(oracle.pbch_encode(pdu), ref.pbch_encode(pdu))
+        grid = np.zeros((2, 14, 52 * 12, 2), np.uint16)
+        assert np.array_equal(oracle.ssb_process(pdu, grid), ref.ssb_process(pdu, grid))
+
+
+def dl_control_golden(kind, i):
+    """(PDU, packed encoder output, expected grid) of entry i of tests/golden/dl_control.npz."""
+    g = np.load(os.path.join(cases.GOLDEN, "dl_control.npz"))
+    key = "%s%02d_" % (kind, i)
+    pdu = cases.pdu_from_arrays(abi.PdcchPdu if kind == "pdcch" else abi.SsbPdu, g, key)
+    nof_ports = 4 if kind == "pdcch" else 3
+    grid = np.zeros(nof_ports * 14 * 52 * 12, np.uint32)
+    grid[g[key + "idx"]] = g[key + "val"]
+    return pdu, g[key + "encoded"], grid.view(np.uint16).reshape(nof_ports, 14, 52 * 12, 2)
+
+
+def test_oracle_dl_control_golden(oracle):
+    """The oracle against the reference's outputs stored in tests/golden/dl_control.npz (runs on the GPU box too)."""
+    g = np.load(os.path.join(cases.GOLDEN, "dl_control.npz"))
+    for i in range(int(g["n_pdcch"])):
+        pdu, enc, grid = dl_control_golden("pdcch", i)
+        payload = np.array(list(pdu.payload)[: pdu.payload_size], np.uint8)
+        assert np.array_equal(np.packbits(oracle.pdcch_encode(payload, pdu.rnti, 108 * pdu.aggregation_level)), enc), i
+        assert np.array_equal(oracle.pdcch_process(pdu, np.zeros_like(grid)), grid), i
+    for i in range(int(g["n_ssb"])):
+        pdu, enc, grid = dl_control_golden("ssb", i)
+        assert np.array_equal(np.packbits(oracle.pbch_encode(pdu)), enc), i
+        assert np.array_equal(oracle.ssb_process(pdu, np.zeros_like(grid)), grid), i
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # 3. known-answer restatements
 # ---------------------------------------------------------------------------------------------------------------------
 def gold_bits(c_init, n):
