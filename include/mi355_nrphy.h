@@ -552,6 +552,96 @@ int nrphy_ofdm_demodulate_slot_host(nrphy_ofdm_plan_t* plan, const float* iq, ui
 int nrphy_ofdm_demodulate_symbol_host(nrphy_ofdm_plan_t* plan, const float* input, uint32_t input_size,
                                       uint32_t symbol_index, uint32_t window_offset, void* grid_row);
 
+/* ---- lower-PHY tail: amplitude controller, radio sample format, fronthaul compression ----
+ * Amplitude controller: replaces amplitude_controller::process (R/include/srsran/phy/lower/amplitude_controller/
+ * amplitude_controller.h:52-66; impl amplitude_controller_clipping_impl.cpp:31-68 and _scaling_impl.cpp:28-37) for
+ * n_buffers baseband buffers of nof_samples complex floats (what the lower PHY hands over per port):
+ * out = in * 10^(input_gain_dB / 20), then, with clipping enabled, real and imaginary parts limited to
+ * +-full_scale_lin * 10^(ceiling_dBFS / 20).  kind 1 is the scaling implementation (gain only, no measurements).
+ * The device leaves the raw measurements per buffer in d_stats (may be NULL): sum of |x|^2 and largest |x|^2 after
+ * the gain and before clipping, number of clipped real / imaginary parts; nrphy_amplitude_metrics() turns them into
+ * amplitude_controller_metrics on the host, carrying the running counters of the reference's object.  The reference
+ * skips clipping when the measured power is not a normal number (all-zero, NaN): for such buffers clipping changes
+ * nothing unless the ceiling itself is denormal, which is refused. */
+typedef struct nrphy_amplitude_cfg {
+  uint32_t kind;            /* 0 amplitude_controller_clipping_impl, 1 amplitude_controller_scaling_impl */
+  uint32_t enable_clipping;
+  float    input_gain_dB;
+  float    full_scale_lin;
+  float    ceiling_dBFS;
+} nrphy_amplitude_cfg_t;
+typedef struct nrphy_amplitude_stats { /* device side, one per buffer */
+  float    sum_power;
+  float    peak_power;
+  uint32_t nof_clipped;
+  uint32_t nof_samples;
+} nrphy_amplitude_stats_t;
+typedef struct nrphy_amplitude_metrics { /* amplitude_controller_metrics */
+  float    avg_power_fs;
+  float    peak_power_fs;
+  float    papr_lin;
+  float    gain_dB;
+  uint64_t nof_processed_samples; /* running totals: pass the same struct to every call for one controller */
+  uint64_t nof_clipped_samples;
+  double   clipping_probability;
+  uint32_t clipping_enabled;
+  uint32_t reserved_;
+} nrphy_amplitude_metrics_t;
+/* Buffer i at d_in + i * in_stride / d_out + i * out_stride (strides in complex samples; in place allowed).
+ * Asynchronous on `stream`, capturable (d_stats is cleared by the call itself with a memset node). */
+int nrphy_amplitude_control(nrphy_ctx_t* ctx, const nrphy_amplitude_cfg_t* cfg, uint32_t n_buffers, uint32_t nof_samples,
+                            const float* d_in, size_t in_stride, float* d_out, size_t out_stride,
+                            nrphy_amplitude_stats_t* d_stats, void* stream);
+/* Host arithmetic of amplitude_controller_clipping_impl::process on the measurements of ONE buffer; `metrics` is read
+ * (running counters) and written. */
+int nrphy_amplitude_metrics(const nrphy_amplitude_cfg_t* cfg, const nrphy_amplitude_stats_t* stats,
+                            nrphy_amplitude_metrics_t* metrics);
+/* One buffer from and to host memory (blocking); metrics may be NULL. */
+int nrphy_amplitude_control_host(nrphy_ctx_t* ctx, const nrphy_amplitude_cfg_t* cfg, const float* in, uint32_t nof_samples,
+                                 float* out, nrphy_amplitude_metrics_t* metrics);
+
+/* Radio sample format: complex float -> complex int16 (I, Q interleaved), out = round_to_nearest_even(in * scale)
+ * saturated to int16 -- srsvec::convert(span<const cf_t>, float, span<int16_t>) (R/lib/srsvec/conversion.cpp:29-65,
+ * 323-328), which the radio layers call on every transmit buffer.  The reference's vector loop converts 16 values at
+ * a time this way; the last (2 * nof_samples) mod 16 values of a buffer go through std::round (ties away from zero),
+ * and so do they here.  Strides in complex samples. */
+int nrphy_iq_convert_ci16(nrphy_ctx_t* ctx, uint32_t n_buffers, uint32_t nof_samples, const float* d_in, size_t in_stride,
+                          float scale, int16_t* d_out, size_t out_stride, void* stream);
+int nrphy_iq_convert_ci16_host(nrphy_ctx_t* ctx, const float* in, uint32_t nof_samples, float scale, int16_t* out);
+
+/* The two above fused into the OFDM modulator's store: nrphy_ofdm_run with the slot leaving the device as complex
+ * int16 (4 bytes per sample instead of 8: the IQ write is 71 % of the modulator's traffic).  Every sample takes the
+ * path modulator -> amplitude controller (gain, clipping per buffer = per (grid, port) slot) -> conversion, in the
+ * reference's order of roundings.  d_iq: [grid][port][slot_stride] complex int16; d_stats: [grid][port] or NULL. */
+typedef struct nrphy_iq_wire_cfg {
+  nrphy_amplitude_cfg_t amplitude;
+  float                 ci16_scale;
+} nrphy_iq_wire_cfg_t;
+int nrphy_ofdm_run_ci16(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid, const uint32_t* slot_index,
+                        const nrphy_iq_wire_cfg_t* cfg, int16_t* d_iq, nrphy_amplitude_stats_t* d_stats, void* stream);
+
+/* Open Fronthaul IQ compression of resource-grid PRBs (split 7.2: the grid, not the time-domain signal, leaves the
+ * DU).  Replaces iq_compressor::compress (R/include/srsran/ofh/compression/iq_compressor.h; impl
+ * R/lib/ofh/compression/iq_compression_none_impl.cpp:31-55 and iq_compression_bfp_impl.cpp:31-98 with quantizer.h and
+ * compressed_prb_packer.cpp) and the serialisation of the result in ofh_uplane_message_builder_impl.cpp:137-144: per
+ * PRB [udCompParam: the BFP exponent, one byte, BFP only] + 24 samples of data_width bits packed MSB first.  One
+ * row = one compress() call = the PRBs of one OFDM symbol of one port; results are those of the reference built for
+ * AVX2 (its 16-lane conversion loop rounds to nearest even and saturates, the tail of a call rounds half away). */
+typedef struct nrphy_ofh_compression_cfg {
+  uint32_t type;        /* 0 none, 1 BFP */
+  uint32_t data_width;  /* 1..16 */
+  float    iq_scaling;
+} nrphy_ofh_compression_cfg_t;
+/* Bytes per compressed PRB: 3 * data_width (+ 1 for BFP). */
+uint32_t nrphy_ofh_compressed_prb_bytes(const nrphy_ofh_compression_cfg_t* cfg);
+/* n_rows rows of nof_prb PRBs: row r reads 12 * nof_prb cbf16 at d_prbs + r * row_stride (in cbf16 words) and writes
+ * nof_prb records at d_out + r * out_row_stride bytes.  A batch of whole grids is n_rows = grids * ports * 14,
+ * row_stride = 12 * nof_prb.  Asynchronous on `stream`, capturable. */
+int nrphy_ofh_compress(nrphy_ctx_t* ctx, const nrphy_ofh_compression_cfg_t* cfg, uint32_t n_rows, uint32_t nof_prb,
+                       const void* d_prbs, size_t row_stride, uint8_t* d_out, size_t out_row_stride, void* stream);
+int nrphy_ofh_compress_host(nrphy_ctx_t* ctx, const nrphy_ofh_compression_cfg_t* cfg, uint32_t nof_prb, const void* prbs,
+                            uint8_t* out);
+
 /* dft_processor::run (R/include/srsran/phy/generic_functions/dft_processor.h:34-73; generic impl
  * dft_processor_generic_impl.cpp:14-218).  Unnormalised DFT of `size` complex floats, `batch` of them
  * back to back.  inverse != 0 uses exp(+j...).  Sizes: every size of the reference's generic implementation

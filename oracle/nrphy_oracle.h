@@ -58,6 +58,14 @@ int oracle_pdcch_process(const nrphy_pdcch_pdu_t* pdu, uint16_t* grid, uint32_t 
 int oracle_ssb_validate(const nrphy_ssb_pdu_t* pdu);
 int oracle_pbch_encode(const nrphy_ssb_pdu_t* pdu, uint8_t* encoded);
 int oracle_ssb_process(const nrphy_ssb_pdu_t* pdu, uint16_t* grid, uint32_t nof_ports, uint32_t nof_subc);
+/* Lower-PHY tail (section 8f-3), oracle/nrphy_oracle_lower.c. */
+int oracle_amplitude_control(const nrphy_amplitude_cfg_t* cfg, const float* in, uint32_t nof_samples, float* out,
+                             nrphy_amplitude_stats_t* stats);
+int oracle_amplitude_metrics(const nrphy_amplitude_cfg_t* cfg, const nrphy_amplitude_stats_t* stats,
+                             nrphy_amplitude_metrics_t* metrics);
+int oracle_iq_convert_ci16(const float* in, uint32_t nof_samples, float scale, int16_t* out);
+uint32_t oracle_ofh_compressed_prb_bytes(const nrphy_ofh_compression_cfg_t* cfg);
+int oracle_ofh_compress(const nrphy_ofh_compression_cfg_t* cfg, const uint16_t* prbs, uint32_t nof_prb, uint8_t* out);
 /* LDPC rate dematcher ("next" row): out = soft buffer of (66 or 50) * Zc LLRs, read and written. */
 int oracle_ldpc_rate_dematch(uint32_t bg, uint32_t zc, uint32_t rv, uint32_t qm, uint32_t nref, uint32_t nof_filler,
                              int new_data, const int8_t* in, uint32_t e, int8_t* out);

@@ -26,6 +26,14 @@
 #include "lib/phy/upper/signal_processors/dmrs_pdcch_processor_impl.h"
 #include "lib/phy/upper/signal_processors/pss_processor_impl.h"
 #include "lib/phy/upper/signal_processors/sss_processor_impl.h"
+#include "lib/ofh/compression/iq_compression_bfp_avx2.h"
+#include "lib/ofh/compression/iq_compression_bfp_impl.h"
+#include "lib/ofh/compression/iq_compression_none_avx2.h"
+#include "lib/ofh/compression/iq_compression_none_impl.h"
+#include "lib/phy/lower/amplitude_controller/amplitude_controller_clipping_impl.h"
+#include "lib/phy/lower/amplitude_controller/amplitude_controller_scaling_impl.h"
+#include "srsran/srslog/srslog.h"
+#include "srsran/srsvec/conversion.h"
 
 #include <cstring>
 #include <memory>
@@ -241,6 +249,82 @@ int ref_ssb_process(const nrphy_ssb_pdu_t* in, uint16_t* grid_io, unsigned nof_p
   proc.process(grid.get_writer(), pdu);
   store_grid(grid_io, grid.get_reader(), nof_ports, nof_subc);
   return NRPHY_OK;
+}
+
+// ---- lower-PHY tail ---------------------------------------------------------------------------
+// amplitude_controller::process on one buffer of nof_samples complex floats.  kind 0: clipping implementation
+// (gain, measurements, optional clipping), 1: scaling implementation (gain only).  metrics_out: avg_power_fs,
+// peak_power_fs, papr_lin, gain_dB; counters_out: nof_processed_samples, nof_clipped_samples.
+int ref_amplitude_control(int          kind,
+                          int          enable_clipping,
+                          float        input_gain_dB,
+                          float        full_scale_lin,
+                          float        ceiling_dBFS,
+                          const float* in,
+                          unsigned     nof_samples,
+                          float*       out,
+                          float*       metrics_out,
+                          uint64_t*    counters_out)
+{
+  span<const cf_t> x(reinterpret_cast<const cf_t*>(in), nof_samples);
+  span<cf_t>       y(reinterpret_cast<cf_t*>(out), nof_samples);
+  amplitude_controller_metrics m;
+  if (kind == 0) {
+    amplitude_controller_clipping_impl ctl(enable_clipping != 0, input_gain_dB, full_scale_lin, ceiling_dBFS);
+    m = ctl.process(y, x);
+  } else {
+    amplitude_controller_scaling_impl ctl(input_gain_dB);
+    m = ctl.process(y, x);
+  }
+  metrics_out[0]  = m.avg_power_fs;
+  metrics_out[1]  = m.peak_power_fs;
+  metrics_out[2]  = m.papr_lin;
+  metrics_out[3]  = m.gain_dB;
+  counters_out[0] = m.nof_processed_samples;
+  counters_out[1] = m.nof_clipped_samples;
+  return NRPHY_OK;
+}
+
+// srsvec::convert(span<const cf_t>, float scale, span<int16_t>): what the radio layer does with the baseband buffers.
+int ref_convert_cf_to_ci16(const float* in, unsigned nof_samples, float scale, int16_t* out)
+{
+  srsvec::convert(span<const cf_t>(reinterpret_cast<const cf_t*>(in), nof_samples), scale, span<int16_t>(out, 2 * nof_samples));
+  return NRPHY_OK;
+}
+
+// iq_compressor::compress of nof_prb PRBs (cbf16, raw) into the serialised form of the Open Fronthaul user plane:
+// per PRB [udCompParam (BFP only)] + packed IQ (ofh_uplane_message_builder_impl.cpp:137-144).  type 0 none, 1 BFP;
+// simd selects the AVX2 compressor.  Returns the number of bytes written.
+int ref_ofh_compress(int type, int simd, unsigned data_width, float iq_scaling, const uint16_t* grid_prbs, unsigned nof_prb, uint8_t* out)
+{
+  static srslog::basic_logger& logger = srslog::fetch_basic_logger("OFH_REF");
+  std::unique_ptr<ofh::iq_compressor> comp;
+  if (type == 0) {
+    if (simd) {
+      comp = std::make_unique<ofh::iq_compression_none_avx2>(logger, iq_scaling);
+    } else {
+      comp = std::make_unique<ofh::iq_compression_none_impl>(logger, iq_scaling);
+    }
+  } else if (simd) {
+    comp = std::make_unique<ofh::iq_compression_bfp_avx2>(logger, iq_scaling);
+  } else {
+    comp = std::make_unique<ofh::iq_compression_bfp_impl>(logger, iq_scaling);
+  }
+  std::vector<ofh::compressed_prb> prbs(nof_prb);
+  ofh::ru_compression_params       params;
+  params.type       = type == 0 ? ofh::compression_type::none : ofh::compression_type::BFP;
+  params.data_width = data_width;
+  comp->compress(prbs, span<const cbf16_t>(reinterpret_cast<const cbf16_t*>(grid_prbs), 12 * nof_prb), params);
+  unsigned n = 0;
+  for (const ofh::compressed_prb& c : prbs) {
+    if (type != 0) {
+      out[n++] = c.get_compression_param();
+    }
+    span<const uint8_t> d = c.get_packed_data();
+    std::memcpy(out + n, d.data(), d.size());
+    n += d.size();
+  }
+  return static_cast<int>(n);
 }
 
 } // extern "C"

@@ -228,6 +228,32 @@ def make_ssb(*, pattern_case, ssb_idx, L_max, phys_cell_id, payload, sfn=0, nume
     return p
 
 
+class AmplitudeCfg(C.Structure):
+    """nrphy_amplitude_cfg_t (the constructor arguments of amplitude_controller_{clipping,scaling}_impl)."""
+    _fields_ = [("kind", C.c_uint32), ("enable_clipping", C.c_uint32), ("input_gain_dB", C.c_float),
+                ("full_scale_lin", C.c_float), ("ceiling_dBFS", C.c_float)]
+
+
+class AmplitudeStats(C.Structure):
+    _fields_ = [("sum_power", C.c_float), ("peak_power", C.c_float), ("nof_clipped", C.c_uint32), ("nof_samples", C.c_uint32)]
+
+
+class AmplitudeMetrics(C.Structure):
+    """nrphy_amplitude_metrics_t (amplitude_controller_metrics)."""
+    _fields_ = [("avg_power_fs", C.c_float), ("peak_power_fs", C.c_float), ("papr_lin", C.c_float), ("gain_dB", C.c_float),
+                ("nof_processed_samples", C.c_uint64), ("nof_clipped_samples", C.c_uint64),
+                ("clipping_probability", C.c_double), ("clipping_enabled", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
+class IqWireCfg(C.Structure):
+    _fields_ = [("amplitude", AmplitudeCfg), ("ci16_scale", C.c_float)]
+
+
+class OfhCompressionCfg(C.Structure):
+    """nrphy_ofh_compression_cfg_t (ru_compression_params + the compressor's iq_scaling)."""
+    _fields_ = [("type", C.c_uint32), ("data_width", C.c_uint32), ("iq_scaling", C.c_float)]
+
+
 class OfdmConfig(C.Structure):
     _fields_ = [
         ("numerology", C.c_uint32),
@@ -385,6 +411,15 @@ def declare(lib, prefix="nrphy_"):
     sig("ssb_process", i32, vp, u32, P(SsbPdu), P(u32), vp, u32, u32, vp)
     sig("ssb_process_host", i32, vp, P(SsbPdu), vp, u32, u32)
     sig("pbch_encode_host", i32, vp, P(SsbPdu), u8p)
+    sig("amplitude_control", i32, vp, P(AmplitudeCfg), u32, u32, vp, C.c_size_t, vp, C.c_size_t, vp, vp)
+    sig("amplitude_metrics", i32, P(AmplitudeCfg), P(AmplitudeStats), P(AmplitudeMetrics))
+    sig("amplitude_control_host", i32, vp, P(AmplitudeCfg), vp, u32, vp, P(AmplitudeMetrics))
+    sig("iq_convert_ci16", i32, vp, u32, u32, vp, C.c_size_t, C.c_float, vp, C.c_size_t, vp)
+    sig("iq_convert_ci16_host", i32, vp, vp, u32, C.c_float, vp)
+    sig("ofdm_run_ci16", i32, vp, u32, vp, vp, P(IqWireCfg), vp, vp, vp)
+    sig("ofh_compressed_prb_bytes", u32, P(OfhCompressionCfg))
+    sig("ofh_compress", i32, vp, P(OfhCompressionCfg), u32, u32, vp, C.c_size_t, vp, C.c_size_t, vp)
+    sig("ofh_compress_host", i32, vp, P(OfhCompressionCfg), u32, vp, vp)
     sig("pusch_decoder_sizes", i32, P(PuschDecoderCfg), u32, P(u64), P(u64), P(u32))
     sig("pusch_decode_batch", i32, vp, P(PuschDecoderCfg), u32, vp, u64, vp, vp, vp, u32, vp, vp)
     sig("pusch_decode_codeblock_host", i32, vp, P(LdpcRateDematcherCfg), u32, u32, C.c_float, vp, vp, i32, u8p, P(u32))
@@ -408,4 +443,7 @@ ABI_SYMBOLS = [
     "nrphy_llr_descramble", "nrphy_llr_descramble_host",
     "nrphy_pdcch_validate", "nrphy_pdcch_process", "nrphy_pdcch_process_host", "nrphy_pdcch_encode_host",
     "nrphy_ssb_validate", "nrphy_ssb_process", "nrphy_ssb_process_host", "nrphy_pbch_encode_host",
+    "nrphy_amplitude_control", "nrphy_amplitude_metrics", "nrphy_amplitude_control_host", "nrphy_iq_convert_ci16",
+    "nrphy_iq_convert_ci16_host", "nrphy_ofdm_run_ci16", "nrphy_ofh_compressed_prb_bytes", "nrphy_ofh_compress",
+    "nrphy_ofh_compress_host",
 ]

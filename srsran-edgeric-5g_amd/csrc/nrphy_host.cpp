@@ -356,6 +356,7 @@ struct nrphy_ofdm_plan {
   nrphy_ctx*          ctx = nullptr;
   nrphy_ofdm_config_t cfg;
   uint32_t            nof_ports = 0, nsymb = 14, slot_stride = 0, nsym_subframe = 0;
+  const float2*       d_twiddle = nullptr; // the context's table of the DFT size
   float2*             d_phase = nullptr;
   float2*             d_phase_rx = nullptr; // demodulator: conjugate phase x scale (phase_compensation_lut, is_tx = false)
   uint32_t*           d_cp = nullptr;
@@ -2320,6 +2321,7 @@ extern "C" int nrphy_ofdm_plan_create(nrphy_ctx_t* ctx, const nrphy_ofdm_config_
   }
   plan->ctx           = ctx;
   plan->cfg           = *cfg;
+  plan->d_twiddle     = get_twiddle(ctx, cfg->dft_size);
   plan->nof_ports     = nof_ports;
   plan->nsymb         = cfg->cp ? 12 : 14; // get_nsymb_per_slot (cyclic_prefix.h:108-114)
   plan->nsym_subframe = plan->nsymb << cfg->numerology;
@@ -2381,8 +2383,29 @@ extern "C" uint32_t nrphy_ofdm_plan_slot_stride(const nrphy_ofdm_plan_t* plan)
   return plan ? plan->slot_stride : 0;
 }
 
-extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid,
-                              const uint32_t* slot_index, float* d_iq, void* stream)
+namespace {
+
+// Amplitude controller parameters as the reference's constructors derive them
+// (amplitude_controller_clipping_impl.h:52-62, amplitude_controller_scaling_impl.h).
+struct AmplitudeParams {
+  float gain, ceiling;
+  bool  measure, clip;
+};
+bool amplitude_params(const nrphy_amplitude_cfg_t& c, AmplitudeParams& a)
+{
+  if (c.kind > 1) {
+    return false;
+  }
+  a.gain    = std::pow(10.0F, c.input_gain_dB / 20.0F);
+  a.ceiling = c.full_scale_lin * std::pow(10.0F, c.ceiling_dBFS / 20.0F);
+  a.measure = c.kind == 0;
+  a.clip    = c.kind == 0 && c.enable_clipping != 0;
+  // a ceiling that is not a normal number cannot be told from the reference's zero-power exception (see the header)
+  return std::isfinite(a.gain) && (!a.clip || std::isnormal(a.ceiling));
+}
+
+int ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid, const uint32_t* slot_index, void* d_iq,
+             const nrphy_iq_wire_cfg_t* wire, nrphy_amplitude_stats_t* d_stats, void* stream)
 {
   if (plan == nullptr || d_grid == nullptr || d_iq == nullptr) {
     return NRPHY_ERR_ARGUMENT;
@@ -2395,7 +2418,7 @@ extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const
   p.nof_ports   = plan->nof_ports;
   p.nsymb       = plan->nsymb;
   p.slot_stride = plan->slot_stride;
-  p.twiddle     = get_twiddle(ctx, plan->cfg.dft_size);
+  p.twiddle     = plan->d_twiddle;
   p.phase       = plan->d_phase;
   p.cp_len      = plan->d_cp;
   p.sym_offset  = plan->d_off;
@@ -2404,7 +2427,22 @@ extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const
     static const char* probe_env = std::getenv("NRPHY_OFDM_PROBE");
     p.probe                      = probe_env ? (uint32_t)std::atoi(probe_env) : 0;
   }
-  hipStream_t s  = stream ? (hipStream_t)stream : ctx->stream;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  if (wire != nullptr) {
+    AmplitudeParams a;
+    if (!amplitude_params(wire->amplitude, a) || !std::isfinite(wire->ci16_scale)) {
+      return NRPHY_ERR_ARGUMENT;
+    }
+    p.wire         = 1;
+    p.wire_clip    = a.clip ? 1U : 0U;
+    p.wire_gain    = a.gain;
+    p.wire_ceiling = a.ceiling;
+    p.wire_scale   = wire->ci16_scale;
+    p.wire_stats   = a.measure ? d_stats : nullptr;
+    if (d_stats != nullptr) {
+      HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(nrphy_amplitude_stats_t) * (size_t)nof_grids * plan->nof_ports, s));
+    }
+  }
   hipEvent_t* ev = nullptr;
   if (plan->timed_runs < plan->max_timed_runs) {
     ev = &plan->events[2 * plan->timed_runs++];
@@ -2414,6 +2452,212 @@ extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const
   if (ev) {
     HIP_TRY(hipEventRecord(ev[1], s));
   }
+  return NRPHY_OK;
+}
+
+} // namespace
+
+extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid,
+                              const uint32_t* slot_index, float* d_iq, void* stream)
+{
+  return ofdm_run(plan, nof_grids, d_grid, slot_index, d_iq, nullptr, nullptr, stream);
+}
+
+extern "C" int nrphy_ofdm_run_ci16(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid, const uint32_t* slot_index,
+                                   const nrphy_iq_wire_cfg_t* cfg, int16_t* d_iq, nrphy_amplitude_stats_t* d_stats, void* stream)
+{
+  if (cfg == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  return ofdm_run(plan, nof_grids, d_grid, slot_index, d_iq, cfg, d_stats, stream);
+}
+
+// ================================================================================================================
+// Lower-PHY tail: amplitude controller, radio sample format, fronthaul compression
+// ================================================================================================================
+extern "C" int nrphy_amplitude_control(nrphy_ctx_t* ctx, const nrphy_amplitude_cfg_t* cfg, uint32_t n_buffers, uint32_t nof_samples,
+                                       const float* d_in, size_t in_stride, float* d_out, size_t out_stride,
+                                       nrphy_amplitude_stats_t* d_stats, void* stream)
+{
+  AmplitudeParams a;
+  if (ctx == nullptr || cfg == nullptr || d_in == nullptr || d_out == nullptr || !amplitude_params(*cfg, a) ||
+      (n_buffers > 1 && (in_stride < nof_samples || out_stride < nof_samples))) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  if (d_stats != nullptr) {
+    HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(nrphy_amplitude_stats_t) * (size_t)n_buffers, s));
+  }
+  for (uint32_t first = 0; first < n_buffers; first += 32768) { // the launch's second grid dimension holds 65535
+    AmplitudeLaunch p;
+    p.in          = d_in + 2 * first * in_stride;
+    p.out         = d_out + 2 * first * out_stride;
+    p.in_stride   = in_stride;
+    p.out_stride  = out_stride;
+    p.nof_samples = nof_samples;
+    p.measure     = a.measure ? 1U : 0U;
+    p.clip        = a.clip ? 1U : 0U;
+    p.gain        = a.gain;
+    p.ceiling     = a.ceiling;
+    p.stats       = d_stats ? d_stats + first : nullptr;
+    HIP_TRY(launch_amplitude(p, std::min<uint32_t>(32768, n_buffers - first), s));
+  }
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_amplitude_metrics(const nrphy_amplitude_cfg_t* cfg, const nrphy_amplitude_stats_t* stats,
+                                       nrphy_amplitude_metrics_t* m)
+{
+  if (cfg == nullptr || stats == nullptr || m == nullptr || cfg->kind > 1) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (cfg->kind == 1) { // amplitude_controller_scaling_impl returns empty metrics
+    std::memset(m, 0, sizeof(*m));
+    return NRPHY_OK;
+  }
+  // amplitude_controller_clipping_impl::process, the part after the vector operations
+  const float full_scale_pwr = cfg->full_scale_lin * cfg->full_scale_lin;
+  const float avg            = stats->nof_samples ? stats->sum_power / (float)stats->nof_samples : 0.0F;
+  m->clipping_enabled        = cfg->enable_clipping ? 1U : 0U;
+  m->gain_dB                 = 20.0F * std::log10(std::pow(10.0F, cfg->input_gain_dB / 20.0F)); // convert_amplitude_to_dB
+  m->avg_power_fs            = avg / full_scale_pwr;
+  m->peak_power_fs           = stats->peak_power / full_scale_pwr;
+  if (!std::isnormal(avg) || !std::isnormal(stats->peak_power)) {
+    m->papr_lin = 1.0F;
+    return NRPHY_OK;
+  }
+  m->papr_lin = stats->peak_power / avg;
+  if (cfg->enable_clipping) {
+    m->nof_processed_samples += stats->nof_samples;
+    m->nof_clipped_samples += stats->nof_clipped;
+    m->clipping_probability = (double)m->nof_clipped_samples / (double)m->nof_processed_samples;
+  }
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_amplitude_control_host(nrphy_ctx_t* ctx, const nrphy_amplitude_cfg_t* cfg, const float* in,
+                                            uint32_t nof_samples, float* out, nrphy_amplitude_metrics_t* metrics)
+{
+  if (ctx == nullptr || cfg == nullptr || in == nullptr || out == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)nof_samples * sizeof(float2);
+  float*       d_buf = (float*)ctx_scratch(ctx, SCRATCH_IQ, bytes + 64);
+  if (d_buf == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  nrphy_amplitude_stats_t* d_stats = (nrphy_amplitude_stats_t*)((uint8_t*)d_buf + ((bytes + 15) & ~(size_t)15));
+  HIP_TRY(hipMemcpyAsync(d_buf, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int rc = nrphy_amplitude_control(ctx, cfg, 1, nof_samples, d_buf, nof_samples, d_buf, nof_samples, d_stats, ctx->stream);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  nrphy_amplitude_stats_t st;
+  HIP_TRY(hipMemcpyAsync(out, d_buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&st, d_stats, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return metrics ? nrphy_amplitude_metrics(cfg, &st, metrics) : NRPHY_OK;
+}
+
+extern "C" int nrphy_iq_convert_ci16(nrphy_ctx_t* ctx, uint32_t n_buffers, uint32_t nof_samples, const float* d_in, size_t in_stride,
+                                     float scale, int16_t* d_out, size_t out_stride, void* stream)
+{
+  if (ctx == nullptr || d_in == nullptr || d_out == nullptr || !std::isfinite(scale) ||
+      (n_buffers > 1 && (in_stride < nof_samples || out_stride < nof_samples))) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  for (uint32_t first = 0; first < n_buffers; first += 32768) {
+    HIP_TRY(launch_convert_ci16(d_in + 2 * first * in_stride, in_stride, d_out + 2 * first * out_stride, out_stride,
+                                std::min<uint32_t>(32768, n_buffers - first), nof_samples, scale, s));
+  }
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_iq_convert_ci16_host(nrphy_ctx_t* ctx, const float* in, uint32_t nof_samples, float scale, int16_t* out)
+{
+  if (ctx == nullptr || in == nullptr || out == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)nof_samples * sizeof(float2), obytes = (size_t)nof_samples * 4;
+  uint8_t*     d_buf = (uint8_t*)ctx_scratch(ctx, SCRATCH_IQ, bytes + obytes + 64);
+  if (d_buf == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  int16_t* d_out = (int16_t*)(d_buf + ((bytes + 15) & ~(size_t)15));
+  HIP_TRY(hipMemcpyAsync(d_buf, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int rc = nrphy_iq_convert_ci16(ctx, 1, nof_samples, (const float*)d_buf, nof_samples, scale, d_out, nof_samples, ctx->stream);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(out, d_out, obytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return NRPHY_OK;
+}
+
+extern "C" uint32_t nrphy_ofh_compressed_prb_bytes(const nrphy_ofh_compression_cfg_t* cfg)
+{
+  return cfg ? 3U * cfg->data_width + (cfg->type == 1 ? 1U : 0U) : 0U;
+}
+
+extern "C" int nrphy_ofh_compress(nrphy_ctx_t* ctx, const nrphy_ofh_compression_cfg_t* cfg, uint32_t n_rows, uint32_t nof_prb,
+                                  const void* d_prbs, size_t row_stride, uint8_t* d_out, size_t out_row_stride, void* stream)
+{
+  // Below 8 bits the reference's packer has no defined result (it hands bit_buffer::insert values wider than the
+  // field, compressed_prb_packer.cpp:39-47).
+  if (ctx == nullptr || cfg == nullptr || d_prbs == nullptr || d_out == nullptr || cfg->type > 1 || cfg->data_width < 8 ||
+      cfg->data_width > 16 || !std::isfinite(cfg->iq_scaling) || nof_prb > NRPHY_MAX_RB ||
+      (n_rows > 1 && (row_stride < 12 * (size_t)nof_prb || out_row_stride < (size_t)nof_prb * nrphy_ofh_compressed_prb_bytes(cfg)))) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  for (uint32_t first = 0; first < n_rows; first += 32768) {
+    OfhCompressLaunch p;
+    p.prbs           = (const uint32_t*)d_prbs + first * row_stride;
+    p.out            = d_out + first * out_row_stride;
+    p.row_stride     = row_stride;
+    p.out_row_stride = out_row_stride;
+    p.nof_prb        = nof_prb;
+    p.data_width     = cfg->data_width;
+    p.bfp            = cfg->type == 1 ? 1U : 0U;
+    // the AVX2 compressors convert the whole call at once for BFP and for the widths their packer has (9, 16)
+    p.whole_span = (cfg->type == 1 || cfg->data_width == 9 || cfg->data_width == 16) ? 1U : 0U;
+    // quantizer: gain = 2^(width - 1) - 1, 16 bits for BFP (Q_BIT_WIDTH); scale = gain * iq_scaling in float
+    const float gain = (float)((1 << ((cfg->type == 1 ? 16 : (int)cfg->data_width) - 1)) - 1.0F);
+    p.scale          = gain * cfg->iq_scaling;
+    HIP_TRY(launch_ofh_compress(p, std::min<uint32_t>(32768, n_rows - first), s));
+  }
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ofh_compress_host(nrphy_ctx_t* ctx, const nrphy_ofh_compression_cfg_t* cfg, uint32_t nof_prb, const void* prbs,
+                                       uint8_t* out)
+{
+  if (ctx == nullptr || cfg == nullptr || prbs == nullptr || out == nullptr || nof_prb == 0 || nof_prb > NRPHY_MAX_RB) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t in_bytes = (size_t)nof_prb * 48, out_bytes = (size_t)nof_prb * 49;
+  uint8_t*     d_buf    = (uint8_t*)ctx_scratch(ctx, SCRATCH_GRID, in_bytes + out_bytes + 64);
+  if (d_buf == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  uint8_t* d_out = d_buf + ((in_bytes + 15) & ~(size_t)15);
+  HIP_TRY(hipMemcpyAsync(d_buf, prbs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const int rc = nrphy_ofh_compress(ctx, cfg, 1, nof_prb, d_buf, 12 * (size_t)nof_prb, d_out, out_bytes, ctx->stream);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)nof_prb * nrphy_ofh_compressed_prb_bytes(cfg), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return NRPHY_OK;
 }
 
@@ -2433,7 +2677,7 @@ extern "C" int nrphy_ofdm_demod_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids,
   p.nof_ports   = plan->nof_ports;
   p.nsymb       = plan->nsymb;
   p.slot_stride = plan->slot_stride;
-  p.twiddle     = get_twiddle(ctx, plan->cfg.dft_size);
+  p.twiddle     = plan->d_twiddle;
   p.phase       = plan->d_phase_rx;
   p.cp_len      = plan->d_cp;
   p.sym_offset  = plan->d_off;

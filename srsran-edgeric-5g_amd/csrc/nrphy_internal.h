@@ -361,7 +361,33 @@ struct OfdmLaunch {
   const uint32_t* cp_len;     // [symbols per subframe]
   const uint32_t* sym_offset; // [symbols per subframe] start of the symbol within its slot (samples)
   uint32_t       probe;       // NRPHY_OFDM_PROBE: timing-only runs with the loads and/or stores range-checked away
+  // Wire-format output (nrphy_ofdm_run_ci16): amplitude controller + int16 conversion fused into the store; d_iq then
+  // points at complex int16 samples.
+  uint32_t       wire = 0, wire_clip = 0;
+  float          wire_gain = 1.f, wire_ceiling = 0.f, wire_scale = 1.f;
+  nrphy_amplitude_stats_t* wire_stats = nullptr; // [grid][port], may be null
 };
+
+// ---- lower-PHY tail ("next" row: amplitude controller, radio sample format, fronthaul compression) ----------------------
+struct AmplitudeLaunch {
+  const float* in;
+  float*       out;
+  size_t       in_stride, out_stride; // complex samples between buffers
+  uint32_t     nof_samples, measure, clip;
+  float        gain, ceiling;
+  nrphy_amplitude_stats_t* stats; // per buffer, cleared by the caller; may be null
+};
+hipError_t launch_amplitude(const AmplitudeLaunch& p, uint32_t n_buffers, hipStream_t stream);
+hipError_t launch_convert_ci16(const float* in, size_t in_stride, int16_t* out, size_t out_stride, uint32_t n_buffers,
+                               uint32_t nof_samples, float scale, hipStream_t stream);
+struct OfhCompressLaunch {
+  const uint32_t* prbs;      // cbf16 words
+  uint8_t*        out;
+  size_t          row_stride, out_row_stride; // words / bytes between rows
+  uint32_t        nof_prb, data_width, bfp, whole_span;
+  float           scale;     // quantiser gain * iq_scaling
+};
+hipError_t launch_ofh_compress(const OfhCompressLaunch& p, uint32_t n_rows, hipStream_t stream);
 hipError_t launch_ofdm(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* d_grid, const uint32_t* d_slot_index,
                        float2* d_iq, hipStream_t stream);
 // OFDM demodulation (the receive-side mirror of launch_ofdm): `p.phase` is the receive table (conjugate phase x scale),

@@ -537,6 +537,91 @@ struct IqSink {
   }
 };
 
+// The same output side with the samples leaving as complex int16: every sample goes through
+// the reference's chain behind the modulator in its order of roundings -- amplitude controller (gain, optional
+// clipping of real and imaginary parts: amplitude_controller_clipping_impl.cpp:31-68) and the radio's sample conversion
+// (value * scale, round to nearest even, saturate: R/lib/srsvec/conversion.cpp:29-65) -- and 4 bytes instead of 8 go to
+// HBM.  The controller's measurements (sum and maximum of |x|^2 after the gain, clipped parts) accumulate per thread;
+// a sample inside the cyclic prefix counts twice, as in the buffer the reference measures.
+template <int N>
+struct IqSinkCi16 {
+  __amdgpu_buffer_rsrc_t rsrc;
+  cf                     ph;
+  uint32_t               cp;
+  float                  gain, ceiling, scale;
+  bool                   clip;
+  float*                 sum;
+  float*                 peak;
+  uint32_t*              clipped;
+
+  __device__ __forceinline__ uint32_t convert(cf v, uint32_t idx) const
+  {
+    const cf       y  = cmul_uniform(v, ph);
+    float          re = __fmul_rn(y.x, gain), im = __fmul_rn(y.y, gain);
+    const uint32_t copies = idx >= N - cp ? 2u : 1u;
+    const float    pw = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    *sum += copies == 2u ? pw + pw : pw;
+    *peak = fmaxf(*peak, pw);
+    if (clip) {
+      uint32_t c = 0;
+      if (re > ceiling) {
+        re = ceiling, ++c;
+      } else if (re < -ceiling) {
+        re = -ceiling, ++c;
+      }
+      if (im > ceiling) {
+        im = ceiling, ++c;
+      } else if (im < -ceiling) {
+        im = -ceiling, ++c;
+      }
+      *clipped += c * copies;
+    }
+    int a = __float2int_rn(__fmul_rn(re, scale)), b = __float2int_rn(__fmul_rn(im, scale));
+    a     = a > 32767 ? 32767 : (a < -32768 ? -32768 : a);
+    b     = b > 32767 ? 32767 : (b < -32768 ? -32768 : b);
+    return ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16);
+  }
+
+  __device__ __forceinline__ void prefix_copy(uint32_t i, uint32_t d) const
+  {
+    if (i >= N - cp) {
+      __builtin_amdgcn_raw_buffer_store_b32(d, rsrc, (int)((i - (N - cp)) * 4u), 0, AUX_NT);
+    }
+  }
+
+  template <uint32_t B, uint32_t S>
+  __device__ __forceinline__ void operator()(uint32_t q, Const<B>, Const<S>, cf v) const
+  {
+    const uint32_t d = convert(v, q + B);
+    __builtin_amdgcn_raw_buffer_store_b32(d, rsrc, (int)(q * 4u), (int)((cp + B) * 4u), AUX_NT);
+    if constexpr (B + S > N - N / 4) {
+      prefix_copy(q + B, d);
+    }
+  }
+
+  template <uint32_t S, int R>
+  __device__ __forceinline__ void operator()(uint32_t q, Const<S>, cf (&a)[R]) const
+  {
+    const bool     odd  = (q & 1u) != 0;
+    const uint32_t voff = ((q & ~1u) + (odd ? S : 0u)) * 4u;
+    static_for<R / 2>([&](auto I) {
+      constexpr uint32_t j0   = 2 * decltype(I)::value;
+      const cf           keep = odd ? a[j0 + 1] : a[j0];
+      const cf           recv = from_neighbour(odd ? a[j0] : a[j0 + 1]);
+      const uint32_t     i    = (q & ~1u) + S * (odd ? j0 + 1 : j0);
+      const u32x2_t      d    = {convert(odd ? recv : keep, i), convert(odd ? keep : recv, i + 1u)};
+      __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)voff, (int)((cp + S * j0) * 4u), AUX_NT);
+      if constexpr (S * (j0 + 2) > N - N / 4) {
+        prefix_copy(i, d.x);
+        prefix_copy(i + 1u, d.y);
+      }
+    });
+    if constexpr (R % 2 != 0) {
+      (*this)(q, Const<S * (R - 1)>{}, Const<S>{}, a[R - 1]);
+    }
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void load_symbol_row(uint32_t (&raw)[Plan<N>::R0], const OfdmLaunch& p,
                                                 const uint32_t* row, uint32_t t4)
@@ -555,7 +640,7 @@ __device__ __forceinline__ void load_symbol_row(uint32_t (&raw)[Plan<N>::R0], co
   }
 }
 
-template <int N, int SPW>
+template <int N, int SPW, bool WIRE>
 __global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_grid,
                                                           const uint32_t* __restrict__ d_slot_index,
                                                           float2* __restrict__ d_iq)
@@ -569,6 +654,8 @@ __global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const ui
   const uint32_t    t4   = (tid + (p.rg_size >> 1)) * 4u;
   const uint32_t*   rows = d_grid + (size_t)gp * NRPHY_NSYMB * p.rg_size;
   float2*           iq   = d_iq + (size_t)gp * p.slot_stride;
+  float             w_sum = 0.f, w_peak = 0.f; // amplitude controller measurements of this thread (WIRE)
+  uint32_t          w_clipped = 0;
 
   const TwiddleBase<N> tb = load_twiddle_base<+1, N>(p.twiddle, tid);
   uint32_t             raw[Plan<N>::R0];
@@ -589,10 +676,37 @@ __global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const ui
     const uint32_t sym = slot * p.nsymb + l; // symbol index within the subframe
     const uint32_t cp  = to_constant(p.cp_len)[sym];
     const cf       ph  = make_cf(to_constant(p.phase)[sym].x, to_constant(p.phase)[sym].y);
-    const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
-        iq + to_constant(p.sym_offset)[sym], 0, (int)((p.probe & 1u) ? 0u : (N + cp) * 8u), 0x00020000);
-    const IqSink<N> store = {rsrc_out, ph, cp};
-    fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
+    if constexpr (WIRE) {
+      // complex int16 out: [grid][port][slot_stride] samples of 4 bytes
+      uint32_t* iq16 = reinterpret_cast<uint32_t*>(d_iq) + (size_t)gp * p.slot_stride + to_constant(p.sym_offset)[sym];
+      const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(iq16, 0, (int)((N + cp) * 4u), 0x00020000);
+      const IqSinkCi16<N> store = {rsrc_out, ph, cp, p.wire_gain, p.wire_ceiling, p.wire_scale, p.wire_clip != 0, &w_sum, &w_peak, &w_clipped};
+      fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
+    } else {
+      const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
+          iq + to_constant(p.sym_offset)[sym], 0, (int)((p.probe & 1u) ? 0u : (N + cp) * 8u), 0x00020000);
+      const IqSink<N> store = {rsrc_out, ph, cp};
+      fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
+    }
+  }
+  if constexpr (WIRE) {
+    if (p.wire_stats != nullptr) { // wave-uniform
+      for (int o = WAVE / 2; o != 0; o >>= 1) {
+        w_sum += __shfl_xor(w_sum, o, WAVE);
+        w_peak = fmaxf(w_peak, __shfl_xor(w_peak, o, WAVE));
+        w_clipped += __shfl_xor(w_clipped, o, WAVE);
+      }
+      if ((tid & (WAVE - 1)) == 0) {
+        nrphy_amplitude_stats_t* st = p.wire_stats + gp;
+        atomicAdd(&st->sum_power, w_sum);
+        atomicMax(reinterpret_cast<uint32_t*>(&st->peak_power), __float_as_uint(w_peak));
+        atomicAdd(&st->nof_clipped, w_clipped);
+        if (tid == 0 && blockIdx.x == 0) {
+          const uint32_t last = slot * p.nsymb + p.nsymb - 1u;
+          st->nof_samples     = to_constant(p.sym_offset)[last] + to_constant(p.cp_len)[last] + N;
+        }
+      }
+    }
   }
 }
 
@@ -609,8 +723,13 @@ static hipError_t launch_ofdm_n(const OfdmLaunch& p, uint32_t nof_grids, const u
                                 const uint32_t* d_slot_index, float2* d_iq, hipStream_t stream)
 {
   constexpr int SPW    = OFDM_SYMBOLS_PER_WG;
-  hipLaunchKernelGGL((ofdm_kernel<N, SPW>), dim3((p.nsymb + SPW - 1) / SPW, p.nof_ports, nof_grids), dim3(Plan<N>::T), 0, stream, p,
-                     d_grid, d_slot_index, d_iq);
+  if (p.wire) {
+    hipLaunchKernelGGL((ofdm_kernel<N, SPW, true>), dim3((p.nsymb + SPW - 1) / SPW, p.nof_ports, nof_grids), dim3(Plan<N>::T), 0,
+                       stream, p, d_grid, d_slot_index, d_iq);
+  } else {
+    hipLaunchKernelGGL((ofdm_kernel<N, SPW, false>), dim3((p.nsymb + SPW - 1) / SPW, p.nof_ports, nof_grids), dim3(Plan<N>::T), 0,
+                       stream, p, d_grid, d_slot_index, d_iq);
+  }
   return hipGetLastError();
 }
 

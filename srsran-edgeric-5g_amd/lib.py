@@ -219,6 +219,48 @@ class Context:
         _check(self.lib.nrphy_pbch_encode_host(self.handle, C.byref(pdu), out.ctypes.data), "nrphy_pbch_encode_host")
         return out
 
+    # ---- lower-PHY tail (amplitude controller, radio sample format, fronthaul compression) ------------------------
+    def amplitude_control(self, cfg, n_buffers, nof_samples, d_in, d_out, d_stats=None, in_stride=None, out_stride=None,
+                          stream=None):
+        """amplitude_controller::process for n_buffers device buffers of nof_samples complex floats."""
+        _check(self.lib.nrphy_amplitude_control(self.handle, C.byref(cfg), n_buffers, nof_samples, _dptr(d_in),
+                                                in_stride or nof_samples, _dptr(d_out), out_stride or nof_samples,
+                                                _dptr(d_stats), stream), "nrphy_amplitude_control")
+
+    def amplitude_control_host(self, cfg, x, metrics=None):
+        """One host buffer (complex64) -> (output, abi.AmplitudeMetrics updated in place when given)."""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.zeros_like(x)
+        m = metrics if metrics is not None else abi.AmplitudeMetrics()
+        _check(self.lib.nrphy_amplitude_control_host(self.handle, C.byref(cfg), x.ctypes.data, x.size, out.ctypes.data,
+                                                     C.byref(m)), "nrphy_amplitude_control_host")
+        return out, m
+
+    def iq_convert_ci16_host(self, x, scale):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.zeros(2 * x.size, np.int16)
+        _check(self.lib.nrphy_iq_convert_ci16_host(self.handle, x.ctypes.data, x.size, scale, out.ctypes.data),
+               "nrphy_iq_convert_ci16_host")
+        return out
+
+    def iq_convert_ci16(self, n_buffers, nof_samples, d_in, scale, d_out, in_stride=None, out_stride=None, stream=None):
+        _check(self.lib.nrphy_iq_convert_ci16(self.handle, n_buffers, nof_samples, _dptr(d_in), in_stride or nof_samples,
+                                              scale, _dptr(d_out), out_stride or nof_samples, stream), "nrphy_iq_convert_ci16")
+
+    def ofh_compress_host(self, cfg, prbs):
+        """iq_compressor::compress + serialisation: prbs [nof_prb][12][2] uint16 (raw cbf16) -> bytes."""
+        prbs = np.ascontiguousarray(prbs, dtype=np.uint16)
+        nof_prb = prbs.size // 24
+        out = np.zeros(nof_prb * self.lib.nrphy_ofh_compressed_prb_bytes(C.byref(cfg)), np.uint8)
+        _check(self.lib.nrphy_ofh_compress_host(self.handle, C.byref(cfg), nof_prb, prbs.ctypes.data, out.ctypes.data),
+               "nrphy_ofh_compress_host")
+        return out
+
+    def ofh_compress(self, cfg, n_rows, nof_prb, d_prbs, d_out, row_stride=None, out_row_stride=None, stream=None):
+        rec = self.lib.nrphy_ofh_compressed_prb_bytes(C.byref(cfg))
+        _check(self.lib.nrphy_ofh_compress(self.handle, C.byref(cfg), n_rows, nof_prb, _dptr(d_prbs), row_stride or 12 * nof_prb,
+                                           _dptr(d_out), out_row_stride or rec * nof_prb, stream), "nrphy_ofh_compress")
+
     def pusch_decoder_sizes(self, cfg, n_tb):
         """(soft-buffer bytes per transport block, state bytes of the batch, codeblocks per transport block)."""
         soft, state, ncb = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
@@ -323,6 +365,11 @@ class OfdmPlan:
     def run(self, nof_grids, d_grid, d_iq, d_slot_index=None, stream=None):
         _check(self.ctx.lib.nrphy_ofdm_run(self.handle, nof_grids, _dptr(d_grid), _dptr(d_slot_index), _dptr(d_iq),
                                            stream), "nrphy_ofdm_run")
+
+    def run_ci16(self, nof_grids, d_grid, wire_cfg, d_iq16, d_slot_index=None, d_stats=None, stream=None):
+        """nrphy_ofdm_run with the amplitude controller and the complex int16 conversion fused into the store."""
+        _check(self.ctx.lib.nrphy_ofdm_run_ci16(self.handle, nof_grids, _dptr(d_grid), _dptr(d_slot_index), C.byref(wire_cfg),
+                                                _dptr(d_iq16), _dptr(d_stats), stream), "nrphy_ofdm_run_ci16")
 
     def enable_timing(self, max_runs):
         _check(self.ctx.lib.nrphy_ofdm_plan_enable_timing(self.handle, max_runs), "nrphy_ofdm_plan_enable_timing")

@@ -366,6 +366,56 @@ class CpuBackend:
         assert rc == 0, rc
         return out
 
+    # ---- lower-PHY tail (section 8f-3) ------------------------------------------------------------------------
+    def amplitude_control(self, cfg, x):
+        """amplitude_controller::process on one buffer (complex64) -> (output, dict of measurements).  For the reference:
+        avg_power_fs, peak_power_fs, papr_lin, gain_dB, nof_processed, nof_clipped; for the oracle the raw statistics."""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.zeros_like(x)
+        if self.is_ref:
+            m, cnt = np.zeros(4, np.float32), np.zeros(2, np.uint64)
+            f = self._f("amplitude_control")
+            f.restype = C.c_int
+            rc = f(C.c_int(cfg.kind), C.c_int(cfg.enable_clipping), C.c_float(cfg.input_gain_dB), C.c_float(cfg.full_scale_lin),
+                   C.c_float(cfg.ceiling_dBFS), _ptr(x), C.c_uint32(x.size), _ptr(out), _ptr(m), _ptr(cnt))
+            assert rc == 0
+            return out, dict(avg_power_fs=float(m[0]), peak_power_fs=float(m[1]), papr_lin=float(m[2]), gain_dB=float(m[3]),
+                             nof_processed=int(cnt[0]), nof_clipped=int(cnt[1]))
+        st = abi.AmplitudeStats()
+        f = self._f("amplitude_control")
+        f.restype = C.c_int
+        assert f(C.byref(cfg), _ptr(x), C.c_uint32(x.size), _ptr(out), C.byref(st)) == 0
+        m = abi.AmplitudeMetrics()
+        g = self._f("amplitude_metrics")
+        g.restype = C.c_int
+        assert g(C.byref(cfg), C.byref(st), C.byref(m)) == 0
+        return out, dict(avg_power_fs=m.avg_power_fs, peak_power_fs=m.peak_power_fs, papr_lin=m.papr_lin, gain_dB=m.gain_dB,
+                         nof_processed=int(m.nof_processed_samples), nof_clipped=int(m.nof_clipped_samples), stats=st)
+
+    def iq_convert_ci16(self, x, scale):
+        """srsvec::convert(cf -> int16 with scale): complex64 [n] -> int16 [2n]."""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.zeros(2 * x.size, np.int16)
+        f = self._f("convert_cf_to_ci16" if self.is_ref else "iq_convert_ci16")
+        f.restype = C.c_int
+        assert f(_ptr(x), C.c_uint32(x.size), C.c_float(scale), _ptr(out)) == 0
+        return out
+
+    def ofh_compress(self, cfg, prbs, simd=0):
+        """iq_compressor::compress + serialisation of one call's PRBs: prbs [nof_prb][12][2] uint16 (raw cbf16) -> bytes."""
+        prbs = np.ascontiguousarray(prbs, dtype=np.uint16)
+        nof_prb = prbs.size // 24
+        out = np.zeros(nof_prb * 49, np.uint8)
+        f = self._f("ofh_compress")
+        f.restype = C.c_int
+        if self.is_ref:
+            n = f(C.c_int(cfg.type), C.c_int(simd), C.c_uint32(cfg.data_width), C.c_float(cfg.iq_scaling), _ptr(prbs),
+                  C.c_uint32(nof_prb), _ptr(out))
+        else:
+            n = f(C.byref(cfg), _ptr(prbs), C.c_uint32(nof_prb), _ptr(out))
+        assert n > 0, n
+        return out[:n].copy()
+
     def codebook(self, kind, a=0, b=0, c=0):
         assert self.is_ref
         w = np.zeros((4, 4, 2), np.float32)
@@ -381,7 +431,7 @@ _REF = None
 def build_oracle():
     """Compiles oracle/liboracle.so when missing or stale (gcc, a second or two)."""
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", n) for n in ("nrphy_oracle.c", "nrphy_oracle_dl.c", "nrphy_oracle.h")]
+    srcs = [os.path.join(ROOT, "oracle", n) for n in ("nrphy_oracle.c", "nrphy_oracle_dl.c", "nrphy_oracle_lower.c", "nrphy_oracle.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, capture_output=True,
                        timeout=300)

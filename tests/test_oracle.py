@@ -514,6 +514,59 @@ def test_oracle_vs_ref_ssb_processor(oracle, ref):
         assert np.array_equal(oracle.ssb_process(pdu, grid), ref.ssb_process(pdu, grid))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# 2c. lower-PHY tail: amplitude controller, cf32 -> ci16, Open Fronthaul compression
+# ---------------------------------------------------------------------------------------------------------------------
+def test_oracle_vs_ref_amplitude_controller_and_ci16(oracle, ref):
+    """amplitude_controller_{clipping,scaling}_impl::process (samples bit for bit, measurements to float accuracy, clip
+    counts exactly) and srsvec::convert to int16 (vector lanes round to nearest even and saturate, the tail of a call
+    rounds half away: exact ties included)."""
+    rng = np.random.default_rng(4)
+    for t in range(60):
+        n = int(rng.integers(1, 3000))
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) * float(rng.choice([0.1, 0.5, 1.0]))
+        if t == 0:
+            x[:] = 0   # zero power: the reference reports PAPR 1 and leaves the counters alone
+        cfg = abi.AmplitudeCfg(int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.choice([0.0, -3.0, 2.5])),
+                               float(rng.choice([1.0, 2.0])), float(rng.choice([-0.1, -6.0, -12.0])))
+        ya, ma = oracle.amplitude_control(cfg, x)
+        yb, mb = ref.amplitude_control(cfg, x)
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+        for k in ("avg_power_fs", "peak_power_fs", "papr_lin", "gain_dB"):
+            assert abs(ma[k] - mb[k]) <= 2e-5 * max(1e-9, abs(mb[k])), (k, ma[k], mb[k])
+        assert (ma["nof_clipped"], ma["nof_processed"]) == (mb["nof_clipped"], mb["nof_processed"])
+        scale = float(rng.choice([32767.0, 1000.0, 20000.0]))
+        assert np.array_equal(oracle.iq_convert_ci16(x, scale), ref.iq_convert_ci16(x, scale))
+    x = np.zeros(37, np.complex64)
+    x.real, x.imag = np.arange(37) + 0.5, -(np.arange(37) + 0.5)
+    for k in (1.0, 2000.0):   # ties; saturation in the vector lanes
+        assert np.array_equal(oracle.iq_convert_ci16(x * k, 1.0), ref.iq_convert_ci16(x * k, 1.0))
+
+
+def test_oracle_vs_ref_ofh_compression(oracle, ref):
+    """iq_compression_{none,bfp}: the reference's AVX2 compressors (what its factory picks on this host) for every
+    supported width, 1-59 PRBs per call, all-zero PRBs, exact ties; and its generic compressors wherever the two agree
+    by construction (BFP: always)."""
+    rng = np.random.default_rng(4)
+    for t in range(300):
+        typ, w, nprb = int(rng.integers(0, 2)), int(rng.integers(8, 17)), int(rng.integers(1, 60))
+        x = (rng.standard_normal((nprb, 12, 2)) * float(rng.choice([0.01, 0.2, 0.33]))).astype(np.float32)
+        prbs = (x.view(np.uint32) >> 16).astype(np.uint16)
+        if t % 7 == 0:
+            prbs[0] = 0
+        cfg = abi.OfhCompressionCfg(typ, w, float(rng.choice([1.0, 0.5, 0.9])))
+        got = oracle.ofh_compress(cfg, prbs)
+        assert np.array_equal(got, ref.ofh_compress(cfg, prbs, 1)), (typ, w, nprb)
+        if typ == 1:
+            assert np.array_equal(got, ref.ofh_compress(cfg, prbs, 0)), (typ, w, nprb)
+    for w, typ in ((9, 0), (16, 0), (12, 0), (9, 1), (14, 1)):
+        gain = ((1 << (w - 1)) - 1) if typ == 0 else 32767
+        vals = (np.arange(24 * 5) % 40 - 20 + 0.5).astype(np.float32)   # half-integers, exact in bf16
+        prbs = (vals.view(np.uint32) >> 16).astype(np.uint16).reshape(5, 12, 2)
+        cfg = abi.OfhCompressionCfg(typ, w, 1.0 / gain)
+        assert np.array_equal(oracle.ofh_compress(cfg, prbs), ref.ofh_compress(cfg, prbs, 1)), (w, typ)
+
+
 def dl_control_golden(kind, i):
     """(PDU, packed encoder output, expected grid) of entry i of tests/golden/dl_control.npz."""
     g = np.load(os.path.join(cases.GOLDEN, "dl_control.npz"))
