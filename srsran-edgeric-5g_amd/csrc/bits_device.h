@@ -269,22 +269,51 @@ __device__ inline void gold_sequence_workgroup(const GoldTables* gold, const uin
   if (nwords == 0) { // workgroup-uniform
     return;
   }
+  // Seeding.  Wave 0 jumps the state to the part's offset; then all waves share the 31 seed words: wave w evaluates
+  // bit positions 8w .. 8w + 7 of every word (eight independent table rows per lane, requested together) and ORs its
+  // share into the ring.  (The seed used to be wave 0's alone, 32 dependent-latency rows per lane, while the other
+  // waves waited: at four parts per PDU it was most of the sequence role's time.)
+  static_assert(NT == 4 * WAVE, "four waves share the seed words");
+  if (tid < 31u) {
+    ring[tid] = 0u;
+  }
   if (tid < WAVE) {
     uint32_t       state  = c_init & 0x7FFFFFFFu;
     const uint32_t offset = 1600u + 32u * first_word;
-#pragma unroll 1
+    // The rows of every jump matrix the offset needs are requested before the first one is used: the products depend on
+    // each other (the state), the loads do not -- taken one by one, every step paid a trip to L2.
+    uint32_t row[GOLD_JUMP_BITS];
+#pragma unroll
+    for (uint32_t k = 0; k != GOLD_JUMP_BITS; ++k) {
+      row[k] = ((offset >> k) & 1u) ? gold->x2_jump[k][lane & 31u] : 0u;
+    }
+#pragma unroll
     for (uint32_t k = 0; k != GOLD_JUMP_BITS; ++k) {
       if ((offset >> k) & 1u) { // wave-uniform
-        state = gold_matvec(gold->x2_jump[k], state, lane);
+        const uint32_t bit = (lane < 31u) ? (__popc(row[k] & state) & 1u) : 0u;
+        state              = (uint32_t)__ballot(bit != 0) & 0x7FFFFFFFu;
       }
     }
+    if (lane == 0) {
+      ring[GOLD_RING_WORDS - 1u] = state; // a slot the recurrence does not reach before the ring wraps
+    }
+  }
+  lds_barrier();
+  {
+    const uint32_t state = ring[GOLD_RING_WORDS - 1u];
+    const uint32_t t0    = 8u * (tid / WAVE);
     if (lane < 31u) {
-      uint32_t word = 0;
-#pragma unroll 8
-      for (uint32_t t = 0; t != 32; ++t) {
-        word |= (__popc(gold->x2_head[t][lane] & state) & 1u) << (31u - t);
+      uint32_t head[8];
+#pragma unroll
+      for (uint32_t t = 0; t != 8; ++t) {
+        head[t] = gold->x2_head[t0 + t][lane];
       }
-      ring[lane] = word;
+      uint32_t word = 0;
+#pragma unroll
+      for (uint32_t t = 0; t != 8; ++t) {
+        word |= (__popc(head[t] & state) & 1u) << (31u - (t0 + t));
+      }
+      atomicOr(&ring[lane], word);
     }
   }
   lds_barrier();
