@@ -477,10 +477,18 @@ typedef struct nrphy_ldpc_decoder_cfg {
 } nrphy_ldpc_decoder_cfg_t;
 /* n_cb codeblocks that share the configuration.  d_llr: codeblock i at i * llr_stride_bytes.  d_out:
  * the Kb*Zc hard bits of codeblock i, packed MSB first, at i * out_stride_bytes.  d_iterations (may be
- * NULL): per codeblock the iteration after which the CRC passed, 0 when it did not (or no CRC given). */
+ * NULL): per codeblock the iteration after which the CRC passed, 0 when it did not (or no CRC given).
+ * d_scratch: nrphy_ldpc_decoder_scratch_bytes() bytes of device memory the CALLER owns for the duration of the call
+ * (the decoder's check-to-variable records: a pool of slots shared by the workgroups resident at once, so its size
+ * stops growing with the batch -- 0.2 GB at most); calls in flight at the same time need a scratch each.
+ * After nrphy_ldpc_decoder_prepare() for the configuration (it uploads the decoder's graph and CRC weights; a call
+ * without it does so itself, once, with an allocation and a blocking copy) the call neither allocates nor
+ * synchronises and can be captured in a hipGraph. */
+int nrphy_ldpc_decoder_scratch_bytes(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb, uint64_t* bytes);
+int nrphy_ldpc_decoder_prepare(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg);
 int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb, const int8_t* d_llr,
                       uint32_t llr_stride_bytes, uint8_t* d_out, uint32_t out_stride_bytes, uint32_t* d_iterations,
-                      void* stream);
+                      void* d_scratch, void* stream);
 /* Host-span form for one codeblock (blocking). */
 int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, const int8_t* llr,
                            uint8_t* message_packed, uint32_t* iterations);
@@ -520,16 +528,20 @@ typedef struct nrphy_pusch_decoder_cfg {
 /* HARQ state the caller keeps per batch between transmissions (sizes from nrphy_pusch_decoder_sizes):
  * d_soft  = n_tb * soft_bytes_per_tb  int8 soft buffers, [tb][codeblock][(66 or 50) * Zc];
  * d_state = n_tb-dependent codeblock state (CRC flags, decoded messages, iteration counts), state_bytes(n_tb).
- * Neither needs initialising before a new_data call. */
-int nrphy_pusch_decoder_sizes(const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb, uint64_t* soft_bytes_per_tb,
-                              uint64_t* state_bytes, uint32_t* nof_codeblocks);
+ * Neither needs initialising before a new_data call.  d_scratch = scratch_bytes of device memory owned by the caller
+ * for the duration of one call (the LDPC decoder's records, see nrphy_ldpc_decode); it carries nothing between calls. */
+int nrphy_pusch_decoder_sizes(nrphy_ctx_t* ctx, const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb, uint64_t* soft_bytes_per_tb,
+                              uint64_t* state_bytes, uint64_t* scratch_bytes, uint32_t* nof_codeblocks);
+/* Uploads what the configuration needs once (decoder graph, CRC weights): afterwards nrphy_pusch_decode_batch neither
+ * allocates nor synchronises (capturable). */
+int nrphy_pusch_decoder_prepare(nrphy_ctx_t* ctx, const nrphy_pusch_decoder_cfg_t* cfg);
 /* d_llr: codeword LLRs of transport block i at i * llr_stride_bytes (nof_ch_symbols * qm of them, in the
  * order the demodulator delivers them).  d_tb: transport block i at i * tb_stride_bytes (written whenever
  * all its codeblock CRCs pass; valid when its tb_crc_ok is 1).  d_result: 4 words per transport block --
  * tb_crc_ok, codeblocks whose CRC passed, sum and maximum of the LDPC iterations of the codeblocks decoded
  * in this call (a failed decode counts max_iterations).  Asynchronous on `stream`. */
 int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb, const int8_t* d_llr,
-                             uint64_t llr_stride_bytes, int8_t* d_soft, uint8_t* d_state, uint8_t* d_tb,
+                             uint64_t llr_stride_bytes, int8_t* d_soft, uint8_t* d_state, void* d_scratch, uint8_t* d_tb,
                              uint32_t tb_stride_bytes, uint32_t* d_result, void* stream);
 
 /* ---- receive side of seam C ("next" row): OFDM demodulator ---------------

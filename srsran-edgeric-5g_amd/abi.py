@@ -393,7 +393,9 @@ def declare(lib, prefix="nrphy_"):
     sig("ofdm_demod_run", i32, vp, u32, vp, vp, u32, vp, vp)
     sig("ofdm_demodulate_slot_host", i32, vp, vp, u32, u32, vp)
     sig("ofdm_demodulate_symbol_host", i32, vp, vp, u32, u32, u32, vp)
-    sig("ldpc_decode", i32, vp, P(LdpcDecoderCfg), u32, vp, u32, vp, u32, vp, vp)
+    sig("ldpc_decoder_scratch_bytes", i32, vp, P(LdpcDecoderCfg), u32, P(u64))
+    sig("ldpc_decoder_prepare", i32, vp, P(LdpcDecoderCfg))
+    sig("ldpc_decode", i32, vp, P(LdpcDecoderCfg), u32, vp, u32, vp, u32, vp, vp, vp)
     sig("ldpc_decode_host", i32, vp, P(LdpcDecoderCfg), vp, u8p, P(u32))
     sig("ldpc_rate_dematch", i32, vp, P(LdpcRateDematcherCfg), u32, vp, u32, vp, u32, i32, vp)
     sig("ldpc_rate_dematch_host", i32, vp, P(LdpcRateDematcherCfg), vp, vp, i32)
@@ -420,8 +422,9 @@ def declare(lib, prefix="nrphy_"):
     sig("ofh_compressed_prb_bytes", u32, P(OfhCompressionCfg))
     sig("ofh_compress", i32, vp, P(OfhCompressionCfg), u32, u32, vp, C.c_size_t, vp, C.c_size_t, vp)
     sig("ofh_compress_host", i32, vp, P(OfhCompressionCfg), u32, vp, vp)
-    sig("pusch_decoder_sizes", i32, P(PuschDecoderCfg), u32, P(u64), P(u64), P(u32))
-    sig("pusch_decode_batch", i32, vp, P(PuschDecoderCfg), u32, vp, u64, vp, vp, vp, u32, vp, vp)
+    sig("pusch_decoder_sizes", i32, vp, P(PuschDecoderCfg), u32, P(u64), P(u64), P(u64), P(u32))
+    sig("pusch_decoder_prepare", i32, vp, P(PuschDecoderCfg))
+    sig("pusch_decode_batch", i32, vp, P(PuschDecoderCfg), u32, vp, u64, vp, vp, vp, vp, u32, vp, vp)
     sig("pusch_decode_codeblock_host", i32, vp, P(LdpcRateDematcherCfg), u32, u32, C.c_float, vp, vp, i32, u8p, P(u32))
     return lib
 
@@ -439,6 +442,7 @@ ABI_SYMBOLS = [
     "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",
     "nrphy_ldpc_decode", "nrphy_ldpc_decode_host", "nrphy_ldpc_rate_dematch", "nrphy_ldpc_rate_dematch_host",
     "nrphy_pusch_decode_codeblock_host", "nrphy_pusch_decoder_sizes", "nrphy_pusch_decode_batch",
+    "nrphy_ldpc_decoder_scratch_bytes", "nrphy_ldpc_decoder_prepare", "nrphy_pusch_decoder_prepare",
     "nrphy_csi_rs_validate", "nrphy_csi_rs_map", "nrphy_csi_rs_map_host", "nrphy_grid_put",
     "nrphy_llr_descramble", "nrphy_llr_descramble_host",
     "nrphy_pdcch_validate", "nrphy_pdcch_process", "nrphy_pdcch_process_host", "nrphy_pdcch_encode_host",

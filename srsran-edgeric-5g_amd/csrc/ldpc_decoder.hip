@@ -145,6 +145,32 @@ __device__ __forceinline__ uint32_t hard_word(const int8_t* soft, uint32_t w, ui
   return word;
 }
 
+// The check records of a codeblock live in a slot of the caller's scratch.  A batch larger than the pool shares it:
+// a workgroup claims a free slot (one bit of a bitmap) when it starts decoding and gives it back when it is done.  The
+// pool holds at least as many slots as workgroups fit the device at once, so a free one always exists and the search
+// ends; should that bound ever be wrong the search gives up after a fixed number of probes and the codeblock is
+// reported as not decoded (never a hang).
+__device__ __forceinline__ uint32_t acquire_slot(uint32_t* bitmap, uint32_t nof_slots, uint32_t seed)
+{
+  const uint32_t nwords = (nof_slots + 31u) >> 5;
+  uint32_t       w      = (seed * 2654435761u) % nwords;
+  for (uint32_t probes = 0; probes != (1u << 20); ++probes) {
+    const uint32_t valid = (32u * w + 32u <= nof_slots) ? 0xFFFFFFFFu : ((1u << (nof_slots & 31u)) - 1u);
+    const uint32_t cur   = __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t avail = ~cur & valid;
+    if (avail != 0) {
+      const uint32_t bit = 1u << ((uint32_t)__ffs((int)avail) - 1u);
+      if ((atomicOr(&bitmap[w], bit) & bit) == 0) {
+        return 32u * w + (uint32_t)__ffs((int)avail) - 1u;
+      }
+    } else {
+      w = w + 1u == nwords ? 0u : w + 1u;
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  return 0xFFFFFFFFu;
+}
+
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void ldpc_decode_kernel(LdpcDecodeLaunch p)
 {
   extern __shared__ __attribute__((aligned(16))) int8_t dec_lds[];
@@ -158,8 +184,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   }
   const auto*   graph  = to_constant(p.graph); // wave-uniform reads: scalar loads
   const int8_t* llr    = p.llr + (size_t)blockIdx.x * p.llr_stride;
-  uint2*        rec    = p.scratch + (size_t)blockIdx.x * p.nof_layers_max * zc;
   const bool    active = j < zc;
+  const bool    pooled = p.nof_slots < gridDim.x; // fewer slots than codeblocks: claim one
 
   // load_soft_bits (ldpc_decoder_impl.cpp:128-164): two punctured nodes, then the input.  The last non-zero soft bit
   // decides how many layers take part (:88-116).
@@ -234,12 +260,19 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   const uint32_t jm = j - zc;
 
   if (input_size != 0) { // workgroup-uniform
+    if (j == 0) {
+      s_flag[3] = pooled ? acquire_slot(p.slot_bitmap, p.nof_slots, blockIdx.x) : blockIdx.x;
+    }
+    __syncthreads();
+    const uint32_t slot = s_flag[3];
+    uint2*         rec  = p.scratch + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * p.nof_layers_max * zc;
+    const uint32_t max_iterations = slot == 0xFFFFFFFFu ? 0u : p.max_iterations; // no slot: reported as not decoded
     uint32_t cb_len = input_size + 2u * zc;
     cb_len          = cb_len < K + 4u * zc ? K + 4u * zc : cb_len;
     cb_len          = ((cb_len + zc - 1u) / zc) * zc;
     const uint32_t nof_layers = cb_len / zc - p.bg_k;
 
-    for (uint32_t it = 0; it != p.max_iterations && iterations == 0; ++it) {
+    for (uint32_t it = 0; it != max_iterations && iterations == 0; ++it) {
       uint2 next = make_uint2(0, 0);
       if (it != 0 && active) {
         next = rec[j];
@@ -270,7 +303,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
       }
       // Early stop (ldpc_decoder_impl.cpp:118-126): every hard bit decided and the CRC of the significant bits zero.
       // crc_at_end (pusch_codeblock_decoder.cpp:59-68): no check until the last iteration, then the CRC alone decides.
-      if (p.crc_order != 0 && (!p.crc_at_end || it + 1u == p.max_iterations)) {
+      if (p.crc_order != 0 && (!p.crc_at_end || it + 1u == max_iterations)) {
         if (j < 2) {
           s_flag[1 + j] = 0;
         }
@@ -297,6 +330,14 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
           iterations = it + 1u;
         }
         lds_barrier(); // the flags are cleared again at the top of the next check
+      }
+    }
+    if (pooled && slot != 0xFFFFFFFFu) {
+      // Give the slot back: this workgroup's record stores must have landed before another one's can.
+      __threadfence();
+      __syncthreads();
+      if (j == 0) {
+        atomicAnd(&p.slot_bitmap[slot >> 5], ~(1u << (slot & 31u)));
       }
     }
   }

@@ -653,6 +653,12 @@ extern "C" int nrphy_create(nrphy_ctx_t** out, int device_id)
     return NRPHY_ERR_CAPACITY;
   }
   ctx->device = device_id;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
+      ctx->nof_cus = (uint32_t)prop.multiProcessorCount;
+    }
+  }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return NRPHY_ERR_DEVICE;
@@ -1758,24 +1764,81 @@ namespace {
 // skip / ok_flags: per-codeblock HARQ state of a transport-block decoder; crc_at_end: no early stop.
 int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb, const int8_t* d_llr,
                       uint32_t llr_stride_bytes, uint8_t* d_out, uint32_t out_stride_bytes, uint32_t* d_iterations,
-                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* stream);
+                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* d_scratch, void* stream);
+
+// The caller-owned scratch of a decoder launch: a pool of check-record slots + the bitmap that hands them out.
+struct DecoderScratch {
+  uint32_t nof_slots, nof_layers_max;
+  uint64_t records_bytes, bitmap_bytes, total_bytes;
+};
+bool decoder_scratch_layout(const nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t& cfg, uint32_t n_cb, DecoderScratch& s)
+{
+  const unsigned bg_k = (cfg.base_graph == 1) ? 22 : 10, zc = cfg.lifting_size;
+  if ((cfg.base_graph != 1 && cfg.base_graph != 2) || lifting_position(zc) < 0 || n_cb == 0) {
+    return false;
+  }
+  const uint32_t nof_nodes = std::max<uint32_t>(divide_ceil(cfg.nof_llr, zc) + 2, bg_k + 4);
+  s.nof_layers_max         = nof_nodes - bg_k;
+  // Workgroups of the decoder the device can hold at once: 32 wavefronts per CU (the kernel is built for 8 per SIMD),
+  // ceil(Zc / 64) per workgroup; one slot per CU more as a margin.  A smaller batch gets a slot per codeblock.
+  const uint32_t waves    = divide_ceil(zc, 64);
+  const uint32_t resident = ctx->nof_cus * (32U / waves) + ctx->nof_cus;
+  s.nof_slots             = std::min<uint32_t>(n_cb, resident);
+  s.records_bytes         = (uint64_t)s.nof_slots * s.nof_layers_max * zc * sizeof(uint2);
+  s.bitmap_bytes          = ((uint64_t)divide_ceil(s.nof_slots, 32) * 4 + 255) & ~(uint64_t)255;
+  s.total_bytes           = ((s.records_bytes + 255) & ~(uint64_t)255) + s.bitmap_bytes;
+  return true;
+}
 } // namespace
+
+extern "C" int nrphy_ldpc_decoder_scratch_bytes(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb,
+                                                uint64_t* bytes)
+{
+  DecoderScratch s;
+  if (ctx == nullptr || cfg == nullptr || bytes == nullptr || !decoder_scratch_layout(ctx, *cfg, n_cb, s)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  *bytes = s.total_bytes;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ldpc_decoder_prepare(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg)
+{
+  if (ctx == nullptr || cfg == nullptr || (cfg->base_graph != 1 && cfg->base_graph != 2) || lifting_position(cfg->lifting_size) < 0 ||
+      (cfg->crc_poly != 0 && cfg->crc_poly != 16 && cfg->crc_poly != 0x24A && cfg->crc_poly != 0x24B)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
+  if (get_decoder_graph(ctx, cfg->base_graph, cfg->lifting_size) == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  if (cfg->crc_poly != 0) {
+    const uint32_t order = cfg->crc_poly == 16 ? 16 : 24;
+    const uint32_t poly  = (cfg->crc_poly == 16) ? 0x11021U : (cfg->crc_poly == 0x24B ? 0x1800063U : 0x1864CFBU);
+    const uint32_t K     = ((cfg->base_graph == 1) ? 22U : 10U) * cfg->lifting_size;
+    if (cfg->nof_filler_bits >= K || get_decoder_crc_weights(ctx, poly, order, K - cfg->nof_filler_bits) == nullptr) {
+      return NRPHY_ERR_DEVICE;
+    }
+  }
+  return NRPHY_OK;
+}
 
 extern "C" int nrphy_ldpc_decode(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb,
                                  const int8_t* d_llr, uint32_t llr_stride_bytes, uint8_t* d_out,
-                                 uint32_t out_stride_bytes, uint32_t* d_iterations, void* stream)
+                                 uint32_t out_stride_bytes, uint32_t* d_iterations, void* d_scratch, void* stream)
 {
   return ldpc_decode_batch(ctx, cfg, n_cb, d_llr, llr_stride_bytes, d_out, out_stride_bytes, d_iterations, nullptr,
-                           nullptr, false, stream);
+                           nullptr, false, d_scratch, stream);
 }
 
 namespace {
 
 int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb, const int8_t* d_llr,
                       uint32_t llr_stride_bytes, uint8_t* d_out, uint32_t out_stride_bytes, uint32_t* d_iterations,
-                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* stream)
+                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* d_scratch, void* stream)
 {
-  if (ctx == nullptr || cfg == nullptr || d_llr == nullptr || d_out == nullptr ||
+  if (ctx == nullptr || cfg == nullptr || d_llr == nullptr || d_out == nullptr || d_scratch == nullptr ||
       (cfg->base_graph != 1 && cfg->base_graph != 2) || cfg->max_iterations == 0 ||
       !(cfg->scaling_factor > 0.0F && cfg->scaling_factor < 1.0F) ||
       (cfg->crc_poly != 0 && cfg->crc_poly != 16 && cfg->crc_poly != 0x24A && cfg->crc_poly != 0x24B)) {
@@ -1816,18 +1879,30 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
   p.ok_flags       = d_ok_flags;
   p.crc_at_end     = crc_at_end ? 1U : 0U;
   p.crc_weight     = nullptr;
-  {
-    // Check records: context-owned, grow-only (a first call with a larger batch allocates; not stream-ordered).
+  if (p.crc_order != 0) {
+    // Uploaded by nrphy_ldpc_decoder_prepare(); a first use without it allocates and copies here (not capturable).
     std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
-    p.scratch = (uint2*)ctx_scratch(ctx, SCRATCH_DECODER, (size_t)n_cb * p.nof_layers_max * zc * sizeof(uint2));
-    if (p.crc_order != 0) {
-      p.crc_weight = get_decoder_crc_weights(ctx, p.crc_poly, p.crc_order, K - cfg->nof_filler_bits);
+    p.crc_weight = get_decoder_crc_weights(ctx, p.crc_poly, p.crc_order, K - cfg->nof_filler_bits);
+    if (p.crc_weight == nullptr) {
+      return NRPHY_ERR_DEVICE;
     }
   }
-  if (p.scratch == nullptr || (p.crc_order != 0 && p.crc_weight == nullptr)) {
-    return NRPHY_ERR_DEVICE;
+  if (n_cb == 0) {
+    return NRPHY_OK;
   }
-  HIP_TRY(launch_ldpc_decode(p, n_cb, stream ? (hipStream_t)stream : ctx->stream));
+  // Check records: the caller's scratch, a pool of slots shared by the workgroups resident at once.
+  DecoderScratch sl;
+  if (!decoder_scratch_layout(ctx, *cfg, n_cb, sl)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  p.scratch     = (uint2*)d_scratch;
+  p.slot_bitmap = (uint32_t*)((uint8_t*)d_scratch + ((sl.records_bytes + 255) & ~(uint64_t)255));
+  p.nof_slots   = sl.nof_slots;
+  if (sl.nof_slots < n_cb) {
+    HIP_TRY(hipMemsetAsync(p.slot_bitmap, 0, sl.bitmap_bytes, s));
+  }
+  HIP_TRY(launch_ldpc_decode(p, n_cb, s));
   return NRPHY_OK;
 }
 
@@ -1844,6 +1919,7 @@ extern "C" int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder
   const unsigned K     = ((cfg->base_graph == 1) ? 22U : 10U) * cfg->lifting_size;
   int8_t*        d_llr = nullptr;
   uint8_t*       d_out = nullptr;
+  void*          d_scratch = nullptr;
   int            rc    = NRPHY_ERR_DEVICE;
   do {
     if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&d_llr, cfg->nof_llr + 16) != hipSuccess ||
@@ -1852,7 +1928,15 @@ extern "C" int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder
       break;
     }
     uint32_t* d_it = (uint32_t*)(d_out + (((K + 7) / 8 + 3) & ~3U));
-    rc = nrphy_ldpc_decode(ctx, cfg, 1, d_llr, cfg->nof_llr, d_out, (K + 7) / 8, d_it, ctx->stream);
+    uint64_t  scratch_bytes = 0;
+    if (nrphy_ldpc_decoder_scratch_bytes(ctx, cfg, 1, &scratch_bytes) != NRPHY_OK) {
+      rc = NRPHY_ERR_ARGUMENT;
+      break;
+    }
+    if (hipMalloc(&d_scratch, scratch_bytes) != hipSuccess) {
+      break;
+    }
+    rc = nrphy_ldpc_decode(ctx, cfg, 1, d_llr, cfg->nof_llr, d_out, (K + 7) / 8, d_it, d_scratch, ctx->stream);
     if (rc != NRPHY_OK) {
       break;
     }
@@ -1870,6 +1954,7 @@ extern "C" int nrphy_ldpc_decode_host(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder
   } while (false);
   (void)hipFree(d_llr);
   (void)hipFree(d_out);
+  (void)hipFree(d_scratch);
   return rc;
 }
 
@@ -1913,8 +1998,16 @@ extern "C" int nrphy_pusch_decode_codeblock_host(nrphy_ctx_t* ctx, const nrphy_l
   dec.nof_llr         = n;
   dec.max_iterations  = max_iterations;
   dec.scaling_factor  = scaling_factor;
+  uint64_t scratch_bytes = 0;
+  if (nrphy_ldpc_decoder_scratch_bytes(ctx, &dec, 1, &scratch_bytes) != NRPHY_OK) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  void* d_scratch = ctx_scratch(ctx, SCRATCH_DECODER, scratch_bytes); // host_mutex is held for the whole call
+  if (d_scratch == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
   rc = nrphy_ldpc_decode(ctx, &dec, 1, (const int8_t*)(base + off_soft), n, base + off_out, kbytes,
-                         (uint32_t*)(base + off_it), ctx->stream);
+                         (uint32_t*)(base + off_it), d_scratch, ctx->stream);
   if (rc != NRPHY_OK) {
     return rc;
   }
@@ -1973,12 +2066,75 @@ bool pusch_layout(const nrphy_pusch_decoder_cfg_t& cfg, uint32_t n_tb, PuschLayo
 
 } // namespace
 
-extern "C" int nrphy_pusch_decoder_sizes(const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb, uint64_t* soft_bytes_per_tb,
-                                         uint64_t* state_bytes, uint32_t* nof_codeblocks)
+namespace {
+// Weights of the assembly kernel's per-thread transport-block CRC pieces (pusch_decoder.hip): fixed by the block size.
+const uint32_t* get_pusch_tb_crc_weights(nrphy_ctx* ctx, uint32_t tb_size_bytes)
+{
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
+  auto                                  it = ctx->d_tb_crc_w.find(tb_size_bytes);
+  if (it == ctx->d_tb_crc_w.end()) {
+    const uint32_t        piece = divide_ceil(tb_size_bytes, PUSCH_ASSEMBLE_THREADS);
+    std::vector<uint32_t> w(PUSCH_ASSEMBLE_THREADS);
+    for (uint32_t t = 0; t != PUSCH_ASSEMBLE_THREADS; ++t) {
+      const uint32_t end = std::min<uint32_t>(std::min<uint32_t>(t * piece, tb_size_bytes) + piece, tb_size_bytes);
+      w[t]               = CRC24A_FIELD.xpow(8 * (int64_t)(tb_size_bytes - end));
+    }
+    uint32_t* d_w = nullptr;
+    if (upload(&d_w, w.data(), w.size() * sizeof(uint32_t)) != hipSuccess) {
+      return nullptr;
+    }
+    it = ctx->d_tb_crc_w.emplace(tb_size_bytes, d_w).first;
+  }
+  return it->second;
+}
+
+nrphy_ldpc_decoder_cfg_t pusch_ldpc_cfg(const nrphy_pusch_decoder_cfg_t& cfg, const nrphy_pdsch_derived_t& d)
+{
+  // Decoding of the codeblocks whose CRC has not passed yet (pusch_codeblock_decoder.cpp:36-71): CRC24B per codeblock,
+  // the transport block's own CRC when it is a single codeblock.
+  nrphy_ldpc_decoder_cfg_t dec;
+  dec.base_graph      = cfg.base_graph;
+  dec.lifting_size    = d.lifting_size;
+  dec.nof_filler_bits = d.nof_filler_bits;
+  dec.crc_poly        = (d.nof_codeblocks > 1) ? 0x24B : (d.nof_tb_crc_bits == 16 ? 16 : 0x24A);
+  dec.nof_llr         = d.full_length;
+  dec.max_iterations  = cfg.max_iterations;
+  dec.scaling_factor  = 0.8F; // ldpc_decoder::configuration::algorithm_details default, which pusch_codeblock_decoder keeps
+  return dec;
+}
+} // namespace
+
+extern "C" int nrphy_pusch_decoder_prepare(nrphy_ctx_t* ctx, const nrphy_pusch_decoder_cfg_t* cfg)
 {
   PuschLayout l;
-  if (cfg == nullptr || !pusch_layout(*cfg, n_tb, l)) {
+  if (ctx == nullptr || cfg == nullptr || !pusch_layout(*cfg, 1, l)) {
     return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const nrphy_ldpc_decoder_cfg_t dec = pusch_ldpc_cfg(*cfg, l.d);
+  const int                      rc  = nrphy_ldpc_decoder_prepare(ctx, &dec);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  if (l.d.nof_codeblocks > 1 && get_pusch_tb_crc_weights(ctx, cfg->tb_size_bytes) == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_pusch_decoder_sizes(nrphy_ctx_t* ctx, const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb,
+                                         uint64_t* soft_bytes_per_tb, uint64_t* state_bytes, uint64_t* scratch_bytes,
+                                         uint32_t* nof_codeblocks)
+{
+  PuschLayout l;
+  if (ctx == nullptr || cfg == nullptr || !pusch_layout(*cfg, n_tb, l)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (scratch_bytes) {
+    const nrphy_ldpc_decoder_cfg_t dec = pusch_ldpc_cfg(*cfg, l.d);
+    if (nrphy_ldpc_decoder_scratch_bytes(ctx, &dec, std::max<uint32_t>(1, n_tb * l.d.nof_codeblocks), scratch_bytes) != NRPHY_OK) {
+      return NRPHY_ERR_ARGUMENT;
+    }
   }
   if (soft_bytes_per_tb) {
     *soft_bytes_per_tb = (uint64_t)l.d.nof_codeblocks * l.d.full_length;
@@ -1994,10 +2150,11 @@ extern "C" int nrphy_pusch_decoder_sizes(const nrphy_pusch_decoder_cfg_t* cfg, u
 
 extern "C" int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_decoder_cfg_t* cfg, uint32_t n_tb,
                                         const int8_t* d_llr, uint64_t llr_stride_bytes, int8_t* d_soft, uint8_t* d_state,
-                                        uint8_t* d_tb, uint32_t tb_stride_bytes, uint32_t* d_result, void* stream)
+                                        void* d_scratch, uint8_t* d_tb, uint32_t tb_stride_bytes, uint32_t* d_result, void* stream)
 {
   PuschLayout l;
   if (ctx == nullptr || cfg == nullptr || d_llr == nullptr || d_soft == nullptr || d_state == nullptr || d_tb == nullptr ||
+      d_scratch == nullptr ||
       d_result == nullptr || !pusch_layout(*cfg, n_tb, l) || tb_stride_bytes < cfg->tb_size_bytes ||
       llr_stride_bytes < (uint64_t)cfg->nof_ch_symbols * cfg->qm) {
     return NRPHY_ERR_ARGUMENT;
@@ -2040,40 +2197,19 @@ extern "C" int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_deco
   if (rc != NRPHY_OK) {
     return rc;
   }
-  // Decoding of the codeblocks whose CRC has not passed yet (pusch_codeblock_decoder.cpp:36-71): CRC24B per codeblock,
-  // the transport block's own CRC when it is a single codeblock.
-  nrphy_ldpc_decoder_cfg_t dec;
-  dec.base_graph      = cfg->base_graph;
-  dec.lifting_size    = d.lifting_size;
-  dec.nof_filler_bits = d.nof_filler_bits;
-  dec.crc_poly        = (C > 1) ? 0x24B : (d.nof_tb_crc_bits == 16 ? 16 : 0x24A);
-  dec.nof_llr         = N;
-  dec.max_iterations  = cfg->max_iterations;
-  dec.scaling_factor  = 0.8F; // ldpc_decoder::configuration::algorithm_details default, which pusch_codeblock_decoder keeps
-  rc = ldpc_decode_batch(ctx, &dec, (uint32_t)n_cb, d_soft, N, msg, l.msg_stride, iter, skip, ok, cfg->use_early_stop == 0, s);
+  const nrphy_ldpc_decoder_cfg_t dec = pusch_ldpc_cfg(*cfg, d);
+  rc = ldpc_decode_batch(ctx, &dec, (uint32_t)n_cb, d_soft, N, msg, l.msg_stride, iter, skip, ok, cfg->use_early_stop == 0,
+                         d_scratch, s);
   if (rc != NRPHY_OK) {
     return rc;
   }
   PuschAssembleLaunch a;
   a.crc_weight = nullptr;
   if (C > 1) {
-    // weights of the assembly kernel's per-thread CRC pieces (pusch_decoder.hip): fixed by the block size
-    std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
-    auto                        it = ctx->d_tb_crc_w.find(cfg->tb_size_bytes);
-    if (it == ctx->d_tb_crc_w.end()) {
-      const uint32_t        piece = divide_ceil(cfg->tb_size_bytes, PUSCH_ASSEMBLE_THREADS);
-      std::vector<uint32_t> w(PUSCH_ASSEMBLE_THREADS);
-      for (uint32_t t = 0; t != PUSCH_ASSEMBLE_THREADS; ++t) {
-        const uint32_t end = std::min<uint32_t>(std::min<uint32_t>(t * piece, cfg->tb_size_bytes) + piece, cfg->tb_size_bytes);
-        w[t]               = CRC24A_FIELD.xpow(8 * (int64_t)(cfg->tb_size_bytes - end));
-      }
-      uint32_t* d_w = nullptr;
-      if (upload(&d_w, w.data(), w.size() * sizeof(uint32_t)) != hipSuccess) {
-        return NRPHY_ERR_DEVICE;
-      }
-      it = ctx->d_tb_crc_w.emplace(cfg->tb_size_bytes, d_w).first;
+    a.crc_weight = get_pusch_tb_crc_weights(ctx, cfg->tb_size_bytes); // uploaded by nrphy_pusch_decoder_prepare() or here
+    if (a.crc_weight == nullptr) {
+      return NRPHY_ERR_DEVICE;
     }
-    a.crc_weight = it->second;
   }
   a.cb_msg         = msg;
   a.cb_ok          = ok;

@@ -77,6 +77,7 @@ hipError_t upload(T** dptr, const void* src, size_t bytes)
 
 struct nrphy_ctx {
   int          device   = 0;
+  uint32_t     nof_cus  = 256; // compute units of the device (sizes the decoder's scratch pool)
   hipStream_t  stream   = nullptr;
   LiftedGraph* d_graphs = nullptr;
   GoldTables*  d_gold   = nullptr;

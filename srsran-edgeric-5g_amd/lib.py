@@ -263,22 +263,47 @@ class Context:
 
     def pusch_decoder_sizes(self, cfg, n_tb):
         """(soft-buffer bytes per transport block, state bytes of the batch, codeblocks per transport block)."""
-        soft, state, ncb = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
-        _check(self.lib.nrphy_pusch_decoder_sizes(C.byref(cfg), n_tb, C.byref(soft), C.byref(state), C.byref(ncb)),
-               "nrphy_pusch_decoder_sizes")
+        soft, state, scratch, ncb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        _check(self.lib.nrphy_pusch_decoder_sizes(self.handle, C.byref(cfg), n_tb, C.byref(soft), C.byref(state),
+                                                  C.byref(scratch), C.byref(ncb)), "nrphy_pusch_decoder_sizes")
+        self._pusch_scratch_bytes = int(scratch.value)
         return int(soft.value), int(state.value), int(ncb.value)
 
-    def pusch_decode_batch(self, cfg, n_tb, d_llr, llr_stride, d_soft, d_state, d_tb, tb_stride, d_result, stream=None):
-        """pusch_decoder for n_tb transport blocks of one configuration, everything resident in HBM."""
-        _check(self.lib.nrphy_pusch_decode_batch(self.handle, C.byref(cfg), n_tb, _dptr(d_llr), llr_stride, _dptr(d_soft),
-                                                 _dptr(d_state), _dptr(d_tb), tb_stride, _dptr(d_result), stream),
-               "nrphy_pusch_decode_batch")
+    def _scratch(self, nbytes, d_scratch):
+        """The decoder scratch the caller owns: given, or a grow-only device buffer kept by this wrapper (one call in
+        flight at a time, as the tests and benchmarks use it)."""
+        if d_scratch is not None:
+            return d_scratch
+        import torch
+        cur = getattr(self, "_dec_scratch", None)
+        if cur is None or cur.numel() < nbytes:
+            torch.cuda.synchronize()
+            self._dec_scratch = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+        return self._dec_scratch
 
-    def ldpc_decode(self, cfg, n_cb, d_llr, llr_stride, d_out, out_stride, d_iterations=None, stream=None):
+    def pusch_decode_batch(self, cfg, n_tb, d_llr, llr_stride, d_soft, d_state, d_tb, tb_stride, d_result, stream=None,
+                           d_scratch=None):
+        """pusch_decoder for n_tb transport blocks of one configuration, everything resident in HBM."""
+        scratch = C.c_uint64(0)
+        _check(self.lib.nrphy_pusch_decoder_sizes(self.handle, C.byref(cfg), n_tb, None, None, C.byref(scratch), None),
+               "nrphy_pusch_decoder_sizes")
+        d_scratch = self._scratch(scratch.value, d_scratch)
+        _check(self.lib.nrphy_pusch_decode_batch(self.handle, C.byref(cfg), n_tb, _dptr(d_llr), llr_stride, _dptr(d_soft),
+                                                 _dptr(d_state), _dptr(d_scratch), _dptr(d_tb), tb_stride, _dptr(d_result),
+                                                 stream), "nrphy_pusch_decode_batch")
+
+    def ldpc_decoder_scratch_bytes(self, cfg, n_cb):
+        b = C.c_uint64(0)
+        _check(self.lib.nrphy_ldpc_decoder_scratch_bytes(self.handle, C.byref(cfg), n_cb, C.byref(b)),
+               "nrphy_ldpc_decoder_scratch_bytes")
+        return int(b.value)
+
+    def ldpc_decode(self, cfg, n_cb, d_llr, llr_stride, d_out, out_stride, d_iterations=None, stream=None, d_scratch=None):
         """ldpc_decoder::decode for n_cb codeblocks resident in HBM (cfg: abi.LdpcDecoderCfg)."""
+        d_scratch = self._scratch(self.ldpc_decoder_scratch_bytes(cfg, max(1, n_cb)), d_scratch)
         _check(self.lib.nrphy_ldpc_decode(self.handle, C.byref(cfg), n_cb, _dptr(d_llr), llr_stride, _dptr(d_out),
                                           out_stride, _dptr(d_iterations) if d_iterations is not None else None,
-                                          stream), "nrphy_ldpc_decode")
+                                          _dptr(d_scratch), stream), "nrphy_ldpc_decode")
 
     def ldpc_decode_host(self, base_graph, lifting_size, nof_filler, crc_poly, max_iterations, scaling, llr):
         """ldpc_decoder::decode on host spans: returns (iterations or 0, Kb*Zc hard bits one per byte)."""

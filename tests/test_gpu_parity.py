@@ -676,6 +676,56 @@ def test_ldpc_decoder_batch_and_argument_checks(gpu_ctx, oracle):
         assert rc == abi.ERR_ARGUMENT, bad
 
 
+def test_ldpc_decoder_scratch_pool_streams_and_graph(gpu_ctx, oracle):
+    """The decoder's check records live in a caller-owned pool that stops growing with the batch: a batch far larger than
+    the pool (workgroups claim and release slots), two decodes in flight on two streams with a scratch each, and a decode
+    captured in a hipGraph after nrphy_ldpc_decoder_prepare -- all bit-exact against the oracle."""
+    import torch
+    bg, zc, filler, crc_id = 2, 32, 8, 0x24B
+    nof_llr = 50 * zc
+    rng = np.random.default_rng(99)
+    base = 40
+    llr_base, want = [], []
+    for i in range(base):
+        _, llr = cases.make_ldpc_llrs(oracle, rng, bg, zc, nof_llr, crc_id, filler, 20, 7 + i % 5)
+        llr_base.append(llr)
+        want.append(oracle.ldpc_decode(bg, zc, filler, crc_id, 5, 0.8, llr))
+    cfg = abi.LdpcDecoderCfg(bg, zc, filler, crc_id, nof_llr, 5, 0.8)
+    n_cb = 20000
+    pool = gpu_ctx.ldpc_decoder_scratch_bytes(cfg, n_cb)
+    assert pool < gpu_ctx.ldpc_decoder_scratch_bytes(cfg, 1) * n_cb // 2, "the pool does not grow with the batch"
+    llrs = np.stack([llr_base[i % base] for i in range(n_cb)])
+    k = 10 * zc
+    d_llr = dev(llrs)
+    outs = [torch.zeros((n_cb, k // 8), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    its = [torch.full((n_cb,), 77, dtype=torch.int32, device="cuda") for _ in range(2)]
+    scratch = [torch.empty(pool, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    assert gpu_ctx.lib.nrphy_ldpc_decoder_prepare(gpu_ctx.handle, C.byref(cfg)) == 0
+    torch.cuda.synchronize()
+    for q in range(2):
+        gpu_ctx.ldpc_decode(cfg, n_cb, d_llr, nof_llr, outs[q], k // 8, its[q], stream=streams[q].cuda_stream, d_scratch=scratch[q])
+    torch.cuda.synchronize()
+    for q in range(2):
+        got_its = its[q].cpu().numpy()
+        got_bits = np.unpackbits(outs[q].cpu().numpy(), axis=1)
+        for i in list(range(0, n_cb, 397)) + [n_cb - 1]:
+            assert got_its[i] == want[i % base][0] and np.array_equal(got_bits[i], want[i % base][1]), (q, i)
+        assert np.array_equal(got_its, np.array([want[i % base][0] for i in range(n_cb)], np.int32))
+    # captured: the call neither allocates nor synchronises once the configuration is prepared
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    outs[0].zero_()
+    its[0].fill_(55)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        gpu_ctx.ldpc_decode(cfg, n_cb, d_llr, nof_llr, outs[0], k // 8, its[0], stream=torch.cuda.current_stream().cuda_stream,
+                            d_scratch=scratch[0])
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(its[0].cpu().numpy(), np.array([want[i % base][0] for i in range(n_cb)], np.int32))
+
+
 def test_ldpc_encode_decode_round_trip_full_size(gpu_ctx, oracle):
     """Size-independent property at the config-3 shape: every codeblock the GPU encoder produces, with errors inside the
     code's reach, decodes back to its message (encode -> corrupt -> decode)."""
