@@ -207,6 +207,26 @@ int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_t* pdu, con
                              uint32_t grid_nof_ports, uint32_t grid_nof_subc, uint8_t* cw_rm,
                              uint8_t* cw_scrambled);
 
+/* Asynchronous host-span form: pdsch_processor::process "may return before completion, the notifier fires from any
+ * thread exactly once" (pdsch_processor.h:157-170; the reference's own asynchronous pool:
+ * R/lib/phy/upper/channel_processors/pdsch_processor_asynchronous_pool.h:39-143).  A queue keeps up to `depth` PDUs in
+ * flight, each on a stream of its own with pinned staging; plans are cached per PDU shape, so a shape seen before costs
+ * no host derivation.  Submit copies the transport block (the caller's span is free on return) and returns at once;
+ * `done(user, status, grid)` runs on a thread of the HIP runtime when the PDU's grid has reached the host: `grid`
+ * points at [grid_nof_ports][14][grid_nof_subc] cbf16 (zeros + the PDU's resource elements, DM-RS included), valid until
+ * `done` returns -- the handler merges the PDU's RE into the caller's grid and signals its notifier.  NRPHY_ERR_CAPACITY:
+ * `depth` PDUs in flight (wait or retry).  The handler must not call HIP or this library. */
+typedef struct nrphy_pdsch_async nrphy_pdsch_async_t;
+typedef void (*nrphy_pdsch_done_fn)(void* user, int status, const void* grid);
+int nrphy_pdsch_async_create(nrphy_ctx_t* ctx, uint32_t depth, uint32_t grid_nof_ports, uint32_t grid_nof_subc,
+                             uint32_t max_tb_bytes, nrphy_pdsch_async_t** queue);
+int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* queue, const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb,
+                             nrphy_pdsch_done_fn done, void* user);
+int nrphy_pdsch_async_wait(nrphy_pdsch_async_t* queue);    /* until nothing is in flight */
+int nrphy_pdsch_async_destroy(nrphy_pdsch_async_t* queue); /* waits, then frees */
+/* A completion handler that counts: `user` points at a uint64_t incremented atomically per successful PDU. */
+void nrphy_pdsch_async_count_done(void* user, int status, const void* grid);
+
 /* ---- seam B: pdsch_encoder::encode / hal::hw_accelerator_pdsch_enc in transport-block mode --------
  * Replaces pdsch_encoder::encode (R/include/srsran/phy/upper/channel_processors/pdsch_encoder.h;
  * impl R/lib/phy/upper/channel_processors/pdsch_encoder_impl.cpp:28-77) and what

@@ -1,0 +1,573 @@
+// TEST INFRASTRUCTURE -- not part of the product.
+//
+// Runtime evidence for the srsRAN-side adaptors (srsran-edgeric-5g_amd/adaptors/mi355_nrphy_srsran.h) in the build
+// container, where there is no GPU: the adaptors are compiled against the reference's headers and linked with
+//   * the compiled reference (oracle/_ref/libsrsref.so): its resource grids, PDU types and its own processors, and
+//   * a MOCK of the C ABI of include/mi355_nrphy.h whose entry points are backed by the CPU oracle (oracle/liboracle.so).
+// Every test_* function below pushes one reference-side object (pdu_t, config, span) through an adaptor and through the
+// reference's own implementation and hands both results back; tests/test_oracle.py compares them.  What this exercises
+// is the adaptors' own logic: pdu_t -> POD translation, RE masks, grid access through the mapper, asynchronous
+// completion, the HAL enqueue / dequeue protocol, the slot cache of the symbol modulator.  The library behind the real
+// ABI is tested against the same oracle on the GPU (tests/test_gpu_parity.py).
+#include "mi355_nrphy_srsran.h"
+
+#include "lib/phy/generic_functions/dft_processor_generic_impl.h"
+#include "lib/phy/lower/modulation/ofdm_modulator_impl.h"
+#include "lib/phy/support/resource_grid_impl.h"
+#include "lib/phy/upper/channel_coding/crc_calculator_lut_impl.h"
+#include "lib/phy/upper/channel_processors/pdsch_encoder_hw_impl.h"
+#include "lib/phy/upper/sequence_generators/pseudo_random_generator_impl.h"
+#include "lib/phy/upper/signal_processors/nzp_csi_rs_generator_impl.h"
+#include "lib/ofh/compression/iq_compression_bfp_avx2.h"
+#include "lib/ofh/compression/iq_compression_none_avx2.h"
+#include "lib/phy/lower/amplitude_controller/amplitude_controller_clipping_impl.h"
+#include "srsran/srslog/srslog.h"
+
+#include "../nrphy_oracle.h"
+
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+using namespace srsran;
+
+// Built by ref_harness.cpp / ref_harness_dl.cpp (libsrsref.so).
+pdsch_processor::pdu_t            ref_make_pdsch_pdu(const nrphy_pdsch_pdu_t& in);
+std::unique_ptr<pdsch_processor>  ref_make_pdsch_processor(int simd);
+std::unique_ptr<channel_precoder> ref_make_precoder(int simd);
+pdcch_processor::pdu_t            ref_make_pdcch_pdu(const nrphy_pdcch_pdu_t& in);
+ssb_processor::pdu_t              ref_make_ssb_pdu(const nrphy_ssb_pdu_t& in);
+std::unique_ptr<pdcch_processor>  ref_make_pdcch_processor();
+std::unique_ptr<ssb_processor>    ref_make_ssb_processor();
+std::unique_ptr<pdsch_encoder>    ref_make_pdsch_encoder(int simd);
+std::unique_ptr<ldpc_segmenter_tx> ref_make_segmenter();
+
+// ====================================================================================================================
+// Mock of the C ABI, backed by the oracle.  Only what the adaptors under test call.
+// ====================================================================================================================
+struct nrphy_ctx {
+  int dummy;
+};
+struct nrphy_ofdm_plan {
+  nrphy_ofdm_config_t cfg;
+  uint32_t            nof_ports;
+};
+struct nrphy_pdsch_async {
+  uint32_t                 depth, nof_ports, nof_subc;
+  std::mutex               mutex;
+  std::condition_variable  idle;
+  uint32_t                 in_flight = 0;
+  std::vector<std::thread> threads;
+};
+
+extern "C" {
+
+const char* nrphy_strerror(int status)
+{
+  return status == NRPHY_OK ? "ok" : "mock error";
+}
+int nrphy_create(nrphy_ctx_t** ctx, int)
+{
+  *ctx = new nrphy_ctx{0};
+  return NRPHY_OK;
+}
+int nrphy_destroy(nrphy_ctx_t* ctx)
+{
+  delete ctx;
+  return NRPHY_OK;
+}
+int nrphy_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
+{
+  return oracle_pdsch_validate(pdu);
+}
+
+int nrphy_pdsch_async_create(nrphy_ctx_t*, uint32_t depth, uint32_t nof_ports, uint32_t nof_subc, uint32_t, nrphy_pdsch_async_t** q)
+{
+  *q              = new nrphy_pdsch_async;
+  (*q)->depth     = depth;
+  (*q)->nof_ports = nof_ports;
+  (*q)->nof_subc  = nof_subc;
+  return NRPHY_OK;
+}
+int nrphy_pdsch_async_wait(nrphy_pdsch_async_t* q)
+{
+  std::unique_lock<std::mutex> lock(q->mutex);
+  q->idle.wait(lock, [q] { return q->in_flight == 0; });
+  return NRPHY_OK;
+}
+int nrphy_pdsch_async_destroy(nrphy_pdsch_async_t* q)
+{
+  if (q == nullptr) {
+    return NRPHY_OK;
+  }
+  nrphy_pdsch_async_wait(q);
+  for (std::thread& t : q->threads) {
+    t.join();
+  }
+  delete q;
+  return NRPHY_OK;
+}
+// Like the real queue: copies what it needs, returns, completes on another thread -- here a thread per PDU that runs
+// the oracle after a short sleep, so that process() has returned before the notifier fires.
+int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* q, const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb, nrphy_pdsch_done_fn done, void* user)
+{
+  {
+    std::lock_guard<std::mutex> lock(q->mutex);
+    if (q->in_flight == q->depth) {
+      return NRPHY_ERR_CAPACITY;
+    }
+    ++q->in_flight;
+  }
+  nrphy_pdsch_pdu_t    pod = *pdu;
+  std::vector<float>   weights(pdu->precoding, pdu->precoding + 2 * (size_t)pdu->nof_prg * pdu->nof_ports * pdu->nof_layers);
+  std::vector<uint8_t> block(tb, tb + pdu->tb_size_bytes);
+  std::lock_guard<std::mutex> lock(q->mutex);
+  q->threads.emplace_back([q, pod, weights, block, done, user]() mutable {
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    pod.precoding = weights.data();
+    std::vector<uint16_t> grid((size_t)q->nof_ports * 14 * q->nof_subc * 2, 0);
+    const int             rc = oracle_pdsch_process(&pod, block.data(), grid.data(), q->nof_ports, q->nof_subc, nullptr, nullptr);
+    done(user, rc, grid.data());
+    {
+      std::lock_guard<std::mutex> l(q->mutex);
+      --q->in_flight;
+    }
+    q->idle.notify_all();
+  });
+  return NRPHY_OK;
+}
+
+int nrphy_pdsch_encode_host(nrphy_ctx_t*, const nrphy_pdsch_encoder_cfg_t* cfg, const uint8_t* tb, uint8_t* codeword_bits, uint8_t* codeword_packed)
+{
+  int pdu = 0;
+  (void)pdu;
+  // the oracle's pieces in the order of pdsch_encoder_impl::encode: segment, encode, rate match, concatenate
+  const unsigned        cw_bits = cfg->nof_ch_symbols * cfg->qm, stride = 8448 / 8;
+  std::vector<uint8_t>  segments((size_t)NRPHY_MAX_CODEBLOCKS * stride), bits(cw_bits, 0);
+  std::vector<uint32_t> meta(5 * NRPHY_MAX_CODEBLOCKS);
+  uint32_t              zc = 0;
+  const int             C  = oracle_ldpc_segment(cfg->base_graph, cfg->rv, cfg->qm, cfg->nref, cfg->nof_layers, cfg->nof_ch_symbols, tb,
+                                    cfg->tb_size_bytes, segments.data(), stride, meta.data(), &zc);
+  if (C <= 0) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const unsigned       n_full = (cfg->base_graph == 1 ? 66U : 50U) * zc;
+  std::vector<uint8_t> block((n_full + 7) / 8), rm(cw_bits / 8 + 8);
+  for (int i = 0; i != C; ++i) {
+    const uint32_t e = meta[5 * i], offset = meta[5 * i + 1], filler = meta[5 * i + 2];
+    if (oracle_ldpc_encode(cfg->base_graph, zc, &segments[(size_t)i * stride], n_full, block.data()) != NRPHY_OK ||
+        oracle_ldpc_rate_match(cfg->base_graph, zc, cfg->rv, cfg->qm, cfg->nref, filler, block.data(), n_full, rm.data(), e) != NRPHY_OK) {
+      return NRPHY_ERR_ARGUMENT;
+    }
+    for (unsigned k = 0; k != e; ++k) {
+      bits[offset + k] = (rm[k / 8] >> (7 - k % 8)) & 1U;
+    }
+  }
+  for (unsigned i = 0; i != cw_bits; ++i) {
+    if (codeword_bits != nullptr) {
+      codeword_bits[i] = bits[i];
+    }
+    if (codeword_packed != nullptr) {
+      if (i % 8 == 0) {
+        codeword_packed[i / 8] = 0;
+      }
+      codeword_packed[i / 8] |= (uint8_t)(bits[i] << (7 - i % 8));
+    }
+  }
+  return NRPHY_OK;
+}
+
+int nrphy_ofdm_plan_create(nrphy_ctx_t*, const nrphy_ofdm_config_t* cfg, uint32_t nof_ports, nrphy_ofdm_plan_t** plan)
+{
+  *plan = new nrphy_ofdm_plan{*cfg, nof_ports};
+  return NRPHY_OK;
+}
+int nrphy_ofdm_plan_destroy(nrphy_ofdm_plan_t* plan)
+{
+  delete plan;
+  return NRPHY_OK;
+}
+uint32_t nrphy_ofdm_symbol_size(const nrphy_ofdm_config_t* cfg, uint32_t symbol_index)
+{
+  return oracle_ofdm_symbol_size(cfg, symbol_index);
+}
+uint32_t nrphy_ofdm_slot_size(const nrphy_ofdm_config_t* cfg, uint32_t slot_index)
+{
+  return oracle_ofdm_slot_size(cfg, slot_index);
+}
+int nrphy_ofdm_modulate_slot_host(nrphy_ofdm_plan_t* plan, const void* grid, uint32_t slot_index, float* iq)
+{
+  return oracle_ofdm_modulate_slot(&plan->cfg, static_cast<const uint16_t*>(grid), plan->nof_ports, slot_index, iq) > 0 ? NRPHY_OK
+                                                                                                                        : NRPHY_ERR_ARGUMENT;
+}
+
+int nrphy_csi_rs_validate(const nrphy_csi_rs_cfg_t* cfg)
+{
+  return oracle_csi_rs_validate(cfg);
+}
+int nrphy_csi_rs_map_host(nrphy_ctx_t*, const nrphy_csi_rs_cfg_t* cfg, void* grid, uint32_t nof_ports, uint32_t nof_subc)
+{
+  return oracle_csi_rs_map(cfg, static_cast<uint16_t*>(grid), nof_ports, nof_subc);
+}
+int nrphy_pdcch_validate(const nrphy_pdcch_pdu_t* pdu)
+{
+  return oracle_pdcch_validate(pdu);
+}
+int nrphy_pdcch_process_host(nrphy_ctx_t*, const nrphy_pdcch_pdu_t* pdu, void* grid, uint32_t nof_ports, uint32_t nof_subc)
+{
+  return oracle_pdcch_process(pdu, static_cast<uint16_t*>(grid), nof_ports, nof_subc);
+}
+int nrphy_ssb_validate(const nrphy_ssb_pdu_t* pdu)
+{
+  return oracle_ssb_validate(pdu);
+}
+int nrphy_ssb_process_host(nrphy_ctx_t*, const nrphy_ssb_pdu_t* pdu, void* grid, uint32_t nof_ports, uint32_t nof_subc)
+{
+  return oracle_ssb_process(pdu, static_cast<uint16_t*>(grid), nof_ports, nof_subc);
+}
+int nrphy_amplitude_control_host(nrphy_ctx_t*, const nrphy_amplitude_cfg_t* cfg, const float* in, uint32_t nof_samples, float* out,
+                                 nrphy_amplitude_metrics_t* metrics)
+{
+  nrphy_amplitude_stats_t st;
+  oracle_amplitude_control(cfg, in, nof_samples, out, &st);
+  return metrics ? oracle_amplitude_metrics(cfg, &st, metrics) : NRPHY_OK;
+}
+uint32_t nrphy_ofh_compressed_prb_bytes(const nrphy_ofh_compression_cfg_t* cfg)
+{
+  return oracle_ofh_compressed_prb_bytes(cfg);
+}
+int nrphy_ofh_compress_host(nrphy_ctx_t*, const nrphy_ofh_compression_cfg_t* cfg, uint32_t nof_prb, const void* prbs, uint8_t* out)
+{
+  return oracle_ofh_compress(cfg, static_cast<const uint16_t*>(prbs), nof_prb, out) > 0 ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
+}
+
+} // extern "C"
+
+// ====================================================================================================================
+// Tests: adaptor vs the reference's own implementation
+// ====================================================================================================================
+namespace {
+
+void load_grid(resource_grid& grid, const uint16_t* raw, unsigned nof_ports, unsigned nof_subc)
+{
+  grid.set_all_zero();
+  for (unsigned p = 0; p != nof_ports; ++p) {
+    for (unsigned l = 0; l != 14; ++l) {
+      const cbf16_t* row = reinterpret_cast<const cbf16_t*>(raw) + (static_cast<size_t>(p) * 14 + l) * nof_subc;
+      grid.get_writer().put(p, l, 0, 1, span<const cbf16_t>(row, nof_subc));
+    }
+  }
+}
+void store_grid(uint16_t* out, const resource_grid& grid, unsigned nof_ports, unsigned nof_subc)
+{
+  for (unsigned p = 0; p != nof_ports; ++p) {
+    for (unsigned l = 0; l != 14; ++l) {
+      span<const cbf16_t> view = grid.get_reader().get_view(p, l);
+      std::memcpy(out + 2 * (static_cast<size_t>(p * 14 + l) * nof_subc), view.data(), nof_subc * sizeof(cbf16_t));
+    }
+  }
+}
+std::unique_ptr<resource_grid> make_grid(unsigned nof_ports, unsigned nof_subc, bool with_writer_access)
+{
+  std::unique_ptr<resource_grid> g = std::make_unique<resource_grid_impl>(nof_ports, 14, nof_subc, ref_make_precoder(1));
+  if (with_writer_access) {
+    return std::make_unique<mi355::resource_grid_adaptor>(std::move(g));
+  }
+  return g;
+}
+
+class counting_notifier : public pdsch_processor_notifier
+{
+public:
+  void on_finish_processing() override
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    ++count;
+    thread = std::this_thread::get_id();
+    cv.notify_all();
+  }
+  void wait(unsigned n)
+  {
+    std::unique_lock<std::mutex> lock(mutex);
+    cv.wait(lock, [&] { return count >= n; });
+  }
+  std::mutex              mutex;
+  std::condition_variable cv;
+  unsigned                count = 0;
+  std::thread::id         thread;
+};
+
+} // namespace
+
+extern "C" {
+
+// pdsch_processor_adaptor: n PDUs (same grid geometry) submitted back to back into grids of their own, `depth` in
+// flight.  grid_init / grid_adaptor / grid_ref: [n][nof_ports][14][nof_subc] cbf16 raw.  with_writer_access selects
+// how the adaptor reaches the grid (resource_grid_adaptor vs plain reference grid through mapper.map).  Returns the
+// number of notifications received (must be n), or a negative value when one came from the submitting thread before
+// process() returned.
+int adaptor_test_pdsch(unsigned                 n,
+                       const nrphy_pdsch_pdu_t* pods,
+                       const uint8_t* const*    tbs,
+                       unsigned                 nof_ports,
+                       unsigned                 nof_subc,
+                       int                      with_writer_access,
+                       unsigned                 depth,
+                       const uint16_t*          grid_init,
+                       uint16_t*                grid_adaptor,
+                       uint16_t*                grid_ref)
+{
+  const size_t                   words = (size_t)nof_ports * 14 * nof_subc * 2;
+  std::shared_ptr<mi355::context> ctx  = std::make_shared<mi355::context>(0);
+  mi355::pdsch_processor_adaptor  adaptor(ctx, nof_ports, nof_subc, depth);
+  std::unique_ptr<pdsch_processor> reference = ref_make_pdsch_processor(1);
+  std::vector<std::unique_ptr<resource_grid>> grids;
+  std::vector<pdsch_processor::pdu_t>         pdus;
+  counting_notifier                           notifier;
+  bool                                        early = false;
+  for (unsigned i = 0; i != n; ++i) {
+    grids.push_back(make_grid(nof_ports, nof_subc, with_writer_access != 0));
+    load_grid(*grids.back(), grid_init + i * words, nof_ports, nof_subc);
+    pdus.push_back(ref_make_pdsch_pdu(pods[i]));
+  }
+  for (unsigned i = 0; i != n; ++i) {
+    const unsigned before = notifier.count;
+    static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data;
+    data.push_back(span<const uint8_t>(tbs[i], pods[i].tb_size_bytes));
+    adaptor.process(grids[i]->get_mapper(), notifier, data, pdus[i]);
+    // with free slots the call must have returned before its own PDU completed (the mock sleeps 2 ms per PDU)
+    if (i < depth && notifier.count > before) {
+      early = true;
+    }
+  }
+  notifier.wait(n);
+  for (unsigned i = 0; i != n; ++i) {
+    store_grid(grid_adaptor + i * words, *grids[i], nof_ports, nof_subc);
+    // the reference's own processor on the same PDU and the same initial grid
+    std::unique_ptr<resource_grid> g = make_grid(nof_ports, nof_subc, false);
+    load_grid(*g, grid_init + i * words, nof_ports, nof_subc);
+    counting_notifier done;
+    static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data;
+    data.push_back(span<const uint8_t>(tbs[i], pods[i].tb_size_bytes));
+    reference->process(g->get_mapper(), done, data, pdus[i]);
+    store_grid(grid_ref + i * words, *g, nof_ports, nof_subc);
+  }
+  if (early || notifier.thread == std::this_thread::get_id()) {
+    return -1;
+  }
+  return (int)notifier.count;
+}
+
+// hal::hw_accelerator_pdsch_enc adaptor driven by the reference's own pdsch_encoder_hw_impl (configure / enqueue /
+// dequeue protocol, transport-block mode) against pdsch_encoder_impl: codeword bits, one per byte.
+int adaptor_test_pdsch_encoder_hw(unsigned bg, unsigned rv, unsigned qm, unsigned nref, unsigned nof_layers, unsigned nof_ch_symbols,
+                                  const uint8_t* tb, unsigned tb_bytes, uint8_t* out_adaptor, uint8_t* out_ref)
+{
+  pdsch_encoder::configuration cfg;
+  cfg.base_graph     = bg == 1 ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+  cfg.rv             = rv;
+  cfg.mod            = qm == 2 ? modulation_scheme::QPSK : qm == 4 ? modulation_scheme::QAM16 : qm == 6 ? modulation_scheme::QAM64 : modulation_scheme::QAM256;
+  cfg.Nref           = nref;
+  cfg.nof_layers     = nof_layers;
+  cfg.nof_ch_symbols = nof_ch_symbols;
+  const unsigned cw_bits = nof_ch_symbols * qm;
+  pdsch_encoder_hw_impl::sch_crc crcs;
+  crcs.crc16  = std::make_unique<crc_calculator_lut_impl>(crc_generator_poly::CRC16);
+  crcs.crc24A = std::make_unique<crc_calculator_lut_impl>(crc_generator_poly::CRC24A);
+  crcs.crc24B = std::make_unique<crc_calculator_lut_impl>(crc_generator_poly::CRC24B);
+  std::shared_ptr<mi355::context> ctx = std::make_shared<mi355::context>(0);
+  pdsch_encoder_hw_impl through_hal(crcs, ref_make_segmenter(), std::make_unique<mi355::hw_accelerator_pdsch_enc_adaptor>(ctx));
+  through_hal.encode(span<uint8_t>(out_adaptor, cw_bits), span<const uint8_t>(tb, tb_bytes), cfg);
+  ref_make_pdsch_encoder(1)->encode(span<uint8_t>(out_ref, cw_bits), span<const uint8_t>(tb, tb_bytes), cfg);
+  return (int)cw_bits;
+}
+
+// pdsch_pdu_validator_adaptor (pdu_t -> POD -> validate) against the reference's validator.
+int adaptor_test_pdsch_validator(const nrphy_pdsch_pdu_t* pod)
+{
+  mi355::pdsch_pdu_validator_adaptor v;
+  return v.is_valid(ref_make_pdsch_pdu(*pod)) ? 1 : 0;
+}
+
+// ofdm_symbol_modulator_adaptor / ofdm_slot_modulator_adaptor: a grid through the adaptor symbol by symbol (port-major
+// order, as pdxch_processor_impl asks) and slot by slot, and through the reference's ofdm_slot_modulator_impl.
+int adaptor_test_ofdm(const nrphy_ofdm_config_t* c, const uint16_t* grid_raw, unsigned nof_ports, unsigned slot_index, float* iq_symbols,
+                      float* iq_slot, float* iq_ref)
+{
+  const unsigned                 nof_subc = 12 * c->bw_rb;
+  std::unique_ptr<resource_grid> grid     = make_grid(nof_ports, nof_subc, false);
+  load_grid(*grid, grid_raw, nof_ports, nof_subc);
+  ofdm_modulator_configuration cfg;
+  cfg.numerology     = c->numerology;
+  cfg.bw_rb          = c->bw_rb;
+  cfg.dft_size       = c->dft_size;
+  cfg.cp             = c->cp ? cyclic_prefix::EXTENDED : cyclic_prefix::NORMAL;
+  cfg.scale          = c->scale;
+  cfg.center_freq_hz = c->center_freq_hz;
+  std::shared_ptr<mi355::context>      ctx = std::make_shared<mi355::context>(0);
+  mi355::ofdm_symbol_modulator_adaptor by_symbol(ctx, cfg, nof_ports);
+  mi355::ofdm_slot_modulator_adaptor   by_slot(ctx, cfg, nof_ports);
+  dft_processor::configuration         dft_cfg;
+  dft_cfg.size = c->dft_size;
+  dft_cfg.dir  = dft_processor::direction::INVERSE;
+  ofdm_modulator_common_configuration common;
+  common.dft = std::make_unique<dft_processor_generic_impl>(dft_cfg);
+  ofdm_slot_modulator_impl reference(common, cfg);
+  const unsigned           nsymb = c->cp ? 12 : 14, slot_size = reference.get_slot_size(slot_index);
+  if (by_slot.get_slot_size(slot_index) != slot_size) {
+    return -1;
+  }
+  for (unsigned l = 0, offset = 0; l != nsymb; ++l) { // the real-time loop: every port of one symbol, then the next symbol
+    const unsigned size = by_symbol.get_symbol_size(nsymb * slot_index + l);
+    for (unsigned p = 0; p != nof_ports; ++p) {
+      by_symbol.modulate(span<cf_t>(reinterpret_cast<cf_t*>(iq_symbols) + (size_t)p * slot_size + offset, size), grid->get_reader(), p,
+                         nsymb * slot_index + l);
+    }
+    offset += size;
+  }
+  for (unsigned p = 0; p != nof_ports; ++p) {
+    by_slot.modulate(span<cf_t>(reinterpret_cast<cf_t*>(iq_slot) + (size_t)p * slot_size, slot_size), grid->get_reader(), p, slot_index);
+    reference.modulate(span<cf_t>(reinterpret_cast<cf_t*>(iq_ref) + (size_t)p * slot_size, slot_size), grid->get_reader(), p, slot_index);
+  }
+  return (int)slot_size;
+}
+
+// nzp_csi_rs_generator_adaptor against nzp_csi_rs_generator_impl, both ways into the grid.
+int adaptor_test_csi_rs(const nrphy_csi_rs_cfg_t* c, unsigned nof_ports, unsigned nof_subc, int with_writer_access, const uint16_t* grid_init,
+                        uint16_t* grid_adaptor, uint16_t* grid_ref)
+{
+  nzp_csi_rs_generator::config_t cfg;
+  cfg.slot                     = slot_point(4, 0, c->slot_index);
+  cfg.cp                       = c->cp ? cyclic_prefix::EXTENDED : cyclic_prefix::NORMAL;
+  cfg.start_rb                 = c->start_rb;
+  cfg.nof_rb                   = c->nof_rb;
+  cfg.csi_rs_mapping_table_row = c->row;
+  for (unsigned i = 0; i != c->nof_k_ref; ++i) {
+    cfg.freq_allocation_ref_idx.push_back(c->k_ref[i]);
+  }
+  cfg.symbol_l0     = c->symbol_l0;
+  cfg.symbol_l1     = c->symbol_l1;
+  cfg.cdm           = static_cast<csi_rs_cdm_type>(c->cdm);
+  cfg.freq_density  = static_cast<csi_rs_freq_density_type>(c->density);
+  cfg.scrambling_id = c->scrambling_id;
+  cfg.amplitude     = c->amplitude;
+  cfg.precoding     = precoding_configuration(c->nof_ports, c->nof_ports, c->nof_prg, c->prg_size_rb);
+  for (unsigned p = 0; p != c->nof_ports; ++p) {
+    for (unsigned l = 0; l != c->nof_ports; ++l) {
+      const float* w = c->precoding + 2 * (p * c->nof_ports + l);
+      cfg.precoding.set_coefficient(cf_t(w[0], w[1]), l, p, 0);
+    }
+  }
+  std::shared_ptr<mi355::context>     ctx = std::make_shared<mi355::context>(0);
+  mi355::nzp_csi_rs_generator_adaptor adaptor(ctx, nof_ports, nof_subc);
+  std::unique_ptr<resource_grid>      ga = make_grid(nof_ports, nof_subc, with_writer_access != 0), gr = make_grid(nof_ports, nof_subc, false);
+  load_grid(*ga, grid_init, nof_ports, nof_subc);
+  load_grid(*gr, grid_init, nof_ports, nof_subc);
+  adaptor.map(ga->get_mapper(), cfg);
+  nzp_csi_rs_generator_impl reference(std::make_unique<pseudo_random_generator_impl>());
+  reference.map(gr->get_mapper(), cfg);
+  store_grid(grid_adaptor, *ga, nof_ports, nof_subc);
+  store_grid(grid_ref, *gr, nof_ports, nof_subc);
+  return NRPHY_OK;
+}
+
+int adaptor_test_pdcch(const nrphy_pdcch_pdu_t* pod, unsigned nof_ports, unsigned nof_subc, int with_writer_access, const uint16_t* grid_init,
+                       uint16_t* grid_adaptor, uint16_t* grid_ref)
+{
+  const pdcch_processor::pdu_t    pdu = ref_make_pdcch_pdu(*pod);
+  std::shared_ptr<mi355::context> ctx = std::make_shared<mi355::context>(0);
+  mi355::pdcch_processor_adaptor  adaptor(ctx, nof_ports, nof_subc);
+  mi355::pdcch_pdu_validator_adaptor validator;
+  if (!validator.is_valid(pdu)) {
+    return -1;
+  }
+  std::unique_ptr<resource_grid> ga = make_grid(nof_ports, nof_subc, with_writer_access != 0), gr = make_grid(nof_ports, nof_subc, false);
+  load_grid(*ga, grid_init, nof_ports, nof_subc);
+  load_grid(*gr, grid_init, nof_ports, nof_subc);
+  adaptor.process(ga->get_mapper(), pdu);
+  ref_make_pdcch_processor()->process(gr->get_mapper(), pdu);
+  store_grid(grid_adaptor, *ga, nof_ports, nof_subc);
+  store_grid(grid_ref, *gr, nof_ports, nof_subc);
+  return NRPHY_OK;
+}
+
+int adaptor_test_ssb(const nrphy_ssb_pdu_t* pod, unsigned nof_ports, unsigned nof_subc, const uint16_t* grid_init, uint16_t* grid_adaptor,
+                     uint16_t* grid_ref)
+{
+  const ssb_processor::pdu_t      pdu = ref_make_ssb_pdu(*pod);
+  std::shared_ptr<mi355::context> ctx = std::make_shared<mi355::context>(0);
+  mi355::ssb_processor_adaptor    adaptor(ctx, nof_ports, nof_subc);
+  std::unique_ptr<resource_grid>  ga = make_grid(nof_ports, nof_subc, false), gr = make_grid(nof_ports, nof_subc, false);
+  load_grid(*ga, grid_init, nof_ports, nof_subc);
+  load_grid(*gr, grid_init, nof_ports, nof_subc);
+  adaptor.process(ga->get_writer(), pdu);
+  ref_make_ssb_processor()->process(gr->get_writer(), pdu);
+  store_grid(grid_adaptor, *ga, nof_ports, nof_subc);
+  store_grid(grid_ref, *gr, nof_ports, nof_subc);
+  return NRPHY_OK;
+}
+
+// amplitude_controller_adaptor against amplitude_controller_clipping_impl over `calls` consecutive buffers (running counters).
+int adaptor_test_amplitude(int enable_clipping, float gain_dB, float full_scale, float ceiling_dBFS, const float* in, unsigned nof_samples,
+                           unsigned calls, float* out_adaptor, float* out_ref, double* metrics_adaptor, double* metrics_ref)
+{
+  nrphy_amplitude_cfg_t           cfg = {0, (uint32_t)enable_clipping, gain_dB, full_scale, ceiling_dBFS};
+  std::shared_ptr<mi355::context> ctx = std::make_shared<mi355::context>(0);
+  mi355::amplitude_controller_adaptor adaptor(ctx, cfg);
+  amplitude_controller_clipping_impl  reference(enable_clipping != 0, gain_dB, full_scale, ceiling_dBFS);
+  amplitude_controller_metrics        ma = {}, mr = {};
+  for (unsigned i = 0; i != calls; ++i) {
+    span<const cf_t> x(reinterpret_cast<const cf_t*>(in) + (size_t)i * nof_samples, nof_samples);
+    ma = adaptor.process(span<cf_t>(reinterpret_cast<cf_t*>(out_adaptor) + (size_t)i * nof_samples, nof_samples), x);
+    mr = reference.process(span<cf_t>(reinterpret_cast<cf_t*>(out_ref) + (size_t)i * nof_samples, nof_samples), x);
+  }
+  const amplitude_controller_metrics* m[2]   = {&ma, &mr};
+  double*                             out[2] = {metrics_adaptor, metrics_ref};
+  for (unsigned k = 0; k != 2; ++k) {
+    out[k][0] = m[k]->avg_power_fs;
+    out[k][1] = m[k]->peak_power_fs;
+    out[k][2] = m[k]->papr_lin;
+    out[k][3] = m[k]->gain_dB;
+    out[k][4] = (double)m[k]->nof_processed_samples;
+    out[k][5] = (double)m[k]->nof_clipped_samples;
+    out[k][6] = (double)m[k]->clipping_probability;
+    out[k][7] = m[k]->clipping_enabled ? 1.0 : 0.0;
+  }
+  return NRPHY_OK;
+}
+
+// iq_compressor_adaptor against the reference's AVX2 compressors: serialised PRBs of both.
+int adaptor_test_ofh(int type, unsigned data_width, float iq_scaling, const uint16_t* prbs, unsigned nof_prb, uint8_t* out_adaptor, uint8_t* out_ref)
+{
+  static srslog::basic_logger&    logger = srslog::fetch_basic_logger("OFH_ADAPTOR");
+  std::shared_ptr<mi355::context> ctx    = std::make_shared<mi355::context>(0);
+  mi355::iq_compressor_adaptor    adaptor(ctx, iq_scaling);
+  std::unique_ptr<ofh::iq_compressor> reference;
+  if (type == 0) {
+    reference = std::make_unique<ofh::iq_compression_none_avx2>(logger, iq_scaling);
+  } else {
+    reference = std::make_unique<ofh::iq_compression_bfp_avx2>(logger, iq_scaling);
+  }
+  ofh::ru_compression_params params;
+  params.type       = type == 0 ? ofh::compression_type::none : ofh::compression_type::BFP;
+  params.data_width = data_width;
+  std::vector<ofh::compressed_prb> a(nof_prb), r(nof_prb);
+  span<const cbf16_t>              x(reinterpret_cast<const cbf16_t*>(prbs), 12 * nof_prb);
+  adaptor.compress(a, x, params);
+  reference->compress(r, x, params);
+  unsigned na = 0, nr = 0;
+  for (unsigned i = 0; i != nof_prb; ++i) {
+    if (type != 0) {
+      out_adaptor[na++] = a[i].get_compression_param();
+      out_ref[nr++]     = r[i].get_compression_param();
+    }
+    span<const uint8_t> da = a[i].get_packed_data(), dr = r[i].get_packed_data();
+    std::memcpy(out_adaptor + na, da.data(), da.size());
+    std::memcpy(out_ref + nr, dr.data(), dr.size());
+    na += da.size();
+    nr += dr.size();
+  }
+  return na == nr ? (int)na : -1;
+}
+
+} // extern "C"

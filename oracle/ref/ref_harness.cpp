@@ -242,6 +242,28 @@ void copy_grid_out(uint16_t* out, const resource_grid_reader& reader, unsigned n
 
 } // namespace
 
+// For oracle/ref/adaptor_harness.cpp: the reference objects behind the PODs and a processor of the reference.
+srsran::pdsch_processor::pdu_t ref_make_pdsch_pdu(const nrphy_pdsch_pdu_t& in)
+{
+  return to_pdu(in);
+}
+std::unique_ptr<srsran::pdsch_processor> ref_make_pdsch_processor(int simd)
+{
+  return make_processor(simd);
+}
+std::unique_ptr<srsran::channel_precoder> ref_make_precoder(int simd)
+{
+  return make_precoder(simd);
+}
+std::unique_ptr<srsran::pdsch_encoder> ref_make_pdsch_encoder(int simd)
+{
+  return make_pdsch_encoder(simd);
+}
+std::unique_ptr<srsran::ldpc_segmenter_tx> ref_make_segmenter()
+{
+  return make_segmenter();
+}
+
 extern "C" {
 
 // ---- 3GPP TS 38.212 Tables 5.3.2-2 / 5.3.2-3 as the reference holds them -------------------------

@@ -119,6 +119,89 @@ pbch_encoder::pbch_msg_t to_pbch_msg(const nrphy_ssb_pdu_t& in)
 
 } // namespace
 
+// For oracle/ref/adaptor_harness.cpp too: the reference objects behind the PODs.
+pdcch_processor::pdu_t ref_make_pdcch_pdu(const nrphy_pdcch_pdu_t& in_)
+{
+  const nrphy_pdcch_pdu_t* in = &in_;
+  pdcch_processor::pdu_t pdu;
+  pdu.context                    = std::nullopt;
+  pdu.slot                       = slot_point(4, 0, in->slot_index);
+  pdu.cp                         = in->cp ? cyclic_prefix::EXTENDED : cyclic_prefix::NORMAL;
+  pdu.coreset.bwp_size_rb        = in->bwp_size_rb;
+  pdu.coreset.bwp_start_rb       = in->bwp_start_rb;
+  pdu.coreset.start_symbol_index = in->start_symbol_index;
+  pdu.coreset.duration           = in->duration;
+  pdu.coreset.frequency_resources.resize(pdcch_constants::MAX_NOF_FREQ_RESOURCES);
+  for (unsigned i = 0; i != pdcch_constants::MAX_NOF_FREQ_RESOURCES; ++i) {
+    pdu.coreset.frequency_resources.set(i, (in->frequency_resources >> i) & 1U);
+  }
+  pdu.coreset.cce_to_reg_mapping = static_cast<pdcch_processor::cce_to_reg_mapping_type>(in->cce_to_reg_mapping);
+  pdu.coreset.reg_bundle_size    = in->reg_bundle_size;
+  pdu.coreset.interleaver_size   = in->interleaver_size;
+  pdu.coreset.shift_index        = in->shift_index;
+  pdu.dci.rnti                   = in->rnti;
+  pdu.dci.n_id_pdcch_dmrs        = in->n_id_pdcch_dmrs;
+  pdu.dci.n_id_pdcch_data        = in->n_id_pdcch_data;
+  pdu.dci.n_rnti                 = in->n_rnti;
+  pdu.dci.cce_index              = in->cce_index;
+  pdu.dci.aggregation_level      = in->aggregation_level;
+  pdu.dci.dmrs_power_offset_dB   = in->dmrs_power_offset_dB;
+  pdu.dci.data_power_offset_dB   = in->data_power_offset_dB;
+  for (unsigned i = 0; i != in->payload_size; ++i) {
+    pdu.dci.payload.push_back(in->payload[i]);
+  }
+  pdu.dci.precoding = precoding_configuration(1, in->nof_ports, in->nof_prg, in->prg_size_rb);
+  for (unsigned g = 0; g != in->nof_prg; ++g) {
+    for (unsigned p = 0; p != in->nof_ports; ++p) {
+      const float* w = in->precoding + 2 * (g * in->nof_ports + p);
+      pdu.dci.precoding.set_coefficient(cf_t(w[0], w[1]), 0, p, g);
+    }
+  }
+  return pdu;
+}
+
+ssb_processor::pdu_t ref_make_ssb_pdu(const nrphy_ssb_pdu_t& in_)
+{
+  const nrphy_ssb_pdu_t* in = &in_;
+  ssb_processor::pdu_t pdu;
+  pdu.slot              = slot_point(in->numerology, in->sfn, in->slot_index);
+  pdu.phys_cell_id      = static_cast<pci_t>(in->phys_cell_id);
+  pdu.beta_pss          = in->beta_pss_dB;
+  pdu.ssb_idx           = in->ssb_idx;
+  pdu.L_max             = in->L_max;
+  pdu.common_scs        = to_subcarrier_spacing(in->common_scs);
+  pdu.subcarrier_offset = in->subcarrier_offset;
+  pdu.offset_to_pointA  = in->offset_to_pointA;
+  pdu.pattern_case      = static_cast<ssb_pattern_case>(in->pattern_case);
+  for (unsigned i = 0; i != 32; ++i) {
+    pdu.bch_payload[i] = in->bch_payload[i];
+  }
+  for (unsigned i = 0; i != in->nof_ports; ++i) {
+    pdu.ports.push_back(in->ports[i]);
+  }
+  return pdu;
+}
+
+std::unique_ptr<pdcch_processor> ref_make_pdcch_processor()
+{
+  return std::make_unique<pdcch_processor_impl>(
+      make_pdcch_encoder(),
+      std::make_unique<pdcch_modulator_impl>(std::make_unique<modulation_mapper_lut_impl>(), std::make_unique<pseudo_random_generator_impl>()),
+      std::make_unique<dmrs_pdcch_processor_impl>(std::make_unique<pseudo_random_generator_impl>()));
+}
+
+std::unique_ptr<ssb_processor> ref_make_ssb_processor()
+{
+  ssb_processor_config cfg;
+  cfg.encoder   = make_pbch_encoder();
+  cfg.modulator = std::make_unique<pbch_modulator_impl>(std::make_unique<modulation_mapper_lut_impl>(),
+                                                        std::make_unique<pseudo_random_generator_impl>());
+  cfg.dmrs      = std::make_unique<dmrs_pbch_processor_impl>(std::make_unique<pseudo_random_generator_impl>());
+  cfg.pss       = std::make_unique<pss_processor_impl>();
+  cfg.sss       = std::make_unique<sss_processor_impl>();
+  return std::make_unique<ssb_processor_impl>(std::move(cfg));
+}
+
 extern "C" {
 
 // TS 38.212 Table 5.3.1.2-1 (polar sequence, 1024 entries in ascending reliability) and Table 5.3.1.1-1 (interleaving
@@ -166,40 +249,7 @@ int ref_pdcch_process(const nrphy_pdcch_pdu_t* in, uint16_t* grid_io, unsigned n
 {
   resource_grid_impl grid(nof_ports, 14, nof_subc, make_precoder_dl(simd));
   load_grid(grid, grid_io, nof_ports, nof_subc);
-  pdcch_processor::pdu_t pdu;
-  pdu.context                    = std::nullopt;
-  pdu.slot                       = slot_point(4, 0, in->slot_index);
-  pdu.cp                         = in->cp ? cyclic_prefix::EXTENDED : cyclic_prefix::NORMAL;
-  pdu.coreset.bwp_size_rb        = in->bwp_size_rb;
-  pdu.coreset.bwp_start_rb       = in->bwp_start_rb;
-  pdu.coreset.start_symbol_index = in->start_symbol_index;
-  pdu.coreset.duration           = in->duration;
-  pdu.coreset.frequency_resources.resize(pdcch_constants::MAX_NOF_FREQ_RESOURCES);
-  for (unsigned i = 0; i != pdcch_constants::MAX_NOF_FREQ_RESOURCES; ++i) {
-    pdu.coreset.frequency_resources.set(i, (in->frequency_resources >> i) & 1U);
-  }
-  pdu.coreset.cce_to_reg_mapping = static_cast<pdcch_processor::cce_to_reg_mapping_type>(in->cce_to_reg_mapping);
-  pdu.coreset.reg_bundle_size    = in->reg_bundle_size;
-  pdu.coreset.interleaver_size   = in->interleaver_size;
-  pdu.coreset.shift_index        = in->shift_index;
-  pdu.dci.rnti                   = in->rnti;
-  pdu.dci.n_id_pdcch_dmrs        = in->n_id_pdcch_dmrs;
-  pdu.dci.n_id_pdcch_data        = in->n_id_pdcch_data;
-  pdu.dci.n_rnti                 = in->n_rnti;
-  pdu.dci.cce_index              = in->cce_index;
-  pdu.dci.aggregation_level      = in->aggregation_level;
-  pdu.dci.dmrs_power_offset_dB   = in->dmrs_power_offset_dB;
-  pdu.dci.data_power_offset_dB   = in->data_power_offset_dB;
-  for (unsigned i = 0; i != in->payload_size; ++i) {
-    pdu.dci.payload.push_back(in->payload[i]);
-  }
-  pdu.dci.precoding = precoding_configuration(1, in->nof_ports, in->nof_prg, in->prg_size_rb);
-  for (unsigned g = 0; g != in->nof_prg; ++g) {
-    for (unsigned p = 0; p != in->nof_ports; ++p) {
-      const float* w = in->precoding + 2 * (g * in->nof_ports + p);
-      pdu.dci.precoding.set_coefficient(cf_t(w[0], w[1]), 0, p, g);
-    }
-  }
+  pdcch_processor::pdu_t pdu = ref_make_pdcch_pdu(*in);
   pdcch_processor_impl proc(make_pdcch_encoder(),
                             std::make_unique<pdcch_modulator_impl>(std::make_unique<modulation_mapper_lut_impl>(),
                                                                    std::make_unique<pseudo_random_generator_impl>()),
@@ -222,22 +272,7 @@ int ref_ssb_process(const nrphy_ssb_pdu_t* in, uint16_t* grid_io, unsigned nof_p
 {
   resource_grid_impl grid(nof_ports, 14, nof_subc, make_precoder_dl(0));
   load_grid(grid, grid_io, nof_ports, nof_subc);
-  ssb_processor::pdu_t pdu;
-  pdu.slot              = slot_point(in->numerology, in->sfn, in->slot_index);
-  pdu.phys_cell_id      = static_cast<pci_t>(in->phys_cell_id);
-  pdu.beta_pss          = in->beta_pss_dB;
-  pdu.ssb_idx           = in->ssb_idx;
-  pdu.L_max             = in->L_max;
-  pdu.common_scs        = to_subcarrier_spacing(in->common_scs);
-  pdu.subcarrier_offset = in->subcarrier_offset;
-  pdu.offset_to_pointA  = in->offset_to_pointA;
-  pdu.pattern_case      = static_cast<ssb_pattern_case>(in->pattern_case);
-  for (unsigned i = 0; i != 32; ++i) {
-    pdu.bch_payload[i] = in->bch_payload[i];
-  }
-  for (unsigned i = 0; i != in->nof_ports; ++i) {
-    pdu.ports.push_back(in->ports[i]);
-  }
+  ssb_processor::pdu_t pdu = ref_make_ssb_pdu(*in);
   ssb_processor_config cfg;
   cfg.encoder   = make_pbch_encoder();
   cfg.modulator = std::make_unique<pbch_modulator_impl>(std::make_unique<modulation_mapper_lut_impl>(),

@@ -37,6 +37,37 @@ def main():
         ms_p, ms_o = 1e3 * (t1 - t0) / n, 1e3 * (t2 - t1) / n
         print("config %d: pdsch_process_host %.3f ms/PDU, ofdm modulate_slot_host (all ports) %.3f ms/slot -> %.0f slots/s "
               "through the shim, one slot in flight" % (cfg, ms_p, ms_o, 1e3 / (ms_p + ms_o)), flush=True)
+        # The asynchronous seam (nrphy_pdsch_async_*: what the asynchronous pdsch_processor drop-in uses): `depth` PDUs in
+        # flight, transport block in and whole grid out over PCIe for every PDU, completions counted by the library's
+        # counting handler on the runtime's threads.
+        import ctypes as C
+        h = ctx.lib
+        done_fn = C.cast(h.nrphy_pdsch_async_count_done, C.c_void_p)
+        for depth in (1, 4, 8):
+            q = C.c_void_p()
+            assert h.nrphy_pdsch_async_create(ctx.handle, depth, ports, subc, pdu.tb_size_bytes, C.byref(q)) == 0
+            count = C.c_uint64(0)
+            total = 400
+
+            def pump(n_submit):
+                sent = 0
+                while sent < n_submit:
+                    rc = h.nrphy_pdsch_async_submit(q, C.byref(pdu), tb.ctypes.data, done_fn, C.byref(count))
+                    if rc == 0:
+                        sent += 1
+                    elif rc != 4:   # NRPHY_ERR_CAPACITY: queue full, try again
+                        raise RuntimeError(rc)
+                h.nrphy_pdsch_async_wait(q)
+
+            pump(20)
+            count.value = 0
+            t0 = time.perf_counter()
+            pump(total)
+            dt = time.perf_counter() - t0
+            assert count.value == total, (count.value, total)
+            print("config %d: asynchronous seam, %d in flight: %.0f PDUs/s (%.3f ms per PDU)" % (cfg, depth, total / dt, 1e3 * dt / total),
+                  flush=True)
+            h.nrphy_pdsch_async_destroy(q)
 
 
 if __name__ == "__main__":

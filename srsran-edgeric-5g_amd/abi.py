@@ -122,6 +122,8 @@ class CsiRsCfg(C.Structure):
                 ("precoding", C.POINTER(C.c_float))]
 
 
+PDSCH_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)   # nrphy_pdsch_done_fn
+
 CSI_DENSITY = {"dot5_even": 0, "dot5_odd": 1, "one": 2, "three": 3}
 CSI_ROW_PORTS = {1: 1, 2: 1, 3: 2, 4: 4, 5: 4}
 
@@ -380,6 +382,10 @@ def declare(lib, prefix="nrphy_"):
     sig("ofdm_plan_enable_timing", i32, vp, u32)
     sig("ofdm_plan_kernel_time", i32, vp, P(C.c_float), P(u32))
     sig("pdsch_process_host", i32, vp, P(PdschPdu), u8p, vp, u32, u32, u8p, u8p)
+    sig("pdsch_async_create", i32, vp, u32, u32, u32, u32, P(vp))
+    sig("pdsch_async_submit", i32, vp, P(PdschPdu), u8p, vp, vp)
+    sig("pdsch_async_wait", i32, vp)
+    sig("pdsch_async_destroy", i32, vp)
     sig("pdsch_encode_host", i32, vp, P(PdschEncoderCfg), u8p, u8p, u8p)
     sig("ldpc_encode", i32, vp, u32, u32, u32, u8p, u32, u32, u8p, u32, vp)
     sig("ofdm_plan_create", i32, vp, P(OfdmConfig), u32, P(vp))
@@ -447,6 +453,8 @@ ABI_SYMBOLS = [
     "nrphy_llr_descramble", "nrphy_llr_descramble_host",
     "nrphy_pdcch_validate", "nrphy_pdcch_process", "nrphy_pdcch_process_host", "nrphy_pdcch_encode_host",
     "nrphy_ssb_validate", "nrphy_ssb_process", "nrphy_ssb_process_host", "nrphy_pbch_encode_host",
+    "nrphy_pdsch_async_create", "nrphy_pdsch_async_submit", "nrphy_pdsch_async_wait", "nrphy_pdsch_async_destroy",
+    "nrphy_pdsch_async_count_done",
     "nrphy_amplitude_control", "nrphy_amplitude_metrics", "nrphy_amplitude_control_host", "nrphy_iq_convert_ci16",
     "nrphy_iq_convert_ci16_host", "nrphy_ofdm_run_ci16", "nrphy_ofh_compressed_prb_bytes", "nrphy_ofh_compress",
     "nrphy_ofh_compress_host",

@@ -38,12 +38,31 @@
 #include "srsran/ran/csi_rs/csi_rs_pattern.h"
 #include "srsran/srsvec/bit.h"
 
+#include "srsran/ofh/compression/iq_compressor.h"
+#include "srsran/phy/lower/amplitude_controller/amplitude_controller.h"
+#include "srsran/phy/lower/amplitude_controller/amplitude_controller_factories.h"
+#include "srsran/phy/support/re_buffer.h"
+#include "srsran/phy/support/resource_grid.h"
+#include "srsran/phy/support/support_factories.h"
+#include "srsran/phy/upper/channel_processors/pdcch_processor.h"
+#include "srsran/phy/upper/channel_processors/ssb_processor.h"
+#include "srsran/ran/precoding/precoding_codebooks.h"
+
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <memory>
 #include <vector>
 
 namespace mi355 {
+
+/// Failure of a library call behind an interface that cannot return one: always logged, never compiled out.
+inline void report_failure(const char* what, int rc)
+{
+  if (rc != NRPHY_OK) {
+    fmt::print(stderr, "mi355: {} failed: {}\n", what, nrphy_strerror(rc));
+  }
+}
 
 /// Shared ownership of one nrphy context per process/device.
 class context
@@ -52,7 +71,7 @@ public:
   explicit context(int device_id = 0)
   {
     int rc = nrphy_create(&ctx, device_id);
-    srsran_assert(rc == NRPHY_OK, "nrphy_create failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_create", rc);
   }
   ~context() { nrphy_destroy(ctx); }
   context(const context&)            = delete;
@@ -146,20 +165,208 @@ public:
   }
 };
 
-/// Resolves the grid writer behind the mapper handed to pdsch_processor::process().  srsRAN 24.04 gives the
-/// processor only a resource_grid_mapper; the integration adds the one-line accessor shown in INTEGRATION.md.
-using writer_resolver = std::function<srsran::resource_grid_writer&(srsran::resource_grid_mapper&)>;
+// ---- from a staging grid into the caller's grid ----------------------------------------------------------------------
+// srsRAN 24.04 hands channel processors a resource_grid_mapper, not the grid.  Two ways in, neither a patch to the
+// reference: (1) the gNB creates its grids through resource_grid_factory_adaptor below (a factory swap where upper_phy
+// builds its grid pool): the mapper of such a grid also gives its writer, and the adaptors put cbf16 words straight
+// into the grid -- bit-exact; (2) with any other grid the adaptors go through resource_grid_mapper::map with an
+// identity precoding, one call per run of PRBs that share a RE mask -- numerically identical, a -0.0 may come out
+// as +0.0 (the precoder adds the zero contributions of the other ports).
 
-/// pdsch_processor over nrphy_pdsch_process_host: the grid rows of the PDU are computed on the GPU into a host
-/// staging grid and put into the caller's grid through its writer (only the RE this PDU maps are touched).
+/// A mapper that forwards to the grid's own and also gives the grid's writer.
+class resource_grid_mapper_with_writer : public srsran::resource_grid_mapper
+{
+public:
+  resource_grid_mapper_with_writer(srsran::resource_grid_mapper& inner_, srsran::resource_grid_writer& writer_) :
+    inner(inner_), writer(writer_)
+  {
+  }
+  void map(const srsran::re_buffer_reader<srsran::cf_t>& input,
+           const srsran::re_pattern&                     pattern,
+           const srsran::precoding_configuration&        precoding) override
+  {
+    inner.map(input, pattern, precoding);
+  }
+  void map(symbol_buffer&                         buffer,
+           const srsran::re_pattern_list&         pattern,
+           const srsran::re_pattern_list&         reserved,
+           const srsran::precoding_configuration& precoding,
+           unsigned                               re_skip = 0) override
+  {
+    inner.map(buffer, pattern, reserved, precoding, re_skip);
+  }
+  srsran::resource_grid_writer& get_writer() { return writer; }
+
+private:
+  srsran::resource_grid_mapper& inner;
+  srsran::resource_grid_writer& writer;
+};
+
+/// A resource grid of the reference behind a mapper that gives its writer.
+class resource_grid_adaptor : public srsran::resource_grid
+{
+public:
+  explicit resource_grid_adaptor(std::unique_ptr<srsran::resource_grid> inner_) :
+    inner(std::move(inner_)), mapper(inner->get_mapper(), inner->get_writer())
+  {
+  }
+  void                                set_all_zero() override { inner->set_all_zero(); }
+  srsran::resource_grid_writer&       get_writer() override { return inner->get_writer(); }
+  const srsran::resource_grid_reader& get_reader() const override { return inner->get_reader(); }
+  srsran::resource_grid_mapper&       get_mapper() override { return mapper; }
+
+private:
+  std::unique_ptr<srsran::resource_grid> inner;
+  resource_grid_mapper_with_writer       mapper;
+};
+
+class resource_grid_factory_adaptor : public srsran::resource_grid_factory
+{
+public:
+  explicit resource_grid_factory_adaptor(std::shared_ptr<srsran::resource_grid_factory> inner_) : inner(std::move(inner_)) {}
+  std::unique_ptr<srsran::resource_grid> create(unsigned nof_ports, unsigned nof_symbols, unsigned nof_subc) override
+  {
+    return std::make_unique<resource_grid_adaptor>(inner->create(nof_ports, nof_symbols, nof_subc));
+  }
+
+private:
+  std::shared_ptr<srsran::resource_grid_factory> inner;
+};
+
+/// The RE of one transmission: per OFDM symbol the subcarriers it owns.
+using re_symbol_masks = std::array<srsran::bounded_bitset<srsran::MAX_RB * srsran::NRE>, NRPHY_NSYMB>;
+
+/// Puts the RE `masks` select from a staging grid [port][14][nof_subc] into the grid behind `mapper`, ports 0..nof_ports-1.
+inline void put_staging_grid(srsran::resource_grid_mapper& mapper,
+                             const srsran::cbf16_t*        staging,
+                             unsigned                      nof_ports,
+                             unsigned                      nof_subc,
+                             const re_symbol_masks&        masks)
+{
+  using namespace srsran;
+  auto*                with_writer = dynamic_cast<resource_grid_mapper_with_writer*>(&mapper);
+  std::vector<cbf16_t> packed(nof_subc);
+  for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+    const bounded_bitset<MAX_RB * NRE>& mask = masks[l];
+    if (mask.size() == 0 || mask.none()) {
+      continue;
+    }
+    if (with_writer != nullptr) {
+      for (unsigned port = 0; port != nof_ports; ++port) {
+        const cbf16_t* row = &staging[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc];
+        unsigned       n   = 0;
+        mask.for_each(0, mask.size(), [&](unsigned k) { packed[n++] = row[k]; });
+        with_writer->get_writer().put(port, l, 0, mask, span<const cbf16_t>(packed).first(n));
+      }
+      continue;
+    }
+    // Through the mapper: PRBs that share a RE mask make one re_pattern; identity precoding keeps every port's values.
+    // ones on the diagonal (the codebook's make_identity is normalised by 1 / sqrt(ports))
+    precoding_configuration identity(nof_ports, nof_ports, 1, MAX_RB);
+    for (unsigned layer = 0; layer != nof_ports; ++layer) {
+      for (unsigned port = 0; port != nof_ports; ++port) {
+        identity.set_coefficient(layer == port ? cf_t(1.0F, 0.0F) : cf_t(0.0F, 0.0F), layer, port, 0);
+      }
+    }
+    std::array<bool, MAX_RB>      done     = {};
+    const unsigned                nof_prb  = mask.size() / NRE;
+    for (unsigned first = 0; first != nof_prb; ++first) {
+      uint32_t bits = 0;
+      for (unsigned k = 0; k != NRE; ++k) {
+        bits |= mask.test(NRE * first + k) ? (1U << k) : 0U;
+      }
+      if (done[first] || bits == 0) {
+        continue;
+      }
+      re_pattern pattern;
+      pattern.prb_mask.resize(nof_prb);
+      pattern.symbols.set(l);
+      for (unsigned k = 0; k != NRE; ++k) {
+        pattern.re_mask.set(k, (bits >> k) & 1U);
+      }
+      unsigned nof_re = 0;
+      for (unsigned prb = first; prb != nof_prb; ++prb) {
+        uint32_t other = 0;
+        for (unsigned k = 0; k != NRE; ++k) {
+          other |= mask.test(NRE * prb + k) ? (1U << k) : 0U;
+        }
+        if (!done[prb] && other == bits) {
+          done[prb] = true;
+          pattern.prb_mask.set(prb);
+          nof_re += __builtin_popcount(bits);
+        }
+      }
+      dynamic_re_buffer<cf_t> values(nof_ports, nof_re);
+      for (unsigned port = 0; port != nof_ports; ++port) {
+        const cbf16_t* row = &staging[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc];
+        span<cf_t>     dst = values.get_slice(port);
+        unsigned       n   = 0;
+        for (unsigned prb = 0; prb != nof_prb; ++prb) {
+          if (pattern.prb_mask.test(prb)) {
+            for (unsigned k = 0; k != NRE; ++k) {
+              if ((bits >> k) & 1U) {
+                dst[n++] = to_cf(row[NRE * prb + k]);
+              }
+            }
+          }
+        }
+      }
+      mapper.map(values, pattern, identity);
+    }
+  }
+}
+
+/// The RE a PDSCH transmission owns: data RE built like pdsch_modulator_impl::map does (pdsch_modulator_impl.cpp:52-106)
+/// plus the DM-RS RE of the CDM groups of its layers.
+inline void pdsch_re_masks(re_symbol_masks& masks, const srsran::pdsch_processor::pdu_t& pdu, unsigned nof_subc)
+{
+  using namespace srsran;
+  const bounded_bitset<MAX_RB> prb_mask = pdu.freq_alloc.get_prb_mask(pdu.bwp_start_rb, pdu.bwp_size_rb);
+  re_pattern_list              reserved(pdu.reserved);
+  reserved.merge(pdu.dmrs.get_dmrs_pattern(pdu.bwp_start_rb, pdu.bwp_size_rb, pdu.nof_cdm_groups_without_data, pdu.dmrs_symbol_mask));
+  re_pattern alloc;
+  alloc.prb_mask = prb_mask;
+  alloc.re_mask  = ~re_prb_mask();
+  alloc.symbols.fill(pdu.start_symbol_index, pdu.start_symbol_index + pdu.nof_symbols);
+  const unsigned nof_groups = (pdu.precoding.get_nof_layers() + 1) / 2;
+  for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+    masks[l].resize(nof_subc);
+    masks[l].reset();
+    if (l >= get_nsymb_per_slot(pdu.cp)) {
+      continue;
+    }
+    alloc.get_inclusion_mask(masks[l], l);
+    reserved.get_exclusion_mask(masks[l], l);
+    if (pdu.dmrs_symbol_mask.test(l)) {
+      for (unsigned prb = 0; prb != prb_mask.size(); ++prb) {
+        if (prb_mask.test(prb)) {
+          for (unsigned k = 0; k != NRE; ++k) {
+            if ((k % 2) < nof_groups) {
+              masks[l].set(NRE * prb + k);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+/// pdsch_processor over the asynchronous queue of the C ABI (nrphy_pdsch_async_*): process() copies the transport block,
+/// enqueues the PDU on one of `depth` streams and returns; when the PDU's grid has reached the host, a thread of the HIP
+/// runtime merges its RE into the caller's grid and calls the notifier -- exactly once per process(), also on failure
+/// (pdsch_processor.h:157-170; the contract of pdsch_processor_asynchronous_pool.h:124-130).  The grid behind `mapper`
+/// must stay valid until then, as for the reference's concurrent processor.
 class pdsch_processor_adaptor : public srsran::pdsch_processor
 {
 public:
-  pdsch_processor_adaptor(std::shared_ptr<context> ctx_, writer_resolver resolver_, unsigned nof_ports_, unsigned nof_subc_) :
-    ctx(std::move(ctx_)), resolver(std::move(resolver_)), nof_ports(nof_ports_), nof_subc(nof_subc_),
-    staging(static_cast<size_t>(nof_ports_) * NRPHY_NSYMB * nof_subc_)
+  pdsch_processor_adaptor(std::shared_ptr<context> ctx_, unsigned nof_ports_, unsigned nof_subc_, unsigned depth = 4) :
+    ctx(std::move(ctx_)), nof_ports(nof_ports_), nof_subc(nof_subc_), ops(depth)
   {
+    int rc = nrphy_pdsch_async_create(ctx->get(), depth, nof_ports, nof_subc, 1277992 / 8 + 8, &queue);
+    report_failure("nrphy_pdsch_async_create", rc);
+    srsran_assert(rc == NRPHY_OK, "nrphy_pdsch_async_create failed.");
   }
+  ~pdsch_processor_adaptor() override { nrphy_pdsch_async_destroy(queue); } // waits for what is in flight
 
   void process(srsran::resource_grid_mapper&                                                mapper,
                srsran::pdsch_processor_notifier&                                            notifier,
@@ -171,68 +378,78 @@ public:
     nrphy_pdsch_pdu_t  pod = to_pod(pdu, data[0].size(), weights);
     // The reference asserts on invalid PDUs (pdsch_processor_validator_impl::assert_pdu).
     srsran_assert(nrphy_pdsch_validate(&pod) == NRPHY_OK, "Invalid PDSCH PDU.");
-    std::fill(staging.begin(), staging.end(), cbf16_t());
-    int rc = nrphy_pdsch_process_host(ctx->get(), &pod, data[0].data(), staging.data(), nof_ports, nof_subc, nullptr, nullptr);
-    srsran_assert(rc == NRPHY_OK, "nrphy_pdsch_process_host failed: {}", nrphy_strerror(rc));
-
-    // Masks of the RE this transmission owns, built like pdsch_modulator_impl::map does (pdsch_modulator_impl.cpp:52-106).
-    resource_grid_writer&        writer   = resolver(mapper);
-    const bounded_bitset<MAX_RB> prb_mask = pdu.freq_alloc.get_prb_mask(pdu.bwp_start_rb, pdu.bwp_size_rb);
-    re_pattern_list              reserved(pdu.reserved);
-    reserved.merge(pdu.dmrs.get_dmrs_pattern(pdu.bwp_start_rb, pdu.bwp_size_rb, pdu.nof_cdm_groups_without_data, pdu.dmrs_symbol_mask));
-    re_pattern alloc;
-    alloc.prb_mask = prb_mask;
-    alloc.re_mask  = ~re_prb_mask();
-    alloc.symbols.fill(pdu.start_symbol_index, pdu.start_symbol_index + pdu.nof_symbols);
-    std::vector<cbf16_t> packed(nof_subc);
-    for (unsigned l = 0, nsymb = get_nsymb_per_slot(pdu.cp); l != nsymb; ++l) {
-      bounded_bitset<MAX_RB * NRE> mask(nof_subc);
-      alloc.get_inclusion_mask(mask, l);
-      reserved.get_exclusion_mask(mask, l);
-      // DM-RS RE of this transmission: CDM groups of its layers on the allocated PRBs.
-      if (pdu.dmrs_symbol_mask.test(l)) {
-        unsigned nof_groups = (pod.nof_layers + 1) / 2;
-        for (unsigned prb = 0; prb != prb_mask.size(); ++prb) {
-          if (prb_mask.test(prb)) {
-            for (unsigned k = 0; k != NRE; ++k) {
-              if ((k % 2) < nof_groups) {
-                mask.set(NRE * prb + k);
-              }
-            }
-          }
+    for (;;) {
+      operation* op = nullptr;
+      for (operation& o : ops) {
+        bool expected = false;
+        if (o.busy.compare_exchange_strong(expected, true)) {
+          op = &o;
+          break;
         }
       }
-      if (mask.none()) {
-        continue;
+      if (op != nullptr) {
+        op->self      = this;
+        op->mapper    = &mapper;
+        op->notifier  = &notifier;
+        op->nof_ports = pod.nof_ports;
+        pdsch_re_masks(op->masks, pdu, nof_subc);
+        int rc = nrphy_pdsch_async_submit(queue, &pod, data[0].data(), &pdsch_processor_adaptor::on_done, op);
+        if (rc == NRPHY_OK) {
+          return;
+        }
+        op->busy.store(false);
+        if (rc != NRPHY_ERR_CAPACITY) {
+          // Like the reference's pool when it runs out of processors: log, and still notify exactly once.
+          report_failure("nrphy_pdsch_async_submit", rc);
+          notifier.on_finish_processing();
+          return;
+        }
       }
-      for (unsigned port = 0; port != pod.nof_ports; ++port) {
-        const cbf16_t* row = &staging[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc];
-        unsigned       n   = 0;
-        mask.for_each(0, mask.size(), [&](unsigned k) { packed[n++] = row[k]; });
-        writer.put(port, l, 0, mask, span<const cbf16_t>(packed).first(n));
-      }
+      nrphy_pdsch_async_wait(queue); // every slot in flight: wait for them, then retry
     }
-    notifier.on_finish_processing();
   }
 
 private:
-  std::shared_ptr<context>     ctx;
-  writer_resolver              resolver;
-  unsigned                     nof_ports;
-  unsigned                     nof_subc;
-  std::vector<srsran::cbf16_t> staging;
+  struct operation {
+    std::atomic<bool>                 busy{false};
+    pdsch_processor_adaptor*          self     = nullptr;
+    srsran::resource_grid_mapper*     mapper   = nullptr;
+    srsran::pdsch_processor_notifier* notifier = nullptr;
+    unsigned                          nof_ports = 0;
+    re_symbol_masks                   masks;
+  };
+
+  // Runs on a thread of the HIP runtime (no HIP or nrphy calls here).
+  static void on_done(void* user, int status, const void* grid)
+  {
+    operation* op = static_cast<operation*>(user);
+    if (status == NRPHY_OK) {
+      put_staging_grid(*op->mapper, static_cast<const srsran::cbf16_t*>(grid), op->nof_ports, op->self->nof_subc, op->masks);
+    } else {
+      report_failure("PDSCH processing", status);
+    }
+    srsran::pdsch_processor_notifier* notifier = op->notifier;
+    op->busy.store(false);
+    notifier->on_finish_processing();
+  }
+
+  std::shared_ptr<context> ctx;
+  unsigned                 nof_ports;
+  unsigned                 nof_subc;
+  nrphy_pdsch_async_t*     queue = nullptr;
+  std::vector<operation>   ops;
 };
 
 class pdsch_processor_factory_adaptor : public srsran::pdsch_processor_factory
 {
 public:
-  pdsch_processor_factory_adaptor(std::shared_ptr<context> ctx_, writer_resolver resolver_, unsigned nof_ports_, unsigned nof_subc_) :
-    ctx(std::move(ctx_)), resolver(std::move(resolver_)), nof_ports(nof_ports_), nof_subc(nof_subc_)
+  pdsch_processor_factory_adaptor(std::shared_ptr<context> ctx_, unsigned nof_ports_, unsigned nof_subc_, unsigned depth_ = 4) :
+    ctx(std::move(ctx_)), nof_ports(nof_ports_), nof_subc(nof_subc_), depth(depth_)
   {
   }
   std::unique_ptr<srsran::pdsch_processor> create() override
   {
-    return std::make_unique<pdsch_processor_adaptor>(ctx, resolver, nof_ports, nof_subc);
+    return std::make_unique<pdsch_processor_adaptor>(ctx, nof_ports, nof_subc, depth);
   }
   std::unique_ptr<srsran::pdsch_pdu_validator> create_validator() override
   {
@@ -241,9 +458,9 @@ public:
 
 private:
   std::shared_ptr<context> ctx;
-  writer_resolver          resolver;
   unsigned                 nof_ports;
   unsigned                 nof_subc;
+  unsigned                 depth;
 };
 
 /// hal::hw_accelerator_pdsch_enc over nrphy_pdsch_encode_host, transport-block mode (get_cb_mode() == false): what
@@ -310,7 +527,7 @@ public:
     }
     srsran_assert(data.size() == cw_bits, "Invalid codeword size.");
     int rc = nrphy_pdsch_encode_host(ctx->get(), &enc, tb.data(), data.data(), aux_data.empty() ? nullptr : aux_data.data());
-    srsran_assert(rc == NRPHY_OK, "nrphy_pdsch_encode_host failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_pdsch_encode_host", rc);
     return true;
   }
 
@@ -349,7 +566,7 @@ public:
     cfg.scale          = config.scale;
     cfg.center_freq_hz = config.center_freq_hz;
     int rc             = nrphy_ofdm_plan_create(ctx->get(), &cfg, nof_ports, &plan);
-    srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_plan_create failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_ofdm_plan_create", rc);
     staging.resize(static_cast<size_t>(nof_ports) * NRPHY_NSYMB * cfg.bw_rb * srsran::NRE);
   }
   ~ofdm_symbol_modulator_adaptor() override { nrphy_ofdm_plan_destroy(plan); }
@@ -377,7 +594,10 @@ public:
       slot_size = nrphy_ofdm_slot_size(&cfg, slot);
       iq.resize(static_cast<size_t>(nof_ports) * slot_size);
       int rc = nrphy_ofdm_modulate_slot_host(plan, staging.data(), slot, reinterpret_cast<float*>(iq.data()));
-      srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_modulate_slot_host failed: {}", nrphy_strerror(rc));
+      report_failure("nrphy_ofdm_modulate_slot_host", rc);
+      if (rc != NRPHY_OK) {
+        std::fill(iq.begin(), iq.end(), cf_t()); // silence rather than stale samples
+      }
       cached_grid = &grid;
       cached_slot = slot;
     }
@@ -462,7 +682,7 @@ protected:
     cfg.scale          = config.scale;
     cfg.center_freq_hz = config.center_freq_hz;
     int rc             = nrphy_ofdm_plan_create(ctx->get(), &cfg, 1, &plan);
-    srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_plan_create failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_ofdm_plan_create", rc);
     staging.resize(static_cast<size_t>(NRPHY_NSYMB) * cfg.bw_rb * srsran::NRE);
   }
   ~ofdm_demodulator_adaptor_base() { nrphy_ofdm_plan_destroy(plan); }
@@ -488,7 +708,7 @@ public:
     unsigned nof_subc = cfg.bw_rb * NRE;
     int      rc       = nrphy_ofdm_demodulate_symbol_host(plan, reinterpret_cast<const float*>(input.data()), input.size(),
                                                symbol_index, window_offset, staging.data());
-    srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_demodulate_symbol_host failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_ofdm_demodulate_symbol_host", rc);
     grid.put(port_index, symbol_index % (cfg.cp ? 12 : 14), 0, 1, span<const cbf16_t>(staging.data(), nof_subc));
   }
 };
@@ -507,7 +727,7 @@ public:
     srsran_assert(input.size() == get_slot_size(slot_index), "Invalid input size.");
     unsigned nof_subc = cfg.bw_rb * NRE;
     int rc = nrphy_ofdm_demodulate_slot_host(plan, reinterpret_cast<const float*>(input.data()), slot_index, window_offset, staging.data());
-    srsran_assert(rc == NRPHY_OK, "nrphy_ofdm_demodulate_slot_host failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_ofdm_demodulate_slot_host", rc);
     for (unsigned l = 0, nsymb = cfg.cp ? 12 : 14; l != nsymb; ++l) {
       grid.put(port_index, l, 0, 1, span<const cbf16_t>(&staging[static_cast<size_t>(l) * nof_subc], nof_subc));
     }
@@ -546,7 +766,7 @@ public:
   {
     int rc = nrphy_dft_run_host(ctx->get(), input.size(), dir == direction::INVERSE, reinterpret_cast<const float*>(input.data()),
                                 reinterpret_cast<float*>(output.data()));
-    srsran_assert(rc == NRPHY_OK, "nrphy_dft_run_host failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_dft_run_host", rc);
     return output;
   }
 
@@ -563,7 +783,7 @@ public:
   explicit dft_processor_factory_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
   std::unique_ptr<srsran::dft_processor> create(const srsran::dft_processor::configuration& config) override
   {
-    switch (config.size) {
+    switch (config.size) { // the sizes of dft_processor_generic_impl.cpp:190-208
       case 128:
       case 256:
       case 384:
@@ -574,6 +794,14 @@ public:
       case 2048:
       case 3072:
       case 4096:
+      case 4608:
+      case 6144:
+      case 9216:
+      case 12288:
+      case 18432:
+      case 24576:
+      case 36864:
+      case 49152:
         return std::make_unique<dft_processor_adaptor>(ctx, config);
       default:
         return nullptr;
@@ -611,7 +839,7 @@ public:
     static_assert(sizeof(log_likelihood_ratio) == sizeof(int8_t), "LLRs are plain int8");
     int rc = nrphy_ldpc_rate_dematch_host(ctx->get(), &c, reinterpret_cast<const int8_t*>(input.data()),
                                           reinterpret_cast<int8_t*>(output.data()), new_data ? 1 : 0);
-    srsran_assert(rc == NRPHY_OK, "nrphy_ldpc_rate_dematch_host failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_ldpc_rate_dematch_host", rc);
   }
 
 private:
@@ -668,7 +896,10 @@ public:
     packed.resize((k + 7) / 8);
     uint32_t iterations = 0;
     int rc = nrphy_ldpc_decode_host(ctx->get(), &c, reinterpret_cast<const int8_t*>(input.data()), packed.data(), &iterations);
-    srsran_assert(rc == NRPHY_OK, "nrphy_ldpc_decode_host failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_ldpc_decode_host", rc);
+    if (rc != NRPHY_OK) {
+      return std::nullopt; // reported like a codeblock that did not converge
+    }
     // output holds the message without (or with) its filler bits: the first output.size() hard bits
     const unsigned nbits = std::min<unsigned>(output.size(), k);
     for (unsigned i = 0; i < nbits; i += 8) {
@@ -744,10 +975,14 @@ public:
     uint32_t iterations = 0;
     int      rc = nrphy_pusch_decode_codeblock_host(ctx->get(), &dm, crc_poly, cfg.max_nof_ldpc_iterations, 0.8F, data.data(),
                                                op.soft.data(), cfg.new_data ? 1 : 0, op.message.data(), &iterations);
-    srsran_assert(rc == NRPHY_OK, "nrphy_pusch_decode_codeblock_host failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_pusch_decode_codeblock_host", rc);
+    if (rc != NRPHY_OK) {
+      iterations = 0; // reported like a codeblock whose CRC failed
+      std::fill(op.message.begin(), op.message.end(), 0xFF);
+    }
     op.out.nof_ldpc_iterations = (iterations != 0) ? iterations : cfg.max_nof_ldpc_iterations;
     // Without early stop the decoder did not look at the CRC: divide the payload + CRC by the generator here.
-    op.out.CRC_pass = (iterations != 0) || (!cfg.use_early_stop && crc_is_zero(op.message, cfg));
+    op.out.CRC_pass = (iterations != 0) || (rc == NRPHY_OK && !cfg.use_early_stop && crc_is_zero(op.message, cfg));
     op.pending      = true;
     return true;
   }
@@ -830,8 +1065,8 @@ private:
 class nzp_csi_rs_generator_adaptor : public srsran::nzp_csi_rs_generator
 {
 public:
-  nzp_csi_rs_generator_adaptor(std::shared_ptr<context> ctx_, writer_resolver resolver_, unsigned nof_ports_, unsigned nof_subc_) :
-    ctx(std::move(ctx_)), resolver(std::move(resolver_)), nof_ports(nof_ports_), nof_subc(nof_subc_),
+  nzp_csi_rs_generator_adaptor(std::shared_ptr<context> ctx_, unsigned nof_ports_, unsigned nof_subc_) :
+    ctx(std::move(ctx_)), nof_ports(nof_ports_), nof_subc(nof_subc_),
     staging(static_cast<size_t>(nof_ports_) * NRPHY_NSYMB * nof_subc_)
   {
   }
@@ -870,7 +1105,7 @@ public:
     srsran_assert(nrphy_csi_rs_validate(&c) == NRPHY_OK, "CSI-RS configuration outside rows 1-5 / wideband precoding.");
     std::fill(staging.begin(), staging.end(), cbf16_t());
     int rc = nrphy_csi_rs_map_host(ctx->get(), &c, staging.data(), nof_ports, nof_subc);
-    srsran_assert(rc == NRPHY_OK, "nrphy_csi_rs_map_host failed: {}", nrphy_strerror(rc));
+    report_failure("nrphy_csi_rs_map_host", rc);
 
     // The RE of the signal: the union of the per-port patterns, every one of them written on all precoding ports.
     csi_rs_pattern_configuration pc;
@@ -882,11 +1117,14 @@ public:
     pc.symbol_l1                = config.symbol_l1;
     pc.cdm                      = config.cdm;
     pc.freq_density             = config.freq_density;
-    csi_rs_pattern        pattern = get_csi_rs_pattern(pc);
-    resource_grid_writer& writer  = resolver(mapper);
-    std::vector<cbf16_t>  packed(nof_subc);
-    for (unsigned l = 0, nsymb = get_nsymb_per_slot(config.cp); l != nsymb; ++l) {
-      bounded_bitset<MAX_RB * NRE> mask(nof_subc);
+    csi_rs_pattern  pattern = get_csi_rs_pattern(pc);
+    re_symbol_masks masks;
+    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+      masks[l].resize(nof_subc);
+      masks[l].reset();
+      if (l >= get_nsymb_per_slot(config.cp)) {
+        continue;
+      }
       for (const csi_rs_pattern_port& port_pattern : pattern.prb_patterns) {
         if (!port_pattern.symbol_mask.test(l)) {
           continue;
@@ -894,29 +1132,277 @@ public:
         for (unsigned prb = pattern.rb_begin; prb < pattern.rb_end; prb += pattern.rb_stride) {
           for (unsigned k = 0; k != NRE; ++k) {
             if (port_pattern.re_mask.test(k)) {
-              mask.set(NRE * prb + k);
+              masks[l].set(NRE * prb + k);
             }
           }
         }
       }
-      if (mask.none()) {
-        continue;
+    }
+    put_staging_grid(mapper, staging.data(), c.nof_ports, nof_subc, masks);
+  }
+
+private:
+  std::shared_ptr<context>     ctx;
+  unsigned                     nof_ports;
+  unsigned                     nof_subc;
+  std::vector<srsran::cbf16_t> staging;
+};
+
+// ---- other downlink grid writers: PDCCH and SS/PBCH block processors --------------------------------------------------
+/// pdcch_processor::pdu_t -> POD.  \c weights receives the precoding coefficients the POD points to.
+inline nrphy_pdcch_pdu_t to_pod(const srsran::pdcch_processor::pdu_t& pdu, std::vector<float>& weights)
+{
+  using namespace srsran;
+  nrphy_pdcch_pdu_t p;
+  std::memset(&p, 0, sizeof(p));
+  p.slot_index         = pdu.slot.slot_index();
+  p.cp                 = (pdu.cp == cyclic_prefix::NORMAL) ? 0 : 1;
+  p.bwp_size_rb        = pdu.coreset.bwp_size_rb;
+  p.bwp_start_rb       = pdu.coreset.bwp_start_rb;
+  p.start_symbol_index = pdu.coreset.start_symbol_index;
+  p.duration           = pdu.coreset.duration;
+  for (unsigned i = 0; i != pdu.coreset.frequency_resources.size(); ++i) {
+    p.frequency_resources |= pdu.coreset.frequency_resources.test(i) ? (uint64_t(1) << i) : 0;
+  }
+  p.cce_to_reg_mapping   = static_cast<uint32_t>(pdu.coreset.cce_to_reg_mapping);
+  p.reg_bundle_size      = pdu.coreset.reg_bundle_size;
+  p.interleaver_size     = pdu.coreset.interleaver_size;
+  p.shift_index          = pdu.coreset.shift_index;
+  p.rnti                 = pdu.dci.rnti;
+  p.n_id_pdcch_dmrs      = pdu.dci.n_id_pdcch_dmrs;
+  p.n_id_pdcch_data      = pdu.dci.n_id_pdcch_data;
+  p.n_rnti               = pdu.dci.n_rnti;
+  p.cce_index            = pdu.dci.cce_index;
+  p.aggregation_level    = pdu.dci.aggregation_level;
+  p.dmrs_power_offset_dB = pdu.dci.dmrs_power_offset_dB;
+  p.data_power_offset_dB = pdu.dci.data_power_offset_dB;
+  p.payload_size         = pdu.dci.payload.size();
+  for (unsigned i = 0; i != p.payload_size && i != NRPHY_PDCCH_MAX_PAYLOAD; ++i) {
+    p.payload[i] = pdu.dci.payload[i];
+  }
+  p.nof_ports   = pdu.dci.precoding.get_nof_ports();
+  p.prg_size_rb = pdu.dci.precoding.get_prg_size();
+  p.nof_prg     = pdu.dci.precoding.get_nof_prg();
+  weights.resize(2 * p.nof_prg * p.nof_ports);
+  for (unsigned g = 0; g != p.nof_prg; ++g) {
+    for (unsigned port = 0; port != p.nof_ports; ++port) {
+      cf_t w                                    = pdu.dci.precoding.get_coefficient(0, port, g);
+      weights[2 * (g * p.nof_ports + port)]     = w.real();
+      weights[2 * (g * p.nof_ports + port) + 1] = w.imag();
+    }
+  }
+  p.precoding = weights.data();
+  return p;
+}
+
+/// pdcch_processor over nrphy_pdcch_process_host (host-span form; a device-resident L1 calls nrphy_pdcch_process on
+/// its device grids).  The candidate's RE are found in the staging grid by the words the kernel wrote.
+class pdcch_processor_adaptor : public srsran::pdcch_processor
+{
+public:
+  pdcch_processor_adaptor(std::shared_ptr<context> ctx_, unsigned nof_ports_, unsigned nof_subc_) :
+    ctx(std::move(ctx_)), nof_ports(nof_ports_), nof_subc(nof_subc_), staging(static_cast<size_t>(nof_ports_) * NRPHY_NSYMB * nof_subc_)
+  {
+  }
+  void process(srsran::resource_grid_mapper& mapper, const pdu_t& pdu) override
+  {
+    using namespace srsran;
+    std::vector<float> weights;
+    nrphy_pdcch_pdu_t  pod = to_pod(pdu, weights);
+    srsran_assert(nrphy_pdcch_validate(&pod) == NRPHY_OK, "Invalid PDCCH PDU.");
+    // A marker no precoder output equals (a NaN pattern) tells the candidate's RE from the rest of the staging grid.
+    cbf16_t marker;
+    const uint32_t marker_bits = 0x7FC17FC1U;
+    std::memcpy(&marker, &marker_bits, sizeof(marker));
+    std::fill(staging.begin(), staging.end(), marker);
+    int rc = nrphy_pdcch_process_host(ctx->get(), &pod, staging.data(), nof_ports, nof_subc);
+    report_failure("nrphy_pdcch_process_host", rc);
+    if (rc != NRPHY_OK) {
+      return;
+    }
+    re_symbol_masks masks;
+    for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+      masks[l].resize(nof_subc);
+      masks[l].reset();
+      const cbf16_t* row = &staging[static_cast<size_t>(l) * nof_subc]; // port 0 carries every RE of the candidate
+      for (unsigned k = 0; k != nof_subc; ++k) {
+        if (std::memcmp(&row[k], &marker, sizeof(marker)) != 0) {
+          masks[l].set(k);
+        }
       }
-      for (unsigned port = 0; port != c.nof_ports; ++port) {
-        const cbf16_t* row = &staging[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc];
-        unsigned       n   = 0;
-        mask.for_each(0, mask.size(), [&](unsigned k) { packed[n++] = row[k]; });
-        writer.put(port, l, 0, mask, span<const cbf16_t>(packed).first(n));
+    }
+    put_staging_grid(mapper, staging.data(), pod.nof_ports, nof_subc, masks);
+  }
+
+private:
+  std::shared_ptr<context>     ctx;
+  unsigned                     nof_ports;
+  unsigned                     nof_subc;
+  std::vector<srsran::cbf16_t> staging;
+};
+
+class pdcch_pdu_validator_adaptor : public srsran::pdcch_pdu_validator
+{
+public:
+  bool is_valid(const srsran::pdcch_processor::pdu_t& pdu) const override
+  {
+    std::vector<float> weights;
+    nrphy_pdcch_pdu_t  pod = to_pod(pdu, weights);
+    return nrphy_pdcch_validate(&pod) == NRPHY_OK;
+  }
+};
+
+class pdcch_processor_factory_adaptor : public srsran::pdcch_processor_factory
+{
+public:
+  pdcch_processor_factory_adaptor(std::shared_ptr<context> ctx_, unsigned nof_ports_, unsigned nof_subc_) :
+    ctx(std::move(ctx_)), nof_ports(nof_ports_), nof_subc(nof_subc_)
+  {
+  }
+  std::unique_ptr<srsran::pdcch_processor>     create() override { return std::make_unique<pdcch_processor_adaptor>(ctx, nof_ports, nof_subc); }
+  std::unique_ptr<srsran::pdcch_pdu_validator> create_validator() override { return std::make_unique<pdcch_pdu_validator_adaptor>(); }
+
+private:
+  std::shared_ptr<context> ctx;
+  unsigned                 nof_ports;
+  unsigned                 nof_subc;
+};
+
+inline nrphy_ssb_pdu_t to_pod(const srsran::ssb_processor::pdu_t& pdu)
+{
+  using namespace srsran;
+  nrphy_ssb_pdu_t p;
+  std::memset(&p, 0, sizeof(p));
+  p.numerology        = pdu.slot.numerology();
+  p.sfn               = pdu.slot.sfn();
+  p.slot_index        = pdu.slot.slot_index();
+  p.phys_cell_id      = pdu.phys_cell_id;
+  p.beta_pss_dB       = pdu.beta_pss;
+  p.ssb_idx           = pdu.ssb_idx;
+  p.L_max             = pdu.L_max;
+  p.common_scs        = to_numerology_value(pdu.common_scs);
+  p.subcarrier_offset = pdu.subcarrier_offset.to_uint();
+  p.offset_to_pointA  = pdu.offset_to_pointA.to_uint();
+  p.pattern_case      = static_cast<uint32_t>(pdu.pattern_case);
+  for (unsigned i = 0; i != 32; ++i) {
+    p.bch_payload[i] = pdu.bch_payload[i];
+  }
+  p.nof_ports = pdu.ports.size();
+  for (unsigned i = 0; i != p.nof_ports && i != NRPHY_MAX_PORTS; ++i) {
+    p.ports[i] = pdu.ports[i];
+  }
+  return p;
+}
+
+/// ssb_processor over nrphy_ssb_process_host: the block's 4 symbols x 240 subcarriers are computed into a staging grid
+/// and written through the grid's writer (PBCH, its DM-RS, PSS, SSS -- the zeros around PSS / SSS are not written, as
+/// in the reference).
+class ssb_processor_adaptor : public srsran::ssb_processor
+{
+public:
+  ssb_processor_adaptor(std::shared_ptr<context> ctx_, unsigned nof_ports_, unsigned nof_subc_) :
+    ctx(std::move(ctx_)), nof_ports(nof_ports_), nof_subc(nof_subc_), staging(static_cast<size_t>(nof_ports_) * NRPHY_NSYMB * nof_subc_)
+  {
+  }
+  void process(srsran::resource_grid_writer& grid, const pdu_t& pdu) override
+  {
+    using namespace srsran;
+    nrphy_ssb_pdu_t pod = to_pod(pdu);
+    srsran_assert(nrphy_ssb_validate(&pod) == NRPHY_OK, "Invalid SS/PBCH block PDU.");
+    cbf16_t        marker;
+    const uint32_t marker_bits = 0x7FC17FC1U;
+    std::memcpy(&marker, &marker_bits, sizeof(marker));
+    std::fill(staging.begin(), staging.end(), marker);
+    int rc = nrphy_ssb_process_host(ctx->get(), &pod, staging.data(), nof_ports, nof_subc);
+    report_failure("nrphy_ssb_process_host", rc);
+    if (rc != NRPHY_OK) {
+      return;
+    }
+    std::vector<cbf16_t> packed(nof_subc);
+    for (unsigned port : pdu.ports) {
+      for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+        const cbf16_t*               row = &staging[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc];
+        bounded_bitset<MAX_RB * NRE> mask(nof_subc);
+        unsigned                     n = 0;
+        for (unsigned k = 0; k != nof_subc; ++k) {
+          if (std::memcmp(&row[k], &marker, sizeof(marker)) != 0) {
+            mask.set(k);
+            packed[n++] = row[k];
+          }
+        }
+        if (n != 0) {
+          grid.put(port, l, 0, mask, span<const cbf16_t>(packed).first(n));
+        }
       }
     }
   }
 
 private:
   std::shared_ptr<context>     ctx;
-  writer_resolver              resolver;
   unsigned                     nof_ports;
   unsigned                     nof_subc;
   std::vector<srsran::cbf16_t> staging;
+};
+
+// ---- lower-PHY tail: amplitude controller, Open Fronthaul compressor ---------------------------------------------------
+/// amplitude_controller over nrphy_amplitude_control_host (one buffer per call, as the lower PHY calls it per port).
+class amplitude_controller_adaptor : public srsran::amplitude_controller
+{
+public:
+  amplitude_controller_adaptor(std::shared_ptr<context> ctx_, const nrphy_amplitude_cfg_t& cfg_) : ctx(std::move(ctx_)), cfg(cfg_)
+  {
+    std::memset(&metrics, 0, sizeof(metrics));
+  }
+  srsran::amplitude_controller_metrics process(srsran::span<srsran::cf_t> output, srsran::span<const srsran::cf_t> input) override
+  {
+    srsran_srsvec_assert_size(output, input);
+    int rc = nrphy_amplitude_control_host(ctx->get(), &cfg, reinterpret_cast<const float*>(input.data()), input.size(),
+                                          reinterpret_cast<float*>(output.data()), &metrics);
+    report_failure("nrphy_amplitude_control_host", rc);
+    if (rc != NRPHY_OK) {
+      std::fill(output.begin(), output.end(), srsran::cf_t()); // silence rather than an unbounded signal
+    }
+    return {metrics.avg_power_fs, metrics.peak_power_fs, metrics.papr_lin, metrics.gain_dB, metrics.nof_processed_samples,
+            metrics.nof_clipped_samples, static_cast<long double>(metrics.clipping_probability), metrics.clipping_enabled != 0};
+  }
+
+private:
+  std::shared_ptr<context>  ctx;
+  nrphy_amplitude_cfg_t     cfg;
+  nrphy_amplitude_metrics_t metrics;
+};
+
+/// ofh::iq_compressor over nrphy_ofh_compress_host: the serialised records come back and are unpacked into the
+/// reference's compressed_prb objects (the device-resident form, nrphy_ofh_compress, writes the user-plane payload
+/// itself).
+class iq_compressor_adaptor : public srsran::ofh::iq_compressor
+{
+public:
+  iq_compressor_adaptor(std::shared_ptr<context> ctx_, float iq_scaling_) : ctx(std::move(ctx_)), iq_scaling(iq_scaling_) {}
+  void compress(srsran::span<srsran::ofh::compressed_prb> compressed_prbs,
+                srsran::span<const srsran::cbf16_t>       iq_data,
+                const srsran::ofh::ru_compression_params& params) override
+  {
+    using namespace srsran;
+    nrphy_ofh_compression_cfg_t cfg = {params.type == ofh::compression_type::BFP ? 1U : 0U, params.data_width, iq_scaling};
+    const unsigned              rec = nrphy_ofh_compressed_prb_bytes(&cfg), nof_prb = compressed_prbs.size();
+    packed.assign(static_cast<size_t>(rec) * nof_prb, 0);
+    int rc = nrphy_ofh_compress_host(ctx->get(), &cfg, nof_prb, iq_data.data(), packed.data());
+    report_failure("nrphy_ofh_compress_host", rc); // on failure the PRBs go out as zeros
+    for (unsigned i = 0; i != nof_prb; ++i) {
+      const uint8_t* r = &packed[static_cast<size_t>(i) * rec];
+      if (cfg.type == 1) {
+        compressed_prbs[i].set_compression_param(*r++);
+      }
+      std::memcpy(compressed_prbs[i].get_byte_buffer().data(), r, 3 * params.data_width);
+      compressed_prbs[i].set_stored_size(3 * params.data_width);
+    }
+  }
+
+private:
+  std::shared_ptr<context> ctx;
+  float                    iq_scaling;
+  std::vector<uint8_t>     packed;
 };
 
 } // namespace mi355

@@ -374,6 +374,52 @@ class PdschPlan:
             pass
 
 
+class PdschAsyncQueue:
+    """nrphy_pdsch_async: up to `depth` PDUs in flight through the host-span seam, completion on a runtime thread."""
+
+    def __init__(self, ctx, depth, nof_ports, nof_subc, max_tb_bytes):
+        self.ctx, self.nof_ports, self.nof_subc = ctx, nof_ports, nof_subc
+        h = C.c_void_p()
+        _check(ctx.lib.nrphy_pdsch_async_create(ctx.handle, depth, nof_ports, nof_subc, max_tb_bytes, C.byref(h)),
+               "nrphy_pdsch_async_create")
+        self.handle = h
+        self._keep = []
+
+    def submit(self, pdu, tb, on_done):
+        """on_done(status, grid) runs on a HIP runtime thread; grid is a copy [nof_ports][14][nof_subc][2] uint16.
+        Returns False when `depth` PDUs are in flight (retry after a completion)."""
+        shape = (self.nof_ports, 14, self.nof_subc, 2)
+
+        def trampoline(user, status, grid_ptr):
+            grid = np.ctypeslib.as_array(C.cast(grid_ptr, C.POINTER(C.c_uint16)), shape=shape).copy() if status == 0 else None
+            on_done(status, grid)
+
+        cb = abi.PDSCH_DONE_FN(trampoline)
+        self._keep.append(cb)
+        tb = np.ascontiguousarray(tb, dtype=np.uint8)
+        rc = self.ctx.lib.nrphy_pdsch_async_submit(self.handle, C.byref(pdu), tb.ctypes.data, cb, None)
+        if rc == abi.ERR_CAPACITY:
+            self._keep.pop()
+            return False
+        _check(rc, "nrphy_pdsch_async_submit")
+        return True
+
+    def wait(self):
+        _check(self.ctx.lib.nrphy_pdsch_async_wait(self.handle), "nrphy_pdsch_async_wait")
+        self._keep.clear()
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.nrphy_pdsch_async_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class OfdmPlan:
     """nrphy_ofdm_plan: ofdm_modulator_configuration + port count."""
 

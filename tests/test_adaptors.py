@@ -1,0 +1,157 @@
+"""Runtime evidence for the srsRAN-side adaptors (srsran-edgeric-5g_amd/adaptors/mi355_nrphy_srsran.h).
+
+Build container only (needs /root/reference): oracle/_ref/libadaptor_test.so = the adaptors compiled against the
+reference's headers + the compiled reference + a MOCK of the C ABI backed by the CPU oracle
+(oracle/ref/adaptor_harness.cpp, `make -C oracle adaptors`).  Every test pushes reference-side objects through an adaptor
+and through the reference's own implementation and compares the caller-visible results.  What is under test is the
+adaptors' logic (pdu_t -> POD, RE masks, grid access through the mapper, asynchronous completion, HAL protocol, slot
+cache); the library behind the real ABI is tested against the same oracle on the GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import backends
+import cases
+
+abi = backends.abi
+_vp, _u32, _i = C.c_void_p, C.c_uint32, C.c_int
+
+
+@pytest.fixture(scope="module")
+def harness():
+    if not os.path.isdir("/root/reference/srsRAN-5G-ER"):
+        pytest.skip("reference sources not available on this machine")
+    oracle_dir = os.path.join(backends.ROOT, "oracle")
+    subprocess.run(["make", "-C", oracle_dir, "oracle"], check=True, capture_output=True, timeout=600)
+    subprocess.run(["make", "-C", oracle_dir, "ref", "-j8"], check=True, capture_output=True, timeout=3000)
+    subprocess.run(["make", "-C", oracle_dir, "adaptors"], check=True, capture_output=True, timeout=900)
+    return C.CDLL(os.path.join(oracle_dir, "_ref", "libadaptor_test.so"))
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+def random_grid(rng, *shape):
+    return (rng.standard_normal(shape + (2,)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+@pytest.mark.parametrize("with_writer_access", [1, 0])
+def test_pdsch_processor_adaptor_asynchronous(harness, with_writer_access):
+    """pdsch_processor_adaptor: 10 PDUs (layers 1-4, reserved RE patterns, several modulations) submitted back to back
+    with 3 in flight.  process() returns before its PDU completes, every notifier fires exactly once from another
+    thread, and each caller grid equals what pdsch_processor_impl writes into the same initial grid -- through the
+    writer-access grid (bit-exact) and through a plain reference grid (mapper.map with identity precoding)."""
+    rng = np.random.default_rng(31)
+    pdus = (cases.unit_test_like_pdus(rng) * 2)[:10]
+    nof_ports, nof_subc, n = 4, 26 * 12, len(pdus)
+    tbs = [cases.random_tb(rng, p) for p in pdus]
+    arr = (abi.PdschPdu * n)(*pdus)
+    tb_ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in tbs])
+    init = random_grid(rng, n, nof_ports, 14, nof_subc)
+    got, want = np.zeros_like(init), np.zeros_like(init)
+    harness.adaptor_test_pdsch.restype = _i
+    rc = harness.adaptor_test_pdsch(_u32(n), arr, tb_ptrs, _u32(nof_ports), _u32(nof_subc), _i(with_writer_access), _u32(3),
+                                    _p(init), _p(got), _p(want))
+    assert rc == n, rc
+    if with_writer_access:
+        assert np.array_equal(got, want)
+    else:
+        # through the precoder a -0.0 may come out as +0.0: compare values, and bits wherever neither is a zero
+        a, b = backends.bf16_to_f32(got), backends.bf16_to_f32(want)
+        assert np.array_equal(a, b)
+        assert np.all(a[got != want] == 0)   # the only bit differences: signed zeros
+
+
+def test_pdsch_validator_adaptor(harness, ref):
+    """pdsch_pdu_validator_adaptor agrees with the reference's validator on valid and broken PDUs."""
+    rng = np.random.default_rng(32)
+    harness.adaptor_test_pdsch_validator.restype = _i
+    pdus = cases.unit_test_like_pdus(rng) + [p for p, _, _ in cases.random_pdus(backends.oracle().tbs, rng, 20)]
+    for pdu in pdus:
+        for field, value in ((None, 0), ("nof_codewords", 2), ("dmrs_type", 2), ("nof_symbols", 15), ("rv", 1)):
+            q = abi.PdschPdu.from_buffer_copy(pdu)
+            q._keepalive = pdu._keepalive
+            if field:
+                setattr(q, field, value)
+            assert harness.adaptor_test_pdsch_validator(C.byref(q)) == (1 if ref.validate(q) == 0 else 0), field
+
+
+def test_pdsch_encoder_hw_adaptor_through_the_references_hal_client(harness):
+    """hal::hw_accelerator_pdsch_enc adaptor driven by the reference's pdsch_encoder_hw_impl (configure / enqueue /
+    dequeue, transport-block mode) equals pdsch_encoder_impl bit for bit."""
+    rng = np.random.default_rng(33)
+    harness.adaptor_test_pdsch_encoder_hw.restype = _i
+    for bg, rv, qm, layers, nre, tb_bytes in ((1, 0, 8, 4, 2700, 8000), (2, 2, 2, 1, 600, 40), (1, 3, 6, 2, 5000, 3000),
+                                              (1, 0, 4, 3, 999, 1200), (2, 1, 2, 1, 288, 100)):
+        tb = rng.integers(0, 256, tb_bytes, dtype=np.uint8)
+        cw = nre * layers * qm
+        a, b = np.zeros(cw, np.uint8), np.zeros(cw, np.uint8)
+        n = harness.adaptor_test_pdsch_encoder_hw(_u32(bg), _u32(rv), _u32(qm), _u32(0), _u32(layers), _u32(nre * layers), _p(tb),
+                                                  _u32(tb_bytes), _p(a), _p(b))
+        assert n == cw and np.array_equal(a, b), (bg, rv, qm, layers)
+
+
+def test_ofdm_modulator_adaptors(harness):
+    """ofdm_symbol_modulator_adaptor in the real-time loop's order (every port of a symbol, then the next symbol: the slot
+    cache) and ofdm_slot_modulator_adaptor against ofdm_slot_modulator_impl."""
+    rng = np.random.default_rng(34)
+    harness.adaptor_test_ofdm.restype = _i
+    for mu, bw, n, ext, ports, slot in ((1, 51, 2048, 0, 2, 1), (0, 52, 1024, 0, 1, 0), (2, 24, 512, 1, 2, 3)):
+        cfg = abi.OfdmConfig(mu, bw, n, ext, 0.37, 3.5e9)
+        grid = random_grid(rng, ports, 14, bw * 12)
+        size = backends.pkg.lib.slot_size(cfg, slot)
+        by_symbol, by_slot, want = (np.zeros((ports, size), np.complex64) for _ in range(3))
+        rc = harness.adaptor_test_ofdm(C.byref(cfg), _p(grid), _u32(ports), _u32(slot), _p(by_symbol), _p(by_slot), _p(want))
+        assert rc == size
+        scale = np.abs(want).max()
+        assert np.abs(by_symbol - want).max() / scale < 1e-5 and np.array_equal(by_symbol, by_slot)
+
+
+@pytest.mark.parametrize("with_writer_access", [1, 0])
+def test_csi_rs_and_pdcch_adaptors(harness, with_writer_access):
+    rng = np.random.default_rng(35)
+    for fn in ("adaptor_test_csi_rs", "adaptor_test_pdcch"):
+        getattr(harness, fn).restype = _i
+    for name, cfg, nof_ports, nof_subc in list(cases.csi_rs_cases(rng))[::3]:
+        init = random_grid(rng, nof_ports, 14, nof_subc)
+        got, want = np.zeros_like(init), np.zeros_like(init)
+        assert harness.adaptor_test_csi_rs(C.byref(cfg), _u32(nof_ports), _u32(nof_subc), _i(with_writer_access), _p(init), _p(got), _p(want)) == 0
+        assert np.array_equal(backends.bf16_to_f32(got), backends.bf16_to_f32(want)), name
+        assert np.array_equal(got, want) if with_writer_access else np.all(backends.bf16_to_f32(got)[got != want] == 0), name
+    for i in range(25):
+        pdu = cases.random_pdcch(rng)
+        init = random_grid(rng, 4, 14, 624)
+        got, want = np.zeros_like(init), np.zeros_like(init)
+        assert harness.adaptor_test_pdcch(C.byref(pdu), _u32(4), _u32(624), _i(with_writer_access), _p(init), _p(got), _p(want)) == 0
+        assert np.array_equal(backends.bf16_to_f32(got), backends.bf16_to_f32(want)), i
+        assert np.array_equal(got, want) if with_writer_access else np.all(backends.bf16_to_f32(got)[got != want] == 0), i
+
+
+def test_ssb_amplitude_and_ofh_adaptors(harness):
+    rng = np.random.default_rng(36)
+    for fn in ("adaptor_test_ssb", "adaptor_test_amplitude", "adaptor_test_ofh"):
+        getattr(harness, fn).restype = _i
+    for i in range(15):
+        pdu = cases.random_ssb(rng, nof_ports=3)
+        init = random_grid(rng, 3, 14, 624)
+        got, want = np.zeros_like(init), np.zeros_like(init)
+        assert harness.adaptor_test_ssb(C.byref(pdu), _u32(3), _u32(624), _p(init), _p(got), _p(want)) == 0
+        assert np.array_equal(got, want), i
+    x = ((rng.standard_normal((5, 2000)) + 1j * rng.standard_normal((5, 2000))) * 0.5).astype(np.complex64)
+    ya, yr = np.zeros_like(x), np.zeros_like(x)
+    ma, mr = np.zeros(8), np.zeros(8)
+    assert harness.adaptor_test_amplitude(_i(1), C.c_float(-1.0), C.c_float(1.0), C.c_float(-6.0), _p(x), _u32(2000), _u32(5), _p(ya),
+                                          _p(yr), _p(ma), _p(mr)) == 0
+    assert np.array_equal(ya.view(np.uint32), yr.view(np.uint32))
+    assert np.array_equal(ma[4:], mr[4:]) and np.allclose(ma[:4], mr[:4], rtol=2e-5)   # counters exactly, powers to float accuracy
+    for typ, w in ((0, 9), (0, 16), (0, 12), (1, 9), (1, 14), (1, 8)):
+        nprb = int(rng.integers(1, 60))
+        prbs = ((rng.standard_normal((nprb, 12, 2)) * 0.25).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        a, r = np.zeros(nprb * 49, np.uint8), np.zeros(nprb * 49, np.uint8)
+        n = harness.adaptor_test_ofh(_i(typ), _u32(w), C.c_float(0.9), _p(prbs), _u32(nprb), _p(a), _p(r))
+        assert n == nprb * (3 * w + typ) and np.array_equal(a[:n], r[:n]), (typ, w)

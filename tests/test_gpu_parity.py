@@ -563,6 +563,46 @@ def test_mixed_host_span_calls_from_several_threads(gpu_ctx, oracle):
     assert not errors, sorted(set(errors))
 
 
+def test_pdsch_async_queue_keeps_pdus_in_flight(gpu_ctx, oracle):
+    """nrphy_pdsch_async_*: several PDUs in flight through the host-span seam (what an asynchronous pdsch_processor
+    drop-in uses); every completion fires exactly once on a runtime thread with the PDU's grid, also when the shapes
+    alternate (cached plans) and when the queue is full (NRPHY_ERR_CAPACITY, then retry)."""
+    import threading
+    import time
+    rng = np.random.default_rng(606)
+    pdus = []
+    for cfg in (1, 2, 1, 2, 2, 1):
+        pdu, nof_ports, nof_subc, _ = cases.baseline_config(cfg, slot_index=len(pdus) % 3)
+        pdus.append((pdu, nof_ports, nof_subc))
+    nof_ports = max(p[1] for p in pdus)
+    nof_subc = max(p[2] for p in pdus)
+    q = lib.PdschAsyncQueue(gpu_ctx, 3, nof_ports, nof_subc, max(p[0].tb_size_bytes for p in pdus))
+    results, lock, threads_seen = {}, threading.Lock(), set()
+    jobs = []
+    for i in range(24):
+        pdu = pdus[i % len(pdus)][0]
+        tb = cases.random_tb(rng, pdu)
+        jobs.append((pdu, tb))
+    full = 0
+    for i, (pdu, tb) in enumerate(jobs):
+        def on_done(status, grid, i=i):
+            with lock:
+                results.setdefault(i, []).append((status, grid))
+                threads_seen.add(threading.get_ident())
+        while not q.submit(pdu, tb, on_done):
+            full += 1
+            time.sleep(0.0005)
+    q.wait()
+    assert sorted(results) == list(range(len(jobs))) and all(len(v) == 1 for v in results.values())
+    assert threading.get_ident() not in threads_seen, "completions come from a runtime thread, not from the submitter"
+    for i, (pdu, tb) in enumerate(jobs):
+        status, grid = results[i][0]
+        assert status == 0
+        want = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc)
+        assert np.array_equal(grid, want), i
+    q.close()
+
+
 def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
     """The host-span entry points the srsRAN adaptors call (dft_processor::run, ofdm_slot_modulator::modulate)."""
     rng = np.random.default_rng(77)
