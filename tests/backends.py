@@ -169,6 +169,17 @@ class CpuBackend:
         return out, float(scale)
 
     # ---- PDSCH ------------------------------------------------------------------------------------
+    def pdsch_encode_cfg(self, bg, rv, qm, nref, nof_layers, nof_ch_symbols, tb, simd=1):
+        """pdsch_encoder::encode for an explicit configuration, composed from the per-block functions (segment -> encode
+        -> rate match -> concatenate): the packed codeword."""
+        segs, meta, zc = self.segment(bg, rv, qm, nref, nof_layers, nof_ch_symbols, tb)
+        out = np.zeros(nof_ch_symbols * qm, np.uint8)
+        for seg, (rm_length, cw_offset, nof_filler, _full, _crc) in zip(segs, meta.tolist()):
+            cb = self.ldpc_encode(bg, zc, seg, (66 if bg == 1 else 50) * zc, simd)
+            e = self.rate_match(bg, zc, rv, qm, nref, nof_filler, cb, rm_length)
+            out[cw_offset:cw_offset + rm_length] = np.unpackbits(e)[:rm_length]
+        return np.packbits(out)
+
     def derive(self, pdu):
         d = abi.PdschDerived()
         assert not self.is_ref

@@ -465,3 +465,37 @@ def pdu_from_arrays(cls, g, prefix):
         else:
             setattr(pdu, name, v.item())
     return pdu
+
+
+def attach_weights(pdu, weights):
+    """Points a PdschPdu's precoding at a float32 array [nof_prg][nof_ports][nof_layers][2] (kept alive on the struct)."""
+    import ctypes as C
+    f = np.ascontiguousarray(weights, dtype=np.float32).reshape(-1)
+    assert f.size == 2 * pdu.nof_prg * pdu.nof_ports * pdu.nof_layers
+    pdu._keepalive = f
+    pdu.precoding = f.ctypes.data_as(C.POINTER(C.c_float))
+    return pdu
+
+
+def pdsch_pdu_from_fixture(g, key):
+    """A PDSCH PDU stored by tests/golden/generate.py as the raw nrphy_pdsch_pdu_t bytes (`<key>_pod`) and its precoding
+    weights (`<key>_weights`)."""
+    from backends import abi
+    import ctypes as C
+    assert int(g["sizeof_pdu"]) == C.sizeof(abi.PdschPdu), "nrphy_pdsch_pdu_t changed: regenerate the fixture"
+    pdu = abi.PdschPdu.from_buffer_copy(g[key + "_pod"].tobytes())
+    return attach_weights(pdu, g[key + "_weights"])
+
+
+def ref_test_config_grid(case_row, index):
+    """The seeded grid tests/golden/generate.py fed the reference for case `index` of ofdm_modulator_test_data.h."""
+    bw_rb, cp = int(case_row[1]), int(case_row[3])
+    rng = np.random.default_rng([ord("o"), index])
+    nsymb = 12 if cp else 14
+    grid = np.zeros((1, 14, bw_rb * 12, 2), np.uint16)
+    grid[:, :nsymb] = (rng.standard_normal((1, nsymb, bw_rb * 12, 2)).astype(np.float32).view(np.uint32) >> 16)
+    return grid
+
+
+def ref_test_config_tb(g, key, nbytes):
+    return np.random.default_rng([int(x) for x in g[key + "_tb_seed"]]).integers(0, 256, nbytes, dtype=np.uint8)

@@ -6,7 +6,9 @@ expected outputs, never reference source) are committed and travel to the GPU bo
     python tests/golden/generate.py [section ...]     (no argument: every section)
 
 Sections: base (the round-1 files: codebooks, ldpc_encoder, pdsch_processor, ofdm_modulator, ofdm_demodulator),
-ofdm_sizes (DFT sizes 4608 / 6144: ofdm_sizes.npz), dl_control (PDCCH and SS/PBCH block processors: dl_control.npz).
+ofdm_sizes (DFT sizes 4608 / 6144: ofdm_sizes.npz), dl_control (PDCCH and SS/PBCH block processors: dl_control.npz),
+ref_test_configs (the configurations of the reference's own unit-test vectors, read from its test-data headers by
+oracle/ref/ref_testdata.cpp, with the compiled reference's outputs on seeded payloads: ref_test_configs.npz).
 """
 import hashlib
 import os
@@ -27,7 +29,7 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-SECTIONS = sys.argv[1:] or ["base", "ofdm_sizes", "dl_control"]
+SECTIONS = sys.argv[1:] or ["base", "ofdm_sizes", "dl_control", "ref_test_configs"]
 
 
 def section_ofdm_sizes():
@@ -83,6 +85,169 @@ def section_dl_control():
     np.savez_compressed(os.path.join(HERE, "dl_control.npz"), **g)
 
 
+def section_ref_test_configs():
+    """Every configuration of the six test-data headers SURVEY.md section 8c lists.  The headers' .dat payloads are not in the
+    reference checkout, so payloads are seeded here and the expected outputs come from the compiled reference:
+      proc_*  pdsch_processor_test_data.h (24): the PDU verbatim -> codeword and grid hashes
+      enc_*   pdsch_encoder_test_data.h (168): segmenter_config verbatim -> codeword hash
+      mod_*   pdsch_modulator_test_data.h (36): config_t as the PDU that produces it -> codeword and grid hashes
+      seg_*   ldpc_segmenter_test_data.h (11): the header's own known answers (segments, segment length) + segment hashes
+      ofdm_*  ofdm_modulator_test_data.h (20): configuration, port and slot verbatim -> sampled IQ
+      dmrs_*  dmrs_pdsch_processor_test_data.h (192): config_t verbatim through dmrs_pdsch_processor_impl::map -> written
+              positions and values; and as the PDU that produces it through the PDSCH processor -> grid hash.
+    Transport block sizes (absent with the .dat files) follow one rule: half the codeword capacity, at most 478 bytes for
+    base graph 2 (its 3824-bit limit), at least 3 bytes."""
+    import ctypes as C
+    import cases
+    h = r.lib
+    o = backends.oracle()
+    g = {}
+    sizeof_pdu = C.sizeof(abi.PdschPdu)
+    g["sizeof_pdu"] = np.array(sizeof_pdu)
+
+    def tb_rule(codeword_bits, bg):
+        n = max(3, codeword_bits // 16)
+        return min(n, 478) if bg == 2 else n
+
+    def fetch_pdu(fn, i, *extra):
+        pdu = abi.PdschPdu()
+        w = np.zeros(2 * 4 * 4 * 16, np.float32)
+        n = fn(i, C.byref(pdu), w.ctypes.data_as(C.c_void_p), w.size, *extra)
+        assert n > 0, n
+        return pdu, w[:n].copy()
+
+    def finish_pdu(pdu, w):
+        cases.attach_weights(pdu, w)
+        d = o.derive(pdu)
+        pdu.tb_size_bytes = tb_rule(d["codeword_bits"], pdu.ldpc_base_graph)
+        return o.derive(pdu)
+
+    def run_processor(prefix, i, pdu, w, nof_subc):
+        d = finish_pdu(pdu, w)
+        tb = np.random.default_rng([ord(prefix[0]), i]).integers(0, 256, pdu.tb_size_bytes, dtype=np.uint8)
+        assert r.validate(pdu) == 0 and o.validate(pdu) == 0, (prefix, i)
+        grid = r.pdsch_process(pdu, tb, pdu.nof_ports, nof_subc, simd=1)
+        cw = r.pdsch_encode(pdu, tb, d)[: (d["codeword_bits"] + 7) // 8]
+        g["%s%d_pod" % (prefix, i)] = np.frombuffer(bytes(pdu), np.uint8).copy()
+        g["%s%d_weights" % (prefix, i)] = w
+        g["%s%d_tb_seed" % (prefix, i)] = np.array([ord(prefix[0]), i])
+        g["%s%d_cw_sha" % (prefix, i)] = np.array(sha(cw))
+        g["%s%d_grid_sha" % (prefix, i)] = np.array(sha(grid))
+        return grid
+
+    # 1. pdsch_processor_test_data.h
+    fn = h.ref_testdata_pdsch_processor
+    n_proc = fn(0, None, None, 0, None)
+    g["proc_count"] = np.array(n_proc)
+    for i in range(n_proc):
+        rg = (C.c_uint * 2)()
+        pdu, w = fetch_pdu(fn, i, rg)
+        assert rg[1] == 14
+        g["proc_%d_rg" % i] = np.array([rg[0], rg[1]])
+        run_processor("proc_", i, pdu, w, rg[0] * 12)
+
+    # 2. pdsch_encoder_test_data.h
+    fn = h.ref_testdata_pdsch_encoder
+    n_enc = fn(0, None)
+    cfgs, shas, tbs = [], [], []
+    for i in range(n_enc):
+        c = (C.c_uint * 6)()
+        fn(i, c)
+        bg, rv, qm, nref, layers, nsym = list(c)
+        tb_bytes = tb_rule(nsym * qm, bg)
+        tb = np.random.default_rng([ord("e"), i]).integers(0, 256, tb_bytes, dtype=np.uint8)
+        unpacked = np.zeros(nsym * qm, np.uint8)
+        assert h.ref_pdsch_encode(bg, rv, qm, nref, layers, nsym, tb.ctypes.data_as(C.c_void_p), tb_bytes,
+                                  unpacked.ctypes.data_as(C.c_void_p), 1) == 0
+        cfgs.append([bg, rv, qm, nref, layers, nsym, tb_bytes])
+        shas.append(sha(np.packbits(unpacked)))
+    g["enc_cfg"] = np.array(cfgs, np.uint32)
+    g["enc_cw_sha"] = np.array(shas)
+
+    # 3. pdsch_modulator_test_data.h
+    fn = h.ref_testdata_pdsch_modulator
+    n_mod = fn(0, None, None, 0)
+    g["mod_count"] = np.array(n_mod)
+    for i in range(n_mod):
+        pdu, w = fetch_pdu(fn, i)
+        run_processor("mod_", i, pdu, w, (pdu.bwp_start_rb + pdu.bwp_size_rb) * 12)
+
+    # 4. ldpc_segmenter_test_data.h
+    fn = h.ref_testdata_ldpc_segmenter
+    n_seg = fn(0, None)
+    rows, shas = [], []
+    for i in range(n_seg):
+        c = (C.c_uint * 4)()
+        fn(i, c)
+        tbs_bits, bg, nof_segments, segment_length = list(c)
+        tb = np.random.default_rng([ord("s"), i]).integers(0, 256, tbs_bits // 8, dtype=np.uint8)
+        segs, meta, zc = r.segment(bg, 0, 2, 0, 1, 150, tb)      # ldpc_segmenter_test.cpp:112-118
+        assert segs.shape[0] == nof_segments and (22 if bg == 1 else 10) * zc == segment_length, (i, segs.shape, zc)
+        rows.append([tbs_bits, bg, nof_segments, segment_length])
+        shas.append(sha(segs))
+    g["seg_cases"] = np.array(rows, np.uint32)
+    g["seg_sha"] = np.array(shas)
+
+    # 5. ofdm_modulator_test_data.h
+    fn = h.ref_testdata_ofdm_modulator
+    n_ofdm = fn(0, None, None)
+    rows = []
+    for i in range(n_ofdm):
+        cfg = abi.OfdmConfig()
+        extra = (C.c_uint * 2)()
+        fn(i, C.byref(cfg), extra)
+        rng = np.random.default_rng([ord("o"), i])
+        nsymb = 12 if cfg.cp else 14
+        grid = np.zeros((1, 14, cfg.bw_rb * 12, 2), np.uint16)
+        grid[:, :nsymb] = (rng.standard_normal((1, nsymb, cfg.bw_rb * 12, 2)).astype(np.float32).view(np.uint32) >> 16)
+        iq = r.ofdm_slot(cfg, grid, int(extra[1]))
+        n = iq.shape[1]
+        idx = np.unique(np.concatenate([np.arange(256), np.arange(n - 256, n), rng.integers(0, n, 1536)]))
+        rows.append([cfg.numerology, cfg.bw_rb, cfg.dft_size, cfg.cp, cfg.scale, cfg.center_freq_hz, extra[0], extra[1], n])
+        g["ofdm_%d_idx" % i] = idx.astype(np.uint32)
+        g["ofdm_%d_iq" % i] = iq[0, idx]
+        g["ofdm_%d_energy" % i] = np.array(float(np.sum(np.abs(iq.astype(np.complex128)) ** 2)))
+    g["ofdm_cases"] = np.array(rows, np.float64)
+
+    # 6. dmrs_pdsch_processor_test_data.h
+    fn = h.ref_testdata_dmrs_pdsch
+    n_dmrs = fn(0, None, None, 0, None)
+    g["dmrs_count"] = np.array(n_dmrs)
+    info_rows = []
+    marker = np.uint16(0x7FC1)
+    for i in range(n_dmrs):
+        info = (C.c_uint * 4)()
+        pdu, w = fetch_pdu(fn, i, info)
+        dmrs_type, numerology, amp_ok, k_rb = list(info)
+        assert amp_ok == 1 and k_rb == 0
+        nof_subc = pdu.bwp_size_rb * 12
+        # The configuration verbatim through dmrs_pdsch_processor_impl::map.
+        dm = np.full((pdu.nof_ports, 14, nof_subc, 2), marker, np.uint16)
+        assert h.ref_testdata_dmrs_pdsch_map(i, dm.ctypes.data_as(C.c_void_p), pdu.nof_ports, nof_subc, 1) == 0
+        written = (dm.view(np.uint32).reshape(pdu.nof_ports, 14, nof_subc) != 0x7FC17FC1)
+        values = dm.view(np.uint32).reshape(pdu.nof_ports, 14, nof_subc)[written]
+        g["dmrs_%d_written" % i] = np.packbits(written.reshape(-1))
+        g["dmrs_%d_values_sha" % i] = np.array(sha(values))
+        cases.attach_weights(pdu, w)
+        if dmrs_type == 2:
+            # pdsch_processor_validator_impl refuses type 2; so must the C ABI.  Only the DM-RS-only result is kept.
+            pdu.tb_size_bytes = 16
+            assert r.validate(pdu) != 0 and o.validate(pdu) != 0, i
+            g["dmrs_%d_pod" % i] = np.frombuffer(bytes(pdu), np.uint8).copy()
+            g["dmrs_%d_weights" % i] = w
+            info_rows.append([dmrs_type, numerology, 0])
+            continue
+        grid = run_processor("dmrs_", i, pdu, w, nof_subc)
+        # The PDU reproduces the configuration: the processor's grid holds exactly those values at those positions.
+        assert np.array_equal(grid.view(np.uint32).reshape(pdu.nof_ports, 14, nof_subc)[written], values), i
+        info_rows.append([dmrs_type, numerology, 1])
+    g["dmrs_info"] = np.array(info_rows, np.uint32)
+    np.savez_compressed(os.path.join(HERE, "ref_test_configs.npz"), **g)
+    print("ref_test_configs:", n_proc, n_enc, n_mod, n_seg, n_ofdm, n_dmrs)
+
+
+if "ref_test_configs" in SECTIONS:
+    section_ref_test_configs()
 if "ofdm_sizes" in SECTIONS:
     section_ofdm_sizes()
 if "dl_control" in SECTIONS:

@@ -1668,3 +1668,95 @@ def test_pusch_decoder_random_shapes(gpu_ctx, oracle):
                 assert np.array_equal(d_tb.cpu().numpy()[0, : pdu.tb_size_bytes], tb)
                 break
         done += 1
+
+
+# ---- the reference's own unit-test configurations (tests/golden/ref_test_configs.npz) ---------------------------------
+# Every configuration of the six test-data headers SURVEY.md section 8c lists, read from the headers themselves
+# (oracle/ref/ref_testdata.cpp), with the compiled reference's outputs on seeded payloads as the expected values.
+
+@pytest.fixture(scope="module")
+def ref_cfgs():
+    return np.load(os.path.join(cases.GOLDEN, "ref_test_configs.npz"))
+
+
+def device_processor_case(gpu_ctx, g, key, nof_subc):
+    pdu = cases.pdsch_pdu_from_fixture(g, key)
+    assert lib.validate(pdu) == 0, key
+    tb = cases.ref_test_config_tb(g, key, pdu.tb_size_bytes)
+    grid, rm, _ = gpu_ctx.pdsch_process_host(pdu, tb, pdu.nof_ports, nof_subc, taps=True)
+    assert sha(rm) == str(g[key + "_cw_sha"]), key
+    assert sha(grid) == str(g[key + "_grid_sha"]), key
+    return pdu, grid
+
+
+def test_ref_test_configs_pdsch_processor(gpu_ctx, ref_cfgs):
+    g = ref_cfgs
+    assert int(g["proc_count"]) == 24
+    for i in range(24):
+        device_processor_case(gpu_ctx, g, "proc_%d" % i, int(g["proc_%d_rg" % i][0]) * 12)
+
+
+def test_ref_test_configs_pdsch_encoder(gpu_ctx, ref_cfgs):
+    g = ref_cfgs
+    assert g["enc_cfg"].shape == (168, 7)
+    for i, (bg, rv, qm, nref, layers, nsym, tb_bytes) in enumerate(g["enc_cfg"].tolist()):
+        tb = np.random.default_rng([ord("e"), i]).integers(0, 256, tb_bytes, dtype=np.uint8)
+        bits, packed = gpu_ctx.pdsch_encode_host(bg, rv, qm, nref, layers, nsym, tb)
+        assert sha(packed) == str(g["enc_cw_sha"][i]), i
+        assert np.array_equal(np.packbits(bits), packed)
+
+
+def test_ref_test_configs_pdsch_modulator(gpu_ctx, ref_cfgs):
+    g = ref_cfgs
+    assert int(g["mod_count"]) == 36
+    for i in range(36):
+        key = "mod_%d" % i
+        pdu = cases.pdsch_pdu_from_fixture(g, key)
+        device_processor_case(gpu_ctx, g, key, (pdu.bwp_start_rb + pdu.bwp_size_rb) * 12)
+
+
+def test_ref_test_configs_ldpc_segmenter(gpu_ctx, oracle, ref_cfgs):
+    """The header's known answers from nrphy_pdsch_derive; the segments themselves are internal to the codeblock kernel, so
+    their content is checked through the codeword: the test's own 150-symbol configuration, and one long enough for
+    redundancy version 0 to carry every systematic bit past the first 2 Zc."""
+    g = ref_cfgs
+    assert g["seg_cases"].shape == (11, 4)
+    for i, (tbs_bits, bg, nof_segments, segment_length) in enumerate(g["seg_cases"].tolist()):
+        pdu = abi.make_pdu(base_graph=bg, tb_size_bytes=tbs_bits // 8, prb_count=52, qm=2)
+        d = lib.derive(pdu)
+        assert (d["nof_codeblocks"], d["segment_length"]) == (nof_segments, segment_length)
+        tb = np.random.default_rng([ord("s"), i]).integers(0, 256, tbs_bits // 8, dtype=np.uint8)
+        for nsym in (150, nof_segments * segment_length):
+            _, packed = gpu_ctx.pdsch_encode_host(bg, 0, 2, 0, 1, nsym, tb)
+            assert np.array_equal(packed, oracle.pdsch_encode_cfg(bg, 0, 2, 0, 1, nsym, tb)), (i, nsym)
+
+
+def test_ref_test_configs_ofdm_modulator(gpu_ctx, ref_cfgs):
+    g = ref_cfgs
+    assert g["ofdm_cases"].shape[0] == 20
+    for i, row in enumerate(g["ofdm_cases"]):
+        cfg = abi.OfdmConfig(int(row[0]), int(row[1]), int(row[2]), int(row[3]), float(row[4]), float(row[5]))
+        plan = lib.OfdmPlan(gpu_ctx, cfg, 1)
+        iq = plan.modulate_slot_host(cases.ref_test_config_grid(row, i), int(row[7]))
+        plan.close()
+        assert iq.shape[1] == int(row[8])
+        want = g["ofdm_%d_iq" % i]
+        got = iq[0, g["ofdm_%d_idx" % i]]
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), i
+        energy = float(np.sum(np.abs(iq.astype(np.complex128)) ** 2))
+        assert abs(energy - float(g["ofdm_%d_energy" % i])) <= 1e-5 * energy
+
+
+def test_ref_test_configs_dmrs_pdsch(gpu_ctx, ref_cfgs):
+    g = ref_cfgs
+    assert int(g["dmrs_count"]) == 192 and int(np.sum(g["dmrs_info"][:, 2])) == 96
+    for i in range(192):
+        key = "dmrs_%d" % i
+        pdu = cases.pdsch_pdu_from_fixture(g, key)
+        if not g["dmrs_info"][i, 2]:
+            assert lib.validate(pdu) != 0, key
+            continue
+        nof_subc = pdu.bwp_size_rb * 12
+        _, grid = device_processor_case(gpu_ctx, g, key, nof_subc)
+        written = np.unpackbits(g[key + "_written"])[: pdu.nof_ports * 14 * nof_subc].astype(bool)
+        assert sha(grid.view(np.uint32).reshape(-1)[written]) == str(g[key + "_values_sha"]), key

@@ -193,3 +193,28 @@ def test_adaptors_compile_against_reference_headers(tmp_path):
            "-I", ref + "/external", str(src)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_reference_unit_test_configurations_host_side():
+    """The product's validator and derivation (host logic, no GPU) on every PDU of tests/golden/ref_test_configs.npz: the 24
+    pdsch_processor_test_data.h PDUs, the 36 pdsch_modulator_test_data.h and 96 type-1 dmrs_pdsch_processor_test_data.h
+    configurations are accepted and derive like the oracle; the 96 type-2 ones are refused; the 11
+    ldpc_segmenter_test_data.h known answers come out of nrphy_pdsch_derive."""
+    import os
+    g = np.load(os.path.join(cases.GOLDEN, "ref_test_configs.npz"))
+    o = backends.oracle()
+    lib = backends.pkg.lib
+    keys = ["proc_%d" % i for i in range(24)] + ["mod_%d" % i for i in range(36)]
+    for i in range(192):
+        pdu = cases.pdsch_pdu_from_fixture(g, "dmrs_%d" % i)
+        if g["dmrs_info"][i, 2]:
+            keys.append("dmrs_%d" % i)
+        else:
+            assert lib.validate(pdu) != 0
+    for key in keys:
+        pdu = cases.pdsch_pdu_from_fixture(g, key)
+        assert lib.validate(pdu) == 0, key
+        assert lib.derive(pdu) == o.derive(pdu), key
+    for tbs_bits, bg, nof_segments, segment_length in g["seg_cases"].tolist():
+        d = lib.derive(backends.abi.make_pdu(base_graph=bg, tb_size_bytes=tbs_bits // 8, prb_count=52, qm=2))
+        assert (d["nof_codeblocks"], d["segment_length"]) == (nof_segments, segment_length)
