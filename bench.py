@@ -7,9 +7,14 @@
 
 A "step" is one pass of the whole hot path (TB CRC -> segmentation -> LDPC -> rate matching -> scrambling -> QAM ->
 layer mapping/precoding/RE mapping -> DM-RS -> OFDM) over one batch of --slots BASELINE-config-3 slots per GPU with
-distinct transport blocks already resident in HBM.  Slots are independent, so ranks just own disjoint slot batches
-(weak scaling, no data-path collective); RCCL is used for the barrier and the max-over-ranks time only.
-Rank 0 prints ONE JSON line.
+distinct transport blocks already resident in HBM.  Slots are independent, so ranks own disjoint slot batches
+(sharding.shard_slots; config 4: sharding.cell_affine_rank), weak scaling, no data-path collective; RCCL is used for the
+barrier and the max-over-ranks time only.  Rank 0 prints ONE JSON line.
+
+At N=1 the same line also carries, under "secondary", measured-and-verified entries for the other BASELINE configs
+(2: 20 MHz 2-layer 64-QAM 1000-slot batch; 4: four cells x four UEs mixed MCS, 1024 cell-slots; 5: receive chain with
+8 LDPC iterations) and for config 3 with the wire-format (complex int16) OFDM output, each with its own roofline dict,
+and "cpu_baseline": the reference's CPU path timed on this host's cores.
 """
 import argparse
 import json
@@ -25,9 +30,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=20.0):
-    """Times the CPU path on the host cores for a bounded sample of the same workload (rank 0, N=1 only).
-    Uses the compiled reference (oracle/_ref, kind "reference") when that library travelled with the repository,
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=24.0):
+    """Times the CPU path on the host cores for a bounded sample of the same workload (rank 0, N=1 only): all threads and
+    one thread, several batches each, median and 5th/95th percentile of the per-batch rate.  Uses the compiled reference
+    (oracle/_ref, kind "reference": it travels to the GPU box as a built library like the product's own .so) when present,
     the C oracle (kind "port") otherwise."""
     import ctypes as C
     import backends
@@ -45,18 +61,210 @@ def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=20.0):
 
         def run(threads, reps):
             return o.lib.oracle_bench(C.byref(pdu), tb.ctypes.data, nof_ports, nof_subc, C.byref(ofdm), threads, reps)
-    run(cores, 1)       # warms caches / page-faults the buffers
-    t1 = run(cores, 4) / 4.0  # calibration: seconds per slot per thread
-    reps = int(max(2, min(20000, budget_s / max(t1, 1e-4))))
-    dt = run(cores, reps)
+
+    def measure(threads, share_s, batches=7):
+        run(threads, 1)                          # warms caches / page-faults the buffers
+        t1 = run(threads, 2) / 2.0               # calibration: seconds per slot per thread
+        reps = int(max(1, min(5000, share_s / batches / max(t1, 1e-4))))
+        rates, total = [], 0.0
+        for _ in range(batches):
+            dt = run(threads, reps)
+            rates.append(threads * reps / dt)
+            total += dt
+        rates = np.array(rates)
+        return {"threads": threads, "slots_per_sec": round(float(np.median(rates)), 2),
+                "p5": round(float(np.percentile(rates, 5)), 2), "p95": round(float(np.percentile(rates, 95)), 2),
+                "batches": batches, "slots_per_thread_per_batch": reps, "seconds": round(total, 1)}
+
+    full = measure(cores, budget_s * 0.6)
+    one = measure(1, budget_s * 0.4)
     return {
-        "value": cores * reps / dt,
+        "value": full["slots_per_sec"],
         "unit": "slots/s",
         "cores": cores,
         "kind": kind,
-        "sample": "%d threads x %d config-3 slots each (PDSCH %s + OFDM generic radix-2 DFT), %.1f s" % (
-            cores, reps, "AVX2 LDPC/precoder" if kind == "reference" else "scalar C oracle", dt),
+        "cpu_model": cpu_model(),
+        "all_threads": full,
+        "one_thread": one,
+        "sample": "config-3 slots (PDSCH %s + OFDM generic radix-2 DFT): %d threads x %d batches x %d slots each (%.1f s), "
+                  "then 1 thread x %d batches x %d slots (%.1f s); value = median over the all-thread batches" % (
+                      "AVX2 LDPC/precoder, the reference's own objects" if kind == "reference" else "scalar C oracle", cores,
+                      full["batches"], full["slots_per_thread_per_batch"], full["seconds"], one["batches"],
+                      one["slots_per_thread_per_batch"], one["seconds"]),
     }
+
+
+def roof(name, ms, nbytes, traffic=None):
+    gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes),
+            "traffic": traffic}
+
+
+def run_downlink(env, config, slots, steps, warmup, wire=False):
+    """Builds the workload of BASELINE config 2, 3 or 4 for this rank, times `steps` steps and returns the measurement (on
+    rank 0: the JSON fields; elsewhere None)."""
+    torch, lib, abi, cases, sharding = env["torch"], env["lib"], env["abi"], env["cases"], env["sharding"]
+    ctx, dist, rank, world, device = env["ctx"], env["dist"], env["rank"], env["world"], env["device"]
+    if config == 4:
+        # Four cells x four UEs (68 PRB each, QPSK / 16 / 64 / 256-QAM): one grid per cell-slot, four PDUs per grid.  The
+        # job's stream of cell-slots (cell = i % 4, slot = i // 4) is placed by cell affinity; every rank gets `slots` of them.
+        mine = [i for i in range(slots * world) if sharding.cell_affine_rank(i % 4, i // 4, world, 4) == rank]
+        assert len(mine) == slots, (len(mine), slots)
+        pdus, grid_of = [], []
+        for g, i in enumerate(mine):
+            cell, nof_ports, nof_subc = cases.mixed_cell(i % 4, slot_index=(i // 4) % 20)
+            pdus += cell
+            grid_of += [g] * len(cell)
+        ofdm = cases.baseline_config(3)[3]
+        workload = ("BASELINE config 4: 100 MHz cell-slots, 4 cells x 4 UEs (68 PRB each; QPSK 120, 16-QAM 658, "
+                    "64-QAM 873, 256-QAM 948; 4 layers) + 4-port OFDM")
+    else:
+        nof_ports, nof_subc, ofdm = cases.baseline_config(config)[1:]
+        first, count = sharding.shard_slots(slots * world, rank, world)
+        assert count == slots
+        period = 20 if config == 3 else 10
+        pdus = [cases.baseline_config(config, slot_index=(first + i) % period)[0] for i in range(slots)]
+        grid_of = list(range(slots))
+        d0 = lib.derive(pdus[0])
+        workload = {
+            3: "BASELINE config 3: 100 MHz (FFT 4096, 30 kHz SCS, 273 PRB grid) 4-layer 256-QAM R=948/1024 full-TBS "
+               "PDSCH (TBS %d bit, %d CB, BG1 Zc %d) + 4-port OFDM",
+            2: "BASELINE config 2: 20 MHz (FFT 2048, 15 kHz SCS, 106 PRB) 2-layer 64-QAM R=873/1024 PDSCH "
+               "(TBS %d bit, %d CB, BG1 Zc %d) + 2-port OFDM",
+        }[config] % (8 * pdus[0].tb_size_bytes, d0["nof_codeblocks"], d0["lifting_size"])
+    if wire:
+        workload += ", OFDM output as complex int16 (amplitude controller + cf32->ci16 fused into the modulator's store)"
+    tb_strides = [(q.tb_size_bytes + 255) & ~255 for q in pdus]
+    tb_offsets = [0]
+    for st in tb_strides[:-1]:
+        tb_offsets.append(tb_offsets[-1] + st)
+    tb_total = tb_offsets[-1] + tb_strides[-1]
+    tb_bytes_per_step = sum(q.tb_size_bytes for q in pdus)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    # Four sets of transport blocks taken in turn (0.45 GB at the default size): a step never finds its input in the
+    # memory-side cache because an earlier step read the same bytes.
+    tb_sets = [torch.randint(0, 256, (tb_total,), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(4)]
+    plan = lib.PdschPlan(ctx, pdus, tb_offsets, grid_of, slots, nof_ports, nof_subc)
+    oplan = lib.OfdmPlan(ctx, ofdm, nof_ports)
+    d_grid = torch.zeros((slots, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
+    if wire:
+        wire_cfg = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -2.0, 1.0, -9.0), 32767.0)
+        d_iq = torch.zeros((slots, nof_ports, oplan.slot_stride, 2), dtype=torch.int16, device="cuda")
+        d_stats = torch.zeros((slots * nof_ports, 4), dtype=torch.int32, device="cuda")
+    else:
+        d_iq = torch.zeros((slots, nof_ports, oplan.slot_stride, 2), dtype=torch.float32, device="cuda")
+    sps = 2 if config != 2 else 1  # slots per subframe
+    d_slot = torch.tensor([i % sps for i in range(slots)], dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    step_no = [0]
+
+    def step():
+        plan.run(tb_sets[step_no[0] % len(tb_sets)], d_grid, zero_grids=True)
+        if wire:
+            oplan.run_ci16(slots, d_grid, wire_cfg, d_iq, d_slot_index=d_slot, d_stats=d_stats)
+        else:
+            oplan.run(slots, d_grid, d_iq, d_slot_index=d_slot)
+        step_no[0] += 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(warmup):
+        step()
+    ctx.synchronize()
+    plan.enable_timing(steps)
+    oplan.enable_timing(steps)
+    barrier()
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    # Whole-job totals: slots and IQ samples summed over ranks, time = max over ranks (RCCL all-reduce of 3 numbers).
+    samples_per_slot = nof_ports * oplan.slot_stride
+    total_slots, total_samples, dt = sharding.aggregate(dist, device, slots * steps, slots * steps * samples_per_slot, dt)
+
+    (ms_crc, ms_cb, ms_dmrs, ms_run), _ = plan.kernel_times()
+    ms_ofdm, _ = oplan.kernel_time()
+    out = None
+    if rank == 0:
+        # Algorithmic bytes per slot (SURVEY.md section 8d): TB read + grid written once (incl. zeros) + grid read by the OFDM
+        # modulator + IQ write (8 bytes per sample as complex float, 4 as complex int16).
+        grid_bytes = nof_ports * 14 * nof_subc * 4
+        alg_pdsch = tb_bytes_per_step / slots + grid_bytes
+        alg_ofdm = grid_bytes + samples_per_slot * (4 if wire else 8)
+        ofdm_name = "ofdm_kernel<%d%s>" % (ofdm.dft_size, ", ci16" if wire else "")
+        kernels = {
+            # name: (avg ms per launch, algorithmic bytes per launch)
+            ofdm_name: (ms_ofdm, slots * alg_ofdm),
+            # The codeblock launch also carries the DM-RS and zero-fill waves: it writes every grid word exactly once.
+            "codeblock_kernel": (ms_cb, tb_bytes_per_step + slots * grid_bytes),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and config == 3 and not wire:
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("slots") == slots and dom in tj.get("hbm_bytes_per_launch", {}):
+                    traffic = tj["hbm_bytes_per_launch"][dom]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "pdsch_slots_per_sec",
+            "value": round(total_slots / dt, 1),
+            "unit": "slots/s",
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(1e3 * dt / steps, 4),
+            "config": {"workload": workload, "slots_per_gpu_per_step": slots,
+                       "parallelism": "slot-sharded x%d, no data-path collective" % world},
+            "iq_gsamples_per_sec": round(total_samples / dt / 1e9, 3),
+            "whole_path_hbm_frac": round(total_slots * (alg_pdsch + alg_ofdm) / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "kernel_ms": {"prologue_tbcrc_scrambling_seq": round(ms_crc, 4), "codeblock_dmrs_zerofill": round(ms_cb, 4),
+                          "separate_dmrs": round(ms_dmrs, 4), "pdsch_run": round(ms_run, 4), "ofdm": round(ms_ofdm, 4)},
+            "roofline": roof(dom, *kernels[dom], traffic=traffic),
+            "roofline_other": [roof(k, *kernels[k]) for k in kernels if k != dom],
+        }
+        # Sanity: grid 0 of the last step against the CPU oracle (checker only, outside the timed region).
+        last = tb_sets[(step_no[0] - 1) % len(tb_sets)]
+        try:
+            import backends
+            o = backends.oracle()
+            want = None
+            for k, q in enumerate(pdus):  # the PDUs of grid 0 map disjoint RE: their grids OR together
+                if grid_of[k] != 0:
+                    break
+                tbk = last[tb_offsets[k]: tb_offsets[k] + q.tb_size_bytes].cpu().numpy()
+                part = o.pdsch_process(q, tbk, nof_ports, nof_subc)
+                want = part if want is None else np.bitwise_or(want, part)
+            got = d_grid[0].cpu().numpy().view(np.uint16).reshape(want.shape)
+            ok = bool(np.array_equal(got, want))
+            if ok and wire:
+                # wire format: slot 0, port 0 against the oracle's modulator -> amplitude controller -> int16 chain (one LSB:
+                # the two FFTs differ by 1e-7 relative)
+                ref_iq = o.ofdm_slot(ofdm, want, 0)[0]
+                y, _ = o.amplitude_control(wire_cfg.amplitude, ref_iq)
+                w16 = o.iq_convert_ci16(y, wire_cfg.ci16_scale).reshape(-1, 2).astype(np.int32)
+                g16 = d_iq[0, 0, : w16.shape[0]].cpu().numpy().astype(np.int32)
+                ok = bool(np.abs(g16 - w16).max() <= 1)
+            out["verified_vs_oracle"] = ok
+        except Exception as e:  # the oracle is optional at bench time
+            out["verified_vs_oracle"] = "unavailable: %s" % e
+        out["_first_pdu"] = (pdus[0], last[: pdus[0].tb_size_bytes].cpu().numpy().copy(), nof_ports, nof_subc, ofdm)
+    plan.close()
+    oplan.close()
+    del tb_sets, d_grid, d_iq
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -66,17 +274,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--slots", type=int, default=1024, help="slots (config 4: cell-slots) per GPU per step")
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
-                    help="BASELINE config: 3 = the headline workload (default); 2, 4 and 5 (receive-side add-on, one GPU) "
-                         "are secondary measurements")
+                    help="BASELINE config measured as the line's value: 3 = the headline workload (default)")
+    ap.add_argument("--wire", action="store_true", help="OFDM output as complex int16 (amplitude controller + conversion fused)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary entries (configs 2, 4, 5, wire format)")
     args = ap.parse_args()
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
     if args.config == 5:
         # the receive-side chain has its own script (profiles/rx_chain_bench.py); same JSON schema, one GPU
-        sys.path.insert(0, os.path.join(ROOT, "profiles"))
         import rx_chain_bench
-        sys.argv = [sys.argv[0], "--steps", str(args.steps), "--warmup", str(args.warmup)] + (
-            ["--slots", str(args.slots)] if args.slots != 1024 else [])
-        rx_chain_bench.main()
+        print(json.dumps(rx_chain_bench.run(argparse.Namespace(
+            slots=args.slots if args.slots != 1024 else 64, iterations=8, steps=args.steps, warmup=args.warmup, sigma=7.0))),
+            flush=True)
         return
 
     import torch
@@ -89,161 +298,41 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
+        # under torch.distributed.run, also at N=1: RCCL initialisation, barrier and the totals' all-reduce all run
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    env = {"torch": torch, "lib": lib, "abi": backends.abi, "cases": cases, "sharding": backends.pkg.sharding,
+           "ctx": lib.Context(local_rank), "dist": dist, "rank": rank, "world": world,
+           "device": torch.device("cuda", local_rank)}
 
-    ctx = lib.Context(local_rank)
-    slots = args.slots
-    if args.config == 4:
-        # four cells x four UEs (68 PRB each, QPSK / 16 / 64 / 256-QAM): one grid per cell-slot, four PDUs per grid
-        pdus, grid_of = [], []
-        for i in range(slots):
-            cell, nof_ports, nof_subc = cases.mixed_cell(i % 4, slot_index=(i // 4) % 20)
-            pdus += cell
-            grid_of += [i] * len(cell)
-        ofdm = cases.baseline_config(3)[3]
-        workload = ("BASELINE config 4: 100 MHz cell-slots, 4 cells x 4 UEs (68 PRB each; QPSK 120, 16-QAM 658, "
-                    "64-QAM 873, 256-QAM 948; 4 layers) + 4-port OFDM")
-    else:
-        nof_ports, nof_subc, ofdm = cases.baseline_config(args.config)[1:]
-        pdus = [cases.baseline_config(args.config, slot_index=i % (20 if args.config == 3 else 10))[0]
-                for i in range(slots)]
-        grid_of = list(range(slots))
-        d0 = lib.derive(pdus[0])
-        workload = {
-            3: "BASELINE config 3: 100 MHz (FFT 4096, 30 kHz SCS, 273 PRB grid) 4-layer 256-QAM R=948/1024 full-TBS "
-               "PDSCH (TBS %d bit, %d CB, BG1 Zc %d) + 4-port OFDM",
-            2: "BASELINE config 2: 20 MHz (FFT 2048, 15 kHz SCS, 106 PRB) 2-layer 64-QAM R=873/1024 PDSCH "
-               "(TBS %d bit, %d CB, BG1 Zc %d) + 2-port OFDM",
-        }[args.config] % (8 * pdus[0].tb_size_bytes, d0["nof_codeblocks"], d0["lifting_size"])
-    pdu0 = pdus[0]
-    tb_strides = [(q.tb_size_bytes + 255) & ~255 for q in pdus]
-    tb_offsets = [0]
-    for st in tb_strides[:-1]:
-        tb_offsets.append(tb_offsets[-1] + st)
-    tb_total = tb_offsets[-1] + tb_strides[-1]
-    tb_bytes_per_step = sum(q.tb_size_bytes for q in pdus)
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-    # Four sets of transport blocks taken in turn (0.45 GB at the default size): a step never finds its input in the
-    # memory-side cache because an earlier step read the same bytes.
-    tb_sets = [torch.randint(0, 256, (tb_total,), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(4)]
-    d_tb = tb_sets[0]
-    plan = lib.PdschPlan(ctx, pdus, tb_offsets, grid_of, slots, nof_ports, nof_subc)
-    oplan = lib.OfdmPlan(ctx, ofdm, nof_ports)
-    d_grid = torch.zeros((slots, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
-    d_iq = torch.zeros((slots, nof_ports, oplan.slot_stride, 2), dtype=torch.float32, device="cuda")
-    sps = 2 if args.config != 2 else 1  # slots per subframe
-    d_slot = torch.tensor([i % sps for i in range(slots)], dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-
-    step_no = [0]
-
-    def step():
-        plan.run(tb_sets[step_no[0] % len(tb_sets)], d_grid, zero_grids=True)
-        oplan.run(slots, d_grid, d_iq, d_slot_index=d_slot)
-        step_no[0] += 1
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    ctx.synchronize()
-    plan.enable_timing(args.steps)
-    oplan.enable_timing(args.steps)
-    barrier()
-    torch.cuda.synchronize()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    # Whole-job totals: slots and IQ samples summed over ranks, time = max over ranks (RCCL all-reduce of 3 numbers).
-    samples_per_slot = nof_ports * oplan.slot_stride
-    total_slots, total_samples, dt = backends.pkg.sharding.aggregate(
-        dist, torch.device("cuda", local_rank), slots * args.steps, slots * args.steps * samples_per_slot, dt)
-
-    (ms_crc, ms_cb, ms_dmrs, ms_run), _ = plan.kernel_times()
-    ms_ofdm, _ = oplan.kernel_time()
-
+    head = run_downlink(env, args.config, args.slots, args.steps, args.warmup, wire=args.wire)
     if rank == 0:
-        # Algorithmic bytes per slot: TB read + grid written once (incl. zeros) +
-        # grid read by the OFDM modulator + IQ write.
-        grid_bytes = nof_ports * 14 * nof_subc * 4
-        alg_pdsch = tb_bytes_per_step / slots + grid_bytes
-        alg_ofdm = grid_bytes + samples_per_slot * 8
-        ofdm_name = "ofdm_kernel<%d>" % ofdm.dft_size
-        kernels = {
-            # name: (avg ms per launch, algorithmic bytes per launch)
-            ofdm_name: (ms_ofdm, slots * alg_ofdm),
-            # The codeblock launch also carries the DM-RS and zero-fill waves: it writes every grid word exactly once.
-            "codeblock_kernel": (ms_cb, tb_bytes_per_step + slots * grid_bytes),
-        }
-        dom = max(kernels, key=lambda k: kernels[k][0])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if args.config == 3 and tj.get("slots") == slots and dom in tj.get("hbm_bytes_per_launch", {}):
-                    traffic = tj["hbm_bytes_per_launch"][dom]
-            except Exception:
-                traffic = None
-
-        def roof(name):
-            ms, nbytes = kernels[name]
-            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4),
-                    "algorithmic_bytes_per_launch": int(nbytes)}
-
-        roofline = roof(dom)
-        roofline["traffic"] = traffic
+        first = head.pop("_first_pdu")
         out = {
-            "metric": "pdsch_slots_per_sec",
-            "value": round(total_slots / dt, 1),
-            "unit": "slots/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
+            "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 bit-packed GF(2) + bf16 grid + f32 IQ",
+            "dtype": "u32 bit-packed GF(2) + bf16 grid + %s IQ" % ("ci16" if args.wire else "f32"),
             "data": "synthetic",
-            "config": {"workload": workload, "slots_per_gpu_per_step": slots, "parallelism": "slot-sharded x%d, no data-path collective" % world},
-            "iq_gsamples_per_sec": round(total_samples / dt / 1e9, 3),
-            "whole_path_hbm_frac": round(total_slots * (alg_pdsch + alg_ofdm) / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
-            "kernel_ms": {"prologue_tbcrc_scrambling_seq": round(ms_crc, 4), "codeblock_dmrs_zerofill": round(ms_cb, 4),
-                          "separate_dmrs": round(ms_dmrs, 4), "pdsch_run": round(ms_run, 4), "ofdm": round(ms_ofdm, 4)},
-            "roofline": roofline,
-            "roofline_other": [roof(k) for k in kernels if k != dom],
         }
-        # Sanity: slot 0 of the last step against the CPU oracle (checker only, outside the timed region).
-        try:
-            o = backends.oracle()
-            want = None
-            for k, q in enumerate(pdus):  # the PDUs of grid 0 map disjoint RE: their grids OR together
-                if grid_of[k] != 0:
-                    break
-                last = tb_sets[(step_no[0] - 1) % len(tb_sets)]
-                tbk = last[tb_offsets[k]: tb_offsets[k] + q.tb_size_bytes].cpu().numpy()
-                part = o.pdsch_process(q, tbk, nof_ports, nof_subc)
-                want = part if want is None else np.bitwise_or(want, part)
-            got = d_grid[0].cpu().numpy().view(np.uint16).reshape(want.shape)
-            out["verified_vs_oracle"] = bool(np.array_equal(got, want))
-        except Exception as e:  # the oracle is optional at bench time
-            out["verified_vs_oracle"] = "unavailable: %s" % e
+        out.update({k: v for k, v in head.items() if k not in out})
+        out["collective_backend"] = "rccl (torch.distributed nccl)" if dist is not None else "none (single process)"
+    if world == 1 and not args.no_secondary and args.config == 3 and not args.wire:
+        # Secondary measurements, same process and GPU, fewer steps each; every entry is verified against the oracle.
+        sec = {}
+        s_steps, s_warm = max(3, min(args.steps, 8)), 2
+        for name, (cfg, slots, wire) in {"config3_wire_ci16": (3, args.slots, True), "config2": (2, 1000, False),
+                                         "config4": (4, 1024, False)}.items():
+            e = run_downlink(env, cfg, slots, s_steps, s_warm, wire=wire)
+            e.pop("_first_pdu")
+            sec[name] = e
+        import rx_chain_bench
+        sec["config5"] = rx_chain_bench.run(argparse.Namespace(slots=64, iterations=8, steps=s_steps, warmup=s_warm, sigma=7.0))
+        out["secondary"] = sec
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.config == 3:
-            tb_host = d_tb[: pdu0.tb_size_bytes].cpu().numpy().copy()
-            out["cpu_baseline"] = cpu_baseline(pdus[0], tb_host, nof_ports, nof_subc, ofdm)
+            out["cpu_baseline"] = cpu_baseline(*first)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -7,7 +7,7 @@ cp $LIB /tmp/keep.so
 for i in $(seq $ROUNDS); do
   for v in $A $B; do
     cp $v $LIB
-    python3 bench.py --no-cpu-baseline --steps 20 2>/dev/null | tail -1 | \
+    python3 bench.py --no-cpu-baseline --no-secondary --steps 20 2>/dev/null | tail -1 | \
       python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['kernel_ms'], round(d['value']))"
   done
 done

@@ -12,7 +12,7 @@ mkdir -p "$OUT"
 python3 bench.py > "$OUT/${TAG}_bench.log" 2>&1 && tail -1 "$OUT/${TAG}_bench.log" > "$OUT/${TAG}_bench.json"
 echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/${TAG}_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-secondary > "$OUT/${TAG}_stats.log" 2>&1
 echo "stats rc=$?"
 cp "$OUT/${TAG}_stats"/*/*kernel_stats.csv "$OUT/${TAG}_kernel_stats.csv"
 cd "$ROOT"

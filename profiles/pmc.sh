@@ -3,10 +3,10 @@
 # domains), as /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes.  Usage (on the GPU box, from the
 # repository root):  bash profiles/pmc.sh <out_dir> [bench args]
 set -u
-OUT=$1; shift
+OUT=$(realpath -m "$1"); shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary $*"
 run() { # name, counters
   rocprofv3 --kernel-trace --pmc $2 --output-format csv -d "$OUT/$1" -- python3 "$GRAFT_REPO_ROOT/bench.py" $ARGS > "$OUT/$1.log" 2>&1
   echo "$1 rc=$?"

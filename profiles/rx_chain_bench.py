@@ -26,7 +26,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sigma", type=float, default=7.0)
-    args = ap.parse_args()
+    print(json.dumps(run(ap.parse_args())))
+
+
+def run(args):
+    """One measurement of the receive chain; `args` carries slots, iterations, steps, warmup, sigma.  Returns the bench line
+    as a dict (bench.py embeds it as its config-5 entry)."""
     import torch
     import backends
     import cases
@@ -100,7 +105,7 @@ def main():
                  "pusch_decode_batch": ev[2].elapsed_time(ev[3])}
     n_cb = slots * C
     alg = n_cb * d["full_length"] + slots * tb_size  # decoder: soft buffers in, transport blocks out
-    print(json.dumps({
+    return {
         "metric": "pusch_rx_slots_per_second", "value": slots / ms * 1e3, "unit": "slots/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int8 LLR / f32 IQ", "data": "synthetic",
@@ -113,7 +118,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "ldpc_decode_kernel", "achieved": alg / kernel_ms["pusch_decode_batch"] * 1e-6,
                      "peak": 8000.0, "unit": "GB/s", "frac": alg / kernel_ms["pusch_decode_batch"] * 1e-6 / 8000.0,
                      "traffic": None, "note": "VALU-issue bound, see DESIGN.md section 5"},
-    }))
+        "verified": "every transport block decoded (CRC24A) and equal to what was sent",
+    }
 
 
 if __name__ == "__main__":

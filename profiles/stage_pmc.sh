@@ -10,6 +10,6 @@ cd /tmp && export TMPDIR=/tmp
 for st in ${STAGES:-1 2 3 4 0}; do
   export NRPHY_PROFILE_STAGE=$st
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY \
-    --output-format csv -d "$OUT/stage$st" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --slots 256 > "$OUT/stage$st.log" 2>&1
+    --output-format csv -d "$OUT/stage$st" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --slots 256 > "$OUT/stage$st.log" 2>&1
   echo "stage $st rc=$?"
 done

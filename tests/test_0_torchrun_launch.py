@@ -1,0 +1,28 @@
+"""bench.py under the launcher the driver uses for N > 1, at N = 1 on the one GPU of the test box: RCCL initialisation, the
+barrier and sharding.aggregate's all-reduces run on a real device.  The file sorts first so the launcher starts before this
+pytest process has touched the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_one_rank():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--slots", "64", "--no-secondary", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["metric"] == "pdsch_slots_per_sec"
+    assert out["collective_backend"].startswith("rccl")
+    assert out["verified_vs_oracle"] is True
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
