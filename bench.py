@@ -150,7 +150,8 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
     oplan = lib.OfdmPlan(ctx, ofdm, nof_ports)
     d_grid = torch.zeros((slots, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
     if wire:
-        wire_cfg = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -2.0, 1.0, -9.0), 32767.0)
+        # clipping enabled with a realistic back-off: gain -14 dB puts the signal about 14 dB (rms) under the -1 dBFS ceiling
+        wire_cfg = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -14.0, 1.0, -1.0), 32767.0)
         d_iq = torch.zeros((slots, nof_ports, oplan.slot_stride, 2), dtype=torch.int16, device="cuda")
         d_stats = torch.zeros((slots * nof_ports, 4), dtype=torch.int32, device="cuda")
     else:

@@ -7,7 +7,7 @@ cp $LIB /tmp/keep.so
 for i in $(seq $ROUNDS); do
   for v in "$@"; do
     cp $v $LIB
-    python3 bench.py --no-cpu-baseline --no-secondary --steps 20 2>/dev/null | tail -1 | \
+    python3 bench.py --no-cpu-baseline --no-secondary --steps 20 ${BENCH_ARGS:-} 2>/dev/null | tail -1 | \
       python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['kernel_ms'], round(d['value']), d.get('verified_vs_oracle'))"
   done
 done

@@ -366,6 +366,8 @@ struct nrphy_ofdm_plan {
   std::mutex          window_mutex;           // guards the map (the host-span entry points already hold ctx->host_mutex)
   std::vector<hipEvent_t> events; // 2 per recorded run
   uint32_t            timed_runs = 0, max_timed_runs = 0;
+  uint4*              d_wire_partials = nullptr; // wire-format runs with measurements: one record per workgroup
+  size_t              wire_partials_cap = 0;     // records
 };
 
 // ================================================================================================================
@@ -2508,6 +2510,7 @@ extern "C" int nrphy_ofdm_plan_destroy(nrphy_ofdm_plan_t* plan)
   (void)hipFree(plan->d_phase_rx);
   (void)hipFree(plan->d_cp);
   (void)hipFree(plan->d_off);
+  (void)hipFree(plan->d_wire_partials);
   for (auto& kv : plan->d_window_phase) {
     (void)hipFree(kv.second);
   }
@@ -2578,8 +2581,31 @@ int ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid, co
     p.wire_gain    = a.gain;
     p.wire_ceiling = a.ceiling;
     p.wire_scale   = wire->ci16_scale;
+    // Largest magnitude whose scaled value stays within int16 (so the saturation is an identity below it).
+    float sat = wire->ci16_scale != 0.f ? 32767.0f / std::fabs(wire->ci16_scale) : INFINITY;
+    while ((double)sat * std::fabs((double)wire->ci16_scale) > 32767.0) {
+      sat = std::nextafterf(sat, 0.f);
+    }
+    // ... squared, and a hair lower: the kernel compares the rounded power re^2 + im^2 of a sample with it
+    const float lim = a.clip ? std::fmin(a.ceiling, sat) : sat;
+    p.wire_limit    = std::isfinite(lim) ? (float)((double)lim * (double)lim * (1.0 - 1e-6)) : lim;
     p.wire_stats   = a.measure ? d_stats : nullptr;
-    if (d_stats != nullptr) {
+    if (p.wire_stats != nullptr) {
+      // One record per workgroup (at most one workgroup per symbol), added up by a second small kernel.  The buffer belongs to
+      // the plan and grows with the largest batch seen (a synchronous reallocation, on growth only): runs of one plan are
+      // ordered, as the conventions in mi355_nrphy.h say.
+      const size_t need = (size_t)nof_grids * plan->nof_ports * plan->nsymb;
+      if (need > plan->wire_partials_cap) {
+        if (plan->d_wire_partials != nullptr) {
+          HIP_TRY(hipFree(plan->d_wire_partials));
+          plan->d_wire_partials   = nullptr;
+          plan->wire_partials_cap = 0;
+        }
+        HIP_TRY(hipMalloc(&plan->d_wire_partials, need * sizeof(uint4)));
+        plan->wire_partials_cap = need;
+      }
+      p.wire_partials = plan->d_wire_partials;
+    } else if (d_stats != nullptr) {
       HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(nrphy_amplitude_stats_t) * (size_t)nof_grids * plan->nof_ports, s));
     }
   }

@@ -367,7 +367,9 @@ struct OfdmLaunch {
   // points at complex int16 samples.
   uint32_t       wire = 0, wire_clip = 0;
   float          wire_gain = 1.f, wire_ceiling = 0.f, wire_scale = 1.f;
+  float          wire_limit = 0.f; // sample powers up to this neither clip nor saturate: min(ceiling, largest x with x * scale <= 32767)^2
   nrphy_amplitude_stats_t* wire_stats = nullptr; // [grid][port], may be null
+  uint4*         wire_partials = nullptr; // [grid][port][workgroup]: {sum power, peak power, clipped, -} of one workgroup
 };
 
 // ---- lower-PHY tail ("next" row: amplitude controller, radio sample format, fronthaul compression) ----------------------

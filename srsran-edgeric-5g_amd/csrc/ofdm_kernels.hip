@@ -543,82 +543,145 @@ struct IqSink {
 // (value * scale, round to nearest even, saturate: R/lib/srsvec/conversion.cpp:29-65) -- and 4 bytes instead of 8 go to
 // HBM.  The controller's measurements (sum and maximum of |x|^2 after the gain, clipped parts) accumulate per thread;
 // a sample inside the cyclic prefix counts twice, as in the buffer the reference measures.
+// Wave-wide reductions without LDS traffic: butterflies inside a row of 16 lanes by DPP (lane ^ 1, lane ^ 2, mirrored halves,
+// mirrored row), then the four row results through scalar registers.  Every lane returns the result.
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_reduce_bits(uint32_t v, Op op)
+{
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));  // quad_perm [1, 0, 3, 2]
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));  // quad_perm [2, 3, 0, 1]
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true)); // row_half_mirror
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true)); // row_mirror
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+  return __uint_as_float(wave_reduce_bits(__float_as_uint(v), [](uint32_t a, uint32_t b) { return __float_as_uint(__uint_as_float(a) + __uint_as_float(b)); }));
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+  return __uint_as_float(wave_reduce_bits(__float_as_uint(v), [](uint32_t a, uint32_t b) { return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b))); }));
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+  return wave_reduce_bits(v, [](uint32_t a, uint32_t b) { return a + b; });
+}
+
+#ifndef NRPHY_WIRE_EXP
+#define NRPHY_WIRE_EXP 0 // profiling experiments (profiles/make_variant.sh): 1 = no power measurements, 2 = no exact path, 3 = no atomics
+#endif
 template <int N>
 struct IqSinkCi16 {
   __amdgpu_buffer_rsrc_t rsrc;
   cf                     ph;
   uint32_t               cp;
-  float                  gain, ceiling, scale;
-  bool                   clip;
+  float                  gain, ceiling, scale, limit_sq;
   float*                 sum;
   float*                 peak;
   uint32_t*              clipped;
 
-  __device__ __forceinline__ uint32_t convert(cf v, uint32_t idx) const
+  // A sample through the amplitude controller and the int16 conversion, in three pieces.  PREFIX: the index may lie in the
+  // part of the symbol that is also written as the cyclic prefix (those samples count twice in the measurements).
+  //   measure: phase x scale, gain, power sum and peak (per lane).
+  //   pack_exact: clipping with its count, then round-to-nearest-even of v * scale saturated to int16 (the reference's
+  //     vector path) as a clamp to [-32768, 32767] followed by the addition of 1.5 * 2^23, whose low 16 result bits are the
+  //     rounded integer.
+  //   pack_plain: the same when no sample of the wave has a power above `limit_sq` = min(ceiling, largest magnitude that
+  //     cannot saturate)^2, so that no component reaches the limit: both clamps are identities and nothing is counted.
+  template <bool PREFIX>
+  __device__ __forceinline__ cf measure(cf v, uint32_t idx, float& reach) const
   {
-    const cf       y  = cmul_uniform(v, ph);
-    float          re = __fmul_rn(y.x, gain), im = __fmul_rn(y.y, gain);
-    const uint32_t copies = idx >= N - cp ? 2u : 1u;
-    const float    pw = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
-    *sum += copies == 2u ? pw + pw : pw;
-    *peak = fmaxf(*peak, pw);
-    if (clip) {
-      uint32_t c = 0;
-      if (re > ceiling) {
-        re = ceiling, ++c;
-      } else if (re < -ceiling) {
-        re = -ceiling, ++c;
-      }
-      if (im > ceiling) {
-        im = ceiling, ++c;
-      } else if (im < -ceiling) {
-        im = -ceiling, ++c;
-      }
-      *clipped += c * copies;
+#pragma clang fp contract(off) // every product is rounded on its own, as the reference's separate steps are
+    const cf    g  = cmul_uniform(v, ph) * gain; // packed: (re, im) x gain
+#if NRPHY_WIRE_EXP != 1
+    const cf    sq = g * g;
+    const float pw = sq.x + sq.y;
+    *sum += pw;
+    reach = __builtin_fmaxf(reach, pw);
+    if constexpr (PREFIX) {
+      *sum += idx >= N - cp ? pw : 0.f;
     }
-    int a = __float2int_rn(__fmul_rn(re, scale)), b = __float2int_rn(__fmul_rn(im, scale));
-    a     = a > 32767 ? 32767 : (a < -32768 ? -32768 : a);
-    b     = b > 32767 ? 32767 : (b < -32768 ? -32768 : b);
-    return ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16);
+#endif
+    return g;
   }
 
-  __device__ __forceinline__ void prefix_copy(uint32_t i, uint32_t d) const
+  static constexpr float MAGIC = 12582912.f;
+
+  template <bool PREFIX>
+  __device__ __forceinline__ uint32_t pack_exact(cf g, uint32_t idx) const
   {
-    if (i >= N - cp) {
-      __builtin_amdgcn_raw_buffer_store_b32(d, rsrc, (int)((i - (N - cp)) * 4u), 0, AUX_NT);
+#pragma clang fp contract(off)
+    const cf cl = make_cf(__builtin_amdgcn_fmed3f(g.x, -ceiling, ceiling), __builtin_amdgcn_fmed3f(g.y, -ceiling, ceiling));
+    uint32_t c  = (g.x != cl.x ? 1u : 0u) + (g.y != cl.y ? 1u : 0u);
+    if constexpr (PREFIX) {
+      c = idx >= N - cp ? 2u * c : c;
     }
+    *clipped += c;
+    const cf sc = cl * scale;
+    const cf r  = make_cf(__builtin_amdgcn_fmed3f(sc.x, -32768.f, 32767.f), __builtin_amdgcn_fmed3f(sc.y, -32768.f, 32767.f)) + MAGIC;
+    return __builtin_amdgcn_perm(__float_as_uint(r.y), __float_as_uint(r.x), 0x05040100u);
+  }
+
+  __device__ __forceinline__ uint32_t pack_plain(cf g) const
+  {
+#pragma clang fp contract(off)
+    const cf r = g * scale + MAGIC;
+    return __builtin_amdgcn_perm(__float_as_uint(r.y), __float_as_uint(r.x), 0x05040100u);
   }
 
   template <uint32_t B, uint32_t S>
   __device__ __forceinline__ void operator()(uint32_t q, Const<B>, Const<S>, cf v) const
   {
-    const uint32_t d = convert(v, q + B);
+    constexpr bool PREFIX = B + S > N - N / 4;
+    float          reach  = 0.f;
+    const uint32_t d      = pack_exact<PREFIX>(measure<PREFIX>(v, q + B, reach), q + B);
+    *peak                 = fmaxf(*peak, reach);
     __builtin_amdgcn_raw_buffer_store_b32(d, rsrc, (int)(q * 4u), (int)((cp + B) * 4u), AUX_NT);
-    if constexpr (B + S > N - N / 4) {
-      prefix_copy(q + B, d);
+    if constexpr (PREFIX) {
+      if (q + B >= N - cp) {
+        __builtin_amdgcn_raw_buffer_store_b32(d, rsrc, (int)((q + B - (N - cp)) * 4u), 0, AUX_NT);
+      }
     }
   }
 
+  // The thread's R outputs idx = q + S j: measured, packed (the plain way unless some lane of the wave has a sample above the
+  // limit), and stored one 4-byte sample per lane: a wave instruction writes 256 contiguous bytes.  (Swapping halves between
+  // lane pairs for 8-byte stores costs more vector instructions than the wider stores save: the kernel is bound by its
+  // instruction stream, not by the stores -- profiles/r02_ofdm_wire_probes.txt.)
   template <uint32_t S, int R>
   __device__ __forceinline__ void operator()(uint32_t q, Const<S>, cf (&a)[R]) const
   {
-    const bool     odd  = (q & 1u) != 0;
-    const uint32_t voff = ((q & ~1u) + (odd ? S : 0u)) * 4u;
-    static_for<R / 2>([&](auto I) {
-      constexpr uint32_t j0   = 2 * decltype(I)::value;
-      const cf           keep = odd ? a[j0 + 1] : a[j0];
-      const cf           recv = from_neighbour(odd ? a[j0] : a[j0 + 1]);
-      const uint32_t     i    = (q & ~1u) + S * (odd ? j0 + 1 : j0);
-      const u32x2_t      d    = {convert(odd ? recv : keep, i), convert(odd ? keep : recv, i + 1u)};
-      __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, (int)voff, (int)((cp + S * j0) * 4u), AUX_NT);
-      if constexpr (S * (j0 + 2) > N - N / 4) {
-        prefix_copy(i, d.x);
-        prefix_copy(i + 1u, d.y);
+    float reach = 0.f;
+    cf    g[R];
+    static_for<R>([&](auto J) {
+      constexpr uint32_t j = decltype(J)::value;
+      g[j]                 = measure<(S * (j + 1) > N - N / 4)>(a[j], q + S * j, reach);
+    });
+    *peak = fmaxf(*peak, reach);
+    uint32_t w[R];
+#if NRPHY_WIRE_EXP == 2
+    if (false) {
+#else
+    if (__builtin_expect(__ballot(reach > limit_sq) != 0, 0)) {
+#endif
+      static_for<R>([&](auto J) {
+        constexpr uint32_t j = decltype(J)::value;
+        w[j]                 = pack_exact<(S * (j + 1) > N - N / 4)>(g[j], q + S * j);
+      });
+    } else {
+      static_for<R>([&](auto J) { w[decltype(J)::value] = pack_plain(g[decltype(J)::value]); });
+    }
+    static_for<R>([&](auto J) {
+      constexpr uint32_t j = decltype(J)::value;
+      __builtin_amdgcn_raw_buffer_store_b32(w[j], rsrc, (int)(q * 4u), (int)((cp + S * j) * 4u), AUX_NT);
+      if constexpr (S * (j + 1) > N - N / 4) {
+        if (q + S * j >= N - cp) {
+          __builtin_amdgcn_raw_buffer_store_b32(w[j], rsrc, (int)((q + S * j - (N - cp)) * 4u), 0, AUX_NT);
+        }
       }
     });
-    if constexpr (R % 2 != 0) {
-      (*this)(q, Const<S * (R - 1)>{}, Const<S>{}, a[R - 1]);
-    }
   }
 };
 
@@ -640,8 +703,13 @@ __device__ __forceinline__ void load_symbol_row(uint32_t (&raw)[Plan<N>::R0], co
   }
 }
 
+#ifdef NRPHY_OFDM_WAVES // profiling experiment: register budget for this many waves per SIMD
+#define OFDM_OCCUPANCY __attribute__((amdgpu_waves_per_eu(NRPHY_OFDM_WAVES, NRPHY_OFDM_WAVES)))
+#else
+#define OFDM_OCCUPANCY
+#endif
 template <int N, int SPW, bool WIRE>
-__global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_grid,
+__global__ __launch_bounds__(Plan<N>::T) OFDM_OCCUPANCY void ofdm_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_grid,
                                                           const uint32_t* __restrict__ d_slot_index,
                                                           float2* __restrict__ d_iq)
 {
@@ -679,8 +747,11 @@ __global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const ui
     if constexpr (WIRE) {
       // complex int16 out: [grid][port][slot_stride] samples of 4 bytes
       uint32_t* iq16 = reinterpret_cast<uint32_t*>(d_iq) + (size_t)gp * p.slot_stride + to_constant(p.sym_offset)[sym];
-      const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(iq16, 0, (int)((N + cp) * 4u), 0x00020000);
-      const IqSinkCi16<N> store = {rsrc_out, ph, cp, p.wire_gain, p.wire_ceiling, p.wire_scale, p.wire_clip != 0, &w_sum, &w_peak, &w_clipped};
+      const __amdgpu_buffer_rsrc_t rsrc_out =
+          __builtin_amdgcn_make_buffer_rsrc(iq16, 0, (int)((p.probe & 1u) ? 0u : (N + cp) * 4u), 0x00020000);
+      // no clipping = a ceiling nothing exceeds
+      const IqSinkCi16<N> store = {rsrc_out, ph, cp, p.wire_gain, p.wire_clip != 0 ? p.wire_ceiling : __builtin_inff(), p.wire_scale,
+                                   p.wire_limit, &w_sum, &w_peak, &w_clipped};
       fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
     } else {
       const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
@@ -690,24 +761,59 @@ __global__ __launch_bounds__(Plan<N>::T) void ofdm_kernel(OfdmLaunch p, const ui
     }
   }
   if constexpr (WIRE) {
-    if (p.wire_stats != nullptr) { // wave-uniform
-      for (int o = WAVE / 2; o != 0; o >>= 1) {
-        w_sum += __shfl_xor(w_sum, o, WAVE);
-        w_peak = fmaxf(w_peak, __shfl_xor(w_peak, o, WAVE));
-        w_clipped += __shfl_xor(w_clipped, o, WAVE);
-      }
+    // The workgroup's measurements go to its own record (lane 0 of each wave through LDS, then one 16-byte store): atomics
+    // on the [grid][port] record from every wave cost 0.13 ms per 1024 slots; wire_stats_kernel adds the records up, in a
+    // fixed order.
+    if (p.wire_stats != nullptr && NRPHY_WIRE_EXP != 3) { // wave-uniform
+      w_sum     = wave_sum(w_sum);
+      w_peak    = wave_max(w_peak);
+      w_clipped = wave_sum(w_clipped);
+      constexpr uint32_t NW  = Plan<N>::T / WAVE;
+      uint32_t*          red = reinterpret_cast<uint32_t*>(lds);
+      __syncthreads(); // the last symbol's butterflies are done with the LDS
       if ((tid & (WAVE - 1)) == 0) {
-        nrphy_amplitude_stats_t* st = p.wire_stats + gp;
-        atomicAdd(&st->sum_power, w_sum);
-        atomicMax(reinterpret_cast<uint32_t*>(&st->peak_power), __float_as_uint(w_peak));
-        atomicAdd(&st->nof_clipped, w_clipped);
-        if (tid == 0 && blockIdx.x == 0) {
-          const uint32_t last = slot * p.nsymb + p.nsymb - 1u;
-          st->nof_samples     = to_constant(p.sym_offset)[last] + to_constant(p.cp_len)[last] + N;
+        red[3 * (tid / WAVE) + 0] = __float_as_uint(w_sum);
+        red[3 * (tid / WAVE) + 1] = __float_as_uint(w_peak);
+        red[3 * (tid / WAVE) + 2] = w_clipped;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float    sum = 0.f, peak = 0.f;
+        uint32_t clipped = 0;
+        for (uint32_t w = 0; w != NW; ++w) {
+          sum += __uint_as_float(red[3 * w]);
+          peak = fmaxf(peak, __uint_as_float(red[3 * w + 1]));
+          clipped += red[3 * w + 2];
         }
+        p.wire_partials[(size_t)gp * gridDim.x + blockIdx.x] = make_uint4(__float_as_uint(sum), __float_as_uint(peak), clipped, 0u);
       }
     }
   }
+}
+
+// Adds the per-workgroup records of ofdm_kernel<.., WIRE> up into the caller's [grid][port] measurements.
+__global__ void wire_stats_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_slot_index, uint32_t nof_gp, uint32_t per_gp)
+{
+  const uint32_t gp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gp >= nof_gp) {
+    return;
+  }
+  float    sum = 0.f, peak = 0.f;
+  uint32_t clipped = 0;
+  for (uint32_t i = 0; i != per_gp; ++i) {
+    const uint4 r = p.wire_partials[(size_t)gp * per_gp + i];
+    sum += __uint_as_float(r.x);
+    peak = fmaxf(peak, __uint_as_float(r.y));
+    clipped += r.z;
+  }
+  const uint32_t slot = d_slot_index ? d_slot_index[gp / p.nof_ports] : 0u;
+  const uint32_t last = slot * p.nsymb + p.nsymb - 1u;
+  nrphy_amplitude_stats_t st;
+  st.sum_power     = sum;
+  st.peak_power    = peak;
+  st.nof_clipped   = clipped;
+  st.nof_samples   = p.sym_offset[last] + p.cp_len[last] + p.dft_size;
+  p.wire_stats[gp] = st;
 }
 
 // Symbols per workgroup.  Measured at 1024 slots: 1 -> 0.512 ms, 7 (with the register prefetch) -> 0.519 ms; the
@@ -726,6 +832,11 @@ static hipError_t launch_ofdm_n(const OfdmLaunch& p, uint32_t nof_grids, const u
   if (p.wire) {
     hipLaunchKernelGGL((ofdm_kernel<N, SPW, true>), dim3((p.nsymb + SPW - 1) / SPW, p.nof_ports, nof_grids), dim3(Plan<N>::T), 0,
                        stream, p, d_grid, d_slot_index, d_iq);
+    if (p.wire_stats != nullptr) {
+      const uint32_t nof_gp = nof_grids * p.nof_ports;
+      hipLaunchKernelGGL(wire_stats_kernel, dim3((nof_gp + 255) / 256), dim3(256), 0, stream, p, d_slot_index, nof_gp,
+                         (p.nsymb + SPW - 1) / SPW);
+    }
   } else {
     hipLaunchKernelGGL((ofdm_kernel<N, SPW, false>), dim3((p.nsymb + SPW - 1) / SPW, p.nof_ports, nof_grids), dim3(Plan<N>::T), 0,
                        stream, p, d_grid, d_slot_index, d_iq);

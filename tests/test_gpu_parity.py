@@ -1379,13 +1379,19 @@ def test_ofdm_modulator_wire_format_output(gpu_ctx, oracle):
     device steps bit for bit, the oracle's chain to one LSB (its FFT differs by 1e-7), and the measurements agree."""
     import torch
     rng = np.random.default_rng(85)
-    for (mu, bw, n, ext, ports, slots) in ((1, 273, 4096, 0, 2, 3), (0, 52, 1024, 0, 1, 2), (2, 24, 512, 1, 1, 2), (0, 270, 6144, 0, 1, 1)):
+    # amplitude settings: clipping everywhere (every wave takes the exact path), nowhere (no wave does: gain -20 dB under a
+    # -1 dBFS ceiling), in some waves only (ceiling at about 3.5 sigma), and clipping disabled with saturating conversions
+    amps = (abi.AmplitudeCfg(0, 1, -2.0, 1.0, -9.0), abi.AmplitudeCfg(0, 1, -20.0, 1.0, -1.0),
+            abi.AmplitudeCfg(0, 1, -10.0, 1.0, -6.0), abi.AmplitudeCfg(0, 0, 6.0, 1.0, -1.0))
+    for k, (mu, bw, n, ext, ports, slots) in enumerate(((1, 273, 4096, 0, 2, 3), (1, 273, 4096, 0, 1, 1), (1, 273, 4096, 0, 1, 2),
+                                                        (1, 273, 4096, 0, 1, 1), (0, 52, 1024, 0, 1, 2), (2, 24, 512, 1, 1, 2),
+                                                        (0, 270, 6144, 0, 1, 1), (0, 52, 1024, 0, 1, 2))):
         ocfg = abi.OfdmConfig(mu, bw, n, ext, 1.0 / np.sqrt(n), 3.5e9)
         grid = ((rng.standard_normal((slots, ports, 14, bw * 12, 2)) * 0.5).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
         plan = lib.OfdmPlan(gpu_ctx, ocfg, ports)
         d_grid = dev(grid.view(np.uint32).reshape(slots, ports, 14, bw * 12).view(np.int32))
         d_slot = dev(np.arange(slots, dtype=np.uint32).view(np.int32) % (1 << mu))
-        wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -2.0, 1.0, -9.0), 32767.0)
+        wire = abi.IqWireCfg(amps[k % len(amps)], 32767.0)
         d_iq16 = torch.zeros((slots, ports, plan.slot_stride, 2), dtype=torch.int16, device="cuda")
         d_stats = torch.zeros((slots * ports, 4), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
