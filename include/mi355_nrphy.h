@@ -18,7 +18,7 @@
  *  - Pointers named d_* are device (HBM) pointers valid on the context's device; `stream` is a
  *    hipStream_t passed as void* (NULL = the context's own stream).  Calls that take a stream are
  *    asynchronous with respect to the host.  The plan-based calls (nrphy_pdsch_run, nrphy_ofdm_run,
- *    nrphy_ofdm_demod_run, nrphy_llr_descramble, nrphy_dft_run) neither allocate nor touch host memory and can be
+ *    nrphy_ofdm_demod_run, nrphy_demodulate_soft, nrphy_llr_descramble, nrphy_dft_run) neither allocate nor touch host memory and can be
  *    captured in a hipGraph, any number of them in any order; the others say what they do at the call.
  *  - A PDSCH plan owns device scratch that every run rewrites before reading it (sequences, CRC shares): runs of
  *    ONE plan must be ordered (one stream, or events between streams); different plans may run concurrently.
@@ -316,6 +316,32 @@ int nrphy_llr_descramble(nrphy_ctx_t* ctx, uint32_t n_cw, const uint32_t* d_c_in
                          size_t in_stride, int8_t* d_out, size_t out_stride, void* stream);
 /* One codeword from and to host memory (blocking; for tests and small cases). */
 int nrphy_llr_descramble_host(nrphy_ctx_t* ctx, uint32_t c_init, uint32_t length, const int8_t* in, int8_t* out);
+
+/* ---- receive side ("next" row): soft demodulator ("demodulation mapper") -------------------
+ * Replaces demodulation_mapper::demodulate_soft (R/include/srsran/phy/upper/channel_modulation/demodulation_mapper.h:
+ * 38-62; R/lib/phy/upper/channel_modulation/demodulation_mapper_impl.cpp:33-106 and demodulation_mapper_{qpsk,qam16,
+ * qam64,qam256}.cpp): equalised symbols and their noise variances -> 8-bit log-likelihood ratios in [-120, 120],
+ * bits-per-symbol values per symbol in the bit order of TS 38.211 Section 5.1.
+ * The reference's value depends on the symbol's position in the span it is handed: with AVX2 (the build this library is
+ * pinned to) the first floor(n / B) * B symbols (B = 16 QPSK, 8 16-QAM, 16 64-QAM, 4 256-QAM; none for the BPSKs) use
+ * 1 / noise_var (0 when the variance is not > 0), floor(v * (1 / width)) for the interval, round-to-nearest-even and
+ * blank a COMPONENT with |v| <= 1e-9; the remaining symbols divide by the variance (QPSK, 16-QAM), use floor(v / width),
+ * round half away from zero and blank a SYMBOL with |z|^2 < 1e-9.  This call reproduces both, per position, bit for bit;
+ * so one call must cover exactly one reference call: nof_spans spans of span_len symbols each, span r at
+ * d_symbols + 2 * r * span_len floats (real, imaginary), d_noise_vars + r * span_len, d_llr + r * span_len * Qm.
+ * A variance that is zero, negative or NaN gives zeros (as in the reference).  Asynchronous on `stream`; no host memory is
+ * touched, so the call can be captured in a hipGraph. */
+#define NRPHY_MOD_PI2_BPSK 0u
+#define NRPHY_MOD_BPSK 1u
+#define NRPHY_MOD_QPSK 2u
+#define NRPHY_MOD_QAM16 4u
+#define NRPHY_MOD_QAM64 6u
+#define NRPHY_MOD_QAM256 8u
+int nrphy_demodulate_soft(nrphy_ctx_t* ctx, uint32_t modulation, uint32_t nof_spans, uint32_t span_len, const float* d_symbols,
+                          const float* d_noise_vars, int8_t* d_llr, void* stream);
+/* One span from and to host memory (blocking; for the adaptor, tests and small cases). */
+int nrphy_demodulate_soft_host(nrphy_ctx_t* ctx, uint32_t modulation, uint32_t nof_symbols, const float* symbols,
+                               const float* noise_vars, int8_t* llr);
 
 /* ---- other downlink grid writers ("next" row): NZP-CSI-RS generator -----------
  * Replaces nzp_csi_rs_generator::map (R/include/srsran/phy/upper/signal_processors/nzp_csi_rs_generator.h:

@@ -42,6 +42,9 @@ int oracle_pdsch_encode(const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb, uint8_t
 int oracle_pdsch_process(const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb, uint16_t* grid, uint32_t nof_ports,
                          uint32_t nof_subc, uint8_t* cw_rm, uint8_t* cw_scrambled);
 int      oracle_dft(uint32_t n, int inverse, const float* in, float* out);
+/* demodulation_mapper::demodulate_soft (nrphy_oracle_rx.c); modulation = NRPHY_MOD_*. */
+int  oracle_demodulate_soft(uint32_t modulation, size_t n, const float* symbols, const float* noise_vars, int8_t* llr);
+void oracle_demod_tables(unsigned qm, unsigned pair, float* width, unsigned* n, float* slope, float* intercept);
 /* LDPC decoder ("next" row, receive side): returns the iteration count (>= 1) when the CRC passed, 0 otherwise. */
 int oracle_ldpc_decode(uint32_t bg, uint32_t zc, uint32_t nof_filler, uint32_t crc_poly_id, uint32_t max_iterations,
                        float scaling_factor, const int8_t* llr, uint32_t nof_llr, uint8_t* message_bits);

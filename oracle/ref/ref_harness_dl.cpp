@@ -363,3 +363,39 @@ int ref_ofh_compress(int type, int simd, unsigned data_width, float iq_scaling, 
 }
 
 } // extern "C"
+
+// demodulation_mapper_impl::demodulate_soft (AVX2 + generic paths as compiled here).  modulation = NRPHY_MOD_*.
+#include "lib/phy/upper/channel_modulation/demodulation_mapper_impl.h"
+extern "C" int ref_demodulate_soft(uint32_t modulation, size_t n, const float* symbols, const float* noise_vars, int8_t* llr)
+{
+  using namespace srsran;
+  modulation_scheme mod;
+  switch (modulation) {
+    case 0:
+      mod = modulation_scheme::PI_2_BPSK;
+      break;
+    case 1:
+      mod = modulation_scheme::BPSK;
+      break;
+    case 2:
+      mod = modulation_scheme::QPSK;
+      break;
+    case 4:
+      mod = modulation_scheme::QAM16;
+      break;
+    case 6:
+      mod = modulation_scheme::QAM64;
+      break;
+    case 8:
+      mod = modulation_scheme::QAM256;
+      break;
+    default:
+      return NRPHY_ERR_ARGUMENT;
+  }
+  demodulation_mapper_impl mapper;
+  mapper.demodulate_soft(span<log_likelihood_ratio>(reinterpret_cast<log_likelihood_ratio*>(llr), n * get_bits_per_symbol(mod)),
+                         span<const cf_t>(reinterpret_cast<const cf_t*>(symbols), n),
+                         span<const float>(noise_vars, n),
+                         mod);
+  return NRPHY_OK;
+}

@@ -230,6 +230,10 @@ def make_ssb(*, pattern_case, ssb_idx, L_max, phys_cell_id, payload, sfn=0, nume
     return p
 
 
+# NRPHY_MOD_*: bits per symbol, 0 for pi/2-BPSK
+MOD_PI2_BPSK, MOD_BPSK, MOD_QPSK, MOD_QAM16, MOD_QAM64, MOD_QAM256 = 0, 1, 2, 4, 6, 8
+
+
 class AmplitudeCfg(C.Structure):
     """nrphy_amplitude_cfg_t (the constructor arguments of amplitude_controller_{clipping,scaling}_impl)."""
     _fields_ = [("kind", C.c_uint32), ("enable_clipping", C.c_uint32), ("input_gain_dB", C.c_float),
@@ -407,6 +411,8 @@ def declare(lib, prefix="nrphy_"):
     sig("ldpc_rate_dematch_host", i32, vp, P(LdpcRateDematcherCfg), vp, vp, i32)
     sig("llr_descramble", i32, vp, u32, vp, u32, vp, C.c_size_t, vp, C.c_size_t, vp)
     sig("llr_descramble_host", i32, vp, u32, u32, vp, vp)
+    sig("demodulate_soft", i32, vp, u32, u32, u32, vp, vp, vp, vp)
+    sig("demodulate_soft_host", i32, vp, u32, u32, vp, vp, vp)
     sig("grid_put", i32, vp, vp, u32, u32, u32, P(GridRe), vp)
     sig("csi_rs_validate", i32, P(CsiRsCfg))
     sig("csi_rs_map", i32, vp, u32, P(CsiRsCfg), P(u32), vp, u32, u32, vp)
@@ -450,7 +456,7 @@ ABI_SYMBOLS = [
     "nrphy_pusch_decode_codeblock_host", "nrphy_pusch_decoder_sizes", "nrphy_pusch_decode_batch",
     "nrphy_ldpc_decoder_scratch_bytes", "nrphy_ldpc_decoder_prepare", "nrphy_pusch_decoder_prepare",
     "nrphy_csi_rs_validate", "nrphy_csi_rs_map", "nrphy_csi_rs_map_host", "nrphy_grid_put",
-    "nrphy_llr_descramble", "nrphy_llr_descramble_host",
+    "nrphy_llr_descramble", "nrphy_llr_descramble_host", "nrphy_demodulate_soft", "nrphy_demodulate_soft_host",
     "nrphy_pdcch_validate", "nrphy_pdcch_process", "nrphy_pdcch_process_host", "nrphy_pdcch_encode_host",
     "nrphy_ssb_validate", "nrphy_ssb_process", "nrphy_ssb_process_host", "nrphy_pbch_encode_host",
     "nrphy_pdsch_async_create", "nrphy_pdsch_async_submit", "nrphy_pdsch_async_wait", "nrphy_pdsch_async_destroy",

@@ -1641,6 +1641,157 @@ extern "C" int nrphy_ldpc_rate_dematch_host(nrphy_ctx_t* ctx, const nrphy_ldpc_r
   return rc;
 }
 
+namespace {
+
+// Label bit k of a Gray-mapped PAM level (TS 38.211 Section 5.1): bit 0 is the sign; bit k >= 1 is set in the outer half of
+// the magnitude's current range, which then folds around its middle.
+unsigned pam_label_bit(int level, unsigned k, unsigned m)
+{
+  if (k == 0) {
+    return level < 0;
+  }
+  int t = std::abs(level), r = 1 << m;
+  for (unsigned j = 1;; ++j) {
+    const unsigned bit = t > r / 2;
+    if (j == k) {
+      return bit;
+    }
+    t = std::abs(t - r / 2);
+    r /= 2;
+  }
+}
+
+// Max-log LLR of bit pair k as a piecewise-linear function on n intervals of width_units / sqrt(norm): in the interval whose
+// nearest points with the bit 0 / 1 are a0 / a1, LLR(v) = 2 (a0 - a1) v + (a1^2 - a0^2).  The values are those of the
+// reference's tables (demodulation_mapper_qam64.cpp:49-92, demodulation_mapper_qam256.cpp:47-160), derived, not copied.
+void demod_interval_table(DemodLaunch& p, unsigned pair, unsigned m, float a, unsigned norm, unsigned width_units, unsigned n)
+{
+  const int M            = 1 << m;
+  p.nof_intervals[pair]  = n;
+  p.width[pair]          = (float)width_units * a;
+  p.rcp_width[pair]      = 1.0F / p.width[pair];
+  for (unsigned j = 0; j != n; ++j) {
+    const double centre = ((double)j - (double)n / 2 + 0.5) * (double)width_units;
+    int          a0 = 0, a1 = 0;
+    double       d0 = 1e30, d1 = 1e30;
+    for (int q = 0; q != M; ++q) {
+      const int    level = 2 * q - (M - 1);
+      const double d     = std::fabs(centre - level);
+      if (pam_label_bit(level, pair, m)) {
+        if (d < d1) {
+          d1 = d, a1 = level;
+        }
+      } else if (d < d0) {
+        d0 = d, a0 = level;
+      }
+    }
+    p.slope[pair][j]     = (float)(2 * (a0 - a1)) * a;
+    p.intercept[pair][j] = (float)(a1 * a1 - a0 * a0) / (float)norm;
+  }
+}
+
+bool demod_launch_params(uint32_t modulation, uint32_t span_len, DemodLaunch& p)
+{
+  std::memset(&p, 0, sizeof(p));
+  p.modulation = modulation;
+  p.span_len   = span_len;
+  uint32_t batch = 0;
+  switch (modulation) {
+    case NRPHY_MOD_PI2_BPSK:
+    case NRPHY_MOD_BPSK:
+      p.range = 24.0F;
+      break;
+    case NRPHY_MOD_QPSK:
+      p.range = 24.0F;
+      batch   = 16;
+      break;
+    case NRPHY_MOD_QAM16:
+      p.range           = 20.0F;
+      batch             = 8;
+      p.qam16_gain      = 4.0F * (1.0F / std::sqrt(10.0F));
+      p.qam16_threshold = 2 * (1.0F / std::sqrt(10.0F));
+      break;
+    case NRPHY_MOD_QAM64: {
+      p.range       = 20.0F;
+      batch         = 16;
+      const float a = 1.0F / std::sqrt(42.0F);
+      demod_interval_table(p, 0, 3, a, 42, 2, 8);
+      demod_interval_table(p, 1, 3, a, 42, 2, 8);
+      demod_interval_table(p, 2, 3, a, 42, 4, 4);
+      break;
+    }
+    case NRPHY_MOD_QAM256: {
+      p.range       = 20.0F;
+      batch         = 4;
+      const float a = 1.0F / std::sqrt(170.0F);
+      demod_interval_table(p, 0, 4, a, 170, 2, 16);
+      demod_interval_table(p, 1, 4, a, 170, 2, 16);
+      demod_interval_table(p, 2, 4, a, 170, 2, 16);
+      demod_interval_table(p, 3, 4, a, 170, 4, 8);
+      break;
+    }
+    default:
+      return false;
+  }
+  p.scale      = 120.0F / p.range;
+  p.nof_vector = batch ? span_len / batch * batch : 0;
+  return true;
+}
+
+} // namespace
+
+extern "C" int nrphy_demodulate_soft(nrphy_ctx_t* ctx, uint32_t modulation, uint32_t nof_spans, uint32_t span_len,
+                                     const float* d_symbols, const float* d_noise_vars, int8_t* d_llr, void* stream)
+{
+  DemodLaunch p;
+  if (ctx == nullptr || !demod_launch_params(modulation, span_len, p) || nof_spans > 65535U) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (nof_spans == 0 || span_len == 0) {
+    return NRPHY_OK;
+  }
+  if (d_symbols == nullptr || d_noise_vars == nullptr || d_llr == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(launch_demodulate_soft(p, nof_spans, d_symbols, d_noise_vars, d_llr, stream ? (hipStream_t)stream : ctx->stream));
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_demodulate_soft_host(nrphy_ctx_t* ctx, uint32_t modulation, uint32_t nof_symbols, const float* symbols,
+                                          const float* noise_vars, int8_t* llr)
+{
+  DemodLaunch p;
+  if (ctx == nullptr || !demod_launch_params(modulation, nof_symbols, p)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (nof_symbols == 0) {
+    return NRPHY_OK;
+  }
+  if (symbols == nullptr || noise_vars == nullptr || llr == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const uint32_t              qm = modulation == NRPHY_MOD_PI2_BPSK ? 1U : modulation;
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
+  HIP_TRY(hipSetDevice(ctx->device));
+  StreamStaging sym(ctx->stream), nv(ctx->stream), out(ctx->stream);
+  float*  d_sym = (float*)sym.alloc((size_t)nof_symbols * 8);
+  float*  d_nv  = (float*)nv.alloc((size_t)nof_symbols * 4);
+  int8_t* d_out = (int8_t*)out.alloc((size_t)nof_symbols * qm + 16);
+  if (d_sym == nullptr || d_nv == nullptr || d_out == nullptr) {
+    return NRPHY_ERR_DEVICE;
+  }
+  HIP_TRY(hipMemcpyAsync(d_sym, symbols, (size_t)nof_symbols * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_nv, noise_vars, (size_t)nof_symbols * 4, hipMemcpyHostToDevice, ctx->stream));
+  const int rc = nrphy_demodulate_soft(ctx, modulation, 1, nof_symbols, d_sym, d_nv, d_out, ctx->stream);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(llr, d_out, (size_t)nof_symbols * qm, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return NRPHY_OK;
+}
+
 extern "C" int nrphy_llr_descramble(nrphy_ctx_t* ctx, uint32_t n_cw, const uint32_t* d_c_init, uint32_t length,
                                     const int8_t* d_in, size_t in_stride, int8_t* d_out, size_t out_stride, void* stream)
 {

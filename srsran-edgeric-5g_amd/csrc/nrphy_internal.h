@@ -303,6 +303,20 @@ hipError_t launch_csi_rs(const CsiRsLaunch& p, uint32_t n_work, hipStream_t stre
 hipError_t launch_llr_descramble(const GoldTables* gold, const uint32_t* x1_words, const uint32_t* d_c_init, uint32_t n_cw,
                                  uint32_t length, const int8_t* d_in, size_t in_stride, int8_t* d_out, size_t out_stride,
                                  hipStream_t stream);
+// ---- soft demodulator ("next" row, receive side) ---------------------------------------------------------------------
+constexpr uint32_t DEMOD_MAX_PAIRS = 4;
+struct DemodLaunch {
+  uint32_t modulation; // NRPHY_MOD_*
+  uint32_t span_len;   // symbols per span
+  uint32_t nof_vector; // leading symbols of a span that take the reference's vector arithmetic
+  float    range, scale; // quantisation range limit and 120 / range
+  float    qam16_gain, qam16_threshold; // 4 / sqrt(10), 2 / sqrt(10)
+  uint32_t nof_intervals[DEMOD_MAX_PAIRS];
+  float    width[DEMOD_MAX_PAIRS], rcp_width[DEMOD_MAX_PAIRS];
+  float    slope[DEMOD_MAX_PAIRS][16], intercept[DEMOD_MAX_PAIRS][16];
+};
+hipError_t launch_demodulate_soft(const DemodLaunch& p, uint32_t nof_spans, const float* d_symbols, const float* d_noise,
+                                  int8_t* d_llr, hipStream_t stream);
 hipError_t launch_grid_put(const uint32_t* d_index, const uint32_t* d_value, uint32_t n, uint32_t* d_grid, hipStream_t stream);
 
 // ---- PDCCH and SS/PBCH block ("next" row: other downlink grid writers) --------------------------------------------------

@@ -153,6 +153,21 @@ class Context:
                "nrphy_llr_descramble_host")
         return out
 
+    def demodulate_soft(self, modulation, nof_spans, span_len, d_symbols, d_noise_vars, d_llr, stream=None):
+        """demodulation_mapper::demodulate_soft for nof_spans spans of span_len symbols in device memory."""
+        _check(self.lib.nrphy_demodulate_soft(self.handle, modulation, nof_spans, span_len, _dptr(d_symbols), _dptr(d_noise_vars),
+                                              _dptr(d_llr), stream), "nrphy_demodulate_soft")
+
+    def demodulate_soft_host(self, modulation, symbols, noise_vars):
+        """One span from host memory: symbols complex64 [n], noise_vars float32 [n] -> int8 [n * bits per symbol]."""
+        symbols = np.ascontiguousarray(symbols, dtype=np.complex64)
+        noise_vars = np.ascontiguousarray(noise_vars, dtype=np.float32)
+        assert symbols.size == noise_vars.size
+        out = np.zeros(symbols.size * max(modulation, 1), np.int8)
+        _check(self.lib.nrphy_demodulate_soft_host(self.handle, modulation, symbols.size, symbols.ctypes.data,
+                                                   noise_vars.ctypes.data, out.ctypes.data), "nrphy_demodulate_soft_host")
+        return out
+
     def grid_put(self, d_grid, nof_ports, nof_subc, entries, stream=None):
         """Sparse host writes into ONE device grid: entries = [(port, symbol, subc, cbf16 word)], later ones win."""
         n = len(entries)

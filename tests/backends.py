@@ -273,6 +273,17 @@ class CpuBackend:
         f(C.c_uint32(c_init), C.c_uint32(offset), _ptr(llr), _ptr(out), C.c_uint32(llr.size))
         return out
 
+    def demodulate_soft(self, modulation, symbols, noise_vars):
+        """demodulation_mapper::demodulate_soft of one span: complex64 [n], float32 [n] -> int8 [n * bits per symbol]."""
+        symbols = np.ascontiguousarray(symbols, dtype=np.complex64)
+        noise_vars = np.ascontiguousarray(noise_vars, dtype=np.float32)
+        out = np.zeros(symbols.size * max(modulation, 1), np.int8)
+        f = self._f("demodulate_soft")
+        f.argtypes = [C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = f(modulation, symbols.size, symbols.ctypes.data, noise_vars.ctypes.data, out.ctypes.data)
+        assert rc == 0, rc
+        return out
+
     def csi_rs_map(self, cfg, grid, simd=1):
         """nzp_csi_rs_generator::map into a copy of grid [nof_ports][14][nof_subc][2] uint16 (raw cbf16)."""
         out = np.array(grid, dtype=np.uint16, copy=True)

@@ -499,3 +499,21 @@ def ref_test_config_grid(case_row, index):
 
 def ref_test_config_tb(g, key, nbytes):
     return np.random.default_rng([int(x) for x in g[key + "_tb_seed"]]).integers(0, 256, nbytes, dtype=np.uint8)
+
+
+def demod_inputs(rng, modulation, n, kind):
+    """Equalised symbols and noise variances for the soft demodulator.  kind 0: uniform over a little more than the
+    constellation; 1: values on the interval boundaries and decision thresholds (integer multiples of the constellation's unit
+    amplitude), a tenth of them shrunk below the near-zero threshold; 2: like 0 with zero, negative and NaN variances."""
+    amp = {0: 1.0, 1: 1.0, 2: 1.0, 4: 1.2, 6: 1.3, 8: 1.4}[modulation]
+    unit = {0: 1.0, 1: 1.0, 2: 1.0, 4: 1 / np.sqrt(10), 6: 1 / np.sqrt(42), 8: 1 / np.sqrt(170)}[modulation]
+    sym = rng.uniform(-amp, amp, (n, 2)).astype(np.float32)
+    if kind == 1:
+        sym = (rng.integers(-18, 19, (n, 2)) * np.float32(unit)).astype(np.float32)
+        sym[rng.random((n, 2)) < 0.1] *= np.float32(1e-10)
+    noise = rng.uniform(0.001, 2.0, n).astype(np.float32)
+    if kind == 2:
+        noise[rng.random(n) < 0.2] = 0
+        noise[rng.random(n) < 0.1] = -1
+        noise[rng.random(n) < 0.05] = np.nan
+    return sym.view(np.complex64).reshape(n), noise

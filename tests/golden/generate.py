@@ -8,7 +8,8 @@ expected outputs, never reference source) are committed and travel to the GPU bo
 Sections: base (the round-1 files: codebooks, ldpc_encoder, pdsch_processor, ofdm_modulator, ofdm_demodulator),
 ofdm_sizes (DFT sizes 4608 / 6144: ofdm_sizes.npz), dl_control (PDCCH and SS/PBCH block processors: dl_control.npz),
 ref_test_configs (the configurations of the reference's own unit-test vectors, read from its test-data headers by
-oracle/ref/ref_testdata.cpp, with the compiled reference's outputs on seeded payloads: ref_test_configs.npz).
+oracle/ref/ref_testdata.cpp, with the compiled reference's outputs on seeded payloads: ref_test_configs.npz), demod (soft
+demodulator: demod.npz).
 """
 import hashlib
 import os
@@ -29,7 +30,7 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-SECTIONS = sys.argv[1:] or ["base", "ofdm_sizes", "dl_control", "ref_test_configs"]
+SECTIONS = sys.argv[1:] or ["base", "ofdm_sizes", "dl_control", "ref_test_configs", "demod"]
 
 
 def section_ofdm_sizes():
@@ -246,6 +247,24 @@ def section_ref_test_configs():
     print("ref_test_configs:", n_proc, n_enc, n_mod, n_seg, n_ofdm, n_dmrs)
 
 
+def section_demod():
+    """Soft demodulator (demodulation_mapper_impl, AVX2 + generic paths as compiled in oracle/_ref): hashes of the soft bits for
+    seeded inputs (tests/cases.py demod_inputs) at span lengths around the vector batch sizes."""
+    import cases
+    lengths = [1, 3, 4, 7, 8, 15, 16, 17, 31, 33, 100, 1003, 20011]
+    g = {"lengths": np.array(lengths)}
+    for modulation in (0, 1, 2, 4, 6, 8):
+        for kind in (0, 1, 2):
+            shas = []
+            for n in lengths:
+                sym, noise = cases.demod_inputs(np.random.default_rng([modulation, n, kind]), modulation, n, kind)
+                shas.append(sha(r.demodulate_soft(modulation, sym, noise)))
+            g["sha_%d_%d" % (modulation, kind)] = np.array(shas)
+    np.savez_compressed(os.path.join(HERE, "demod.npz"), **g)
+
+
+if "demod" in SECTIONS:
+    section_demod()
 if "ref_test_configs" in SECTIONS:
     section_ref_test_configs()
 if "ofdm_sizes" in SECTIONS:

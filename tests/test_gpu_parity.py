@@ -1766,3 +1766,37 @@ def test_ref_test_configs_dmrs_pdsch(gpu_ctx, ref_cfgs):
         _, grid = device_processor_case(gpu_ctx, g, key, nof_subc)
         written = np.unpackbits(g[key + "_written"])[: pdu.nof_ports * 14 * nof_subc].astype(bool)
         assert sha(grid.view(np.uint32).reshape(-1)[written]) == str(g[key + "_values_sha"]), key
+
+
+# ---- soft demodulator -----------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("modulation", [0, 1, 2, 4, 6, 8])
+def test_demodulate_soft_vs_oracle_and_golden(gpu_ctx, oracle, modulation):
+    """nrphy_demodulate_soft: every soft bit equals the reference's at the same position of the span (vector arithmetic for the
+    leading multiple of the batch, generic for the tail), on boundary / tie / near-zero values and non-positive variances; the
+    hashes are those of the compiled reference."""
+    import torch
+    g = np.load(os.path.join(cases.GOLDEN, "demod.npz"))
+    for k, n in enumerate(g["lengths"].tolist()):
+        for kind in (0, 1, 2):
+            sym, noise = cases.demod_inputs(np.random.default_rng([modulation, n, kind]), modulation, n, kind)
+            got = gpu_ctx.demodulate_soft_host(modulation, sym, noise)
+            want = oracle.demodulate_soft(modulation, sym, noise)
+            assert np.array_equal(got, want), (modulation, n, kind, np.flatnonzero(got != want)[:4])
+            assert sha(got) == str(g["sha_%d_%d" % (modulation, kind)][k])
+    # batched form: spans of odd and even lengths back to back (rows then start at any alignment)
+    rng = np.random.default_rng(77 + modulation)
+    qm = max(modulation, 1)
+    for nof_spans, span_len in ((5, 1003), (3, 64), (7, 1), (2, 4099)):
+        sym, noise = cases.demod_inputs(rng, modulation, nof_spans * span_len, 1)
+        d_llr = torch.zeros(nof_spans * span_len * qm + 32, dtype=torch.int8, device="cuda")
+        gpu_ctx.demodulate_soft(modulation, nof_spans, span_len, dev(sym.view(np.float32)), dev(noise), d_llr)
+        gpu_ctx.synchronize()
+        got = d_llr.cpu().numpy()
+        assert not got[nof_spans * span_len * qm:].any()
+        for r in range(nof_spans):
+            want = oracle.demodulate_soft(modulation, sym[r * span_len:(r + 1) * span_len], noise[r * span_len:(r + 1) * span_len])
+            assert np.array_equal(got[r * span_len * qm:(r + 1) * span_len * qm], want), (modulation, nof_spans, span_len, r)
+    assert gpu_ctx.lib.nrphy_demodulate_soft(gpu_ctx.handle, 3, 1, 16, None, None, None, None) == abi.ERR_ARGUMENT
+    assert gpu_ctx.lib.nrphy_demodulate_soft(gpu_ctx.handle, 8, 1, 16, None, None, None, None) == abi.ERR_ARGUMENT
+    assert gpu_ctx.lib.nrphy_demodulate_soft(gpu_ctx.handle, 8, 0, 16, None, None, None, None) == abi.OK

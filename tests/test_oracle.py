@@ -771,3 +771,59 @@ def test_ref_test_configs_dmrs_pdsch(oracle, ref_cfgs):
     assert int(g["dmrs_count"]) == 192 and int(np.sum(g["dmrs_info"][:, 2])) == 96
     for i in range(192):
         check_dmrs_case(oracle, g, i)
+
+
+# ---- soft demodulator ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("modulation", [0, 1, 2, 4, 6, 8])
+def test_oracle_vs_ref_demodulation_mapper(oracle, ref, modulation):
+    """oracle/nrphy_oracle_rx.c against the compiled demodulation_mapper_impl: every span length around the vector batch sizes
+    (the leading multiple of the batch takes the AVX2 arithmetic, the tail the generic one), values on interval boundaries,
+    rounding ties and near-zero components, and variances that are zero, negative or NaN."""
+    if ref is None:
+        pytest.skip("compiled reference not built")
+    rng = np.random.default_rng(1000 + modulation)
+    for n in list(range(1, 36)) + [100, 1003, 65536 + 5]:
+        for kind in (0, 1, 2):
+            sym, noise = cases.demod_inputs(rng, modulation, n, kind)
+            got, want = oracle.demodulate_soft(modulation, sym, noise), ref.demodulate_soft(modulation, sym, noise)
+            assert np.array_equal(got, want), (modulation, n, kind, np.flatnonzero(got != want)[:4])
+
+
+def test_demodulation_mapper_golden(oracle):
+    g = np.load(os.path.join(cases.GOLDEN, "demod.npz"))
+    for modulation in (0, 1, 2, 4, 6, 8):
+        for k, n in enumerate(g["lengths"].tolist()):
+            for kind in (0, 1, 2):
+                sym, noise = cases.demod_inputs(np.random.default_rng([modulation, n, kind]), modulation, n, kind)
+                assert sha(oracle.demodulate_soft(modulation, sym, noise)) == str(g["sha_%d_%d" % (modulation, kind)][k])
+
+
+def test_demodulation_mapper_tables_are_max_log_llrs(oracle):
+    """The derived interval tables reproduce a brute-force max-log LLR over the constellation (TS 38.211 Section 5.1 mapping via
+    the oracle's modulation mapper), away from rounding: |LLR - (min_{b=1} |v - a|^2 - min_{b=0} |v - a|^2)| small."""
+    import ctypes as C
+    for qm, norm in ((6, 42.0), (8, 170.0)):
+        m = qm // 2
+        # constellation of one dimension: map all bit patterns, keep real parts and the even-position bits
+        pts = {}
+        for word in range(1 << qm):
+            bits = np.array([(word >> (qm - 1 - i)) & 1 for i in range(qm)], np.uint8)
+            out, sc = oracle.modulate(qm, np.packbits(bits), 1)
+            pts[tuple(bits[0::2])] = float(out[0, 0]) * sc
+        a = np.array(list(pts.values()))
+        labels = np.array(list(pts.keys()))
+        assert abs(np.abs(a).max() - ((1 << m) - 1) / np.sqrt(norm)) < 1e-6
+        xs = np.linspace(-1.3, 1.3, 2001)
+        for pair in range(m):
+            width = C.c_float()
+            n = C.c_uint()
+            slope = (C.c_float * 16)()
+            intercept = (C.c_float * 16)()
+            oracle.lib.oracle_demod_tables(qm, pair, C.byref(width), C.byref(n), slope, intercept)
+            idx = np.clip(np.floor(xs / width.value).astype(int) + n.value // 2, 0, n.value - 1)
+            got = np.array(slope[:16])[idx] * xs + np.array(intercept[:16])[idx]
+            d = (xs[:, None] - a[None, :]) ** 2
+            one = labels[:, pair] == 1
+            want = d[:, one].min(axis=1) - d[:, ~one].min(axis=1)
+            assert np.abs(got - want).max() < 1e-5, (qm, pair)
