@@ -145,30 +145,37 @@ __device__ __forceinline__ uint32_t hard_word(const int8_t* soft, uint32_t w, ui
   return word;
 }
 
-// The check records of a codeblock live in a slot of the caller's scratch.  A batch larger than the pool shares it:
-// a workgroup claims a free slot (one bit of a bitmap) when it starts decoding and gives it back when it is done.  The
-// pool holds at least as many slots as workgroups fit the device at once, so a free one always exists and the search
-// ends; should that bound ever be wrong the search gives up after a fixed number of probes and the codeblock is
-// reported as not decoded (never a hang).
-__device__ __forceinline__ uint32_t acquire_slot(uint32_t* bitmap, uint32_t nof_slots, uint32_t seed)
+// The check records of a codeblock live in a slot of the caller's scratch.  A batch larger than the pool shares it: a
+// workgroup claims a free slot (one flag word per slot) when it starts and gives it back when it is done.  Workgroup b first
+// tries slot b mod nof_slots -- free for the workgroups that start a launch, and usually given back by workgroup
+// b - nof_slots by the time b starts -- and walks on from there.  The pool holds at least as many slots as workgroups fit the
+// device at once, so a free one always exists and the search ends; should that bound ever be wrong the search gives up
+// after a fixed number of probes and the codeblock is reported as not decoded (never a hang).
+//
+// Handing a slot from one workgroup to the next needs no cache maintenance: a workgroup never reads a record it has not
+// written itself, every record store is a write-through (agent-scope) store, and the owner waits for its stores to complete
+// before it clears the flag -- so no write of the old owner can land after one of the new owner.  (An agent-scope fence
+// here instead, with plain stores, wrote the L2 back per workgroup and cost 1 ms per 6656 codeblocks.)
+__device__ __forceinline__ uint32_t acquire_slot(uint32_t* flags, uint32_t nof_slots, uint32_t first)
 {
-  const uint32_t nwords = (nof_slots + 31u) >> 5;
-  uint32_t       w      = (seed * 2654435761u) % nwords;
+  uint32_t s = first % nof_slots;
   for (uint32_t probes = 0; probes != (1u << 20); ++probes) {
-    const uint32_t valid = (32u * w + 32u <= nof_slots) ? 0xFFFFFFFFu : ((1u << (nof_slots & 31u)) - 1u);
-    const uint32_t cur   = __hip_atomic_load(&bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t avail = ~cur & valid;
-    if (avail != 0) {
-      const uint32_t bit = 1u << ((uint32_t)__ffs((int)avail) - 1u);
-      if ((atomicOr(&bitmap[w], bit) & bit) == 0) {
-        return 32u * w + (uint32_t)__ffs((int)avail) - 1u;
-      }
-    } else {
-      w = w + 1u == nwords ? 0u : w + 1u;
-      __builtin_amdgcn_s_sleep(4);
+    if (__hip_atomic_load(&flags[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+        __hip_atomic_exchange(&flags[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      return s;
+    }
+    s = s + 1u == nof_slots ? 0u : s + 1u;
+    if ((probes & 63u) == 63u) {
+      __builtin_amdgcn_s_sleep(8);
     }
   }
   return 0xFFFFFFFFu;
+}
+
+__device__ __forceinline__ void store_record(uint2* rec, uint2 v)
+{
+  __hip_atomic_store(reinterpret_cast<uint64_t*>(rec), (uint64_t)v.x | ((uint64_t)v.y << 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void ldpc_decode_kernel(LdpcDecodeLaunch p)
@@ -186,6 +193,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   const int8_t* llr    = p.llr + (size_t)blockIdx.x * p.llr_stride;
   const bool    active = j < zc;
   const bool    pooled = p.nof_slots < gridDim.x; // fewer slots than codeblocks: claim one
+  if (j == 0) { // (read after the barriers below; the claim's latency hides behind the loads)
+    s_flag[3] = pooled ? acquire_slot(p.slot_flags, p.nof_slots, blockIdx.x) : blockIdx.x;
+  }
 
   // load_soft_bits (ldpc_decoder_impl.cpp:128-164): two punctured nodes, then the input.  The last non-zero soft bit
   // decides how many layers take part (:88-116).
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   for (uint32_t m = j; m <= (uint32_t)LLR_MAX_V; m += T) { // a workgroup may be a single wavefront (Zc <= 64)
     s_scaled[m] = (uint8_t)roundf((float)m * p.scaling_factor); // rounded half away from zero
   }
-  if (j < 4) {
+  if (j < 3) {
     s_flag[j] = 0;
   }
   __syncthreads();
@@ -260,10 +270,6 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   const uint32_t jm = j - zc;
 
   if (input_size != 0) { // workgroup-uniform
-    if (j == 0) {
-      s_flag[3] = pooled ? acquire_slot(p.slot_bitmap, p.nof_slots, blockIdx.x) : blockIdx.x;
-    }
-    __syncthreads();
     const uint32_t slot = s_flag[3];
     uint2*         rec  = p.scratch + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * p.nof_layers_max * zc;
     const uint32_t max_iterations = slot == 0xFFFFFFFFu ? 0u : p.max_iterations; // no slot: reported as not decoded
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
             case 10: mine = process_check<10>(soft, s_scaled, edge, zc, j, jm, old); break;
             default: mine = process_check<19>(soft, s_scaled, edge, zc, j, jm, old); break;
           }
-          rec[(size_t)m * zc + j] = mine;
+          store_record(&rec[(size_t)m * zc + j], mine);
         }
         lds_barrier();
       }
@@ -332,13 +338,13 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
         lds_barrier(); // the flags are cleared again at the top of the next check
       }
     }
-    if (pooled && slot != 0xFFFFFFFFu) {
-      // Give the slot back: this workgroup's record stores must have landed before another one's can.
-      __threadfence();
-      __syncthreads();
-      if (j == 0) {
-        atomicAnd(&p.slot_bitmap[slot >> 5], ~(1u << (slot & 31u)));
-      }
+  }
+  if (pooled && s_flag[3] != 0xFFFFFFFFu) { // workgroup-uniform
+    // Give the slot back once every record store of this workgroup has completed (see acquire_slot).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (j == 0) {
+      __hip_atomic_store(&p.slot_flags[s_flag[3]], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   // Hard bits of the message, packed MSB first (all-zero input: soft <= 0 everywhere, every bit one as in

@@ -1922,7 +1922,7 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
 // The caller-owned scratch of a decoder launch: a pool of check-record slots + the bitmap that hands them out.
 struct DecoderScratch {
   uint32_t nof_slots, nof_layers_max;
-  uint64_t records_bytes, bitmap_bytes, total_bytes;
+  uint64_t records_bytes, flags_bytes, total_bytes;
 };
 bool decoder_scratch_layout(const nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t& cfg, uint32_t n_cb, DecoderScratch& s)
 {
@@ -1937,9 +1937,16 @@ bool decoder_scratch_layout(const nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg
   const uint32_t waves    = divide_ceil(zc, 64);
   const uint32_t resident = ctx->nof_cus * (32U / waves) + ctx->nof_cus;
   s.nof_slots             = std::min<uint32_t>(n_cb, resident);
+  {
+    // Profiling aid (profiles/): a slot per codeblock, i.e. no pooling.
+    static const char* all_env = std::getenv("NRPHY_DECODER_SLOTS_ALL");
+    if (all_env != nullptr && all_env[0] == '1') {
+      s.nof_slots = n_cb;
+    }
+  }
   s.records_bytes         = (uint64_t)s.nof_slots * s.nof_layers_max * zc * sizeof(uint2);
-  s.bitmap_bytes          = ((uint64_t)divide_ceil(s.nof_slots, 32) * 4 + 255) & ~(uint64_t)255;
-  s.total_bytes           = ((s.records_bytes + 255) & ~(uint64_t)255) + s.bitmap_bytes;
+  s.flags_bytes           = ((uint64_t)s.nof_slots * 4 + 255) & ~(uint64_t)255;
+  s.total_bytes           = ((s.records_bytes + 255) & ~(uint64_t)255) + s.flags_bytes;
   return true;
 }
 } // namespace
@@ -2050,10 +2057,10 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
   }
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   p.scratch     = (uint2*)d_scratch;
-  p.slot_bitmap = (uint32_t*)((uint8_t*)d_scratch + ((sl.records_bytes + 255) & ~(uint64_t)255));
+  p.slot_flags = (uint32_t*)((uint8_t*)d_scratch + ((sl.records_bytes + 255) & ~(uint64_t)255));
   p.nof_slots   = sl.nof_slots;
   if (sl.nof_slots < n_cb) {
-    HIP_TRY(hipMemsetAsync(p.slot_bitmap, 0, sl.bitmap_bytes, s));
+    HIP_TRY(hipMemsetAsync(p.slot_flags, 0, sl.flags_bytes, s));
   }
   HIP_TRY(launch_ldpc_decode(p, n_cb, s));
   return NRPHY_OK;

@@ -232,7 +232,7 @@ struct LdpcDecodeLaunch {
   const DecoderGraph* graph;
   const int8_t*       llr;        // per codeblock: nof_llr soft bits (the codeblock without its first 2 Zc bits)
   uint2*              scratch;    // check records of 8 bytes: nof_slots slots of nof_layers_max * Zc records
-  uint32_t*           slot_bitmap; // one bit per slot, all clear at launch; unused when every codeblock has a slot of its own
+  uint32_t*           slot_flags;  // one word per slot (0 = free), all clear at launch; unused when every codeblock has a slot of its own
   uint32_t            nof_slots;  // >= the workgroups of this kernel the device can hold at once, <= codeblocks
   uint8_t*            out;        // per codeblock: Kb * Zc hard bits, packed MSB first
   uint32_t*           iterations; // per codeblock: iterations until the CRC passed, 0 = it did not (may be null)
