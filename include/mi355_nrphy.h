@@ -206,6 +206,13 @@ int nrphy_pdsch_plan_kernel_times(nrphy_pdsch_plan_t* plan, float avg_ms[4], uin
 int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb, void* grid,
                              uint32_t grid_nof_ports, uint32_t grid_nof_subc, uint8_t* cw_rm,
                              uint8_t* cw_scrambled);
+/* All PDSCH PDUs of one slot from host spans, blocking: one plan and one launch for the n_pdu transport blocks (tbs[i]:
+ * pdus[i].tb_size_bytes bytes), all mapped into the one host grid, which is read first (what other channels wrote stays)
+ * and written back.  What a FAPI DL_TTI.request carries for a slot (R/lib/fapi_adaptor/phy/fapi_to_phy_translator.cpp:
+ * every dl_pdsch_pdu goes to its own pdsch_processor::process there) in one call; the PDUs' allocations are disjoint, as
+ * the scheduler guarantees.  Statuses as nrphy_pdsch_plan_create. */
+int nrphy_pdsch_process_slot_host(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus, const uint8_t* const* tbs,
+                                  void* grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc);
 
 /* Asynchronous host-span form: pdsch_processor::process "may return before completion, the notifier fires from any
  * thread exactly once" (pdsch_processor.h:157-170; the reference's own asynchronous pool:

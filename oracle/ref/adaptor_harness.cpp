@@ -21,6 +21,8 @@
 #include "lib/ofh/compression/iq_compression_bfp_avx2.h"
 #include "lib/ofh/compression/iq_compression_none_avx2.h"
 #include "lib/phy/lower/amplitude_controller/amplitude_controller_clipping_impl.h"
+#include "lib/phy/upper/channel_modulation/demodulation_mapper_impl.h"
+#include "srsran/fapi_adaptor/phy/messages/pdsch.h"
 #include "srsran/srslog/srslog.h"
 
 #include "../nrphy_oracle.h"
@@ -235,6 +237,33 @@ int nrphy_amplitude_control_host(nrphy_ctx_t*, const nrphy_amplitude_cfg_t* cfg,
 uint32_t nrphy_ofh_compressed_prb_bytes(const nrphy_ofh_compression_cfg_t* cfg)
 {
   return oracle_ofh_compressed_prb_bytes(cfg);
+}
+int nrphy_demodulate_soft_host(nrphy_ctx_t*, uint32_t modulation, uint32_t nof_symbols, const float* symbols, const float* noise_vars,
+                               int8_t* llr)
+{
+  return oracle_demodulate_soft(modulation, nof_symbols, symbols, noise_vars, llr);
+}
+// All PDUs of a slot into one host grid: what the oracle maps for each PDU replaces what the grid held.
+int nrphy_pdsch_process_slot_host(nrphy_ctx_t*, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus, const uint8_t* const* tbs, void* grid,
+                                  uint32_t nof_ports, uint32_t nof_subc)
+{
+  const size_t          words = (size_t)nof_ports * 14 * nof_subc;
+  std::vector<uint32_t> part(words);
+  uint32_t*             out = static_cast<uint32_t*>(grid);
+  const uint32_t        marker = 0x7FC17FC1u; // a NaN pattern no channel produces: tells written from untouched
+  for (uint32_t i = 0; i != n_pdu; ++i) {
+    std::fill(part.begin(), part.end(), marker);
+    int rc = oracle_pdsch_process(&pdus[i], tbs[i], reinterpret_cast<uint16_t*>(part.data()), nof_ports, nof_subc, nullptr, nullptr);
+    if (rc != NRPHY_OK) {
+      return rc;
+    }
+    for (size_t w = 0; w != words; ++w) {
+      if (part[w] != marker) {
+        out[w] = part[w];
+      }
+    }
+  }
+  return NRPHY_OK;
 }
 int nrphy_ofh_compress_host(nrphy_ctx_t*, const nrphy_ofh_compression_cfg_t* cfg, uint32_t nof_prb, const void* prbs, uint8_t* out)
 {
@@ -568,6 +597,125 @@ int adaptor_test_ofh(int type, unsigned data_width, float iq_scaling, const uint
     nr += dr.size();
   }
   return na == nr ? (int)na : -1;
+}
+
+// demodulation_mapper_adaptor against demodulation_mapper_impl.
+int adaptor_test_demod(unsigned modulation, unsigned n, const float* symbols, const float* noise_vars, int8_t* llr_adaptor, int8_t* llr_ref)
+{
+  std::shared_ptr<mi355::context>    ctx = std::make_shared<mi355::context>(0);
+  mi355::demodulation_mapper_adaptor adaptor(ctx);
+  demodulation_mapper_impl           reference;
+  const modulation_scheme mod = modulation == 0 ? modulation_scheme::PI_2_BPSK : static_cast<modulation_scheme>(modulation);
+  const unsigned          qm  = get_bits_per_symbol(mod);
+  span<const cf_t>        sym(reinterpret_cast<const cf_t*>(symbols), n);
+  span<const float>       nv(noise_vars, n);
+  adaptor.demodulate_soft(span<log_likelihood_ratio>(reinterpret_cast<log_likelihood_ratio*>(llr_adaptor), n * qm), sym, nv, mod);
+  reference.demodulate_soft(span<log_likelihood_ratio>(reinterpret_cast<log_likelihood_ratio*>(llr_ref), n * qm), sym, nv, mod);
+  return NRPHY_OK;
+}
+
+// FAPI shim.  n PDSCH PDUs described by rows of 16 numbers {rnti, bwp_start, bwp_size, qm, rv, nid, dmrs mask, scrambling id,
+// nscid, cdm groups without data, rb_start, rb_size, start symbol, nof symbols, power offset profile, layers (pm_index = layers
+// - 1 in a repository of identity matrices)} plus flags {ref point (0 A / 1 subcarrier 0), resource allocation (1 / 0 with a
+// bitmap of the same RBs), trans_type, ss profile, csi pattern (0 none / 1 one CSI-RS-like pattern)}.
+//  (a) fapi_to_pod against convert_pdsch_fapi_to_phy + to_pod: every POD byte and weight equal -> return bit 0 clear;
+//  (b) fapi_pdsch_slot_batch::process against the reference's processor run PDU by PDU into the same grid.
+int adaptor_test_fapi(unsigned n, const int* rows, const uint8_t* const* tbs, const unsigned* tb_sizes, unsigned nof_ports,
+                      unsigned nof_subc, const uint16_t* grid_init, uint16_t* grid_adaptor, uint16_t* grid_ref)
+{
+  using namespace fapi;
+  std::vector<precoding_weight_matrix> mats;
+  for (unsigned l = 1; l <= 4; ++l) {
+    mats.push_back(make_identity(l));
+  }
+  fapi_adaptor::precoding_matrix_repository repo(std::move(mats));
+  re_pattern csi;
+  csi.prb_mask = bounded_bitset<MAX_RB>(nof_subc / 12);
+  csi.prb_mask.fill(0, nof_subc / 12);
+  csi.symbols.set(5);
+  csi.re_mask.set(3);
+  csi.re_mask.set(9);
+  std::vector<re_pattern_list> csi_lists(1);
+  csi_lists[0].merge(csi);
+
+  std::shared_ptr<mi355::context>  ctx = std::make_shared<mi355::context>(0);
+  mi355::fapi_pdsch_slot_batch     batch(ctx, nof_ports, nof_subc);
+  std::unique_ptr<pdsch_processor> reference = ref_make_pdsch_processor(1);
+  std::unique_ptr<resource_grid>   g_ref = make_grid(nof_ports, nof_subc, false), g_ad = make_grid(nof_ports, nof_subc, false);
+  load_grid(*g_ref, grid_init, nof_ports, nof_subc);
+  load_grid(*g_ad, grid_init, nof_ports, nof_subc);
+  int result = 0;
+  const uint16_t sfn = 37, slot = 3;
+  for (unsigned i = 0; i != n; ++i) {
+    const int*  r = rows + 21 * i;
+    dl_pdsch_pdu f = {};
+    f.rnti      = to_rnti(r[0]);
+    f.bwp_start = r[1];
+    f.bwp_size  = r[2];
+    f.scs       = subcarrier_spacing::kHz30;
+    f.cp        = cyclic_prefix::NORMAL;
+    dl_pdsch_codeword cw = {};
+    cw.qam_mod_order = r[3];
+    cw.rv_index      = r[4];
+    f.cws.push_back(cw);
+    f.nid_pdsch                 = r[5];
+    f.dl_dmrs_symb_pos          = r[6];
+    f.pdsch_dmrs_scrambling_id  = r[7];
+    f.dmrs_type                 = dmrs_cfg_type::type_1;
+    f.nscid                     = r[8];
+    f.num_dmrs_cdm_grps_no_data = r[9];
+    f.rb_start                  = r[10];
+    f.rb_size                   = r[11];
+    f.start_symbol_index        = r[12];
+    f.nr_of_symbols             = r[13];
+    f.power_control_offset_profile_nr = r[14];
+    f.num_layers                = r[15];
+    tx_precoding_and_beamforming_pdu::prgs_info prg = {};
+    prg.pm_index                = r[15] - 1;
+    f.precoding_and_beamforming.prgs.push_back(prg);
+    f.ref_point      = r[16] ? pdsch_ref_point_type::subcarrier_0 : pdsch_ref_point_type::point_a;
+    f.resource_alloc = r[17] ? resource_allocation_type::type_1 : resource_allocation_type::type_0;
+    f.rb_bitmap.fill(0);
+    if (!r[17]) {
+      for (int rb = r[10]; rb != r[10] + r[11]; ++rb) {
+        f.rb_bitmap[rb / 8] |= static_cast<uint8_t>(1U << (rb % 8));
+      }
+    }
+    f.vrb_to_prb_mapping                       = vrb_to_prb_mapping_type::non_interleaved;
+    f.pdsch_maintenance_v3.trans_type          = static_cast<pdsch_trans_type>(r[18]);
+    f.pdsch_maintenance_v3.coreset_start_point = r[1];
+    f.pdsch_maintenance_v3.initial_dl_bwp_size = r[2];
+    f.pdsch_maintenance_v3.ldpc_base_graph     = tb_sizes[i] * 8 <= 3824 ? ldpc_base_graph_type::BG2 : ldpc_base_graph_type::BG1;
+    f.pdsch_maintenance_v3.tb_size_lbrm_bytes  = units::bytes(159749);
+    f.power_control_offset_ss_profile_nr       = static_cast<power_control_offset_ss>(r[19]);
+    if (r[20]) {
+      f.pdsch_maintenance_v3.csi_for_rm.push_back(0);
+    }
+
+    // (a) the two conversions
+    pdsch_processor::pdu_t pdu;
+    fapi_adaptor::convert_pdsch_fapi_to_phy(pdu, f, sfn, slot, csi_lists, repo);
+    std::vector<float> wa, wb;
+    nrphy_pdsch_pdu_t  a = mi355::to_pod(pdu, tb_sizes[i], wa);
+    nrphy_pdsch_pdu_t  b = mi355::fapi_to_pod(f, sfn, slot, csi_lists, repo, tb_sizes[i], wb);
+    a.precoding = b.precoding = nullptr;
+    if (std::memcmp(&a, &b, sizeof(a)) != 0 || wa != wb) {
+      result |= 1;
+    }
+    // (b) reference, PDU by PDU; adaptor, one batch
+    counting_notifier notifier;
+    reference->process(g_ref->get_mapper(), notifier, {span<const uint8_t>(tbs[i], tb_sizes[i])}, pdu);
+    notifier.wait(1);
+    if (!batch.add(f, sfn, slot, csi_lists, repo, span<const uint8_t>(tbs[i], tb_sizes[i]))) {
+      result |= 2;
+    }
+  }
+  if (batch.size() != n || !batch.process(*g_ad)) {
+    result |= 4;
+  }
+  store_grid(grid_ref, *g_ref, nof_ports, nof_subc);
+  store_grid(grid_adaptor, *g_ad, nof_ports, nof_subc);
+  return result;
 }
 
 } // extern "C"

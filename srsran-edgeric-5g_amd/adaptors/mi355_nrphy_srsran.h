@@ -47,6 +47,11 @@
 #include "srsran/phy/upper/channel_processors/pdcch_processor.h"
 #include "srsran/phy/upper/channel_processors/ssb_processor.h"
 #include "srsran/ran/precoding/precoding_codebooks.h"
+#include "srsran/fapi/messages.h"
+#include "srsran/fapi_adaptor/precoding_matrix_repository.h"
+#include "srsran/phy/upper/channel_modulation/demodulation_mapper.h"
+#include "srsran/phy/upper/vrb_to_prb_mapper.h"
+#include "srsran/ran/sch/sch_dmrs_power.h"
 
 #include <atomic>
 #include <cstring>
@@ -1403,6 +1408,258 @@ private:
   std::shared_ptr<context> ctx;
   float                    iq_scaling;
   std::vector<uint8_t>     packed;
+};
+
+// ---- soft demodulator ---------------------------------------------------------------------------------------------------
+/// demodulation_mapper over nrphy_demodulate_soft_host (one span per call, as the reference's callers use it:
+/// pusch_demodulator_impl.cpp:235-245, one OFDM symbol's worth of equalised resource elements at a time).  On failure the
+/// soft bits are zeros (undecided), which the decoder then reports as a failed CRC.
+class demodulation_mapper_adaptor : public srsran::demodulation_mapper
+{
+public:
+  explicit demodulation_mapper_adaptor(std::shared_ptr<context> ctx_) : ctx(std::move(ctx_)) {}
+  void demodulate_soft(srsran::span<srsran::log_likelihood_ratio> llrs,
+                       srsran::span<const srsran::cf_t>           symbols,
+                       srsran::span<const float>                  noise_vars,
+                       srsran::modulation_scheme                  mod) override
+  {
+    using namespace srsran;
+    srsran_assert(symbols.size() == noise_vars.size(), "Inputs symbols and noise_vars must have the same length.");
+    srsran_assert(symbols.size() * get_bits_per_symbol(mod) == llrs.size(), "Input and output lengths are incompatible.");
+    const uint32_t m = mod == modulation_scheme::PI_2_BPSK ? NRPHY_MOD_PI2_BPSK : get_bits_per_symbol(mod);
+    int rc = nrphy_demodulate_soft_host(ctx->get(), m, symbols.size(), reinterpret_cast<const float*>(symbols.data()),
+                                        noise_vars.data(), reinterpret_cast<int8_t*>(llrs.data()));
+    if (rc != NRPHY_OK) {
+      report_failure("nrphy_demodulate_soft_host", rc);
+      std::memset(static_cast<void*>(llrs.data()), 0, llrs.size());
+    }
+  }
+
+private:
+  std::shared_ptr<context> ctx;
+};
+
+// ---- FAPI batching shim --------------------------------------------------------------------------
+/// dl_pdsch_pdu -> POD, field for field what convert_pdsch_fapi_to_phy builds as a pdu_t
+/// (R/lib/fapi_adaptor/phy/messages/pdsch.cpp:152-206) and to_pod() then flattens, without the pdu_t in between.  The
+/// resource allocation goes through the reference's own rb_allocation / vrb_to_prb_mapper (pdsch.cpp:100-150), the power
+/// offsets follow pdsch.cpp:57-82.  \c weights receives the precoding coefficients the POD points to.
+inline nrphy_pdsch_pdu_t fapi_to_pod(const srsran::fapi::dl_pdsch_pdu&                         fapi_pdu,
+                                     uint16_t                                                   sfn,
+                                     uint16_t                                                   slot,
+                                     srsran::span<const srsran::re_pattern_list>                csi_re_pattern_list,
+                                     const srsran::fapi_adaptor::precoding_matrix_repository&   pm_repo,
+                                     size_t                                                     tb_size,
+                                     std::vector<float>&                                        weights)
+{
+  using namespace srsran;
+  nrphy_pdsch_pdu_t p;
+  std::memset(&p, 0, sizeof(p));
+  p.slot_index    = slot_point(fapi_pdu.scs, sfn, slot).slot_index();
+  p.rnti          = to_value(fapi_pdu.rnti);
+  p.bwp_start_rb  = fapi_pdu.bwp_start;
+  p.bwp_size_rb   = fapi_pdu.bwp_size;
+  p.cp            = (fapi_pdu.cp == cyclic_prefix::NORMAL) ? 0 : 1;
+  p.nof_codewords = fapi_pdu.cws.size();
+  p.qm            = fapi_pdu.cws.empty() ? 0 : static_cast<unsigned>(fapi_pdu.cws[0].qam_mod_order);
+  p.rv            = fapi_pdu.cws.empty() ? 0 : fapi_pdu.cws[0].rv_index;
+  p.n_id          = fapi_pdu.nid_pdsch;
+  p.ref_point     = (fapi_pdu.ref_point == fapi::pdsch_ref_point_type::point_a) ? 0 : 1;
+  p.dmrs_symbol_mask            = fapi_pdu.dl_dmrs_symb_pos & 0x3FFFU;
+  p.dmrs_type                   = (fapi_pdu.dmrs_type == fapi::dmrs_cfg_type::type_1) ? 1 : 2;
+  p.scrambling_id               = fapi_pdu.pdsch_dmrs_scrambling_id;
+  p.n_scid                      = (fapi_pdu.nscid == 1U) ? 1 : 0;
+  p.nof_cdm_groups_without_data = fapi_pdu.num_dmrs_cdm_grps_no_data;
+  p.start_symbol_index          = fapi_pdu.start_symbol_index;
+  p.nof_symbols                 = fapi_pdu.nr_of_symbols;
+  p.ldpc_base_graph             = (fapi_pdu.pdsch_maintenance_v3.ldpc_base_graph == ldpc_base_graph_type::BG1) ? 1 : 2;
+  p.tbs_lbrm_bytes              = fapi_pdu.pdsch_maintenance_v3.tb_size_lbrm_bytes.value();
+  p.tb_size_bytes               = tb_size;
+
+  // Resource allocation: VRB-to-PRB mapping by transmission type, then type 1 (start, length) or type 0 (bitmap, LSB of
+  // byte 0 = VRB 0).
+  const unsigned bwp_start = fapi_pdu.bwp_start, bwp_size = fapi_pdu.bwp_size;
+  const unsigned n_start_coreset = fapi_pdu.pdsch_maintenance_v3.coreset_start_point - bwp_start;
+  const unsigned n_bwp_init      = fapi_pdu.pdsch_maintenance_v3.initial_dl_bwp_size;
+  unsigned       bundle          = 0;
+  if (fapi_pdu.vrb_to_prb_mapping == fapi::vrb_to_prb_mapping_type::interleaved_rb_size2) {
+    bundle = 2;
+  } else if (fapi_pdu.vrb_to_prb_mapping == fapi::vrb_to_prb_mapping_type::interleaved_rb_size4) {
+    bundle = 4;
+  }
+  vrb_to_prb_mapper vrb_map = vrb_to_prb_mapper::create_non_interleaved_other();
+  switch (fapi_pdu.pdsch_maintenance_v3.trans_type) {
+    case fapi::pdsch_trans_type::non_interleaved_common_ss:
+      vrb_map = vrb_to_prb_mapper::create_non_interleaved_common_ss(n_start_coreset);
+      break;
+    case fapi::pdsch_trans_type::interleaved_common_type0_coreset0:
+      vrb_map = vrb_to_prb_mapper::create_interleaved_coreset0(n_start_coreset, n_bwp_init);
+      break;
+    case fapi::pdsch_trans_type::interleaved_common_any_coreset0_present:
+      vrb_map = vrb_to_prb_mapper::create_interleaved_common(n_start_coreset, bwp_start, n_bwp_init);
+      break;
+    case fapi::pdsch_trans_type::interleaved_common_any_coreset0_not_present:
+      vrb_map = vrb_to_prb_mapper::create_interleaved_common(n_start_coreset, bwp_start, bwp_size);
+      break;
+    case fapi::pdsch_trans_type::interleaved_other:
+      vrb_map = vrb_to_prb_mapper::create_interleaved_other(bwp_start, bwp_size, bundle);
+      break;
+    default:
+      break;
+  }
+  rb_allocation alloc;
+  if (fapi_pdu.resource_alloc == fapi::resource_allocation_type::type_1) {
+    alloc = rb_allocation::make_type1(fapi_pdu.rb_start, fapi_pdu.rb_size, vrb_map);
+  } else {
+    bounded_bitset<MAX_RB> vrb_bitmap(bwp_size);
+    for (unsigned vrb = 0; vrb != bwp_size; ++vrb) {
+      if ((fapi_pdu.rb_bitmap[vrb / 8] >> (vrb % 8)) & 1U) {
+        vrb_bitmap.set(vrb);
+      }
+    }
+    alloc = rb_allocation::make_type0(vrb_bitmap, vrb_map);
+  }
+  p.vrb_contiguous           = alloc.is_contiguous() ? 1 : 0;
+  bounded_bitset<MAX_RB> prb = alloc.get_prb_mask(bwp_start, bwp_size);
+  for (unsigned i = 0; i != prb.size(); ++i) {
+    if (prb.test(i)) {
+      p.prb_mask[i / 64] |= uint64_t(1) << (i % 64);
+    }
+  }
+
+  // Power: data offset from the two profile fields, DM-RS offset from TS 38.214 Table 4.1-1.
+  float ss_dB = 6.0F;
+  switch (fapi_pdu.power_control_offset_ss_profile_nr) {
+    case fapi::power_control_offset_ss::dB_minus_3:
+      ss_dB = -3.0F;
+      break;
+    case fapi::power_control_offset_ss::dB0:
+      ss_dB = 0.0F;
+      break;
+    case fapi::power_control_offset_ss::dB3:
+      ss_dB = 3.0F;
+      break;
+    default:
+      break;
+  }
+  p.ratio_pdsch_data_to_sss_dB = ss_dB + static_cast<float>(fapi_pdu.power_control_offset_profile_nr);
+  p.ratio_pdsch_dmrs_to_sss_dB = p.ratio_pdsch_data_to_sss_dB + get_sch_to_dmrs_ratio_dB(fapi_pdu.num_dmrs_cdm_grps_no_data);
+
+  // Reserved RE: the CSI-RS patterns this PDU rate-matches around, merged as re_pattern_list::merge does.
+  re_pattern_list reserved;
+  for (auto csi_index : fapi_pdu.pdsch_maintenance_v3.csi_for_rm) {
+    srsran_assert(csi_index < csi_re_pattern_list.size(), "CSI-RS PDU index out of bounds.");
+    reserved.merge(csi_re_pattern_list[csi_index]);
+  }
+  for (const re_pattern& pat : reserved.get_re_patterns()) {
+    nrphy_re_pattern_t& o = p.reserved[p.nof_reserved++];
+    for (unsigned i = 0; i != pat.prb_mask.size(); ++i) {
+      if (pat.prb_mask.test(i)) {
+        o.prb_mask[i / 64] |= uint64_t(1) << (i % 64);
+      }
+    }
+    for (unsigned k = 0; k != NRE; ++k) {
+      o.re_mask |= pat.re_mask.test(k) ? (1U << k) : 0U;
+    }
+    for (unsigned l = 0; l != pat.symbols.size(); ++l) {
+      o.symbol_mask |= pat.symbols.test(l) ? (1U << l) : 0U;
+    }
+  }
+
+  // Wideband precoding from the repository (one PRG, as the reference asserts).
+  srsran_assert(fapi_pdu.precoding_and_beamforming.prgs.size() == 1U, "Unsupported number of PRGs.");
+  const precoding_weight_matrix& w = pm_repo.get_precoding_matrix(fapi_pdu.precoding_and_beamforming.prgs.front().pm_index);
+  p.nof_layers                     = w.get_nof_layers();
+  p.nof_ports                      = w.get_nof_ports();
+  p.prg_size_rb                    = MAX_RB;
+  p.nof_prg                        = 1;
+  weights.resize(2 * p.nof_ports * p.nof_layers);
+  for (unsigned port = 0; port != p.nof_ports; ++port) {
+    for (unsigned l = 0; l != p.nof_layers; ++l) {
+      cf_t c                                  = w.get_coefficient(l, port);
+      weights[2 * (port * p.nof_layers + l)]     = c.real();
+      weights[2 * (port * p.nof_layers + l) + 1] = c.imag();
+    }
+  }
+  p.precoding = weights.data();
+  return p;
+}
+
+/// All PDSCH PDUs of one DL_TTI.request: add() converts and keeps each PDU with its transport block, process() runs them as
+/// ONE plan and one launch into the slot's grid (nrphy_pdsch_process_slot_host) -- where the reference's translator hands
+/// every PDU to its own pdsch_processor::process (fapi_to_phy_translator.cpp).  Blocking; the grid is read first, so what
+/// the other channels wrote stays.
+class fapi_pdsch_slot_batch
+{
+public:
+  fapi_pdsch_slot_batch(std::shared_ptr<context> ctx_, unsigned nof_ports_, unsigned nof_subc_) :
+    ctx(std::move(ctx_)), nof_ports(nof_ports_), nof_subc(nof_subc_)
+  {
+  }
+
+  /// Returns false (and keeps nothing) when the PDU is one the reference's validator refuses.
+  bool add(const srsran::fapi::dl_pdsch_pdu&                       fapi_pdu,
+           uint16_t                                                 sfn,
+           uint16_t                                                 slot,
+           srsran::span<const srsran::re_pattern_list>              csi_re_pattern_list,
+           const srsran::fapi_adaptor::precoding_matrix_repository& pm_repo,
+           srsran::span<const uint8_t>                              transport_block)
+  {
+    weights.emplace_back();
+    nrphy_pdsch_pdu_t pod = fapi_to_pod(fapi_pdu, sfn, slot, csi_re_pattern_list, pm_repo, transport_block.size(), weights.back());
+    if (nrphy_pdsch_validate(&pod) != NRPHY_OK) {
+      weights.pop_back();
+      return false;
+    }
+    pods.push_back(pod);
+    tbs.push_back(transport_block.data());
+    return true;
+  }
+
+  unsigned size() const { return pods.size(); }
+
+  /// Runs the batch into `grid` and empties it.  On failure the grid is left as it was and false is returned.
+  bool process(srsran::resource_grid& grid)
+  {
+    using namespace srsran;
+    if (pods.empty()) {
+      return true;
+    }
+    for (unsigned i = 0; i != pods.size(); ++i) {
+      pods[i].precoding = weights[i].data(); // (the vectors may have moved while the batch grew)
+    }
+    staging.resize(static_cast<size_t>(nof_ports) * MAX_NSYMB_PER_SLOT * nof_subc);
+    const resource_grid_reader& reader = grid.get_reader();
+    for (unsigned p = 0; p != nof_ports; ++p) {
+      for (unsigned l = 0; l != MAX_NSYMB_PER_SLOT; ++l) {
+        span<const cbf16_t> view = reader.get_view(p, l);
+        std::memcpy(&staging[(static_cast<size_t>(p) * MAX_NSYMB_PER_SLOT + l) * nof_subc], view.data(), nof_subc * sizeof(cbf16_t));
+      }
+    }
+    int rc = nrphy_pdsch_process_slot_host(ctx->get(), pods.size(), pods.data(), tbs.data(), staging.data(), nof_ports, nof_subc);
+    pods.clear();
+    tbs.clear();
+    weights.clear();
+    if (rc != NRPHY_OK) {
+      report_failure("nrphy_pdsch_process_slot_host", rc);
+      return false;
+    }
+    resource_grid_writer& writer = grid.get_writer();
+    for (unsigned p = 0; p != nof_ports; ++p) {
+      for (unsigned l = 0; l != MAX_NSYMB_PER_SLOT; ++l) {
+        writer.put(p, l, 0, 1, span<const cbf16_t>(&staging[(static_cast<size_t>(p) * MAX_NSYMB_PER_SLOT + l) * nof_subc], nof_subc));
+      }
+    }
+    return true;
+  }
+
+private:
+  std::shared_ptr<context>        ctx;
+  unsigned                        nof_ports, nof_subc;
+  std::vector<nrphy_pdsch_pdu_t>  pods;
+  std::vector<const uint8_t*>     tbs;
+  std::vector<std::vector<float>> weights;
+  std::vector<srsran::cbf16_t>    staging;
 };
 
 } // namespace mi355

@@ -1412,6 +1412,62 @@ extern "C" int nrphy_pdsch_process_host(nrphy_ctx_t* ctx, const nrphy_pdsch_pdu_
   return rc;
 }
 
+extern "C" int nrphy_pdsch_process_slot_host(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
+                                             const uint8_t* const* tbs, void* grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc)
+{
+  if (ctx == nullptr || grid == nullptr || (n_pdu != 0 && (pdus == nullptr || tbs == nullptr))) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (n_pdu == 0) {
+    return NRPHY_OK;
+  }
+  // One plan for the slot: every PDU's codeblocks in one launch, all into grid 0.
+  std::vector<uint64_t> tb_off(n_pdu);
+  std::vector<uint32_t> grid_of(n_pdu, 0);
+  size_t                tb_total = 0;
+  for (uint32_t i = 0; i != n_pdu; ++i) {
+    if (tbs[i] == nullptr) {
+      return NRPHY_ERR_ARGUMENT;
+    }
+    tb_off[i] = tb_total;
+    tb_total += ((size_t)pdus[i].tb_size_bytes + 7) & ~(size_t)3; // readable to the next multiple of 4
+  }
+  nrphy_pdsch_plan_t* plan = nullptr;
+  int rc = nrphy_pdsch_plan_create(ctx, n_pdu, pdus, tb_off.data(), grid_of.data(), 1, grid_nof_ports, grid_nof_subc, &plan);
+  if (rc != NRPHY_OK) {
+    return rc;
+  }
+  const size_t grid_bytes = (size_t)grid_nof_ports * NRPHY_NSYMB * grid_nof_subc * 4;
+  std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
+  uint8_t* d_tb   = (uint8_t*)ctx_scratch(ctx, SCRATCH_TB, tb_total + 8);
+  uint8_t* d_grid = (uint8_t*)ctx_scratch(ctx, SCRATCH_GRID, grid_bytes);
+  rc              = NRPHY_ERR_DEVICE;
+  do {
+    if (d_tb == nullptr || d_grid == nullptr || hipMemsetAsync(d_tb, 0, tb_total + 8, ctx->stream) != hipSuccess) {
+      break;
+    }
+    bool ok = true;
+    for (uint32_t i = 0; ok && i != n_pdu; ++i) {
+      ok = hipMemcpyAsync(d_tb + tb_off[i], tbs[i], pdus[i].tb_size_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    }
+    if (!ok || hipMemcpyAsync(d_grid, grid, grid_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+      break;
+    }
+    rc = nrphy_pdsch_run(plan, d_tb, d_grid, nullptr, nullptr, 0, ctx->stream);
+    if (rc != NRPHY_OK) {
+      break;
+    }
+    rc = NRPHY_ERR_DEVICE;
+    if (hipMemcpyAsync(grid, d_grid, grid_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      break;
+    }
+    rc = NRPHY_OK;
+  } while (false);
+  nrphy_pdsch_plan_destroy(plan);
+  return rc;
+}
+
 extern "C" int nrphy_pdsch_encode_host(nrphy_ctx_t* ctx, const nrphy_pdsch_encoder_cfg_t* cfg, const uint8_t* tb,
                                        uint8_t* codeword_bits, uint8_t* codeword_packed)
 {

@@ -153,6 +153,17 @@ class Context:
                "nrphy_llr_descramble_host")
         return out
 
+    def pdsch_process_slot_host(self, pdus, tbs, grid):
+        """All PDSCH PDUs of one slot into one host grid [nof_ports][14][nof_subc][2] uint16 (read first, written back)."""
+        n = len(pdus)
+        arr = (abi.PdschPdu * n)(*pdus)
+        keep = [np.ascontiguousarray(t, dtype=np.uint8) for t in tbs]
+        ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in keep])
+        grid = np.ascontiguousarray(grid, dtype=np.uint16)
+        _check(self.lib.nrphy_pdsch_process_slot_host(self.handle, n, arr, ptrs, grid.ctypes.data, grid.shape[0], grid.shape[2]),
+               "nrphy_pdsch_process_slot_host")
+        return grid
+
     def demodulate_soft(self, modulation, nof_spans, span_len, d_symbols, d_noise_vars, d_llr, stream=None):
         """demodulation_mapper::demodulate_soft for nof_spans spans of span_len symbols in device memory."""
         _check(self.lib.nrphy_demodulate_soft(self.handle, modulation, nof_spans, span_len, _dptr(d_symbols), _dptr(d_noise_vars),

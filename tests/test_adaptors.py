@@ -155,3 +155,45 @@ def test_ssb_amplitude_and_ofh_adaptors(harness):
         a, r = np.zeros(nprb * 49, np.uint8), np.zeros(nprb * 49, np.uint8)
         n = harness.adaptor_test_ofh(_i(typ), _u32(w), C.c_float(0.9), _p(prbs), _u32(nprb), _p(a), _p(r))
         assert n == nprb * (3 * w + typ) and np.array_equal(a[:n], r[:n]), (typ, w)
+
+
+@pytest.mark.parametrize("modulation", [0, 1, 2, 4, 6, 8])
+def test_demodulation_mapper_adaptor(harness, modulation):
+    """demodulation_mapper_adaptor against demodulation_mapper_impl on spans around the vector batch sizes."""
+    rng = np.random.default_rng(600 + modulation)
+    qm = max(modulation, 1)
+    for n in (1, 5, 16, 37, 1003):
+        for kind in (0, 1, 2):
+            sym, noise = cases.demod_inputs(rng, modulation, n, kind)
+            got, want = np.zeros(n * qm, np.int8), np.full(n * qm, 99, np.int8)
+            harness.adaptor_test_demod.restype = _i
+            assert harness.adaptor_test_demod(_u32(modulation), _u32(n), _p(sym), _p(noise), _p(got), _p(want)) == 0
+            assert np.array_equal(got, want), (modulation, n, kind)
+
+
+def test_fapi_pdsch_shim(harness):
+    """fapi_to_pod equals convert_pdsch_fapi_to_phy followed by to_pod (every POD byte and weight), for both reference
+    points, both resource allocation types, several transmission types and power profiles, with and without a CSI-RS
+    rate-matching pattern; and fapi_pdsch_slot_batch (all PDUs of the slot in one call) leaves the slot's grid as the
+    reference's processor does PDU by PDU."""
+    rng = np.random.default_rng(808)
+    nof_ports, nof_subc = 4, 106 * 12
+    # rnti, bwp_start, bwp_size, qm, rv, nid, dmrs mask, scr id, nscid, cdm groups, rb_start, rb_size, start symbol, nof symbols,
+    # power offset, layers | ref point, type-1 allocation, trans_type, ss profile, csi pattern
+    rows = np.array([
+        [0x4601, 0, 106, 2, 0, 11, 0b000100000100, 5, 0, 2, 0, 20, 2, 12, 0, 1, 0, 1, 0, 1, 1],
+        [0x4602, 0, 106, 4, 1, 12, 0b000100000100, 6, 1, 2, 20, 30, 2, 12, 3, 2, 0, 0, 0, 2, 0],
+        [0x4603, 0, 106, 6, 2, 13, 0b100000000100, 7, 0, 1, 50, 25, 1, 13, -2, 3, 0, 1, 0, 0, 1],
+        [0x4604, 0, 106, 8, 3, 14, 0b000100000100, 8, 1, 2, 75, 31, 2, 12, 8, 4, 1, 0, 0, 3, 0],
+    ], dtype=np.int32)
+    n = rows.shape[0]
+    tb_sizes = np.array([160, 700, 2100, 9000], dtype=np.uint32)
+    tbs = [rng.integers(0, 256, int(s), dtype=np.uint8) for s in tb_sizes]
+    tb_ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in tbs])
+    init = random_grid(rng, nof_ports, 14, nof_subc)
+    got, want = np.zeros_like(init), np.zeros_like(init)
+    harness.adaptor_test_fapi.restype = _i
+    rc = harness.adaptor_test_fapi(_u32(n), _p(rows), tb_ptrs, _p(tb_sizes), _u32(nof_ports), _u32(nof_subc), _p(init), _p(got), _p(want))
+    assert rc == 0, rc
+    assert not np.array_equal(want, init)
+    assert np.array_equal(got, want)

@@ -1800,3 +1800,32 @@ def test_demodulate_soft_vs_oracle_and_golden(gpu_ctx, oracle, modulation):
     assert gpu_ctx.lib.nrphy_demodulate_soft(gpu_ctx.handle, 3, 1, 16, None, None, None, None) == abi.ERR_ARGUMENT
     assert gpu_ctx.lib.nrphy_demodulate_soft(gpu_ctx.handle, 8, 1, 16, None, None, None, None) == abi.ERR_ARGUMENT
     assert gpu_ctx.lib.nrphy_demodulate_soft(gpu_ctx.handle, 8, 0, 16, None, None, None, None) == abi.OK
+
+
+def test_pdsch_process_slot_host_all_pdus_of_a_slot(gpu_ctx, oracle):
+    """nrphy_pdsch_process_slot_host: the four PDUs of a config-4 cell-slot in one plan and one launch equal the four separate
+    reference-shaped calls into the same grid; resource elements other channels wrote before stay."""
+    rng = np.random.default_rng(404)
+    pdus, nof_ports, nof_subc = cases.mixed_cell(2, slot_index=7)
+    tbs = [cases.random_tb(rng, q) for q in pdus]
+    grid = np.zeros((nof_ports, 14, nof_subc, 2), np.uint16)
+    grid[:, 0, :, :] = 0x3F80          # what other channels left: all of symbol 0 (inside the allocations, so mostly replaced) ...
+    grid[:, 13, ::7, 0] = 0x4000       # ... and scattered elements of symbol 13 (outside: the PDUs span symbols 0 to 11)
+    before = grid.copy()
+    want = before.copy()
+    mapped = np.zeros(grid.shape[:3], bool)
+    for q, tb in zip(pdus, tbs):
+        part = oracle.pdsch_process(q, tb, nof_ports, nof_subc)
+        m = part.view(np.uint32).reshape(part.shape[:3]) != 0
+        want[m] = part[m]
+        mapped |= m
+    got = gpu_ctx.pdsch_process_slot_host(pdus, tbs, grid.copy())
+    # every resource element a PDU maps (data, DM-RS and the zeros of its reserved positions) is the oracle's; the rest is kept
+    single = before.copy()
+    for q, tb in zip(pdus, tbs):
+        single = gpu_ctx.pdsch_process_host(q, tb, nof_ports, nof_subc, grid=single)
+    assert np.array_equal(got, single)
+    assert np.array_equal(got[mapped], want[mapped])
+    untouched = (single == before).all(axis=-1) & ~mapped
+    assert np.array_equal(got[untouched], before[untouched])
+    assert gpu_ctx.lib.nrphy_pdsch_process_slot_host(gpu_ctx.handle, 0, None, None, got.ctypes.data, nof_ports, nof_subc) == abi.OK
