@@ -4,7 +4,7 @@
 # 4 +rate matching/interleaving, 0 everything).  STAGES="5 6 7 1" selects a subset.
 # Usage (GPU box, repository root): bash profiles/stage_pmc.sh <out_dir>
 set -u
-OUT=$1; shift
+OUT=$(realpath -m "$1"); shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for st in ${STAGES:-1 2 3 4 0}; do

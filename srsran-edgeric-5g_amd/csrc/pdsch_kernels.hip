@@ -385,6 +385,10 @@ __device__ __forceinline__ void grid_store(uint32_t* p, uint32_t v)
   __builtin_nontemporal_store(v, p);
 }
 
+#ifndef NRPHY_GRID_BUFFER_STORES
+#define NRPHY_GRID_BUFFER_STORES 1 // A/B on one box: -1.3 % on the codeblock launch against 64-bit flat addressing
+#endif
+
 struct ChunkGeom {
   uint32_t E;      // rate-matched length of the codeblock
   uint32_t cw_cb;  // first codeword bit of the codeblock
@@ -453,6 +457,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   const size_t   grid_base = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
   const uint64_t cw_bit0 = pd.cw_bit_offset + g.cw_cb + (uint64_t)wk.re_begin * LQ;
   const uint32_t* __restrict__ scr = p.scr + pd.scr_offset;
+  const bool      scr_aligned      = (g.bit0 & 31u) == 0;
   // The OFDM symbol of the chunk's first RE, found once; the loop below only checks (on the scalar unit) whether the
   // next 64 RE stay inside the current symbol and walks on when they do not.
   const uint32_t re0   = re_cb + wk.re_begin;
@@ -464,6 +469,13 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   uint32_t cur_start = pd.sym_re_start[l_cur], cur_end = pd.sym_re_start[l_cur + 1u];
   // Wideband precoding (the common case): the weights are wave-uniform, scalar loads put them in SGPRs.
   const float NRPHY_CONSTANT* wuni = to_constant(wbase);
+#if NRPHY_GRID_BUFFER_STORES
+  // The PDU's grid through a buffer descriptor (scalar base, 32-bit per-lane offsets, the port plane in the scalar offset):
+  // no 64-bit address arithmetic in the vector unit.
+  const uint32_t plane_bytes = NRPHY_NSYMB * p.grid_nof_subc * 4u;
+  const __amdgpu_buffer_rsrc_t grid_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(d_grid + grid_base, 0, (int)(p.grid_nof_ports * plane_bytes), 0x00020000);
+#endif
 
   for (uint32_t r0 = 0; r0 < wk.re_count; r0 += WAVE) { // r0 is wave-uniform
     const uint32_t r = r0 + lane;
@@ -477,8 +489,19 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
     if (r >= wk.re_count) {
       continue;
     }
-    const uint32_t bytes = ext32(sh.symb, 8u * r * L);           // the RE's L symbol bytes, first in the MSB
-    const uint32_t gbits = ext32(scr, g.bit0 + r * LQ);          // its L*Qm scrambling bits (prologue), MSB first
+    // The RE's L symbol bytes (first in the MSB) and its L*Qm scrambling bits (prologue; MSB first).  Four layers make the
+    // first a whole word; L*Qm = 32 with a word-aligned chunk (the headline shape) makes the second one too.
+    uint32_t bytes, gbits;
+    if constexpr (L == 4) {
+      bytes = sh.symb[r];
+    } else {
+      bytes = ext32(sh.symb, 8u * r * L);
+    }
+    if (LQ == 32 && scr_aligned) { // wave-uniform
+      gbits = scr[(g.bit0 >> 5) + r];
+    } else {
+      gbits = ext32(scr, g.bit0 + r * LQ);
+    }
     uint32_t       idx[L];
     uint32_t       v_rm = 0;
 #pragma unroll
@@ -541,7 +564,12 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
           for (int l = 1; l != L; ++l) {
             acc += cmul_ref_packed_uniform(x[l], cf2{wuni[2 * (port * L + l)], wuni[2 * (port * L + l) + 1]});
           }
+#if NRPHY_GRID_BUFFER_STORES
+          __builtin_amdgcn_raw_buffer_store_b32(pack_cbf16(acc.x, acc.y), grid_rsrc, (int)((l_sym * p.grid_nof_subc + subc) * 4u),
+                                                (int)(port * plane_bytes), 2 /* nt */);
+#else
           grid_store(&out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc], pack_cbf16(acc.x, acc.y));
+#endif
         }
       }
     } else {
