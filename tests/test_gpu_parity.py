@@ -1829,3 +1829,65 @@ def test_pdsch_process_slot_host_all_pdus_of_a_slot(gpu_ctx, oracle):
     untouched = (single == before).all(axis=-1) & ~mapped
     assert np.array_equal(got[untouched], before[untouched])
     assert gpu_ctx.lib.nrphy_pdsch_process_slot_host(gpu_ctx.handle, 0, None, None, got.ctypes.data, nof_ports, nof_subc) == abi.OK
+
+
+@pytest.mark.parametrize("qm,rate,snr_db", [(2, 449, 6.0), (4, 616, 14.0), (6, 719, 21.0), (8, 797, 28.0), (2, 120, -1.0)])
+def test_link_all_modulations_through_soft_demodulator(gpu_ctx, oracle, qm, rate, snr_db):
+    """The receive chain on real soft bits, in the manner of the reference's pxsch_bler_test (one layer, 30 kHz, DM-RS in
+    symbols 2 and 7, 10 iterations): transport blocks -> device PDSCH chain (scrambled codeword tap) -> constellation symbols
+    (TS 38.211 Section 5.1) + white noise -> nrphy_demodulate_soft -> nrphy_llr_descramble -> nrphy_pusch_decode_batch.
+    A few dB above the code's threshold every block comes back; 12 dB lower none passes its CRC (no false positive)."""
+    import torch
+    nprb, slots = 52, 6
+    tb_bits = oracle.tbs(12, 12, 0, qm, float(rate), 1, nprb)
+    bg = 2 if (rate <= 256 or tb_bits <= 292 or (tb_bits <= 3824 and rate <= 686)) else 1
+    pdus = [abi.make_pdu(slot_index=i, rnti=0x1234, bwp_size_rb=nprb, qm=qm, dmrs_symbols=(2, 7), prb_start=0, prb_count=nprb,
+                         nof_symbols=14, base_graph=bg, tb_size_bytes=tb_bits // 8, nof_cdm_groups_without_data=2,
+                         precoding=np.ones((1, 1, 1), np.complex64)) for i in range(slots)]
+    pdu = pdus[0]
+    d = lib.derive(pdu)
+    G, tb_size = d["codeword_bits"], pdu.tb_size_bytes
+    nsym = G // qm
+    tb_stride = (tb_size + 3) & ~3
+    d_tb = torch.randint(0, 256, (slots, tb_stride), dtype=torch.uint8, device="cuda")
+    plan = lib.PdschPlan(gpu_ctx, pdus, [i * tb_stride for i in range(slots)], list(range(slots)), slots, 1, nprb * 12)
+    d_cw = torch.zeros((plan.codeword_bits + 7) // 8 + 64, dtype=torch.uint8, device="cuda")
+    plan.run(d_tb.reshape(-1), None, d_cw_scr=d_cw)
+    gpu_ctx.synchronize()
+    cw = d_cw.cpu().numpy()
+    rng = np.random.default_rng(1000 * qm + rate)
+    sym = np.zeros((slots, nsym), np.complex64)
+    for i in range(slots):
+        o = plan.codeword_offset(i)
+        assert o % 8 == 0
+        pts, sc = oracle.modulate(qm, cw[o // 8: o // 8 + (G + 7) // 8], nsym)
+        sym[i] = (pts[:, 0] + 1j * pts[:, 1]) * sc
+    assert abs(np.mean(np.abs(sym) ** 2) - 1.0) < 0.05
+    d_c_init = dev(np.array([(p.rnti << 15) + p.n_id for p in pdus], np.uint32).view(np.int32))
+    cfg = abi.PuschDecoderCfg(bg, qm, 0, 1, d["n_ref"], tb_size, nsym, 10, 1, 1)
+    soft_bytes, state_bytes, _ = gpu_ctx.pusch_decoder_sizes(cfg, slots)
+    for good in (True, False):
+        nv = float(10.0 ** (-(snr_db if good else snr_db - 12.0) / 10.0))
+        noisy = sym + (rng.standard_normal(sym.shape) + 1j * rng.standard_normal(sym.shape)).astype(np.complex64) * np.float32(
+            np.sqrt(nv / 2))
+        d_llr_scr = torch.zeros((slots, G), dtype=torch.int8, device="cuda")
+        d_llr = torch.zeros_like(d_llr_scr)
+        gpu_ctx.demodulate_soft(qm, slots, nsym, dev(noisy.view(np.float32)), dev(np.full((slots, nsym), nv, np.float32)), d_llr_scr)
+        gpu_ctx.llr_descramble(d_c_init, slots, G, d_llr_scr, G, d_llr, G)
+        d_soft = torch.zeros((slots, soft_bytes), dtype=torch.int8, device="cuda")
+        d_state = torch.zeros((state_bytes,), dtype=torch.uint8, device="cuda")
+        d_out = torch.zeros((slots, tb_stride), dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros((slots, 4), dtype=torch.int32, device="cuda")
+        gpu_ctx.pusch_decode_batch(cfg, slots, d_llr, G, d_soft, d_state, d_out, tb_stride, d_res)
+        gpu_ctx.synchronize()
+        torch.cuda.synchronize()
+        ok = d_res.cpu().numpy()[:, 0]
+        if good:
+            assert ok.all(), (qm, rate, ok)
+            assert torch.equal(d_out[:, :tb_size], d_tb[:, :tb_size])
+            # the soft bits agree with the oracle's on the same symbols (first slot)
+            want = oracle.demodulate_soft(qm, noisy[0], np.full(nsym, nv, np.float32))
+            assert np.array_equal(d_llr_scr[0].cpu().numpy(), want)
+        else:
+            assert not ok.any(), (qm, rate, ok)
+    plan.close()
