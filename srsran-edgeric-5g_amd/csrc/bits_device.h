@@ -258,7 +258,9 @@ __device__ __forceinline__ void lds_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <uint32_t NT>
+// WITH_X1 = false: the x2 part alone (the caller adds the x1 words, which are the same for every sequence, where it consumes
+// the result) -- the loop then has no global load whose latency a step must wait for.
+template <uint32_t NT, bool WITH_X1 = true>
 __device__ inline void gold_sequence_workgroup(const GoldTables* gold, const uint32_t* x1_words, uint32_t c_init,
                                                uint32_t first_word, uint32_t nwords, uint32_t* __restrict__ out,
                                                uint32_t* ring, uint32_t tid)
@@ -324,7 +326,7 @@ __device__ inline void gold_sequence_workgroup(const GoldTables* gold, const uin
   for (uint32_t i = 0; i != PER; ++i) {
     const uint32_t k = tid + i * NT;
     pw[i]            = (k < pend) ? ring[k] : 0u;
-    px[i]            = (k < pend) ? x1_words[first_word + k] : 0u;
+    px[i]            = (WITH_X1 && k < pend) ? x1_words[first_word + k] : 0u;
   }
   // One step: request the x1 words of the next block, compute the block into `nw`, write out the previous block
   // (`ow`, `ox`: its x1 words were requested a step ago).  The two register sets swap roles from step to step --
@@ -338,7 +340,7 @@ __device__ inline void gold_sequence_workgroup(const GoldTables* gold, const uin
 #pragma unroll
     for (uint32_t i = 0; i != PER; ++i) {
       const uint32_t k = have + tid + i * NT;
-      nx[i]            = (k < end) ? x1_words[first_word + k] : 0u;
+      nx[i]            = (WITH_X1 && k < end) ? x1_words[first_word + k] : 0u;
     }
 #pragma unroll
     for (uint32_t i = 0; i != PER; ++i) {

@@ -14,6 +14,10 @@
 // in its per-codeblock form (pdsch_processor_concurrent_impl.cpp:55-338, pdsch_codeblock_processor.cpp:27-141).
 #include "ldpc_device.h"
 
+#ifndef NRPHY_SCR_X2_ONLY
+#define NRPHY_SCR_X2_ONLY 1 // the prologue writes the x2 part of the scrambling sequences, map_chunk adds x1 (see there)
+#endif
+
 namespace nrphy {
 
 // ================================================================================================================
@@ -47,16 +51,23 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   static_assert(GOLD_RING_WORDS >= 2 * 1024 + TB_CRC_THREADS, "LDS of the CRC role");
   const uint32_t tid = threadIdx.x;
 
-  if (blockIdx.x < p.n_scr_work) { // workgroup-uniform; first in the grid: the longest dependent chains
+  // Sequence workgroups first, then the CRC workgroups: measured against CRC first (+11 % on this launch) and against one
+  // sequence workgroup after every few CRC workgroups (+95 %: the two roles' LDS traffic -- a ring walked in order, byte
+  // tables hit at random -- slow each other down when they share a CU).  profiles/r02_codeblock_experiments.txt.
+  const uint32_t scr_index = blockIdx.x, crc_index = blockIdx.x - p.n_scr_work;
+  const bool     scr_role  = blockIdx.x < p.n_scr_work;
+  if (scr_role) { // workgroup-uniform; first in the grid: the longest dependent chains
     if (p.profile_stage == 8) {
       return;
     }
-    const auto*    swc   = to_constant(&p.scr_work[blockIdx.x]);
+    const auto*    swc   = to_constant(&p.scr_work[scr_index]);
     const uint32_t first = swc->first, count = swc->count;
     const bool     with_dmrs = swc->with_dmrs != 0;
     PduRef         pd    = *to_constant(&p.pdus[swc->pdu]);
-    gold_sequence_workgroup<TB_CRC_THREADS>(p.gold, p.x1_words, pd.c_init, first, count, p.scr + pd.scr_offset + first,
-                                            lds, tid);
+    // The scrambling sequence goes out as its x2 part (NRPHY_SCR_X2_ONLY): map_chunk adds the x1 words, which every sequence
+    // shares, when it reads the scrambling bits.
+    gold_sequence_workgroup<TB_CRC_THREADS, !NRPHY_SCR_X2_ONLY>(p.gold, p.x1_words, pd.c_init, first, count,
+                                                                 p.scr + pd.scr_offset + first, lds, tid);
     // The DM-RS sequences, from bit 0 to the last allocated PRB: short, so one wave generates one (the four waves of
     // the PDU's first workgroup take the DM-RS symbols in turn, each with its own quarter of the LDS as scratch).
     if (with_dmrs) {
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   if (p.profile_stage == 9) {
     return;
   }
-  const auto*     wkc = to_constant(&p.crc_work[blockIdx.x - p.n_scr_work]);
+  const auto*     wkc = to_constant(&p.crc_work[crc_index]);
   const uint32_t  wk_pdu = wkc->pdu, wk_region = wkc->region, wk_factor = wkc->factor;
   PduRef          pd  = *to_constant(&p.pdus[wk_pdu]);
   const uint32_t  sel = (pd.tb_crc_bits == 16) ? 1u : 0u;
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
     if (tid == 0) {
       // The region's share of the PDU's CRC in a slot of its own: the codeblock wave that attaches the CRC adds the
       // shares up, so a run neither relies on nor leaves behind any accumulator state.
-      p.tb_crc_part[blockIdx.x - p.n_scr_work] = crc_mulmod(r, wk_factor, c);
+      p.tb_crc_part[crc_index] = crc_mulmod(r, wk_factor, c);
     }
   }
 }
@@ -499,8 +510,14 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
     }
     if (LQ == 32 && scr_aligned) { // wave-uniform
       gbits = scr[(g.bit0 >> 5) + r];
+      if (NRPHY_SCR_X2_ONLY) {
+        gbits ^= p.x1_words[(g.bit0 >> 5) + r];
+      }
     } else {
       gbits = ext32(scr, g.bit0 + r * LQ);
+      if (NRPHY_SCR_X2_ONLY) {
+        gbits ^= ext32(p.x1_words, g.bit0 + r * LQ);
+      }
     }
     uint32_t       idx[L];
     uint32_t       v_rm = 0;
