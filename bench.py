@@ -322,7 +322,7 @@ def main():
     if world == 1 and not args.no_secondary and args.config == 3 and not args.wire:
         # Secondary measurements, same process and GPU, fewer steps each; every entry is verified against the oracle.
         sec = {}
-        s_steps, s_warm = max(3, min(args.steps, 8)), 2
+        s_steps, s_warm = max(3, args.steps), max(3, args.warmup)  # the same count as the headline: short runs read 5-10 % slow
         for name, (cfg, slots, wire) in {"config3_wire_ci16": (3, args.slots, True), "config2": (2, 1000, False),
                                          "config4": (4, 1024, False)}.items():
             e = run_downlink(env, cfg, slots, s_steps, s_warm, wire=wire)
