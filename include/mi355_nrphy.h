@@ -335,7 +335,8 @@ int nrphy_llr_descramble_host(nrphy_ctx_t* ctx, uint32_t c_init, uint32_t length
  * blank a COMPONENT with |v| <= 1e-9; the remaining symbols divide by the variance (QPSK, 16-QAM), use floor(v / width),
  * round half away from zero and blank a SYMBOL with |z|^2 < 1e-9.  This call reproduces both, per position, bit for bit;
  * so one call must cover exactly one reference call: nof_spans spans of span_len symbols each, span r at
- * d_symbols + 2 * r * span_len floats (real, imaginary), d_noise_vars + r * span_len, d_llr + r * span_len * Qm.
+ * d_symbols + 2 * r * span_len floats (real, imaginary), d_noise_vars + r * span_len, d_llr + r * span_len * Qm
+ * (nof_spans <= 65535).
  * A variance that is zero, negative or NaN gives zeros (as in the reference).  Asynchronous on `stream`; no host memory is
  * touched, so the call can be captured in a hipGraph. */
 #define NRPHY_MOD_PI2_BPSK 0u
@@ -677,7 +678,11 @@ int nrphy_iq_convert_ci16_host(nrphy_ctx_t* ctx, const float* in, uint32_t nof_s
 /* The two above fused into the OFDM modulator's store: nrphy_ofdm_run with the slot leaving the device as complex
  * int16 (4 bytes per sample instead of 8: the IQ write is 71 % of the modulator's traffic).  Every sample takes the
  * path modulator -> amplitude controller (gain, clipping per buffer = per (grid, port) slot) -> conversion, in the
- * reference's order of roundings.  d_iq: [grid][port][slot_stride] complex int16; d_stats: [grid][port] or NULL. */
+ * reference's order of roundings.  d_iq: [grid][port][slot_stride] complex int16; d_stats: [grid][port] or NULL.
+ * Every conversion rounds to nearest even (the reference's vector path: a whole slot never reaches its scalar tail).
+ * With d_stats the plan keeps one 16-byte record per workgroup in a buffer of its own that grows with the largest
+ * nof_grids seen (a synchronous reallocation on growth only): run the largest batch once before capturing the call in a
+ * hipGraph, and keep the runs of one plan ordered (Conventions). */
 typedef struct nrphy_iq_wire_cfg {
   nrphy_amplitude_cfg_t amplitude;
   float                 ci16_scale;
