@@ -14,6 +14,9 @@
 // in its per-codeblock form (pdsch_processor_concurrent_impl.cpp:55-338, pdsch_codeblock_processor.cpp:27-141).
 #include "ldpc_device.h"
 
+#ifndef NRPHY_PHASE_A_STAGED
+#define NRPHY_PHASE_A_STAGED 1
+#endif
 #ifndef NRPHY_SCR_X2_ONLY
 #define NRPHY_SCR_X2_ONLY 1 // the prologue writes the x2 part of the scrambling sequences, map_chunk adds x1 (see there)
 #endif
@@ -429,6 +432,33 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   {
     const uint32_t s0   = wk.re_begin * L;             // first modulation symbol of the chunk (multiple of 32)
     const uint32_t nblk = (wk.re_count * L + 31u) >> 5;
+#if NRPHY_PHASE_A_STAGED
+    // Two passes over the wave's 64 lanes instead of one lane per block (a 281-RE codeblock has 36 blocks: 36 busy lanes doing
+    // Qm gathers and four transpositions each).  First the Qm * nblk row words, one gather per item, into the block's eight
+    // words of `symb` (word 8 blk + j = row j); then the 4 * nblk (block, byte column) items: eight byte reads, one 8x8
+    // transposition, two words back into the same eight words (the four items of a block sit in neighbouring lanes of one
+    // instruction: all their reads precede their writes).
+    for (uint32_t item = lane; item < QM * nblk; item += WAVE) {
+      const uint32_t blk = item / QM, j = item - blk * QM;
+      sh.symb[8u * blk + j] = rm_gather32<WRAP>(rm, sh.lin, zc2, j * esym + s0 + 32u * blk);
+    }
+    wave_sync();
+    const uint8_t* rows = reinterpret_cast<const uint8_t*>(sh.symb);
+    for (uint32_t item = lane; item < 4u * nblk; item += WAVE) {
+      const uint32_t blk = item >> 2, m = item & 3u;
+      const uint8_t* b   = rows + 32u * blk + (3u - m); // byte 3 - m of a row word holds its columns 8m .. 8m + 7
+      uint32_t       r8[8];
+#pragma unroll
+      for (int j = 0; j != 8; ++j) {
+        r8[j] = (j < QM) ? b[4 * j] : 0u;
+      }
+      uint32_t hi = (r8[0] << 24) | (r8[1] << 16) | (r8[2] << 8) | r8[3];
+      uint32_t lo = (r8[4] << 24) | (r8[5] << 16) | (r8[6] << 8) | r8[7];
+      transpose8x8(hi, lo);
+      sh.symb[8u * blk + 2u * m]      = hi;
+      sh.symb[8u * blk + 2u * m + 1u] = lo;
+    }
+#else
     for (uint32_t blk = lane; blk < nblk; blk += WAVE) {
       uint32_t row[8];
 #pragma unroll
@@ -447,6 +477,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
         sh.symb[8u * blk + 2u * m + 1u] = lo; // symbols 8m+4 .. 8m+7
       }
     }
+#endif
     if (lane < 8) {
       sh.symb[8u * nblk + lane] = 0; // read-ahead padding
     }
