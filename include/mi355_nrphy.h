@@ -229,6 +229,11 @@ int nrphy_pdsch_async_create(nrphy_ctx_t* ctx, uint32_t depth, uint32_t grid_nof
                              uint32_t max_tb_bytes, nrphy_pdsch_async_t** queue);
 int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* queue, const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb,
                              nrphy_pdsch_done_fn done, void* user);
+/* All PDSCH PDUs of one slot as ONE operation (one plan, one launch, one grid, one completion): what a FAPI DL_TTI.request
+ * carries for a slot.  The transport blocks together (each rounded up to a multiple of 4, plus 4) must fit max_tb_bytes of
+ * nrphy_pdsch_async_create; the PDUs' allocations are disjoint.  Statuses as nrphy_pdsch_async_submit. */
+int nrphy_pdsch_async_submit_slot(nrphy_pdsch_async_t* queue, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
+                                  const uint8_t* const* tbs, nrphy_pdsch_done_fn done, void* user);
 int nrphy_pdsch_async_wait(nrphy_pdsch_async_t* queue);    /* until nothing is in flight */
 int nrphy_pdsch_async_destroy(nrphy_pdsch_async_t* queue); /* waits, then frees */
 /* A completion handler that counts: `user` points at a uint64_t incremented atomically per successful PDU. */

@@ -412,6 +412,7 @@ def declare(lib, prefix="nrphy_"):
     sig("llr_descramble", i32, vp, u32, vp, u32, vp, C.c_size_t, vp, C.c_size_t, vp)
     sig("llr_descramble_host", i32, vp, u32, u32, vp, vp)
     sig("pdsch_process_slot_host", i32, vp, u32, vp, vp, vp, u32, u32)
+    sig("pdsch_async_submit_slot", i32, vp, u32, vp, vp, vp, vp)
     sig("demodulate_soft", i32, vp, u32, u32, u32, vp, vp, vp, vp)
     sig("demodulate_soft_host", i32, vp, u32, u32, vp, vp, vp)
     sig("grid_put", i32, vp, vp, u32, u32, u32, P(GridRe), vp)
@@ -457,7 +458,7 @@ ABI_SYMBOLS = [
     "nrphy_pusch_decode_codeblock_host", "nrphy_pusch_decoder_sizes", "nrphy_pusch_decode_batch",
     "nrphy_ldpc_decoder_scratch_bytes", "nrphy_ldpc_decoder_prepare", "nrphy_pusch_decoder_prepare",
     "nrphy_csi_rs_validate", "nrphy_csi_rs_map", "nrphy_csi_rs_map_host", "nrphy_grid_put",
-    "nrphy_llr_descramble", "nrphy_llr_descramble_host", "nrphy_demodulate_soft", "nrphy_demodulate_soft_host", "nrphy_pdsch_process_slot_host",
+    "nrphy_llr_descramble", "nrphy_llr_descramble_host", "nrphy_demodulate_soft", "nrphy_demodulate_soft_host", "nrphy_pdsch_process_slot_host", "nrphy_pdsch_async_submit_slot",
     "nrphy_pdcch_validate", "nrphy_pdcch_process", "nrphy_pdcch_process_host", "nrphy_pdcch_encode_host",
     "nrphy_ssb_validate", "nrphy_ssb_process", "nrphy_ssb_process_host", "nrphy_pbch_encode_host",
     "nrphy_pdsch_async_create", "nrphy_pdsch_async_submit", "nrphy_pdsch_async_wait", "nrphy_pdsch_async_destroy",

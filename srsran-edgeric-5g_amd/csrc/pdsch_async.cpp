@@ -49,7 +49,7 @@ void signature_of(const nrphy_pdsch_pdu_t& pdu, std::vector<uint8_t>& sig)
 {
   nrphy_pdsch_pdu_t copy = pdu;
   copy.precoding         = nullptr;
-  sig.assign(reinterpret_cast<const uint8_t*>(&copy), reinterpret_cast<const uint8_t*>(&copy) + sizeof(copy));
+  sig.insert(sig.end(), reinterpret_cast<const uint8_t*>(&copy), reinterpret_cast<const uint8_t*>(&copy) + sizeof(copy));
   const size_t nw = 2 * (size_t)pdu.nof_prg * pdu.nof_ports * pdu.nof_layers * sizeof(float);
   if (pdu.precoding != nullptr && nw != 0 && nw <= 2 * NRPHY_MAX_RB * NRPHY_MAX_PORTS * NRPHY_MAX_LAYERS * sizeof(float)) {
     const uint8_t* w = reinterpret_cast<const uint8_t*>(pdu.precoding);
@@ -146,10 +146,24 @@ extern "C" int nrphy_pdsch_async_destroy(nrphy_pdsch_async_t* q)
   return NRPHY_OK;
 }
 
-extern "C" int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* q, const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb,
-                                        nrphy_pdsch_done_fn done, void* user)
+// n PDUs whose transport blocks sit back to back (each readable to the next multiple of 4) in the slot's staging buffer, all
+// into the slot's one grid: one plan, one run.
+static int submit_pdus(nrphy_pdsch_async_t* q, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus, const uint8_t* const* tbs,
+                       nrphy_pdsch_done_fn done, void* user)
 {
-  if (q == nullptr || pdu == nullptr || tb == nullptr || pdu->tb_size_bytes == 0 || pdu->tb_size_bytes > q->max_tb_bytes) {
+  if (q == nullptr || pdus == nullptr || tbs == nullptr || n_pdu == 0) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  std::vector<uint64_t> tb_off(n_pdu);
+  size_t                tb_total = 0;
+  for (uint32_t i = 0; i != n_pdu; ++i) {
+    if (tbs[i] == nullptr || pdus[i].tb_size_bytes == 0) {
+      return NRPHY_ERR_ARGUMENT;
+    }
+    tb_off[i] = tb_total;
+    tb_total += ((size_t)pdus[i].tb_size_bytes + 7) & ~(size_t)3;
+  }
+  if (tb_total > (((size_t)q->max_tb_bytes + 7) & ~(size_t)3)) {
     return NRPHY_ERR_ARGUMENT;
   }
   AsyncSlot* slot = nullptr;
@@ -179,9 +193,11 @@ extern "C" int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* q, const nrphy_pdsc
   if (hipSetDevice(q->ctx->device) != hipSuccess) {
     return give_back(NRPHY_ERR_DEVICE);
   }
-  // The plan of this PDU shape: the slot's own, created on first sight.
+  // The plan of this shape (every PDU's bytes and weights): the slot's own, created on first sight.
   std::vector<uint8_t> sig;
-  signature_of(*pdu, sig);
+  for (uint32_t i = 0; i != n_pdu; ++i) {
+    signature_of(pdus[i], sig);
+  }
   nrphy_pdsch_plan_t* plan = nullptr;
   for (size_t i = 0; i != slot->plans.size(); ++i) {
     if (slot->plans[i].first == sig) {
@@ -191,9 +207,8 @@ extern "C" int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* q, const nrphy_pdsc
     }
   }
   if (plan == nullptr) {
-    uint64_t tb_off = 0;
-    uint32_t gi     = 0;
-    const int rc = nrphy_pdsch_plan_create(q->ctx, 1, pdu, &tb_off, &gi, 1, q->nof_ports, q->nof_subc, &plan);
+    std::vector<uint32_t> grid_of(n_pdu, 0);
+    const int rc = nrphy_pdsch_plan_create(q->ctx, n_pdu, pdus, tb_off.data(), grid_of.data(), 1, q->nof_ports, q->nof_subc, &plan);
     if (rc != NRPHY_OK) {
       return give_back(rc);
     }
@@ -203,13 +218,15 @@ extern "C" int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* q, const nrphy_pdsc
     }
     slot->plans.insert(slot->plans.begin(), std::make_pair(std::move(sig), plan));
   }
-  const size_t tb_alloc = ((size_t)pdu->tb_size_bytes + 7) & ~(size_t)3;
-  std::memcpy(slot->h_tb, tb, pdu->tb_size_bytes);
-  std::memset(slot->h_tb + pdu->tb_size_bytes, 0, tb_alloc - pdu->tb_size_bytes); // readable to the next multiple of 4
+  for (uint32_t i = 0; i != n_pdu; ++i) {
+    const size_t span = (i + 1 != n_pdu ? tb_off[i + 1] : tb_total) - tb_off[i];
+    std::memcpy(slot->h_tb + tb_off[i], tbs[i], pdus[i].tb_size_bytes);
+    std::memset(slot->h_tb + tb_off[i] + pdus[i].tb_size_bytes, 0, span - pdus[i].tb_size_bytes); // readable to the next multiple of 4
+  }
   slot->done   = done;
   slot->user   = user;
   slot->status = NRPHY_OK;
-  if (hipMemcpyAsync(slot->d_tb, slot->h_tb, tb_alloc, hipMemcpyHostToDevice, slot->stream) != hipSuccess) {
+  if (hipMemcpyAsync(slot->d_tb, slot->h_tb, tb_total, hipMemcpyHostToDevice, slot->stream) != hipSuccess) {
     return give_back(NRPHY_ERR_DEVICE);
   }
   const int rc = nrphy_pdsch_run(plan, slot->d_tb, slot->d_grid, nullptr, nullptr, 1, slot->stream);
@@ -223,6 +240,18 @@ extern "C" int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* q, const nrphy_pdsc
     return give_back(NRPHY_ERR_DEVICE);
   }
   return NRPHY_OK;
+}
+
+extern "C" int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* q, const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb,
+                                        nrphy_pdsch_done_fn done, void* user)
+{
+  return submit_pdus(q, 1, pdu, &tb, done, user);
+}
+
+extern "C" int nrphy_pdsch_async_submit_slot(nrphy_pdsch_async_t* q, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
+                                             const uint8_t* const* tbs, nrphy_pdsch_done_fn done, void* user)
+{
+  return submit_pdus(q, n_pdu, pdus, tbs, done, user);
 }
 
 // A ready-made completion handler: `user` points at a uint64_t that counts completions (benchmarks, tests).

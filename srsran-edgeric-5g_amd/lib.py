@@ -430,6 +430,27 @@ class PdschAsyncQueue:
         _check(rc, "nrphy_pdsch_async_submit")
         return True
 
+    def submit_slot(self, pdus, tbs, on_done):
+        """All PDUs of one slot as one operation (nrphy_pdsch_async_submit_slot); otherwise as submit()."""
+        shape = (self.nof_ports, 14, self.nof_subc, 2)
+
+        def trampoline(user, status, grid_ptr):
+            grid = np.ctypeslib.as_array(C.cast(grid_ptr, C.POINTER(C.c_uint16)), shape=shape).copy() if status == 0 else None
+            on_done(status, grid)
+
+        cb = abi.PDSCH_DONE_FN(trampoline)
+        self._keep.append(cb)
+        n = len(pdus)
+        arr = (abi.PdschPdu * n)(*pdus)
+        keep = [np.ascontiguousarray(t, dtype=np.uint8) for t in tbs]
+        ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in keep])
+        rc = self.ctx.lib.nrphy_pdsch_async_submit_slot(self.handle, n, arr, ptrs, cb, None)
+        if rc == abi.ERR_CAPACITY:
+            self._keep.pop()
+            return False
+        _check(rc, "nrphy_pdsch_async_submit_slot")
+        return True
+
     def wait(self):
         _check(self.ctx.lib.nrphy_pdsch_async_wait(self.handle), "nrphy_pdsch_async_wait")
         self._keep.clear()

@@ -1891,3 +1891,43 @@ def test_link_all_modulations_through_soft_demodulator(gpu_ctx, oracle, qm, rate
         else:
             assert not ok.any(), (qm, rate, ok)
     plan.close()
+
+
+def test_pdsch_async_slot_batches_in_flight(gpu_ctx, oracle):
+    """nrphy_pdsch_async_submit_slot: whole slots (four PDUs each, one plan and one launch per slot) in flight on the queue's
+    streams; every slot's grid comes back once, from a runtime thread, equal to the oracle's four PDUs in one grid."""
+    import threading
+    import time
+    rng = np.random.default_rng(909)
+    slots = []
+    for i in range(10):
+        pdus, nof_ports, nof_subc = cases.mixed_cell(i % 3, slot_index=i % 5)
+        slots.append((pdus, [cases.random_tb(rng, q) for q in pdus]))
+    total_tb = max(sum(((q.tb_size_bytes + 7) & ~3) for q in pdus) for pdus, _ in slots)
+    q = lib.PdschAsyncQueue(gpu_ctx, 3, nof_ports, nof_subc, total_tb)
+    results, lock, threads_seen = {}, threading.Lock(), set()
+    for i, (pdus, tbs) in enumerate(slots):
+        def on_done(status, grid, i=i):
+            with lock:
+                results.setdefault(i, []).append((status, grid))
+                threads_seen.add(threading.get_ident())
+        while not q.submit_slot(pdus, tbs, on_done):
+            time.sleep(0.0005)
+    q.wait()
+    assert sorted(results) == list(range(len(slots))) and all(len(v) == 1 for v in results.values())
+    assert threading.get_ident() not in threads_seen
+    for i, (pdus, tbs) in enumerate(slots):
+        status, grid = results[i][0]
+        assert status == 0
+        want = None
+        for pdu, tb in zip(pdus, tbs):
+            part = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc)
+            want = part if want is None else np.bitwise_or(want, part)   # disjoint allocations
+        assert np.array_equal(grid, want), i
+    # too many transport-block bytes for the queue's staging: refused, nothing in flight afterwards
+    small = lib.PdschAsyncQueue(gpu_ctx, 1, nof_ports, nof_subc, 64)
+    with pytest.raises(Exception):
+        small.submit_slot(slots[0][0], slots[0][1], lambda *a: None)
+    small.wait()
+    small.close()
+    q.close()
