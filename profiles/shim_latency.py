@@ -69,6 +69,50 @@ def main():
                   flush=True)
             h.nrphy_pdsch_async_destroy(q)
 
+    # A whole cell-slot of BASELINE config 4 (four PDUs, 68 PRB each) through the asynchronous seam, 4 operations in flight:
+    # PDU by PDU (four operations, four grids back) against nrphy_pdsch_async_submit_slot (one operation, one grid back).
+    import ctypes as C
+    abi = backends.abi
+    h = ctx.lib
+    done_fn = C.cast(h.nrphy_pdsch_async_count_done, C.c_void_p)
+    pdus, ports, subc = cases.mixed_cell(0)
+    tbs = [cases.random_tb(rng, q) for q in pdus]
+    arr = (abi.PdschPdu * 4)(*pdus)
+    ptrs = (C.c_void_p * 4)(*[t.ctypes.data for t in tbs])
+    total_tb = sum(((q.tb_size_bytes + 7) & ~3) for q in pdus)
+    for label, per_slot in (("PDU by PDU", 4), ("one operation per slot", 1)):
+        q = C.c_void_p()
+        assert h.nrphy_pdsch_async_create(ctx.handle, 4, ports, subc, total_tb, C.byref(q)) == 0
+        count = C.c_uint64(0)
+
+        def pump(n_slots):
+            for _ in range(n_slots):
+                if per_slot == 1:
+                    while True:
+                        rc = h.nrphy_pdsch_async_submit_slot(q, 4, arr, ptrs, done_fn, C.byref(count))
+                        if rc == 0:
+                            break
+                        assert rc == 4, rc
+                else:
+                    for k in range(4):
+                        while True:
+                            rc = h.nrphy_pdsch_async_submit(q, C.byref(pdus[k]), tbs[k].ctypes.data, done_fn, C.byref(count))
+                            if rc == 0:
+                                break
+                            assert rc == 4, rc
+            h.nrphy_pdsch_async_wait(q)
+
+        pump(10)
+        count.value = 0
+        n_slots = 200
+        t0 = time.perf_counter()
+        pump(n_slots)
+        dt = time.perf_counter() - t0
+        assert count.value == n_slots * per_slot
+        print("config 4 cell-slot (4 PDUs), asynchronous seam, 4 in flight, %s: %.0f cell-slots/s (%.3f ms per slot)" % (
+            label, n_slots / dt, 1e3 * dt / n_slots), flush=True)
+        h.nrphy_pdsch_async_destroy(q)
+
 
 if __name__ == "__main__":
     main()
