@@ -19,7 +19,10 @@
  *    hipStream_t passed as void* (NULL = the context's own stream).  Calls that take a stream are
  *    asynchronous with respect to the host.  The plan-based calls (nrphy_pdsch_run, nrphy_ofdm_run,
  *    nrphy_ofdm_demod_run, nrphy_demodulate_soft, nrphy_llr_descramble, nrphy_dft_run) neither allocate nor touch host memory and can be
- *    captured in a hipGraph, any number of them in any order; the others say what they do at the call.
+ *    captured in a hipGraph, any number of them in any order; the others say what they do at the call.  The grid writers
+ *    that take host descriptors (nrphy_csi_rs_map, nrphy_pdcch_process, nrphy_ssb_process, nrphy_grid_put) copy them from
+ *    host memory when called, like a plan creation: asynchronous, but not for capture (a replay would read host memory the
+ *    caller has long released).
  *  - A PDSCH plan owns device scratch that every run rewrites before reading it (sequences, CRC shares): runs of
  *    ONE plan must be ordered (one stream, or events between streams); different plans may run concurrently.
  *    Every run is self-contained -- no state is carried from one run of a plan to the next.

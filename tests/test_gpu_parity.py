@@ -1931,3 +1931,87 @@ def test_pdsch_async_slot_batches_in_flight(gpu_ctx, oracle):
     small.wait()
     small.close()
     q.close()
+
+
+def test_whole_slot_chain_in_a_hip_graph(gpu_ctx, oracle):
+    """The plan-based / descriptor-free device entry points added in round 2 are capturable too: PDSCH -> OFDM with wire-format
+    output (measurements on), and on the receive side soft demodulation -> descrambling, in one graph replayed on new inputs;
+    the replayed results equal the eager ones bit for bit.  (The PDCCH / SS-PBCH / CSI-RS writers copy their host descriptors
+    at the call, like a plan creation, and therefore stay outside a graph: they run eagerly between the replays here.)"""
+    import torch
+    rng = np.random.default_rng(2468)
+    nof_ports, nof_rb = 2, 52
+    nof_subc = 12 * nof_rb
+    tbs = lib.tbs_calculate(12, 12, 0, 4, 490, 2, 30)
+    pdsch = abi.make_pdu(bwp_size_rb=nof_rb, qm=4, rnti=17, n_id=5, dmrs_symbols=(2, 11), prb_start=22, prb_count=30,
+                         start_symbol=2, nof_symbols=12, precoding=cases.codebook("two_layer_two_ports_0"),
+                         tb_size_bytes=tbs // 8, slot_index=0)
+    pdcch = abi.make_pdcch(payload=rng.integers(0, 2, 41, dtype=np.uint8), rnti=17, cce_index=0, aggregation_level=4, duration=2,
+                           frequency_resources=tuple(range(8)), mapping="interleaved", reg_bundle_size=6, interleaver_size=2,
+                           shift_index=3, n_id_dmrs=5, n_id_data=5, n_rnti=17, bwp_size_rb=nof_rb,
+                           precoding=np.array([[1.0, 1.0j]], np.complex64) / np.sqrt(2))
+    ssb = abi.make_ssb(pattern_case="A", ssb_idx=0, L_max=4, phys_cell_id=5, payload=rng.integers(0, 2, 32, dtype=np.uint8),
+                       sfn=100, ports=(0,))
+    csi = abi.make_csi_rs(row=3, start_rb=0, nof_rb=nof_rb, k0=4, l0=13, density="one", scrambling_id=5,
+                          precoding=np.eye(2, dtype=np.complex64)[None])
+    ocfg = abi.OfdmConfig(0, nof_rb, 1024, 0, 1.0 / np.sqrt(1024), 2.4e9)
+    plan = lib.PdschPlan(gpu_ctx, [pdsch], [0], [0], 1, nof_ports, nof_subc)
+    oplan = lib.OfdmPlan(gpu_ctx, ocfg, nof_ports)
+    wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -12.0, 1.0, -3.0), 32767.0)
+    tb_bytes = (pdsch.tb_size_bytes + 3) & ~3
+    d_tb = torch.zeros(tb_bytes, dtype=torch.uint8, device="cuda")
+    d_grid = torch.zeros((1, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
+    d_iq16 = torch.zeros((1, nof_ports, oplan.slot_stride, 2), dtype=torch.int16, device="cuda")
+    d_stats = torch.zeros((nof_ports, 4), dtype=torch.int32, device="cuda")
+    nsym, qm = 1000, 6
+    d_sym = torch.zeros((nsym, 2), dtype=torch.float32, device="cuda")
+    d_nv = torch.full((nsym,), 0.01, dtype=torch.float32, device="cuda")
+    d_llr = torch.zeros(nsym * qm, dtype=torch.int8, device="cuda")
+    d_c_init = dev(np.array([12345], np.int32))
+
+    def chain(stream):
+        plan.run(d_tb, d_grid, zero_grids=True, stream=stream)
+        oplan.run_ci16(1, d_grid, wire, d_iq16, d_stats=d_stats, stream=stream)
+        gpu_ctx.demodulate_soft(qm, 1, nsym, d_sym, d_nv, d_llr, stream=stream)
+        gpu_ctx.llr_descramble(d_c_init, 1, nsym * qm, d_llr, nsym * qm, d_llr, nsym * qm, stream=stream)
+
+    def new_inputs():
+        tb = cases.random_tb(rng, pdsch)
+        d_tb[: tb.size].copy_(torch.from_numpy(tb))
+        d_sym.copy_(torch.from_numpy(rng.uniform(-1.2, 1.2, (nsym, 2)).astype(np.float32)))
+        return tb
+
+    s = torch.cuda.Stream()
+    new_inputs()
+    with torch.cuda.stream(s):
+        chain(s.cuda_stream)   # warm-up outside the capture (tables, the wire-format run's record buffer)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        chain(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        tb = new_inputs()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (d_grid, d_iq16, d_stats, d_llr)]
+        with torch.cuda.stream(s):
+            chain(s.cuda_stream)
+        torch.cuda.synchronize()
+        for a, b in zip(got, (d_grid, d_iq16, d_stats, d_llr)):
+            assert torch.equal(a, b)
+        grid = got[0][0].cpu().numpy().view(np.uint16).reshape(nof_ports, 14, nof_subc, 2)
+        assert np.array_equal(grid, oracle.pdsch_process(pdsch, tb, nof_ports, nof_subc))
+        # the other grid writers, eagerly, on the replayed grid: the oracle's slot
+        with torch.cuda.stream(s):
+            gpu_ctx.pdcch_process([pdcch], [0], d_grid, nof_ports, nof_subc, stream=s.cuda_stream)
+            gpu_ctx.ssb_process([ssb], [0], d_grid, nof_ports, nof_subc, stream=s.cuda_stream)
+            gpu_ctx.csi_rs_map([csi], [0], d_grid, nof_ports, nof_subc, stream=s.cuda_stream)
+        torch.cuda.synchronize()
+        want = oracle.pdsch_process(pdsch, tb, nof_ports, nof_subc)
+        want = oracle.pdcch_process(pdcch, want)
+        want = oracle.ssb_process(ssb, want)
+        want = oracle.csi_rs_map(csi, want)
+        assert np.array_equal(d_grid[0].cpu().numpy().view(np.uint16).reshape(nof_ports, 14, nof_subc, 2), want)
+    plan.close()
+    oplan.close()
