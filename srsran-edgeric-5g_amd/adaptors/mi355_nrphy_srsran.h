@@ -49,6 +49,7 @@
 #include "srsran/ran/precoding/precoding_codebooks.h"
 #include "srsran/fapi/messages.h"
 #include "srsran/fapi_adaptor/precoding_matrix_repository.h"
+#include "srsran/phy/upper/channel_modulation/channel_modulation_factories.h"
 #include "srsran/phy/upper/channel_modulation/demodulation_mapper.h"
 #include "srsran/phy/upper/vrb_to_prb_mapper.h"
 #include "srsran/ran/sch/sch_dmrs_power.h"
@@ -1437,6 +1438,28 @@ public:
 
 private:
   std::shared_ptr<context> ctx;
+};
+
+/// channel_modulation_factory that hands out the device-backed demodulation mapper and leaves the modulation mapper and
+/// the EVM calculator to the reference's factory it wraps (create_channel_modulation_sw_factory()): what
+/// create_pusch_demodulator_factory_sw takes as its demodulation factory (R/lib/phy/upper/channel_processors/pusch/factories.cpp:160).
+class channel_modulation_factory_adaptor : public srsran::channel_modulation_factory
+{
+public:
+  channel_modulation_factory_adaptor(std::shared_ptr<context> ctx_, std::shared_ptr<srsran::channel_modulation_factory> inner_) :
+    ctx(std::move(ctx_)), inner(std::move(inner_))
+  {
+  }
+  std::unique_ptr<srsran::modulation_mapper>   create_modulation_mapper() override { return inner->create_modulation_mapper(); }
+  std::unique_ptr<srsran::demodulation_mapper> create_demodulation_mapper() override
+  {
+    return std::make_unique<demodulation_mapper_adaptor>(ctx);
+  }
+  std::unique_ptr<srsran::evm_calculator> create_evm_calculator() override { return inner->create_evm_calculator(); }
+
+private:
+  std::shared_ptr<context>                            ctx;
+  std::shared_ptr<srsran::channel_modulation_factory> inner;
 };
 
 // ---- FAPI batching shim --------------------------------------------------------------------------
