@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void ldpc_dematch_kernel(DematchLaunch p)
 
 // One workgroup per codeblock: the input is read once, coalesced, into LDS; the strided reads of the deinterleaver
 // then stay on chip.
-constexpr uint32_t DEMATCH_LDS_THREADS = 1024;
+constexpr uint32_t DEMATCH_LDS_THREADS = 1024; // 512: the same; 256: 7 % slower on the config-5 chain (A/B on one box)
 
 // One workgroup per codeblock, everything on chip: the input and the soft buffer are read once, coalesced, into LDS;
 // the operations run one after the other over their own ranges (no per-position range tests, the strided reads of the
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(DEMATCH_LDS_THREADS) void ldpc_dematch_lds_kernel(D
   const int8_t*  in      = p.in + (size_t)blockIdx.y * p.in_stride_outer + (size_t)blockIdx.x * p.in_stride;
   int8_t*        out_row = p.out + (size_t)blockIdx.y * p.out_stride_outer + (size_t)blockIdx.x * p.out_stride;
   const uint32_t T = blockDim.x, tid = threadIdx.x;
-  {
+  if (!p.skip_load) { // (a first transmission overwrites the whole block: 25 KB per codeblock less to read)
     const uint32_t* src = reinterpret_cast<const uint32_t*>(out_row); // dword aligned (checked by the launcher)
     uint32_t*       dst = reinterpret_cast<uint32_t*>(soft);
     for (uint32_t i = tid; i < p.block_length / 4u; i += T) {

@@ -1644,6 +1644,25 @@ int rate_dematch_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* 
     HIP_TRY(hipMemcpyAsync(d_ops, ops.data(), ops.size() * sizeof(DematchOp), hipMemcpyHostToDevice, s));
     p.ops_ext = d_ops;
   }
+  {
+    // Do the copying / clearing / filling operations cover the whole block?  Then no soft bit keeps its old value and the
+    // kernel skips reading the buffer (always so for a first transmission that does not wrap; never with combining).
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    bool combines = false;
+    for (const DematchOp& op : ops) {
+      combines = combines || op.kind == DEMATCH_COMBINE;
+      ranges.emplace_back(op.begin, op.begin + op.count);
+    }
+    std::sort(ranges.begin(), ranges.end());
+    uint32_t reach = 0;
+    for (const auto& r : ranges) {
+      if (r.first > reach) {
+        break;
+      }
+      reach = std::max(reach, r.second);
+    }
+    p.skip_load = (!combines && reach >= block_length) ? 1U : 0U;
+  }
   p.in           = d_in;
   p.out          = d_soft;
   p.in_stride    = in_stride_bytes;

@@ -261,6 +261,7 @@ struct DematchLaunch {
   int8_t*       out; // per codeblock: the soft buffer, block_length soft bits
   uint32_t      in_stride, out_stride, block_length, qm, cols, n_ops;
   uint32_t      in_stride_outer, out_stride_outer; // a second batch dimension (transport blocks of codeblocks)
+  uint32_t      skip_load; // the operations write every soft bit of the block: the old contents need not be read
   const DematchOp* ops_ext; // the list in device memory when it has more than MAX_DEMATCH_OPS entries, else null
   DematchOp        ops[MAX_DEMATCH_OPS];
 };
