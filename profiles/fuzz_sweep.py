@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Larger randomised sweeps than the test-suite runs, GPU against the oracle through the C ABI (the numbers DESIGN.md section
-2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [rx] [ofdm] [csi]   (default: all)"""
+2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
 import ctypes as C
 import os
 import sys
@@ -160,7 +160,82 @@ def csi():
     return bad
 
 
+def dlctrl():
+    """PDCCH and SS/PBCH block processors: random PDUs into grids full of other data."""
+    rng = np.random.default_rng(515151)
+    bad = n = 0
+    for t in range(1500):
+        pdu = cases.random_pdcch(rng)
+        grid = (rng.standard_normal((4, 14, 52 * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        n += 1
+        if not np.array_equal(ctx.pdcch_process_host(pdu, grid), o.pdcch_process(pdu, grid)):
+            bad += 1
+            print("PDCCH MISMATCH", t, flush=True)
+    print("pdcch: %d random PDUs, %d mismatches" % (n, bad), flush=True)
+    n2 = bad2 = 0
+    for t in range(600):
+        nrb = int(rng.integers(24, 107))
+        ports = int(rng.integers(1, 5))
+        pdu = cases.random_ssb(rng, nrb, ports)
+        grid = (rng.standard_normal((ports, 14, nrb * 12, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        if o.ssb_validate(pdu) != 0:
+            continue
+        n2 += 1
+        if not np.array_equal(ctx.ssb_process_host(pdu, grid), o.ssb_process(pdu, grid)):
+            bad2 += 1
+            print("SSB MISMATCH", t, flush=True)
+    print("ssb: %d random PDUs, %d mismatches" % (n2, bad2), flush=True)
+    return bad + bad2
+
+
+def demod():
+    """Soft demodulator: random span lengths, the three input kinds of tests/cases.py, every modulation."""
+    rng = np.random.default_rng(626262)
+    bad = n = 0
+    for t in range(1200):
+        modulation = int(rng.choice([0, 1, 2, 4, 6, 8]))
+        length = int(rng.integers(1, 5000))
+        sym, noise = cases.demod_inputs(rng, modulation, length, int(rng.integers(0, 3)))
+        n += 1
+        if not np.array_equal(ctx.demodulate_soft_host(modulation, sym, noise), o.demodulate_soft(modulation, sym, noise)):
+            bad += 1
+            print("DEMOD MISMATCH", modulation, length, flush=True)
+    print("soft demodulator: %d random spans, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
+def lower():
+    """Amplitude controller, cf32 -> ci16, OFH compression on random buffers and parameters."""
+    rng = np.random.default_rng(737373)
+    bad = n = 0
+    for t in range(400):
+        nsamp = int(rng.integers(1, 20000))
+        x = ((rng.standard_normal(nsamp) + 1j * rng.standard_normal(nsamp)) * rng.uniform(0.05, 2.0)).astype(np.complex64)
+        cfg = abi.AmplitudeCfg(int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.uniform(-12, 6)), float(rng.uniform(0.5, 2)),
+                               float(rng.uniform(-12, -0.1)))
+        y, m = ctx.amplitude_control_host(cfg, x)
+        oy, om = o.amplitude_control(cfg, x)
+        scale = float(rng.choice([32767.0, 1000.0, 40000.0]))
+        n += 1
+        ok = np.array_equal(y.view(np.uint32), oy.view(np.uint32)) and np.array_equal(ctx.iq_convert_ci16_host(y, scale),
+                                                                                     o.iq_convert_ci16(oy, scale))
+        if not ok:
+            bad += 1
+            print("LOWER-PHY MISMATCH amplitude/ci16", t, flush=True)
+    for t in range(400):
+        nprb = int(rng.integers(1, 274))
+        prbs = (((rng.standard_normal((nprb, 12, 2)) * rng.uniform(0.01, 1.5)).astype(np.float32).view(np.uint32)) >> 16).astype(np.uint16)
+        cfg = abi.OfhCompressionCfg(int(rng.integers(0, 2)), int(rng.integers(8, 17)), float(rng.uniform(0.2, 1.5)))
+        n += 1
+        if not np.array_equal(ctx.ofh_compress_host(cfg, prbs), o.ofh_compress(cfg, prbs)):
+            bad += 1
+            print("OFH MISMATCH", cfg.type, cfg.data_width, nprb, flush=True)
+    print("lower-PHY tail: %d random cases, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pdsch", "rx", "ofdm", "csi"]
-    total = sum({"pdsch": pdsch, "rx": rx, "ofdm": ofdm, "csi": csi}[w]() for w in which)
+    legs = {"pdsch": pdsch, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    which = sys.argv[1:] or list(legs)
+    total = sum(legs[w]() for w in which)
     sys.exit(1 if total else 0)
