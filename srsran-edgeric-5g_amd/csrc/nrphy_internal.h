@@ -122,7 +122,10 @@ struct CbWork {
 // One workgroup of the DM-RS kernel: OFDM symbol `symbol` of PDU `pdu`.
 constexpr int DMRS_PRB_CHUNK = 32; // PRBs per DM-RS wavefront
 // Transport-block CRC: one 256-thread workgroup reduces a 16 KiB region of the transport block.
-constexpr uint32_t TB_CRC_REGION_WORDS = 4096;
+#ifndef NRPHY_CRC_WORDS_PER_THREAD
+#define NRPHY_CRC_WORDS_PER_THREAD 16
+#endif
+constexpr uint32_t TB_CRC_REGION_WORDS = 256 * NRPHY_CRC_WORDS_PER_THREAD;
 constexpr uint32_t TB_CRC_REGION_BYTES = 4 * TB_CRC_REGION_WORDS;
 
 // Tables of the transport-block CRC, per polynomial ([0] CRC24A, [1] CRC16).  Thread t of a workgroup owns the words

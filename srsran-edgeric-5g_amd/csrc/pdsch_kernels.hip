@@ -37,7 +37,8 @@ namespace nrphy {
 // Scrambling and DM-RS sequences: see gold_sequence_workgroup().
 // ================================================================================================================
 constexpr int TB_CRC_THREADS = 256;
-static_assert(TB_CRC_REGION_WORDS == 16 * TB_CRC_THREADS, "sixteen words per thread");
+constexpr int TB_CRC_WPT = NRPHY_CRC_WORDS_PER_THREAD;
+static_assert(TB_CRC_REGION_WORDS == TB_CRC_WPT * TB_CRC_THREADS, "words per thread");
 
 // reg * y mod g for a 32-bit partial, y's table in LDS: tab[k * 256 + b] = (b x^(8k)) y mod g.
 __device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t reg)
@@ -107,9 +108,9 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   // The region's words (zero beyond the transport block, bytes beyond its end masked off).
   const uint32_t nwords = (n + 3u) >> 2;
   const uint32_t word0  = wk_region * TB_CRC_REGION_WORDS + tid;
-  uint32_t       w[16];
+  uint32_t       w[TB_CRC_WPT];
 #pragma unroll
-  for (int i = 0; i != 16; ++i) {
+  for (int i = 0; i != TB_CRC_WPT; ++i) {
     const uint32_t idx = word0 + (uint32_t)i * TB_CRC_THREADS;
     w[i]               = (idx < nwords) ? be_word(tbw, idx) : 0u;
     if ((n & 3u) != 0 && idx + 1u == nwords) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   __syncthreads();
   uint32_t reg = w[0];
 #pragma unroll
-  for (int i = 1; i != 16; ++i) {
+  for (int i = 1; i != TB_CRC_WPT; ++i) {
     reg = crc_advance(y1, reg) ^ w[i];
   }
   msg[tid] = reg;
