@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dynamic instruction counts of the codeblock kernel stage by stage: NRPHY_PROFILE_STAGE=n makes the codeblock waves
 # return after stage n (5 work item only, 6 +graph staging, 7 +segmentation, 1 +CRC, 2 +LDPC, 3 +weights,
-# 4 +rate matching/interleaving, 0 everything).  STAGES="5 6 7 1" selects a subset.
+# 4 +rate matching/interleaving, 0 everything; 11 everything but the data-RE stores).  STAGES="5 6 7 1" selects a subset.
 # Usage (GPU box, repository root): bash profiles/stage_pmc.sh <out_dir>
 set -u
 OUT=$(realpath -m "$1"); shift

@@ -517,7 +517,8 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   // no 64-bit address arithmetic in the vector unit.
   const uint32_t plane_bytes = NRPHY_NSYMB * p.grid_nof_subc * 4u;
   const __amdgpu_buffer_rsrc_t grid_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(d_grid + grid_base, 0, (int)(p.grid_nof_ports * plane_bytes), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(d_grid + grid_base, 0, (int)(p.profile_stage == 11 ? 0u : p.grid_nof_ports * plane_bytes),
+                                        0x00020000);
 #endif
 
   for (uint32_t r0 = 0; r0 < wk.re_count; r0 += WAVE) { // r0 is wave-uniform
@@ -614,6 +615,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
             acc += cmul_ref_packed_uniform(x[l], cf2{wuni[2 * (port * L + l)], wuni[2 * (port * L + l) + 1]});
           }
 #if NRPHY_GRID_BUFFER_STORES
+          // (profiling aid, NRPHY_PROFILE_STAGE=11: a zero-sized descriptor drops the data stores, everything else runs)
           __builtin_amdgcn_raw_buffer_store_b32(pack_cbf16(acc.x, acc.y), grid_rsrc, (int)((l_sym * p.grid_nof_subc + subc) * 4u),
                                                 (int)(port * plane_bytes), 2 /* nt */);
 #else
