@@ -218,3 +218,47 @@ def test_reference_unit_test_configurations_host_side():
     for tbs_bits, bg, nof_segments, segment_length in g["seg_cases"].tolist():
         d = lib.derive(backends.abi.make_pdu(base_graph=bg, tb_size_bytes=tbs_bits // 8, prb_count=52, qm=2))
         assert (d["nof_codeblocks"], d["segment_length"]) == (nof_segments, segment_length)
+
+
+def test_host_only_helpers_of_the_lower_phy_tail():
+    """Entry points that are pure host arithmetic: nrphy_amplitude_metrics (amplitude_controller_clipping_impl's metrics from
+    the device's raw measurements, running counters included) against the compiled reference where it is built and against the
+    oracle; nrphy_ofh_compressed_prb_bytes; OFDM symbol / slot sizes against the oracle's for every numerology and prefix."""
+    import ctypes as C
+    lib, o, abi = backends.pkg.lib, backends.oracle(), backends.abi
+    h = lib.load()
+    r = backends.ref()
+    rng = np.random.default_rng(99)
+    running = abi.AmplitudeMetrics()
+    total = clipped = 0
+    for cfg in (abi.AmplitudeCfg(0, 1, -2.0, 1.0, -9.0), abi.AmplitudeCfg(0, 0, 3.0, 2.0, -3.0), abi.AmplitudeCfg(0, 1, -20.0, 1.0, -1.0)):
+        x = ((rng.standard_normal(3000) + 1j * rng.standard_normal(3000)) * 0.4).astype(np.complex64)
+        _, om = o.amplitude_control(cfg, x)
+        m = abi.AmplitudeMetrics()
+        assert h.nrphy_amplitude_metrics(C.byref(cfg), C.byref(om["stats"]), C.byref(m)) == 0
+        for key in ("avg_power_fs", "peak_power_fs", "papr_lin", "gain_dB"):
+            assert getattr(m, key) == om[key], key
+        if r is not None:
+            _, rm = r.amplitude_control(cfg, x)
+            assert abs(m.avg_power_fs - rm["avg_power_fs"]) <= 1e-5 * abs(rm["avg_power_fs"])
+            assert m.peak_power_fs == np.float32(rm["peak_power_fs"]) and m.gain_dB == np.float32(rm["gain_dB"])
+            assert int(m.nof_clipped_samples) == rm["nof_clipped"] and int(m.nof_processed_samples) == rm["nof_processed"]
+        # one controller object over several buffers: the counters accumulate -- while clipping is enabled, as in the
+        # reference (amplitude_controller_clipping_impl.cpp:37-66 measures and counts inside `if (clipping_enabled)`)
+        assert h.nrphy_amplitude_metrics(C.byref(cfg), C.byref(om["stats"]), C.byref(running)) == 0
+        total += 3000 if cfg.enable_clipping else 0
+        clipped += int(m.nof_clipped_samples)
+        assert int(running.nof_processed_samples) == total and int(running.nof_clipped_samples) == clipped
+    for typ, width in ((0, 8), (0, 9), (0, 16), (1, 8), (1, 9), (1, 14)):
+        cfg = abi.OfhCompressionCfg(typ, width, 1.0)
+        assert h.nrphy_ofh_compressed_prb_bytes(C.byref(cfg)) == o.lib.oracle_ofh_compressed_prb_bytes(C.byref(cfg)) == 3 * width + typ
+    for mu in range(5):
+        for cp in ((0, 1) if mu == 2 else (0,)):
+            cfg = abi.OfdmConfig(mu, 24, 512, cp, 1.0, 3.5e9)
+            nsym = 12 if cp else 14
+            sizes = [lib.symbol_size(cfg, s) for s in range(nsym << mu)]
+            assert all(s >= 512 for s in sizes)
+            for slot in range(1 << mu):
+                assert lib.slot_size(cfg, slot) == sum(sizes[slot * nsym:(slot + 1) * nsym])
+            # one subframe is 1 ms: 15 kHz * 512 samples * 2^mu per ms
+            assert sum(sizes) == 15 * 512 * (1 << mu)
