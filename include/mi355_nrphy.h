@@ -468,7 +468,7 @@ typedef struct nrphy_ssb_pdu {
   float    beta_pss_dB;      /* PSS power relative to SSS */
   uint32_t ssb_idx;
   uint32_t L_max;            /* 4, 8 or 64 */
-  uint32_t common_scs;       /* subCarrierSpacingCommon as a numerology: 0 = 15 kHz, 1 = 30, 2 = 60, 3 = 120 */
+  uint32_t common_scs;       /* subCarrierSpacingCommon as a numerology: 0 = 15 kHz, 1 = 30, 2 = 60, 3 = 120, 4 = 240 */
   uint32_t subcarrier_offset; /* k_SSB */
   uint32_t offset_to_pointA;
   uint32_t pattern_case;     /* 0..4 = case A..E */
@@ -476,6 +476,7 @@ typedef struct nrphy_ssb_pdu {
   uint32_t nof_ports;
   uint8_t  ports[NRPHY_MAX_PORTS]; /* grid ports that carry the block */
 } nrphy_ssb_pdu_t;
+/* Also refused: a block whose four symbols would run past symbol 13 of the slot (pattern case E, blocks starting at symbol 12). */
 int nrphy_ssb_validate(const nrphy_ssb_pdu_t* pdu);
 /* n blocks into device grids, as nrphy_pdcch_process. */
 int nrphy_ssb_process(nrphy_ctx_t* ctx, uint32_t n, const nrphy_ssb_pdu_t* pdus, const uint32_t* grid_index, void* d_grid,

@@ -422,7 +422,7 @@ static int ssb_l_first(unsigned pattern_case, unsigned ssb_idx)
 static int ssb_k_first(const nrphy_ssb_pdu_t* p)
 {
   static const unsigned ssb_scs_khz[5] = {15, 30, 30, 120, 240};
-  if (p->pattern_case > 4 || p->common_scs > 3 || p->offset_to_pointA > 2199) {
+  if (p->pattern_case > 4 || p->common_scs > 4 || p->offset_to_pointA > 2199) { /* is_scs_valid: up to 240 kHz */
     return -1;
   }
   const int      fr2     = p->pattern_case >= 3;
@@ -457,6 +457,11 @@ int oracle_ssb_validate(const nrphy_ssb_pdu_t* p)
   }
   /* the slot must be the one of the half frame that holds the block (ssb_processor_impl.cpp:41-44) */
   if ((unsigned)l / 14 != p->slot_index % (slots_per_frame(p->numerology) / 2)) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
+  /* Pattern case E holds blocks that start at symbol 12 of a slot (ssb_mapping.h:78-96: first symbols {8, 12, 16, 20, ...});
+     their four symbols run past the 14 of the slot grid, where the reference writes outside the grid.  Refused here. */
+  if ((unsigned)l % 14 + 4 > 14) {
     return NRPHY_ERR_INVALID_PDU;
   }
   for (unsigned i = 0; i != p->nof_ports; ++i) {

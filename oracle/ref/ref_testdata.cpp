@@ -11,6 +11,15 @@
 //   4 upper/channel_coding/ldpc/ldpc_segmenter_test_data.h     (11 cases)
 //   5 lower/modulation/ofdm_modulator_test_data.h              (20 cases)
 //   6 upper/signal_processors/dmrs_pdsch_processor_test_data.h (192 cases)
+// and, for the "next" rows built in round 2 (section 8f of SURVEY.md):
+//   7 upper/channel_processors/pdcch_processor_test_data.h     (114 cases)
+//   8 upper/channel_processors/ssb_processor_test_data.h       (240 cases)
+//   9 upper/signal_processors/nzp_csi_rs_generator_test_data.h (102 cases)
+//  10 upper/channel_modulation/demodulation_mapper_test_data.h (12 cases)
+//  11 lower/modulation/ofdm_demodulator_test_data.h            (20 cases)
+//  12 ofh/compression/ofh_compression_test_data.h              (36 cases; under tests/unittests/ofh)
+//  13 upper/channel_processors/pdcch_encoder_test_data.h       (29 cases)
+//  14 upper/channel_processors/pbch_encoder_test_data.h        (232 cases)
 // Each export returns the number of cases when called with a null output.
 
 #include "mi355_nrphy.h"
@@ -23,8 +32,11 @@
 #include <cstring>
 #include <vector>
 
-#if WHICH == 1 || WHICH == 3 || WHICH == 6
+#if WHICH == 1 || WHICH == 3 || WHICH == 6 || WHICH == 7 || WHICH == 8 || WHICH == 9
 #include "mi355_nrphy_srsran.h"
+#endif
+#if WHICH == 1 || WHICH == 3 || WHICH == 6
+
 
 namespace {
 int emit_pdu(const srsran::pdsch_processor::pdu_t& pdu, nrphy_pdsch_pdu_t* pod, float* weights, unsigned weights_cap)
@@ -265,5 +277,173 @@ extern "C" int ref_testdata_dmrs_pdsch_map(unsigned i, uint16_t* grid_io, unsign
     }
   }
   return NRPHY_OK;
+}
+#endif
+
+#if WHICH == 7
+#include "upper/channel_processors/pdcch_processor_test_data.h"
+
+// Returns the number of weight floats written (> 0).
+extern "C" int ref_testdata_pdcch_processor(unsigned i, nrphy_pdcch_pdu_t* pod, float* weights, unsigned weights_cap)
+{
+  using namespace srsran;
+  if (pod == nullptr) {
+    return static_cast<int>(pdcch_processor_test_data.size());
+  }
+  std::vector<float> w;
+  *pod = mi355::to_pod(pdcch_processor_test_data[i].config, w);
+  if (w.size() > weights_cap) {
+    return -1;
+  }
+  std::memcpy(weights, w.data(), w.size() * sizeof(float));
+  pod->precoding = nullptr;
+  return static_cast<int>(w.size());
+}
+#endif
+
+#if WHICH == 8
+#include "upper/channel_processors/ssb_processor_test_data.h"
+
+extern "C" int ref_testdata_ssb_processor(unsigned i, nrphy_ssb_pdu_t* pod)
+{
+  using namespace srsran;
+  if (pod == nullptr) {
+    return static_cast<int>(ssb_processor_test_data.size());
+  }
+  *pod = mi355::to_pod(ssb_processor_test_data[i].config);
+  return 0;
+}
+#endif
+
+#if WHICH == 9
+#include "upper/signal_processors/nzp_csi_rs_generator_test_data.h"
+
+// Returns the number of weight floats written (> 0).
+extern "C" int ref_testdata_nzp_csi_rs(unsigned i, nrphy_csi_rs_cfg_t* pod, float* weights, unsigned weights_cap)
+{
+  using namespace srsran;
+  if (pod == nullptr) {
+    return static_cast<int>(nzp_csi_rs_generator_test_data.size());
+  }
+  std::vector<float> w;
+  *pod = mi355::to_pod(nzp_csi_rs_generator_test_data[i].config, w);
+  if (w.size() > weights_cap) {
+    return -1;
+  }
+  std::memcpy(weights, w.data(), w.size() * sizeof(float));
+  pod->precoding = nullptr;
+  return static_cast<int>(w.size());
+}
+#endif
+
+#if WHICH == 10
+#include "srsran/phy/upper/log_likelihood_ratio.h"
+#include "srsran/ran/sch/modulation_scheme.h"
+#include "upper/channel_modulation/demodulation_mapper_test_data.h"
+
+// out = {number of symbols, modulation as NRPHY_MOD_*}.
+extern "C" int ref_testdata_demodulation_mapper(unsigned i, unsigned* out)
+{
+  using namespace srsran;
+  if (out == nullptr) {
+    return static_cast<int>(demodulation_mapper_test_data.size());
+  }
+  const test_case_t& c = demodulation_mapper_test_data[i];
+  out[0]               = c.nsymbols;
+  out[1]               = c.scheme == modulation_scheme::PI_2_BPSK ? NRPHY_MOD_PI2_BPSK : get_bits_per_symbol(c.scheme);
+  return 0;
+}
+#endif
+
+#if WHICH == 11
+#include "support/resource_grid_test_doubles.h"
+#include "lower/modulation/ofdm_demodulator_test_data.h"
+
+// extra = {port_idx, slot_idx, nof_samples_window_offset}.
+extern "C" int ref_testdata_ofdm_demodulator(unsigned i, nrphy_ofdm_config_t* cfg, unsigned* extra)
+{
+  using namespace srsran;
+  if (cfg == nullptr) {
+    return static_cast<int>(ofdm_demodulator_test_data.size());
+  }
+  const ofdm_demodulator_test_configuration& c = ofdm_demodulator_test_data[i].test_config;
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->numerology     = c.config.numerology;
+  cfg->bw_rb          = c.config.bw_rb;
+  cfg->dft_size       = c.config.dft_size;
+  cfg->cp             = (c.config.cp == cyclic_prefix::NORMAL) ? 0 : 1;
+  cfg->scale          = c.config.scale;
+  cfg->center_freq_hz = c.config.center_freq_hz;
+  extra[0]            = c.port_idx;
+  extra[1]            = c.slot_idx;
+  extra[2]            = c.config.nof_samples_window_offset;
+  return 0;
+}
+#endif
+
+#if WHICH == 12
+#include "srsran/adt/complex.h"
+#include "srsran/ofh/compression/compression_params.h"
+#include "ofh_compression_test_data.h"
+
+// out = {nof_prb, compression type (0 none, 1 BFP, other values as the reference's enum), data width}; *iq_scaling.
+extern "C" int ref_testdata_ofh_compression(unsigned i, unsigned* out, float* iq_scaling)
+{
+  using namespace srsran;
+  if (out == nullptr) {
+    return static_cast<int>(ofh_compression_test_data.size());
+  }
+  const test_case_t& c = ofh_compression_test_data[i];
+  out[0]               = c.nof_prb;
+  out[1]               = c.type == ofh::compression_type::none ? 0 : (c.type == ofh::compression_type::BFP ? 1 : 2);
+  out[2]               = c.cIQ_width;
+  *iq_scaling          = c.iq_scaling;
+  return 0;
+}
+#endif
+
+#if WHICH == 13
+#include "srsran/phy/upper/channel_processors/pdcch_encoder.h"
+#include "upper/channel_processors/pdcch_encoder_test_data.h"
+
+// out = {E, rnti}.
+extern "C" int ref_testdata_pdcch_encoder(unsigned i, unsigned* out)
+{
+  using namespace srsran;
+  if (out == nullptr) {
+    return static_cast<int>(pdcch_encoder_test_data.size());
+  }
+  out[0] = pdcch_encoder_test_data[i].config.E;
+  out[1] = pdcch_encoder_test_data[i].config.rnti;
+  return 0;
+}
+#endif
+
+#if WHICH == 14
+#include "srsran/phy/upper/channel_processors/pbch_encoder.h"
+#include "upper/channel_processors/pbch_encoder_test_data.h"
+
+// The PBCH message as the SS/PBCH block PDU whose processor builds exactly this pbch_msg_t (ssb_processor_impl.cpp:46-53):
+// 15 kHz slot 0 or 5 for the half-frame bit, the other fields verbatim; the fields the encoder does not see stay zero.
+extern "C" int ref_testdata_pbch_encoder(unsigned i, nrphy_ssb_pdu_t* pod)
+{
+  using namespace srsran;
+  if (pod == nullptr) {
+    return static_cast<int>(pbch_encoder_test_data.size());
+  }
+  const pbch_encoder::pbch_msg_t& m = pbch_encoder_test_data[i].pbch_msg;
+  std::memset(pod, 0, sizeof(*pod));
+  pod->numerology        = 0;
+  pod->sfn               = m.sfn;
+  pod->slot_index        = m.hrf ? 5 : 0;
+  pod->phys_cell_id      = m.N_id;
+  pod->ssb_idx           = m.ssb_idx;
+  pod->L_max             = m.L_max;
+  pod->subcarrier_offset = m.k_ssb.to_uint();
+  for (unsigned k = 0; k != m.payload.size() && k != 32; ++k) {
+    pod->bch_payload[k] = m.payload[k];
+  }
+  pod->nof_ports = 1;
+  return 0;
 }
 #endif

@@ -1063,6 +1063,41 @@ private:
   std::shared_ptr<context> ctx;
 };
 
+/// nzp_csi_rs_generator::config_t -> POD.  \c weights receives the precoding coefficients the POD points to.
+inline nrphy_csi_rs_cfg_t to_pod(const srsran::nzp_csi_rs_generator::config_t& config, std::vector<float>& weights)
+{
+  using namespace srsran;
+  weights.assign(2 * config.precoding.get_nof_ports() * config.precoding.get_nof_layers(), 0.0F);
+  nrphy_csi_rs_cfg_t c = {};
+  c.slot_index         = config.slot.slot_index();
+  c.cp                 = (config.cp == cyclic_prefix::NORMAL) ? 0 : 1;
+  c.start_rb           = config.start_rb;
+  c.nof_rb             = config.nof_rb;
+  c.row                = config.csi_rs_mapping_table_row;
+  c.nof_k_ref          = config.freq_allocation_ref_idx.size();
+  for (unsigned i = 0; i != c.nof_k_ref && i != 6; ++i) {
+    c.k_ref[i] = config.freq_allocation_ref_idx[i];
+  }
+  c.symbol_l0     = config.symbol_l0;
+  c.symbol_l1     = config.symbol_l1;
+  c.cdm           = static_cast<uint32_t>(config.cdm);
+  c.density       = static_cast<uint32_t>(config.freq_density);
+  c.scrambling_id = config.scrambling_id;
+  c.amplitude     = config.amplitude;
+  c.nof_ports     = config.precoding.get_nof_ports();
+  c.prg_size_rb   = config.precoding.get_prg_size();
+  c.nof_prg       = config.precoding.get_nof_prg();
+  for (unsigned port = 0; port != c.nof_ports; ++port) {
+    for (unsigned layer = 0; layer != config.precoding.get_nof_layers(); ++layer) {
+      cf_t w                                                              = config.precoding.get_coefficient(layer, port, 0);
+      weights[2 * (port * config.precoding.get_nof_layers() + layer)]     = w.real();
+      weights[2 * (port * config.precoding.get_nof_layers() + layer) + 1] = w.imag();
+    }
+  }
+  c.precoding = weights.data();
+  return c;
+}
+
 // ---- other downlink grid writers ("next" row): NZP-CSI-RS generator -------------------------------------------------
 // Drop-in for create_nzp_csi_rs_generator_factory_sw (R/include/srsran/phy/upper/signal_processors/
 // signal_processor_factories.h) for rows 1-5 of TS 38.211 Table 7.4.1.5.3-1.  Host-span form: the signal is computed
@@ -1080,34 +1115,8 @@ public:
   void map(srsran::resource_grid_mapper& mapper, const config_t& config) override
   {
     using namespace srsran;
-    std::vector<float> weights(2 * config.precoding.get_nof_ports() * config.precoding.get_nof_layers());
-    nrphy_csi_rs_cfg_t c = {};
-    c.slot_index         = config.slot.slot_index();
-    c.cp                 = (config.cp == cyclic_prefix::NORMAL) ? 0 : 1;
-    c.start_rb           = config.start_rb;
-    c.nof_rb             = config.nof_rb;
-    c.row                = config.csi_rs_mapping_table_row;
-    c.nof_k_ref          = config.freq_allocation_ref_idx.size();
-    for (unsigned i = 0; i != c.nof_k_ref && i != 6; ++i) {
-      c.k_ref[i] = config.freq_allocation_ref_idx[i];
-    }
-    c.symbol_l0     = config.symbol_l0;
-    c.symbol_l1     = config.symbol_l1;
-    c.cdm           = static_cast<uint32_t>(config.cdm);
-    c.density       = static_cast<uint32_t>(config.freq_density);
-    c.scrambling_id = config.scrambling_id;
-    c.amplitude     = config.amplitude;
-    c.nof_ports     = config.precoding.get_nof_ports();
-    c.prg_size_rb   = config.precoding.get_prg_size();
-    c.nof_prg       = config.precoding.get_nof_prg();
-    for (unsigned port = 0; port != c.nof_ports; ++port) {
-      for (unsigned layer = 0; layer != config.precoding.get_nof_layers(); ++layer) {
-        cf_t w                                                  = config.precoding.get_coefficient(layer, port, 0);
-        weights[2 * (port * config.precoding.get_nof_layers() + layer)]     = w.real();
-        weights[2 * (port * config.precoding.get_nof_layers() + layer) + 1] = w.imag();
-      }
-    }
-    c.precoding = weights.data();
+    std::vector<float> weights;
+    nrphy_csi_rs_cfg_t c = to_pod(config, weights);
     srsran_assert(nrphy_csi_rs_validate(&c) == NRPHY_OK, "CSI-RS configuration outside rows 1-5 / wideband precoding.");
     std::fill(staging.begin(), staging.end(), cbf16_t());
     int rc = nrphy_csi_rs_map_host(ctx->get(), &c, staging.data(), nof_ports, nof_subc);

@@ -345,7 +345,7 @@ int ssb_first_symbol(uint32_t pattern_case, uint32_t idx)
 int ssb_first_subcarrier(const nrphy_ssb_pdu_t& p)
 {
   static const uint32_t block_scs_khz[5] = {15, 30, 30, 120, 240};
-  if (p.pattern_case > 4 || p.common_scs > 3 || p.offset_to_pointA > 2199) {
+  if (p.pattern_case > 4 || p.common_scs > 4 || p.offset_to_pointA > 2199) { // is_scs_valid: up to 240 kHz
     return -1;
   }
   const bool     fr2        = p.pattern_case >= 3;
@@ -617,6 +617,11 @@ extern "C" int nrphy_ssb_validate(const nrphy_ssb_pdu_t* p)
   }
   // ssb_processor_impl.cpp:41-44: the slot is the one of its half frame that holds the block
   if ((uint32_t)l / 14 != p->slot_index % ((10U << p->numerology) / 2)) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
+  // A case-E block that starts at symbol 12 of its slot would run past the 14 symbols of the slot grid (the reference
+  // writes outside its grid there): refused.
+  if ((uint32_t)l % 14 + 4 > 14) {
     return NRPHY_ERR_INVALID_PDU;
   }
   for (uint32_t i = 0; i != p->nof_ports; ++i) {

@@ -517,3 +517,51 @@ def demod_inputs(rng, modulation, n, kind):
         noise[rng.random(n) < 0.1] = -1
         noise[rng.random(n) < 0.05] = np.nan
     return sym.view(np.complex64).reshape(n), noise
+
+
+def struct_from_fixture(cls, g, key):
+    """A ctypes POD stored by tests/golden/generate.py as raw bytes (`<key>_pod`), with its precoding weights (`<key>_weights`)
+    re-attached when the struct has a `precoding` pointer."""
+    import ctypes as C
+    raw = g[key + "_pod"].tobytes()
+    assert len(raw) == C.sizeof(cls), "%s changed: regenerate the fixture" % cls.__name__
+    obj = cls.from_buffer_copy(raw)
+    if key + "_weights" in g:
+        f = np.ascontiguousarray(g[key + "_weights"], dtype=np.float32).reshape(-1)
+        obj._keepalive = f
+        obj.precoding = f.ctypes.data_as(C.POINTER(C.c_float))
+    return obj
+
+
+def seeded_grid(seed, *shape):
+    """A grid of finite bf16 pairs for tests that map into a non-empty grid."""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(shape + (2,)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def pdcch_encoder_payload_bits(index, E):
+    """Payload length rule for the pdcch_encoder_test_data.h cases (their message files are absent): 12 + 5 (index mod 24) bits,
+    at most 128 and at most E - 25 (the encoder needs K + 24 < E)."""
+    return int(max(12, min(12 + 5 * (index % 24), 128, E - 25)))
+
+
+def pbch_message_pdu(pod):
+    """pbch_encoder_test_data.h draws ssb_idx up to 63 with L_max 4 or 8, which no SS/PBCH block has; the encoder does not read
+    ssb_idx unless L_max = 64 (pbch_encoder_impl.cpp:62-75).  Returns the case-A block PDU this ABI accepts that produces the same
+    PBCH message: ssb_idx reduced modulo L_max, the slot that holds that candidate in the half frame of the header's HRF bit."""
+    pdu = type(pod).from_buffer_copy(bytes(pod))
+    assert pdu.L_max in (4, 8) and pdu.numerology == 0 and pdu.pattern_case == 0
+    hrf = pdu.slot_index >= 5
+    pdu.ssb_idx = pod.ssb_idx % pdu.L_max
+    l_first = (2, 8)[pdu.ssb_idx % 2] + 14 * (pdu.ssb_idx // 2)     # case A: {2, 8} + 14 n (ssb_mapping.h:46-52)
+    pdu.slot_index = l_first // 14 + (5 if hrf else 0)
+    return pdu
+
+
+def ssb_grid_rb(pdu):
+    """PRBs of a grid that holds the SS/PBCH block of `pdu`: its first subcarrier (ssb_get_k_first, ssb_mapping.h:116-167) plus
+    the block's 20 PRBs, at least 24."""
+    fr2 = pdu.pattern_case >= 3
+    scs = (15, 30, 30, 120, 240)[pdu.pattern_case]
+    k15 = (pdu.offset_to_pointA * 12 * (60 if fr2 else 15) + pdu.subcarrier_offset * ((15 << pdu.common_scs) if fr2 else 15)) // 15
+    return max(24, (k15 * 15 // scs + 240 + 11) // 12)

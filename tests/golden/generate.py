@@ -9,7 +9,7 @@ Sections: base (the round-1 files: codebooks, ldpc_encoder, pdsch_processor, ofd
 ofdm_sizes (DFT sizes 4608 / 6144: ofdm_sizes.npz), dl_control (PDCCH and SS/PBCH block processors: dl_control.npz),
 ref_test_configs (the configurations of the reference's own unit-test vectors, read from its test-data headers by
 oracle/ref/ref_testdata.cpp, with the compiled reference's outputs on seeded payloads: ref_test_configs.npz), demod (soft
-demodulator: demod.npz).
+demodulator: demod.npz), ref_test_configs2 (the same for the test-data headers of the round-2 components: ref_test_configs2.npz).
 """
 import hashlib
 import os
@@ -30,7 +30,7 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-SECTIONS = sys.argv[1:] or ["base", "ofdm_sizes", "dl_control", "ref_test_configs", "demod"]
+SECTIONS = sys.argv[1:] or ["base", "ofdm_sizes", "dl_control", "ref_test_configs", "demod", "ref_test_configs2"]
 
 
 def section_ofdm_sizes():
@@ -263,6 +263,164 @@ def section_demod():
     np.savez_compressed(os.path.join(HERE, "demod.npz"), **g)
 
 
+def section_ref_test_configs2():
+    """Configurations of the reference's unit-test headers for the components built in round 2 (oracle/ref/ref_testdata.cpp, 7-14),
+    payloads seeded here, expected outputs from the compiled reference:
+      pdcch_*  pdcch_processor_test_data.h (114): PDU verbatim (DCI payload included) -> grid hash
+      ssb_*    ssb_processor_test_data.h (240): PDU verbatim -> grid hash
+      csi_*    nzp_csi_rs_generator_test_data.h (102): configuration verbatim -> grid hash (rows 1-5; the others are recorded as
+               outside this library's rows and must be refused)
+      dm_*     demodulation_mapper_test_data.h (12): (symbols, modulation) -> soft-bit hash on seeded inputs
+      od_*     ofdm_demodulator_test_data.h (20): configuration, slot, window offset -> grid on seeded IQ
+      ofh_*    ofh_compression_test_data.h (36): (PRBs, type, width, scaling) -> bytes hash on seeded PRBs
+      pe_*     pdcch_encoder_test_data.h (29): (E, RNTI) -> encoded-bits hash, payload length by cases.pdcch_encoder_payload_bits
+      pb_*     pbch_encoder_test_data.h (232): message as the block PDU that produces it -> 864 encoded bits hash."""
+    import ctypes as C
+    import cases
+    h = r.lib
+    o = backends.oracle()
+    g = {}
+
+    def raw(obj):
+        return np.frombuffer(bytes(obj), np.uint8).copy()
+
+    # 7. PDCCH processor
+    fn = h.ref_testdata_pdcch_processor
+    n = fn(0, None, None, 0)
+    flags = []
+    for i in range(n):
+        pdu = abi.PdcchPdu()
+        w = np.zeros(2 * 16 * 4, np.float32)
+        nw = fn(i, C.byref(pdu), w.ctypes.data_as(C.c_void_p), w.size)
+        assert nw > 0
+        g["pdcch_%d_pod" % i], g["pdcch_%d_weights" % i] = raw(pdu), w[:nw].copy()
+        pdu = cases.struct_from_fixture(abi.PdcchPdu, g, "pdcch_%d" % i)
+        ok = o.pdcch_validate(pdu) == 0
+        flags.append(int(ok))
+        if ok:
+            nof_rb = pdu.bwp_start_rb + pdu.bwp_size_rb
+            grid = cases.seeded_grid([7, i], pdu.nof_ports, 14, nof_rb * 12)
+            g["pdcch_%d_sha" % i] = np.array(sha(r.pdcch_process(pdu, grid)))
+    g["pdcch_valid"] = np.array(flags, np.uint8)
+
+    # 8. SS/PBCH block processor
+    fn = h.ref_testdata_ssb_processor
+    n = fn(0, None)
+    flags = []
+    for i in range(n):
+        pdu = abi.SsbPdu()
+        fn(i, C.byref(pdu))
+        # The reference's unit test writes into a spy grid that takes any port index (the header's cases carry indices up to
+        # 63); this ABI's grids have at most four ports: the block's ports are renumbered 0, 1, ... (the index only selects
+        # the grid plane, the values do not depend on it).  The original indices are kept for the record.
+        g["ssb_%d_ports" % i] = np.array(list(pdu.ports)[: pdu.nof_ports], np.uint8)
+        for k in range(pdu.nof_ports):
+            pdu.ports[k] = k
+        g["ssb_%d_pod" % i] = raw(pdu)
+        ok = o.ssb_validate(pdu) == 0
+        flags.append(int(ok))
+        if ok:
+            ports = max(list(pdu.ports)[: pdu.nof_ports]) + 1
+            nof_rb = cases.ssb_grid_rb(pdu)
+            g["ssb_%d_rb" % i] = np.array(nof_rb)
+            grid = cases.seeded_grid([8, i], ports, 14, nof_rb * 12)
+            g["ssb_%d_sha" % i] = np.array(sha(r.ssb_process(pdu, grid)))
+    g["ssb_valid"] = np.array(flags, np.uint8)
+
+    # 9. NZP-CSI-RS generator
+    fn = h.ref_testdata_nzp_csi_rs
+    n = fn(0, None, None, 0)
+    flags = []
+    for i in range(n):
+        cfg = abi.CsiRsCfg()
+        w = np.zeros(2 * 32 * 32, np.float32)
+        nw = fn(i, C.byref(cfg), w.ctypes.data_as(C.c_void_p), w.size)
+        assert nw > 0
+        g["csi_%d_pod" % i], g["csi_%d_weights" % i] = raw(cfg), w[:nw].copy()
+        cfg = cases.struct_from_fixture(abi.CsiRsCfg, g, "csi_%d" % i)
+        ok = o.csi_rs_validate(cfg) == 0
+        flags.append(int(ok))
+        if ok:
+            grid = cases.seeded_grid([9, i], cfg.nof_ports, 14, (cfg.start_rb + cfg.nof_rb) * 12)
+            g["csi_%d_sha" % i] = np.array(sha(r.csi_rs_map(cfg, grid)))
+    g["csi_valid"] = np.array(flags, np.uint8)
+
+    # 10. demodulation mapper
+    fn = h.ref_testdata_demodulation_mapper
+    n = fn(0, None)
+    rows, shas = [], []
+    for i in range(n):
+        c = (C.c_uint * 2)()
+        fn(i, c)
+        sym, noise = cases.demod_inputs(np.random.default_rng([10, i]), int(c[1]), int(c[0]), 0)
+        rows.append([c[0], c[1]])
+        shas.append(sha(r.demodulate_soft(int(c[1]), sym, noise)))
+    g["dm_cases"], g["dm_sha"] = np.array(rows, np.uint32), np.array(shas)
+
+    # 11. OFDM demodulator
+    fn = h.ref_testdata_ofdm_demodulator
+    n = fn(0, None, None)
+    rows = []
+    for i in range(n):
+        cfg = abi.OfdmConfig()
+        extra = (C.c_uint * 3)()
+        fn(i, C.byref(cfg), extra)
+        size = backends.pkg.lib.slot_size(cfg, int(extra[1]))
+        rng = np.random.default_rng([11, i])
+        iq = (rng.standard_normal((1, size)) + 1j * rng.standard_normal((1, size))).astype(np.complex64)
+        rows.append([cfg.numerology, cfg.bw_rb, cfg.dft_size, cfg.cp, cfg.scale, cfg.center_freq_hz, extra[0], extra[1], extra[2], size])
+        g["od_%d_grid" % i] = r.ofdm_demod_slot(cfg, iq, int(extra[1]), int(extra[2]))
+    g["od_cases"] = np.array(rows, np.float64)
+
+    # 12. OFH compression
+    fn = h.ref_testdata_ofh_compression
+    n = fn(0, None, None)
+    rows, shas = [], []
+    for i in range(n):
+        c = (C.c_uint * 3)()
+        sc = C.c_float()
+        fn(i, c, C.byref(sc))
+        rows.append([c[0], c[1], c[2], sc.value])
+        if c[1] > 1 or c[2] < 8:
+            shas.append("")   # a compression type / width outside this library's ABI
+            continue
+        cfg = abi.OfhCompressionCfg(int(c[1]), int(c[2]), float(sc.value))
+        prbs = cases.seeded_grid([12, i], int(c[0]), 12)
+        a, b = r.ofh_compress(cfg, prbs, simd=1), r.ofh_compress(cfg, prbs, simd=0)
+        shas.append(sha(a))
+        g["ofh_%d_generic_differs" % i] = np.array(int(not np.array_equal(a, b)))
+    g["ofh_cases"], g["ofh_sha"] = np.array(rows, np.float64), np.array(shas)
+
+    # 13. PDCCH encoder
+    fn = h.ref_testdata_pdcch_encoder
+    n = fn(0, None)
+    rows, shas = [], []
+    for i in range(n):
+        c = (C.c_uint * 2)()
+        fn(i, c)
+        k = cases.pdcch_encoder_payload_bits(i, int(c[0]))
+        payload = np.random.default_rng([13, i]).integers(0, 2, k, dtype=np.uint8)
+        rows.append([c[0], c[1], k])
+        shas.append(sha(r.pdcch_encode(payload, int(c[1]), int(c[0]))))
+    g["pe_cases"], g["pe_sha"] = np.array(rows, np.uint32), np.array(shas)
+
+    # 14. PBCH encoder
+    fn = h.ref_testdata_pbch_encoder
+    n = fn(0, None)
+    shas = []
+    for i in range(n):
+        pdu = abi.SsbPdu()
+        fn(i, C.byref(pdu))
+        g["pb_%d_pod" % i] = raw(pdu)
+        shas.append(sha(r.pbch_encode(pdu)))
+    g["pb_sha"] = np.array(shas)
+    np.savez_compressed(os.path.join(HERE, "ref_test_configs2.npz"), **g)
+    print("ref_test_configs2:", {k: (int(np.sum(g[k])), len(g[k])) for k in ("pdcch_valid", "ssb_valid", "csi_valid")},
+          len(g["dm_sha"]), len(g["od_cases"]), len(g["ofh_sha"]), len(g["pe_sha"]), len(g["pb_sha"]))
+
+
+if "ref_test_configs2" in SECTIONS:
+    section_ref_test_configs2()
 if "demod" in SECTIONS:
     section_demod()
 if "ref_test_configs" in SECTIONS:

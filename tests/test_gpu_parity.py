@@ -2015,3 +2015,41 @@ def test_whole_slot_chain_in_a_hip_graph(gpu_ctx, oracle):
         assert np.array_equal(d_grid[0].cpu().numpy().view(np.uint16).reshape(nof_ports, 14, nof_subc, 2), want)
     plan.close()
     oplan.close()
+
+
+# ---- the reference's unit-test configurations of the round-2 components (tests/golden/ref_test_configs2.npz) ----------------
+class DeviceApi2:
+    """The calls test_oracle.check_ref_test_configs2 needs, through the C ABI."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.pdcch_process, self.pdcch_encode = ctx.pdcch_process_host, ctx.pdcch_encode_host
+        self.ssb_process, self.pbch_encode = ctx.ssb_process_host, ctx.pbch_encode_host
+        self.csi_rs_map, self.demodulate_soft, self.ofh_compress = ctx.csi_rs_map_host, ctx.demodulate_soft_host, ctx.ofh_compress_host
+
+    def pdcch_validate(self, pdu):
+        return self.ctx.lib.nrphy_pdcch_validate(C.byref(pdu))
+
+    def ssb_validate(self, pdu):
+        return self.ctx.lib.nrphy_ssb_validate(C.byref(pdu))
+
+    def csi_rs_validate(self, cfg):
+        return self.ctx.lib.nrphy_csi_rs_validate(C.byref(cfg))
+
+    def ofdm_demod_slot(self, cfg, iq, slot_index, window_offset):
+        plan = lib.OfdmPlan(self.ctx, cfg, iq.shape[0])
+        try:
+            return plan.demodulate_slot_host(iq, slot_index, window_offset)
+        finally:
+            plan.close()
+
+
+@pytest.mark.parametrize("what", ["pdcch", "ssb", "csi", "dm", "od", "ofh", "pe", "pb"])
+def test_ref_test_configs2(gpu_ctx, what):
+    """All 114 / 240 / 102 / 12 / 20 / 36 / 29 / 232 configurations of the pdcch_processor, ssb_processor, nzp_csi_rs_generator,
+    demodulation_mapper, ofdm_demodulator, ofh_compression, pdcch_encoder and pbch_encoder test-data headers on the device; expected
+    values from the compiled reference (12 case-E blocks that cross the slot boundary are refused, compression types outside the ABI
+    are skipped as recorded in the fixture)."""
+    import test_oracle
+    g = np.load(os.path.join(cases.GOLDEN, "ref_test_configs2.npz"))
+    test_oracle.check_ref_test_configs2(DeviceApi2(gpu_ctx), g, what)

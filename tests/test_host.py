@@ -220,6 +220,27 @@ def test_reference_unit_test_configurations_host_side():
         assert (d["nof_codeblocks"], d["segment_length"]) == (nof_segments, segment_length)
 
 
+def test_reference_unit_test_configurations_round2_host_side():
+    """The product's PDCCH / SS-PBCH / NZP-CSI-RS validators (host logic) on every configuration of
+    tests/golden/ref_test_configs2.npz: accepted or refused exactly as the fixture records and as the oracle decides."""
+    import ctypes as C
+    import os
+    g = np.load(os.path.join(cases.GOLDEN, "ref_test_configs2.npz"))
+    o, abi = backends.oracle(), backends.abi
+    h = backends.pkg.lib.load()
+    for kind, cls, n, product, oracle in (("pdcch", abi.PdcchPdu, 114, h.nrphy_pdcch_validate, o.pdcch_validate),
+                                          ("ssb", abi.SsbPdu, 240, h.nrphy_ssb_validate, o.ssb_validate),
+                                          ("csi", abi.CsiRsCfg, 102, h.nrphy_csi_rs_validate, o.csi_rs_validate)):
+        flags = g[kind + "_valid"]
+        assert flags.shape == (n,)
+        for i in range(n):
+            obj = cases.struct_from_fixture(cls, g, "%s_%d" % (kind, i))
+            assert (product(C.byref(obj)) == 0) == bool(flags[i]) == (oracle(obj) == 0), (kind, i)
+    for i in range(232):
+        pdu = cases.pbch_message_pdu(cases.struct_from_fixture(abi.SsbPdu, g, "pb_%d" % i))
+        assert h.nrphy_ssb_validate(C.byref(pdu)) == 0, i
+
+
 def test_host_only_helpers_of_the_lower_phy_tail():
     """Entry points that are pure host arithmetic: nrphy_amplitude_metrics (amplitude_controller_clipping_impl's metrics from
     the device's raw measurements, running counters included) against the compiled reference where it is built and against the

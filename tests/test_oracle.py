@@ -827,3 +827,106 @@ def test_demodulation_mapper_tables_are_max_log_llrs(oracle):
             one = labels[:, pair] == 1
             want = d[:, one].min(axis=1) - d[:, ~one].min(axis=1)
             assert np.abs(got - want).max() < 1e-5, (qm, pair)
+
+
+# ---- the reference's unit-test configurations of the round-2 components (tests/golden/ref_test_configs2.npz) ----------------
+# Same scheme as above for the other downlink grid writers, the receive-side front end and the fronthaul compressor:
+# configurations from the headers (oracle/ref/ref_testdata.cpp, sections 7-14), expected outputs from the compiled reference.
+
+@pytest.fixture(scope="module")
+def ref_cfgs2():
+    return np.load(os.path.join(cases.GOLDEN, "ref_test_configs2.npz"))
+
+
+class OracleApi2:
+    """The calls check_ref_test_configs2 needs, on the oracle (test_gpu_parity.py has the same over the C ABI)."""
+
+    def __init__(self, o):
+        self.o = o
+        self.pdcch_validate, self.pdcch_process, self.pdcch_encode = o.pdcch_validate, o.pdcch_process, o.pdcch_encode
+        self.ssb_validate, self.ssb_process, self.pbch_encode = o.ssb_validate, o.ssb_process, o.pbch_encode
+        self.csi_rs_validate, self.csi_rs_map = o.csi_rs_validate, o.csi_rs_map
+        self.demodulate_soft, self.ofdm_demod_slot = o.demodulate_soft, o.ofdm_demod_slot
+
+    def ofh_compress(self, cfg, prbs):
+        return self.o.ofh_compress(cfg, prbs, simd=1)
+
+
+def check_ref_test_configs2(api, g, what):
+    abi = backends.abi
+    if what == "pdcch":
+        assert g["pdcch_valid"].shape == (114,) and int(g["pdcch_valid"].sum()) == 114
+        for i in range(114):
+            pdu = cases.struct_from_fixture(abi.PdcchPdu, g, "pdcch_%d" % i)
+            assert api.pdcch_validate(pdu) == 0, i
+            grid = cases.seeded_grid([7, i], pdu.nof_ports, 14, (pdu.bwp_start_rb + pdu.bwp_size_rb) * 12)
+            assert sha(api.pdcch_process(pdu, grid)) == str(g["pdcch_%d_sha" % i]), i
+    elif what == "ssb":
+        assert g["ssb_valid"].shape == (240,) and int(g["ssb_valid"].sum()) == 228
+        for i in range(240):
+            pdu = cases.struct_from_fixture(abi.SsbPdu, g, "ssb_%d" % i)
+            if not g["ssb_valid"][i]:
+                # pattern case E, block starting at symbol 12: runs past the slot grid (the header's spy grid does not mind)
+                assert pdu.pattern_case == 4 and api.ssb_validate(pdu) != 0, i
+                continue
+            assert api.ssb_validate(pdu) == 0, i
+            grid = cases.seeded_grid([8, i], pdu.nof_ports, 14, int(g["ssb_%d_rb" % i]) * 12)
+            assert sha(api.ssb_process(pdu, grid)) == str(g["ssb_%d_sha" % i]), i
+    elif what == "csi":
+        assert g["csi_valid"].shape == (102,) and int(g["csi_valid"].sum()) == 102
+        for i in range(102):
+            cfg = cases.struct_from_fixture(abi.CsiRsCfg, g, "csi_%d" % i)
+            assert api.csi_rs_validate(cfg) == 0, i
+            grid = cases.seeded_grid([9, i], cfg.nof_ports, 14, (cfg.start_rb + cfg.nof_rb) * 12)
+            assert sha(api.csi_rs_map(cfg, grid)) == str(g["csi_%d_sha" % i]), i
+    elif what == "dm":
+        assert g["dm_cases"].shape == (12, 2)
+        for i, (n, modulation) in enumerate(g["dm_cases"].tolist()):
+            sym, noise = cases.demod_inputs(np.random.default_rng([10, i]), modulation, n, 0)
+            assert sha(api.demodulate_soft(modulation, sym, noise)) == str(g["dm_sha"][i]), i
+    elif what == "od":
+        assert g["od_cases"].shape == (20, 10)
+        for i, row in enumerate(g["od_cases"]):
+            cfg = abi.OfdmConfig(int(row[0]), int(row[1]), int(row[2]), int(row[3]), float(row[4]), float(row[5]))
+            slot, window, size = int(row[7]), int(row[8]), int(row[9])
+            rng = np.random.default_rng([11, i])
+            iq = (rng.standard_normal((1, size)) + 1j * rng.standard_normal((1, size))).astype(np.complex64)
+            want = g["od_%d_grid" % i]
+            got = api.ofdm_demod_slot(cfg, iq, slot, window)
+            assert got.shape == want.shape, i
+            assert_bf16_grids_close(got, want)   # cbf16 out of two float FFTs: within a bf16 ulp, 99 % identical
+    elif what == "ofh":
+        assert g["ofh_cases"].shape == (36, 4)
+        ran = 0
+        for i, (nof_prb, ctype, width, scaling) in enumerate(g["ofh_cases"].tolist()):
+            if str(g["ofh_sha"][i]) == "":
+                continue   # a compression type the ABI does not have (the reference builds none/BFP only, too) or width < 8
+            cfg = abi.OfhCompressionCfg(int(ctype), int(width), float(scaling))
+            prbs = cases.seeded_grid([12, i], int(nof_prb), 12)
+            assert sha(api.ofh_compress(cfg, prbs)) == str(g["ofh_sha"][i]), i
+            ran += 1
+        assert ran >= 12
+    elif what == "pe":
+        assert g["pe_cases"].shape == (29, 3)
+        for i, (E, rnti, k) in enumerate(g["pe_cases"].tolist()):
+            assert k == cases.pdcch_encoder_payload_bits(i, E)
+            payload = np.random.default_rng([13, i]).integers(0, 2, k, dtype=np.uint8)
+            assert sha(api.pdcch_encode(payload, rnti, E)) == str(g["pe_sha"][i]), i
+    elif what == "pb":
+        assert g["pb_sha"].shape == (232,)
+        for i in range(232):
+            pdu = cases.pbch_message_pdu(cases.struct_from_fixture(abi.SsbPdu, g, "pb_%d" % i))
+            assert sha(api.pbch_encode(pdu)) == str(g["pb_sha"][i]), i
+    else:
+        raise KeyError(what)
+
+
+REF_TEST_CONFIGS2 = ("pdcch", "ssb", "csi", "dm", "od", "ofh", "pe", "pb")
+
+
+@pytest.mark.parametrize("what", REF_TEST_CONFIGS2)
+def test_ref_test_configs2(oracle, ref_cfgs2, what):
+    """pdcch_processor (114), ssb_processor (240, of which 12 case-E blocks cross the slot boundary and are refused),
+    nzp_csi_rs_generator (102), demodulation_mapper (12), ofdm_demodulator (20), ofh_compression (36), pdcch_encoder (29) and
+    pbch_encoder (232) test-data headers on the oracle."""
+    check_ref_test_configs2(OracleApi2(oracle), ref_cfgs2, what)
