@@ -12,7 +12,8 @@ import numpy as np
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmi355nrphy.so")
+# NRPHY_LIB_SO: another build of the same library (A/B variants, the host-sanitizer build of profiles/sanitize_cpu.sh)
+LIB_PATH = os.environ.get("NRPHY_LIB_SO") or os.path.join(HERE, "csrc", "libmi355nrphy.so")
 
 _LIB = None
 

@@ -452,8 +452,11 @@ _REF = None
 
 def build_oracle():
     """Compiles oracle/liboracle.so when missing or stale (gcc, a second or two)."""
+    if os.environ.get("NRPHY_ORACLE_SO"):      # e.g. the sanitizer build (oracle/Makefile: make sanitize)
+        return os.path.abspath(os.environ["NRPHY_ORACLE_SO"])
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", n) for n in ("nrphy_oracle.c", "nrphy_oracle_dl.c", "nrphy_oracle_lower.c", "nrphy_oracle.h")]
+    srcs = [os.path.join(ROOT, "oracle", n) for n in ("nrphy_oracle.c", "nrphy_oracle_dl.c", "nrphy_oracle_lower.c", "nrphy_oracle_rx.c",
+                                                       "nrphy_oracle.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], check=True, capture_output=True,
                        timeout=300)
