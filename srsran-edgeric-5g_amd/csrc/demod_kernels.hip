@@ -27,10 +27,9 @@ __device__ __forceinline__ int quantize_generic(float value, float range)
 // mm256::quantize_ps (R/lib/phy/upper/channel_modulation/avx2_helpers.h:118-170): scale, clip, nearest even, NaN -> 0.
 __device__ __forceinline__ int quantize_vector(float value, float scale /* 120 / range */)
 {
-  float v = __fmul_rn(value, scale);
-  v       = v > LLR_MAXF ? LLR_MAXF : v;
-  v       = v < -LLR_MAXF ? -LLR_MAXF : v;
-  return v != v ? 0 : (int)rintf(v);
+  const float v = __fmul_rn(value, scale);
+  const float c = __builtin_fmaxf(-LLR_MAXF, __builtin_fminf(v, LLR_MAXF)); // v_med3_f32; a NaN is replaced below
+  return v != v ? 0 : (int)rintf(c);
 }
 
 __device__ __forceinline__ float safe_rcp(float noise)
@@ -39,121 +38,150 @@ __device__ __forceinline__ float safe_rcp(float noise)
 }
 
 struct Tables {
-  float slope[DEMOD_MAX_PAIRS][16], intercept[DEMOD_MAX_PAIRS][16];
+  float2 line[DEMOD_MAX_PAIRS][16]; // (slope, intercept) of an interval: one 8-byte LDS read per soft bit
 };
 
-// One component (real or imaginary part) of a table-driven constellation, bit pair p.
-__device__ __forceinline__ int interval_llr(const DemodLaunch& p, const Tables& t, uint32_t pair, float v, float rcp, bool vector)
+// The soft bits of a thread (up to 16) collected in registers: byte k of the thread's output.  Every index is a compile-time
+// constant after unrolling (a byte array here ends up in LDS, one ds_write_b8 per soft bit).
+struct LlrBytes {
+  uint32_t w[4] = {0, 0, 0, 0};
+  __device__ __forceinline__ void put(uint32_t k, int v) { w[k >> 2] |= ((uint32_t)v & 0xFFu) << (8u * (k & 3u)); }
+  __device__ __forceinline__ uint8_t get(uint32_t k) const { return (uint8_t)(w[k >> 2] >> (8u * (k & 3u))); }
+};
+
+// One component (real or imaginary part) of a table-driven constellation, bit pair `pair`.  VECTOR: the reference's AVX2
+// arithmetic (reciprocal width, nearest-even quantiser), else its generic one.
+template <bool VECTOR>
+__device__ __forceinline__ int interval_llr(const DemodLaunch& p, const Tables& t, uint32_t pair, float v, float rcp)
 {
-  const int   n   = (int)p.nof_intervals[pair];
-  const float pos = vector ? __fmul_rn(v, p.rcp_width[pair]) : __fdiv_rn(v, p.width[pair]);
-  int         idx = (int)floorf(pos) + n / 2;
-  idx             = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
-  const float l   = __fmul_rn(__fmaf_rn(t.slope[pair][idx], v, t.intercept[pair][idx]), rcp);
-  if (vector) {
+  const int    n    = (int)p.nof_intervals[pair];
+  const float  pos  = VECTOR ? __fmul_rn(v, p.rcp_width[pair]) : __fdiv_rn(v, p.width[pair]);
+  const int    idx  = max(0, min((int)floorf(pos) + n / 2, n - 1));
+  const float2 line = t.line[pair][idx];
+  const float  l    = __fmul_rn(__fmaf_rn(line.x, v, line.y), rcp);
+  if (VECTOR) {
     return quantize_vector(fabsf(v) <= NEAR_ZERO ? 0.f : l, p.scale);
   }
   return quantize_generic(l, p.range);
 }
 
-// The soft bits of one symbol into out[0 .. qm).
+// The soft bits of symbol i of its span into bytes [at, at + qm) of out.  The kernel is specialised per modulation (no run-time
+// switch, the bit-pair loop unrolled) and per arithmetic: a thread whose symbols all lie in the span's vector part -- every
+// thread but the last few of a span -- runs the VECTOR copy.
+template <uint32_t MOD, bool VECTOR>
 __device__ __forceinline__ void demodulate_symbol(const DemodLaunch& p, const Tables& t, uint32_t i, float re, float im, float noise,
-                                                  int8_t* out)
+                                                  LlrBytes& out, uint32_t at)
 {
-  const bool  vector = i < p.nof_vector;
   constexpr float GAIN_PSK = 2.0f * 1.41421356237309504880f;
-  switch (p.modulation) {
-    case NRPHY_MOD_BPSK:
-    case NRPHY_MOD_PI2_BPSK: {
-      // pi/2-BPSK: odd symbols are rotated by -90 degrees first, (im, -re)
-      const bool  rot = p.modulation == NRPHY_MOD_PI2_BPSK && (i & 1u);
-      const float a = rot ? im : re, b = rot ? -re : im;
-      out[0] = !(noise > 0.f) ? 0 : (int8_t)quantize_generic(__fdiv_rn(__fmul_rn(GAIN_PSK, __fadd_rn(a, b)), noise), p.range);
-      break;
-    }
-    case NRPHY_MOD_QPSK: {
+  if constexpr (MOD == NRPHY_MOD_BPSK || MOD == NRPHY_MOD_PI2_BPSK) {
+    // pi/2-BPSK: odd symbols are rotated by -90 degrees first, (im, -re)
+    const bool  rot = MOD == NRPHY_MOD_PI2_BPSK && (i & 1u);
+    const float a = rot ? im : re, b = rot ? -re : im;
+    out.put(at, !(noise > 0.f) ? 0 : quantize_generic(__fdiv_rn(__fmul_rn(GAIN_PSK, __fadd_rn(a, b)), noise), p.range));
+  } else if constexpr (MOD == NRPHY_MOD_QPSK) {
 #pragma unroll
-      for (int c = 0; c != 2; ++c) {
-        const float v = c ? im : re;
-        if (vector) {
-          out[c] = (int8_t)quantize_vector(__fmul_rn(__fmul_rn(GAIN_PSK, v), safe_rcp(noise)), p.scale);
-        } else {
-          out[c] = !(noise > 0.f) ? 0 : (int8_t)quantize_generic(__fdiv_rn(__fmul_rn(GAIN_PSK, v), noise), p.range);
-        }
+    for (uint32_t c = 0; c != 2; ++c) {
+      const float v = c ? im : re;
+      if (VECTOR) {
+        out.put(at + c, quantize_vector(__fmul_rn(__fmul_rn(GAIN_PSK, v), safe_rcp(noise)), p.scale));
+      } else {
+        out.put(at + c, !(noise > 0.f) ? 0 : quantize_generic(__fdiv_rn(__fmul_rn(GAIN_PSK, v), noise), p.range));
       }
-      break;
     }
-    case NRPHY_MOD_QAM16: {
-      const float g1 = p.qam16_gain, thr = p.qam16_threshold;
-      const bool  blank = !vector && __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)) < NEAR_ZERO;
+  } else if constexpr (MOD == NRPHY_MOD_QAM16) {
+    const float g1 = p.qam16_gain, thr = p.qam16_threshold;
+    const bool  blank = !VECTOR && __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)) < NEAR_ZERO;
 #pragma unroll
-      for (int c = 0; c != 2; ++c) {
-        const float v     = c ? im : re;
-        const float first = __fmul_rn(g1, v);
-        // 2 * first is exact, so the reference's contracted and uncontracted forms agree
-        const float l01 = fabsf(v) > thr ? __fsub_rn(__fmul_rn(2.0f, first), copysignf(0.8f, v)) : first;
-        if (vector) {
-          const float rcp  = safe_rcp(noise);
-          const bool  zero = fabsf(v) <= NEAR_ZERO;
-          out[c]           = (int8_t)quantize_vector(zero ? 0.f : __fmul_rn(l01, rcp), p.scale);
-          out[2 + c]       = (int8_t)quantize_vector(zero ? 0.f : __fmul_rn(__fsub_rn(0.8f, fabsf(first)), rcp), p.scale);
-        } else if (blank || !(noise > 0.f)) {
-          out[c] = out[2 + c] = 0;
-        } else {
-          out[c]     = (int8_t)quantize_generic(__fdiv_rn(l01, noise), p.range);
-          out[2 + c] = (int8_t)quantize_generic(__fdiv_rn(__fmaf_rn(-g1, fabsf(v), 0.8f), noise), p.range); // contracted there
-        }
+    for (uint32_t c = 0; c != 2; ++c) {
+      const float v     = c ? im : re;
+      const float first = __fmul_rn(g1, v);
+      // 2 * first is exact, so the reference's contracted and uncontracted forms agree
+      const float l01 = fabsf(v) > thr ? __fsub_rn(__fmul_rn(2.0f, first), copysignf(0.8f, v)) : first;
+      if (VECTOR) {
+        const float rcp  = safe_rcp(noise);
+        const bool  zero = fabsf(v) <= NEAR_ZERO;
+        out.put(at + c, quantize_vector(zero ? 0.f : __fmul_rn(l01, rcp), p.scale));
+        out.put(at + 2u + c, quantize_vector(zero ? 0.f : __fmul_rn(__fsub_rn(0.8f, fabsf(first)), rcp), p.scale));
+      } else if (!(blank || !(noise > 0.f))) {
+        out.put(at + c, quantize_generic(__fdiv_rn(l01, noise), p.range));
+        out.put(at + 2u + c, quantize_generic(__fdiv_rn(__fmaf_rn(-g1, fabsf(v), 0.8f), noise), p.range)); // contracted there
       }
-      break;
     }
-    default: { // 64-QAM, 256-QAM
-      const uint32_t pairs = p.modulation / 2u;
-      const float    rcp   = safe_rcp(noise);
-      const bool     blank = !vector && __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)) < NEAR_ZERO;
-      for (uint32_t k = 0; k != pairs; ++k) {
-        out[2 * k]     = blank ? 0 : (int8_t)interval_llr(p, t, k, re, rcp, vector);
-        out[2 * k + 1] = blank ? 0 : (int8_t)interval_llr(p, t, k, im, rcp, vector);
-      }
+  } else { // 64-QAM, 256-QAM
+    constexpr uint32_t pairs = MOD / 2u;
+    const float        rcp   = safe_rcp(noise);
+    const bool         blank = !VECTOR && __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)) < NEAR_ZERO;
+#pragma unroll
+    for (uint32_t k = 0; k != pairs; ++k) {
+      out.put(at + 2u * k, blank ? 0 : interval_llr<VECTOR>(p, t, k, re, rcp));
+      out.put(at + 2u * k + 1u, blank ? 0 : interval_llr<VECTOR>(p, t, k, im, rcp));
     }
   }
 }
 
+template <uint32_t MOD>
 __global__ __launch_bounds__(256) void demodulate_soft_kernel(DemodLaunch p, const float2* __restrict__ d_symbols,
                                                               const float* __restrict__ d_noise, int8_t* __restrict__ d_llr)
 {
   __shared__ Tables t;
-  for (uint32_t k = threadIdx.x; k < DEMOD_MAX_PAIRS * 16u; k += blockDim.x) {
-    t.slope[k / 16u][k % 16u]     = p.slope[k / 16u][k % 16u];
-    t.intercept[k / 16u][k % 16u] = p.intercept[k / 16u][k % 16u];
+  if constexpr (MOD >= NRPHY_MOD_QAM64) {
+    for (uint32_t k = threadIdx.x; k < DEMOD_MAX_PAIRS * 16u; k += blockDim.x) {
+      t.line[k / 16u][k % 16u] = make_float2(p.slope[k / 16u][k % 16u], p.intercept[k / 16u][k % 16u]);
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  const uint32_t span  = blockIdx.y;
-  const uint32_t qm    = p.modulation == NRPHY_MOD_PI2_BPSK ? 1u : p.modulation;
-  const uint32_t first = 2u * (blockIdx.x * blockDim.x + threadIdx.x); // the thread's first symbol
+  constexpr uint32_t qm    = MOD == NRPHY_MOD_PI2_BPSK ? 1u : MOD;
+  const uint32_t     span  = blockIdx.y;
+  const uint32_t     first = 2u * (blockIdx.x * blockDim.x + threadIdx.x); // the thread's first symbol
   if (first >= p.span_len) {
     return;
   }
   const uint32_t count = first + 1u < p.span_len ? 2u : 1u;
   const size_t   base  = (size_t)span * p.span_len + first;
-  alignas(16) int8_t out[16];
+  LlrBytes       out;
+  if (count == 2u && first + 2u <= p.nof_vector) {
+    // two symbols of the vector part: one 16-byte and one 8-byte load where the addresses allow
+    float2 z0, z1;
+    float  n0, n1;
+    if (((reinterpret_cast<uintptr_t>(d_symbols + base) & 15u) | (reinterpret_cast<uintptr_t>(d_noise + base) & 7u)) == 0) {
+      const float4 zz = *reinterpret_cast<const float4*>(d_symbols + base);
+      const float2 nn = *reinterpret_cast<const float2*>(d_noise + base);
+      z0 = make_float2(zz.x, zz.y), z1 = make_float2(zz.z, zz.w), n0 = nn.x, n1 = nn.y;
+    } else {
+      z0 = d_symbols[base], z1 = d_symbols[base + 1], n0 = d_noise[base], n1 = d_noise[base + 1];
+    }
+    demodulate_symbol<MOD, true>(p, t, first, z0.x, z0.y, n0, out, 0);
+    demodulate_symbol<MOD, true>(p, t, first + 1u, z1.x, z1.y, n1, out, qm);
+  } else {
 #pragma unroll
-  for (uint32_t s = 0; s != 2; ++s) {
-    if (s < count) {
-      const float2 z = d_symbols[base + s];
-      demodulate_symbol(p, t, first + s, z.x, z.y, d_noise[base + s], out + s * qm);
+    for (uint32_t s = 0; s != 2; ++s) {
+      if (s < count) {
+        const float2 z = d_symbols[base + s];
+        if (first + s < p.nof_vector) {
+          demodulate_symbol<MOD, true>(p, t, first + s, z.x, z.y, d_noise[base + s], out, s * qm);
+        } else {
+          demodulate_symbol<MOD, false>(p, t, first + s, z.x, z.y, d_noise[base + s], out, s * qm);
+        }
+      }
     }
   }
   int8_t*        dst    = d_llr + base * qm;
   const uint32_t nbytes = count * qm;
-  if (nbytes == 16u && ((uintptr_t)dst & 15u) == 0) {
-    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(out);
-  } else if ((nbytes & 3u) == 0 && ((uintptr_t)dst & 3u) == 0) {
-    for (uint32_t k = 0; k != nbytes / 4u; ++k) {
-      reinterpret_cast<uint32_t*>(dst)[k] = reinterpret_cast<const uint32_t*>(out)[k];
+  if (nbytes == 16u && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+    *reinterpret_cast<uint4*>(dst) = make_uint4(out.w[0], out.w[1], out.w[2], out.w[3]);
+  } else if ((nbytes & 3u) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0) {
+#pragma unroll
+    for (uint32_t k = 0; k != 4; ++k) {
+      if (4u * k < nbytes) {
+        reinterpret_cast<uint32_t*>(dst)[k] = out.w[k];
+      }
     }
   } else {
-    for (uint32_t k = 0; k != nbytes; ++k) {
-      dst[k] = out[k];
+#pragma unroll
+    for (uint32_t k = 0; k != 16; ++k) {
+      if (k < nbytes) {
+        dst[k] = (int8_t)out.get(k);
+      }
     }
   }
 }
@@ -164,8 +192,30 @@ hipError_t launch_demodulate_soft(const DemodLaunch& p, uint32_t nof_spans, cons
                                   int8_t* d_llr, hipStream_t stream)
 {
   const uint32_t pairs  = (p.span_len + 1u) / 2u;
-  hipLaunchKernelGGL(demodulate_soft_kernel, dim3((pairs + 255u) / 256u, nof_spans), dim3(256), 0, stream, p,
-                     reinterpret_cast<const float2*>(d_symbols), d_noise, d_llr);
+  const dim3     grid((pairs + 255u) / 256u, nof_spans), block(256);
+  const float2*  sym = reinterpret_cast<const float2*>(d_symbols);
+  switch (p.modulation) {
+    case NRPHY_MOD_PI2_BPSK:
+      hipLaunchKernelGGL(demodulate_soft_kernel<NRPHY_MOD_PI2_BPSK>, grid, block, 0, stream, p, sym, d_noise, d_llr);
+      break;
+    case NRPHY_MOD_BPSK:
+      hipLaunchKernelGGL(demodulate_soft_kernel<NRPHY_MOD_BPSK>, grid, block, 0, stream, p, sym, d_noise, d_llr);
+      break;
+    case NRPHY_MOD_QPSK:
+      hipLaunchKernelGGL(demodulate_soft_kernel<NRPHY_MOD_QPSK>, grid, block, 0, stream, p, sym, d_noise, d_llr);
+      break;
+    case NRPHY_MOD_QAM16:
+      hipLaunchKernelGGL(demodulate_soft_kernel<NRPHY_MOD_QAM16>, grid, block, 0, stream, p, sym, d_noise, d_llr);
+      break;
+    case NRPHY_MOD_QAM64:
+      hipLaunchKernelGGL(demodulate_soft_kernel<NRPHY_MOD_QAM64>, grid, block, 0, stream, p, sym, d_noise, d_llr);
+      break;
+    case NRPHY_MOD_QAM256:
+      hipLaunchKernelGGL(demodulate_soft_kernel<NRPHY_MOD_QAM256>, grid, block, 0, stream, p, sym, d_noise, d_llr);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

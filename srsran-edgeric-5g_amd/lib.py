@@ -6,6 +6,7 @@ callers (tests, bench.py): tensors are passed down as raw device pointers.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -48,6 +49,23 @@ def strerror(status):
 def _check(status, what):
     if status != abi.OK:
         raise NrphyError(status, what)
+
+
+# Callers that order their PyTorch work and this library's streams themselves (bench.py: explicit synchronisation around the timed
+# region) switch the wait below off.
+ORDER_AFTER_TORCH = True
+
+
+def _stream(stream):
+    """The stream argument of a device entry point.  None selects the context's own stream, which is non-blocking and therefore
+    NOT ordered after PyTorch's streams: work PyTorch has queued on its current stream (the fill of a fresh torch.zeros, a
+    host-to-device copy) is waited for first, so that a tensor handed over is what the caller sees.  An explicit stream is the
+    caller's to order."""
+    if stream is None and ORDER_AFTER_TORCH:
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+    return stream
 
 
 def _dptr(t):
@@ -109,12 +127,12 @@ class Context:
 
     def ldpc_encode(self, base_graph, lifting_size, d_msg, msg_stride, out_bits, d_out, out_stride, n_cb, stream=None):
         _check(self.lib.nrphy_ldpc_encode(self.handle, base_graph, lifting_size, n_cb, _dptr(d_msg), msg_stride,
-                                          out_bits, _dptr(d_out), out_stride, stream), "nrphy_ldpc_encode")
+                                          out_bits, _dptr(d_out), out_stride, _stream(stream)), "nrphy_ldpc_encode")
 
     def ldpc_rate_dematch(self, cfg, n_cb, d_in, in_stride, d_soft, soft_stride, new_data, stream=None):
         """ldpc_rate_dematcher::rate_dematch for n_cb codeblocks resident in HBM (cfg: abi.LdpcRateDematcherCfg)."""
         _check(self.lib.nrphy_ldpc_rate_dematch(self.handle, C.byref(cfg), n_cb, _dptr(d_in), in_stride, _dptr(d_soft),
-                                                soft_stride, int(new_data), stream), "nrphy_ldpc_rate_dematch")
+                                                soft_stride, int(new_data), _stream(stream)), "nrphy_ldpc_rate_dematch")
 
     def ldpc_rate_dematch_host(self, base_graph, lifting_size, rv, qm, nref, nof_filler, new_data, llr_in, soft_buffer):
         """ldpc_rate_dematcher::rate_dematch on host spans: returns the updated soft buffer (copy)."""
@@ -144,7 +162,7 @@ class Context:
     def llr_descramble(self, d_c_init, n_cw, length, d_in, in_stride, d_out, out_stride, stream=None):
         """pseudo_random_generator::apply_xor on soft bits for n_cw codewords in device memory (d_c_init: device uint32)."""
         _check(self.lib.nrphy_llr_descramble(self.handle, n_cw, _dptr(d_c_init), length, _dptr(d_in), in_stride, _dptr(d_out),
-                                             out_stride, stream), "nrphy_llr_descramble")
+                                             out_stride, _stream(stream)), "nrphy_llr_descramble")
 
     def llr_descramble_host(self, c_init, llr):
         """One codeword of int8 soft bits from host memory; returns the descrambled copy."""
@@ -168,7 +186,7 @@ class Context:
     def demodulate_soft(self, modulation, nof_spans, span_len, d_symbols, d_noise_vars, d_llr, stream=None):
         """demodulation_mapper::demodulate_soft for nof_spans spans of span_len symbols in device memory."""
         _check(self.lib.nrphy_demodulate_soft(self.handle, modulation, nof_spans, span_len, _dptr(d_symbols), _dptr(d_noise_vars),
-                                              _dptr(d_llr), stream), "nrphy_demodulate_soft")
+                                              _dptr(d_llr), _stream(stream)), "nrphy_demodulate_soft")
 
     def demodulate_soft_host(self, modulation, symbols, noise_vars):
         """One span from host memory: symbols complex64 [n], noise_vars float32 [n] -> int8 [n * bits per symbol]."""
@@ -184,14 +202,14 @@ class Context:
         """Sparse host writes into ONE device grid: entries = [(port, symbol, subc, cbf16 word)], later ones win."""
         n = len(entries)
         arr = (abi.GridRe * n)(*[abi.GridRe(*e) for e in entries])
-        _check(self.lib.nrphy_grid_put(self.handle, _dptr(d_grid), nof_ports, nof_subc, n, arr, stream), "nrphy_grid_put")
+        _check(self.lib.nrphy_grid_put(self.handle, _dptr(d_grid), nof_ports, nof_subc, n, arr, _stream(stream)), "nrphy_grid_put")
 
     def csi_rs_map(self, cfgs, grid_indices, d_grid, nof_ports, nof_subc, stream=None):
         """nzp_csi_rs_generator::map for a batch of signals into device grids [grid][port][14][subc]."""
         n = len(cfgs)
         arr = (abi.CsiRsCfg * n)(*cfgs)
         idx = (C.c_uint32 * n)(*grid_indices)
-        _check(self.lib.nrphy_csi_rs_map(self.handle, n, arr, idx, _dptr(d_grid), nof_ports, nof_subc, stream),
+        _check(self.lib.nrphy_csi_rs_map(self.handle, n, arr, idx, _dptr(d_grid), nof_ports, nof_subc, _stream(stream)),
                "nrphy_csi_rs_map")
 
     def csi_rs_map_host(self, cfg, grid):
@@ -207,7 +225,7 @@ class Context:
         n = len(pdus)
         arr = (abi.PdcchPdu * n)(*pdus)
         idx = (C.c_uint32 * n)(*grid_indices)
-        _check(self.lib.nrphy_pdcch_process(self.handle, n, arr, idx, _dptr(d_grid), nof_ports, nof_subc, stream),
+        _check(self.lib.nrphy_pdcch_process(self.handle, n, arr, idx, _dptr(d_grid), nof_ports, nof_subc, _stream(stream)),
                "nrphy_pdcch_process")
 
     def pdcch_process_host(self, pdu, grid):
@@ -230,7 +248,7 @@ class Context:
         n = len(pdus)
         arr = (abi.SsbPdu * n)(*pdus)
         idx = (C.c_uint32 * n)(*grid_indices)
-        _check(self.lib.nrphy_ssb_process(self.handle, n, arr, idx, _dptr(d_grid), nof_ports, nof_subc, stream),
+        _check(self.lib.nrphy_ssb_process(self.handle, n, arr, idx, _dptr(d_grid), nof_ports, nof_subc, _stream(stream)),
                "nrphy_ssb_process")
 
     def ssb_process_host(self, pdu, grid):
@@ -252,7 +270,7 @@ class Context:
         """amplitude_controller::process for n_buffers device buffers of nof_samples complex floats."""
         _check(self.lib.nrphy_amplitude_control(self.handle, C.byref(cfg), n_buffers, nof_samples, _dptr(d_in),
                                                 in_stride or nof_samples, _dptr(d_out), out_stride or nof_samples,
-                                                _dptr(d_stats), stream), "nrphy_amplitude_control")
+                                                _dptr(d_stats), _stream(stream)), "nrphy_amplitude_control")
 
     def amplitude_control_host(self, cfg, x, metrics=None):
         """One host buffer (complex64) -> (output, abi.AmplitudeMetrics updated in place when given)."""
@@ -272,7 +290,7 @@ class Context:
 
     def iq_convert_ci16(self, n_buffers, nof_samples, d_in, scale, d_out, in_stride=None, out_stride=None, stream=None):
         _check(self.lib.nrphy_iq_convert_ci16(self.handle, n_buffers, nof_samples, _dptr(d_in), in_stride or nof_samples,
-                                              scale, _dptr(d_out), out_stride or nof_samples, stream), "nrphy_iq_convert_ci16")
+                                              scale, _dptr(d_out), out_stride or nof_samples, _stream(stream)), "nrphy_iq_convert_ci16")
 
     def ofh_compress_host(self, cfg, prbs):
         """iq_compressor::compress + serialisation: prbs [nof_prb][12][2] uint16 (raw cbf16) -> bytes."""
@@ -286,7 +304,7 @@ class Context:
     def ofh_compress(self, cfg, n_rows, nof_prb, d_prbs, d_out, row_stride=None, out_row_stride=None, stream=None):
         rec = self.lib.nrphy_ofh_compressed_prb_bytes(C.byref(cfg))
         _check(self.lib.nrphy_ofh_compress(self.handle, C.byref(cfg), n_rows, nof_prb, _dptr(d_prbs), row_stride or 12 * nof_prb,
-                                           _dptr(d_out), out_row_stride or rec * nof_prb, stream), "nrphy_ofh_compress")
+                                           _dptr(d_out), out_row_stride or rec * nof_prb, _stream(stream)), "nrphy_ofh_compress")
 
     def pusch_decoder_sizes(self, cfg, n_tb):
         """(soft-buffer bytes per transport block, state bytes of the batch, codeblocks per transport block)."""
@@ -317,7 +335,7 @@ class Context:
         d_scratch = self._scratch(scratch.value, d_scratch)
         _check(self.lib.nrphy_pusch_decode_batch(self.handle, C.byref(cfg), n_tb, _dptr(d_llr), llr_stride, _dptr(d_soft),
                                                  _dptr(d_state), _dptr(d_scratch), _dptr(d_tb), tb_stride, _dptr(d_result),
-                                                 stream), "nrphy_pusch_decode_batch")
+                                                 _stream(stream)), "nrphy_pusch_decode_batch")
 
     def ldpc_decoder_scratch_bytes(self, cfg, n_cb):
         b = C.c_uint64(0)
@@ -330,7 +348,7 @@ class Context:
         d_scratch = self._scratch(self.ldpc_decoder_scratch_bytes(cfg, max(1, n_cb)), d_scratch)
         _check(self.lib.nrphy_ldpc_decode(self.handle, C.byref(cfg), n_cb, _dptr(d_llr), llr_stride, _dptr(d_out),
                                           out_stride, _dptr(d_iterations) if d_iterations is not None else None,
-                                          _dptr(d_scratch), stream), "nrphy_ldpc_decode")
+                                          _dptr(d_scratch), _stream(stream)), "nrphy_ldpc_decode")
 
     def ldpc_decode_host(self, base_graph, lifting_size, nof_filler, crc_poly, max_iterations, scaling, llr):
         """ldpc_decoder::decode on host spans: returns (iterations or 0, Kb*Zc hard bits one per byte)."""
@@ -344,7 +362,7 @@ class Context:
         return int(it.value), np.unpackbits(packed)[:k]
 
     def dft(self, size, inverse, batch, d_in, d_out, stream=None):
-        _check(self.lib.nrphy_dft_run(self.handle, size, int(inverse), batch, _dptr(d_in), _dptr(d_out), stream),
+        _check(self.lib.nrphy_dft_run(self.handle, size, int(inverse), batch, _dptr(d_in), _dptr(d_out), _stream(stream)),
                "nrphy_dft_run")
 
 
@@ -377,7 +395,7 @@ class PdschPlan:
 
     def run(self, d_tb, d_grid, d_cw_rm=None, d_cw_scr=None, zero_grids=True, stream=None):
         _check(self.ctx.lib.nrphy_pdsch_run(self.handle, _dptr(d_tb), _dptr(d_grid), _dptr(d_cw_rm), _dptr(d_cw_scr),
-                                            int(zero_grids), stream), "nrphy_pdsch_run")
+                                            int(zero_grids), _stream(stream)), "nrphy_pdsch_run")
 
     def enable_timing(self, max_runs):
         _check(self.ctx.lib.nrphy_pdsch_plan_enable_timing(self.handle, max_runs), "nrphy_pdsch_plan_enable_timing")
@@ -483,12 +501,12 @@ class OfdmPlan:
 
     def run(self, nof_grids, d_grid, d_iq, d_slot_index=None, stream=None):
         _check(self.ctx.lib.nrphy_ofdm_run(self.handle, nof_grids, _dptr(d_grid), _dptr(d_slot_index), _dptr(d_iq),
-                                           stream), "nrphy_ofdm_run")
+                                           _stream(stream)), "nrphy_ofdm_run")
 
     def run_ci16(self, nof_grids, d_grid, wire_cfg, d_iq16, d_slot_index=None, d_stats=None, stream=None):
         """nrphy_ofdm_run with the amplitude controller and the complex int16 conversion fused into the store."""
         _check(self.ctx.lib.nrphy_ofdm_run_ci16(self.handle, nof_grids, _dptr(d_grid), _dptr(d_slot_index), C.byref(wire_cfg),
-                                                _dptr(d_iq16), _dptr(d_stats), stream), "nrphy_ofdm_run_ci16")
+                                                _dptr(d_iq16), _dptr(d_stats), _stream(stream)), "nrphy_ofdm_run_ci16")
 
     def enable_timing(self, max_runs):
         _check(self.ctx.lib.nrphy_ofdm_plan_enable_timing(self.handle, max_runs), "nrphy_ofdm_plan_enable_timing")
@@ -511,7 +529,7 @@ class OfdmPlan:
     def demod_run(self, nof_grids, d_iq, d_grid, d_slot_index=None, window_offset=0, stream=None):
         """ofdm_slot_demodulator::demodulate for every port of nof_grids slots (device buffers)."""
         _check(self.ctx.lib.nrphy_ofdm_demod_run(self.handle, nof_grids, _dptr(d_iq), _dptr(d_slot_index),
-                                                 window_offset, _dptr(d_grid), stream), "nrphy_ofdm_demod_run")
+                                                 window_offset, _dptr(d_grid), _stream(stream)), "nrphy_ofdm_demod_run")
 
     def demodulate_slot_host(self, iq, slot_index, window_offset=0):
         """Host-span form: iq [nof_ports][slot samples] complex64 -> grid [nof_ports][14][12*bw_rb][2] uint16."""

@@ -1849,13 +1849,13 @@ def test_link_all_modulations_through_soft_demodulator(gpu_ctx, oracle, qm, rate
     G, tb_size = d["codeword_bits"], pdu.tb_size_bytes
     nsym = G // qm
     tb_stride = (tb_size + 3) & ~3
-    d_tb = torch.randint(0, 256, (slots, tb_stride), dtype=torch.uint8, device="cuda")
+    rng = np.random.default_rng(1000 * qm + rate)
+    d_tb = dev(rng.integers(0, 256, (slots, tb_stride), dtype=np.uint8))   # seeded: the verdicts below must not vary from run to run
     plan = lib.PdschPlan(gpu_ctx, pdus, [i * tb_stride for i in range(slots)], list(range(slots)), slots, 1, nprb * 12)
     d_cw = torch.zeros((plan.codeword_bits + 7) // 8 + 64, dtype=torch.uint8, device="cuda")
     plan.run(d_tb.reshape(-1), None, d_cw_scr=d_cw)
     gpu_ctx.synchronize()
     cw = d_cw.cpu().numpy()
-    rng = np.random.default_rng(1000 * qm + rate)
     sym = np.zeros((slots, nsym), np.complex64)
     for i in range(slots):
         o = plan.codeword_offset(i)
