@@ -198,6 +198,74 @@ __global__ __launch_bounds__(DEMATCH_LDS_THREADS) void ldpc_dematch_lds_kernel(D
   }
 }
 
+// Direct form for operation lists whose destination ranges do not overlap (p.disjoint: no repetition that wraps onto itself -- every
+// first transmission and every retransmission of a codeblock shorter than its buffer): nothing is staged.  A thread takes one
+// received symbol -- its Qm soft bits are row 0 .. Qm-1 of one column of the deinterleaver table, contiguous in the input -- and
+// stores each of them where the operation covering that element puts it: the lanes of a wavefront write 64 consecutive soft bits
+// of every row.  Clearing and filling run as dword stores.  Soft bits no operation covers are never touched, and the buffer is
+// read only where an operation combines.
+template <bool EXT>
+__global__ __launch_bounds__(256) void ldpc_dematch_scatter_kernel(DematchLaunch p)
+{
+  const int8_t*  in      = p.in + (size_t)blockIdx.z * p.in_stride_outer + (size_t)blockIdx.y * p.in_stride;
+  int8_t*        out_row = p.out + (size_t)blockIdx.z * p.out_stride_outer + (size_t)blockIdx.y * p.out_stride;
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
+  const uint32_t qm = p.qm, cols = p.cols;
+  // the thread's symbol
+  uint32_t lo = 0, hi = 0;
+  if (gtid < cols) {
+    const int8_t* src = in + (size_t)gtid * qm;
+    if (qm == 8 && (reinterpret_cast<uintptr_t>(src) & 7u) == 0) {
+      const uint2 w = *reinterpret_cast<const uint2*>(src);
+      lo = w.x, hi = w.y;
+    } else if (qm == 4 && (reinterpret_cast<uintptr_t>(src) & 3u) == 0) {
+      lo = *reinterpret_cast<const uint32_t*>(src);
+    } else {
+      for (uint32_t j = 0; j != qm; ++j) {
+        const uint32_t b = (uint32_t)(uint8_t)src[j];
+        if (j < 4) {
+          lo |= b << (8u * j);
+        } else {
+          hi |= b << (8u * (j - 4u));
+        }
+      }
+    }
+  }
+  for (uint32_t k = 0; k != p.n_ops; ++k) { // uniform
+    const DematchOp op  = EXT ? p.ops_ext[k] : p.ops[k];
+    int8_t*         dst = out_row + op.begin;
+    if (op.kind == DEMATCH_ZERO || op.kind == DEMATCH_FILL) {
+      const int8_t   value = op.kind == DEMATCH_ZERO ? 0 : 127; // LLR_INFINITY: a filler bit is a certain zero
+      const uint32_t head  = min(op.count, (4u - (op.begin & 3u)) & 3u); // bytes up to the first aligned dword
+      const uint32_t words = (op.count - head) >> 2;
+      if (gtid < head) {
+        dst[gtid] = value;
+      }
+      uint32_t* dst32 = reinterpret_cast<uint32_t*>(dst + head);
+      for (uint32_t q = gtid; q < words; q += gsize) {
+        dst32[q] = 0x01010101u * (uint32_t)(uint8_t)value;
+      }
+      const uint32_t q = head + 4u * words + gtid;
+      if (q < op.count) {
+        dst[q] = value;
+      }
+      continue;
+    }
+    if (gtid >= cols) {
+      continue;
+    }
+    // element j * cols + i of the deinterleaved input, for the rows the operation's source range [src, src + count) reaches
+    for (uint32_t j = 0; j != qm; ++j) {
+      const uint32_t s = j * cols + gtid;
+      if (s - op.src < op.count) { // (unsigned: also false for s < src)
+        const int v = (int)(int8_t)((j < 4 ? lo >> (8u * j) : hi >> (8u * (j - 4u))) & 0xFFu);
+        int8_t*   d = dst + (s - op.src);
+        *d          = (int8_t)(op.kind == DEMATCH_COPY ? v : dematch_sum(v, (int)*d));
+      }
+    }
+  }
+}
+
 template <bool EXT>
 static void launch_dematch_variant(const DematchLaunch& p, uint32_t n_cb, uint32_t n_outer, hipStream_t stream)
 {
@@ -205,7 +273,9 @@ static void launch_dematch_variant(const DematchLaunch& p, uint32_t n_cb, uint32
   const bool     vec4 = ((reinterpret_cast<uintptr_t>(p.out) | p.out_stride | p.out_stride_outer | p.block_length) & 3u) == 0;
   const uint32_t e    = p.cols * p.qm;
   const uint32_t lds  = ((e + 15u) & ~15u) + ((p.block_length + 15u) & ~15u);
-  if (vec4 && lds <= 64u * 1024u) {
+  if (vec4 && p.disjoint) {
+    hipLaunchKernelGGL(ldpc_dematch_scatter_kernel<EXT>, dim3((p.cols + 255u) / 256u, n_cb, n_outer), dim3(256), 0, stream, p);
+  } else if (vec4 && lds <= 64u * 1024u) {
     hipLaunchKernelGGL(ldpc_dematch_lds_kernel<EXT>, dim3(n_cb, n_outer), dim3(DEMATCH_LDS_THREADS), lds, stream, p);
   } else if (vec4) {
     const uint32_t blocks = (p.block_length / 4 + 255) / 256;

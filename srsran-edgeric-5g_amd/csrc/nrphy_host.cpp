@@ -1662,6 +1662,13 @@ int rate_dematch_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_rate_dematcher_cfg_t* 
       reach = std::max(reach, r.second);
     }
     p.skip_load = (!combines && reach >= block_length) ? 1U : 0U;
+    // Pairwise disjoint destination ranges (sorted by begin: each starts where the previous one has ended or later)?
+    p.disjoint = 1U;
+    for (size_t i = 1; i < ranges.size(); ++i) {
+      if (ranges[i].first < ranges[i - 1].second) {
+        p.disjoint = 0U;
+      }
+    }
   }
   p.in           = d_in;
   p.out          = d_soft;

@@ -265,6 +265,7 @@ struct DematchLaunch {
   uint32_t      in_stride, out_stride, block_length, qm, cols, n_ops;
   uint32_t      in_stride_outer, out_stride_outer; // a second batch dimension (transport blocks of codeblocks)
   uint32_t      skip_load; // the operations write every soft bit of the block: the old contents need not be read
+  uint32_t      disjoint;  // no two operations touch the same soft bit: they can run in any order, element by element
   const DematchOp* ops_ext; // the list in device memory when it has more than MAX_DEMATCH_OPS entries, else null
   DematchOp        ops[MAX_DEMATCH_OPS];
 };
