@@ -19,16 +19,17 @@
 namespace nrphy {
 
 constexpr int LLR_MAX_V = 120;
-constexpr int LLR_INF_V = 127;
+constexpr int LLR_INF_V = 121; // what this kernel keeps an infinite soft bit as (the reference's LLR_INFTY is 127), see below
 
 // ---- LLR arithmetic -------------------------------------------------------------------------------------------------
 // The check-to-variable magnitudes are finite by construction: the two minima start at LLR_MAX and only shrink
 // (ldpc_decoder_generic.cpp:88-107), and the scaling factor is below one.  With a finite message c the rules of
 // log_likelihood_ratio.cpp:37-87 reduce to: "a - c" clamps to +-LLR_MAX unless the soft bit a is infinite, which then
 // stays; "c + v" promotes a sum beyond +-LLR_MAX to infinity, and an infinite v stays (the "a == -b gives 0" case is
-// what the plain sum yields anyway).  Infinite soft bits are kept as exactly +-LLR_INFTY (normalised on load; any value
-// beyond +-LLR_MAX behaves the same in every rule, and only hard bits leave the kernel).  Everything is written with
-// median / min / max / bit-field operations: no compare-and-select pairs, which cost wait states on gfx950.
+// what the plain sum yields anyway).  Any value beyond +-LLR_MAX behaves the same in every rule and only hard bits leave
+// the kernel, so an infinite soft bit is kept as +-(LLR_MAX + 1): promotion is then a plain clamp of the sum to
+// +-(LLR_MAX + 1), and so is the normalisation on load.  Everything is written with median / min / max / bit-field
+// operations: no compare-and-select pairs, which cost wait states on gfx950.
 __device__ __forceinline__ int med3(int x, int lo, int hi)
 {
   return max(lo, min(x, hi)); // v_med3_i32
@@ -41,19 +42,17 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
 }
 
 // Variable-to-check message a - c.  An infinite soft bit yields a value far beyond the finite range with the sign of
-// a (+-384 on top): never a minimum, the right sign, and llr_add_promote() turns it back into +-LLR_INFTY.
+// a (+-512 on top): never a minimum, the right sign, and llr_add_promote() turns it back into an infinite soft bit.
 __device__ __forceinline__ int llr_sub(int a, int c)
 {
   const int d   = med3(a - c, -LLR_MAX_V, LLR_MAX_V);
-  const int big = a - med3(a, -LLR_MAX_V - 1, LLR_MAX_V + 1); // 0, or +-6 for +-127
-  return (big << 6) + d;
+  const int big = a - med3(a, -LLR_MAX_V, LLR_MAX_V); // 0, or +-1 for an infinite soft bit
+  return (big << 9) + d;
 }
 // New soft bit c + v, promoting.
 __device__ __forceinline__ int llr_add_promote(int c, int v)
 {
-  const int r = c + v;
-  const int e = med3(r, -LLR_MAX_V - 1, LLR_MAX_V + 1), f = med3(r, -LLR_MAX_V, LLR_MAX_V);
-  return e + 6 * (e - f); // +-121 -> +-127
+  return med3(c + v, -LLR_INF_V, LLR_INF_V);
 }
 
 // Check record: lo = min1 | min2 << 8 | index of the minimum << 16 (scaled magnitudes, index 0xFF: none), hi = one sign
@@ -120,11 +119,10 @@ __device__ __forceinline__ uint2 process_check(int8_t* soft, const uint8_t* scal
 }
 
 // One soft bit as it enters the decoder (ldpc_decoder_impl.cpp:128-164): whole nodes are clamped to +-64, the tail
-// is taken as is (infinities normalised, see above).
+// is taken as is (infinities in this kernel's form, see above).
 __device__ __forceinline__ int load_soft(int v, bool whole_node)
 {
-  const int t = v > LLR_MAX_V ? LLR_INF_V : (v < -LLR_MAX_V ? -LLR_INF_V : v);
-  return whole_node ? med3(v, -64, 64) : t;
+  return whole_node ? med3(v, -64, 64) : med3(v, -LLR_INF_V, LLR_INF_V);
 }
 
 // Hard bits [32 w, 32 w + 32) of the soft bits (MSB first); zero_seen: an undecided one among the first `limit`.
@@ -217,9 +215,11 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
 #pragma unroll 4
     for (uint32_t d = j; d < nd; d += T) {
       const uint32_t x = src[d];
-      if (x != 0) {
-        last_nz = max(last_nz, 4u * d + 4u - ((uint32_t)__clz(x) >> 3));
+      if (x == 0) { // (at high code rates most of the buffer: nothing received there yet)
+        dst[d] = 0;
+        continue;
       }
+      last_nz    = max(last_nz, 4u * d + 4u - ((uint32_t)__clz(x) >> 3));
       uint32_t y = 0;
 #pragma unroll
       for (uint32_t b = 0; b != 4; ++b) {
