@@ -68,6 +68,41 @@ def main():
             print("config %d: asynchronous seam, %d in flight: %.0f PDUs/s (%.3f ms per PDU)" % (cfg, depth, total / dt, 1e3 * dt / total),
                   flush=True)
             h.nrphy_pdsch_async_destroy(q)
+        # Several submitting threads on one queue (the reference runs one processor instance per downlink thread,
+        # pdsch_processor_pool.h:51-58): ctypes releases the interpreter lock during the call, so the submits run in parallel.
+        import threading
+        for nthreads in (2, 4):
+            q = C.c_void_p()
+            assert h.nrphy_pdsch_async_create(ctx.handle, 8, ports, subc, pdu.tb_size_bytes, C.byref(q)) == 0
+            count = C.c_uint64(0)
+            total = 800
+
+            def worker(n_submit):
+                sent = 0
+                while sent < n_submit:
+                    rc = h.nrphy_pdsch_async_submit(q, C.byref(pdu), tb.ctypes.data, done_fn, C.byref(count))
+                    if rc == 0:
+                        sent += 1
+                    elif rc != 4:
+                        raise RuntimeError(rc)
+
+            def pump_threads(n_submit):
+                ts = [threading.Thread(target=worker, args=(n_submit // nthreads,)) for _ in range(nthreads)]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+                h.nrphy_pdsch_async_wait(q)
+
+            pump_threads(40)
+            count.value = 0
+            t0 = time.perf_counter()
+            pump_threads(total)
+            dt = time.perf_counter() - t0
+            assert count.value == total, (count.value, total)
+            print("config %d: asynchronous seam, 8 in flight, %d submitting threads: %.0f PDUs/s (%.3f ms per PDU)" % (
+                cfg, nthreads, total / dt, 1e3 * dt / total), flush=True)
+            h.nrphy_pdsch_async_destroy(q)
 
     # A whole cell-slot of BASELINE config 4 (four PDUs, 68 PRB each) through the asynchronous seam, 4 operations in flight:
     # PDU by PDU (four operations, four grids back) against nrphy_pdsch_async_submit_slot (one operation, one grid back).
