@@ -78,7 +78,9 @@ struct CheckMessages {
 
 // One lifted check of degree DEG: reads the soft bits of its neighbours, returns its new record, writes them back.
 // jm = j - Zc (wraps): min(j + shift, jm + shift) = (j + shift) mod Zc.
-template <uint32_t DEG>
+// FIRST: the first iteration, in which the check has not sent a message yet (all of old_rec zero): a - 0 needs no message and no
+// subtraction.
+template <uint32_t DEG, bool FIRST>
 __device__ __forceinline__ uint2 process_check(int8_t* soft, const uint8_t* scaled, const NRPHY_CONSTANT uint32_t* edge,
                                                uint32_t zc, uint32_t j, uint32_t jm, uint2 old_rec)
 {
@@ -99,7 +101,7 @@ __device__ __forceinline__ uint2 process_check(int8_t* soft, const uint8_t* scal
   uint32_t key1 = ((uint32_t)LLR_MAX_V << 8) | 0xFFu, key2 = key1, neg = 0;
 #pragma unroll
   for (uint32_t t = 0; t != DEG; ++t) {
-    const int x = llr_sub(v[t], old(t));
+    const int x = FIRST ? llr_sub(v[t], 0) : llr_sub(v[t], old(t));
     v[t]        = x;
     const uint32_t key = ((uint32_t)max(x, -x) << 8) | t;
     key2               = med3_u32(key, key1, key2);
@@ -116,6 +118,24 @@ __device__ __forceinline__ uint2 process_check(int8_t* soft, const uint8_t* scal
     soft[addr[t]] = (int8_t)llr_add_promote(now(t), v[t]);
   }
   return mine;
+}
+
+// The layer routine for every row degree of the two base graphs.
+template <bool FIRST>
+__device__ __forceinline__ uint2 process_layer(uint32_t deg, int8_t* soft, const uint8_t* scaled,
+                                               const NRPHY_CONSTANT uint32_t* edge, uint32_t zc, uint32_t j, uint32_t jm, uint2 old)
+{
+  switch (deg) {
+    case 3: return process_check<3, FIRST>(soft, scaled, edge, zc, j, jm, old);
+    case 4: return process_check<4, FIRST>(soft, scaled, edge, zc, j, jm, old);
+    case 5: return process_check<5, FIRST>(soft, scaled, edge, zc, j, jm, old);
+    case 6: return process_check<6, FIRST>(soft, scaled, edge, zc, j, jm, old);
+    case 7: return process_check<7, FIRST>(soft, scaled, edge, zc, j, jm, old);
+    case 8: return process_check<8, FIRST>(soft, scaled, edge, zc, j, jm, old);
+    case 9: return process_check<9, FIRST>(soft, scaled, edge, zc, j, jm, old);
+    case 10: return process_check<10, FIRST>(soft, scaled, edge, zc, j, jm, old);
+    default: return process_check<19, FIRST>(soft, scaled, edge, zc, j, jm, old);
+  }
 }
 
 // One soft bit as it enters the decoder (ldpc_decoder_impl.cpp:128-164): whole nodes are clamped to +-64, the tail
@@ -291,18 +311,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
         }
         if (active) {
           const auto* edge = graph->edge + e0;
-                    uint2       mine;
-          switch (deg) { // every row degree of the two base graphs
-            case 3: mine = process_check<3>(soft, s_scaled, edge, zc, j, jm, old); break;
-            case 4: mine = process_check<4>(soft, s_scaled, edge, zc, j, jm, old); break;
-            case 5: mine = process_check<5>(soft, s_scaled, edge, zc, j, jm, old); break;
-            case 6: mine = process_check<6>(soft, s_scaled, edge, zc, j, jm, old); break;
-            case 7: mine = process_check<7>(soft, s_scaled, edge, zc, j, jm, old); break;
-            case 8: mine = process_check<8>(soft, s_scaled, edge, zc, j, jm, old); break;
-            case 9: mine = process_check<9>(soft, s_scaled, edge, zc, j, jm, old); break;
-            case 10: mine = process_check<10>(soft, s_scaled, edge, zc, j, jm, old); break;
-            default: mine = process_check<19>(soft, s_scaled, edge, zc, j, jm, old); break;
-          }
+          const uint2 mine = it == 0 ? process_layer<true>(deg, soft, s_scaled, edge, zc, j, jm, old)
+                                     : process_layer<false>(deg, soft, s_scaled, edge, zc, j, jm, old);
           store_record(&rec[(size_t)m * zc + j], mine);
         }
         lds_barrier();
