@@ -289,7 +289,7 @@ def main():
         # the receive-side chain has its own script (profiles/rx_chain_bench.py); same JSON schema, one GPU
         import rx_chain_bench
         print(json.dumps(rx_chain_bench.run(argparse.Namespace(
-            slots=args.slots if args.slots != 1024 else 64, iterations=8, steps=args.steps, warmup=args.warmup, snr_db=32.0))),
+            slots=args.slots if args.slots != 1024 else 256, iterations=8, steps=args.steps, warmup=args.warmup, snr_db=32.0))),
             flush=True)
         return
 
@@ -333,7 +333,7 @@ def main():
             e.pop("_first_pdu")
             sec[name] = e
         import rx_chain_bench
-        sec["config5"] = rx_chain_bench.run(argparse.Namespace(slots=64, iterations=8, steps=s_steps, warmup=s_warm, snr_db=32.0))
+        sec["config5"] = rx_chain_bench.run(argparse.Namespace(slots=256, iterations=8, steps=s_steps, warmup=s_warm, snr_db=32.0))
         out["secondary"] = sec
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.config == 3:

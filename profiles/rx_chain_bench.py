@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--slots", type=int, default=64)
+    ap.add_argument("--slots", type=int, default=256)
     ap.add_argument("--iterations", type=int, default=8)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
