@@ -225,7 +225,10 @@ int nrphy_pdsch_process_slot_host(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_
  * `done(user, status, grid)` runs on a thread of the HIP runtime when the PDU's grid has reached the host: `grid`
  * points at [grid_nof_ports][14][grid_nof_subc] cbf16 (zeros + the PDU's resource elements, DM-RS included), valid until
  * `done` returns -- the handler merges the PDU's RE into the caller's grid and signals its notifier.  NRPHY_ERR_CAPACITY:
- * `depth` PDUs in flight (wait or retry).  The handler must not call HIP or this library. */
+ * `depth` PDUs in flight (wait or retry).  The handler must not call HIP or this library.
+ * Tunable, read when the queue is created: environment variable NRPHY_ASYNC_ZERO_COPY = 1 lets the kernels read the
+ * transport block from the operation's pinned staging instead of copying it to the device first, = 3 also lets them write
+ * the grid into the pinned buffer `done` receives (pays with many operations in flight). */
 typedef struct nrphy_pdsch_async nrphy_pdsch_async_t;
 typedef void (*nrphy_pdsch_done_fn)(void* user, int status, const void* grid);
 int nrphy_pdsch_async_create(nrphy_ctx_t* ctx, uint32_t depth, uint32_t grid_nof_ports, uint32_t grid_nof_subc,

@@ -9,6 +9,7 @@
 #include "nrphy_host_internal.h"
 
 #include <atomic>
+#include <cstdlib>
 #include <condition_variable>
 
 namespace {
@@ -41,6 +42,7 @@ struct nrphy_pdsch_async {
   std::mutex              mutex;
   std::condition_variable idle;
   uint32_t                in_flight = 0;
+  uint32_t                zero_copy = 0; // NRPHY_ASYNC_ZERO_COPY: bit 0 = the kernels read the pinned transport block, bit 1 = and write the pinned grid
 };
 
 namespace {
@@ -93,6 +95,9 @@ extern "C" int nrphy_pdsch_async_create(nrphy_ctx_t* ctx, uint32_t depth, uint32
   q->nof_subc     = grid_nof_subc;
   q->max_tb_bytes = max_tb_bytes;
   q->grid_bytes   = (size_t)grid_nof_ports * NRPHY_NSYMB * grid_nof_subc * 4;
+  if (const char* e = std::getenv("NRPHY_ASYNC_ZERO_COPY")) {
+    q->zero_copy = (uint32_t)std::atoi(e);
+  }
   q->slots.resize(depth);
   const size_t tb_alloc = ((size_t)max_tb_bytes + 7) & ~(size_t)3;
   for (AsyncSlot& s : q->slots) {
@@ -226,15 +231,17 @@ static int submit_pdus(nrphy_pdsch_async_t* q, uint32_t n_pdu, const nrphy_pdsch
   slot->done   = done;
   slot->user   = user;
   slot->status = NRPHY_OK;
-  if (hipMemcpyAsync(slot->d_tb, slot->h_tb, tb_total, hipMemcpyHostToDevice, slot->stream) != hipSuccess) {
+  const bool tb_direct = (q->zero_copy & 1u) != 0, grid_direct = (q->zero_copy & 2u) != 0;
+  if (!tb_direct && hipMemcpyAsync(slot->d_tb, slot->h_tb, tb_total, hipMemcpyHostToDevice, slot->stream) != hipSuccess) {
     return give_back(NRPHY_ERR_DEVICE);
   }
-  const int rc = nrphy_pdsch_run(plan, slot->d_tb, slot->d_grid, nullptr, nullptr, 1, slot->stream);
+  const int rc = nrphy_pdsch_run(plan, tb_direct ? slot->h_tb : slot->d_tb, grid_direct ? slot->h_grid : slot->d_grid, nullptr,
+                                 nullptr, 1, slot->stream);
   if (rc != NRPHY_OK) {
     (void)hipStreamSynchronize(slot->stream);
     return give_back(rc);
   }
-  if (hipMemcpyAsync(slot->h_grid, slot->d_grid, q->grid_bytes, hipMemcpyDeviceToHost, slot->stream) != hipSuccess ||
+  if ((!grid_direct && hipMemcpyAsync(slot->h_grid, slot->d_grid, q->grid_bytes, hipMemcpyDeviceToHost, slot->stream) != hipSuccess) ||
       hipLaunchHostFunc(slot->stream, on_stream_done, slot) != hipSuccess) {
     (void)hipStreamSynchronize(slot->stream);
     return give_back(NRPHY_ERR_DEVICE);
