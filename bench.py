@@ -275,8 +275,10 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # Defaults: 30 untimed steps (30 ms) bring the device to its steady clocks -- with 3 the compute-bound codeblock launch reads
+    # 11 % slow and the whole step 4-5 % (profiles/r02_codeblock_experiments.txt, "warm-up") -- then 50 timed steps.
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--slots", type=int, default=1024, help="slots (config 4: cell-slots) per GPU per step")
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
                     help="BASELINE config measured as the line's value: 3 = the headline workload (default)")

@@ -563,12 +563,18 @@ def test_mixed_host_span_calls_from_several_threads(gpu_ctx, oracle):
     assert not errors, sorted(set(errors))
 
 
-def test_pdsch_async_queue_keeps_pdus_in_flight(gpu_ctx, oracle):
+@pytest.mark.parametrize("zero_copy", [None, "1", "3"])
+def test_pdsch_async_queue_keeps_pdus_in_flight(gpu_ctx, oracle, zero_copy, monkeypatch):
     """nrphy_pdsch_async_*: several PDUs in flight through the host-span seam (what an asynchronous pdsch_processor
     drop-in uses); every completion fires exactly once on a runtime thread with the PDU's grid, also when the shapes
-    alternate (cached plans) and when the queue is full (NRPHY_ERR_CAPACITY, then retry)."""
+    alternate (cached plans) and when the queue is full (NRPHY_ERR_CAPACITY, then retry).  Also with the kernels reading
+    the transport block from, and writing the grid to, the pinned staging (NRPHY_ASYNC_ZERO_COPY, read at queue creation)."""
     import threading
     import time
+    if zero_copy is None:
+        monkeypatch.delenv("NRPHY_ASYNC_ZERO_COPY", raising=False)
+    else:
+        monkeypatch.setenv("NRPHY_ASYNC_ZERO_COPY", zero_copy)
     rng = np.random.default_rng(606)
     pdus = []
     for cfg in (1, 2, 1, 2, 2, 1):
