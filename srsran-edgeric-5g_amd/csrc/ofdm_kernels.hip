@@ -462,7 +462,10 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // device.  Measured over the whole step (A/B on one box, 60 steps, 16-byte stores): default policy 0.52 ms, nt 0.47-0.50,
 // nt + sc1 0.45 ms (6.1 TB/s); with nt the PDSCH launches that follow also run 4 % faster because 2 GB of IQ no longer
 // pass through the caches.  nt + sc0 and nt + sc0 + sc1 were in between, sc0 + sc1 without nt slower.
-constexpr int AUX_NT = 18;
+#ifndef NRPHY_IQ_STORE_AUX
+#define NRPHY_IQ_STORE_AUX 18 // (0 / 2 / 16 for A/B builds)
+#endif
+constexpr int AUX_NT = NRPHY_IQ_STORE_AUX;
 
 // blockIdx = (symbol group, port, grid): no index arithmetic to undo, every per-symbol quantity is wave-uniform and
 // lives in SGPRs.  A workgroup modulates SPW consecutive symbols of its (grid, port); the row of the next symbol is

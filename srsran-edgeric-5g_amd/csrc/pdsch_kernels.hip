@@ -400,6 +400,9 @@ __device__ __forceinline__ void grid_store(uint32_t* p, uint32_t v)
   __builtin_nontemporal_store(v, p);
 }
 
+#ifndef NRPHY_GRID_STORE_AUX
+#define NRPHY_GRID_STORE_AUX 2 // buffer-store cache policy of the data RE: 2 = non-temporal (0 = default, for A/B builds)
+#endif
 #ifndef NRPHY_GRID_BUFFER_STORES
 #define NRPHY_GRID_BUFFER_STORES 1 // A/B on one box: -1.3 % on the codeblock launch against 64-bit flat addressing
 #endif
@@ -617,7 +620,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
 #if NRPHY_GRID_BUFFER_STORES
           // (profiling aid, NRPHY_PROFILE_STAGE=11: a zero-sized descriptor drops the data stores, everything else runs)
           __builtin_amdgcn_raw_buffer_store_b32(pack_cbf16(acc.x, acc.y), grid_rsrc, (int)((l_sym * p.grid_nof_subc + subc) * 4u),
-                                                (int)(port * plane_bytes), 2 /* nt */);
+                                                (int)(port * plane_bytes), NRPHY_GRID_STORE_AUX);
 #else
           grid_store(&out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc], pack_cbf16(acc.x, acc.y));
 #endif
