@@ -89,7 +89,7 @@ __device__ __forceinline__ uint2 process_check(int8_t* soft, const uint8_t* scal
 #pragma unroll
   for (uint32_t t = 0; t != DEG; ++t) {
     const uint32_t e = edge[t], shift = e & 0xFFFFu;
-    addr[t]          = (e >> 16) * zc + min(j + shift, jm + shift);
+    addr[t]          = (e >> 16) + min(j + shift, jm + shift); // the graph holds node * Zc
   }
 #pragma unroll
   for (uint32_t t = 0; t != DEG; ++t) {

@@ -1948,7 +1948,7 @@ const DecoderGraph* get_decoder_graph(nrphy_ctx* ctx, unsigned bg, unsigned zc)
       g[0].row_ptr[m] = (uint16_t)count;
       for (unsigned e = 0; e != n_edges; ++e) {
         if (edges[e].row == m) {
-          g[0].edge[count++] = ((uint32_t)edges[e].col << 16) | (edges[e].shift[ils] % zc);
+          g[0].edge[count++] = (((uint32_t)edges[e].col * zc) << 16) | (edges[e].shift[ils] % zc); // 67 * 384 < 2^16
         }
       }
     }

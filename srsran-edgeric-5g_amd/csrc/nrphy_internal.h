@@ -228,7 +228,7 @@ hipError_t launch_ldpc_encode(const LiftedGraph* graphs, uint32_t graph, uint32_
 // adjacency order (ascending variable index, the order that breaks ties between equal minima).
 struct DecoderGraph {
   uint16_t row_ptr[MAX_BG_ROWS + 2];
-  uint32_t edge[MAX_BG_EDGES]; // variable node << 16 | lifted shift
+  uint32_t edge[MAX_BG_EDGES]; // (variable node * Zc) << 16 | lifted shift
 };
 
 struct LdpcDecodeLaunch {
