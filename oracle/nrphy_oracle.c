@@ -568,7 +568,11 @@ static void rate_match_bits(const uint8_t* in, unsigned n_cb, unsigned k0, unsig
   unsigned idx = k0;
   for (unsigned t = 0; t != E; ++t) {
     if (idx >= filler_start && idx < filler_stop) {
-      idx = filler_stop % n_cb;
+      /* Past the filler bits; a circular buffer that ends inside them (filler_start < Ncb < filler_stop, only possible with a
+       * limited-buffer size below the transport block's own) wraps to its first bit.  The reference is undefined there
+       * (select_bits jumps to filler_stop, beyond the buffer: ldpc_rate_matcher_impl.cpp:115-137, a crash in the compiled
+       * reference); this is TS 38.212 Section 5.4.2.1 evaluated literally, which is also what the device computes. */
+      idx = filler_stop < n_cb ? filler_stop : 0;
     }
     sel[t] = in[idx];
     idx    = (idx + 1) % n_cb;

@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import backends  # noqa: E402
 import cases  # noqa: E402
 
+# NRPHY_FUZZ_SEED shifts every generator seed: further sweeps over fresh configurations (the default 0 gives the quoted runs).
+BASE = int(os.environ.get("NRPHY_FUZZ_SEED", "0"))
 abi, lib = backends.abi, backends.pkg.lib
 o = backends.oracle()
 ctx = lib.Context(0)
@@ -24,7 +26,7 @@ def f32(raw):
 def pdsch():
     bad = n = 0
     for seed in range(6):
-        rng = np.random.default_rng(1000 + seed)
+        rng = np.random.default_rng(BASE + 1000 + seed)
         for pdu, P, S in cases.random_pdus(o.tbs, rng, 80):
             if o.validate(pdu) != 0 or o.derive(pdu)["nof_re"] == 0:
                 continue
@@ -42,7 +44,7 @@ def pdsch():
 
 
 def rx():
-    rng = np.random.default_rng(424242)
+    rng = np.random.default_rng(BASE + 424242)
     sizes = cases.LIFTING_SIZES
     bad = 0
     for t in range(200):
@@ -103,7 +105,7 @@ def rx():
 
 
 def ofdm():
-    rng = np.random.default_rng(8088)
+    rng = np.random.default_rng(BASE + 8088)
     bad = 0
     for t in range(100):
         n = int(rng.choice([128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 4608, 6144]))
@@ -131,7 +133,7 @@ def ofdm():
 
 
 def csi():
-    rng = np.random.default_rng(8088)
+    rng = np.random.default_rng(BASE + 8088)
     bad = 0
     for t in range(200):
         row = int(rng.integers(1, 6))
@@ -162,7 +164,7 @@ def csi():
 
 def dlctrl():
     """PDCCH and SS/PBCH block processors: random PDUs into grids full of other data."""
-    rng = np.random.default_rng(515151)
+    rng = np.random.default_rng(BASE + 515151)
     bad = n = 0
     for t in range(1500):
         pdu = cases.random_pdcch(rng)
@@ -190,7 +192,7 @@ def dlctrl():
 
 def demod():
     """Soft demodulator: random span lengths, the three input kinds of tests/cases.py, every modulation."""
-    rng = np.random.default_rng(626262)
+    rng = np.random.default_rng(BASE + 626262)
     bad = n = 0
     for t in range(1200):
         modulation = int(rng.choice([0, 1, 2, 4, 6, 8]))
@@ -206,7 +208,7 @@ def demod():
 
 def lower():
     """Amplitude controller, cf32 -> ci16, OFH compression on random buffers and parameters."""
-    rng = np.random.default_rng(737373)
+    rng = np.random.default_rng(BASE + 737373)
     bad = n = 0
     for t in range(400):
         nsamp = int(rng.integers(1, 20000))

@@ -565,3 +565,41 @@ def ssb_grid_rb(pdu):
     scs = (15, 30, 30, 120, 240)[pdu.pattern_case]
     k15 = (pdu.offset_to_pointA * 12 * (60 if fr2 else 15) + pdu.subcarrier_offset * ((15 << pdu.common_scs) if fr2 else 15)) // 15
     return max(24, (k15 * 15 // scs + 240 + 11) // 12)
+
+
+def spec_rate_match(bg, zc, rv, qm, nref, nof_filler, codeblock_bits, e):
+    """TS 38.212 Section 5.4.2.1 / 5.4.2.2 bit by bit: bit selection from the circular buffer of Ncb = min(N, Nref) bits starting at
+    k0, NULL (filler) bits skipped, then the row-column interleaver.  codeblock_bits: the N = 66 Zc (50 Zc) bits after the two
+    punctured columns, one per byte.  Slow; for the corner the reference leaves undefined (RM_CORNER_CASES)."""
+    n = (66 if bg == 1 else 50) * zc
+    k = (22 if bg == 1 else 10) * zc
+    ncb = min(n, nref) if nref > 0 else n
+    k0 = ({1: (0, 17, 33, 56), 2: (0, 13, 25, 43)}[bg][rv] * ncb // n) * zc
+    fs, fe = k - 2 * zc - nof_filler, k - 2 * zc
+    sel, j = [], 0
+    while len(sel) < e:
+        idx = (k0 + j) % ncb
+        if not fs <= idx < fe:
+            sel.append(codeblock_bits[idx])
+        j += 1
+    return np.array(sel, np.uint8).reshape(qm, e // qm).T.reshape(-1)
+
+
+# (base graph, rv, Qm, Nref, transport block bytes, channel symbols): five BG1 / Zc 384 codeblocks whose limited circular buffer of
+# 7603 bits ends INSIDE the filler range [7680 - F, 7680) -- a limited-buffer size below the transport block's own, which the
+# reference's validator accepts and its rate matcher then reads out of bounds on (a crash in the compiled reference); the last
+# two frame the window from outside (buffer beyond the filler bits, buffer before them).
+RM_CORNER_CASES = [(1, 3, 4, 7603, 5122, 17328), (1, 2, 6, 7603, 4992, 8544), (1, 1, 2, 7603, 4867, 25272), (1, 0, 2, 7603, 4867, 40544),
+                   (1, 2, 4, 7700, 5122, 17328), (1, 3, 4, 7000, 5122, 17328)]
+
+
+def rm_corner_expected(oracle, case, tb):
+    """The codeword TS 38.212 gives for one of RM_CORNER_CASES: the oracle's segmentation and LDPC encoding (pinned elsewhere),
+    then spec_rate_match per codeblock."""
+    bg, rv, qm, nref, _, nsym = case
+    segs, meta, zc = oracle.segment(bg, rv, qm, nref, 1, nsym, tb)
+    out = []
+    for c in range(segs.shape[0]):
+        full = np.unpackbits(oracle.ldpc_encode(bg, zc, segs[c], 66 * zc))[: 66 * zc]
+        out.append(spec_rate_match(bg, zc, rv, qm, nref, int(meta[c][2]), full, int(meta[c][0])))
+    return np.concatenate(out)

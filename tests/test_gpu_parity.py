@@ -1587,6 +1587,35 @@ def test_ofdm_random_configurations(gpu_ctx, oracle):
         plan.close()
 
 
+def test_rate_matcher_buffer_ending_inside_the_filler_bits(gpu_ctx, oracle):
+    """The corner the reference leaves undefined (cases.RM_CORNER_CASES): device == TS 38.212 evaluated bit by bit == oracle, through
+    the encoder seam and, for the PDUs the seeded sweep found, through the whole processor."""
+    rng = np.random.default_rng(3)
+    for case in cases.RM_CORNER_CASES:
+        bg, rv, qm, nref, tb_bytes, nsym = case
+        tb = rng.integers(0, 256, tb_bytes, dtype=np.uint8)
+        want = cases.rm_corner_expected(oracle, case, tb)
+        got = np.asarray(gpu_ctx.pdsch_encode_host(bg, rv, qm, nref, 1, nsym, tb)[0])[: want.size]
+        assert np.array_equal(got, want), case
+    found = 0
+    for base, seed in ((1000000, 2), (4000000, 0), (4000000, 3), (6000000, 2)):
+        rng = np.random.default_rng(base + 1000 + seed)
+        for pdu, nof_ports, nof_subc in cases.random_pdus(oracle.tbs, rng, 80):
+            if oracle.validate(pdu) != 0 or oracle.derive(pdu)["nof_re"] == 0:
+                continue
+            tb = cases.random_tb(rng, pdu)
+            rng.integers(0, 3)   # (the sweep's draw of a reference processor)
+            d = oracle.derive(pdu)
+            fs = d["segment_length"] - 2 * d["lifting_size"] - d["nof_filler_bits"]
+            if not (d["nof_filler_bits"] and fs < d["n_cb"] < fs + d["nof_filler_bits"]):
+                continue
+            found += 1
+            want, orm, oscr = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc, taps=True, codeword_bits=d["codeword_bits"])
+            got, rm, scr = gpu_ctx.pdsch_process_host(pdu, tb, nof_ports, nof_subc, taps=True)
+            assert np.array_equal(rm, orm) and np.array_equal(scr, oscr) and np.array_equal(got, want), (base, seed, d)
+    assert found >= 4
+
+
 def test_pdsch_random_pdus_in_one_plan(gpu_ctx, oracle):
     """Fuzz of the batched path: 32 random PDUs (different allocations, layers, code rates, cyclic prefixes) in ONE plan,
     each into its own grid of a common shape, run twice on the same grids (the second run must overwrite everything the

@@ -303,6 +303,19 @@ def test_oracle_vs_ref_random_pdus(oracle, ref):
             assert np.array_equal(got, want), (i, impl, int(np.count_nonzero(got != want)), oracle.derive(pdu))
 
 
+def test_rate_matcher_buffer_ending_inside_the_filler_bits(oracle):
+    """Where the reference is undefined -- a limited circular buffer that ends inside the filler range; its select_bits jumps
+    beyond the buffer (ldpc_rate_matcher_impl.cpp:115-137) and the compiled reference crashes, so it is not called here -- the
+    oracle follows TS 38.212 Section 5.4.2.1 literally (found by profiles/fuzz_sweep.py with NRPHY_FUZZ_SEED=1000000)."""
+    rng = np.random.default_rng(3)
+    for case in cases.RM_CORNER_CASES:
+        bg, rv, qm, nref, tb_bytes, nsym = case
+        tb = rng.integers(0, 256, tb_bytes, dtype=np.uint8)
+        want = cases.rm_corner_expected(oracle, case, tb)
+        got = np.unpackbits(oracle.pdsch_encode_cfg(bg, rv, qm, nref, 1, nsym, tb))[: want.size]
+        assert np.array_equal(got, want), case
+
+
 def test_baseline_config_derived_values(oracle):
     """The derived sizes SURVEY.md section 8d lists for the BASELINE configs."""
     d = oracle.derive(cases.baseline_config(3)[0])
