@@ -20,9 +20,9 @@ assert r is not None, "compiled reference not built (make -C oracle ref)"
 
 def grid_verdict(got, want):
     """'exact'; or 'ulp' when the cbf16 grids differ at a handful of elements by a last-place rounding -- at most one bf16 unit in the
-    last place of the value, or of a thousandth of the grid's largest value where layers cancel -- the reference's scalar tail loops,
-    whose complex products this build of the reference contracts differently from its vector loops and which fall on different
-    elements in its three processors; or 'wrong'."""
+    last place of the value, or of a thousandth of the grid's largest value where layers cancel: the reference's scalar tail loop
+    (channel_precoder_avx2.cpp:119-127), whose imaginary part this build of the reference contracts with the other product rounded
+    first than in its vector loop; or 'wrong'."""
     if np.array_equal(got, want):
         return "exact", 0
     where = got != want
