@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Larger randomised sweeps than the test-suite runs, GPU against the oracle through the C ABI (the numbers DESIGN.md section
-2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
+2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [plan] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
 import ctypes as C
 import os
 import sys
@@ -40,6 +40,49 @@ def pdsch():
                 bad += 1
                 print("PDSCH MISMATCH seed", seed, d, flush=True)
     print("pdsch: %d random PDUs, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
+def plan():
+    """The batched path (what bench.py times): groups of 24 random PDUs in ONE plan, each into its own grid of a common shape, run
+    twice on the same grids with new transport blocks (the second run must overwrite everything the first one wrote)."""
+    import torch
+    bad = n = 0
+    for group in range(4):
+        rng = np.random.default_rng(BASE + 90210 + group)
+        drawn = [x for x in cases.random_pdus(o.tbs, rng, 28) if o.validate(x[0]) == 0 and o.derive(x[0])["nof_re"] > 0][:24]
+        nof_ports, nof_subc = 4, max(x[2] for x in drawn)
+        pdus = [x[0] for x in drawn]
+        m = len(pdus)
+        pl = None
+        d_grid = torch.full((m, nof_ports, 14, nof_subc), 0x7FFF7FFF, dtype=torch.int32, device="cuda")
+        for run in range(2):
+            offs, tbs, pos = [], [], 0
+            for q in pdus:
+                tb = cases.random_tb(rng, q)
+                offs.append(pos)
+                tbs.append(tb)
+                pos += (len(tb) + 15) & ~15
+            buf = np.zeros(pos + 16, np.uint8)
+            for off, tb in zip(offs, tbs):
+                buf[off:off + len(tb)] = tb
+            if pl is None:
+                pl = lib.PdschPlan(ctx, pdus, offs, list(range(m)), m, nof_ports, nof_subc)
+            d_rm = torch.zeros(pl.codeword_bits // 8 + 8, dtype=torch.uint8, device="cuda")
+            pl.run(torch.from_numpy(buf).cuda(), d_grid, d_cw_rm=d_rm, zero_grids=True)
+            ctx.synchronize()
+            grids = d_grid.cpu().numpy().view(np.uint16).reshape(m, nof_ports, 14, nof_subc, 2)
+            rm = d_rm.cpu().numpy()
+            for i, q in enumerate(pdus):
+                d = o.derive(q)
+                want, orm, _ = o.pdsch_process(q, tbs[i], nof_ports, nof_subc, taps=True, codeword_bits=d["codeword_bits"])
+                cw = pl.codeword_offset(i) // 8
+                n += 1
+                if not (np.array_equal(grids[i], want) and np.array_equal(rm[cw:cw + len(orm)], orm)):
+                    bad += 1
+                    print("PLAN MISMATCH group", group, "run", run, "pdu", i, d, flush=True)
+        pl.close()
+    print("pdsch plans: %d PDU runs in plans of 24, %d mismatches" % (n, bad), flush=True)
     return bad
 
 
@@ -237,7 +280,7 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "plan": plan, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     which = sys.argv[1:] or list(legs)
     total = sum(legs[w]() for w in which)
     sys.exit(1 if total else 0)
