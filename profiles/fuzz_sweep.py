@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Larger randomised sweeps than the test-suite runs, GPU against the oracle through the C ABI (the numbers DESIGN.md section
-2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [plan] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
+2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [plan] [pusch] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
 import ctypes as C
 import os
 import sys
@@ -83,6 +83,67 @@ def plan():
                     print("PLAN MISMATCH group", group, "run", run, "pdu", i, d, flush=True)
         pl.close()
     print("pdsch plans: %d PDU runs in plans of 24, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
+def pusch():
+    """The transport-block decoder (nrphy_pusch_decode_batch): random sizes, base graphs, modulations, layers, limited-buffer sizes and
+    redundancy-version orders, up to three transmissions each, against pusch_decoder_impl restated on the oracle's codeblock functions
+    (tests/cases.py: pusch_decode_expected): verdict, counters, the whole soft buffer after every transmission, the transport block."""
+    import torch
+    rng = np.random.default_rng(BASE + 5252)
+    done = bad = 0
+    while done < 40:
+        layers, qm = int(rng.integers(1, 5)), int(rng.choice([2, 4, 6, 8]))
+        n_prb, nsym = int(rng.integers(2, 60)), int(rng.integers(6, 14))
+        rate = float(rng.uniform(100, 800))
+        tb_bits = o.tbs(nsym, 12, 0, qm, rate, layers, n_prb)
+        if tb_bits < 40 or tb_bits > 120000:
+            continue
+        r = rate / 1024
+        bg = 2 if (tb_bits <= 292 or (tb_bits <= 3824 and r <= 0.67) or r <= 0.25) else 1
+        pdu = abi.make_pdu(bwp_size_rb=n_prb, qm=qm, dmrs_symbols=(2,), prb_start=0, prb_count=n_prb, start_symbol=0,
+                           nof_symbols=nsym, precoding=abi.identity_precoding(layers), tb_size_bytes=tb_bits // 8, base_graph=bg,
+                           tbs_lbrm_bytes=int(rng.choice([3168, 20000, abi.TBS_LBRM_DEFAULT])), nof_cdm_groups_without_data=2)
+        if o.validate(pdu) != 0:
+            continue
+        d = o.derive(pdu)
+        nof_sys = d["segment_length"] - 2 * d["lifting_size"]
+        if d["nof_re"] == 0 or d["nof_codeblocks"] > 12 or d["n_cb"] <= nof_sys:   # (a buffer within the systematic part: refused on the receive side)
+            continue
+        C_, n, G = d["nof_codeblocks"], d["full_length"], d["codeword_bits"]
+        tb = cases.random_tb(rng, pdu)
+        cfg0 = abi.PuschDecoderCfg(bg, qm, 0, layers, d["n_ref"], pdu.tb_size_bytes, G // qm, 6, 1, 1)
+        soft_bytes, state_bytes, _ = ctx.pusch_decoder_sizes(cfg0, 1)
+        d_soft = torch.full((1, soft_bytes), -7, dtype=torch.int8, device="cuda")
+        d_state = torch.full((state_bytes,), 0xA5, dtype=torch.uint8, device="cuda")
+        d_tb = torch.zeros((1, pdu.tb_size_bytes + 3), dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros((1, 4), dtype=torch.int32, device="cuda")
+        soft = np.full((C_, n), -7, np.int8)
+        cb_ok = np.ones(C_, np.uint8)
+        cb_msg = np.zeros((C_, d["segment_length"]), np.uint8)
+        sigma, early = float(rng.uniform(3.0, 9.0)), int(rng.integers(0, 2))
+        ok = True
+        for tx, rv in enumerate([0] + [int(x) for x in rng.permutation([1, 2, 3])[:2]]):
+            cfg = abi.PuschDecoderCfg(bg, qm, rv, layers, d["n_ref"], pdu.tb_size_bytes, G // qm, 6, early, 1 if tx == 0 else 0)
+            pdu.rv = rv
+            _, rm, _ = o.pdsch_process(pdu, tb, layers, 12 * n_prb, taps=True, codeword_bits=G)
+            pdu.rv = 0
+            bits = np.unpackbits(rm)[:G].astype(np.float64)
+            llr = np.clip(np.rint((1 - 2 * bits) * 8.0 + rng.normal(0, sigma, G)), -120, 120).astype(np.int8)
+            want = cases.pusch_decode_expected(o, d, cfg, llr, soft, cb_ok, cb_msg)
+            ctx.pusch_decode_batch(cfg, 1, torch.from_numpy(llr[None, :].copy()).cuda(), G, d_soft, d_state, d_tb, d_tb.shape[1], d_res)
+            ctx.synchronize()
+            res = tuple(int(x) for x in d_res.cpu().numpy()[0])
+            ok = ok and res == (int(want[0]), want[1], want[2], want[3]) and np.array_equal(d_soft.cpu().numpy().reshape(C_, n), soft)
+            if want[0]:
+                ok = ok and np.array_equal(d_tb.cpu().numpy()[0, : pdu.tb_size_bytes], tb)
+                break
+        done += 1
+        if not ok:
+            bad += 1
+            print("PUSCH DECODER MISMATCH", done, bg, qm, layers, d["n_ref"], C_, d["lifting_size"], flush=True)
+    print("ul-sch decoder: %d random transport blocks (up to three transmissions each), %d mismatches" % (done, bad), flush=True)
     return bad
 
 
@@ -280,7 +341,7 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "plan": plan, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     which = sys.argv[1:] or list(legs)
     total = sum(legs[w]() for w in which)
     sys.exit(1 if total else 0)
