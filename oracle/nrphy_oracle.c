@@ -269,6 +269,11 @@ int oracle_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
   if (!pdu->vrb_contiguous) {
     return NRPHY_ERR_INVALID_PDU;
   }
+  for (int prb = lo; prb <= hi; ++prb) { /* freq_alloc.is_contiguous(): the mask itself must have no hole */
+    if (!mask_test(pdu->prb_mask, (unsigned)prb)) {
+      return NRPHY_ERR_INVALID_PDU;
+    }
+  }
   if (pdu->nof_ports == 0 || pdu->nof_ports > 4 || pdu->nof_layers == 0 || pdu->nof_layers > pdu->nof_ports) {
     return NRPHY_ERR_INVALID_PDU;
   }
@@ -279,7 +284,7 @@ int oracle_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
     return NRPHY_ERR_INVALID_PDU;
   }
   if (pdu->rv > 3 || (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->tb_size_bytes == 0 ||
-      pdu->nof_prg == 0 || pdu->precoding == NULL) {
+      pdu->nof_prg == 0 || pdu->nof_prg > NRPHY_MAX_RB || pdu->prg_size_rb == 0 || pdu->precoding == NULL || pdu->cp > 1) {
     return NRPHY_ERR_INVALID_PDU;
   }
   /* DM-RS and reserved RE must not collide (check_dmrs_and_reserved_collision, :28-40): no reserved pattern may
@@ -862,9 +867,9 @@ int oracle_csi_rs_validate(const nrphy_csi_rs_cfg_t* c)
     case 1:
       return (k0 <= 3 && c->density == CSI_DENSITY_THREE && c->cdm == 0 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
     case 2:
-      return (k0 < 12 && c->density != CSI_DENSITY_THREE && c->cdm == 0 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
+      return (k0 < 12 && c->density < CSI_DENSITY_THREE && c->cdm == 0 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
     case 3:
-      return (k0 < 11 && c->density != CSI_DENSITY_THREE && c->cdm == 1 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
+      return (k0 < 11 && c->density < CSI_DENSITY_THREE && c->cdm == 1 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
     case 4:
       return (k0 < 9 && c->density == CSI_DENSITY_ONE && c->cdm == 1 && c->symbol_l0 < nsymb) ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
     default:

@@ -220,7 +220,7 @@ static int pdcch_prbs(const nrphy_pdcch_pdu_t* p, unsigned* prb /* 96 */)
     }
   }
   const unsigned n_reg_coreset = n_rb_coreset * dur;
-  if (n_reg_coreset == 0 || 6 * (p->cce_index + AL) > n_reg_coreset) {
+  if (n_reg_coreset == 0 || 6 * ((uint64_t)p->cce_index + AL) > n_reg_coreset) {
     return -1;
   }
   if (p->cce_to_reg_mapping == 1) { /* non-interleaved */
@@ -230,7 +230,7 @@ static int pdcch_prbs(const nrphy_pdcch_pdu_t* p, unsigned* prb /* 96 */)
   } else {
     const unsigned L = p->cce_to_reg_mapping == 0 ? 6 : p->reg_bundle_size;
     const unsigned R = p->cce_to_reg_mapping == 0 ? 2 : p->interleaver_size;
-    if (L == 0 || R == 0 || 6 % L != 0 || n_reg_coreset % (L * R) != 0 || L % dur != 0) {
+    if (L == 0 || R == 0 || L > 6 || R > 6 || 6 % L != 0 || n_reg_coreset % (L * R) != 0 || L % dur != 0) {
       return -1;
     }
     const unsigned C = n_reg_coreset / (L * R), per_cce = 6 / L;
@@ -295,10 +295,10 @@ int oracle_pdcch_validate(const nrphy_pdcch_pdu_t* p)
   /* the PRGs must cover the allocation exactly (resource_grid_mapper_impl.cpp:233-262 walks nof_prg slices of
    * prg_size over a mask that ends with the highest allocated PRB) */
   const unsigned top = prb[n - 1] + 1;
-  if ((p->nof_prg - 1) * p->prg_size_rb >= top) {
+  if ((uint64_t)(p->nof_prg - 1) * p->prg_size_rb >= top) {
     return NRPHY_ERR_INVALID_PDU;
   }
-  if (p->nof_prg * p->prg_size_rb < top) {
+  if ((uint64_t)p->nof_prg * p->prg_size_rb < top) {
     return NRPHY_ERR_INVALID_PDU;
   }
   if (p->cce_to_reg_mapping == 0 && prb[0] < p->bwp_start_rb) {

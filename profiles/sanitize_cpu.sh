@@ -2,12 +2,15 @@
 # AddressSanitizer + UndefinedBehaviorSanitizer on everything that runs without a GPU (the GPU pool has no device sanitizer):
 #   1. the oracle (oracle/Makefile: make sanitize) under the whole CPU suite;
 #   2. the host side of libmi355nrphy.so (validators, derivations, metric arithmetic, plan bookkeeping that needs no device),
-#      host objects rebuilt with -fsanitize=address,undefined -fno-gpu-sanitize, under tests/test_host.py.
+#      host objects rebuilt with -fsanitize=address,undefined -fno-gpu-sanitize, under tests/test_host.py;
+#   3. both under profiles/fuzz_validators_cpu.py (validators and derivations on mutated descriptors).
 # Build container, repository root:  bash profiles/sanitize_cpu.sh   -> prints the two pytest summaries.
 set -eu
 make -C oracle sanitize > /dev/null
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 NRPHY_ORACLE_SO=oracle/_san/liboracle.so \
   python3 -m pytest tests -q -m "not gpu" | tail -2
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 NRPHY_ORACLE_SO=oracle/_san/liboracle.so \
+  python3 profiles/fuzz_validators_cpu.py 3000 | tail -4
 
 C=srsran-edgeric-5g_amd/csrc
 python3 srsran-edgeric-5g_amd/build.py > /dev/null
@@ -23,3 +26,5 @@ OBJS=$(ls $C/*.o | grep -v "/nrphy_host.o\|/dl_control_host.o\|/pdsch_async.o")
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 NRPHY_LIB_SO=$PWD/build/asan/libmi355nrphy.so \
   python3 -m pytest tests/test_host.py -q | tail -2
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 NRPHY_LIB_SO=$PWD/build/asan/libmi355nrphy.so \
+  python3 profiles/fuzz_validators_cpu.py 3000 | tail -4

@@ -124,7 +124,7 @@ bool pdcch_prb_list(const nrphy_pdcch_pdu_t& p, std::vector<uint16_t>& prbs)
     }
   }
   const uint32_t n_reg = (uint32_t)coreset_prb.size() * dur;
-  if (n_reg == 0 || 6 * (p.cce_index + al) > n_reg) {
+  if (n_reg == 0 || 6 * ((uint64_t)p.cce_index + al) > n_reg) { // (64-bit: a huge CCE index must not wrap into range)
     return false;
   }
   std::vector<uint32_t> bundles; // (first REG, REG count) of every REG bundle of the candidate
@@ -135,7 +135,8 @@ bool pdcch_prb_list(const nrphy_pdcch_pdu_t& p, std::vector<uint16_t>& prbs)
   } else {
     L                = p.cce_to_reg_mapping == 0 ? 6 : p.reg_bundle_size;
     const uint32_t R = p.cce_to_reg_mapping == 0 ? 2 : p.interleaver_size;
-    if (L == 0 || R == 0 || 6 % L != 0 || n_reg % (L * R) != 0 || L % dur != 0) {
+    // L in {2, 3, 6}, R in {2, 3, 6} (TS 38.211 Section 7.3.2.2); bounded before L * R is formed
+    if (L == 0 || R == 0 || L > 6 || R > 6 || 6 % L != 0 || n_reg % (L * R) != 0 || L % dur != 0) {
       return false;
     }
     const uint32_t C = n_reg / (L * R);

@@ -421,6 +421,11 @@ extern "C" int nrphy_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
   if (pdu->dmrs_type != 1 || pdu->nof_cdm_groups_without_data > 2 || !pdu->vrb_contiguous) {
     return NRPHY_ERR_INVALID_PDU;
   }
+  for (int prb = lo; prb <= hi; ++prb) { // "only contiguous allocation": the flag and the mask must tell the same story
+    if (!mask_test(pdu->prb_mask, (unsigned)prb)) {
+      return NRPHY_ERR_INVALID_PDU;
+    }
+  }
   if (pdu->nof_ports == 0 || pdu->nof_ports > NRPHY_MAX_PORTS || pdu->nof_layers == 0 ||
       pdu->nof_layers > pdu->nof_ports) {
     return NRPHY_ERR_INVALID_PDU;
@@ -435,7 +440,8 @@ extern "C" int nrphy_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
   }
   if ((pdu->qm != 2 && pdu->qm != 4 && pdu->qm != 6 && pdu->qm != 8) || pdu->rv > 3 ||
       (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->tb_size_bytes == 0 || pdu->nof_prg == 0 ||
-      pdu->prg_size_rb == 0 || pdu->precoding == nullptr || pdu->cp > 1) {
+      pdu->nof_prg > NRPHY_MAX_RB || pdu->prg_size_rb == 0 || pdu->precoding == nullptr || pdu->cp > 1) {
+    // (nof_prg sizes the read of the caller's weight array: at most one PRG per resource block)
     return NRPHY_ERR_INVALID_PDU;
   }
   return NRPHY_OK;

@@ -241,6 +241,44 @@ def test_reference_unit_test_configurations_round2_host_side():
         assert h.nrphy_ssb_validate(C.byref(pdu)) == 0, i
 
 
+def test_validators_on_hostile_descriptors():
+    """The validators are the gate in front of host code that sizes reads and loops by descriptor fields: they must refuse, never
+    crash on, out-of-range values.  Regression cases found by profiles/fuzz_validators_cpu.py (a CCE interleaver size of 2^31 made
+    L * R wrap to zero: division by zero in the product AND the oracle; a PRG count of 2^31 would have sized the read of the weight
+    array; a hole in a "contiguous" allocation, which the reference's validator refuses), then a short run of that fuzz."""
+    import ctypes as C
+    import os
+    import sys
+    o, abi = backends.oracle(), backends.abi
+    lib = backends.pkg.lib
+    h = lib.load()
+    rng = np.random.default_rng(31)
+    pdcch = cases.random_pdcch(rng)
+    assert h.nrphy_pdcch_validate(C.byref(pdcch)) == 0 and o.pdcch_validate(pdcch) == 0
+    for field, value in (("interleaver_size", 1 << 31), ("reg_bundle_size", 1 << 31), ("cce_index", 1 << 31), ("cce_index", (1 << 32) - 1),
+                         ("nof_prg", 1 << 31), ("prg_size_rb", 1 << 31), ("aggregation_level", 1 << 31)):
+        bad = type(pdcch).from_buffer_copy(bytes(pdcch))
+        bad.cce_to_reg_mapping = 2
+        setattr(bad, field, value)
+        assert h.nrphy_pdcch_validate(C.byref(bad)) != 0 and o.pdcch_validate(bad) != 0, field
+    pdu = cases.baseline_config(2)[0]
+    assert lib.validate(pdu) == 0 and o.validate(pdu) == 0
+    for field, value in (("nof_prg", 1 << 31), ("nof_prg", abi.MAX_RB + 1), ("cp", 5), ("prg_size_rb", 0)):
+        bad = type(pdu).from_buffer_copy(bytes(pdu))
+        setattr(bad, field, value)
+        assert lib.validate(bad) != 0 and o.validate(bad) != 0, field
+    bad = type(pdu).from_buffer_copy(bytes(pdu))
+    bad.prb_mask[0] &= ~(1 << 40)          # a hole in the allocation while vrb_contiguous says contiguous
+    assert lib.validate(bad) != 0 and o.validate(bad) != 0
+    r = backends.ref()
+    if r is not None:
+        assert r.validate(bad) != 0
+    sys.path.insert(0, os.path.join(cases.ROOT if hasattr(cases, "ROOT") else os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
+    import fuzz_validators_cpu
+    for kind, (n, refused, disagreements, ref_refuses) in fuzz_validators_cpu.run(300, base=12345, verbose=False).items():
+        assert n >= 300 and refused > 0 and disagreements == 0 and ref_refuses == 0, (kind, n, refused, disagreements, ref_refuses)
+
+
 def test_host_only_helpers_of_the_lower_phy_tail():
     """Entry points that are pure host arithmetic: nrphy_amplitude_metrics (amplitude_controller_clipping_impl's metrics from
     the device's raw measurements, running counters included) against the compiled reference where it is built and against the
