@@ -47,6 +47,7 @@ extern "C" {
 #define NRPHY_PRB_WORDS 5      /* 5 x 64 bits >= 275 PRB */
 #define NRPHY_MAX_RESERVED 4   /* re_pattern_list::MAX_RE_PATTERN, R/include/srsran/phy/support/re_pattern.h:142 */
 #define NRPHY_MAX_CODEBLOCKS 162 /* MAX_NOF_SEGMENTS, R/include/srsran/ran/sch/sch_constants.h:38 */
+#define NRPHY_MAX_TB_BYTES (NRPHY_MAX_CODEBLOCKS * 8448 / 8) /* a transport block never has more bits than its codeblocks hold */
 
 /* Status codes.  The reference aborts (srsran_assert) on argument errors; this ABI returns a code. */
 enum {

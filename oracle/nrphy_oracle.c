@@ -284,6 +284,7 @@ int oracle_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
     return NRPHY_ERR_INVALID_PDU;
   }
   if (pdu->rv > 3 || (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->tb_size_bytes == 0 ||
+      pdu->tb_size_bytes > NRPHY_MAX_TB_BYTES ||
       pdu->nof_prg == 0 || pdu->nof_prg > NRPHY_MAX_RB || pdu->prg_size_rb == 0 || pdu->precoding == NULL || pdu->cp > 1) {
     return NRPHY_ERR_INVALID_PDU;
   }

@@ -439,8 +439,8 @@ extern "C" int nrphy_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
     }
   }
   if ((pdu->qm != 2 && pdu->qm != 4 && pdu->qm != 6 && pdu->qm != 8) || pdu->rv > 3 ||
-      (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->tb_size_bytes == 0 || pdu->nof_prg == 0 ||
-      pdu->nof_prg > NRPHY_MAX_RB || pdu->prg_size_rb == 0 || pdu->precoding == nullptr || pdu->cp > 1) {
+      (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->tb_size_bytes == 0 ||
+      pdu->tb_size_bytes > NRPHY_MAX_TB_BYTES || pdu->nof_prg == 0 || pdu->nof_prg > NRPHY_MAX_RB || pdu->prg_size_rb == 0 || pdu->precoding == nullptr || pdu->cp > 1) {
     // (nof_prg sizes the read of the caller's weight array: at most one PRG per resource block)
     return NRPHY_ERR_INVALID_PDU;
   }
@@ -854,7 +854,7 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
     if (enc == nullptr ? nrphy_pdsch_validate(&pdu) != NRPHY_OK
                        : (pdu.qm < 2 || pdu.qm > 8 || (pdu.qm & 1U) || pdu.rv > 3 || pdu.nof_layers == 0 ||
                           pdu.nof_layers > NRPHY_MAX_LAYERS || pdu.tb_size_bytes == 0 ||
-                          (pdu.ldpc_base_graph != 1 && pdu.ldpc_base_graph != 2))) {
+                          pdu.tb_size_bytes > NRPHY_MAX_TB_BYTES || (pdu.ldpc_base_graph != 1 && pdu.ldpc_base_graph != 2))) {
       status = NRPHY_ERR_INVALID_PDU;
       break;
     }
@@ -2285,7 +2285,7 @@ bool pusch_layout(const nrphy_pusch_decoder_cfg_t& cfg, uint32_t n_tb, PuschLayo
 {
   if ((cfg.base_graph != 1 && cfg.base_graph != 2) || (cfg.qm != 1 && cfg.qm != 2 && cfg.qm != 4 && cfg.qm != 6 && cfg.qm != 8) ||
       cfg.rv > 3 || cfg.nof_layers == 0 || cfg.nof_layers > NRPHY_MAX_LAYERS || cfg.tb_size_bytes == 0 ||
-      cfg.nof_ch_symbols == 0 || cfg.nof_ch_symbols % cfg.nof_layers != 0 || cfg.max_iterations == 0) {
+      cfg.tb_size_bytes > NRPHY_MAX_TB_BYTES || cfg.nof_ch_symbols == 0 || cfg.nof_ch_symbols % cfg.nof_layers != 0 || cfg.max_iterations == 0) {
     return false;
   }
   // Segmentation is the transmitter's (ldpc_segmenter_rx_impl mirrors ldpc_segmenter_tx): reuse its derivation.
