@@ -2641,7 +2641,8 @@ extern "C" int nrphy_csi_rs_map_host(nrphy_ctx_t* ctx, const nrphy_csi_rs_cfg_t*
 extern "C" int nrphy_grid_put(nrphy_ctx_t* ctx, void* d_grid, uint32_t nof_ports, uint32_t nof_subc, uint32_t n,
                               const nrphy_grid_re_t* entries, void* stream)
 {
-  if (ctx == nullptr || d_grid == nullptr || (n != 0 && entries == nullptr)) {
+  if (ctx == nullptr || d_grid == nullptr || (n != 0 && entries == nullptr) || nof_ports > NRPHY_MAX_PORTS ||
+      nof_subc > NRPHY_MAX_RB * 12) { // (also keeps the 32-bit element index below from wrapping)
     return NRPHY_ERR_ARGUMENT;
   }
   if (n == 0) {
