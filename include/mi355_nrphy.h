@@ -100,7 +100,7 @@ typedef struct nrphy_pdsch_pdu {
   uint32_t nof_layers;
   uint32_t nof_ports;
   uint32_t prg_size_rb;
-  uint32_t nof_prg;          /* 1 .. NRPHY_MAX_RB */
+  uint32_t nof_prg;          /* 1 .. NRPHY_MAX_RB (and prg_size_rb likewise; NRPHY_MAX_RB = wideband) */
   const float* precoding;    /* host pointer: [nof_prg][nof_ports][nof_layers] complex (re, im) */
 } nrphy_pdsch_pdu_t;
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Larger randomised sweeps than the test-suite runs, GPU against the oracle through the C ABI (the numbers DESIGN.md section
-2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [plan] [pusch] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
+2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [mutated] [plan] [pusch] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
 import ctypes as C
 import os
 import sys
@@ -16,7 +16,7 @@ import cases  # noqa: E402
 BASE = int(os.environ.get("NRPHY_FUZZ_SEED", "0"))
 abi, lib = backends.abi, backends.pkg.lib
 o = backends.oracle()
-ctx = lib.Context(0)
+ctx = lib.Context(0) if "--oracle-only" not in sys.argv else None
 
 
 def f32(raw):
@@ -40,6 +40,39 @@ def pdsch():
                 bad += 1
                 print("PDSCH MISMATCH seed", seed, d, flush=True)
     print("pdsch: %d random PDUs, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
+def mutated(device=True):
+    """Valid random PDUs with one or two fields overwritten at random (profiles/fuzz_validators_cpu.py: mutate); whatever both
+    validators still accept -- unusual but legal corners: odd identities, power ratios, reserved patterns, symbol ranges -- must
+    come out of the device exactly as out of the oracle.  device=False runs the oracle side alone (for the sanitizer build)."""
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import fuzz_validators_cpu as fv
+    rng = np.random.default_rng(BASE + 31337)
+    bad = n = tried = 0
+    while n < 150 and tried < 4000:
+        for pdu, P, S in cases.random_pdus(o.tbs, rng, 10):
+            tried += 1
+            for _ in range(int(rng.integers(1, 3))):
+                fv.mutate(rng, pdu)
+            if lib.validate(pdu) != 0 or o.validate(pdu) != 0:
+                continue
+            # the caller's side of the contract: a weight array of the size the (possibly overwritten) counts announce
+            cases.attach_weights(pdu, (rng.standard_normal((pdu.nof_prg, pdu.nof_ports, pdu.nof_layers, 2)) / 2).astype(np.float32))
+            d = o.derive(pdu)
+            hi = max((i for i in range(abi.MAX_RB) if (pdu.prb_mask[i // 64] >> (i % 64)) & 1), default=-1)
+            if d["nof_re"] == 0 or d["nof_codeblocks"] > 40 or 12 * (hi + 1) > S or pdu.nof_ports > P:
+                continue
+            tb = cases.random_tb(rng, pdu)
+            want, orm, oscr = o.pdsch_process(pdu, tb, P, S, taps=True, codeword_bits=d["codeword_bits"])
+            n += 1
+            if device:
+                got, rm, scr = ctx.pdsch_process_host(pdu, tb, P, S, taps=True)
+                if not (np.array_equal(got, want) and np.array_equal(rm, orm) and np.array_equal(scr, oscr)):
+                    bad += 1
+                    print("MUTATED PDU MISMATCH", n, d, flush=True)
+    print("mutated pdsch: %d PDUs with overwritten fields that stay valid (of %d tried), %d mismatches" % (n, tried, bad), flush=True)
     return bad
 
 
@@ -341,7 +374,9 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "mutated": mutated, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    if "--oracle-only" in sys.argv:   # the oracle side of the mutated leg alone, for the CPU sanitizer build
+        sys.exit(mutated(device=False))
     which = sys.argv[1:] or list(legs)
     total = sum(legs[w]() for w in which)
     sys.exit(1 if total else 0)
