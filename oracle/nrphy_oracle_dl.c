@@ -452,7 +452,7 @@ int oracle_ssb_validate(const nrphy_ssb_pdu_t* p)
     return NRPHY_ERR_INVALID_PDU;
   }
   const int l = ssb_l_first(p->pattern_case, p->ssb_idx), k = ssb_k_first(p);
-  if (l < 0 || k < 0) {
+  if (l < 0 || k < 0 || !isfinite(powf(10.0F, p->beta_pss_dB / 20.0F))) {
     return NRPHY_ERR_INVALID_PDU;
   }
   /* the slot must be the one of the half frame that holds the block (ssb_processor_impl.cpp:41-44) */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Larger randomised sweeps than the test-suite runs, GPU against the oracle through the C ABI (the numbers DESIGN.md section
-2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [mutated] [plan] [pusch] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
+2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [mutated] [mutated_ctrl] [plan] [pusch] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
 import ctypes as C
 import os
 import sys
@@ -82,6 +82,62 @@ def mutated(device=True):
                           "scrambled", np.array_equal(scr, oscr), d, flush=True)
     print("mutated pdsch: %d PDUs with overwritten fields that stay valid (of %d tried), %d mismatches" % (n, tried, bad), flush=True)
     return bad
+
+
+def mutated_ctrl(device=True):
+    """The same for the other grid writers: PDCCH, SS/PBCH and NZP-CSI-RS descriptors with overwritten fields that both validators
+    still accept, into grids full of other data."""
+    import ctypes as C_
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import fuzz_validators_cpu as fv
+    h = lib.load()
+    rng = np.random.default_rng(BASE + 27182)
+    total = 0
+
+    def weights(obj, count):
+        f = (rng.standard_normal(2 * count) / 2).astype(np.float32)
+        obj._keepalive = f
+        obj.precoding = f.ctypes.data_as(C_.POINTER(C_.c_float))
+
+    for kind in ("pdcch", "ssb", "csi"):
+        bad = n = tried = 0
+        while n < 150 and tried < 6000:
+            tried += 1
+            if kind == "pdcch":
+                obj = cases.random_pdcch(rng)
+            elif kind == "ssb":
+                obj = cases.random_ssb(rng, int(rng.integers(24, 107)), int(rng.integers(1, 5)))
+            else:
+                obj = cases.csi_rs_cases(rng)[int(rng.integers(0, 4))][1]
+            fields = [fv.mutate(rng, obj) for _ in range(int(rng.integers(1, 3)))]
+            if kind == "pdcch":
+                if h.nrphy_pdcch_validate(C_.byref(obj)) != 0 or o.pdcch_validate(obj) != 0:
+                    continue
+                weights(obj, obj.nof_prg * obj.nof_ports)
+                ports, subc = 4, 12 * (obj.bwp_start_rb + obj.bwp_size_rb)
+            elif kind == "ssb":
+                if h.nrphy_ssb_validate(C_.byref(obj)) != 0 or o.ssb_validate(obj) != 0:
+                    continue
+                ports, subc = 4, 12 * cases.ssb_grid_rb(obj)
+            else:
+                if h.nrphy_csi_rs_validate(C_.byref(obj)) != 0 or o.csi_rs_validate(obj) != 0:
+                    continue
+                weights(obj, obj.nof_ports * obj.nof_ports)
+                ports, subc = 4, 12 * (obj.start_rb + obj.nof_rb)
+            if subc > 12 * abi.MAX_RB:
+                continue
+            grid = (rng.standard_normal((ports, 14, subc, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+            want = {"pdcch": o.pdcch_process, "ssb": o.ssb_process, "csi": o.csi_rs_map}[kind](obj, grid)
+            n += 1
+            if device:
+                got = {"pdcch": ctx.pdcch_process_host, "ssb": ctx.ssb_process_host, "csi": ctx.csi_rs_map_host}[kind](obj, grid)
+                if not same_grid(got, want):
+                    bad += 1
+                    print("MUTATED", kind.upper(), "MISMATCH", n, "overwritten:", fields, flush=True)
+        print("mutated %s: %d descriptors with overwritten fields that stay valid (of %d tried), %d mismatches" % (kind, n, tried, bad),
+              flush=True)
+        total += bad
+    return total
 
 
 def plan():
@@ -382,9 +438,9 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "mutated": mutated, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     if "--oracle-only" in sys.argv:   # the oracle side of the mutated leg alone, for the CPU sanitizer build
-        sys.exit(mutated(device=False))
+        sys.exit(mutated(device=False) + mutated_ctrl(device=False))
     which = sys.argv[1:] or list(legs)
     total = sum(legs[w]() for w in which)
     sys.exit(1 if total else 0)

@@ -616,6 +616,10 @@ extern "C" int nrphy_ssb_validate(const nrphy_ssb_pdu_t* p)
   if (l < 0 || ssb_first_subcarrier(*p) < 0) {
     return NRPHY_ERR_INVALID_PDU;
   }
+  // A PSS amplitude that is not a number (the reference would write 0 x inf = NaN imaginary parts): refused.
+  if (!std::isfinite(db_to_amplitude(p->beta_pss_dB))) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
   // ssb_processor_impl.cpp:41-44: the slot is the one of its half frame that holds the block
   if ((uint32_t)l / 14 != p->slot_index % ((10U << p->numerology) / 2)) {
     return NRPHY_ERR_INVALID_PDU;
