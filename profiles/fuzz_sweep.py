@@ -333,6 +333,52 @@ def ofdm():
     return bad
 
 
+def wire():
+    """nrphy_ofdm_run_ci16 (modulator + amplitude controller + int16 conversion fused) on random configurations and amplitude
+    settings: equal to the device modulator followed by the oracle's amplitude controller and conversion up to one LSB at rounding
+    ties (> 99.99 % identical), clipped-sample count, processed count and peak power exact, power sum to 1e-4."""
+    import torch
+    rng = np.random.default_rng(BASE + 16180)
+    bad = n = 0
+    for t in range(40):
+        size = int(rng.choice([256, 512, 1024, 1536, 2048, 4096, 4608, 6144]))
+        mu, ext = int(rng.integers(0, 4)), int(rng.integers(0, 5) == 0)
+        bw, ports, slots = int(rng.integers(1, min(275, (size - 1) // 12) + 1)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        ocfg = abi.OfdmConfig(mu, bw, size, ext, float(rng.uniform(0.5, 2.0)) / np.sqrt(size), float(rng.choice([0.0, 2.4e9, 3.5e9])))
+        amp = abi.AmplitudeCfg(0, int(rng.integers(0, 2)), float(rng.uniform(-20, 6)), float(rng.choice([1.0, 2.0])), float(rng.uniform(-12, -0.5)))
+        wire_cfg = abi.IqWireCfg(amp, float(rng.choice([32767.0, 20000.0, 40000.0])))
+        grid = ((rng.standard_normal((slots, ports, 14, bw * 12, 2)) * rng.uniform(0.2, 1.0)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        pl = lib.OfdmPlan(ctx, ocfg, ports)
+        d_grid = torch.from_numpy(grid.view(np.uint32).reshape(slots, ports, 14, bw * 12).view(np.int32)).cuda()
+        d_slot = torch.from_numpy((np.arange(slots, dtype=np.uint32) % (1 << mu)).view(np.int32)).cuda()
+        d_iq16 = torch.zeros((slots, ports, pl.slot_stride, 2), dtype=torch.int16, device="cuda")
+        d_stats = torch.zeros((slots * ports, 4), dtype=torch.int32, device="cuda")
+        d_iq = torch.zeros((slots, ports, pl.slot_stride, 2), dtype=torch.float32, device="cuda")
+        pl.run_ci16(slots, d_grid, wire_cfg, d_iq16, d_slot_index=d_slot, d_stats=d_stats)
+        pl.run(slots, d_grid, d_iq, d_slot_index=d_slot)
+        ctx.synchronize()
+        fused, stats = d_iq16.cpu().numpy(), d_stats.cpu().numpy()
+        iq = d_iq.cpu().numpy().view(np.complex64).reshape(slots, ports, -1)
+        ok = True
+        for s_ in range(slots):
+            ssz = lib.slot_size(ocfg, int(s_ % (1 << mu)))
+            for p_ in range(ports):
+                y, m = o.amplitude_control(wire_cfg.amplitude, iq[s_, p_, :ssz])
+                want = o.iq_convert_ci16(y, wire_cfg.ci16_scale).reshape(-1, 2)
+                st = stats[s_ * ports + p_]
+                ok = ok and np.abs(fused[s_, p_, :ssz].astype(np.int32) - want.astype(np.int32)).max() <= 1
+                ok = ok and np.mean(fused[s_, p_, :ssz] == want) > 0.9999 and st[3] == ssz and st[2] == m["nof_clipped"]
+                ok = ok and st[1].view(np.float32) == np.float32(m["stats"].peak_power)
+                ok = ok and abs(st[0].view(np.float32) - m["stats"].sum_power) <= 1e-4 * max(m["stats"].sum_power, 1e-30)
+        pl.close()
+        n += 1
+        if not ok:
+            bad += 1
+            print("WIRE MISMATCH", size, mu, ext, bw, ports, slots, amp.enable_clipping, amp.input_gain_dB, amp.ceiling_dBFS, wire_cfg.ci16_scale, flush=True)
+    print("wire-format ofdm: %d random configurations, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
 def csi():
     rng = np.random.default_rng(BASE + 8088)
     bad = 0
@@ -438,7 +484,7 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     if "--oracle-only" in sys.argv:   # the oracle side of the mutated leg alone, for the CPU sanitizer build
         sys.exit(mutated(device=False) + mutated_ctrl(device=False))
     which = sys.argv[1:] or list(legs)

@@ -547,7 +547,11 @@ struct IqSink {
 // HBM.  The controller's measurements (sum and maximum of |x|^2 after the gain, clipped parts) accumulate per thread;
 // a sample inside the cyclic prefix counts twice, as in the buffer the reference measures.
 // Wave-wide reductions without LDS traffic: butterflies inside a row of 16 lanes by DPP (lane ^ 1, lane ^ 2, mirrored halves,
-// mirrored row), then the four row results through scalar registers.  Every lane returns the result.
+// mirrored row), then the four row results through scalar registers.  Every lane returns the result.  Zero must be the
+// operation's identity (sums and maxima of non-negative values here): a disabled lane contributes zero inside a row (bound_ctrl),
+// and a row without active lanes -- the second half of the last wavefront of a 288-thread workgroup (N = 4608) -- is left out
+// (its registers hold whatever an earlier wavefront left there).  Rows are active or inactive as a whole for every workgroup size
+// in use (multiples of 32).
 template <typename Op>
 __device__ __forceinline__ uint32_t wave_reduce_bits(uint32_t v, Op op)
 {
@@ -555,8 +559,11 @@ __device__ __forceinline__ uint32_t wave_reduce_bits(uint32_t v, Op op)
   v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));  // quad_perm [2, 3, 0, 1]
   v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true)); // row_half_mirror
   v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true)); // row_mirror
-  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-  const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  const uint64_t active = __builtin_amdgcn_read_exec();
+  const uint32_t r0 = (active >> 0) & 1u ? (uint32_t)__builtin_amdgcn_readlane((int)v, 0) : 0u;
+  const uint32_t r1 = (active >> 16) & 1u ? (uint32_t)__builtin_amdgcn_readlane((int)v, 16) : 0u;
+  const uint32_t r2 = (active >> 32) & 1u ? (uint32_t)__builtin_amdgcn_readlane((int)v, 32) : 0u;
+  const uint32_t r3 = (active >> 48) & 1u ? (uint32_t)__builtin_amdgcn_readlane((int)v, 48) : 0u;
   return op(op(r0, r1), op(r2, r3));
 }
 __device__ __forceinline__ float wave_sum(float v)
@@ -771,7 +778,7 @@ __global__ __launch_bounds__(Plan<N>::T) OFDM_OCCUPANCY void ofdm_kernel(OfdmLau
       w_sum     = wave_sum(w_sum);
       w_peak    = wave_max(w_peak);
       w_clipped = wave_sum(w_clipped);
-      constexpr uint32_t NW  = Plan<N>::T / WAVE;
+      constexpr uint32_t NW  = (Plan<N>::T + WAVE - 1) / WAVE; // (288 threads at N = 4608: four wavefronts and a half)
       uint32_t*          red = reinterpret_cast<uint32_t*>(lds);
       __syncthreads(); // the last symbol's butterflies are done with the LDS
       if ((tid & (WAVE - 1)) == 0) {

@@ -1391,7 +1391,8 @@ def test_ofdm_modulator_wire_format_output(gpu_ctx, oracle):
             abi.AmplitudeCfg(0, 1, -10.0, 1.0, -6.0), abi.AmplitudeCfg(0, 0, 6.0, 1.0, -1.0))
     for k, (mu, bw, n, ext, ports, slots) in enumerate(((1, 273, 4096, 0, 2, 3), (1, 273, 4096, 0, 1, 1), (1, 273, 4096, 0, 1, 2),
                                                         (1, 273, 4096, 0, 1, 1), (0, 52, 1024, 0, 1, 2), (2, 24, 512, 1, 1, 2),
-                                                        (0, 270, 6144, 0, 1, 1), (0, 52, 1024, 0, 1, 2))):
+                                                        (0, 270, 6144, 0, 1, 1), (0, 52, 1024, 0, 1, 2),
+                                                        (1, 273, 4608, 0, 2, 2), (1, 100, 4608, 1, 1, 1))):   # 4608: 288 threads, a half wavefront
         ocfg = abi.OfdmConfig(mu, bw, n, ext, 1.0 / np.sqrt(n), 3.5e9)
         grid = ((rng.standard_normal((slots, ports, 14, bw * 12, 2)) * 0.5).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
         plan = lib.OfdmPlan(gpu_ctx, ocfg, ports)
