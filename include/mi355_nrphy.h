@@ -692,7 +692,10 @@ int nrphy_iq_convert_ci16_host(nrphy_ctx_t* ctx, const float* in, uint32_t nof_s
  * int16 (4 bytes per sample instead of 8: the IQ write is 71 % of the modulator's traffic).  Every sample takes the
  * path modulator -> amplitude controller (gain, clipping per buffer = per (grid, port) slot) -> conversion, in the
  * reference's order of roundings.  d_iq: [grid][port][slot_stride] complex int16; d_stats: [grid][port] or NULL.
- * Every conversion rounds to nearest even (the reference's vector path: a whole slot never reaches its scalar tail).
+ * Every sample is converted as the reference's vector loop does it (round to nearest even, saturate).  The reference's scalar tail
+ * -- the last (2 n mod 16) floats of ONE conversion call round half away from zero and wrap instead of saturating -- has no
+ * counterpart here: where it falls depends on how the caller of the reference cuts its buffers, not on the slot
+ * (nrphy_iq_convert_ci16 reproduces it per call).
  * With d_stats the plan keeps one 16-byte record per workgroup in a buffer of its own that grows with the largest
  * nof_grids seen (a synchronous reallocation on growth only): run the largest batch once before capturing the call in a
  * hipGraph, and keep the runs of one plan ordered (Conventions). */
