@@ -140,6 +140,54 @@ def mutated_ctrl(device=True):
     return total
 
 
+def encode():
+    """Seam B (nrphy_pdsch_encode_host: segmentation, LDPC, rate matching, interleaving from the encoder configuration alone): random
+    base graph, redundancy version, modulation, layers, limited-buffer size, transport-block and codeword sizes; and nrphy_dft_run on
+    every size of the reference's generic DFT with random batches."""
+    import torch
+    rng = np.random.default_rng(BASE + 14142)
+    bad = n = 0
+    while n < 150:
+        bg, rv, qm, layers = int(rng.integers(1, 3)), int(rng.integers(0, 4)), int(rng.choice([2, 4, 6, 8])), int(rng.integers(1, 5))
+        tb_bytes = int(rng.choice([rng.integers(3, 60), rng.integers(60, 1200), rng.integers(1200, 20000)]))
+        if bg == 2 and tb_bytes * 8 > 3824 and rng.integers(0, 2):
+            continue
+        rate = float(rng.uniform(0.08, 0.93))
+        nsym = max(layers, int(tb_bytes * 8 / rate / qm) // layers * layers)
+        if nsym * qm > 1200000:
+            continue
+        nref = int(rng.choice([0, 0, int(rng.integers(3000, 30000))]))
+        tb = rng.integers(0, 256, tb_bytes, dtype=np.uint8)
+        try:
+            want = o.pdsch_encode_cfg(bg, rv, qm, nref, layers, nsym, tb)
+        except AssertionError:
+            continue   # a configuration the oracle refuses (e.g. more codeblocks than bits): nothing to compare
+        bits, packed = ctx.pdsch_encode_host(bg, rv, qm, nref, layers, nsym, tb)
+        n += 1
+        if not (np.array_equal(packed, want[: packed.size]) and np.array_equal(np.packbits(bits), packed) and bits.size == nsym * qm):
+            bad += 1
+            print("ENCODER MISMATCH", bg, rv, qm, nref, layers, nsym, tb_bytes, flush=True)
+    print("encoder seam: %d random configurations, %d mismatches" % (n, bad), flush=True)
+    bad2 = 0
+    sizes = [128, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 4608, 6144, 9216, 12288, 18432, 24576, 36864, 49152]
+    for t in range(40):
+        size, inverse, batch = int(rng.choice(sizes)), int(rng.integers(0, 2)), int(rng.integers(1, 8))
+        x = ((rng.standard_normal((batch, size)) + 1j * rng.standard_normal((batch, size))) * rng.uniform(0.1, 10)).astype(np.complex64)
+        d_in = torch.from_numpy(x.view(np.float32)).cuda()
+        d_out = torch.zeros_like(d_in)
+        ctx.dft(size, inverse, batch, d_in, d_out)
+        ctx.synchronize()
+        out = d_out.cpu().numpy().view(np.complex64)
+        for i in range(batch):
+            want = o.dft(x[i], inverse)
+            if np.abs(out[i] - want).max() / np.abs(want).max() >= 1e-5:
+                bad2 += 1
+                print("DFT MISMATCH", size, inverse, batch, i, flush=True)
+                break
+    print("dft: 40 random (size, direction, batch), %d mismatches" % bad2, flush=True)
+    return bad + bad2
+
+
 def plan():
     """The batched path (what bench.py times): groups of 24 random PDUs in ONE plan, each into its own grid of a common shape, run
     twice on the same grids with new transport blocks (the second run must overwrite everything the first one wrote)."""
@@ -487,7 +535,7 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     if "--oracle-only" in sys.argv:   # the oracle side of the mutated leg alone, for the CPU sanitizer build
         sys.exit(mutated(device=False) + mutated_ctrl(device=False))
     which = sys.argv[1:] or list(legs)
