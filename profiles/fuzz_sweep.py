@@ -188,6 +188,98 @@ def encode():
     return bad + bad2
 
 
+def batched():
+    """The device-pointer forms with several rows per call and padded strides: soft demodulator spans, soft-bit descrambling of
+    several codewords (also in place), amplitude controller and cf32 -> ci16 on strided buffers, fronthaul compression rows."""
+    import torch
+    rng = np.random.default_rng(BASE + 17320)
+    bad = n = 0
+    for t in range(60):
+        modulation = int(rng.choice([0, 1, 2, 4, 6, 8]))
+        qm = max(modulation, 1)
+        spans, length = int(rng.integers(1, 9)), int(rng.integers(1, 3000))
+        sym, noise = cases.demod_inputs(rng, modulation, spans * length, int(rng.integers(0, 3)))
+        d_llr = torch.zeros(spans * length * qm + 64, dtype=torch.int8, device="cuda")
+        ctx.demodulate_soft(modulation, spans, length, torch.from_numpy(np.ascontiguousarray(sym).view(np.float32)).cuda(),
+                            torch.from_numpy(noise).cuda(), d_llr)
+        ctx.synchronize()
+        got = d_llr.cpu().numpy()
+        ok = not got[spans * length * qm:].any()
+        for r_ in range(spans):
+            want = o.demodulate_soft(modulation, sym[r_ * length:(r_ + 1) * length], noise[r_ * length:(r_ + 1) * length])
+            ok = ok and np.array_equal(got[r_ * length * qm:(r_ + 1) * length * qm], want)
+        n += 1
+        if not ok:
+            bad += 1
+            print("BATCHED DEMOD MISMATCH", modulation, spans, length, flush=True)
+    for t in range(40):
+        n_cw, length = int(rng.integers(1, 7)), int(rng.choice([rng.integers(1, 300), rng.integers(1, 70000), rng.integers(65000, 140000)]))
+        stride = length + int(rng.integers(0, 40))
+        c_init = rng.integers(0, 1 << 31, n_cw).astype(np.uint32)
+        llr = rng.integers(-128, 128, (n_cw, stride)).astype(np.int8)
+        d_in = torch.from_numpy(llr.copy()).cuda()
+        in_place = bool(rng.integers(0, 2))
+        d_out = d_in if in_place else torch.full((n_cw, stride), 99, dtype=torch.int8, device="cuda")
+        ctx.llr_descramble(torch.from_numpy(c_init.view(np.int32)).cuda(), n_cw, length, d_in, stride, d_out, stride)
+        ctx.synchronize()
+        got = d_out.cpu().numpy()
+        ok = True
+        for r_ in range(n_cw):
+            ok = ok and np.array_equal(got[r_, :length], o.prg_apply_xor_llr(int(c_init[r_]), 0, llr[r_, :length]))
+            ok = ok and np.array_equal(got[r_, length:], llr[r_, length:] if in_place else np.full(stride - length, 99, np.int8))
+        n += 1
+        if not ok:
+            bad += 1
+            print("BATCHED DESCRAMBLER MISMATCH", n_cw, length, stride, in_place, flush=True)
+    for t in range(40):
+        n_buf, ns = int(rng.integers(1, 9)), int(rng.integers(1, 5000))
+        stride = ns + int(rng.integers(0, 33))
+        x = ((rng.standard_normal((n_buf, stride)) + 1j * rng.standard_normal((n_buf, stride))) * rng.uniform(0.05, 2.0)).astype(np.complex64)
+        cfg = abi.AmplitudeCfg(int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.uniform(-12, 6)), float(rng.uniform(0.5, 2)),
+                               float(rng.uniform(-12, -0.1)))
+        scale = float(rng.choice([32767.0, 1000.0, 20000.0]))
+        d_x = torch.from_numpy(x.view(np.float32).copy()).cuda()
+        d_y = torch.zeros_like(d_x)
+        d_st = torch.zeros((n_buf, 4), dtype=torch.int32, device="cuda")
+        d16 = torch.zeros((n_buf, stride, 2), dtype=torch.int16, device="cuda")
+        ctx.amplitude_control(cfg, n_buf, ns, d_x, d_y, d_st, in_stride=stride, out_stride=stride)
+        ctx.iq_convert_ci16(n_buf, ns, d_y, scale, d16, in_stride=stride, out_stride=stride)
+        ctx.synchronize()
+        y, st, y16 = d_y.cpu().numpy().view(np.complex64).reshape(n_buf, stride), d_st.cpu().numpy(), d16.cpu().numpy()
+        ok = True
+        for r_ in range(n_buf):
+            want, wm = o.amplitude_control(cfg, x[r_, :ns])
+            ok = ok and np.array_equal(y[r_, :ns].view(np.uint32), want.view(np.uint32)) and not y[r_, ns:].any()
+            ok = ok and np.array_equal(y16[r_, :ns].reshape(-1), o.iq_convert_ci16(want, scale)) and not y16[r_, ns:].any()
+            if cfg.kind == 0:   # the clipping implementation measures
+                ok = ok and st[r_, 2] == wm["nof_clipped"] and st[r_, 1].view(np.float32) == np.float32(wm["stats"].peak_power)
+        n += 1
+        if not ok:
+            bad += 1
+            print("BATCHED AMPLITUDE / CI16 MISMATCH", n_buf, ns, stride, cfg.kind, cfg.enable_clipping, flush=True)
+    for t in range(40):
+        rows, nprb = int(rng.integers(1, 9)), int(rng.integers(1, 120))
+        cfg = abi.OfhCompressionCfg(int(rng.integers(0, 2)), int(rng.integers(8, 17)), float(rng.uniform(0.2, 1.5)))
+        rec = ctx.lib.nrphy_ofh_compressed_prb_bytes(C.byref(cfg))
+        rstride, ostride = 12 * nprb + 12 * int(rng.integers(0, 3)), rec * nprb + int(rng.integers(0, 9))
+        prbs = (((rng.standard_normal((rows, rstride, 2)) * rng.uniform(0.01, 1.5)).astype(np.float32).view(np.uint32)) >> 16).astype(np.uint16)
+        d_p = torch.from_numpy(prbs.view(np.uint32).reshape(rows, rstride).view(np.int32).copy()).cuda()
+        d_o = torch.full((rows, ostride), 0x5A, dtype=torch.uint8, device="cuda")
+        ctx.ofh_compress(cfg, rows, nprb, d_p, d_o, row_stride=rstride, out_row_stride=ostride)
+        ctx.synchronize()
+        got = d_o.cpu().numpy()
+        ok = True
+        for r_ in range(rows):
+            want = o.ofh_compress(cfg, prbs[r_, : 12 * nprb].reshape(nprb, 12, 2))
+            ok = ok and np.array_equal(got[r_, : rec * nprb], want) and np.all(got[r_, rec * nprb:] == 0x5A)
+        n += 1
+        if not ok:
+            bad += 1
+            print("BATCHED OFH MISMATCH", rows, nprb, cfg.type, cfg.data_width, flush=True)
+    print("batched device forms: %d random calls (demodulator, descrambler, amplitude / ci16, fronthaul), %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
 def plan():
     """The batched path (what bench.py times): groups of 24 random PDUs in ONE plan, each into its own grid of a common shape, run
     twice on the same grids with new transport blocks (the second run must overwrite everything the first one wrote)."""
@@ -535,7 +627,7 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "batched": batched, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     if "--oracle-only" in sys.argv:   # the oracle side of the mutated leg alone, for the CPU sanitizer build
         sys.exit(mutated(device=False) + mutated_ctrl(device=False))
     which = sys.argv[1:] or list(legs)
