@@ -280,6 +280,59 @@ def batched():
     return bad
 
 
+def slot():
+    """nrphy_pdsch_process_slot_host: two to six PDUs with disjoint PRB ranges, different users, modulations, rates, layer counts and
+    symbol ranges into ONE grid (the FAPI slot batch); the oracle processes them one by one, the union of their resource elements is
+    the expected grid (each writes zeros elsewhere)."""
+    rng = np.random.default_rng(BASE + 22360)
+    bad = n = 0
+    while n < 30:
+        ports = int(rng.integers(1, 5))
+        bwp = int(rng.integers(24, 273))
+        k = int(rng.integers(2, 7))
+        cuts = np.sort(rng.choice(np.arange(1, bwp), k - 1, replace=False)) if bwp > k else None
+        if cuts is None:
+            continue
+        edges = [0] + [int(c) for c in cuts] + [bwp]
+        pdus, tbs_ = [], []
+        for u in range(k):
+            lo, hi = edges[u], edges[u + 1]
+            if hi - lo > 2 and rng.integers(0, 2):
+                lo += 1   # a gap between two users
+            layers = int(rng.integers(1, ports + 1))
+            qm, rate = int(rng.choice([2, 4, 6, 8])), float(rng.uniform(100, 940))
+            start = int(rng.integers(0, 3))
+            nsym = int(rng.integers(6, 14 - start + 1))
+            dmrs = sorted(int(x) for x in rng.choice(np.arange(start, start + nsym), int(rng.integers(1, 4)), replace=False))
+            groups = int(rng.integers((layers + 1) // 2, 3))
+            tb_bits = o.tbs(nsym, len(dmrs) * 6 * groups, 0, qm, rate, layers, hi - lo)
+            if tb_bits < 24:
+                break
+            r_ = rate / 1024
+            bg = 2 if (tb_bits <= 292 or (tb_bits <= 3824 and r_ <= 0.67) or r_ <= 0.25) else 1
+            w = ((rng.standard_normal((1, ports, layers)) + 1j * rng.standard_normal((1, ports, layers))) / 2).astype(np.complex64)
+            pdus.append(abi.make_pdu(slot_index=int(rng.integers(0, 20)), rnti=int(rng.integers(1, 65535)), n_id=int(rng.integers(0, 1024)),
+                                     bwp_size_rb=bwp, qm=qm, dmrs_symbols=tuple(dmrs), prb_start=lo, prb_count=hi - lo, start_symbol=start,
+                                     nof_symbols=nsym, base_graph=bg, precoding=w, tb_size_bytes=tb_bits // 8,
+                                     nof_cdm_groups_without_data=groups, rv=int(rng.integers(0, 4))))
+            tbs_.append(None)
+        if len(pdus) != k or any(o.validate(q) != 0 or o.derive(q)["nof_re"] == 0 for q in pdus):
+            continue
+        tbs_ = [cases.random_tb(rng, q) for q in pdus]
+        want = np.zeros((ports, 14, bwp * 12, 2), np.uint16)
+        for q, tb in zip(pdus, tbs_):
+            want |= o.pdsch_process(q, tb, ports, bwp * 12)
+        # (an empty grid: what other channels wrote before is kept by the call -- tests/test_gpu_parity.py covers that -- and an element a
+        # PDU maps with the value zero could not be told from one it leaves alone)
+        got = ctx.pdsch_process_slot_host(pdus, tbs_, np.zeros((ports, 14, bwp * 12, 2), np.uint16))
+        n += 1
+        if not np.array_equal(got, want):
+            bad += 1
+            print("SLOT MISMATCH", n, ports, bwp, k, int(np.count_nonzero(got != want)), flush=True)
+    print("pdsch slots: %d random slots of 2-6 PDUs in one grid, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
 def plan():
     """The batched path (what bench.py times): groups of 24 random PDUs in ONE plan, each into its own grid of a common shape, run
     twice on the same grids with new transport blocks (the second run must overwrite everything the first one wrote)."""
@@ -627,7 +680,7 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "batched": batched, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "batched": batched, "slot": slot, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     if "--oracle-only" in sys.argv:   # the oracle side of the mutated leg alone, for the CPU sanitizer build
         sys.exit(mutated(device=False) + mutated_ctrl(device=False))
     which = sys.argv[1:] or list(legs)
