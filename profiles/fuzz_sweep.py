@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Larger randomised sweeps than the test-suite runs, GPU against the oracle through the C ABI (the numbers DESIGN.md section
-2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [mutated] [mutated_ctrl] [plan] [pusch] [rx] [ofdm] [csi] [dlctrl] [demod] [lower]   (default: all)"""
+2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [mutated] [mutated_ctrl] [encode] [batched] [slot] [async] [plan] [pusch] [rx] [ofdm] [wire] [csi] [dlctrl] [demod] [lower]   (default: all)"""
 import ctypes as C
 import os
 import sys
@@ -330,6 +330,42 @@ def slot():
             bad += 1
             print("SLOT MISMATCH", n, ports, bwp, k, int(np.count_nonzero(got != want)), flush=True)
     print("pdsch slots: %d random slots of 2-6 PDUs in one grid, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
+def async_queue():
+    """nrphy_pdsch_async_*: 60 random PDUs through a queue of three operations in flight (random shapes: the plan cache of a slot misses
+    and evicts), every completion once with the PDU's grid, in the three staging modes (NRPHY_ASYNC_ZERO_COPY unset, 1, 3)."""
+    import threading
+    import time
+    bad = n = 0
+    for mode in (None, "1", "3"):
+        if mode is None:
+            os.environ.pop("NRPHY_ASYNC_ZERO_COPY", None)
+        else:
+            os.environ["NRPHY_ASYNC_ZERO_COPY"] = mode
+        rng = np.random.default_rng(BASE + 26457 + (0 if mode is None else int(mode)))
+        drawn = [x for x in cases.random_pdus(o.tbs, rng, 24) if o.validate(x[0]) == 0 and o.derive(x[0])["nof_re"] > 0][:20]
+        nof_ports, nof_subc = 4, max(x[2] for x in drawn)
+        q = lib.PdschAsyncQueue(ctx, 3, nof_ports, nof_subc, max(x[0].tb_size_bytes for x in drawn))
+        results, lock = {}, threading.Lock()
+        jobs = [(x[0], cases.random_tb(rng, x[0])) for x in drawn]
+        for i, (pdu, tb) in enumerate(jobs):
+            def on_done(status, grid, i=i):
+                with lock:
+                    results.setdefault(i, []).append((status, grid))
+            while not q.submit(pdu, tb, on_done):
+                time.sleep(0.0005)
+        q.wait()
+        for i, (pdu, tb) in enumerate(jobs):
+            n += 1
+            got = results.get(i, [])
+            if len(got) != 1 or got[0][0] != 0 or not np.array_equal(got[0][1], o.pdsch_process(pdu, tb, nof_ports, nof_subc)):
+                bad += 1
+                print("ASYNC MISMATCH mode", mode, "job", i, len(got), flush=True)
+        q.close()
+    os.environ.pop("NRPHY_ASYNC_ZERO_COPY", None)
+    print("asynchronous seam: %d random PDUs, three in flight, three staging modes, %d mismatches" % (n, bad), flush=True)
     return bad
 
 
@@ -680,7 +716,7 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "batched": batched, "slot": slot, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "batched": batched, "slot": slot, "async": async_queue, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     if "--oracle-only" in sys.argv:   # the oracle side of the mutated leg alone, for the CPU sanitizer build
         sys.exit(mutated(device=False) + mutated_ctrl(device=False))
     which = sys.argv[1:] or list(legs)
