@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Larger randomised sweeps than the test-suite runs, GPU against the oracle through the C ABI (the numbers DESIGN.md section
-2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [mutated] [mutated_ctrl] [encode] [batched] [slot] [async] [plan] [pusch] [rx] [ofdm] [wire] [csi] [dlctrl] [demod] [lower]   (default: all)"""
+2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [mutated] [mutated_ctrl] [encode] [batched] [slot] [async] [ctrl_batched] [plan] [pusch] [rx] [ofdm] [wire] [csi] [dlctrl] [demod] [lower]   (default: all)"""
 import ctypes as C
 import os
 import sys
@@ -369,6 +369,61 @@ def async_queue():
     return bad
 
 
+def ctrl_batched():
+    """The device-pointer forms of the other grid writers: batches of 4-16 NZP-CSI-RS signals, DCIs and SS/PBCH blocks in one call each,
+    every item into a device grid of its own (full of other data), plus sparse host writes (nrphy_grid_put) with repeated positions."""
+    import torch
+    rng = np.random.default_rng(BASE + 31622)
+    bad = n = 0
+    ports, subc = 4, 106 * 12
+    for t in range(12):
+        m = int(rng.integers(4, 17))
+        kind = ("csi", "pdcch", "ssb")[t % 3]
+        items = []
+        while len(items) < m:
+            if kind == "csi":
+                name, cfg, p_, s_ = cases.csi_rs_cases(rng)[int(rng.integers(0, 4))]
+                if o.csi_rs_validate(cfg) == 0 and p_ <= ports and 12 * (cfg.start_rb + cfg.nof_rb) <= subc:
+                    items.append(cfg)
+            elif kind == "pdcch":
+                pdu = cases.random_pdcch(rng)
+                if 12 * (pdu.bwp_start_rb + pdu.bwp_size_rb) <= subc:
+                    items.append(pdu)
+            else:
+                pdu = cases.random_ssb(rng, 106, int(rng.integers(1, 5)))
+                if o.ssb_validate(pdu) == 0 and cases.ssb_grid_rb(pdu) <= 106:
+                    items.append(pdu)
+        grids = (rng.standard_normal((m, ports, 14, subc, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        d_grid = torch.from_numpy(grids.view(np.uint32).reshape(m, ports, 14, subc).view(np.int32).copy()).cuda()
+        call = {"csi": ctx.csi_rs_map, "pdcch": ctx.pdcch_process, "ssb": ctx.ssb_process}[kind]
+        call(items, list(range(m)), d_grid, ports, subc)
+        ctx.synchronize()
+        got = d_grid.cpu().numpy().view(np.uint16).reshape(m, ports, 14, subc, 2)
+        ref_call = {"csi": o.csi_rs_map, "pdcch": o.pdcch_process, "ssb": o.ssb_process}[kind]
+        for i in range(m):
+            n += 1
+            if not np.array_equal(got[i], ref_call(items[i], grids[i])):
+                bad += 1
+                print("BATCHED", kind.upper(), "MISMATCH", t, i, flush=True)
+    for t in range(10):
+        grid = (rng.standard_normal((ports, 14, subc, 2)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        k = int(rng.integers(1, 400))
+        entries = [(int(rng.integers(0, ports)), int(rng.integers(0, 14)), int(rng.integers(0, subc)), int(rng.integers(0, 1 << 32))) for _ in range(k)]
+        entries += entries[: k // 4]   # repeated positions: the later entry wins, here with the same value
+        want = grid.copy().view(np.uint32).reshape(ports, 14, subc)
+        for p_, l_, s_, v_ in entries:
+            want[p_, l_, s_] = v_
+        d_grid = torch.from_numpy(grid.view(np.uint32).reshape(ports, 14, subc).view(np.int32).copy()).cuda()
+        ctx.grid_put(d_grid, ports, subc, entries)
+        ctx.synchronize()
+        n += 1
+        if not np.array_equal(d_grid.cpu().numpy().view(np.uint32), want):
+            bad += 1
+            print("GRID PUT MISMATCH", t, k, flush=True)
+    print("batched grid writers: %d items (CSI-RS, PDCCH, SS/PBCH in device grids; sparse writes), %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
 def plan():
     """The batched path (what bench.py times): groups of 24 random PDUs in ONE plan, each into its own grid of a common shape, run
     twice on the same grids with new transport blocks (the second run must overwrite everything the first one wrote)."""
@@ -716,7 +771,7 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "batched": batched, "slot": slot, "async": async_queue, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "batched": batched, "slot": slot, "async": async_queue, "ctrl_batched": ctrl_batched, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     if "--oracle-only" in sys.argv:   # the oracle side of the mutated leg alone, for the CPU sanitizer build
         sys.exit(mutated(device=False) + mutated_ctrl(device=False))
     which = sys.argv[1:] or list(legs)
