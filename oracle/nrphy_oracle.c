@@ -991,6 +991,12 @@ int oracle_pdsch_process(const nrphy_pdsch_pdu_t* pdu, const uint8_t* tb, uint16
   }
   nrphy_pdsch_derived_t d;
   oracle_pdsch_derive(pdu, &d);
+  /* Nothing to map, or more codeblocks than resource elements (a codeblock without a single channel bit: the reference's rate
+   * matcher asserts): refused, like the product's plan creation does. */
+  if (d.nof_re == 0 || d.lifting_size == 0 || d.nof_codeblocks > NRPHY_MAX_CODEBLOCKS || d.nof_codeblocks > d.nof_re ||
+      d.rm_length_short == 0) {
+    return NRPHY_ERR_INVALID_PDU;
+  }
   unsigned G    = d.codeword_bits;
   uint8_t* bits = (uint8_t*)malloc(G);
   int      rc   = encode_codeword(pdu, &d, tb, bits);

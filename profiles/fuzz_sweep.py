@@ -72,7 +72,17 @@ def mutated(device=True):
             if d["nof_re"] == 0 or d["nof_codeblocks"] > 40 or 12 * (hi + 1) > S or pdu.nof_ports > P:
                 continue
             tb = cases.random_tb(rng, pdu)
-            want, orm, oscr = o.pdsch_process(pdu, tb, P, S, taps=True, codeword_bits=d["codeword_bits"])
+            try:
+                want, orm, oscr = o.pdsch_process(pdu, tb, P, S, taps=True, codeword_bits=d["codeword_bits"])
+            except AssertionError:   # refused after the derivation (more codeblocks than resource elements): the device must refuse too
+                if device:
+                    try:
+                        ctx.pdsch_process_host(pdu, tb, P, S, taps=True)
+                        bad += 1
+                        print("MUTATED PDU: the oracle refuses, the device accepts; overwritten:", fields, d, flush=True)
+                    except lib.NrphyError:
+                        pass
+                continue
             n += 1
             if device:
                 got, rm, scr = ctx.pdsch_process_host(pdu, tb, P, S, taps=True)
