@@ -47,6 +47,7 @@ extern "C" {
 #define NRPHY_PRB_WORDS 5      /* 5 x 64 bits >= 275 PRB */
 #define NRPHY_MAX_RESERVED 4   /* re_pattern_list::MAX_RE_PATTERN, R/include/srsran/phy/support/re_pattern.h:142 */
 #define NRPHY_MAX_CODEBLOCKS 162 /* MAX_NOF_SEGMENTS, R/include/srsran/ran/sch/sch_constants.h:38 */
+#define NRPHY_MAX_PRG ((NRPHY_MAX_RB + 3) / 4) /* precoding_constants::MAX_NOF_PRG: what the reference's precoding_configuration holds */
 #define NRPHY_MAX_TB_BYTES (NRPHY_MAX_CODEBLOCKS * 8448 / 8) /* a transport block never has more bits than its codeblocks hold */
 
 /* Status codes.  The reference aborts (srsran_assert) on argument errors; this ABI returns a code. */
@@ -100,7 +101,7 @@ typedef struct nrphy_pdsch_pdu {
   uint32_t nof_layers;
   uint32_t nof_ports;
   uint32_t prg_size_rb;
-  uint32_t nof_prg;          /* 1 .. NRPHY_MAX_RB (and prg_size_rb likewise; NRPHY_MAX_RB = wideband) */
+  uint32_t nof_prg;          /* 1 .. NRPHY_MAX_PRG (prg_size_rb: 1 .. NRPHY_MAX_RB, NRPHY_MAX_RB = wideband) */
   const float* precoding;    /* host pointer: [nof_prg][nof_ports][nof_layers] complex (re, im) */
 } nrphy_pdsch_pdu_t;
 

@@ -285,7 +285,7 @@ int oracle_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
   }
   if (pdu->rv > 3 || (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->tb_size_bytes == 0 ||
       pdu->tb_size_bytes > NRPHY_MAX_TB_BYTES ||
-      pdu->nof_prg == 0 || pdu->nof_prg > NRPHY_MAX_RB || pdu->prg_size_rb == 0 || pdu->prg_size_rb > NRPHY_MAX_RB || pdu->precoding == NULL || pdu->cp > 1) {
+      pdu->nof_prg == 0 || pdu->nof_prg > NRPHY_MAX_PRG || pdu->prg_size_rb == 0 || pdu->prg_size_rb > NRPHY_MAX_RB || pdu->precoding == NULL || pdu->cp > 1) {
     return NRPHY_ERR_INVALID_PDU;
   }
   /* DM-RS and reserved RE must not collide (check_dmrs_and_reserved_collision, :28-40): no reserved pattern may

@@ -463,7 +463,7 @@ bool add_pbch_tables(ControlStaging& st, uint32_t* src_offset, uint32_t* crcw_of
 extern "C" int nrphy_pdcch_validate(const nrphy_pdcch_pdu_t* p)
 {
   if (p == nullptr || p->payload_size < 12 || p->payload_size > NRPHY_PDCCH_MAX_PAYLOAD || p->cp > 1 ||
-      p->precoding == nullptr || p->nof_ports == 0 || p->nof_ports > NRPHY_MAX_PORTS || p->nof_prg == 0 ||
+      p->precoding == nullptr || p->nof_ports == 0 || p->nof_ports > NRPHY_MAX_PORTS || p->nof_prg == 0 || p->nof_prg > NRPHY_MAX_PRG ||
       p->prg_size_rb == 0 || p->prg_size_rb > NRPHY_MAX_RB || p->bwp_size_rb == 0 || p->bwp_start_rb + p->bwp_size_rb > NRPHY_MAX_RB ||
       p->start_symbol_index + p->duration > (p->cp ? 12U : 14U) || p->rnti > 65535 || p->n_rnti > 65535 ||
       p->n_id_pdcch_data > 65535 || p->n_id_pdcch_dmrs > 65535 || (p->frequency_resources >> 45) != 0) {

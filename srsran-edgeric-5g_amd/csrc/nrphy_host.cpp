@@ -440,7 +440,7 @@ extern "C" int nrphy_pdsch_validate(const nrphy_pdsch_pdu_t* pdu)
   }
   if ((pdu->qm != 2 && pdu->qm != 4 && pdu->qm != 6 && pdu->qm != 8) || pdu->rv > 3 ||
       (pdu->ldpc_base_graph != 1 && pdu->ldpc_base_graph != 2) || pdu->tb_size_bytes == 0 ||
-      pdu->tb_size_bytes > NRPHY_MAX_TB_BYTES || pdu->nof_prg == 0 || pdu->nof_prg > NRPHY_MAX_RB || pdu->prg_size_rb == 0 || pdu->prg_size_rb > NRPHY_MAX_RB || pdu->precoding == nullptr || pdu->cp > 1) {
+      pdu->tb_size_bytes > NRPHY_MAX_TB_BYTES || pdu->nof_prg == 0 || pdu->nof_prg > NRPHY_MAX_PRG || pdu->prg_size_rb == 0 || pdu->prg_size_rb > NRPHY_MAX_RB || pdu->precoding == nullptr || pdu->cp > 1) {
     // (nof_prg sizes the read of the caller's weight array: at most one PRG per resource block)
     return NRPHY_ERR_INVALID_PDU;
   }

@@ -263,7 +263,7 @@ def test_validators_on_hostile_descriptors():
         assert h.nrphy_pdcch_validate(C.byref(bad)) != 0 and o.pdcch_validate(bad) != 0, field
     pdu = cases.baseline_config(2)[0]
     assert lib.validate(pdu) == 0 and o.validate(pdu) == 0
-    for field, value in (("nof_prg", 1 << 31), ("nof_prg", abi.MAX_RB + 1), ("cp", 5), ("prg_size_rb", 0),
+    for field, value in (("nof_prg", 1 << 31), ("nof_prg", 70), ("cp", 5), ("prg_size_rb", 0),
                          ("tb_size_bytes", (1 << 29) + 1000), ("tb_size_bytes", 162 * 1056 + 1)):   # (8 x the first wraps to 8000 bits)
         bad = type(pdu).from_buffer_copy(bytes(pdu))
         setattr(bad, field, value)
