@@ -2,8 +2,11 @@
 """Headline benchmark: PDSCH slots/s (+ IQ Gsamples/s) at 100 MHz / 4 layers / 256-QAM on N MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...          # N > 1 without a launcher: starts the N ranks itself (a child
+                                          # `python -m torch.distributed.run`, before this process touches a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 2 --dry-run    # the launch / sharding / aggregation path without device work (gloo; CPU tests)
 
 A "step" is one pass of the whole hot path (TB CRC -> segmentation -> LDPC -> rate matching -> scrambling -> QAM ->
 layer mapping/precoding/RE mapping -> DM-RS -> OFDM) over one batch of --slots BASELINE-config-3 slots per GPU with
@@ -40,35 +43,39 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=24.0):
-    """Times the CPU path on the host cores for a bounded sample of the same workload (rank 0, N=1 only): all threads and
-    one thread, several batches each, median and 5th/95th percentile of the per-batch rate.  Uses the compiled reference
-    (oracle/_ref, kind "reference": it travels to the GPU box as a built library like the product's own .so) when present,
-    the C oracle (kind "port") otherwise."""
+def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=26.0):
+    """Times the CPU path on the host cores for a bounded sample of the same workload (rank 0, N=1 only), with the reference
+    benchmark's scheme (pdsch_processor_benchmark.cpp:684-737: T worker threads, each with its own processor instance):
+    T = every core this process may run on and T = 1, PDSCH + OFDM and PDSCH alone, several batches each, median and
+    5th/95th percentile of the per-batch rate.  Uses the compiled reference (oracle/_ref, kind "reference": it travels to
+    the GPU box as a built library like the product's own .so) when present, the C oracle (kind "port") otherwise."""
     import ctypes as C
     import backends
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    affinity = len(os.sched_getaffinity(0))
+    cap = int(os.environ.get("NRPHY_CPU_THREADS_MAX", "0"))  # 0 = no cap
+    cores = min(affinity, cap) if cap > 0 else affinity
     r = backends.ref()
     if r is not None:
         kind = "reference"
 
-        def run(threads, reps):
-            return r.lib.ref_bench_pdsch(C.byref(pdu), tb.ctypes.data, nof_ports, nof_subc, C.byref(ofdm), threads,
-                                         reps, 1)
+        def run(threads, reps, with_ofdm):
+            return r.lib.ref_bench_pdsch(C.byref(pdu), tb.ctypes.data, nof_ports, nof_subc,
+                                         C.byref(ofdm) if with_ofdm else None, threads, reps, 1)
     else:
         kind = "port"
         o = backends.oracle()
 
-        def run(threads, reps):
-            return o.lib.oracle_bench(C.byref(pdu), tb.ctypes.data, nof_ports, nof_subc, C.byref(ofdm), threads, reps)
+        def run(threads, reps, with_ofdm):
+            return o.lib.oracle_bench(C.byref(pdu), tb.ctypes.data, nof_ports, nof_subc,
+                                      C.byref(ofdm) if with_ofdm else None, threads, reps)
 
-    def measure(threads, share_s, batches=7):
-        run(threads, 1)                          # warms caches / page-faults the buffers
-        t1 = run(threads, 2) / 2.0               # calibration: seconds per slot per thread
+    def measure(threads, share_s, with_ofdm, batches=5):
+        run(threads, 1, with_ofdm)               # warms caches / page-faults the buffers
+        t1 = run(threads, 2, with_ofdm) / 2.0    # calibration: seconds per slot per thread
         reps = int(max(1, min(5000, share_s / batches / max(t1, 1e-4))))
         rates, total = [], 0.0
         for _ in range(batches):
-            dt = run(threads, reps)
+            dt = run(threads, reps, with_ofdm)
             rates.append(threads * reps / dt)
             total += dt
         rates = np.array(rates)
@@ -76,29 +83,74 @@ def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=24.0):
                 "p5": round(float(np.percentile(rates, 5)), 2), "p95": round(float(np.percentile(rates, 95)), 2),
                 "batches": batches, "slots_per_thread_per_batch": reps, "seconds": round(total, 1)}
 
-    full = measure(cores, budget_s * 0.6)
-    one = measure(1, budget_s * 0.4)
+    full = measure(cores, budget_s * 0.35, True)
+    full_pdsch = measure(cores, budget_s * 0.25, False)
+    one = measure(1, budget_s * 0.22, True)
+    one_pdsch = measure(1, budget_s * 0.18, False)
     return {
         "value": full["slots_per_sec"],
         "unit": "slots/s",
         "cores": cores,
         "kind": kind,
         "cpu_model": cpu_model(),
+        "host_logical_cpus": os.cpu_count(),
+        "affinity_cpus": affinity,
+        "thread_cap": cap if cap > 0 else None,
         "all_threads": full,
+        "all_threads_pdsch_only": full_pdsch,
         "one_thread": one,
-        "sample": "config-3 slots (PDSCH %s + OFDM generic radix-2 DFT): %d threads x %d batches x %d slots each (%.1f s), "
-                  "then 1 thread x %d batches x %d slots (%.1f s); value = median over the all-thread batches" % (
+        "one_thread_pdsch_only": one_pdsch,
+        "sample": "config-3 slots (PDSCH %s; OFDM generic radix-2 DFT), the reference benchmark's threads x batch scheme: "
+                  "%d threads (every CPU of this process's affinity mask: %d of the host's %s) and 1 thread, PDSCH + OFDM and "
+                  "PDSCH alone, %d batches each of %d / %d / %d / %d slots per thread (%.1f s in all); value = median over the "
+                  "all-thread PDSCH + OFDM batches" % (
                       "AVX2 LDPC/precoder, the reference's own objects" if kind == "reference" else "scalar C oracle", cores,
-                      full["batches"], full["slots_per_thread_per_batch"], full["seconds"], one["batches"],
-                      one["slots_per_thread_per_batch"], one["seconds"]),
+                      affinity, os.cpu_count(), full["batches"], full["slots_per_thread_per_batch"],
+                      full_pdsch["slots_per_thread_per_batch"], one["slots_per_thread_per_batch"],
+                      one_pdsch["slots_per_thread_per_batch"],
+                      full["seconds"] + full_pdsch["seconds"] + one["seconds"] + one_pdsch["seconds"]),
     }
 
 
-def roof(name, ms, nbytes, traffic=None):
+# Vector-issue roof: 1,024 SIMDs (256 CUs x 4) each issue one 64-lane vector instruction per four cycles at the 2.4 GHz
+# peak engine clock (MI355X_MICROARCH.md) -> 614.4 G wavefront-instructions/s.
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0
+
+_PROFILE = None
+
+
+def profile_table():
+    """profiles/traffic.json: per kernel, HBM bytes and vector instructions per launch from the PMC passes of the default
+    command (profiles/pmc.sh) -- measured in the profile run named there, not in this process."""
+    global _PROFILE
+    if _PROFILE is None:
+        try:
+            _PROFILE = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        except Exception:
+            _PROFILE = {}
+    return _PROFILE
+
+
+def roof(name, ms, nbytes, slots=None, config=None, wire=False):
+    """Roofline dict of one kernel.  HBM figures always; for a kernel that profiles/traffic.json lists as bound by vector
+    instruction issue ("valu_bound"), `bound` says so and achieved / peak / frac are its vector-issue rate (instructions
+    per launch from the PMC profile / this run's launch time), with the HBM figures alongside under "hbm"."""
     gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes),
-            "traffic": traffic}
+    out = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes),
+           "traffic": None}
+    tj = profile_table()
+    if config == 3 and not wire and tj.get("slots") == slots:
+        out["traffic"] = tj.get("hbm_bytes_per_launch", {}).get(name)
+        valu = tj.get("valu_insts_per_launch", {}).get(name)
+        if valu and name in tj.get("valu_bound", []) and ms > 0:
+            ginst = valu / (ms * 1e-3) / 1e9
+            out.update({"bound": "valu", "achieved": round(ginst, 1), "peak": round(VALU_PEAK_GINST, 1),
+                        "unit": "Gwaveinst/s", "frac": round(ginst / VALU_PEAK_GINST, 4),
+                        "valu_insts_per_launch": int(valu),
+                        "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(gbs / HBM_PEAK_GBS, 4)}})
+    return out
 
 
 def run_downlink(env, config, slots, steps, warmup, wire=False):
@@ -109,8 +161,10 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
     if config == 4:
         # Four cells x four UEs (68 PRB each, QPSK / 16 / 64 / 256-QAM): one grid per cell-slot, four PDUs per grid.  The
         # job's stream of cell-slots (cell = i % 4, slot = i // 4) is placed by cell affinity; every rank gets `slots` of them.
+        # (1, 2, 4, 8 ranks: `slots` each; other world sizes leave the shares uneven -- every rank then runs its real share and
+        # the totals add up what was processed.)
         mine = [i for i in range(slots * world) if sharding.cell_affine_rank(i % 4, i // 4, world, 4) == rank]
-        assert len(mine) == slots, (len(mine), slots)
+        slots = len(mine)
         pdus, grid_of = [], []
         for g, i in enumerate(mine):
             cell, nof_ports, nof_subc = cases.mixed_cell(i % 4, slot_index=(i // 4) % 20)
@@ -135,6 +189,13 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
         }[config] % (8 * pdus[0].tb_size_bytes, d0["nof_codeblocks"], d0["lifting_size"])
     if wire:
         workload += ", OFDM output as complex int16 (amplitude controller + cf32->ci16 fused into the modulator's store)"
+    if slots == 0:  # a rank without a share (config 4 on 5 ... 7 ranks): takes part in the barriers and the totals only
+        if dist is not None:
+            dist.barrier()
+            dist.barrier()
+        sharding.aggregate(dist, device, 0, 0, 0.0)
+        sharding.gather(dist, device, [0.0, 0.0, 0.0, 0.0])
+        return None
     tb_strides = [(q.tb_size_bytes + 255) & ~255 for q in pdus]
     tb_offsets = [0]
     for st in tb_strides[:-1]:
@@ -195,10 +256,13 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
     lib.ORDER_AFTER_TORCH = True
     # Whole-job totals: slots and IQ samples summed over ranks, time = max over ranks (RCCL all-reduce of 3 numbers).
     samples_per_slot = nof_ports * oplan.slot_stride
+    local_dt = dt
     total_slots, total_samples, dt = sharding.aggregate(dist, device, slots * steps, slots * steps * samples_per_slot, dt)
 
     (ms_crc, ms_cb, ms_dmrs, ms_run), _ = plan.kernel_times()
     ms_ofdm, _ = oplan.kernel_time()
+    # Per rank: slots per step, seconds of the timed region, codeblock and OFDM launch times (rank 0 reports them).
+    per_rank = sharding.gather(dist, device, [float(slots), local_dt, ms_cb, ms_ofdm])
     out = None
     if rank == 0:
         # Algorithmic bytes per slot: TB read + grid written once (incl. zeros) + grid read by the OFDM
@@ -213,16 +277,11 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
             # The codeblock launch also carries the DM-RS and zero-fill waves: it writes every grid word exactly once.
             "codeblock_kernel": (ms_cb, tb_bytes_per_step + slots * grid_bytes),
         }
+        if ms_crc > 0:
+            kernels["prologue_kernel"] = (ms_crc, tb_bytes_per_step)
         dom = max(kernels, key=lambda k: kernels[k][0])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and config == 3 and not wire:
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("slots") == slots and dom in tj.get("hbm_bytes_per_launch", {}):
-                    traffic = tj["hbm_bytes_per_launch"][dom]
-            except Exception:
-                traffic = None
+        alg_slot = alg_pdsch + alg_ofdm
+        rank_rates = [r[0] * steps / r[1] for r in per_rank if r[1] > 0]
         out = {
             "metric": "pdsch_slots_per_sec",
             "value": round(total_slots / dt, 1),
@@ -236,9 +295,20 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
             "whole_path_hbm_frac": round(total_slots * (alg_pdsch + alg_ofdm) / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
             "kernel_ms": {"prologue_tbcrc_scrambling_seq": round(ms_crc, 4), "codeblock_dmrs_zerofill": round(ms_cb, 4),
                           "separate_dmrs": round(ms_dmrs, 4), "pdsch_run": round(ms_run, 4), "ofdm": round(ms_ofdm, 4)},
-            "roofline": roof(dom, *kernels[dom], traffic=traffic),
-            "roofline_other": [roof(k, *kernels[k]) for k in kernels if k != dom],
+            "roofline": roof(dom, *kernels[dom], slots=slots, config=config, wire=wire),
+            "roofline_other": [roof(k, *kernels[k], slots=slots, config=config, wire=wire) for k in kernels if k != dom],
+            "per_rank": {
+                "slots_per_step": [int(r[0]) for r in per_rank],
+                "slots_per_sec": {"min": round(min(rank_rates), 1), "max": round(max(rank_rates), 1)},
+                # algorithmic HBM rate of each GPU over its own timed region, and its fraction of one GPU's 8 TB/s
+                "hbm_gbs": [round(r[0] * steps * alg_slot / r[1] / 1e9, 1) if r[1] > 0 else 0.0 for r in per_rank],
+                "hbm_frac": [round(r[0] * steps * alg_slot / r[1] / 1e9 / HBM_PEAK_GBS, 4) if r[1] > 0 else 0.0
+                             for r in per_rank],
+                "codeblock_ms": [round(r[2], 4) for r in per_rank], "ofdm_ms": [round(r[3], 4) for r in per_rank],
+            },
         }
+        if config == 4:
+            out["config"]["sharding"] = "sharding.cell_affine_rank (cell c keeps to its ranks)"
         # Sanity: grid 0 of the last step against the CPU oracle (checker only, outside the timed region).
         last = tb_sets[(step_no[0] - 1) % len(tb_sets)]
         try:
@@ -272,6 +342,65 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher around us: start the N ranks as a CHILD `python -m torch.distributed.run` (what the
+    reference's harness does with its T worker threads, pdsch_processor_benchmark.cpp:684-737) before this process has
+    made any GPU call -- a process that touched the GPU must never be replaced or re-executed -- and leave with its exit
+    code.  Rank 0 of the child prints the one JSON line on the stdout we share."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """The N-rank path without device work: process group (gloo), slot sharding / cell-affine placement, barriers, totals
+    and the per-rank gather, one line from rank 0.  What the CPU tests run; never a measurement (value 0, "dry_run": true)."""
+    import torch
+    import backends
+    sharding = backends.load_package().sharding
+    dist = None
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    device = torch.device("cpu")
+    if args.config == 4:
+        mine = [i for i in range(args.slots * world) if sharding.cell_affine_rank(i % 4, i // 4, world, 4) == rank]
+        slots = len(mine)
+    else:
+        slots = sharding.shard_slots(args.slots * world, rank, world)[1]
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    total_slots, _, dt = sharding.aggregate(dist, device, slots * args.steps, 0, dt)
+    per_rank = sharding.gather(dist, device, [float(slots), dt, 0.0, 0.0])
+    if rank == 0:
+        print(json.dumps({
+            "metric": "pdsch_slots_per_sec", "value": 0.0, "unit": "slots/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "none", "data": "none (dry run: no device work, not a measurement)", "dry_run": True,
+            "config": {"workload": "dry run of BASELINE config %d" % args.config, "slots_per_gpu_per_step": args.slots,
+                       "parallelism": "slot-sharded x%d, no data-path collective" % world},
+            "total_slots": total_slots, "per_rank": {"slots_per_step": [int(r[0]) for r in per_rank]},
+            "collective_backend": "gloo (torch.distributed)" if dist is not None else "none (single process)",
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,10 +414,30 @@ def main():
     ap.add_argument("--wire", action="store_true", help="OFDM output as complex int16 (amplitude controller + conversion fused)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary entries (configs 2, 4, 5, wire format)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch, sharding and aggregation only (gloo, no device work): the N-rank path on a machine without GPUs")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if "RANK" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(self_launch(args))  # nothing in this process has touched a GPU
+    elif int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ.get("WORLD_SIZE")),
+              file=sys.stderr)
+        sys.exit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    if args.dry_run:
+        dry_run(args, rank, world)
+        return
     if args.config == 5:
         # the receive-side chain has its own script (profiles/rx_chain_bench.py); same JSON schema, one GPU
+        if world != 1:
+            print("bench.py: --config 5 is a one-GPU measurement", file=sys.stderr)
+            sys.exit(2)
         import rx_chain_bench
         print(json.dumps(rx_chain_bench.run(argparse.Namespace(
             slots=args.slots if args.slots != 1024 else 256, iterations=8, steps=args.steps, warmup=args.warmup, snr_db=32.0))),
@@ -300,9 +449,6 @@ def main():
     import cases
     lib = backends.pkg.lib
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dist = None
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
@@ -325,19 +471,27 @@ def main():
         }
         out.update({k: v for k, v in head.items() if k not in out})
         out["collective_backend"] = "rccl (torch.distributed nccl)" if dist is not None else "none (single process)"
+    sec = {}
+    s_steps, s_warm = max(3, args.steps), max(3, args.warmup)  # the same count as the headline: short runs read 5-10 % slow
     if world == 1 and not args.no_secondary and args.config == 3 and not args.wire:
-        # Secondary measurements, same process and GPU, fewer steps each; every entry is verified against the oracle.
-        sec = {}
-        s_steps, s_warm = max(3, args.steps), max(3, args.warmup)  # the same count as the headline: short runs read 5-10 % slow
+        # Secondary measurements, same process and GPU; every entry is verified against the oracle.
         for name, (cfg, slots, wire) in {"config3_wire_ci16": (3, args.slots, True), "config2": (2, 1000, False),
                                          "config4": (4, 1024, False)}.items():
             e = run_downlink(env, cfg, slots, s_steps, s_warm, wire=wire)
             e.pop("_first_pdu")
             sec[name] = e
         import rx_chain_bench
-        sec["config5"] = rx_chain_bench.run(argparse.Namespace(slots=256, iterations=8, steps=s_steps, warmup=s_warm, snr_db=32.0))
-        out["secondary"] = sec
+        sec["config5"] = rx_chain_bench.run_all(s_steps, s_warm)
+    elif world > 1 and not args.no_secondary and args.config == 3 and not args.wire:
+        # N ranks: BASELINE config 4 is the one quoted as a stream sharded over the GPUs -- placed by cell affinity, every
+        # rank its share, whole-job totals like the headline.
+        e = run_downlink(env, 4, 1024, s_steps, s_warm)
+        if rank == 0:
+            e.pop("_first_pdu")
+            sec["config4"] = e
     if rank == 0:
+        if sec:
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and args.config == 3:
             out["cpu_baseline"] = cpu_baseline(*first)
         print(json.dumps(out), flush=True)

@@ -286,6 +286,18 @@ public:
     items.push_back({(void**)dptr, src, bytes, total});
     total += (bytes + 255) & ~(size_t)255;
   }
+  size_t bytes() const { return std::max<size_t>(total, 256); }
+  // The same layout in memory the caller owns: the tables are written to `h_base`, the device pointers point into
+  // `d_base`; copying [h_base, h_base + bytes()) there is the caller's business (no HIP call here).
+  void place(uint8_t* h_base, uint8_t* d_base)
+  {
+    for (const Item& it : items) {
+      if (it.bytes != 0) {
+        std::memcpy(h_base + it.offset, it.src, it.bytes);
+      }
+      *it.dptr = d_base + it.offset;
+    }
+  }
   hipError_t commit(void** base, size_t scratch_bytes, void** scratch)
   {
     std::vector<uint8_t> staging(std::max<size_t>(total, 256), 0);
@@ -330,6 +342,7 @@ struct nrphy_pdsch_plan {
   uint64_t              cw_bits = 0;
   uint32_t              nof_grids = 0, grid_nof_ports = 0, grid_nof_subc = 0;
   void*                 d_arena = nullptr; // the one device allocation every d_* pointer below points into
+  bool                  arena_external = false; // the tables live in memory the caller owns (nrphy_pdsch_plan_create_placed)
   PduDev*               d_pdus = nullptr;
   CbWork*               d_work = nullptr;
   DmrsWork*             d_dmrs = nullptr;
@@ -348,6 +361,7 @@ struct nrphy_pdsch_plan {
   bool                  dmrs_separate = false; // DM-RS must overwrite data RE: keep it in its own, later launch
   uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0, n_crc_work = 0;
   uint32_t              lds_lin_words = 0, lds_symb_words = 0, lds_graph_words = 0;
+  uint32_t              bucket_begin[CB_BUCKETS + 1] = {}; // work items sorted by (modulation order, layers)
   std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs
   uint32_t              timed_runs = 0, max_timed_runs = 0;
 };
@@ -791,6 +805,33 @@ struct ReMapping {
 
 } // namespace
 
+// What a plan derives from the SHAPE of its PDUs alone -- allocation, symbols, DM-RS and reserved patterns, ports and
+// layers -- kept across plans by a caller that builds one plan per PDU (the asynchronous queue): RE mapping tables and
+// zero-fill run lists.  Everything else in a plan (slot index, RNTI, scrambling identities, transport-block size and
+// the sizes derived from it, weights) is per PDU and rebuilt every time; it costs a few microseconds.
+struct PlanShapeCache {
+  struct Remap {
+    ReMapping             m;     // sym_arg of SYM_TABLE symbols relative to `table`
+    std::vector<uint16_t> table;
+  };
+  struct Zero {
+    std::vector<ZeroSeg> segs; // long runs first
+    uint32_t             nof_long = 0;
+  };
+  std::map<std::vector<uint64_t>, Remap> remap;
+  std::map<std::vector<uint64_t>, Zero>  zero; // key: grid size + port + the allocation signatures of the PDUs on the port
+  static constexpr size_t MAX_ENTRIES = 256;   // shapes in use at a time are few; a full cache starts over
+};
+
+PlanShapeCache* plan_shape_cache_create()
+{
+  return new (std::nothrow) PlanShapeCache;
+}
+void plan_shape_cache_destroy(PlanShapeCache* c)
+{
+  delete c;
+}
+
 namespace {
 
 // Seam B (encode + rate match + interleave only): the codeword size and N_ref are given, there is no allocation.
@@ -801,9 +842,16 @@ struct EncodeOnly {
 
 int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus, const uint64_t* tb_offset,
                 const uint32_t* grid_index, uint32_t nof_grids, uint32_t grid_nof_ports, uint32_t grid_nof_subc,
-                const EncodeOnly* enc, nrphy_pdsch_plan_t** out);
+                const EncodeOnly* enc, nrphy_pdsch_plan_t** out, PlanPlacement* place = nullptr);
 
 } // namespace
+
+int nrphy_pdsch_plan_create_placed(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus, const uint64_t* tb_offset,
+                                   const uint32_t* grid_index, uint32_t nof_grids, uint32_t grid_nof_ports,
+                                   uint32_t grid_nof_subc, PlanPlacement* place, nrphy_pdsch_plan_t** out)
+{
+  return plan_create(ctx, n_pdu, pdus, tb_offset, grid_index, nof_grids, grid_nof_ports, grid_nof_subc, nullptr, out, place);
+}
 
 extern "C" int nrphy_pdsch_plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
                                        const uint64_t* tb_offset, const uint32_t* grid_index, uint32_t nof_grids,
@@ -816,7 +864,7 @@ namespace {
 
 int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus, const uint64_t* tb_offset,
                 const uint32_t* grid_index, uint32_t nof_grids, uint32_t grid_nof_ports, uint32_t grid_nof_subc,
-                const EncodeOnly* enc, nrphy_pdsch_plan_t** out)
+                const EncodeOnly* enc, nrphy_pdsch_plan_t** out, PlanPlacement* place)
 {
   if (ctx == nullptr || out == nullptr || (n_pdu != 0 && (pdus == nullptr || tb_offset == nullptr)) ||
       grid_nof_ports == 0 || grid_nof_ports > NRPHY_MAX_PORTS || grid_nof_subc == 0 || grid_nof_subc % 12 != 0 ||
@@ -824,10 +872,17 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
     return NRPHY_ERR_ARGUMENT;
   }
   *out = nullptr;
-  HIP_TRY(hipSetDevice(ctx->device));
+  if (place == nullptr) {
+    HIP_TRY(hipSetDevice(ctx->device));
+  }
   nrphy_pdsch_plan* plan = new (std::nothrow) nrphy_pdsch_plan;
   if (plan == nullptr) {
     return NRPHY_ERR_CAPACITY;
+  }
+  PlanShapeCache* shapes = place ? place->cache : nullptr;
+  if (shapes != nullptr && shapes->remap.size() + shapes->zero.size() > PlanShapeCache::MAX_ENTRIES) {
+    shapes->remap.clear();
+    shapes->zero.clear();
   }
   plan->ctx            = ctx;
   plan->nof_grids      = nof_grids;
@@ -882,38 +937,63 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
       std::memcpy(pd.sym_arg, cached->second.sym_arg, sizeof(pd.sym_arg));
       nof_re = pd.sym_re_start[NRPHY_NSYMB];
     } else {
-      for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
-        pd.sym_re_start[l] = nof_re;
-        data_re_mask(pdu, l, mask);
-        list.clear();
-        for (unsigned k = 0; k != grid_nof_subc; ++k) {
-          if (mask[k]) {
-            list.push_back((uint16_t)k);
-          }
+      // The mapping with its table entries numbered from zero (`rel`): from the caller's shape cache, or built here.
+      PlanShapeCache::Remap        built;
+      const PlanShapeCache::Remap* rel = nullptr;
+      if (shapes != nullptr) {
+        auto known = shapes->remap.find(remap_sig);
+        if (known != shapes->remap.end()) {
+          rel = &known->second;
         }
-        if (list.empty()) {
-          pd.sym_kind[l] = SYM_NONE;
-        } else if ((unsigned)(list.back() - list.front()) + 1 == list.size()) {
-          pd.sym_kind[l] = SYM_CONTIGUOUS;
-          pd.sym_arg[l]  = list.front();
-        } else {
-          pd.sym_kind[l] = SYM_TABLE;
-          pd.sym_arg[l]  = (uint32_t)re_table.size();
-          // Reuse the previous symbol's list when identical (the common case).
-          for (unsigned lp = 0; lp != l; ++lp) {
-            if (pd.sym_kind[lp] == SYM_TABLE && pd.sym_re_start[lp + 1] - pd.sym_re_start[lp] == list.size() &&
-                std::equal(list.begin(), list.end(), re_table.begin() + pd.sym_arg[lp])) {
-              pd.sym_arg[l] = pd.sym_arg[lp];
-              break;
+      }
+      if (rel == nullptr) {
+        for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+          built.m.sym_re_start[l] = nof_re;
+          built.m.sym_arg[l]      = 0;
+          data_re_mask(pdu, l, mask);
+          list.clear();
+          for (unsigned k = 0; k != grid_nof_subc; ++k) {
+            if (mask[k]) {
+              list.push_back((uint16_t)k);
             }
           }
-          if (pd.sym_arg[l] == re_table.size()) {
-            re_table.insert(re_table.end(), list.begin(), list.end());
+          if (list.empty()) {
+            built.m.sym_kind[l] = SYM_NONE;
+          } else if ((unsigned)(list.back() - list.front()) + 1 == list.size()) {
+            built.m.sym_kind[l] = SYM_CONTIGUOUS;
+            built.m.sym_arg[l]  = list.front();
+          } else {
+            built.m.sym_kind[l] = SYM_TABLE;
+            built.m.sym_arg[l]  = (uint32_t)built.table.size();
+            // Reuse an earlier symbol's list when identical (the common case).
+            for (unsigned lp = 0; lp != l; ++lp) {
+              if (built.m.sym_kind[lp] == SYM_TABLE && built.m.sym_re_start[lp + 1] - built.m.sym_re_start[lp] == list.size() &&
+                  std::equal(list.begin(), list.end(), built.table.begin() + built.m.sym_arg[lp])) {
+                built.m.sym_arg[l] = built.m.sym_arg[lp];
+                break;
+              }
+            }
+            if (built.m.sym_arg[l] == built.table.size()) {
+              built.table.insert(built.table.end(), list.begin(), list.end());
+            }
           }
+          nof_re += (unsigned)list.size();
+          built.m.sym_re_start[l + 1] = nof_re;
         }
-        nof_re += (unsigned)list.size();
-        pd.sym_re_start[l + 1] = nof_re;
+        rel = &built;
+        if (shapes != nullptr) {
+          rel = &shapes->remap.insert({remap_sig, built}).first->second;
+        }
       }
+      // Into this plan: the table entries behind what the plan holds already.
+      const uint32_t base = (uint32_t)re_table.size();
+      re_table.insert(re_table.end(), rel->table.begin(), rel->table.end());
+      std::memcpy(pd.sym_re_start, rel->m.sym_re_start, sizeof(pd.sym_re_start));
+      std::memcpy(pd.sym_kind, rel->m.sym_kind, sizeof(pd.sym_kind));
+      for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
+        pd.sym_arg[l] = rel->m.sym_arg[l] + (rel->m.sym_kind[l] == SYM_TABLE ? base : 0U);
+      }
+      nof_re = pd.sym_re_start[NRPHY_NSYMB];
       ReMapping m;
       std::memcpy(m.sym_re_start, pd.sym_re_start, sizeof(m.sym_re_start));
       std::memcpy(m.sym_kind, pd.sym_kind, sizeof(m.sym_kind));
@@ -1108,6 +1188,22 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
           }
           continue;
         }
+        if (shapes != nullptr) {
+          // The run list of this coverage from an earlier plan of the caller (the grid size is part of the key).
+          sig.push_back(((uint64_t)grid_nof_subc << 32) | port);
+          auto kept = shapes->zero.find(sig);
+          sig.pop_back();
+          if (kept != shapes->zero.end()) {
+            const std::array<uint32_t, 3> where = {(uint32_t)zero_segs.size(), (uint32_t)kept->second.segs.size(),
+                                                   kept->second.nof_long};
+            zero_segs.insert(zero_segs.end(), kept->second.segs.begin(), kept->second.segs.end());
+            by_signature.insert({sig, where});
+            if (where[1] != 0) {
+              zero_work.push_back({g, port, where[0], where[1], where[2]});
+            }
+            continue;
+          }
+        }
         std::fill(cov.begin(), cov.end(), 0);
         for (uint32_t i : pdus_of_grid[g]) {
           const nrphy_pdsch_pdu_t& pdu = pdus[i];
@@ -1152,6 +1248,11 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
         }
         if (key.empty()) {
           by_signature.insert({sig, {0, 0, 0}});
+          if (shapes != nullptr) {
+            sig.push_back(((uint64_t)grid_nof_subc << 32) | port);
+            shapes->zero.insert({sig, PlanShapeCache::Zero()});
+            sig.pop_back();
+          }
           continue;
         }
         auto it = seen.find(key);
@@ -1172,12 +1273,33 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
         }
         by_signature.insert({sig, it->second});
         zero_work.push_back({g, port, it->second[0], it->second[1], it->second[2]});
+        if (shapes != nullptr) {
+          PlanShapeCache::Zero z;
+          z.segs.assign(zero_segs.begin() + it->second[0], zero_segs.begin() + it->second[0] + it->second[1]);
+          z.nof_long = it->second[2];
+          sig.push_back(((uint64_t)grid_nof_subc << 32) | port);
+          shapes->zero.insert({sig, std::move(z)});
+          sig.pop_back();
+        }
       }
     }
   }
   plan->n_zero_work = (uint32_t)zero_work.size();
   plan->cw_bits = cw_bits;
   plan->n_work  = (uint32_t)work.size();
+  {
+    // One bucket per (modulation order, layers), PDU and codeblock order kept inside (launch_codeblocks).
+    const auto bucket_of = [&](const CbWork& w) { return cb_bucket(plan->pdus[w.pdu].qm, plan->pdus[w.pdu].nof_layers); };
+    std::stable_sort(work.begin(), work.end(), [&](const CbWork& a, const CbWork& b) { return bucket_of(a) < bucket_of(b); });
+    for (const CbWork& w : work) {
+      ++plan->bucket_begin[bucket_of(w) + 1];
+    }
+    for (uint32_t b = 0; b != CB_BUCKETS; ++b) {
+      plan->bucket_begin[b + 1] += plan->bucket_begin[b];
+    }
+    // The codeblock waves load 2 * NRPHY_MAX_PORTS * layers weights whatever the port count (pdsch_kernels.hip, phase_b).
+    weights.insert(weights.end(), 2 * NRPHY_MAX_PORTS * NRPHY_MAX_PORTS, 0.0F);
+  }
   plan->n_dmrs  = (uint32_t)dmrs.size();
   plan->n_crc_work = (uint32_t)crc_work.size();
   plan->n_scr_work = (uint32_t)scr_work.size();
@@ -1195,8 +1317,18 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
     void* scratch = nullptr;
     // Behind the tables: what every run rewrites before it reads it -- the sequences and the TB-CRC shares.
     const uint64_t scr_alloc = (std::max<uint64_t>(4, plan->scr_words) + 3U) & ~3ULL;
-    if (arena.commit(&plan->d_arena, sizeof(uint32_t) * (scr_alloc + std::max<size_t>(4, crc_work.size())), &scratch) !=
-        hipSuccess) {
+    const uint64_t scratch_words = scr_alloc + std::max<size_t>(4, crc_work.size());
+    if (place != nullptr) {
+      // Caller-owned memory: no allocation, no copy, no synchronisation here (the asynchronous queue's submit path).
+      if (arena.bytes() > place->table_capacity || scratch_words > place->scratch_capacity_words) {
+        delete plan;
+        return NRPHY_ERR_CAPACITY;
+      }
+      arena.place(place->h_tables, place->d_tables);
+      place->table_bytes  = arena.bytes();
+      plan->arena_external = true;
+      scratch              = place->d_scratch;
+    } else if (arena.commit(&plan->d_arena, sizeof(uint32_t) * scratch_words, &scratch) != hipSuccess) {
       nrphy_pdsch_plan_destroy(plan);
       return NRPHY_ERR_DEVICE;
     }
@@ -1216,8 +1348,10 @@ extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
   if (plan == nullptr) {
     return NRPHY_OK;
   }
-  (void)hipSetDevice(plan->ctx->device);
-  (void)hipFree(plan->d_arena);
+  if (!plan->arena_external) {
+    (void)hipSetDevice(plan->ctx->device);
+    (void)hipFree(plan->d_arena); // null for a plan whose creation failed half-way
+  }
   for (hipEvent_t e : plan->events) {
     (void)hipEventDestroy(e);
   }
@@ -1298,7 +1432,12 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   if (ev) {
     HIP_TRY(hipEventRecord(ev[1], s));
   }
-  HIP_TRY(launch_codeblocks(p, d_tb, (uint32_t*)d_grid, (uint32_t*)d_cw_rm, (uint32_t*)d_cw_scrambled, s));
+  {
+    // NRPHY_CB_DISPATCH: 1 = the one-launch mixed kernel, 2 = one launch per (Qm, layers) bucket, unset = by plan shape.
+    const char* dispatch_env = std::getenv("NRPHY_CB_DISPATCH");
+    HIP_TRY(launch_codeblocks(p, plan->bucket_begin, dispatch_env ? std::atoi(dispatch_env) : 0, d_tb, (uint32_t*)d_grid,
+                              (uint32_t*)d_cw_rm, (uint32_t*)d_cw_scrambled, s));
+  }
   if (ev) {
     HIP_TRY(hipEventRecord(ev[2], s));
   }

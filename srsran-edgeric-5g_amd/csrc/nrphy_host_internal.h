@@ -97,6 +97,28 @@ struct nrphy_ctx {
   size_t     scratch_bytes[8] = {};
 };
 
+// ---- PDSCH plans in caller-owned memory (the asynchronous queue) ----------------------------------------------------------
+// nrphy_pdsch_plan_create allocates device memory and copies the plan's tables there with a blocking copy: right for a
+// plan that is built once and run many times, wrong on a path that sees a new PDU per call.  The placed form writes the
+// tables into host memory of the caller (pinned staging it copies in stream order, together with the transport block)
+// and points the plan at the device addresses they will have; it makes no HIP call.  NRPHY_ERR_CAPACITY when the plan
+// does not fit.  The plan must be destroyed before the memory is reused.
+struct PlanShapeCache;
+PlanShapeCache* plan_shape_cache_create();
+void            plan_shape_cache_destroy(PlanShapeCache* cache);
+struct PlanPlacement {
+  uint8_t*        h_tables = nullptr; // host memory the tables are written to
+  uint8_t*        d_tables = nullptr; // device address they will be copied to (256-byte aligned)
+  size_t          table_capacity = 0;
+  size_t          table_bytes    = 0; // out: bytes to copy
+  uint32_t*       d_scratch = nullptr; // device memory for what every run rewrites (sequences, TB-CRC shares)
+  size_t          scratch_capacity_words = 0;
+  PlanShapeCache* cache = nullptr;    // may be null; one cache per thread of use
+};
+int nrphy_pdsch_plan_create_placed(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus, const uint64_t* tb_offset,
+                                   const uint32_t* grid_index, uint32_t nof_grids, uint32_t grid_nof_ports,
+                                   uint32_t grid_nof_subc, PlanPlacement* place, nrphy_pdsch_plan_t** out);
+
 namespace {
 
 // Staging buffer `slot` of the context with room for `bytes` (reallocated only when it has to grow).

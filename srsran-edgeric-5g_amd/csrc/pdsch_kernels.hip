@@ -421,257 +421,362 @@ struct ChunkGeom {
 //   Qm row words.  A lane gathers the Qm row words of its 32 symbols and transposes them 8x8-block-wise into one
 //   byte per symbol (symbol bits in the byte's MSBs) -- 8x less work than extracting bit by bit.
 // Phase B -- per RE: scramble, QAM table lookup, layer mapping + precoding, bf16, coalesced stores.
+//
+// The two phases are separate functions and read the PDU descriptor where they use it (scalar loads through the
+// constant address space) instead of carrying its fields from the top of the kernel: as one function inlined 32 times
+// into one kernel the scalar register file overflowed (106 SGPRs, 393 spilled, 2,387 v_readlane restores -- vector
+// instructions in a kernel bound by vector issue).
 // ================================================================================================================
 template <int QM, int L, bool WRAP>
-__device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const CbWork& wk, const CbShared& sh,
-                                          const ChunkGeom& g, uint32_t lane, uint32_t* __restrict__ d_grid,
-                                          uint32_t* __restrict__ d_cw_rm, uint32_t* __restrict__ d_cw_scr)
+__device__ __forceinline__ void phase_a(const PdschLaunch& p, PduRef pd, const CbWork& wk, const CbShared& sh,
+                                        uint32_t E, uint32_t lane)
 {
-  constexpr uint32_t LQ    = QM * L;
-  const uint32_t     esym  = g.E / QM; // rows of the bit interleaver have esym bits
-  const uint32_t     zc2   = 2u * pd.zc;
-  const RmIndex      rm    = rm_index_init(pd);
-
-  // ---- Phase A ----
-  {
-    const uint32_t s0   = wk.re_begin * L;             // first modulation symbol of the chunk (multiple of 32)
-    const uint32_t nblk = (wk.re_count * L + 31u) >> 5;
+  const uint32_t esym = E / QM; // rows of the bit interleaver have esym bits
+  const uint32_t zc2  = 2u * pd.zc;
+  const RmIndex  rm   = rm_index_init(pd);
+  const uint32_t s0   = wk.re_begin * L;             // first modulation symbol of the chunk (multiple of 32)
+  const uint32_t nblk = (wk.re_count * L + 31u) >> 5;
 #if NRPHY_PHASE_A_STAGED
-    // Two passes over the wave's 64 lanes instead of one lane per block (a 281-RE codeblock has 36 blocks: 36 busy lanes doing
-    // Qm gathers and four transpositions each).  First the Qm * nblk row words, one gather per item, into the block's eight
-    // words of `symb` (word 8 blk + j = row j); then the 4 * nblk (block, byte column) items: eight byte reads, one 8x8
-    // transposition, two words back into the same eight words (the four items of a block sit in neighbouring lanes of one
-    // instruction: all their reads precede their writes).
-    for (uint32_t item = lane; item < QM * nblk; item += WAVE) {
-      const uint32_t blk = item / QM, j = item - blk * QM;
-      sh.symb[8u * blk + j] = rm_gather32<WRAP>(rm, sh.lin, zc2, j * esym + s0 + 32u * blk);
-    }
-    wave_sync();
-    const uint8_t* rows = reinterpret_cast<const uint8_t*>(sh.symb);
-    for (uint32_t item = lane; item < 4u * nblk; item += WAVE) {
-      const uint32_t blk = item >> 2, m = item & 3u;
-      const uint8_t* b   = rows + 32u * blk + (3u - m); // byte 3 - m of a row word holds its columns 8m .. 8m + 7
-      uint32_t       r8[8];
+  // Two passes over the wave's 64 lanes instead of one lane per block (a 281-RE codeblock has 36 blocks: 36 busy lanes doing
+  // Qm gathers and four transpositions each).  First the Qm * nblk row words, one gather per item, into the block's eight
+  // words of `symb` (word 8 blk + j = row j); then the 4 * nblk (block, byte column) items: eight byte reads, one 8x8
+  // transposition, two words back into the same eight words (the four items of a block sit in neighbouring lanes of one
+  // instruction: all their reads precede their writes).
+  for (uint32_t item = lane; item < QM * nblk; item += WAVE) {
+    const uint32_t blk = item / QM, j = item - blk * QM;
+    sh.symb[8u * blk + j] = rm_gather32<WRAP>(rm, sh.lin, zc2, j * esym + s0 + 32u * blk);
+  }
+  wave_sync();
+  const uint8_t* rows = reinterpret_cast<const uint8_t*>(sh.symb);
+  for (uint32_t item = lane; item < 4u * nblk; item += WAVE) {
+    const uint32_t blk = item >> 2, m = item & 3u;
+    const uint8_t* b   = rows + 32u * blk + (3u - m); // byte 3 - m of a row word holds its columns 8m .. 8m + 7
+    uint32_t       r8[8];
 #pragma unroll
-      for (int j = 0; j != 8; ++j) {
-        r8[j] = (j < QM) ? b[4 * j] : 0u;
-      }
-      uint32_t hi = (r8[0] << 24) | (r8[1] << 16) | (r8[2] << 8) | r8[3];
-      uint32_t lo = (r8[4] << 24) | (r8[5] << 16) | (r8[6] << 8) | r8[7];
-      transpose8x8(hi, lo);
-      sh.symb[8u * blk + 2u * m]      = hi;
-      sh.symb[8u * blk + 2u * m + 1u] = lo;
+    for (int j = 0; j != 8; ++j) {
+      r8[j] = (j < QM) ? b[4 * j] : 0u;
     }
+    uint32_t hi = (r8[0] << 24) | (r8[1] << 16) | (r8[2] << 8) | r8[3];
+    uint32_t lo = (r8[4] << 24) | (r8[5] << 16) | (r8[6] << 8) | r8[7];
+    transpose8x8(hi, lo);
+    sh.symb[8u * blk + 2u * m]      = hi;
+    sh.symb[8u * blk + 2u * m + 1u] = lo;
+  }
 #else
-    for (uint32_t blk = lane; blk < nblk; blk += WAVE) {
-      uint32_t row[8];
+  for (uint32_t blk = lane; blk < nblk; blk += WAVE) {
+    uint32_t row[8];
 #pragma unroll
-      for (int j = 0; j != 8; ++j) {
-        row[j] = (j < QM) ? rm_gather32<WRAP>(rm, sh.lin, zc2, (uint32_t)j * esym + s0 + 32u * blk) : 0u;
-      }
-#pragma unroll
-      for (int m = 0; m != 4; ++m) { // columns 8m .. 8m+7
-        const int sft = 24 - 8 * m;
-        uint32_t  hi  = (((row[0] >> sft) & 0xFFu) << 24) | (((row[1] >> sft) & 0xFFu) << 16) |
-                      (((row[2] >> sft) & 0xFFu) << 8) | ((row[3] >> sft) & 0xFFu);
-        uint32_t lo = (((row[4] >> sft) & 0xFFu) << 24) | (((row[5] >> sft) & 0xFFu) << 16) |
-                      (((row[6] >> sft) & 0xFFu) << 8) | ((row[7] >> sft) & 0xFFu);
-        transpose8x8(hi, lo);
-        sh.symb[8u * blk + 2u * m]      = hi; // symbols 8m .. 8m+3 of the block
-        sh.symb[8u * blk + 2u * m + 1u] = lo; // symbols 8m+4 .. 8m+7
-      }
+    for (int j = 0; j != 8; ++j) {
+      row[j] = (j < QM) ? rm_gather32<WRAP>(rm, sh.lin, zc2, (uint32_t)j * esym + s0 + 32u * blk) : 0u;
     }
+#pragma unroll
+    for (int m = 0; m != 4; ++m) { // columns 8m .. 8m+7
+      const int sft = 24 - 8 * m;
+      uint32_t  hi  = (((row[0] >> sft) & 0xFFu) << 24) | (((row[1] >> sft) & 0xFFu) << 16) |
+                    (((row[2] >> sft) & 0xFFu) << 8) | ((row[3] >> sft) & 0xFFu);
+      uint32_t lo = (((row[4] >> sft) & 0xFFu) << 24) | (((row[5] >> sft) & 0xFFu) << 16) |
+                    (((row[6] >> sft) & 0xFFu) << 8) | ((row[7] >> sft) & 0xFFu);
+      transpose8x8(hi, lo);
+      sh.symb[8u * blk + 2u * m]      = hi; // symbols 8m .. 8m+3 of the block
+      sh.symb[8u * blk + 2u * m + 1u] = lo; // symbols 8m+4 .. 8m+7
+    }
+  }
 #endif
-    if (lane < 8) {
-      sh.symb[8u * nblk + lane] = 0; // read-ahead padding
-    }
-    // Modulation table (the CRC table it shares LDS with is no longer needed).
-    for (uint32_t i = lane; i < (1u << QM); i += WAVE) {
-      sh.st->lut.qam[i] = p.gold->qam_lut[QM / 2 - 1][i];
-    }
-    wave_sync();
+  if (lane < 8) {
+    sh.symb[8u * nblk + lane] = 0; // read-ahead padding
   }
+  // Modulation table (the CRC table it shares LDS with is no longer needed).
+  for (uint32_t i = lane; i < (1u << QM); i += WAVE) {
+    sh.st->lut.qam[i] = p.gold->qam_lut[QM / 2 - 1][i];
+  }
+  wave_sync();
+}
 
-  if (p.profile_stage == 4) {
-    return;
+// A wave-uniform complex weight as an opaque value in one aligned scalar register pair: the compiler can neither
+// re-load it inside the RE loop (it used to: one s_load_dwordx8 + s_waitcnt per port and 64 RE) nor split the pair.
+__device__ __forceinline__ void pin_scalar(cf2& w)
+{
+  asm volatile("" : "+s"(w));
+}
+
+// What phase B knows about the chunk before it looks at a resource element.
+struct ChunkMap {
+  uint32_t re0;      // first RE of the chunk within the PDU
+  uint32_t word0;    // first scrambling word of the chunk (valid when the chunk starts on a word and L * Qm = 32)
+  bool     aligned;  // L * Qm = 32 and the chunk starts on a word boundary: one scrambling word per RE
+};
+
+// The RE's L symbol bytes (first in the MSB) and its L*Qm scrambling bits (prologue; MSB first).  Four layers make the
+// first a whole word; L*Qm = 32 with a word-aligned chunk (the headline shape) makes the second one too.
+template <int QM, int L>
+__device__ __forceinline__ void re_bits(const PdschLaunch& p, const uint32_t* __restrict__ scr, const CbShared& sh,
+                                        const ChunkGeom& g, const ChunkMap& cm, uint32_t r, uint32_t& bytes,
+                                        uint32_t& gbits)
+{
+  constexpr uint32_t LQ = QM * L;
+  if constexpr (L == 4) {
+    bytes = sh.symb[r];
+  } else {
+    bytes = ext32(sh.symb, 8u * r * L);
   }
-  // ---- Phase B ----
-  const uint32_t re_cb   = g.cw_cb / LQ; // first RE of the codeblock within the PDU
-  const uint32_t P       = pd.nof_ports;
-  const bool     one_prg = pd.nof_prg == 1;
-  const float*   wbase   = p.weights + pd.weights_offset;
-  const size_t   grid_base = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
-  const uint64_t cw_bit0 = pd.cw_bit_offset + g.cw_cb + (uint64_t)wk.re_begin * LQ;
+  if (LQ == 32 && cm.aligned) { // wave-uniform
+    gbits = scr[cm.word0 + r];
+    if (NRPHY_SCR_X2_ONLY) {
+      gbits ^= p.x1_words[cm.word0 + r];
+    }
+  } else {
+    gbits = ext32(scr, g.bit0 + r * LQ);
+    if (NRPHY_SCR_X2_ONLY) {
+      gbits ^= ext32(p.x1_words, g.bit0 + r * LQ);
+    }
+  }
+}
+
+// The grid loop of phase B for P ports with wideband precoding (every weight in a scalar register pair for the whole
+// loop, no guards, no loads), or -- P = 0 -- for any port count with weights per PRG read from memory per RE.
+template <int QM, int L, int P>
+__device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, const PduDev* __restrict__ pd_global,
+                                             const CbWork& wk, const CbShared& sh, const ChunkGeom& g, const ChunkMap& cm,
+                                             uint32_t lane, uint32_t* __restrict__ d_grid)
+{
   const uint32_t* __restrict__ scr = p.scr + pd.scr_offset;
-  const bool      scr_aligned      = (g.bit0 & 31u) == 0;
-  // The OFDM symbol of the chunk's first RE, found once; the loop below only checks (on the scalar unit) whether the
-  // next 64 RE stay inside the current symbol and walks on when they do not.
-  const uint32_t re0   = re_cb + wk.re_begin;
-  uint32_t       l_cur = 0;
+  const size_t   grid_base   = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
+  const uint32_t plane_words = NRPHY_NSYMB * p.grid_nof_subc;
+  // The PDU's grid through a buffer descriptor (scalar base, 32-bit per-lane offsets, the port plane in the scalar offset):
+  // no 64-bit address arithmetic in the vector unit.  (Profiling aid, NRPHY_PROFILE_STAGE=11: a zero-sized descriptor
+  // drops the data stores, everything else runs.)
+  const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      d_grid + grid_base, 0, (int)(p.profile_stage == 11 ? 0u : p.grid_nof_ports * plane_words * 4u), 0x00020000);
+  cf2 wu[P > 0 ? P : 1][L];
+  if constexpr (P > 0) {
+    const float NRPHY_CONSTANT* wuni = to_constant(p.weights + pd.weights_offset);
 #pragma unroll
-  for (int l = 1; l != NRPHY_NSYMB; ++l) {
-    l_cur += (re0 >= pd.sym_re_start[l]) ? 1u : 0u;
+    for (int port = 0; port != P; ++port) {
+#pragma unroll
+      for (int l = 0; l != L; ++l) {
+        wu[port][l] = cf2{wuni[2 * (port * L + l)], wuni[2 * (port * L + l) + 1]};
+      }
+    }
+#pragma unroll
+    for (int port = 0; port != P; ++port) {
+#pragma unroll
+      for (int l = 0; l != L; ++l) {
+        pin_scalar(wu[port][l]);
+      }
+    }
+  }
+  // The OFDM symbol of the chunk's first RE, found once; the loop below only checks (on the scalar unit) whether the
+  // next 64 RE stay inside the current symbol and walks on when they do not.  What the loop needs of the current symbol
+  // travels in scalar registers (loaded when the symbol changes, not per 64 RE).
+  uint32_t l_cur = 0;
+#pragma unroll 1
+  while (l_cur + 1u < NRPHY_NSYMB && cm.re0 >= pd.sym_re_start[l_cur + 1u]) {
+    ++l_cur;
   }
   uint32_t cur_start = pd.sym_re_start[l_cur], cur_end = pd.sym_re_start[l_cur + 1u];
-  // Wideband precoding (the common case): the weights are wave-uniform, scalar loads put them in SGPRs.
-  const float NRPHY_CONSTANT* wuni = to_constant(wbase);
-#if NRPHY_GRID_BUFFER_STORES
-  // The PDU's grid through a buffer descriptor (scalar base, 32-bit per-lane offsets, the port plane in the scalar offset):
-  // no 64-bit address arithmetic in the vector unit.
-  const uint32_t plane_bytes = NRPHY_NSYMB * p.grid_nof_subc * 4u;
-  const __amdgpu_buffer_rsrc_t grid_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(d_grid + grid_base, 0, (int)(p.profile_stage == 11 ? 0u : p.grid_nof_ports * plane_bytes),
-                                        0x00020000);
-#endif
+  uint32_t cur_arg = pd.sym_arg[l_cur], cur_row = l_cur * p.grid_nof_subc;
+  bool     cur_table = pd.sym_kind[l_cur] == SYM_TABLE;
+  // The chunk's scrambling words: scalar base, small per-lane index.
+  const uint32_t* __restrict__ scr_chunk = scr + cm.word0;
+  const uint32_t* __restrict__ x1_chunk  = p.x1_words + cm.word0;
 
   for (uint32_t r0 = 0; r0 < wk.re_count; r0 += WAVE) { // r0 is wave-uniform
-    const uint32_t r = r0 + lane;
-    const uint32_t re_first = re0 + r0;
+    const uint32_t r        = r0 + lane;
+    const uint32_t re_first = cm.re0 + r0;
     const uint32_t re_last  = re_first + ((wk.re_count - r0 < WAVE ? wk.re_count - r0 : WAVE) - 1u);
-    while (re_first >= cur_end && l_cur + 1u < NRPHY_NSYMB) { // wave-uniform; skips symbols without data RE
-      ++l_cur;
-      cur_start = cur_end;
-      cur_end   = pd.sym_re_start[l_cur + 1u];
+    if (re_first >= cur_end && l_cur + 1u < NRPHY_NSYMB) { // wave-uniform
+#pragma unroll 1
+      do { // skips symbols without data RE
+        ++l_cur;
+        cur_start = cur_end;
+        cur_end   = pd.sym_re_start[l_cur + 1u];
+      } while (re_first >= cur_end && l_cur + 1u < NRPHY_NSYMB);
+      cur_arg   = pd.sym_arg[l_cur];
+      cur_row   = l_cur * p.grid_nof_subc;
+      cur_table = pd.sym_kind[l_cur] == SYM_TABLE;
     }
     if (r >= wk.re_count) {
       continue;
     }
-    // The RE's L symbol bytes (first in the MSB) and its L*Qm scrambling bits (prologue; MSB first).  Four layers make the
-    // first a whole word; L*Qm = 32 with a word-aligned chunk (the headline shape) makes the second one too.
+    __builtin_assume(r < (uint32_t)RE_CHUNK + WAVE);
     uint32_t bytes, gbits;
     if constexpr (L == 4) {
       bytes = sh.symb[r];
     } else {
       bytes = ext32(sh.symb, 8u * r * L);
     }
-    if (LQ == 32 && scr_aligned) { // wave-uniform
-      gbits = scr[(g.bit0 >> 5) + r];
+    if (QM * L == 32 && cm.aligned) { // wave-uniform: one scrambling word per RE (the headline shape)
+      gbits = scr_chunk[r];
       if (NRPHY_SCR_X2_ONLY) {
-        gbits ^= p.x1_words[(g.bit0 >> 5) + r];
+        gbits ^= x1_chunk[r];
       }
     } else {
-      gbits = ext32(scr, g.bit0 + r * LQ);
+      gbits = ext32(scr, g.bit0 + r * (uint32_t)(QM * L));
       if (NRPHY_SCR_X2_ONLY) {
-        gbits ^= ext32(p.x1_words, g.bit0 + r * LQ);
+        gbits ^= ext32(p.x1_words, g.bit0 + r * (uint32_t)(QM * L));
       }
-    }
-    uint32_t       idx[L];
-    uint32_t       v_rm = 0;
-#pragma unroll
-    for (int l = 0; l != L; ++l) {
-      const uint32_t raw = ((bytes >> (24 - 8 * l)) & 0xFFu) >> (8 - QM);
-      v_rm |= raw << (32 - (l + 1) * QM);
-      idx[l] = raw ^ ((gbits >> (32 - (l + 1) * QM)) & ((1u << QM) - 1u)); // scrambling, TS 38.211 Section 7.3.1.1
-    }
-    if (d_cw_rm) {
-      or_bits_global(d_cw_rm, cw_bit0 + (uint64_t)r * LQ, v_rm, LQ);
-    }
-    if (d_cw_scr) {
-      or_bits_global(d_cw_scr, cw_bit0 + (uint64_t)r * LQ, v_rm ^ (gbits & topmask(LQ)), LQ);
-    }
-    if (d_grid == nullptr) {
-      continue;
     }
     // RE position: OFDM symbol from the per-symbol prefix counts, subcarrier from the symbol's pattern.
     const uint32_t re_pdu = re_first + lane;
-    uint32_t       l_sym, subc;
+    uint32_t       subc, word_offset;
     if (re_last < cur_end) { // wave-uniform: the whole group lies in the current symbol
-      l_sym = l_cur;
-      subc  = pd.sym_arg[l_cur] + (re_pdu - cur_start);
-      if (pd.sym_kind[l_cur] == SYM_TABLE) {
+      subc = cur_arg + (re_pdu - cur_start);
+      if (cur_table) {
         subc = (uint32_t)p.re_table[subc];
       }
+      word_offset = cur_row + subc;
     } else {
-      uint32_t start = 0, arg = pd.sym_arg[0];
-      l_sym          = 0;
-#pragma unroll
-      for (int l = 1; l != NRPHY_NSYMB; ++l) {
-        bool ge = re_pdu >= pd.sym_re_start[l];
-        l_sym += ge ? 1u : 0u;
-        start = ge ? pd.sym_re_start[l] : start;
-        arg   = ge ? pd.sym_arg[l] : arg;
+      // The group runs into the next symbol(s): rare (once per symbol and codeblock at most), so each lane walks on by
+      // itself -- the scalar formulation of this search kept 27 prefix counts and pattern arguments in scalar registers
+      // through the whole loop.
+      uint32_t l_sym = l_cur, start = cur_start, end = cur_end;
+#pragma unroll 1
+      while (re_pdu >= end && l_sym + 1u < NRPHY_NSYMB) {
+        ++l_sym;
+        start = end;
+        end   = pd_global->sym_re_start[l_sym + 1u];
       }
-      subc = arg + (re_pdu - start);
-      if (pd.sym_kind[l_sym] == SYM_TABLE) {
+      subc = pd_global->sym_arg[l_sym] + (re_pdu - start);
+      if (pd_global->sym_kind[l_sym] == SYM_TABLE) {
         subc = (uint32_t)p.re_table[subc];
       }
+      word_offset = l_sym * p.grid_nof_subc + subc;
     }
-    // Modulation (table lookup) + layer mapping + precoding
+    // Scrambling (TS 38.211 Section 7.3.1.1), modulation (table lookup), layer mapping + precoding
     // (resource_grid_mapper_impl.cpp:279-437, channel_precoder_avx2.cpp:214-342).
     cf2 x[L];
 #pragma unroll
     for (int l = 0; l != L; ++l) {
-      const float2 point = sh.st->lut.qam[idx[l]];
-      x[l]               = cf2{point.x, point.y};
+      const uint32_t raw   = ((bytes >> (24 - 8 * l)) & 0xFFu) >> (8 - QM);
+      const uint32_t idx   = raw ^ ((gbits >> (32 - (l + 1) * QM)) & ((1u << QM) - 1u));
+      const float2   point = sh.st->lut.qam[idx];
+      x[l]                 = cf2{point.x, point.y};
     }
-    uint32_t* out = d_grid + grid_base + (size_t)l_sym * p.grid_nof_subc + subc;
-    // Two copies of the port loop on purpose: one pointer that may address LDS or global memory would be a generic
-    // pointer and every weight read a flat load.
-    if (one_prg) {
-      // Port loop unrolled with wave-uniform guards so that every weight has a fixed scalar register.
+    if constexpr (P > 0) {
 #pragma unroll
-      for (uint32_t port = 0; port != NRPHY_MAX_PORTS; ++port) {
-        if (port < P) {
-          cf2 acc = cmul_ref_packed_uniform(x[0], cf2{wuni[2 * port * L], wuni[2 * port * L + 1]});
+      for (int port = 0; port != P; ++port) {
+        cf2 acc = cmul_ref_packed_uniform(x[0], wu[port][0]);
 #pragma unroll
-          for (int l = 1; l != L; ++l) {
-            acc += cmul_ref_packed_uniform(x[l], cf2{wuni[2 * (port * L + l)], wuni[2 * (port * L + l) + 1]});
-          }
-#if NRPHY_GRID_BUFFER_STORES
-          // (profiling aid, NRPHY_PROFILE_STAGE=11: a zero-sized descriptor drops the data stores, everything else runs)
-          __builtin_amdgcn_raw_buffer_store_b32(pack_cbf16(acc.x, acc.y), grid_rsrc, (int)((l_sym * p.grid_nof_subc + subc) * 4u),
-                                                (int)(port * plane_bytes), NRPHY_GRID_STORE_AUX);
-#else
-          grid_store(&out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc], pack_cbf16(acc.x, acc.y));
-#endif
+        for (int l = 1; l != L; ++l) {
+          acc += cmul_ref_packed_uniform(x[l], wu[port][l]);
         }
+        __builtin_amdgcn_raw_buffer_store_b32(pack_cbf16(acc.x, acc.y), grid_rsrc, (int)(word_offset * 4u),
+                                              (int)(port * plane_words * 4u), NRPHY_GRID_STORE_AUX);
       }
     } else {
-      uint32_t prg = subc / pd.prg_size_subc;
-      prg          = prg >= pd.nof_prg ? pd.nof_prg - 1 : prg;
-      const float* w = wbase + 2u * prg * P * L;
+      const uint32_t nof_ports = pd.nof_ports;
+      uint32_t       prg       = subc / pd.prg_size_subc;
+      prg                      = prg >= pd.nof_prg ? pd.nof_prg - 1 : prg;
+      const float* w = p.weights + pd.weights_offset + 2u * prg * nof_ports * L;
 #pragma unroll 1
-      for (uint32_t port = 0; port != P; ++port) {
+      for (uint32_t port = 0; port != nof_ports; ++port) {
         cf2 acc = cmul_ref_packed(x[0], cf2{w[2 * port * L], w[2 * port * L + 1]});
 #pragma unroll
         for (int l = 1; l != L; ++l) {
           acc += cmul_ref_packed(x[l], cf2{w[2 * (port * L + l)], w[2 * (port * L + l) + 1]});
         }
-        grid_store(&out[(size_t)port * NRPHY_NSYMB * p.grid_nof_subc], pack_cbf16(acc.x, acc.y));
+        __builtin_amdgcn_raw_buffer_store_b32(pack_cbf16(acc.x, acc.y), grid_rsrc, (int)(word_offset * 4u),
+                                              (int)(port * plane_words * 4u), NRPHY_GRID_STORE_AUX);
       }
     }
   }
 }
 
 template <int QM, int L>
-__device__ __forceinline__ void map_chunk_select(const PdschLaunch& p, PduRef pd, const CbWork& wk,
-                                                 const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
-                                                 uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
+__device__ __forceinline__ void phase_b(const PdschLaunch& p, PduRef pd, const PduDev* __restrict__ pd_global,
+                                        const CbWork& wk, const CbShared& sh, const ChunkGeom& g, uint32_t lane,
+                                        uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
+                                        uint32_t* __restrict__ d_cw_scr)
 {
-  if (wrap) {
-    map_chunk<QM, L, true>(p, pd, wk, sh, g, lane, d_grid, d_cw_rm, d_cw_scr);
+  constexpr uint32_t LQ = QM * L;
+  ChunkMap           cm;
+  cm.re0     = g.cw_cb / LQ + wk.re_begin;
+  cm.word0   = g.bit0 >> 5;
+  cm.aligned = (g.bit0 & 31u) == 0;
+  // Codeword taps (parity tests, seam B): a loop of their own, so that the grid loop carries none of this.
+  if (d_cw_rm != nullptr || d_cw_scr != nullptr) { // wave-uniform
+    const uint32_t* __restrict__ scr = p.scr + pd.scr_offset;
+    const uint64_t cw_bit0 = pd.cw_bit_offset + g.cw_cb + (uint64_t)wk.re_begin * LQ;
+    for (uint32_t r = lane; r < wk.re_count; r += WAVE) {
+      uint32_t bytes, gbits;
+      re_bits<QM, L>(p, scr, sh, g, cm, r, bytes, gbits);
+      uint32_t v_rm = 0;
+#pragma unroll
+      for (int l = 0; l != L; ++l) {
+        const uint32_t raw = ((bytes >> (24 - 8 * l)) & 0xFFu) >> (8 - QM);
+        v_rm |= raw << (32 - (l + 1) * QM);
+      }
+      if (d_cw_rm) {
+        or_bits_global(d_cw_rm, cw_bit0 + (uint64_t)r * LQ, v_rm, LQ);
+      }
+      if (d_cw_scr) {
+        or_bits_global(d_cw_scr, cw_bit0 + (uint64_t)r * LQ, v_rm ^ (gbits & topmask(LQ)), LQ);
+      }
+    }
+  }
+  if (d_grid == nullptr) {
+    return;
+  }
+  // One copy of the grid loop per port count (wave-uniform): straight-line port code with its weights in registers.
+  const uint32_t nof_ports = pd.nof_prg == 1 ? pd.nof_ports : 0u;
+  if (nof_ports == 4u) {
+    phase_b_grid<QM, L, 4>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid);
+  } else if (L <= 3 && nof_ports == 3u) {
+    phase_b_grid<QM, (L <= 3 ? L : 1), 3>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid);
+  } else if (L <= 2 && nof_ports == 2u) {
+    phase_b_grid<QM, (L <= 2 ? L : 1), 2>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid);
+  } else if (L == 1 && nof_ports == 1u) {
+    phase_b_grid<QM, 1, 1>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid);
   } else {
-    map_chunk<QM, L, false>(p, pd, wk, sh, g, lane, d_grid, d_cw_rm, d_cw_scr);
+    phase_b_grid<QM, L, 0>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid); // weights per PRG (or fewer ports than layers)
   }
 }
 
+// Stages 3 and 4 of a codeblock wave for one (Qm, layers): this wave's slice of the codeword, rate matching ... RE mapping.
+template <int QM, int L>
+__device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const PduDev* pd_global, const CbWork& wk,
+                                          const CbShared& sh, uint32_t lane, uint32_t* d_grid, uint32_t* d_cw_rm,
+                                          uint32_t* d_cw_scr)
+{
+  const bool is_long = wk.cb >= pd.n_short;
+  ChunkGeom  g;
+  g.E     = is_long ? pd.e_long : pd.e_short;
+  g.cw_cb = is_long ? pd.n_short * pd.e_short + (wk.cb - pd.n_short) * pd.e_long : wk.cb * pd.e_short;
+  g.bit0  = g.cw_cb + wk.re_begin * (uint32_t)(QM * L);
+  if (p.profile_stage == 3) {
+    return;
+  }
+  {
+    const RmIndex rm = rm_index_init(pd);
+    if (rm.rank0 + g.E > rm.n_valid) { // wave-uniform: the selection wraps around Ncb
+      phase_a<QM, L, true>(p, pd, wk, sh, g.E, lane);
+    } else {
+      phase_a<QM, L, false>(p, pd, wk, sh, g.E, lane);
+    }
+  }
+  if (p.profile_stage == 4) {
+    return;
+  }
+  phase_b<QM, L>(p, pd, pd_global, wk, sh, g, lane, d_grid, d_cw_rm, d_cw_scr);
+}
+
 template <int QM>
-__device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, PduRef pd, const CbWork& wk,
-                                                 const CbShared& sh, const ChunkGeom& g, bool wrap, uint32_t lane,
-                                                 uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
+__device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, PduRef pd, const PduDev* pd_global,
+                                                 const CbWork& wk, const CbShared& sh, uint32_t lane, uint32_t* d_grid,
+                                                 uint32_t* d_cw_rm, uint32_t* d_cw_scr)
 {
   switch (pd.nof_layers) { // wave-uniform
     case 1:
-      map_chunk_select<QM, 1>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk<QM, 1>(p, pd, pd_global, wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     case 2:
-      map_chunk_select<QM, 2>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk<QM, 2>(p, pd, pd_global, wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     case 3:
-      map_chunk_select<QM, 3>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk<QM, 3>(p, pd, pd_global, wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     default:
-      map_chunk_select<QM, 4>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk<QM, 4>(p, pd, pd_global, wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
   }
 }
@@ -798,10 +903,88 @@ __device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_in
 }
 
 // ================================================================================================================
-// The codeblock kernel.  Blocks [0, n_work) build codeblocks; the launch may carry two more kinds of wave behind
+// The codeblock kernels.  Blocks [0, n_work) build codeblocks; the launch may carry two more kinds of wave behind
 // them so that their short, latency-bound work overlaps the codeblock waves instead of paying for own launches:
 // DM-RS waves and zero-fill waves for the grid words nobody maps.
+//
+// The plan sorts its work items by (modulation order, layers) -- a "bucket".  A plan with one bucket (every batch of
+// like PDUs: the headline workload) or with big buckets runs codeblock_kernel_t<QM, L>, one launch per bucket, whose
+// output stage exists once and whose scalar registers hold only what that stage needs; a small mixed plan (one slot
+// with PDUs of several modulations) runs the one-launch codeblock_kernel, which selects the output stage per wave.
 // ================================================================================================================
+
+// The launch's extra waves (DM-RS, zero fill); true when this block was one of them.
+__device__ __forceinline__ bool extra_wave(const PdschLaunch& p, uint32_t* __restrict__ d_grid, uint32_t lane)
+{
+  if (blockIdx.x < p.n_work) { // wave-uniform
+    return false;
+  }
+  const uint32_t extra = blockIdx.x - p.n_work;
+  if (extra < p.n_dmrs_in_launch) {
+    dmrs_wave(p, extra, d_grid, lane);
+  } else {
+    zero_wave(p, extra - p.n_dmrs_in_launch, d_grid, lane);
+  }
+  return true;
+}
+
+// Workgroups go to the eight XCDs round-robin (block b runs on XCD b % 8).  Give each XCD a contiguous run of work
+// items, so that codeblocks which share cache lines -- neighbours in the transport block and in the grid rows --
+// meet in one L2 instead of leaving partial lines in two.
+__device__ __forceinline__ uint32_t xcd_work_item(uint32_t n_work)
+{
+  const uint32_t xcd = blockIdx.x & 7u, turn = blockIdx.x >> 3;
+  const uint32_t q = n_work >> 3, r = n_work & 7u;
+  return xcd * q + (xcd < r ? xcd : r) + turn;
+}
+
+// Stages 1 and 2 of a codeblock wave: segmentation + CRC attachment (the graph rows ride along: their loads overlap the
+// transport block's), LDPC encoding (only the parity rows that rate matching can reach).  False: a profiling stage stopped the wave.
+__device__ __forceinline__ bool codeblock_front(const PdschLaunch& p, PduRef pd, const CbWork& wk, CbShared& sh,
+                                                const uint8_t* __restrict__ d_tb, uint32_t lane)
+{
+  const uint32_t zc = pd.zc, kb = pd.kb;
+  if (p.profile_stage == 5) {
+    return false;
+  }
+  stage_graph(&p.graphs[pd.graph], pd.nof_rows, sh.graph, lane);
+  if (p.profile_stage == 6) {
+    return false;
+  }
+  const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
+  build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), p.tb_crc_part, p.gold, &sh,
+                  total_words, lane, p.profile_stage);
+  if (p.profile_stage == 1 || p.profile_stage == 7) {
+    return false;
+  }
+  ldpc_encode_wave(&p.graphs[pd.graph], sh.graph, kb, zc, pd.nof_rows, sh.lin, &sh.st->ldpc, lane);
+  return p.profile_stage != 2;
+}
+
+template <int QM, int L>
+__global__ __launch_bounds__(WAVE, 6) void codeblock_kernel_t(PdschLaunch p, const uint8_t* __restrict__ d_tb,
+                                                              uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
+                                                              uint32_t* __restrict__ d_cw_scr)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+  __shared__ CbStatic st;
+  CbShared            sh;
+  sh.lin   = dyn_lds;
+  sh.symb  = dyn_lds + p.lds_lin_words;
+  sh.graph = sh.symb + p.lds_symb_words;
+  sh.st    = &st;
+  const uint32_t lane = threadIdx.x;
+  if (p.profile_stage == 10 || extra_wave(p, d_grid, lane)) {
+    return;
+  }
+  const auto*  wkc = to_constant(&p.work[xcd_work_item(p.n_work)]);
+  const CbWork wk  = {wkc->pdu, wkc->cb, wkc->re_begin, wkc->re_count};
+  PduRef       pd  = *to_constant(&p.pdus[wk.pdu]);
+  if (!codeblock_front(p, pd, wk, sh, d_tb, lane)) {
+    return;
+  }
+  map_chunk<QM, L>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+}
 
 __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
                                                          uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
@@ -810,98 +993,91 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
   __shared__ CbStatic st;
   CbShared            sh;
-  sh.lin  = dyn_lds;
+  sh.lin   = dyn_lds;
   sh.symb  = dyn_lds + p.lds_lin_words;
   sh.graph = sh.symb + p.lds_symb_words;
   sh.st    = &st;
-  const uint32_t      lane = threadIdx.x;
-  if (p.profile_stage == 10) {
+  const uint32_t lane = threadIdx.x;
+  if (p.profile_stage == 10 || extra_wave(p, d_grid, lane)) {
     return;
   }
-  if (blockIdx.x >= p.n_work) { // wave-uniform
-    const uint32_t extra = blockIdx.x - p.n_work;
-    if (extra < p.n_dmrs_in_launch) {
-      dmrs_wave(p, extra, d_grid, lane);
-    } else {
-      zero_wave(p, extra - p.n_dmrs_in_launch, d_grid, lane);
-    }
+  const auto*  wkc = to_constant(&p.work[xcd_work_item(p.n_work)]);
+  const CbWork wk  = {wkc->pdu, wkc->cb, wkc->re_begin, wkc->re_count};
+  PduRef       pd  = *to_constant(&p.pdus[wk.pdu]);
+  if (!codeblock_front(p, pd, wk, sh, d_tb, lane)) {
     return;
   }
-  // Workgroups go to the eight XCDs round-robin (block b runs on XCD b % 8).  Give each XCD a contiguous run of work
-  // items, so that codeblocks which share cache lines -- neighbours in the transport block and in the grid rows --
-  // meet in one L2 instead of leaving partial lines in two.
-  uint32_t item = blockIdx.x;
-  {
-    const uint32_t xcd = blockIdx.x & 7u, turn = blockIdx.x >> 3;
-    const uint32_t q = p.n_work >> 3, r = p.n_work & 7u;
-    item = xcd * q + (xcd < r ? xcd : r) + turn;
-  }
-  const auto*         wkc  = to_constant(&p.work[item]);
-  const CbWork        wk   = {wkc->pdu, wkc->cb, wkc->re_begin, wkc->re_count};
-  PduRef              pd   = *to_constant(&p.pdus[wk.pdu]);
-  const uint32_t      zc = pd.zc, kb = pd.kb;
-
-  // 1. Segmentation + CRC attachment (the graph rows ride along: their loads overlap the transport block's).
-  if (p.profile_stage == 5) {
-    return;
-  }
-  stage_graph(&p.graphs[pd.graph], pd.nof_rows, sh.graph, lane);
-  if (p.profile_stage == 6) {
-    return;
-  }
-  const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
-  build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), p.tb_crc_part, p.gold, &sh,
-                  total_words, lane, p.profile_stage);
-
-  if (p.profile_stage == 1) {
-    return;
-  }
-  // 2. LDPC encoding (only the parity rows that rate matching can reach).
-  ldpc_encode_wave(&p.graphs[pd.graph], sh.graph, kb, zc, pd.nof_rows, sh.lin, &st.ldpc, lane);
-
-  if (p.profile_stage == 2) {
-    return;
-  }
-  // 3. This wave's slice of the codeword (its scrambling bits were generated by the prologue).
-  const uint32_t lq      = pd.nof_layers * pd.qm; // bits per RE
-  const bool     is_long = wk.cb >= pd.n_short;
-  ChunkGeom      g;
-  g.E     = is_long ? pd.e_long : pd.e_short;
-  g.cw_cb = is_long ? pd.n_short * pd.e_short + (wk.cb - pd.n_short) * pd.e_long : wk.cb * pd.e_short;
-  g.bit0  = g.cw_cb + wk.re_begin * lq;
-  if (p.profile_stage == 3) {
-    return;
-  }
-  // 4. Rate matching ... RE mapping, specialised per (Qm, layers); `wrap` = the selection wraps around Ncb.
-  const RmIndex rm   = rm_index_init(pd);
-  const bool    wrap = rm.rank0 + g.E > rm.n_valid;
   switch (pd.qm) { // wave-uniform
     case 2:
-      map_chunk_layers<2>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk_layers<2>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     case 4:
-      map_chunk_layers<4>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk_layers<4>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     case 6:
-      map_chunk_layers<6>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk_layers<6>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     default:
-      map_chunk_layers<8>(p, pd, wk, sh, g, wrap, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk_layers<8>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
   }
 }
 
-hipError_t launch_codeblocks(const PdschLaunch& p, const uint8_t* d_tb, uint32_t* d_grid, uint32_t* d_cw_rm,
-                             uint32_t* d_cw_scr, hipStream_t stream)
+typedef void (*CodeblockKernel)(PdschLaunch, const uint8_t*, uint32_t*, uint32_t*, uint32_t*);
+
+static CodeblockKernel bucket_kernel(uint32_t bucket)
+{
+  static const CodeblockKernel table[CB_BUCKETS] = {
+      codeblock_kernel_t<2, 1>, codeblock_kernel_t<2, 2>, codeblock_kernel_t<2, 3>, codeblock_kernel_t<2, 4>,
+      codeblock_kernel_t<4, 1>, codeblock_kernel_t<4, 2>, codeblock_kernel_t<4, 3>, codeblock_kernel_t<4, 4>,
+      codeblock_kernel_t<6, 1>, codeblock_kernel_t<6, 2>, codeblock_kernel_t<6, 3>, codeblock_kernel_t<6, 4>,
+      codeblock_kernel_t<8, 1>, codeblock_kernel_t<8, 2>, codeblock_kernel_t<8, 3>, codeblock_kernel_t<8, 4>};
+  return table[bucket];
+}
+
+// bucket_begin[b] .. bucket_begin[b + 1]: the work items of bucket b = cb_bucket(Qm, layers) (the plan sorts them).
+// dispatch: 0 = by plan shape, 1 = always the one-launch mixed kernel, 2 = always one launch per bucket.
+hipError_t launch_codeblocks(const PdschLaunch& p, const uint32_t* bucket_begin, int dispatch, const uint8_t* d_tb,
+                             uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr, hipStream_t stream)
 {
   if (p.n_work == 0) {
     return hipSuccess;
   }
-  const size_t lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_symb_words + p.lds_graph_words);
-  const uint32_t blocks = p.n_work + (d_grid ? p.n_dmrs_in_launch + p.n_zero_work : 0u);
-  hipLaunchKernelGGL(codeblock_kernel, dim3(blocks), dim3(WAVE), lds_bytes, stream, p, d_tb, d_grid, d_cw_rm,
-                     d_cw_scr);
-  return hipGetLastError();
+  const size_t   lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_symb_words + p.lds_graph_words);
+  const uint32_t extras    = d_grid ? p.n_dmrs_in_launch + p.n_zero_work : 0u;
+  uint32_t       nof_buckets = 0, last_bucket = 0;
+  for (uint32_t b = 0; b != CB_BUCKETS; ++b) {
+    if (bucket_begin[b + 1] != bucket_begin[b]) {
+      ++nof_buckets;
+      last_bucket = b;
+    }
+  }
+  const bool mixed = dispatch == 1 || (dispatch == 0 && nof_buckets > 1 && p.n_work < CB_MIXED_MAX_WORK);
+  if (mixed) {
+    hipLaunchKernelGGL(codeblock_kernel, dim3(p.n_work + extras), dim3(WAVE), lds_bytes, stream, p, d_tb, d_grid, d_cw_rm,
+                       d_cw_scr);
+    return hipGetLastError();
+  }
+  for (uint32_t b = 0; b != CB_BUCKETS; ++b) {
+    const uint32_t n = bucket_begin[b + 1] - bucket_begin[b];
+    if (n == 0) {
+      continue;
+    }
+    PdschLaunch q = p;
+    q.work        = p.work + bucket_begin[b];
+    q.n_work      = n;
+    if (b != last_bucket) { // the DM-RS and zero-fill waves ride at the end of the last launch
+      q.n_dmrs_in_launch = 0;
+      q.n_zero_work      = 0;
+    }
+    const uint32_t blocks = n + (b == last_bucket ? extras : 0u);
+    hipLaunchKernelGGL(bucket_kernel(b), dim3(blocks), dim3(WAVE), lds_bytes, stream, q, d_tb, d_grid, d_cw_rm, d_cw_scr);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      return e;
+    }
+  }
+  return hipSuccess;
 }
 
 __global__ __launch_bounds__(WAVE) void dmrs_kernel(PdschLaunch p, uint32_t* __restrict__ d_grid)

@@ -32,3 +32,15 @@ def aggregate(dist, device, local_slots, local_samples, local_seconds):
     dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return int(round(sums[0].item())), int(round(sums[1].item())), float(tmax.item())
+
+
+def gather(dist, device, values):
+    """Every rank's list of floats, as a list indexed by rank (one all-gather of a few numbers); [values] without a
+    process group."""
+    import torch
+    if dist is None or not dist.is_initialized():
+        return [list(map(float, values))]
+    mine = torch.tensor(list(map(float, values)), dtype=torch.float64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [p.tolist() for p in parts]

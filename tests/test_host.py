@@ -3,6 +3,7 @@ derivation, TBS, OFDM sizes) agrees with the oracle, the product fails loudly wi
 sharding/aggregation path works over gloo with world_size 2."""
 import ctypes as C
 import os
+import sys
 import re
 import socket
 
@@ -178,6 +179,44 @@ def test_slot_sharding_and_aggregation_gloo_world2():
     assert [r[1:3] for r in res] == [(0, 129), (129, 128)]
     for r in res:
         assert r[3] == 257 and r[4] == 257 * 245760 and abs(r[5] - 0.75) < 1e-9
+
+
+def _bench_line(argv, env_extra=None, timeout=300):
+    """Runs bench.py with `argv` as a child process; returns (exit code, the lines of stdout that are JSON objects, stderr)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(backends.ROOT, "bench.py")] + argv, cwd=backends.ROOT, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    return p.returncode, [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")], p.stderr
+
+
+def test_bench_gpus_n_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it starts the two ranks itself (a child torch.distributed.run; the
+    dry mode runs the process group, sharding, totals and per-rank gather over gloo without device work) and prints ONE line
+    that says n_gpus 2 -- the obvious multi-GPU command must not silently measure one rank."""
+    rc, lines, err = _bench_line(["--gpus", "2", "--dry-run", "--steps", "3", "--slots", "100"])
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["scaling"] == "weak"
+    assert out["per_rank"]["slots_per_step"] == [100, 100] and out["total_slots"] == 2 * 100 * 3
+    assert out["collective_backend"].startswith("gloo")
+    # config 4 is placed by cell affinity; three ranks is one of the world sizes that leaves the shares uneven
+    rc, lines, err = _bench_line(["--gpus", "3", "--dry-run", "--steps", "1", "--slots", "8", "--config", "4"])
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 3
+    assert sum(lines[0]["per_rank"]["slots_per_step"]) == 24 and lines[0]["total_slots"] == 24
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    rc, lines, err = _bench_line(["--gpus", "2", "--dry-run"], {"RANK": "0", "WORLD_SIZE": "3", "LOCAL_RANK": "0"})
+    assert rc == 2 and not lines and "WORLD_SIZE=3" in err
+    rc, lines, err = _bench_line(["--gpus", "1", "--dry-run"])   # one rank: no launcher, no process group
+    assert rc == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["collective_backend"].startswith("none")
 
 
 def test_adaptors_compile_against_reference_headers(tmp_path):
