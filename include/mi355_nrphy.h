@@ -222,12 +222,16 @@ int nrphy_pdsch_process_slot_host(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_
 /* Asynchronous host-span form: pdsch_processor::process "may return before completion, the notifier fires from any
  * thread exactly once" (pdsch_processor.h:157-170; the reference's own asynchronous pool:
  * R/lib/phy/upper/channel_processors/pdsch_processor_asynchronous_pool.h:39-143).  A queue keeps up to `depth` PDUs in
- * flight, each on a stream of its own with pinned staging; plans are cached per PDU shape, so a shape seen before costs
- * no host derivation.  Submit copies the transport block (the caller's span is free on return) and returns at once;
+ * flight, each on a stream of its own with pinned staging.  Every submit derives the PDU's state anew, like the reference
+ * (pdsch_processor_concurrent_impl.cpp:55-207) -- live traffic brings a new pdu_t per slot -- straight into the operation's
+ * staging: no device allocation, no blocking copy, one host-to-device copy for the tables and the transport block; only what
+ * depends on the SHAPE of the PDU (RE mapping tables, zero-fill lists) is kept from earlier submits.  Submit copies the
+ * transport block (the caller's span is free on return) and returns at once;
  * `done(user, status, grid)` runs on a thread of the HIP runtime when the PDU's grid has reached the host: `grid`
  * points at [grid_nof_ports][14][grid_nof_subc] cbf16 (zeros + the PDU's resource elements, DM-RS included), valid until
- * `done` returns -- the handler merges the PDU's RE into the caller's grid and signals its notifier.  NRPHY_ERR_CAPACITY:
- * `depth` PDUs in flight (wait or retry).  The handler must not call HIP or this library.
+ * `done` returns -- the handler merges the PDU's RE into the caller's grid and signals its notifier; `status` is
+ * NRPHY_ERR_DEVICE when the operation's stream reported an error.  NRPHY_ERR_CAPACITY: `depth` PDUs in flight
+ * (nrphy_pdsch_async_wait_slot, or retry).  The handler must not call HIP or this library.
  * Tunable, read when the queue is created: environment variable NRPHY_ASYNC_ZERO_COPY = 1 lets the kernels read the
  * transport block from the operation's pinned staging instead of copying it to the device first, = 3 also lets them write
  * the grid into the pinned buffer `done` receives (pays with many operations in flight). */
@@ -243,6 +247,7 @@ int nrphy_pdsch_async_submit(nrphy_pdsch_async_t* queue, const nrphy_pdsch_pdu_t
 int nrphy_pdsch_async_submit_slot(nrphy_pdsch_async_t* queue, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
                                   const uint8_t* const* tbs, nrphy_pdsch_done_fn done, void* user);
 int nrphy_pdsch_async_wait(nrphy_pdsch_async_t* queue);    /* until nothing is in flight */
+int nrphy_pdsch_async_wait_slot(nrphy_pdsch_async_t* queue); /* until fewer than `depth` operations are in flight */
 int nrphy_pdsch_async_destroy(nrphy_pdsch_async_t* queue); /* waits, then frees */
 /* A completion handler that counts: `user` points at a uint64_t incremented atomically per successful PDU. */
 void nrphy_pdsch_async_count_done(void* user, int status, const void* grid);

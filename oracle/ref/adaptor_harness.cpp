@@ -97,6 +97,12 @@ int nrphy_pdsch_async_wait(nrphy_pdsch_async_t* q)
   q->idle.wait(lock, [q] { return q->in_flight == 0; });
   return NRPHY_OK;
 }
+int nrphy_pdsch_async_wait_slot(nrphy_pdsch_async_t* q)
+{
+  std::unique_lock<std::mutex> lock(q->mutex);
+  q->idle.wait(lock, [q] { return q->in_flight < q->depth; });
+  return NRPHY_OK;
+}
 int nrphy_pdsch_async_destroy(nrphy_pdsch_async_t* q)
 {
   if (q == nullptr) {

@@ -149,5 +149,95 @@ def main():
         h.nrphy_pdsch_async_destroy(q)
 
 
+def live_traffic():
+    """The asynchronous seam on LIVE traffic: every submit brings a PDU that differs from the one before, as a gNB's does
+    (the reference derives per-PDU state on every call, pdsch_processor_concurrent_impl.cpp:55-207, and every slot brings a
+    new pdu_t, downlink_processor_single_executor_impl.cpp:98-142).  A pool of 64 config-3-sized PDUs: slot_index cycles
+    0-19, RNTI and scrambling identities are drawn, the allocation starts at PRB 0-3 and has 262-270 PRB (64 different
+    shapes), the MCS is 256-QAM at a rate drawn from 700-948 / 1024 -- transport blocks of 640-870 kbit, 4 layers on the
+    100 MHz grid.  A second pool is ONE shape with everything else drawn (what a cell at full load repeats)."""
+    import ctypes as C
+    import backends
+    import cases
+    abi, lib = backends.abi, backends.pkg.lib
+    ctx = lib.Context(0)
+    h = ctx.lib
+    done_fn = C.cast(h.nrphy_pdsch_async_count_done, C.c_void_p)
+    rng = np.random.default_rng(7)
+    w = cases.codebook("four_layer_four_ports_0_0")
+    ports, subc = 4, 273 * 12
+
+    def pool(vary_shape):
+        out = []
+        for i in range(64):
+            n_prb = int(rng.integers(262, 271)) if vary_shape else 270
+            start = int(rng.integers(0, 273 - n_prb + 1)) if vary_shape else 0
+            rate = float(rng.uniform(700, 948))
+            tb_bits = cases.tbs(12, 36, 8, rate, 4, n_prb)
+            pdu = abi.make_pdu(slot_index=i % 20, rnti=int(rng.integers(1, 65520)), n_id=int(rng.integers(0, 1024)),
+                               scrambling_id=int(rng.integers(0, 65536)), bwp_start_rb=0, bwp_size_rb=273, qm=8,
+                               dmrs_symbols=(2, 7, 11), nof_cdm_groups_without_data=2, prb_start=start, prb_count=n_prb,
+                               start_symbol=0, nof_symbols=12, base_graph=1, precoding=w, tb_size_bytes=tb_bits // 8)
+            out.append((pdu, cases.random_tb(rng, pdu)))
+        return out
+
+    for label, vary in (("64 shapes", True), ("one shape", False)):
+        items = pool(vary)
+        max_tb = max(p.tb_size_bytes for p, _ in items)
+        # parity of the live path first: a few PDUs of the pool through the queue against the blocking call
+        q = lib.PdschAsyncQueue(ctx, 4, ports, subc, max_tb)
+        got = {}
+        for k in range(8):
+            while not q.submit(items[k][0], items[k][1], (lambda st, g, k=k: got.__setitem__(k, (st, g)))):
+                q.wait_slot()
+        q.wait()
+        for k in range(8):
+            want = ctx.pdsch_process_host(items[k][0], items[k][1], ports, subc)
+            assert got[k][0] == 0 and np.array_equal(got[k][1], want), "async grid differs from the blocking call (PDU %d)" % k
+        q.close()
+        for depth, nthreads in ((1, 1), (4, 1), (8, 1), (8, 2), (8, 4)):
+            qh = C.c_void_p()
+            assert h.nrphy_pdsch_async_create(ctx.handle, depth, ports, subc, max_tb, C.byref(qh)) == 0
+            count = C.c_uint64(0)
+            refs = [(C.byref(p), tb.ctypes.data) for p, tb in items]
+
+            def worker(first, n_submit):
+                k = first
+                for _ in range(n_submit):
+                    pr, tbp = refs[k % 64]
+                    k += 1
+                    while True:
+                        rc = h.nrphy_pdsch_async_submit(qh, pr, tbp, done_fn, C.byref(count))
+                        if rc == 0:
+                            break
+                        if rc != 4:
+                            raise RuntimeError(rc)
+                        h.nrphy_pdsch_async_wait_slot(qh)
+
+            def pump(n_submit):
+                import threading
+                ts = [threading.Thread(target=worker, args=(17 * t, n_submit // nthreads)) for t in range(nthreads)]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+                h.nrphy_pdsch_async_wait(qh)
+
+            pump(128)
+            count.value = 0
+            total = 1600
+            t0 = time.perf_counter()
+            pump(total)
+            dt = time.perf_counter() - t0
+            assert count.value == total, (count.value, total)
+            print("live traffic (%s, every submit a different PDU), %d in flight, %d submitting thread(s): %.0f PDUs/s (%.3f ms per PDU)"
+                  % (label, depth, nthreads, total / dt, 1e3 * dt / total), flush=True)
+            h.nrphy_pdsch_async_destroy(qh)
+
+
 if __name__ == "__main__":
-    main()
+    if "--live" in sys.argv:
+        live_traffic()
+    else:
+        main()
+        live_traffic()

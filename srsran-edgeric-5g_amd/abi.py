@@ -389,6 +389,7 @@ def declare(lib, prefix="nrphy_"):
     sig("pdsch_async_create", i32, vp, u32, u32, u32, u32, P(vp))
     sig("pdsch_async_submit", i32, vp, P(PdschPdu), u8p, vp, vp)
     sig("pdsch_async_wait", i32, vp)
+    sig("pdsch_async_wait_slot", i32, vp)
     sig("pdsch_async_destroy", i32, vp)
     sig("pdsch_encode_host", i32, vp, P(PdschEncoderCfg), u8p, u8p, u8p)
     sig("ldpc_encode", i32, vp, u32, u32, u32, u8p, u32, u32, u8p, u32, vp)
@@ -461,7 +462,8 @@ ABI_SYMBOLS = [
     "nrphy_llr_descramble", "nrphy_llr_descramble_host", "nrphy_demodulate_soft", "nrphy_demodulate_soft_host", "nrphy_pdsch_process_slot_host", "nrphy_pdsch_async_submit_slot",
     "nrphy_pdcch_validate", "nrphy_pdcch_process", "nrphy_pdcch_process_host", "nrphy_pdcch_encode_host",
     "nrphy_ssb_validate", "nrphy_ssb_process", "nrphy_ssb_process_host", "nrphy_pbch_encode_host",
-    "nrphy_pdsch_async_create", "nrphy_pdsch_async_submit", "nrphy_pdsch_async_wait", "nrphy_pdsch_async_destroy",
+    "nrphy_pdsch_async_create", "nrphy_pdsch_async_submit", "nrphy_pdsch_async_wait", "nrphy_pdsch_async_wait_slot",
+    "nrphy_pdsch_async_destroy",
     "nrphy_pdsch_async_count_done",
     "nrphy_amplitude_control", "nrphy_amplitude_metrics", "nrphy_amplitude_control_host", "nrphy_iq_convert_ci16",
     "nrphy_iq_convert_ci16_host", "nrphy_ofdm_run_ci16", "nrphy_ofh_compressed_prb_bytes", "nrphy_ofh_compress",

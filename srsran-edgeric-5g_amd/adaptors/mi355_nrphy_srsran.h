@@ -366,7 +366,7 @@ class pdsch_processor_adaptor : public srsran::pdsch_processor
 {
 public:
   pdsch_processor_adaptor(std::shared_ptr<context> ctx_, unsigned nof_ports_, unsigned nof_subc_, unsigned depth = 4) :
-    ctx(std::move(ctx_)), nof_ports(nof_ports_), nof_subc(nof_subc_), ops(depth)
+    ctx(std::move(ctx_)), nof_ports(nof_ports_), nof_subc(nof_subc_), ops(2 * depth)
   {
     int rc = nrphy_pdsch_async_create(ctx->get(), depth, nof_ports, nof_subc, 1277992 / 8 + 8, &queue);
     report_failure("nrphy_pdsch_async_create", rc);
@@ -411,7 +411,10 @@ public:
           return;
         }
       }
-      nrphy_pdsch_async_wait(queue); // every slot in flight: wait for them, then retry
+      // `depth` operations in flight: wait until ONE has completed (not for all of them), then retry.  There are
+      // twice as many operation records as queue slots, because a record is released by the completion handler a moment
+      // before the queue marks its slot free: a record is then always at hand and the wait below is for the queue alone.
+      nrphy_pdsch_async_wait_slot(queue);
     }
   }
 

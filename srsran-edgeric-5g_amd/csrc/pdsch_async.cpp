@@ -3,9 +3,12 @@
 // pdsch_processor::process may return before the PDU is done and signal completion from any thread
 // (R/include/srsran/phy/upper/channel_processors/pdsch_processor.h:157-170; the reference's own asynchronous pool:
 // R/lib/phy/upper/channel_processors/pdsch_processor_asynchronous_pool.h:39-143).  A queue owns `depth` operation
-// slots, each with a stream, device buffers, pinned host staging and the plans of the PDU shapes it has seen; a submit
-// copies the transport block, enqueues H2D + the PDSCH kernels + D2H of the grid + a host function on the slot's
-// stream and returns; the host function hands the grid to the caller's completion handler on a runtime thread.
+// slots, each with a stream, device buffers and pinned host staging; a submit builds the PDU's plan INTO the slot's
+// staging (nrphy_pdsch_plan_create_placed: no allocation, no blocking copy -- the reference derives its per-PDU state on
+// every call too, pdsch_processor_concurrent_impl.cpp:55-207, and every slot of live traffic brings a new pdu_t), copies
+// the transport block behind it, enqueues ONE H2D copy of both + the PDSCH kernels + D2H of the grid + a completion
+// callback on the slot's stream and returns; the callback hands the grid to the caller's handler on a runtime thread.
+// What depends only on the SHAPE of the PDUs (RE mapping tables, zero-fill run lists) is kept per slot across submits.
 #include "nrphy_host_internal.h"
 
 #include <atomic>
@@ -25,19 +28,19 @@ struct AsyncSlot {
   int                 status  = NRPHY_OK;
   nrphy_pdsch_done_fn done    = nullptr;
   void*               user    = nullptr;
-  // plans of the PDU shapes this slot has run, most recent first (a plan must not run on two streams at once, so
-  // every slot keeps its own)
-  std::vector<std::pair<std::vector<uint8_t>, nrphy_pdsch_plan_t*>> plans;
+  // The staging buffers carry the transport block(s) and, behind them (256-byte aligned), the plan's tables: one copy
+  // moves both.  d_scratch: what every run rewrites (sequences, TB-CRC shares).
+  uint32_t*           d_scratch = nullptr;
+  nrphy_pdsch_plan_t* plan    = nullptr;  // the plan of the operation in flight (or of the last one), tables in the staging
+  PlanShapeCache*     shapes  = nullptr;  // RE mapping tables and zero-fill lists by PDU shape, kept across submits
 };
-
-constexpr size_t PLANS_PER_SLOT = 32;
 
 } // namespace
 
 struct nrphy_pdsch_async {
   nrphy_ctx*              ctx = nullptr;
   uint32_t                nof_ports = 0, nof_subc = 0, max_tb_bytes = 0;
-  size_t                  grid_bytes = 0;
+  size_t                  grid_bytes = 0, table_cap = 0, scratch_words = 0;
   std::vector<AsyncSlot>  slots;
   std::mutex              mutex;
   std::condition_variable idle;
@@ -47,23 +50,15 @@ struct nrphy_pdsch_async {
 
 namespace {
 
-void signature_of(const nrphy_pdsch_pdu_t& pdu, std::vector<uint8_t>& sig)
-{
-  nrphy_pdsch_pdu_t copy = pdu;
-  copy.precoding         = nullptr;
-  sig.insert(sig.end(), reinterpret_cast<const uint8_t*>(&copy), reinterpret_cast<const uint8_t*>(&copy) + sizeof(copy));
-  const size_t nw = 2 * (size_t)pdu.nof_prg * pdu.nof_ports * pdu.nof_layers * sizeof(float);
-  if (pdu.precoding != nullptr && nw != 0 && nw <= 2 * NRPHY_MAX_RB * NRPHY_MAX_PORTS * NRPHY_MAX_LAYERS * sizeof(float)) {
-    const uint8_t* w = reinterpret_cast<const uint8_t*>(pdu.precoding);
-    sig.insert(sig.end(), w, w + nw);
-  }
-}
-
-// Runs on a thread of the HIP runtime when everything before it on the slot's stream is done.
-void on_stream_done(void* arg)
+// Runs on a thread of the HIP runtime when everything before it on the slot's stream is done; `error` is the stream's
+// status (a kernel fault or a failed copy surfaces here, and reaches the caller's handler as NRPHY_ERR_DEVICE).
+void on_stream_done(hipStream_t, hipError_t error, void* arg)
 {
   AsyncSlot*         slot = static_cast<AsyncSlot*>(arg);
   nrphy_pdsch_async* q    = slot->queue;
+  if (error != hipSuccess) {
+    slot->status = NRPHY_ERR_DEVICE;
+  }
   if (slot->done != nullptr) {
     slot->done(slot->user, slot->status, slot->h_grid);
   }
@@ -99,17 +94,28 @@ extern "C" int nrphy_pdsch_async_create(nrphy_ctx_t* ctx, uint32_t depth, uint32
     q->zero_copy = (uint32_t)std::atoi(e);
   }
   q->slots.resize(depth);
-  const size_t tb_alloc = ((size_t)max_tb_bytes + 7) & ~(size_t)3;
+  // Room for the tables of one operation (PDU descriptors, work lists, weights, RE tables, zero-fill lists: a few KB for a
+  // wideband PDU; non-contiguous allocations add two bytes per RE) and for what its run rewrites (one sequence word per
+  // 32 codeword bits -- at most 32 bits per RE -- plus DM-RS sequences).  An operation that needs more gets a plan with
+  // memory of its own (the slow path).
+  q->table_cap     = ((size_t)64 * 1024 + (size_t)NRPHY_NSYMB * grid_nof_subc * 6 + 255) & ~(size_t)255;
+  q->scratch_words = (size_t)NRPHY_NSYMB * grid_nof_subc * 2 + 16384;
+  if (const char* e = std::getenv("NRPHY_ASYNC_TABLE_CAP")) { // tests: a small value sends every operation down the slow path
+    q->table_cap = ((size_t)std::max(256, std::atoi(e)) + 255) & ~(size_t)255;
+  }
+  const size_t tb_alloc = q->table_cap + (((size_t)max_tb_bytes + 7 + 255) & ~(size_t)255);
   for (AsyncSlot& s : q->slots) {
     s.queue = q;
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&s.d_tb, tb_alloc) != hipSuccess || hipMalloc(&s.d_grid, q->grid_bytes) != hipSuccess ||
+        hipMalloc((void**)&s.d_scratch, q->scratch_words * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_tb, tb_alloc, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(&s.h_grid, q->grid_bytes, hipHostMallocDefault) != hipSuccess) {
       nrphy_pdsch_async_destroy(q);
       return NRPHY_ERR_DEVICE;
     }
     std::memset(s.h_tb, 0, tb_alloc);
+    s.shapes = plan_shape_cache_create();
   }
   *out = q;
   return NRPHY_OK;
@@ -125,6 +131,18 @@ extern "C" int nrphy_pdsch_async_wait(nrphy_pdsch_async_t* q)
   return NRPHY_OK;
 }
 
+// Blocks while all `depth` operations are in flight: what a caller does after NRPHY_ERR_CAPACITY instead of draining
+// the whole queue with nrphy_pdsch_async_wait.
+extern "C" int nrphy_pdsch_async_wait_slot(nrphy_pdsch_async_t* q)
+{
+  if (q == nullptr) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  std::unique_lock<std::mutex> lock(q->mutex);
+  q->idle.wait(lock, [q] { return q->in_flight < q->slots.size(); });
+  return NRPHY_OK;
+}
+
 extern "C" int nrphy_pdsch_async_destroy(nrphy_pdsch_async_t* q)
 {
   if (q == nullptr) {
@@ -136,9 +154,9 @@ extern "C" int nrphy_pdsch_async_destroy(nrphy_pdsch_async_t* q)
     if (s.stream) {
       (void)hipStreamSynchronize(s.stream);
     }
-    for (auto& kv : s.plans) {
-      nrphy_pdsch_plan_destroy(kv.second);
-    }
+    nrphy_pdsch_plan_destroy(s.plan);
+    plan_shape_cache_destroy(s.shapes);
+    (void)hipFree(s.d_scratch);
     (void)hipFree(s.d_tb);
     (void)hipFree(s.d_grid);
     (void)hipHostFree(s.h_tb);
@@ -159,6 +177,7 @@ static int submit_pdus(nrphy_pdsch_async_t* q, uint32_t n_pdu, const nrphy_pdsch
   if (q == nullptr || pdus == nullptr || tbs == nullptr || n_pdu == 0) {
     return NRPHY_ERR_ARGUMENT;
   }
+  // The transport blocks, back to back (each readable to the next multiple of 4); the plan's tables follow them.
   std::vector<uint64_t> tb_off(n_pdu);
   size_t                tb_total = 0;
   for (uint32_t i = 0; i != n_pdu; ++i) {
@@ -184,7 +203,7 @@ static int submit_pdus(nrphy_pdsch_async_t* q, uint32_t n_pdu, const nrphy_pdsch
     }
   }
   if (slot == nullptr) {
-    return NRPHY_ERR_CAPACITY; // `depth` operations in flight: the caller waits or retries
+    return NRPHY_ERR_CAPACITY; // `depth` operations in flight: the caller waits (nrphy_pdsch_async_wait_slot) or retries
   }
   auto give_back = [q, slot](int rc) {
     {
@@ -198,30 +217,32 @@ static int submit_pdus(nrphy_pdsch_async_t* q, uint32_t n_pdu, const nrphy_pdsch
   if (hipSetDevice(q->ctx->device) != hipSuccess) {
     return give_back(NRPHY_ERR_DEVICE);
   }
-  // The plan of this shape (every PDU's bytes and weights): the slot's own, created on first sight.
-  std::vector<uint8_t> sig;
-  for (uint32_t i = 0; i != n_pdu; ++i) {
-    signature_of(pdus[i], sig);
+  const bool tb_direct = (q->zero_copy & 1u) != 0, grid_direct = (q->zero_copy & 2u) != 0;
+  // The slot's previous operation is complete (the slot was free): its plan goes, this one's is built in its place --
+  // tables into the pinned staging, device pointers into the slot's device buffer, nothing allocated or copied here.
+  nrphy_pdsch_plan_destroy(slot->plan);
+  slot->plan = nullptr;
+  std::vector<uint32_t> grid_of(n_pdu, 0);
+  PlanPlacement         place;
+  const size_t tables_at       = (tb_total + 255) & ~(size_t)255;
+  place.h_tables               = slot->h_tb + tables_at;
+  place.d_tables               = slot->d_tb + tables_at;
+  place.table_capacity         = q->table_cap;
+  place.d_scratch              = slot->d_scratch;
+  place.scratch_capacity_words = q->scratch_words;
+  place.cache                  = slot->shapes;
+  // (the transport-block offsets the plan records are relative to the pointer nrphy_pdsch_run gets: the staging's start)
+  int rc = nrphy_pdsch_plan_create_placed(q->ctx, n_pdu, pdus, tb_off.data(), grid_of.data(), 1, q->nof_ports, q->nof_subc, &place,
+                                          &slot->plan);
+  bool own_memory = false;
+  if (rc == NRPHY_ERR_CAPACITY) {
+    // Too big for the slot's table space: a plan with device memory of its own (allocation + blocking copy; freed when the
+    // slot is used again).  Rare: hundreds of PDUs or RE tables for most of a fragmented grid.
+    rc        = nrphy_pdsch_plan_create(q->ctx, n_pdu, pdus, tb_off.data(), grid_of.data(), 1, q->nof_ports, q->nof_subc, &slot->plan);
+    own_memory = true;
   }
-  nrphy_pdsch_plan_t* plan = nullptr;
-  for (size_t i = 0; i != slot->plans.size(); ++i) {
-    if (slot->plans[i].first == sig) {
-      plan = slot->plans[i].second;
-      std::rotate(slot->plans.begin(), slot->plans.begin() + i, slot->plans.begin() + i + 1); // most recent first
-      break;
-    }
-  }
-  if (plan == nullptr) {
-    std::vector<uint32_t> grid_of(n_pdu, 0);
-    const int rc = nrphy_pdsch_plan_create(q->ctx, n_pdu, pdus, tb_off.data(), grid_of.data(), 1, q->nof_ports, q->nof_subc, &plan);
-    if (rc != NRPHY_OK) {
-      return give_back(rc);
-    }
-    if (slot->plans.size() == PLANS_PER_SLOT) {
-      nrphy_pdsch_plan_destroy(slot->plans.back().second);
-      slot->plans.pop_back();
-    }
-    slot->plans.insert(slot->plans.begin(), std::make_pair(std::move(sig), plan));
+  if (rc != NRPHY_OK) {
+    return give_back(rc);
   }
   for (uint32_t i = 0; i != n_pdu; ++i) {
     const size_t span = (i + 1 != n_pdu ? tb_off[i + 1] : tb_total) - tb_off[i];
@@ -231,18 +252,23 @@ static int submit_pdus(nrphy_pdsch_async_t* q, uint32_t n_pdu, const nrphy_pdsch
   slot->done   = done;
   slot->user   = user;
   slot->status = NRPHY_OK;
-  const bool tb_direct = (q->zero_copy & 1u) != 0, grid_direct = (q->zero_copy & 2u) != 0;
-  if (!tb_direct && hipMemcpyAsync(slot->d_tb, slot->h_tb, tb_total, hipMemcpyHostToDevice, slot->stream) != hipSuccess) {
+  // ONE copy carries the tables and the transport blocks (zero-copy transport blocks: the tables alone -- every wave reads
+  // them, they belong in device memory).
+  const size_t copy_from = tb_direct ? tables_at : 0;
+  const size_t copy_to   = own_memory ? tb_total : tables_at + place.table_bytes;
+  if (copy_to > copy_from &&
+      hipMemcpyAsync(slot->d_tb + copy_from, slot->h_tb + copy_from, copy_to - copy_from, hipMemcpyHostToDevice, slot->stream) !=
+          hipSuccess) {
     return give_back(NRPHY_ERR_DEVICE);
   }
-  const int rc = nrphy_pdsch_run(plan, tb_direct ? slot->h_tb : slot->d_tb, grid_direct ? slot->h_grid : slot->d_grid, nullptr,
-                                 nullptr, 1, slot->stream);
+  rc = nrphy_pdsch_run(slot->plan, tb_direct ? slot->h_tb : slot->d_tb, grid_direct ? slot->h_grid : slot->d_grid, nullptr,
+                       nullptr, 1, slot->stream);
   if (rc != NRPHY_OK) {
     (void)hipStreamSynchronize(slot->stream);
     return give_back(rc);
   }
   if ((!grid_direct && hipMemcpyAsync(slot->h_grid, slot->d_grid, q->grid_bytes, hipMemcpyDeviceToHost, slot->stream) != hipSuccess) ||
-      hipLaunchHostFunc(slot->stream, on_stream_done, slot) != hipSuccess) {
+      hipStreamAddCallback(slot->stream, on_stream_done, slot, 0) != hipSuccess) {
     (void)hipStreamSynchronize(slot->stream);
     return give_back(NRPHY_ERR_DEVICE);
   }

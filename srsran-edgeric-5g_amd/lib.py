@@ -474,6 +474,10 @@ class PdschAsyncQueue:
         _check(self.ctx.lib.nrphy_pdsch_async_wait(self.handle), "nrphy_pdsch_async_wait")
         self._keep.clear()
 
+    def wait_slot(self):
+        """Blocks while all `depth` operations are in flight."""
+        _check(self.ctx.lib.nrphy_pdsch_async_wait_slot(self.handle), "nrphy_pdsch_async_wait_slot")
+
     def close(self):
         if self.handle:
             self.ctx.lib.nrphy_pdsch_async_destroy(self.handle)

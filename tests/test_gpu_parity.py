@@ -609,6 +609,56 @@ def test_pdsch_async_queue_keeps_pdus_in_flight(gpu_ctx, oracle, zero_copy, monk
     q.close()
 
 
+@pytest.mark.parametrize("table_cap", [None, "512"])
+def test_pdsch_async_live_traffic_every_pdu_differs(gpu_ctx, oracle, table_cap, monkeypatch):
+    """The asynchronous seam on live traffic: no two consecutive submits carry the same PDU (slot index, RNTI, identities,
+    allocation, MCS, reserved patterns, weights all drawn), as in a gNB, where the reference derives its per-PDU state on
+    every call (pdsch_processor_concurrent_impl.cpp:55-207).  Every operation builds its plan into the slot's staging (no
+    allocation or blocking copy on the submit path); shapes that come back -- the same allocation with another RNTI and
+    transport block -- take their RE tables and zero-fill lists from the slot's shape cache.  With a table space too small
+    for any plan (NRPHY_ASYNC_TABLE_CAP) every operation takes the slow path with memory of its own.  Grids bit-exact."""
+    import threading
+    monkeypatch.delenv("NRPHY_ASYNC_ZERO_COPY", raising=False)
+    if table_cap is None:
+        monkeypatch.delenv("NRPHY_ASYNC_TABLE_CAP", raising=False)
+    else:
+        monkeypatch.setenv("NRPHY_ASYNC_TABLE_CAP", table_cap)
+    rng = np.random.default_rng(31337)
+    drawn = cases.random_pdus(oracle.tbs, rng, 20)
+    nof_ports, nof_subc = 4, max(p[2] for p in drawn)
+    jobs = []
+    for pdu, _, _ in drawn:
+        jobs.append((pdu, cases.random_tb(rng, pdu)))
+    for k, (pdu, _, _) in enumerate(drawn[:12]):
+        # the same shape again under another identity: allocation, symbols, DM-RS and reserved patterns, layers and ports kept
+        twin = abi.PdschPdu.from_buffer_copy(pdu)
+        twin._keepalive = getattr(pdu, "_keepalive", None)
+        twin.rnti = int(rng.integers(1, 65520))
+        twin.n_id = int(rng.integers(0, 1024))
+        twin.slot_index = (pdu.slot_index + 1 + k) % 20
+        twin.scrambling_id = int(rng.integers(0, 65536))
+        jobs.append((twin, cases.random_tb(rng, twin)))
+    q = lib.PdschAsyncQueue(gpu_ctx, 3, nof_ports, nof_subc, max(j[0].tb_size_bytes for j in jobs))
+    results, lock = {}, threading.Lock()
+    order = list(rng.permutation(len(jobs))) + list(rng.permutation(len(jobs)))
+    for n, i in enumerate(order):
+        def on_done(status, grid, n=n):
+            with lock:
+                results.setdefault(n, []).append((status, grid))
+        while not q.submit(jobs[i][0], jobs[i][1], on_done):
+            q.wait_slot()
+    q.wait()
+    assert sorted(results) == list(range(len(order))) and all(len(v) == 1 for v in results.values())
+    want = {}
+    for n, i in enumerate(order):
+        status, grid = results[n][0]
+        assert status == 0
+        if i not in want:
+            want[i] = oracle.pdsch_process(jobs[i][0], jobs[i][1], nof_ports, nof_subc)
+        assert np.array_equal(grid, want[i]), (n, i)
+    q.close()
+
+
 def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
     """The host-span entry points the srsRAN adaptors call (dft_processor::run, ofdm_slot_modulator::modulate)."""
     rng = np.random.default_rng(77)
