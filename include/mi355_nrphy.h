@@ -144,6 +144,12 @@ typedef struct nrphy_ofdm_plan nrphy_ofdm_plan_t;
 /* ---- library ------------------------------------------------------------------------------- */
 const char* nrphy_version(void);
 const char* nrphy_strerror(int status);
+/* Trace ranges: the entry points bracket their work in rocTX ranges named like the reference's trace points -- "process_pdsch"
+ * (R/lib/phy/upper/downlink_processor_single_executor_impl.cpp:116-125), "CB batch", "process_dmrs"
+ * (R/lib/phy/upper/channel_processors/pdsch_processor_concurrent_impl.cpp:265,317,342,367), "process_pdcch", "process_ssb",
+ * "process_nzp_csi_rs", "process_pusch", "cb_decode", "downlink_baseband" -- when the process has the rocTX library loaded
+ * (a profiler: rocprofv3 --marker-trace) or NRPHY_TRACE=1 is set; NRPHY_TRACE=0 switches them off.  1 = ranges are live. */
+int nrphy_trace_enabled(void);
 
 /* Creates the device context (streams, constant tables).  Replaces the factory chain
  * create_downlink_processor_factory_sw / _hw (R/lib/phy/upper/upper_phy_factories.cpp:659-919).

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the PMC passes of profiles/pmc.sh (default bench command, 1024 config-3 slots per launch):
+per kernel the HBM bytes per launch (FETCH_SIZE, WRITE_SIZE: KiB units; FETCH_SIZE doubled, as MI355X_MICROARCH.md section
+HBM prescribes for gfx950) and the vector instructions per launch (SQ_INSTS_VALU), keyed as bench.py names its kernels.
+Usage: python3 profiles/make_traffic_json.py <pmc_out_dir> <source label> [rx_pmc_summary.txt] > profiles/traffic.json"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root, label = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+    per_dispatch, names = defaultdict(float), {}
+    for row in csv.DictReader(open(path)):
+        per_dispatch[(row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
+        names[row["Dispatch_Id"]] = row["Kernel_Name"]
+    for (disp, counter), v in per_dispatch.items():
+        acc[names[disp].split("(")[0].replace("void ", "")][counter].append(v)
+
+
+def key_of(kernel):
+    if "codeblock_kernel" in kernel:
+        return "codeblock_kernel"
+    if "prologue_kernel" in kernel:
+        return "prologue_kernel"
+    if "ofdm_kernel<4096" in kernel:
+        return "ofdm_kernel<4096>"
+    return None
+
+
+out = {"slots": 1024, "source": label, "hbm_bytes_per_launch": {}, "hbm_read_bytes_per_launch": {},
+       "hbm_write_bytes_per_launch": {}, "valu_insts_per_launch": {}, "salu_insts_per_launch": {},
+       # kernels whose launch time follows their vector instruction count, not their bytes
+       "valu_bound": ["codeblock_kernel"], "kernel_names": {}}
+for kernel, counters in acc.items():
+    k = key_of(kernel)
+    if k is None:
+        continue
+    mean = {c: sum(v) / len(v) for c, v in counters.items()}
+    out["kernel_names"][k] = kernel
+    if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+        rd, wr = int(mean["FETCH_SIZE"] * 1024 * 2), int(mean["WRITE_SIZE"] * 1024)
+        out["hbm_read_bytes_per_launch"][k], out["hbm_write_bytes_per_launch"][k] = rd, wr
+        out["hbm_bytes_per_launch"][k] = rd + wr
+    if "SQ_INSTS_VALU" in mean:
+        out["valu_insts_per_launch"][k] = int(mean["SQ_INSTS_VALU"])
+    if "SQ_INSTS_SALU" in mean:
+        out["salu_insts_per_launch"][k] = int(mean["SQ_INSTS_SALU"])
+# the receive chain's entries are kept from the previous file (they come from profiles/collect_rx.sh)
+try:
+    prev = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")))
+    for k in ("rx_valu_insts_per_codeblock_iteration", "rx_valu_insts_per_codeblock_fixed", "rx_hbm_bytes_per_launch", "rx_source"):
+        if k in prev:
+            out[k] = prev[k]
+except Exception:
+    pass
+print(json.dumps(out, indent=1))

@@ -446,7 +446,7 @@ def declare(lib, prefix="nrphy_"):
 
 # Symbols include/mi355_nrphy.h declares; tests check the shared library exports every one.
 ABI_SYMBOLS = [
-    "nrphy_version", "nrphy_strerror", "nrphy_create", "nrphy_destroy", "nrphy_synchronize",
+    "nrphy_version", "nrphy_strerror", "nrphy_trace_enabled", "nrphy_create", "nrphy_destroy", "nrphy_synchronize",
     "nrphy_pdsch_validate", "nrphy_pdsch_derive", "nrphy_tbs_calculate", "nrphy_ofdm_symbol_size",
     "nrphy_ofdm_slot_size", "nrphy_pdsch_plan_create", "nrphy_pdsch_plan_destroy",
     "nrphy_pdsch_plan_nof_codeblocks", "nrphy_pdsch_plan_codeword_bits", "nrphy_pdsch_plan_codeword_offset",

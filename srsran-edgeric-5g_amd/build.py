@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmi355nrphy.so")
 SOURCES = ["nrphy_host.cpp", "dl_control_host.cpp", "pdsch_async.cpp", "pdsch_kernels.hip", "ofdm_kernels.hip", "ldpc_decoder.hip",
            "ldpc_dematcher.hip", "pusch_decoder.hip", "csi_rs_kernels.hip", "dl_control_kernels.hip", "lower_phy_kernels.hip", "demod_kernels.hip"]
-HEADERS = ["nrphy_internal.h", "nrphy_host_internal.h", "bits_device.h", "ldpc_device.h", "nr_ldpc_bg.inc", "nr_polar_tables.inc",
+HEADERS = ["nrphy_internal.h", "nrphy_host_internal.h", "nrphy_trace.h", "bits_device.h", "ldpc_device.h", "nr_ldpc_bg.inc", "nr_polar_tables.inc",
            os.path.join(ROOT, "include", "mi355_nrphy.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # The PDSCH kernels define their arithmetic with explicit __fmul_rn/__fmaf_rn (bit-exact grid), so contraction is

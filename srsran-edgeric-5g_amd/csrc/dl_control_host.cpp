@@ -4,6 +4,7 @@
 // initialisations, amplitudes -- is derived here and handed to one wavefront per DCI / block
 // (dl_control_kernels.hip).  No channel bit or resource element is produced on the host.
 #include "nrphy_host_internal.h"
+#include "nrphy_trace.h"
 
 #include <cmath>
 
@@ -493,6 +494,7 @@ extern "C" int nrphy_pdcch_validate(const nrphy_pdcch_pdu_t* p)
 extern "C" int nrphy_pdcch_process(nrphy_ctx_t* ctx, uint32_t n, const nrphy_pdcch_pdu_t* pdus, const uint32_t* grid_index,
                                    void* d_grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc, void* stream)
 {
+  const TraceRange trace("process_pdcch");
   if (ctx == nullptr || (n != 0 && (pdus == nullptr || d_grid == nullptr)) || grid_nof_ports == 0 ||
       grid_nof_ports > NRPHY_MAX_PORTS || grid_nof_subc == 0) {
     return NRPHY_ERR_ARGUMENT;
@@ -640,6 +642,7 @@ extern "C" int nrphy_ssb_validate(const nrphy_ssb_pdu_t* p)
 extern "C" int nrphy_ssb_process(nrphy_ctx_t* ctx, uint32_t n, const nrphy_ssb_pdu_t* pdus, const uint32_t* grid_index,
                                  void* d_grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc, void* stream)
 {
+  const TraceRange trace("process_ssb");
   if (ctx == nullptr || (n != 0 && (pdus == nullptr || d_grid == nullptr)) || grid_nof_ports == 0 ||
       grid_nof_ports > NRPHY_MAX_PORTS || grid_nof_subc == 0) {
     return NRPHY_ERR_ARGUMENT;

@@ -13,6 +13,7 @@ namespace nrphy {
 
 constexpr int LDPC_MAX_WPB   = 12;                      // words per Zc-bit block, Zc <= 384
 constexpr int LDPC_LIN_WORDS = (68 * 384) / 32 + 2;     // whole BG1 codeblock + read-ahead padding
+constexpr int LDPC_DBL_WORDS = 2 * 22 * LDPC_MAX_WPB;   // the systematic blocks, doubled
 
 // Word j of block `base` (bit offset of a Zc-bit block) rotated by s: output bit t of the word is block bit
 // (s + 32j + t) mod Zc; bits at or beyond Zc are zero.  Needs 0 <= s < Zc and 32j < Zc.
@@ -91,17 +92,71 @@ __device__ __forceinline__ uint32_t row_word(const uint32_t* gbuf, const uint32_
   return acc;
 }
 
+// Core rows of a word-aligned lifting size (Zc a multiple of 32: every large one) read the systematic blocks from a
+// DOUBLED copy -- block n as its Zc / 32 words twice in a row at dbl[2 (Zc / 32) n] -- so that a rotated word never wraps:
+// the edge descriptor is (byte offset of word q' of the doubled block) << 16 | s', and word j of the rotated block is
+// alignbit(dbl[q' + j], dbl[q' + j + 1], s')  with  s' = (32 - shift % 32) % 32, q' = shift / 32, one less (mod Zc / 32) when
+// shift % 32 = 0 -- one address addition, one two-word LDS read and one funnel shift per edge instead of two wrapped
+// indices, two reads and two shifts (the lifted graph carries these descriptors for its four core rows, see
+// build_lifted_graph).  The reference's AVX2 encoder rotates through a doubled buffer too (ldpc_encoder_avx2.cpp:206-256).
+__device__ __forceinline__ uint32_t core_row_word_dbl(const uint32_t* gbuf, const uint32_t* dbl, uint32_t m, uint32_t j)
+{
+  uint32_t       acc = 0;
+  const uint8_t* at  = reinterpret_cast<const uint8_t*>(dbl) + 4u * j;
+  uint32_t       e = gbuf[m], end = gbuf[m + 1];
+  // Four edges per trip: their descriptors, then their block words, are requested together -- one LDS round trip each per
+  // four edges instead of two per edge (a core row has 15 ... 19 systematic edges).
+  for (; e + 4u <= end; e += 4u) {
+    uint32_t        edge[4];
+    u32x2_unaligned w[4];
+#pragma unroll
+    for (int k = 0; k != 4; ++k) {
+      edge[k] = gbuf[LDPC_GRAPH_ROWPTR + e + k];
+    }
+#pragma unroll
+    for (int k = 0; k != 4; ++k) {
+      w[k] = *reinterpret_cast<const u32x2_unaligned*>(at + (edge[k] >> 16));
+    }
+#pragma unroll
+    for (int k = 0; k != 4; ++k) {
+      acc ^= __builtin_amdgcn_alignbit(w[k].x, w[k].y, edge[k]);
+    }
+  }
+  for (; e != end; ++e) {
+    const uint32_t        edge = gbuf[LDPC_GRAPH_ROWPTR + e];
+    const u32x2_unaligned w    = *reinterpret_cast<const u32x2_unaligned*>(at + (edge >> 16));
+    acc ^= __builtin_amdgcn_alignbit(w.x, w.y, edge);
+  }
+  return acc;
+}
+
+// Fills the doubled copy of the Kb systematic blocks (word-aligned lifting sizes; lin holds them back to back).
+__device__ __forceinline__ void ldpc_double_blocks(const uint32_t* lin, uint32_t kb, uint32_t wpb, uint32_t* dbl, uint32_t lane)
+{
+  const uint32_t magic = (65536u + wpb - 1u) / wpb; // item / wpb = item * magic >> 16 for item < 22 * 12 + 64
+  for (uint32_t item = lane; item < kb * wpb; item += WAVE) {
+    const uint32_t n = (item * magic) >> 16;
+    const uint32_t v = lin[item];
+    dbl[item + n * wpb]       = v;
+    dbl[item + n * wpb + wpb] = v;
+  }
+}
+
 // Computes parity blocks Kb .. Kb + nof_rows - 1 of the codeblock whose Kb systematic blocks are in lin.
 // lin words from ceil(Kb*Zc/32) on must be zero on entry.  All 64 lanes of the wave call this.
 template <bool ALIGNED>
 __device__ inline void ldpc_encode_wave_impl(const LiftedGraph* g, const uint32_t* gbuf, uint32_t kb, uint32_t zc,
-                                             uint32_t nof_rows, uint32_t* lin, LdpcScratch* sc, uint32_t lane)
+                                             uint32_t nof_rows, uint32_t* lin, uint32_t* dbl, LdpcScratch* sc, uint32_t lane)
 {
   const uint32_t wpb = (zc + 31u) >> 5;
   // Core rows 0..3: XOR of the rotated systematic blocks (TS 38.212 Section 5.3.2, H restricted to columns < Kb).
+  if (ALIGNED) {
+    ldpc_double_blocks(lin, kb, wpb, dbl, lane);
+    wave_sync();
+  }
   for (uint32_t item = lane; item < 4u * wpb; item += WAVE) {
     uint32_t m = item / wpb, j = item - m * wpb;
-    sc->aux[m][j] = row_word<ALIGNED>(gbuf, lin, zc, m, j);
+    sc->aux[m][j] = ALIGNED ? core_row_word_dbl(gbuf, dbl, m, j) : row_word<ALIGNED>(gbuf, lin, zc, m, j);
   }
   wave_sync();
   if (lane < wpb) {
@@ -143,13 +198,14 @@ __device__ inline void ldpc_encode_wave_impl(const LiftedGraph* g, const uint32_
 }
 
 // gbuf: LDS, LDPC_GRAPH_ROWPTR + (edges of rows < nof_rows) words, already filled by stage_graph() and synchronised.
+// dbl: LDS, 2 * Kb * Zc / 32 words of scratch (used when Zc is a multiple of 32).
 __device__ inline void ldpc_encode_wave(const LiftedGraph* g, const uint32_t* gbuf, uint32_t kb, uint32_t zc,
-                                        uint32_t nof_rows, uint32_t* lin, LdpcScratch* sc, uint32_t lane)
+                                        uint32_t nof_rows, uint32_t* lin, uint32_t* dbl, LdpcScratch* sc, uint32_t lane)
 {
   if ((zc & 31u) == 0) { // wave-uniform
-    ldpc_encode_wave_impl<true>(g, gbuf, kb, zc, nof_rows, lin, sc, lane);
+    ldpc_encode_wave_impl<true>(g, gbuf, kb, zc, nof_rows, lin, dbl, sc, lane);
   } else {
-    ldpc_encode_wave_impl<false>(g, gbuf, kb, zc, nof_rows, lin, sc, lane);
+    ldpc_encode_wave_impl<false>(g, gbuf, kb, zc, nof_rows, lin, dbl, sc, lane);
   }
 }
 

@@ -4,6 +4,7 @@
 // the CPU before their loops), plan construction and kernel launches.  No compute happens here and there is no CPU
 // fallback: every entry point that produces PHY output needs a HIP device.
 #include "nrphy_host_internal.h"
+#include "nrphy_trace.h"
 
 #include <algorithm>
 #include <cmath>
@@ -113,6 +114,14 @@ void build_lifted_graph(unsigned bg, unsigned zc, LiftedGraph& g)
       } else if (col >= kb + 4) {
         continue; // the identity column of an extension row is its own parity block
       }
+      if (m < 4 && (zc & 31U) == 0) {
+        // Core rows of word-aligned lifting sizes read a doubled copy of the systematic blocks (ldpc_device.h,
+        // core_row_word_dbl): byte offset of word q' of the doubled block, and the funnel shift s'.
+        const unsigned wpb = zc / 32, sh = shift & 31U, q = shift >> 5;
+        const unsigned qd = (sh != 0) ? q : (q + wpb - 1) % wpb, sd = (32U - sh) & 31U;
+        g.edge[count++] = ((4U * (2U * wpb * col + qd)) << 16) | sd;
+        continue;
+      }
       g.edge[count++] = ((col * zc) << 16) | shift; // bit offset of the block in the codeblock (< 2^16), lifted shift
     }
   }
@@ -215,6 +224,20 @@ void build_gold_tables(GoldTables& t, std::vector<uint32_t>& x1_words)
       }
     }
     t.crc24b_table[b] = r & (top - 1);
+  }
+  // (b x^(8k) x^24) mod g for k = 0..3: table k is table k - 1 advanced by one byte.
+  for (uint32_t b = 0; b != 256; ++b) {
+    uint32_t r            = t.crc24b_table[b];
+    t.crc24b_slice[0][b] = r;
+    for (int k = 1; k != 4; ++k) {
+      for (int s = 0; s != 8; ++s) {
+        r <<= 1;
+        if (r & top) {
+          r ^= poly;
+        }
+      }
+      t.crc24b_slice[k][b] = r;
+    }
   }
   {
     auto mulx = [&](uint32_t a, unsigned e) { // a x^e mod g
@@ -360,7 +383,7 @@ struct nrphy_pdsch_plan {
   bool                  encode_only = false;   // seam B plan: no RE mapping, nrphy_pdsch_run only with d_grid = NULL
   bool                  dmrs_separate = false; // DM-RS must overwrite data RE: keep it in its own, later launch
   uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0, n_crc_work = 0;
-  uint32_t              lds_lin_words = 0, lds_symb_words = 0, lds_graph_words = 0;
+  uint32_t              lds_lin_words = 0, lds_symb_words = 0, lds_graph_words = 0, lds_u_words = 0;
   uint32_t              bucket_begin[CB_BUCKETS + 1] = {}; // work items sorted by (modulation order, layers)
   std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs
   uint32_t              timed_runs = 0, max_timed_runs = 0;
@@ -390,6 +413,11 @@ struct nrphy_ofdm_plan {
 extern "C" const char* nrphy_version(void)
 {
   return "mi355-nrphy 0.1 (gfx950)";
+}
+
+extern "C" int nrphy_trace_enabled(void)
+{
+  return trace_enabled() ? 1 : 0;
 }
 
 extern "C" const char* nrphy_strerror(int status)
@@ -1337,6 +1365,9 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
   }
   // The dynamic LDS of the codeblock launch also serves the DM-RS waves it may carry.
   plan->lds_lin_words = std::max<uint32_t>(plan->lds_lin_words, 64);
+  // The scratch region the stages of a codeblock wave share (pdsch_kernels.hip, CbShared): CRC tables, then doubled
+  // systematic blocks + graph rows, then modulation table + symbol bytes.
+  plan->lds_u_words = std::max<uint32_t>({256U * NRPHY_CRC_SLICES, NRPHY_CB_U_GRAPH_OFFSET + plan->lds_graph_words, 512U + plan->lds_symb_words});
   *out = plan;
   return NRPHY_OK;
 }
@@ -1380,6 +1411,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   if (plan == nullptr || d_tb == nullptr || (plan->encode_only && d_grid != nullptr)) {
     return NRPHY_ERR_ARGUMENT;
   }
+  const TraceRange trace_run("process_pdsch");
   nrphy_ctx*  ctx = plan->ctx;
   hipStream_t s   = stream ? (hipStream_t)stream : ctx->stream;
   PdschLaunch p;
@@ -1409,8 +1441,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.grid_nof_ports = plan->grid_nof_ports;
   p.grid_nof_subc  = plan->grid_nof_subc;
   p.lds_lin_words  = plan->lds_lin_words;
-  p.lds_symb_words = plan->lds_symb_words;
-  p.lds_graph_words = plan->lds_graph_words;
+  p.lds_u_words    = plan->lds_u_words;
   {
     // Profiling aid: stop the codeblock waves after a stage to time the stages apart (outputs are then incomplete).
     static const char* stage_env = std::getenv("NRPHY_PROFILE_STAGE");
@@ -1433,6 +1464,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     HIP_TRY(hipEventRecord(ev[1], s));
   }
   {
+    const TraceRange trace_cb("CB batch");
     // NRPHY_CB_DISPATCH: 1 = the one-launch mixed kernel, 2 = one launch per (Qm, layers) bucket, unset = by plan shape.
     const char* dispatch_env = std::getenv("NRPHY_CB_DISPATCH");
     HIP_TRY(launch_codeblocks(p, plan->bucket_begin, dispatch_env ? std::atoi(dispatch_env) : 0, d_tb, (uint32_t*)d_grid,
@@ -1443,6 +1475,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   }
   if (d_grid && !merge_dmrs) {
     // After the data: when data RE share a CDM group with DM-RS the reference lets DM-RS overwrite them.
+    const TraceRange trace_dmrs("process_dmrs");
     HIP_TRY(launch_dmrs(p, (uint32_t*)d_grid, s));
   }
   if (ev) {
@@ -2289,7 +2322,10 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
   if (sl.nof_slots < n_cb) {
     HIP_TRY(hipMemsetAsync(p.slot_flags, 0, sl.flags_bytes, s));
   }
-  HIP_TRY(launch_ldpc_decode(p, n_cb, s));
+  {
+    const TraceRange trace("cb_decode");
+    HIP_TRY(launch_ldpc_decode(p, n_cb, s));
+  }
   return NRPHY_OK;
 }
 
@@ -2539,6 +2575,7 @@ extern "C" int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_deco
                                         const int8_t* d_llr, uint64_t llr_stride_bytes, int8_t* d_soft, uint8_t* d_state,
                                         void* d_scratch, uint8_t* d_tb, uint32_t tb_stride_bytes, uint32_t* d_result, void* stream)
 {
+  const TraceRange trace("process_pusch");
   PuschLayout l;
   if (ctx == nullptr || cfg == nullptr || d_llr == nullptr || d_soft == nullptr || d_state == nullptr || d_tb == nullptr ||
       d_scratch == nullptr ||
@@ -2652,6 +2689,7 @@ extern "C" int nrphy_csi_rs_validate(const nrphy_csi_rs_cfg_t* c)
 extern "C" int nrphy_csi_rs_map(nrphy_ctx_t* ctx, uint32_t n, const nrphy_csi_rs_cfg_t* cfgs, const uint32_t* grid_index,
                                 void* d_grid, uint32_t grid_nof_ports, uint32_t grid_nof_subc, void* stream)
 {
+  const TraceRange trace("process_nzp_csi_rs");
   if (ctx == nullptr || (n != 0 && (cfgs == nullptr || d_grid == nullptr))) {
     return NRPHY_ERR_ARGUMENT;
   }
@@ -3012,6 +3050,7 @@ int ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid, co
 extern "C" int nrphy_ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid,
                               const uint32_t* slot_index, float* d_iq, void* stream)
 {
+  const TraceRange trace("downlink_baseband");
   return ofdm_run(plan, nof_grids, d_grid, slot_index, d_iq, nullptr, nullptr, stream);
 }
 
@@ -3021,6 +3060,7 @@ extern "C" int nrphy_ofdm_run_ci16(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, 
   if (cfg == nullptr) {
     return NRPHY_ERR_ARGUMENT;
   }
+  const TraceRange trace("downlink_baseband");
   return ofdm_run(plan, nof_grids, d_grid, slot_index, d_iq, cfg, d_stats, stream);
 }
 

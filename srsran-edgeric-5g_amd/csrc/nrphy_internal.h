@@ -45,6 +45,7 @@ struct GoldTables {
   uint32_t x2_head[32][32];
   uint32_t crc24b_pow32[CRC_POW_WORDS]; // x^(32 m) mod g_CRC24B(x): places a lane's partial CB-CRC
   uint32_t crc24b_table[256];           // byte table of CRC24B: (b x^24) mod g
+  uint32_t crc24b_slice[4][256];        // (b x^(8k) x^24) mod g, k = 0..3: a 32-bit word per CRC step (16-byte aligned)
   // crc24b_mul[m][n][v] = (v x^(4n)) x^(32 m) mod g: a lane's partial CB-CRC times x^(32 m), one look-up per nibble
   // of the partial instead of a 24-step shift-and-add multiplication.
   uint32_t crc24b_mul[CRC_POW_WORDS][6][16];
@@ -55,6 +56,14 @@ struct GoldTables {
 
 // ---- PDSCH plan ---------------------------------------------------------------------------------------------
 constexpr int RE_CHUNK = 512; // data RE handled by one wavefront
+// Codeblock CRC of the codeblock kernel: 4 = a 32-bit word per step through four byte tables (4 KB of LDS per wave),
+// 3 = 24 bits through three tables + one byte step (3 KB).
+#ifndef NRPHY_CRC_SLICES
+#define NRPHY_CRC_SLICES 3
+#endif
+// Scratch region of a codeblock wave during LDPC encoding: doubled systematic blocks (2 * 22 * 12 words), the core rows'
+// scratch (80 words), then the graph rows (pdsch_kernels.hip, CbShared).
+#define NRPHY_CB_U_GRAPH_OFFSET (2 * 22 * 12 + 80)
 
 enum SymKind : uint32_t { SYM_NONE = 0, SYM_CONTIGUOUS = 1, SYM_TABLE = 2 };
 
@@ -208,9 +217,8 @@ struct PdschLaunch {
   uint32_t           n_dmrs_work;
   uint32_t           grid_nof_ports;
   uint32_t           grid_nof_subc;
-  uint32_t           lds_lin_words;  // dynamic LDS carve of the codeblock kernel (words, multiples of 4)
-  uint32_t           lds_symb_words;
-  uint32_t           lds_graph_words;
+  uint32_t           lds_lin_words;  // dynamic LDS carve of the codeblock kernel (words, multiples of 4): the codeblock ...
+  uint32_t           lds_u_words;    // ... and the scratch region its stages share (pdsch_kernels.hip, CbShared)
   uint32_t           profile_stage; // 0 = run everything; n > 0 = codeblock waves stop after stage n (NRPHY_PROFILE_STAGE)
 };
 

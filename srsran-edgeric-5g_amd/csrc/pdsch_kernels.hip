@@ -158,23 +158,42 @@ hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, hipStream_
 // ================================================================================================================
 // Codeblock construction in LDS (TS 38.212 Section 5.2.2; reference: ldpc_segmenter_impl.cpp:148-217).
 // ================================================================================================================
-// LDS of one codeblock wavefront.  The bit arrays are sized per launch (dynamic LDS: the plan knows the largest
-// codeblock, scrambling run and symbol run it contains), which at the headline configuration keeps ~6 KB per wave
-// instead of ~10 KB and lets the CU hold 6 waves per SIMD.
-struct CbStatic {
-  LdpcScratch ldpc;
-  union {
-    uint32_t crc_table[256]; // CRC24B byte table while the codeblock is built ...
-    float2   qam[256];       // ... then the modulation table (index = Qm bits, value = ci8 symbol as floats)
-  } lut;
-};
+// LDS of one codeblock wavefront: `lin` (the codeblock, sized per launch from the largest one the plan contains) and one
+// scratch region `u` that the stages of the wave use one after the other:
+//   building the codeblock   u[0, 256 * NRPHY_CRC_SLICES)      byte tables of the codeblock CRC
+//   LDPC                     u[0, LDPC_DBL_WORDS)              the systematic blocks doubled (ldpc_device.h)
+//                            then LdpcScratch (core rows), then row pointers + edges of the lifted graph rows needed
+//   output stage             u[0, 512)                         the modulation table (index = Qm bits, value = ci8 symbol as floats)
+//                            u[512, ...)                       interleaver output: one byte per modulation symbol
+// At the headline configuration that is 1.3 + 3.2 KB of LDS per wave: 8 waves per SIMD fit the CU's 160 KB.  (Measured,
+// A/B on one box: four CRC tables -- a 32-bit word per step, but 4 KB of scratch and 7 waves -- 0.347 ms per 1024 slots,
+// three tables 0.328 ms.)
+constexpr uint32_t CB_U_QAM_WORDS     = 512;
+constexpr uint32_t CB_U_LDPC_WORDS    = (sizeof(LdpcScratch) / 4u + 3u) & ~3u;
+constexpr uint32_t CB_U_GRAPH_OFFSET  = LDPC_DBL_WORDS + CB_U_LDPC_WORDS;
+static_assert(CB_U_GRAPH_OFFSET == NRPHY_CB_U_GRAPH_OFFSET, "host and device agree on the layout of the scratch region");
 
 struct CbShared {
-  uint32_t* lin;  // codeblock bits, (Kb + rows) * Zc bits (+ read-ahead)
-  uint32_t* symb; // interleaver output: one byte per modulation symbol, Qm bits in the byte's MSBs
-  uint32_t* graph; // row pointers + edges of the lifted graph rows this codeblock needs
-  CbStatic* st;
+  uint32_t* lin;   // codeblock bits, (Kb + rows) * Zc bits (+ read-ahead)
+  uint32_t* u;     // the scratch region
+  uint32_t* symb;  // u + CB_U_QAM_WORDS
+  uint32_t* graph; // u + CB_U_GRAPH_OFFSET
+  LdpcScratch* ldpc; // u + LDPC_DBL_WORDS
 };
+
+// reg <- CRC24B register after the 32 bits of `word`: independent look-ups (tab[k][b] = (b x^(8k) x^24) mod g) instead of
+// four dependent byte steps.
+__device__ __forceinline__ uint32_t crc24_word_step(const uint32_t* tab, uint32_t reg, uint32_t word)
+{
+#if NRPHY_CRC_SLICES == 4
+  const uint32_t v = (reg << 8) ^ word;
+  return tab[v & 0xFFu] ^ tab[256u + ((v >> 8) & 0xFFu)] ^ tab[512u + ((v >> 16) & 0xFFu)] ^ tab[768u + (v >> 24)];
+#else
+  const uint32_t v = reg ^ (word >> 8); // 24 bits through three tables, then the last byte
+  uint32_t       r = tab[v & 0xFFu] ^ tab[256u + ((v >> 8) & 0xFFu)] ^ tab[512u + (v >> 16)];
+  return ((r << 8) & 0xFFFFFFu) ^ tab[((r >> 16) ^ word) & 0xFFu];
+#endif
+}
 
 // Fills lin with the K bits of codeblock `cb` (payload, TB CRC + zero padding on the last codeblock, CB CRC, filler
 // zeros) and zeroes the parity region up to `total_words`.
@@ -202,10 +221,12 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
     }
     sh->lin[j] = v;
   }
-  if (pd.cb_crc_bits) {
+  if (pd.cb_crc_bits) { // the CRC's byte tables, 16 bytes per lane and step
+    const uint4* src = reinterpret_cast<const uint4*>(&tables->crc24b_slice[0][0]);
+    uint4*       dst = reinterpret_cast<uint4*>(sh->u);
 #pragma unroll
-    for (int k = 0; k != 4; ++k) {
-      sh->st->lut.crc_table[lane + WAVE * k] = tables->crc24b_table[lane + WAVE * k];
+    for (int k = 0; k != NRPHY_CRC_SLICES; ++k) {
+      dst[lane + WAVE * k] = src[lane + WAVE * k];
     }
   }
   wave_sync();
@@ -240,7 +261,7 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
       } else {
         word = ext32(sh->lin, 32u * j - pad);
       }
-      reg = crc_update_word(reg, word, sh->st->lut.crc_table, crc24b());
+      reg = crc24_word_step(sh->u, reg, word);
     }
     // The lane's partial times x^(32 (nw - b)): six independent table look-ups (one per nibble).
     uint32_t part = 0;
@@ -330,10 +351,12 @@ __device__ __forceinline__ uint32_t rm_gather32(const RmIndex& r, const uint32_t
 
 // 8x8 bit-matrix transposition of the 64-bit word (hi:lo), rows = bytes (most significant first), columns = bits
 // (most significant first): three rounds of masked swaps (Hacker's Delight 7-3), on 32-bit halves.
-// Bits of a where m is set, bits of b elsewhere (one v_bfi_b32).
+// Bits of a where m is set, bits of b elsewhere: ONE v_bitop3_b32 (truth table 0xCA).  Written as (a & m) | (b & ~m) with
+// constant masks the compiler re-associated the shifts and masks of transpose8x8 into some sixty and / or / shift
+// instructions per transposition; this way it is two shifts and two of these per half and round.
 __device__ __forceinline__ uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b)
 {
-  return (a & m) | (b & ~m);
+  return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA);
 }
 
 __device__ __forceinline__ void transpose8x8(uint32_t& hi, uint32_t& lo)
@@ -487,7 +510,7 @@ __device__ __forceinline__ void phase_a(const PdschLaunch& p, PduRef pd, const C
   }
   // Modulation table (the CRC table it shares LDS with is no longer needed).
   for (uint32_t i = lane; i < (1u << QM); i += WAVE) {
-    sh.st->lut.qam[i] = p.gold->qam_lut[QM / 2 - 1][i];
+    reinterpret_cast<float2*>(sh.u)[i] = p.gold->qam_lut[QM / 2 - 1][i];
   }
   wave_sync();
 }
@@ -649,7 +672,7 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
     for (int l = 0; l != L; ++l) {
       const uint32_t raw   = ((bytes >> (24 - 8 * l)) & 0xFFu) >> (8 - QM);
       const uint32_t idx   = raw ^ ((gbits >> (32 - (l + 1) * QM)) & ((1u << QM) - 1u));
-      const float2   point = sh.st->lut.qam[idx];
+      const float2   point = reinterpret_cast<const float2*>(sh.u)[idx];
       x[l]                 = cf2{point.x, point.y};
     }
     if constexpr (P > 0) {
@@ -788,43 +811,57 @@ __device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, PduRef pd
 // The pilots of the wave's PRBs for one layer count: r(n) = a ((1 - 2 c(2n)) + j (1 - 2 c(2n + 1))) from the symbol's
 // sequence (generated by the prologue), CDM weights, precoding, mapping.  W: where the weights are read from
 // (constant address space = scalar loads for wideband precoding, global memory per lane otherwise).
+// The pilot of one port on the (L + 1) / 2 CDM groups: one cbf16 word per group.
 template <int L, typename W>
-__device__ __forceinline__ void dmrs_precode(float dr, float di, bool odd, uint32_t P, W w, uint32_t* out,
-                                             size_t port_stride, bool zero_other_group)
+__device__ __forceinline__ void dmrs_port_words(float dr, float di, bool odd, uint32_t port, W w, uint32_t (&word)[(L + 1) / 2])
 {
   // CDM (TS 38.211 Table 7.4.1.1.2-1): w_f = {+1, -1} on odd DM-RS ports flips every other pilot; w_t = +1 for
   // ports 1000-1003.
   const float sr = odd ? -dr : dr, si = odd ? -di : di;
-#pragma unroll 1
-  for (uint32_t port = 0; port != P; ++port) {
-    uint32_t word[(L + 1) / 2];
 #pragma unroll
-    for (int g = 0; g != (L + 1) / 2; ++g) {
-      float accr, acci;
-      cmul_ref(dr, di, w[2 * (port * L + 2 * g)], w[2 * (port * L + 2 * g) + 1], accr, acci);
-      if (2 * g + 1 < L) {
-        float pr, pi;
-        cmul_ref(sr, si, w[2 * (port * L + 2 * g + 1)], w[2 * (port * L + 2 * g + 1) + 1], pr, pi);
-        accr = __fadd_rn(accr, pr);
-        acci = __fadd_rn(acci, pi);
-      }
-      word[g] = pack_cbf16(accr, acci);
+  for (int g = 0; g != (L + 1) / 2; ++g) {
+    float accr, acci;
+    cmul_ref(dr, di, w[2 * (port * L + 2 * g)], w[2 * (port * L + 2 * g) + 1], accr, acci);
+    if (2 * g + 1 < L) {
+      float pr, pi;
+      cmul_ref(sr, si, w[2 * (port * L + 2 * g + 1)], w[2 * (port * L + 2 * g + 1) + 1], pr, pi);
+      accr = __fadd_rn(accr, pr);
+      acci = __fadd_rn(acci, pi);
     }
-    // Both CDM groups of a pilot position are neighbours in the grid (subcarriers 2k', 2k' + 1, 8-byte aligned): one
-    // 8-byte store per lane makes the wave's store contiguous instead of every other word.
-    if ((L + 1) / 2 == 2) {
-      *reinterpret_cast<uint2*>(out + port * port_stride) = make_uint2(word[0], word[(L + 1) / 2 - 1]);
-    } else if (zero_other_group) { // wave-uniform: the reserved, pilot-less neighbour RE is zero
-      *reinterpret_cast<uint2*>(out + port * port_stride) = make_uint2(word[0], 0u);
-    } else {
-      out[port * port_stride] = word[0];
-    }
+    word[g] = pack_cbf16(accr, acci);
   }
 }
 
+// Both CDM groups of a pilot position are neighbours in the grid (subcarriers 2k', 2k' + 1, 8-byte aligned): one
+// 8-byte store per lane makes the wave's store contiguous instead of every other word.
+template <int L>
+__device__ __forceinline__ void dmrs_store(uint32_t* out, const uint32_t (&word)[(L + 1) / 2], bool zero_other_group)
+{
+  if ((L + 1) / 2 == 2) {
+    *reinterpret_cast<uint2*>(out) = make_uint2(word[0], word[(L + 1) / 2 - 1]);
+  } else if (zero_other_group) { // wave-uniform: the reserved, pilot-less neighbour RE is zero
+    *reinterpret_cast<uint2*>(out) = make_uint2(word[0], 0u);
+  } else {
+    out[0] = word[0];
+  }
+}
+
+template <int L, typename W>
+__device__ __forceinline__ void dmrs_precode(float dr, float di, bool odd, uint32_t P, W w, uint32_t* out,
+                                             size_t port_stride, bool zero_other_group)
+{
+#pragma unroll 1
+  for (uint32_t port = 0; port != P; ++port) {
+    uint32_t word[(L + 1) / 2];
+    dmrs_port_words<L>(dr, di, odd, port, w, word);
+    dmrs_store<L>(out + port * port_stride, word, zero_other_group);
+  }
+}
+
+// tab: 64 words of LDS private to the wave.
 template <int L>
 __device__ __forceinline__ void dmrs_items(const PdschLaunch& p, PduRef pd, const DmrsWork& wk,
-                                           uint32_t* __restrict__ d_grid, uint32_t lane)
+                                           uint32_t* __restrict__ d_grid, uint32_t lane, uint32_t* tab)
 {
   const uint32_t  P       = pd.nof_ports;
   const uint32_t  ordinal = __popc(pd.dmrs_symbol_mask & ((1u << wk.symbol) - 1u));
@@ -833,6 +870,24 @@ __device__ __forceinline__ void dmrs_items(const PdschLaunch& p, PduRef pd, cons
   const uint32_t  nof_items = (wk.prb_end - wk.prb_begin) * 6u;
   const size_t    port_stride = (size_t)NRPHY_NSYMB * p.grid_nof_subc;
   uint32_t*       row = d_grid + (size_t)pd.grid_index * p.grid_nof_ports * port_stride + (size_t)wk.symbol * p.grid_nof_subc;
+  const bool      wideband = pd.nof_prg == 1;
+  const bool      zero_other = pd.dmrs_zero_other_group != 0;
+  if (wideband) { // wave-uniform
+    // With one set of weights a pilot position has eight possible values per port -- r(n) is one of four points and the CDM
+    // sign one of two: lane v < 8 computes variant v = c(2n) << 2 | c(2n + 1) << 1 | odd for every port, once per wave, and
+    // the items below only look theirs up (the arithmetic of a value is the same wherever it is evaluated).
+    if (lane < 8u) {
+      const float dr = (lane & 4u) ? -a : a, di = (lane & 2u) ? -a : a;
+#pragma unroll 1
+      for (uint32_t port = 0; port != P; ++port) {
+        uint32_t word[(L + 1) / 2];
+        dmrs_port_words<L>(dr, di, (lane & 1u) != 0, port, to_constant(p.weights + pd.dmrs_weights_offset), word);
+        tab[(lane * NRPHY_MAX_PORTS + port) * 2u]      = word[0];
+        tab[(lane * NRPHY_MAX_PORTS + port) * 2u + 1u] = word[(L + 1) / 2 - 1];
+      }
+    }
+    wave_sync();
+  }
   for (uint32_t item = lane; item < nof_items; item += WAVE) {
     const uint32_t prb = wk.prb_begin + item / 6u;
     const uint32_t kp  = item % 6u;
@@ -842,39 +897,47 @@ __device__ __forceinline__ void dmrs_items(const PdschLaunch& p, PduRef pd, cons
     // Pilot r(n) uses c(2n), c(2n+1); PRB prb holds n = 6 (prb - ref) .. +5: an even bit and its neighbour.
     const uint32_t bit  = 12u * (prb - pd.dmrs_ref_rb) + 2u * kp;
     const uint32_t word = seq[bit >> 5] << (bit & 31u);
-    const float    dr   = (word & 0x80000000u) ? -a : a;
-    const float    di   = (word & 0x40000000u) ? -a : a;
     uint32_t*      out  = row + 12u * prb + 2u * kp;
-    if (pd.nof_prg == 1) {
-      dmrs_precode<L>(dr, di, (kp & 1u) != 0, P, to_constant(p.weights + pd.dmrs_weights_offset), out, port_stride,
-                      pd.dmrs_zero_other_group != 0);
-    } else {
-      uint32_t prg = (12u * prb) / pd.prg_size_subc;
-      prg          = prg >= pd.nof_prg ? pd.nof_prg - 1 : prg;
-      dmrs_precode<L>(dr, di, (kp & 1u) != 0, P, p.weights + pd.dmrs_weights_offset + 2u * prg * P * L, out,
-                      port_stride, pd.dmrs_zero_other_group != 0);
+    if (wideband) {
+      const uint32_t variant = ((word >> 29) & 6u) | (kp & 1u);
+#pragma unroll 1
+      for (uint32_t port = 0; port != P; ++port) {
+        uint32_t words[(L + 1) / 2];
+        words[0] = tab[(variant * NRPHY_MAX_PORTS + port) * 2u];
+        if ((L + 1) / 2 == 2) {
+          words[(L + 1) / 2 - 1] = tab[(variant * NRPHY_MAX_PORTS + port) * 2u + 1u];
+        }
+        dmrs_store<L>(out + port * port_stride, words, zero_other);
+      }
+      continue;
     }
+    const float dr = (word & 0x80000000u) ? -a : a;
+    const float di = (word & 0x40000000u) ? -a : a;
+    uint32_t    prg = (12u * prb) / pd.prg_size_subc;
+    prg             = prg >= pd.nof_prg ? pd.nof_prg - 1 : prg;
+    dmrs_precode<L>(dr, di, (kp & 1u) != 0, P, p.weights + pd.dmrs_weights_offset + 2u * prg * P * L, out, port_stride,
+                    zero_other);
   }
 }
 
 __device__ __forceinline__ void dmrs_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid,
-                                          uint32_t lane)
+                                          uint32_t lane, uint32_t* tab)
 {
   const auto*    wkc = to_constant(&p.dmrs_work[item_index]);
   const DmrsWork wk  = {wkc->pdu, wkc->symbol, wkc->prb_begin, wkc->prb_end};
   PduRef         pd  = *to_constant(&p.pdus[wk.pdu]);
   switch (pd.nof_layers) { // wave-uniform
     case 1:
-      dmrs_items<1>(p, pd, wk, d_grid, lane);
+      dmrs_items<1>(p, pd, wk, d_grid, lane, tab);
       break;
     case 2:
-      dmrs_items<2>(p, pd, wk, d_grid, lane);
+      dmrs_items<2>(p, pd, wk, d_grid, lane, tab);
       break;
     case 3:
-      dmrs_items<3>(p, pd, wk, d_grid, lane);
+      dmrs_items<3>(p, pd, wk, d_grid, lane, tab);
       break;
     default:
-      dmrs_items<4>(p, pd, wk, d_grid, lane);
+      dmrs_items<4>(p, pd, wk, d_grid, lane, tab);
       break;
   }
 }
@@ -914,14 +977,14 @@ __device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_in
 // ================================================================================================================
 
 // The launch's extra waves (DM-RS, zero fill); true when this block was one of them.
-__device__ __forceinline__ bool extra_wave(const PdschLaunch& p, uint32_t* __restrict__ d_grid, uint32_t lane)
+__device__ __forceinline__ bool extra_wave(const PdschLaunch& p, uint32_t* __restrict__ d_grid, uint32_t lane, uint32_t* lds)
 {
   if (blockIdx.x < p.n_work) { // wave-uniform
     return false;
   }
   const uint32_t extra = blockIdx.x - p.n_work;
   if (extra < p.n_dmrs_in_launch) {
-    dmrs_wave(p, extra, d_grid, lane);
+    dmrs_wave(p, extra, d_grid, lane, lds);
   } else {
     zero_wave(p, extra - p.n_dmrs_in_launch, d_grid, lane);
   }
@@ -944,11 +1007,7 @@ __device__ __forceinline__ bool codeblock_front(const PdschLaunch& p, PduRef pd,
                                                 const uint8_t* __restrict__ d_tb, uint32_t lane)
 {
   const uint32_t zc = pd.zc, kb = pd.kb;
-  if (p.profile_stage == 5) {
-    return false;
-  }
-  stage_graph(&p.graphs[pd.graph], pd.nof_rows, sh.graph, lane);
-  if (p.profile_stage == 6) {
+  if (p.profile_stage == 5 || p.profile_stage == 6) {
     return false;
   }
   const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
@@ -957,7 +1016,10 @@ __device__ __forceinline__ bool codeblock_front(const PdschLaunch& p, PduRef pd,
   if (p.profile_stage == 1 || p.profile_stage == 7) {
     return false;
   }
-  ldpc_encode_wave(&p.graphs[pd.graph], sh.graph, kb, zc, pd.nof_rows, sh.lin, &sh.st->ldpc, lane);
+  // The graph rows go where the CRC tables were (build_codeblock ends with a wave barrier); ldpc_encode_wave synchronises
+  // before it reads them.
+  stage_graph(&p.graphs[pd.graph], pd.nof_rows, sh.graph, lane);
+  ldpc_encode_wave(&p.graphs[pd.graph], sh.graph, kb, zc, pd.nof_rows, sh.lin, sh.u, sh.ldpc, lane);
   return p.profile_stage != 2;
 }
 
@@ -967,14 +1029,14 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel_t(PdschLaunch p, con
                                                               uint32_t* __restrict__ d_cw_scr)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-  __shared__ CbStatic st;
-  CbShared            sh;
+  CbShared sh;
   sh.lin   = dyn_lds;
-  sh.symb  = dyn_lds + p.lds_lin_words;
-  sh.graph = sh.symb + p.lds_symb_words;
-  sh.st    = &st;
+  sh.u     = dyn_lds + p.lds_lin_words;
+  sh.symb  = sh.u + CB_U_QAM_WORDS;
+  sh.graph = sh.u + CB_U_GRAPH_OFFSET;
+  sh.ldpc  = reinterpret_cast<LdpcScratch*>(sh.u + LDPC_DBL_WORDS);
   const uint32_t lane = threadIdx.x;
-  if (p.profile_stage == 10 || extra_wave(p, d_grid, lane)) {
+  if (p.profile_stage == 10 || extra_wave(p, d_grid, lane, dyn_lds)) {
     return;
   }
   const auto*  wkc = to_constant(&p.work[xcd_work_item(p.n_work)]);
@@ -991,14 +1053,14 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const
                                                          uint32_t* __restrict__ d_cw_scr)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-  __shared__ CbStatic st;
-  CbShared            sh;
+  CbShared sh;
   sh.lin   = dyn_lds;
-  sh.symb  = dyn_lds + p.lds_lin_words;
-  sh.graph = sh.symb + p.lds_symb_words;
-  sh.st    = &st;
+  sh.u     = dyn_lds + p.lds_lin_words;
+  sh.symb  = sh.u + CB_U_QAM_WORDS;
+  sh.graph = sh.u + CB_U_GRAPH_OFFSET;
+  sh.ldpc  = reinterpret_cast<LdpcScratch*>(sh.u + LDPC_DBL_WORDS);
   const uint32_t lane = threadIdx.x;
-  if (p.profile_stage == 10 || extra_wave(p, d_grid, lane)) {
+  if (p.profile_stage == 10 || extra_wave(p, d_grid, lane, dyn_lds)) {
     return;
   }
   const auto*  wkc = to_constant(&p.work[xcd_work_item(p.n_work)]);
@@ -1043,7 +1105,7 @@ hipError_t launch_codeblocks(const PdschLaunch& p, const uint32_t* bucket_begin,
   if (p.n_work == 0) {
     return hipSuccess;
   }
-  const size_t   lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_symb_words + p.lds_graph_words);
+  const size_t   lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_u_words);
   const uint32_t extras    = d_grid ? p.n_dmrs_in_launch + p.n_zero_work : 0u;
   uint32_t       nof_buckets = 0, last_bucket = 0;
   for (uint32_t b = 0; b != CB_BUCKETS; ++b) {
@@ -1082,7 +1144,8 @@ hipError_t launch_codeblocks(const PdschLaunch& p, const uint32_t* bucket_begin,
 
 __global__ __launch_bounds__(WAVE) void dmrs_kernel(PdschLaunch p, uint32_t* __restrict__ d_grid)
 {
-  dmrs_wave(p, blockIdx.x, d_grid, threadIdx.x);
+  __shared__ uint32_t tab[8 * NRPHY_MAX_PORTS * 2];
+  dmrs_wave(p, blockIdx.x, d_grid, threadIdx.x, tab);
 }
 
 hipError_t launch_dmrs(const PdschLaunch& p, uint32_t* d_grid, hipStream_t stream)
@@ -1104,6 +1167,7 @@ __global__ __launch_bounds__(WAVE) void ldpc_encode_kernel(const LiftedGraph* gr
 {
   __shared__ uint32_t    lin[LDPC_LIN_WORDS];
   __shared__ uint32_t    gbuf[LDPC_GRAPH_ROWPTR + MAX_BG_EDGES];
+  __shared__ uint32_t    dbl[LDPC_DBL_WORDS];
   __shared__ LdpcScratch scratch;
   const uint32_t         lane = threadIdx.x;
   const uint8_t*         msg  = d_msg + (size_t)blockIdx.x * msg_stride;
@@ -1128,7 +1192,7 @@ __global__ __launch_bounds__(WAVE) void ldpc_encode_kernel(const LiftedGraph* gr
   }
   stage_graph(&graphs[graph], nof_rows, gbuf, lane);
   wave_sync();
-  ldpc_encode_wave(&graphs[graph], gbuf, kb, zc, nof_rows, lin, &scratch, lane);
+  ldpc_encode_wave(&graphs[graph], gbuf, kb, zc, nof_rows, lin, dbl, &scratch, lane);
   const uint32_t out_bytes = (out_bits + 7u) >> 3;
   for (uint32_t j = lane; 4u * j < out_bytes; j += WAVE) {
     uint32_t v   = ext32(lin, 2u * zc + 32u * j);

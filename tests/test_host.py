@@ -212,6 +212,18 @@ def test_bench_gpus_n_launches_its_own_ranks_dry_run():
     assert sum(lines[0]["per_rank"]["slots_per_step"]) == 24 and lines[0]["total_slots"] == 24
 
 
+def test_trace_ranges_follow_the_environment():
+    """rocTX ranges named like the reference's trace points ("process_pdsch", "CB batch", ...: nrphy_trace.h) are live when
+    NRPHY_TRACE=1 finds the rocTX library, off with NRPHY_TRACE=0 -- decided once per process, so each case is a child."""
+    import subprocess
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); lib.nrphy_trace_enabled.restype = ctypes.c_int; "
+            "print(lib.nrphy_trace_enabled())")
+    for value, want in (("1", "1"), ("0", "0")):
+        env = dict(os.environ, NRPHY_TRACE=value)
+        r = subprocess.run([sys.executable, "-c", code, backends.pkg.lib.LIB_PATH], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.strip() == want, (value, r.stdout, r.stderr[-500:])
+
+
 def test_bench_refuses_a_world_size_other_than_gpus():
     rc, lines, err = _bench_line(["--gpus", "2", "--dry-run"], {"RANK": "0", "WORLD_SIZE": "3", "LOCAL_RANK": "0"})
     assert rc == 2 and not lines and "WORLD_SIZE=3" in err
