@@ -19,11 +19,14 @@ __device__ __forceinline__ const NRPHY_CONSTANT T* to_constant(const T* p)
 }
 typedef const NRPHY_CONSTANT PduDev& PduRef;
 
-// Orders the LDS traffic of the lanes of ONE wavefront (the codeblock kernel runs one wave per workgroup, so a
-// workgroup barrier is a wave barrier; kept as a function to make the intent explicit).
+// Orders the LDS traffic among the lanes of ONE wavefront: what a wave that works on LDS of its own needs between a
+// phase that writes and a phase that reads.  The LDS executes the instructions of a wave in order, so waiting for the
+// wave's outstanding LDS operations (and keeping the compiler from moving memory accesses across) is enough; no s_barrier
+// -- the codeblock kernels pack several independent waves into a workgroup -- and no wait for global memory, which
+// __syncthreads() would add.
 __device__ __forceinline__ void wave_sync()
 {
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // n most significant bits set, n in [0, 32].
@@ -64,6 +67,16 @@ __device__ __forceinline__ void or_bits_lds(uint32_t* a, uint32_t pos, uint32_t 
       atomicOr(&a[w + 1], lo);
     }
   }
+}
+
+// The same by ONE lane while no other lane touches the words (plain read-modify-write: an LDS atomic issued by a single
+// lane goes through the compiler's wave-level atomic optimiser, some forty instructions of readlane loops).
+__device__ __forceinline__ void or_bits_lds_exclusive(uint32_t* a, uint32_t pos, uint32_t value, uint32_t nbits)
+{
+  value &= topmask(nbits);
+  const uint32_t w = pos >> 5, sh = pos & 31u;
+  a[w] |= value >> sh;
+  a[w + 1] |= (value << 1) << (31u - sh); // sh = 0: nothing (the array has a word of read-ahead)
 }
 
 // Same on global memory (codeword taps; the buffer is zeroed by the caller).
@@ -176,14 +189,17 @@ __device__ __forceinline__ uint32_t crc_update_word(uint32_t reg, uint32_t word,
   return reg;
 }
 
-// XOR reduction over the 64 lanes of a wave.
+// XOR reduction over the 64 lanes of a wave, all of which must be active; the result is wave-uniform.  Four DPP steps fold
+// every row of 16 lanes (pairs, quads, half rows, rows), four v_readlane + scalar XORs fold the rows: 8 vector
+// instructions.  (As six __shfl_xor steps it was six ds_bpermute round trips and 36 vector instructions.)
 __device__ __forceinline__ uint32_t wave_xor(uint32_t v)
 {
-#pragma unroll
-  for (int off = 32; off != 0; off >>= 1) {
-    v ^= __shfl_xor(v, off, WAVE);
-  }
-  return v;
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); // row_half_mirror
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); // row_mirror
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16) ^
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 // ---- Gold sequence (TS 38.211 Section 5.2.1) --------------------------------------------------------------

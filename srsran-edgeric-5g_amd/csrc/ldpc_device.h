@@ -135,10 +135,10 @@ __device__ __forceinline__ void ldpc_double_blocks(const uint32_t* lin, uint32_t
 {
   const uint32_t magic = (65536u + wpb - 1u) / wpb; // item / wpb = item * magic >> 16 for item < 22 * 12 + 64
   for (uint32_t item = lane; item < kb * wpb; item += WAVE) {
-    const uint32_t n = (item * magic) >> 16;
+    const uint32_t n = __umul24(item, magic) >> 16; // (24-bit multiplies: full rate, v_mul_lo_u32 is quarter rate)
     const uint32_t v = lin[item];
-    dbl[item + n * wpb]       = v;
-    dbl[item + n * wpb + wpb] = v;
+    dbl[item + __umul24(n, wpb)]       = v;
+    dbl[item + __umul24(n, wpb) + wpb] = v;
   }
 }
 
@@ -154,8 +154,9 @@ __device__ inline void ldpc_encode_wave_impl(const LiftedGraph* g, const uint32_
     ldpc_double_blocks(lin, kb, wpb, dbl, lane);
     wave_sync();
   }
+  const uint32_t wpb_magic = (65536u + wpb - 1u) / wpb; // item / wpb for item < 4 * 12 + 64 (wpb <= 12)
   for (uint32_t item = lane; item < 4u * wpb; item += WAVE) {
-    uint32_t m = item / wpb, j = item - m * wpb;
+    const uint32_t m = __umul24(item, wpb_magic) >> 16, j = item - __umul24(m, wpb);
     sc->aux[m][j] = ALIGNED ? core_row_word_dbl(gbuf, dbl, m, j) : row_word<ALIGNED>(gbuf, lin, zc, m, j);
   }
   wave_sync();

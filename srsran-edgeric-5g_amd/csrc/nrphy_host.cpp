@@ -385,6 +385,12 @@ struct nrphy_pdsch_plan {
   uint32_t              n_work = 0, n_dmrs = 0, n_cb = 0, n_crc_work = 0;
   uint32_t              lds_lin_words = 0, lds_symb_words = 0, lds_graph_words = 0, lds_u_words = 0;
   uint32_t              bucket_begin[CB_BUCKETS + 1] = {}; // work items sorted by (modulation order, layers)
+  // A batch with several big buckets runs their launches side by side on streams of the plan's own (created at the first
+  // such run), forked from and joined to the caller's stream with events.
+  static constexpr uint32_t MAX_AUX = 3;
+  hipStream_t           aux_stream[MAX_AUX] = {};
+  hipEvent_t            fork_event = nullptr, join_event[MAX_AUX] = {};
+  uint32_t              n_aux = 0;
   std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs
   uint32_t              timed_runs = 0, max_timed_runs = 0;
 };
@@ -1383,6 +1389,13 @@ extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
     (void)hipSetDevice(plan->ctx->device);
     (void)hipFree(plan->d_arena); // null for a plan whose creation failed half-way
   }
+  for (uint32_t k = 0; k != plan->n_aux; ++k) {
+    (void)hipStreamDestroy(plan->aux_stream[k]);
+    (void)hipEventDestroy(plan->join_event[k]);
+  }
+  if (plan->fork_event != nullptr) {
+    (void)hipEventDestroy(plan->fork_event);
+  }
   for (hipEvent_t e : plan->events) {
     (void)hipEventDestroy(e);
   }
@@ -1467,8 +1480,33 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     const TraceRange trace_cb("CB batch");
     // NRPHY_CB_DISPATCH: 1 = the one-launch mixed kernel, 2 = one launch per (Qm, layers) bucket, unset = by plan shape.
     const char* dispatch_env = std::getenv("NRPHY_CB_DISPATCH");
-    HIP_TRY(launch_codeblocks(p, plan->bucket_begin, dispatch_env ? std::atoi(dispatch_env) : 0, d_tb, (uint32_t*)d_grid,
-                              (uint32_t*)d_cw_rm, (uint32_t*)d_cw_scrambled, s));
+    const int   dispatch     = dispatch_env ? std::atoi(dispatch_env) : 0;
+    uint32_t    nof_buckets  = 0;
+    hipStream_t streams[1 + nrphy_pdsch_plan::MAX_AUX] = {s};
+    uint32_t    n_streams = 1;
+    if (codeblocks_take_bucket_launches(p, plan->bucket_begin, dispatch, &nof_buckets) && nof_buckets > 1) {
+      const uint32_t want = std::min<uint32_t>(nof_buckets - 1, nrphy_pdsch_plan::MAX_AUX);
+      while (plan->n_aux < want) { // first run of this kind: the plan's side streams and events
+        const uint32_t k = plan->n_aux;
+        if ((plan->fork_event == nullptr && hipEventCreateWithFlags(&plan->fork_event, hipEventDisableTiming) != hipSuccess) ||
+            hipStreamCreateWithFlags(&plan->aux_stream[k], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&plan->join_event[k], hipEventDisableTiming) != hipSuccess) {
+          return NRPHY_ERR_DEVICE;
+        }
+        ++plan->n_aux;
+      }
+      HIP_TRY(hipEventRecord(plan->fork_event, s));
+      for (uint32_t k = 0; k != want; ++k) {
+        HIP_TRY(hipStreamWaitEvent(plan->aux_stream[k], plan->fork_event, 0));
+        streams[n_streams++] = plan->aux_stream[k];
+      }
+    }
+    HIP_TRY(launch_codeblocks(p, plan->bucket_begin, dispatch, d_tb, (uint32_t*)d_grid, (uint32_t*)d_cw_rm,
+                              (uint32_t*)d_cw_scrambled, streams, n_streams));
+    for (uint32_t k = 1; k < n_streams; ++k) {
+      HIP_TRY(hipEventRecord(plan->join_event[k - 1], streams[k]));
+      HIP_TRY(hipStreamWaitEvent(s, plan->join_event[k - 1], 0));
+    }
   }
   if (ev) {
     HIP_TRY(hipEventRecord(ev[2], s));

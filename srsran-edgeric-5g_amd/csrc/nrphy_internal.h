@@ -231,8 +231,9 @@ inline uint32_t cb_bucket(uint32_t qm, uint32_t nof_layers)
 {
   return (qm / 2u - 1u) * 4u + (nof_layers - 1u);
 }
+bool       codeblocks_take_bucket_launches(const PdschLaunch& p, const uint32_t* bucket_begin, int dispatch, uint32_t* nof_buckets);
 hipError_t launch_codeblocks(const PdschLaunch& p, const uint32_t* bucket_begin, int dispatch, const uint8_t* d_tb,
-                             uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr, hipStream_t stream);
+                             uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr, const hipStream_t* streams, uint32_t n_streams);
 hipError_t launch_dmrs(const PdschLaunch& p, uint32_t* d_grid, hipStream_t stream);
 hipError_t launch_ldpc_encode(const LiftedGraph* graphs, uint32_t graph, uint32_t kb, uint32_t zc, uint32_t n_cb,
                               const uint8_t* d_msg, uint32_t msg_stride, uint32_t out_bits, uint8_t* d_out,

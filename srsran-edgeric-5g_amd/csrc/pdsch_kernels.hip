@@ -236,7 +236,7 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
   if (last) { // wave-uniform: the transport-block CRC = XOR of the shares of its regions (prologue)
     const uint32_t tb_crc = wave_xor(lane < pd.crc_count ? tb_crc_part[pd.crc_first + lane] : 0u);
     if (lane == 0) {
-      or_bits_lds(sh->lin, used, tb_crc << (32u - pd.tb_crc_bits), pd.tb_crc_bits);
+      or_bits_lds_exclusive(sh->lin, used, tb_crc << (32u - pd.tb_crc_bits), pd.tb_crc_bits);
     }
   }
   wave_sync();
@@ -274,7 +274,7 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
     }
     uint32_t crc = wave_xor(part);
     if (lane == 0) {
-      or_bits_lds(sh->lin, n, crc << 8, 24);
+      or_bits_lds_exclusive(sh->lin, n, crc << 8, 24);
     }
     wave_sync();
   }
@@ -976,29 +976,59 @@ __device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_in
 // with PDUs of several modulations) runs the one-launch codeblock_kernel, which selects the output stage per wave.
 // ================================================================================================================
 
-// The launch's extra waves (DM-RS, zero fill); true when this block was one of them.
-__device__ __forceinline__ bool extra_wave(const PdschLaunch& p, uint32_t* __restrict__ d_grid, uint32_t lane, uint32_t* lds)
+// A workgroup is NRPHY_CB_WAVES independent waves, each with its own work unit and its own slice of the dynamic LDS (no
+// barrier between them): the dispatcher hands out a quarter of the workgroups for the same waves (an empty launch of the
+// headline's 138 k one-wave workgroups alone took 0.035 ms).
+#ifndef NRPHY_CB_WAVES
+#define NRPHY_CB_WAVES 4
+#endif
+constexpr uint32_t CB_WAVES = NRPHY_CB_WAVES;
+
+struct CbWave {
+  uint32_t  lane;
+  uint32_t  wave;  // wave-uniform (scalar register)
+  uint32_t* lds;   // this wave's slice of the dynamic LDS
+};
+__device__ __forceinline__ CbWave cb_wave(const PdschLaunch& p, uint32_t* dyn_lds)
 {
-  if (blockIdx.x < p.n_work) { // wave-uniform
+  CbWave w;
+  w.lane = threadIdx.x % WAVE;
+  w.wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  w.lds  = dyn_lds + w.wave * (p.lds_lin_words + p.lds_u_words);
+  return w;
+}
+__host__ __device__ __forceinline__ uint32_t cb_blocks(uint32_t n_units)
+{
+  return (n_units + CB_WAVES - 1u) / CB_WAVES;
+}
+
+// The launch's extra waves (DM-RS, zero fill) sit in the workgroups behind the codeblock ones; true when this wave
+// belongs to one of those (whether or not a unit was left for it).
+__device__ __forceinline__ bool extra_wave(const PdschLaunch& p, const CbWave& w, uint32_t* __restrict__ d_grid)
+{
+  const uint32_t nb = cb_blocks(p.n_work);
+  if (blockIdx.x < nb) { // workgroup-uniform
     return false;
   }
-  const uint32_t extra = blockIdx.x - p.n_work;
+  const uint32_t extra = (blockIdx.x - nb) * CB_WAVES + w.wave;
   if (extra < p.n_dmrs_in_launch) {
-    dmrs_wave(p, extra, d_grid, lane, lds);
-  } else {
-    zero_wave(p, extra - p.n_dmrs_in_launch, d_grid, lane);
+    dmrs_wave(p, extra, d_grid, w.lane, w.lds);
+  } else if (extra - p.n_dmrs_in_launch < p.n_zero_work) {
+    zero_wave(p, extra - p.n_dmrs_in_launch, d_grid, w.lane);
   }
   return true;
 }
 
 // Workgroups go to the eight XCDs round-robin (block b runs on XCD b % 8).  Give each XCD a contiguous run of work
 // items, so that codeblocks which share cache lines -- neighbours in the transport block and in the grid rows --
-// meet in one L2 instead of leaving partial lines in two.
-__device__ __forceinline__ uint32_t xcd_work_item(uint32_t n_work)
+// meet in one L2 instead of leaving partial lines in two.  Returns the wave's work item, or n_work when none is left.
+__device__ __forceinline__ uint32_t xcd_work_item(uint32_t n_work, const CbWave& w)
 {
+  const uint32_t nb  = cb_blocks(n_work);
   const uint32_t xcd = blockIdx.x & 7u, turn = blockIdx.x >> 3;
-  const uint32_t q = n_work >> 3, r = n_work & 7u;
-  return xcd * q + (xcd < r ? xcd : r) + turn;
+  const uint32_t q = nb >> 3, r = nb & 7u;
+  const uint32_t item = (xcd * q + (xcd < r ? xcd : r) + turn) * CB_WAVES + w.wave;
+  return item < n_work ? item : n_work;
 }
 
 // Stages 1 and 2 of a codeblock wave: segmentation + CRC attachment (the graph rows ride along: their loads overlap the
@@ -1024,22 +1054,27 @@ __device__ __forceinline__ bool codeblock_front(const PdschLaunch& p, PduRef pd,
 }
 
 template <int QM, int L>
-__global__ __launch_bounds__(WAVE, 6) void codeblock_kernel_t(PdschLaunch p, const uint8_t* __restrict__ d_tb,
+__global__ __launch_bounds__(WAVE * CB_WAVES) void codeblock_kernel_t(PdschLaunch p, const uint8_t* __restrict__ d_tb,
                                                               uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
                                                               uint32_t* __restrict__ d_cw_scr)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-  CbShared sh;
-  sh.lin   = dyn_lds;
-  sh.u     = dyn_lds + p.lds_lin_words;
+  const CbWave   w    = cb_wave(p, dyn_lds);
+  const uint32_t lane = w.lane;
+  CbShared       sh;
+  sh.lin   = w.lds;
+  sh.u     = w.lds + p.lds_lin_words;
   sh.symb  = sh.u + CB_U_QAM_WORDS;
   sh.graph = sh.u + CB_U_GRAPH_OFFSET;
   sh.ldpc  = reinterpret_cast<LdpcScratch*>(sh.u + LDPC_DBL_WORDS);
-  const uint32_t lane = threadIdx.x;
-  if (p.profile_stage == 10 || extra_wave(p, d_grid, lane, dyn_lds)) {
+  if (p.profile_stage == 10 || extra_wave(p, w, d_grid)) {
     return;
   }
-  const auto*  wkc = to_constant(&p.work[xcd_work_item(p.n_work)]);
+  const uint32_t item = xcd_work_item(p.n_work, w);
+  if (item == p.n_work) { // wave-uniform: the last workgroup's spare waves
+    return;
+  }
+  const auto*  wkc = to_constant(&p.work[item]);
   const CbWork wk  = {wkc->pdu, wkc->cb, wkc->re_begin, wkc->re_count};
   PduRef       pd  = *to_constant(&p.pdus[wk.pdu]);
   if (!codeblock_front(p, pd, wk, sh, d_tb, lane)) {
@@ -1048,22 +1083,27 @@ __global__ __launch_bounds__(WAVE, 6) void codeblock_kernel_t(PdschLaunch p, con
   map_chunk<QM, L>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
 }
 
-__global__ __launch_bounds__(WAVE, 6) void codeblock_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
+__global__ __launch_bounds__(WAVE * CB_WAVES) void codeblock_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
                                                          uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
                                                          uint32_t* __restrict__ d_cw_scr)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-  CbShared sh;
-  sh.lin   = dyn_lds;
-  sh.u     = dyn_lds + p.lds_lin_words;
+  const CbWave   w    = cb_wave(p, dyn_lds);
+  const uint32_t lane = w.lane;
+  CbShared       sh;
+  sh.lin   = w.lds;
+  sh.u     = w.lds + p.lds_lin_words;
   sh.symb  = sh.u + CB_U_QAM_WORDS;
   sh.graph = sh.u + CB_U_GRAPH_OFFSET;
   sh.ldpc  = reinterpret_cast<LdpcScratch*>(sh.u + LDPC_DBL_WORDS);
-  const uint32_t lane = threadIdx.x;
-  if (p.profile_stage == 10 || extra_wave(p, d_grid, lane, dyn_lds)) {
+  if (p.profile_stage == 10 || extra_wave(p, w, d_grid)) {
     return;
   }
-  const auto*  wkc = to_constant(&p.work[xcd_work_item(p.n_work)]);
+  const uint32_t item = xcd_work_item(p.n_work, w);
+  if (item == p.n_work) { // wave-uniform: the last workgroup's spare waves
+    return;
+  }
+  const auto*  wkc = to_constant(&p.work[item]);
   const CbWork wk  = {wkc->pdu, wkc->cb, wkc->re_begin, wkc->re_count};
   PduRef       pd  = *to_constant(&p.pdus[wk.pdu]);
   if (!codeblock_front(p, pd, wk, sh, d_tb, lane)) {
@@ -1099,41 +1139,56 @@ static CodeblockKernel bucket_kernel(uint32_t bucket)
 
 // bucket_begin[b] .. bucket_begin[b + 1]: the work items of bucket b = cb_bucket(Qm, layers) (the plan sorts them).
 // dispatch: 0 = by plan shape, 1 = always the one-launch mixed kernel, 2 = always one launch per bucket.
+bool codeblocks_take_bucket_launches(const PdschLaunch& p, const uint32_t* bucket_begin, int dispatch, uint32_t* nof_buckets)
+{
+  uint32_t n = 0;
+  for (uint32_t b = 0; b != CB_BUCKETS; ++b) {
+    n += bucket_begin[b + 1] != bucket_begin[b] ? 1u : 0u;
+  }
+  *nof_buckets = n;
+  return !(dispatch == 1 || (dispatch == 0 && n > 1 && p.n_work < CB_MIXED_MAX_WORK));
+}
+
+// streams[0] is the caller's stream; with more than one bucket and n_streams > 1 the bucket launches are dealt to the
+// streams in turn, biggest bucket first (the caller has made streams[1 ...] wait for what precedes on streams[0] and
+// joins them afterwards): the buckets of a mixed batch then share the device like the waves of one launch instead of
+// running one after the other, each with a tail of its own.
 hipError_t launch_codeblocks(const PdschLaunch& p, const uint32_t* bucket_begin, int dispatch, const uint8_t* d_tb,
-                             uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr, hipStream_t stream)
+                             uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr, const hipStream_t* streams, uint32_t n_streams)
 {
   if (p.n_work == 0) {
     return hipSuccess;
   }
-  const size_t   lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_u_words);
+  const size_t   lds_bytes = 4u * (size_t)(p.lds_lin_words + p.lds_u_words) * CB_WAVES;
   const uint32_t extras    = d_grid ? p.n_dmrs_in_launch + p.n_zero_work : 0u;
-  uint32_t       nof_buckets = 0, last_bucket = 0;
-  for (uint32_t b = 0; b != CB_BUCKETS; ++b) {
-    if (bucket_begin[b + 1] != bucket_begin[b]) {
-      ++nof_buckets;
-      last_bucket = b;
-    }
-  }
-  const bool mixed = dispatch == 1 || (dispatch == 0 && nof_buckets > 1 && p.n_work < CB_MIXED_MAX_WORK);
-  if (mixed) {
-    hipLaunchKernelGGL(codeblock_kernel, dim3(p.n_work + extras), dim3(WAVE), lds_bytes, stream, p, d_tb, d_grid, d_cw_rm,
-                       d_cw_scr);
+  uint32_t       nof_buckets = 0;
+  if (!codeblocks_take_bucket_launches(p, bucket_begin, dispatch, &nof_buckets)) {
+    hipLaunchKernelGGL(codeblock_kernel, dim3(cb_blocks(p.n_work) + cb_blocks(extras)), dim3(WAVE * CB_WAVES), lds_bytes, streams[0], p,
+                       d_tb, d_grid, d_cw_rm, d_cw_scr);
     return hipGetLastError();
   }
+  uint32_t order[CB_BUCKETS], n_order = 0; // non-empty buckets, biggest first
   for (uint32_t b = 0; b != CB_BUCKETS; ++b) {
-    const uint32_t n = bucket_begin[b + 1] - bucket_begin[b];
-    if (n == 0) {
-      continue;
+    if (bucket_begin[b + 1] != bucket_begin[b]) {
+      uint32_t k = n_order++;
+      for (; k != 0 && bucket_begin[order[k - 1] + 1] - bucket_begin[order[k - 1]] < bucket_begin[b + 1] - bucket_begin[b]; --k) {
+        order[k] = order[k - 1];
+      }
+      order[k] = b;
     }
-    PdschLaunch q = p;
-    q.work        = p.work + bucket_begin[b];
-    q.n_work      = n;
-    if (b != last_bucket) { // the DM-RS and zero-fill waves ride at the end of the last launch
+  }
+  for (uint32_t i = 0; i != n_order; ++i) {
+    const uint32_t b = order[i], n = bucket_begin[b + 1] - bucket_begin[b];
+    PdschLaunch    q = p;
+    q.work           = p.work + bucket_begin[b];
+    q.n_work         = n;
+    if (i != 0) { // the DM-RS and zero-fill waves ride at the end of the biggest bucket's launch
       q.n_dmrs_in_launch = 0;
       q.n_zero_work      = 0;
     }
-    const uint32_t blocks = n + (b == last_bucket ? extras : 0u);
-    hipLaunchKernelGGL(bucket_kernel(b), dim3(blocks), dim3(WAVE), lds_bytes, stream, q, d_tb, d_grid, d_cw_rm, d_cw_scr);
+    const uint32_t blocks = cb_blocks(n) + (i == 0 ? cb_blocks(extras) : 0u);
+    hipLaunchKernelGGL(bucket_kernel(b), dim3(blocks), dim3(WAVE * CB_WAVES), lds_bytes, streams[n_streams > 1 ? i % n_streams : 0], q,
+                       d_tb, d_grid, d_cw_rm, d_cw_scr);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
       return e;
