@@ -18,8 +18,11 @@
  *  - Pointers named d_* are device (HBM) pointers valid on the context's device; `stream` is a
  *    hipStream_t passed as void* (NULL = the context's own stream).  Calls that take a stream are
  *    asynchronous with respect to the host.  The plan-based calls (nrphy_pdsch_run, nrphy_ofdm_run,
- *    nrphy_ofdm_demod_run, nrphy_demodulate_soft, nrphy_llr_descramble, nrphy_dft_run) neither allocate nor touch host memory and can be
- *    captured in a hipGraph, any number of them in any order; the others say what they do at the call.  The grid writers
+ *    nrphy_ofdm_demod_run, nrphy_demodulate_soft, nrphy_llr_descramble, and nrphy_dft_run for the sizes up to 6144) neither
+ *    allocate nor touch host memory and can be captured in a hipGraph, any number of them in any order -- a size's twiddle
+ *    table is uploaded by the first call that uses it (plan creation, or one call outside the capture); nrphy_dft_run at
+ *    the sizes above 6144 allocates its scratch in stream order (hipMallocAsync), which a capture records as memory nodes
+ *    of the graph; the others say what they do at the call.  The grid writers
  *    that take host descriptors (nrphy_csi_rs_map, nrphy_pdcch_process, nrphy_ssb_process, nrphy_grid_put) copy them from
  *    host memory when called, like a plan creation: asynchronous, but not for capture (a replay would read host memory the
  *    caller has long released).

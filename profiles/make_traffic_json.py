@@ -52,7 +52,7 @@ for kernel, counters in acc.items():
 # the receive chain's entries are kept from the previous file (they come from profiles/collect_rx.sh)
 try:
     prev = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")))
-    for k in ("rx_valu_insts_per_codeblock_iteration", "rx_valu_insts_per_codeblock_fixed", "rx_hbm_bytes_per_launch", "rx_source"):
+    for k in ("rx_valu_insts_per_codeblock_iteration", "rx_valu_insts_per_codeblock_fixed", "rx_hbm_bytes_per_codeblock", "rx_source"):
         if k in prev:
             out[k] = prev[k]
 except Exception:

@@ -350,7 +350,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
     }
   }
   if (pooled && s_flag[3] != 0xFFFFFFFFu) { // workgroup-uniform
-    // Give the slot back once every record store of this workgroup has completed (see acquire_slot).
+    // Give the slot back once every record store of this workgroup has completed (see acquire_slot): every wave waits for
+    // its own outstanding stores -- s_waitcnt vmcnt(0), written out because a workgroup-scope release fence only has to
+    // order them with respect to this workgroup (it compiles to a wait for LDS traffic) -- then the barrier, then the flag.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (j == 0) {

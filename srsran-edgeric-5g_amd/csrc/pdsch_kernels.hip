@@ -205,21 +205,40 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
   const uint32_t used    = pd.info_bits - (last ? pd.tb_crc_bits + pd.zero_pad : 0u);
   const uint32_t tb_pos  = cb * pd.info_bits;
   const uint32_t tb_bits = pd.tb_bytes * 8u;
-  for (uint32_t j = lane; j < total_words; j += WAVE) {
-    uint32_t pos = 32u * j, v = 0;
-    if (pos < used) {
-      // Never touch words that lie entirely beyond the transport block.
-      uint32_t abs_pos = tb_pos + pos;
-      uint32_t i = abs_pos >> 5, s = abs_pos & 31u;
-      uint32_t hi = be_word(tbw, i);
-      uint32_t lo = (s != 0 && 32u * (i + 1) < tb_bits) ? be_word(tbw, i + 1) : 0u;
-      v           = __funnelshift_l(lo, hi, s);
-      uint32_t remaining = used - pos;
-      if (remaining < 32u) {
-        v &= topmask(remaining);
+  // The transport-block words of SEG_UNROLL trips are requested before the first is used: taken trip by trip, every trip
+  // waited out a trip to memory (stage timing: this loop alone cost 0.045 ms per 1024 slots for a hundred instructions).
+  constexpr uint32_t SEG_UNROLL = 5; // 320 words: a whole high-rate codeblock with its four core parity blocks
+  for (uint32_t base = lane; base < total_words; base += WAVE * SEG_UNROLL) {
+    uint32_t hi[SEG_UNROLL], lo[SEG_UNROLL];
+#pragma unroll
+    for (uint32_t k = 0; k != SEG_UNROLL; ++k) {
+      const uint32_t pos = 32u * (base + WAVE * k);
+      hi[k] = 0;
+      lo[k] = 0;
+      if (pos < used) { // never touch words that lie entirely beyond the transport block
+        const uint32_t abs_pos = tb_pos + pos;
+        const uint32_t i = abs_pos >> 5, sft = abs_pos & 31u;
+        hi[k] = tbw[i];
+        if (sft != 0 && 32u * (i + 1) < tb_bits) {
+          lo[k] = tbw[i + 1];
+        }
       }
     }
-    sh->lin[j] = v;
+#pragma unroll
+    for (uint32_t k = 0; k != SEG_UNROLL; ++k) {
+      const uint32_t j = base + WAVE * k, pos = 32u * j;
+      if (j < total_words) {
+        uint32_t v = 0;
+        if (pos < used) {
+          v = __funnelshift_l(__builtin_bswap32(lo[k]), __builtin_bswap32(hi[k]), (tb_pos + pos) & 31u);
+          const uint32_t remaining = used - pos;
+          if (remaining < 32u) {
+            v &= topmask(remaining);
+          }
+        }
+        sh->lin[j] = v;
+      }
+    }
   }
   if (pd.cb_crc_bits) { // the CRC's byte tables, 16 bytes per lane and step
     const uint4* src = reinterpret_cast<const uint4*>(&tables->crc24b_slice[0][0]);
@@ -603,8 +622,32 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
   const uint32_t* __restrict__ scr_chunk = scr + cm.word0;
   const uint32_t* __restrict__ x1_chunk  = p.x1_words + cm.word0;
 
+  // The RE's L * Qm scrambling bits (the prologue's x2 part + the shared x1 part; MSB first).  L * Qm = 32 with a word-aligned
+  // chunk (the headline shape) makes them one word of each.  They come from global memory (L2), so the words of the NEXT
+  // 64 RE are requested before this trip's arithmetic starts.
+  auto scrambling_bits = [&](uint32_t r) -> uint32_t {
+    uint32_t bits = 0;
+    if (r < wk.re_count) {
+      if (QM * L == 32 && cm.aligned) { // wave-uniform
+        bits = scr_chunk[r];
+        if (NRPHY_SCR_X2_ONLY) {
+          bits ^= x1_chunk[r];
+        }
+      } else {
+        bits = ext32(scr, g.bit0 + r * (uint32_t)(QM * L));
+        if (NRPHY_SCR_X2_ONLY) {
+          bits ^= ext32(p.x1_words, g.bit0 + r * (uint32_t)(QM * L));
+        }
+      }
+    }
+    return bits;
+  };
+  uint32_t gbits_next = scrambling_bits(lane);
+
   for (uint32_t r0 = 0; r0 < wk.re_count; r0 += WAVE) { // r0 is wave-uniform
     const uint32_t r        = r0 + lane;
+    const uint32_t gbits    = gbits_next;
+    gbits_next              = scrambling_bits(r + WAVE);
     const uint32_t re_first = cm.re0 + r0;
     const uint32_t re_last  = re_first + ((wk.re_count - r0 < WAVE ? wk.re_count - r0 : WAVE) - 1u);
     if (re_first >= cur_end && l_cur + 1u < NRPHY_NSYMB) { // wave-uniform
@@ -622,22 +665,12 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
       continue;
     }
     __builtin_assume(r < (uint32_t)RE_CHUNK + WAVE);
-    uint32_t bytes, gbits;
+    // The RE's L symbol bytes (first in the MSB): four layers make them a whole word.
+    uint32_t bytes;
     if constexpr (L == 4) {
       bytes = sh.symb[r];
     } else {
       bytes = ext32(sh.symb, 8u * r * L);
-    }
-    if (QM * L == 32 && cm.aligned) { // wave-uniform: one scrambling word per RE (the headline shape)
-      gbits = scr_chunk[r];
-      if (NRPHY_SCR_X2_ONLY) {
-        gbits ^= x1_chunk[r];
-      }
-    } else {
-      gbits = ext32(scr, g.bit0 + r * (uint32_t)(QM * L));
-      if (NRPHY_SCR_X2_ONLY) {
-        gbits ^= ext32(p.x1_words, g.bit0 + r * (uint32_t)(QM * L));
-      }
     }
     // RE position: OFDM symbol from the per-symbol prefix counts, subcarrier from the symbol's pattern.
     const uint32_t re_pdu = re_first + lane;
@@ -948,12 +981,27 @@ __device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_in
   const auto*    wkc  = to_constant(&p.zero_work[item_index]);
   const uint32_t seg_begin = wkc->seg_begin, seg_count = wkc->seg_count, seg_long = wkc->seg_long;
   uint32_t*      base = d_grid + ((size_t)wkc->grid * p.grid_nof_ports + wkc->port) * NRPHY_NSYMB * p.grid_nof_subc;
-  for (uint32_t i = 0; i != seg_long; ++i) { // long runs: the wave clears each one together
+  for (uint32_t i = 0; i != seg_long; ++i) { // long runs: the wave clears each one together, 16 bytes per lane and store
     const auto*    sgc   = to_constant(&p.zero_segs[seg_begin + i]);
     const uint32_t count = sgc->count;
     uint32_t*      row   = base + (size_t)sgc->symbol * p.grid_nof_subc + sgc->k0;
-    for (uint32_t k = lane; k < count; k += WAVE) {
-      row[k] = 0u;
+    // 16-byte chunks counted from the aligned address at or below the run's first word; the two chunks at the ends may
+    // be partial and go word by word.
+    const uint32_t off      = (uint32_t)((reinterpret_cast<uintptr_t>(row) >> 2) & 3u);
+    uint32_t*      aligned  = row - off;
+    const uint32_t n_chunks = (off + count + 3u) >> 2;
+    for (uint32_t c = lane; c < n_chunks; c += WAVE) {
+      const uint32_t lo = 4u * c;
+      if (lo >= off && lo + 4u <= off + count) {
+        *reinterpret_cast<uint4*>(aligned + lo) = make_uint4(0u, 0u, 0u, 0u);
+      } else {
+#pragma unroll
+        for (uint32_t w = 0; w != 4; ++w) {
+          if (lo + w >= off && lo + w < off + count) {
+            aligned[lo + w] = 0u;
+          }
+        }
+      }
     }
   }
   for (uint32_t i = seg_long + lane; i < seg_count; i += WAVE) { // short runs (reserved-RE combs): one lane per run
