@@ -28,9 +28,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# SNR of the near-threshold leg and of the fixed-iteration legs (chosen with --sweep: every transport block still decodes
-# within 8 iterations, the mean iteration count is several).
-SNR_THRESHOLD_BG1 = 27.0
+# SNR of the near-threshold leg and of the BG2 leg (chosen with --sweep, profiles/r03_rx_snr_sweeps.txt: every transport block
+# still decodes within 8 iterations -- half a dB lower none does -- and the mean iteration count is 4.7).
+SNR_THRESHOLD_BG1 = 26.0
 SNR_FIXED_BG2 = -4.0
 
 
@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--snr-db", type=float, default=32.0)
     ap.add_argument("--leg", default="bg1", choices=["bg1", "bg2"])
     ap.add_argument("--no-early-stop", action="store_true")
+    ap.add_argument("--allow-failures", action="store_true", help="do not insist that every transport block decodes")
     ap.add_argument("--all", action="store_true", help="the four legs bench.py reports")
     ap.add_argument("--sweep", nargs=4, metavar=("LEG", "FROM", "TO", "STEP"), help="mean iterations against SNR")
     args = ap.parse_args()
@@ -60,6 +61,7 @@ def main():
         print(json.dumps(run_all(args.steps, args.warmup)))
         return
     args.early_stop = not args.no_early_stop
+    args.require_all = not args.allow_failures
     print(json.dumps(run(args)))
 
 
