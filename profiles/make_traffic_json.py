@@ -49,12 +49,13 @@ for kernel, counters in acc.items():
         out["valu_insts_per_launch"][k] = int(mean["SQ_INSTS_VALU"])
     if "SQ_INSTS_SALU" in mean:
         out["salu_insts_per_launch"][k] = int(mean["SQ_INSTS_SALU"])
-# the receive chain's entries are kept from the previous file (they come from profiles/collect_rx.sh)
+# the receive chain's entries: profiles/rx_pmc_summary.py output (third argument), else kept from the previous file
 try:
-    prev = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")))
-    for k in ("rx_valu_insts_per_codeblock_iteration", "rx_valu_insts_per_codeblock_fixed", "rx_hbm_bytes_per_codeblock", "rx_source"):
-        if k in prev:
-            out[k] = prev[k]
+    rx = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else json.load(
+        open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")))
+    for k, v in rx.items():
+        if k.startswith("rx_"):
+            out[k] = v
 except Exception:
     pass
 print(json.dumps(out, indent=1))
