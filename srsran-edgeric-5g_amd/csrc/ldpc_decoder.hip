@@ -16,6 +16,9 @@
 // This is the reference's arithmetic re-indexed by check instead of by variable position; the values are the same.
 #include "bits_device.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace nrphy {
 
 constexpr int LLR_MAX_V = 120;
@@ -138,6 +141,182 @@ __device__ __forceinline__ uint2 process_layer(uint32_t deg, int8_t* soft, const
   }
 }
 
+// ---- Two checks per lane ----------------------------------------------------------------------------------------------
+// For an even lifting size thread j owns checks j and j + Zc / 2 of every layer and carries their values as the two 16-bit
+// halves of one register: the arithmetic of the min-sum rule (subtractions, clamps, magnitudes, the two running minima as
+// 16-bit keys, the promotion of the new soft bit) is one packed instruction for both checks, the sign and minimum-owner masks
+// of an edge come out of the record with two packed shifts for both, and the second check's soft-bit address is the first's
+// plus or minus Zc / 2.  Per check and edge that is about 22 vector instructions instead of 31 -- the kernel is bound by vector
+// issue -- for exactly the same values: every operation is the 16-bit image of the one in process_check (values stay within
+// +-633, keys within 16 bits because magnitudes beyond 255 -- an infinite soft bit's -- are clamped to 255, which like them is
+// above LLR_MAX and never a minimum).
+//
+// Record of a pair of checks (16 bytes: the size of two single records):
+//   x = m1A | m2A << 8 | m1B << 16 | m2B << 24     scaled minima of check A (= j) and B (= j + Zc / 2)
+//   y = idxA | idxB << 16                           edge holding the minimum (0xFF: none)
+//   z = signs of edges 0 .. 15, A in the low half, B in the high half (bit t: message of edge t is negative)
+//   w = the same for edges 16 .. (at most 19 edges per check)
+typedef short          s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t x)
+{
+  return __builtin_bit_cast(s16x2, x);
+}
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t x)
+{
+  return __builtin_bit_cast(u16x2, x);
+}
+__device__ __forceinline__ uint32_t as_word(s16x2 x)
+{
+  return __builtin_bit_cast(uint32_t, x);
+}
+__device__ __forceinline__ uint32_t as_word(u16x2 x)
+{
+  return __builtin_bit_cast(uint32_t, x);
+}
+__device__ __forceinline__ s16x2 splat_s16(int v)
+{
+  return s16x2{(short)v, (short)v};
+}
+// 0xFFFF in every half of `word` whose bit `bit` (< 16) is set, else 0: two packed shifts.
+__device__ __forceinline__ uint32_t half_masks(uint32_t word, uint32_t bit)
+{
+  return as_word((as_s16x2(word) << splat_s16((int)(15u - bit))) >> splat_s16(15));
+}
+__device__ __forceinline__ s16x2 clamp_s16x2(s16x2 x, int lim)
+{
+  return __builtin_elementwise_max(__builtin_elementwise_min(x, splat_s16(lim)), splat_s16(-lim));
+}
+// llr_sub for both halves (a: soft bits, c: old messages).
+__device__ __forceinline__ s16x2 llr_sub_pair(s16x2 a, s16x2 c)
+{
+  const s16x2 d   = clamp_s16x2(a - c, LLR_MAX_V);
+  const s16x2 big = a - clamp_s16x2(a, LLR_MAX_V); // 0, or +-1 for an infinite soft bit
+  return (big << splat_s16(9)) + d;
+}
+__device__ __forceinline__ s16x2 llr_sub_pair_first(s16x2 a)
+{
+  const s16x2 d = clamp_s16x2(a, LLR_MAX_V);
+  return ((a - d) << splat_s16(9)) + d;
+}
+
+// The messages of the pair on edge t from a record's fields: m1 / m2 = (m1A | m1B << 16) / (m2A | m2B << 16), hot0 / hot1 =
+// one-hot minimum owners, signs0 / signs1 = the record's z / w.
+template <uint32_t T>
+__device__ __forceinline__ s16x2 pair_message(uint32_t m1, uint32_t m2, uint32_t hot0, uint32_t hot1, uint32_t signs0, uint32_t signs1)
+{
+  const uint32_t sel = half_masks(T < 16u ? hot0 : hot1, T & 15u);
+  const uint32_t sg  = half_masks(T < 16u ? signs0 : signs1, T & 15u);
+  const uint32_t mag = __builtin_amdgcn_bitop3_b32(sel, m2, m1, 0xCA);
+  return as_s16x2(mag ^ sg) - as_s16x2(sg);
+}
+__device__ __forceinline__ void pair_one_hot(uint32_t y, uint32_t& hot0, uint32_t& hot1)
+{
+  const uint32_t ia = y & 0xFFu, ib = (y >> 16) & 0xFFu;
+  const uint32_t ha = ia < 32u ? 1u << ia : 0u, hb = ib < 32u ? 1u << ib : 0u;
+  hot0              = (ha & 0xFFFFu) | (hb << 16);
+  hot1              = (ha >> 16) | (hb & 0xFFFF0000u);
+}
+
+template <uint32_t DEG, uint32_t T, bool FIRST>
+struct PairEdges {
+  // Pass 1 over edges T .. DEG - 1: v2c messages, running minima, sign bits.
+  static __device__ __forceinline__ void forward(const uint32_t (&a)[DEG], uint32_t (&x)[DEG], uint32_t m1, uint32_t m2, uint32_t hot0,
+                                                 uint32_t hot1, uint32_t z, uint32_t w, uint32_t& k1, uint32_t& k2, uint32_t& nz,
+                                                 uint32_t& nw)
+  {
+    if constexpr (T < DEG) {
+      const s16x2 v = FIRST ? llr_sub_pair_first(as_s16x2(a[T]))
+                            : llr_sub_pair(as_s16x2(a[T]), pair_message<T>(m1, m2, hot0, hot1, z, w));
+      x[T]          = as_word(v);
+      const s16x2    mag = __builtin_elementwise_max(v, splat_s16(0) - v);
+      const uint32_t cap = as_word(__builtin_elementwise_min(as_u16x2(as_word(mag)), u16x2{255, 255}));
+      const uint32_t key = (cap << 8) | (T * 0x00010001u);
+      k2 = as_word(__builtin_elementwise_min(__builtin_elementwise_max(as_u16x2(key), as_u16x2(k1)), as_u16x2(k2)));
+      k1 = as_word(__builtin_elementwise_min(as_u16x2(key), as_u16x2(k1)));
+      const uint32_t neg = as_word(as_u16x2(as_word(v)) >> u16x2{15, 15}); // 1 in a half whose value is negative
+      if (T < 16u) {
+        nz |= neg << (T & 15u);
+      } else {
+        nw |= neg << (T & 15u);
+      }
+      PairEdges<DEG, T + 1, FIRST>::forward(a, x, m1, m2, hot0, hot1, z, w, k1, k2, nz, nw);
+    }
+  }
+  // Pass 2: new soft bits = new message + v2c message, promoted, back to where they came from.
+  static __device__ __forceinline__ void backward(int8_t* soft, const uint32_t (&addr1)[DEG], const uint32_t (&addr2)[DEG],
+                                                  const uint32_t (&x)[DEG], uint32_t m1, uint32_t m2, uint32_t hot0, uint32_t hot1,
+                                                  uint32_t z, uint32_t w)
+  {
+    if constexpr (T < DEG) {
+      const s16x2    sum = pair_message<T>(m1, m2, hot0, hot1, z, w) + as_s16x2(x[T]);
+      const uint32_t out = as_word(clamp_s16x2(sum, LLR_INF_V));
+      soft[addr1[T]]     = (int8_t)out;
+      soft[addr2[T]]     = (int8_t)(out >> 16);
+      PairEdges<DEG, T + 1, FIRST>::backward(soft, addr1, addr2, x, m1, m2, hot0, hot1, z, w);
+    }
+  }
+};
+
+// Checks j and j + half of one layer (degree DEG); j < half = Zc / 2; jm = j - Zc (wraps).
+template <uint32_t DEG, bool FIRST>
+__device__ __forceinline__ uint4 process_check_pair(int8_t* soft, const uint8_t* scaled, const NRPHY_CONSTANT uint32_t* edge,
+                                                    uint32_t half, uint32_t minus_half, uint32_t j, uint32_t jm, uint4 old)
+{
+  uint32_t addr1[DEG], addr2[DEG], a[DEG], x[DEG];
+#pragma unroll
+  for (uint32_t t = 0; t != DEG; ++t) {
+    const uint32_t e = edge[t], shift = e & 0xFFFFu;
+    const uint32_t pos = min(j + shift, jm + shift);   // (j + shift) mod Zc
+    addr1[t]           = (e >> 16) + pos;              // the graph holds node * Zc
+    addr2[t]           = addr1[t] + (pos < half ? half : minus_half); // (j + Zc / 2 + shift) mod Zc
+  }
+#pragma unroll
+  for (uint32_t t = 0; t != DEG; ++t) {
+    const int va = soft[addr1[t]], vb = soft[addr2[t]];
+    a[t]         = __builtin_amdgcn_perm((uint32_t)vb, (uint32_t)va, 0x05040100u); // low halves: A | B << 16
+  }
+  uint32_t m1 = 0, m2 = 0, hot0 = 0, hot1 = 0;
+  if (!FIRST) {
+    m1 = old.x & 0x00FF00FFu;
+    m2 = (old.x >> 8) & 0x00FF00FFu;
+    pair_one_hot(old.y, hot0, hot1);
+  }
+  uint32_t k1 = (((uint32_t)LLR_MAX_V << 8) | 0xFFu) * 0x00010001u, k2 = k1, nz = 0, nw = 0;
+  PairEdges<DEG, 0, FIRST>::forward(a, x, m1, m2, hot0, hot1, old.z, old.w, k1, k2, nz, nw);
+  // scale_llr of the four minima through the table; sign of a message = parity of the OTHER signs
+  const uint32_t s1a = scaled[(k1 >> 8) & 0xFFu], s1b = scaled[k1 >> 24], s2a = scaled[(k2 >> 8) & 0xFFu], s2b = scaled[k2 >> 24];
+  const uint32_t n1 = s1a | (s1b << 16), n2 = s2a | (s2b << 16);
+  const uint32_t sa = (nz & 0xFFFFu) | (nw << 16), sb = (nz >> 16) | (nw & 0xFFFF0000u);
+  const uint32_t flip = ((0u - (__popc(sa) & 1u)) & 0xFFFFu) | ((0u - (__popc(sb) & 1u)) << 16);
+  constexpr uint32_t ZBITS = DEG >= 16u ? 0xFFFFu : (1u << DEG) - 1u, WBITS = DEG > 16u ? (1u << (DEG - 16u)) - 1u : 0u;
+  nz ^= flip & (ZBITS * 0x00010001u);
+  nw ^= flip & (WBITS * 0x00010001u);
+  const uint4 mine = make_uint4(n1 | (n2 << 8), k1 & 0x00FF00FFu, nz, nw);
+  uint32_t    nh0, nh1;
+  pair_one_hot(mine.y, nh0, nh1);
+  PairEdges<DEG, 0, FIRST>::backward(soft, addr1, addr2, x, n1, n2, nh0, nh1, nz, nw);
+  return mine;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ uint4 process_layer_pair(uint32_t deg, int8_t* soft, const uint8_t* scaled,
+                                                    const NRPHY_CONSTANT uint32_t* edge, uint32_t half, uint32_t minus_half, uint32_t j,
+                                                    uint32_t jm, uint4 old)
+{
+  switch (deg) {
+    case 3: return process_check_pair<3, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+    case 4: return process_check_pair<4, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+    case 5: return process_check_pair<5, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+    case 6: return process_check_pair<6, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+    case 7: return process_check_pair<7, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+    case 8: return process_check_pair<8, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+    case 9: return process_check_pair<9, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+    case 10: return process_check_pair<10, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+    default: return process_check_pair<19, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+  }
+}
+
 // One soft bit as it enters the decoder (ldpc_decoder_impl.cpp:128-164): whole nodes are clamped to +-64, the tail
 // is taken as is (infinities in this kernel's form, see above).
 __device__ __forceinline__ int load_soft(int v, bool whole_node)
@@ -195,8 +374,16 @@ __device__ __forceinline__ void store_record(uint2* rec, uint2 v)
   __hip_atomic_store(reinterpret_cast<uint64_t*>(rec), (uint64_t)v.x | ((uint64_t)v.y << 32), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void store_record(uint4* rec, uint4 v) // a pair of checks: two write-through stores
+{
+  uint64_t* q = reinterpret_cast<uint64_t*>(rec);
+  __hip_atomic_store(q, (uint64_t)v.x | ((uint64_t)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, (uint64_t)v.z | ((uint64_t)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void ldpc_decode_kernel(LdpcDecodeLaunch p)
+// PAIR: two checks per lane (even lifting sizes: Zc / 2 threads per codeblock), see process_check_pair.
+template <bool PAIR>
+__device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
 {
   extern __shared__ __attribute__((aligned(16))) int8_t dec_lds[];
   __shared__ uint32_t s_flag[4];
@@ -209,7 +396,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   }
   const auto*   graph  = to_constant(p.graph); // wave-uniform reads: scalar loads
   const int8_t* llr    = p.llr + (size_t)blockIdx.x * p.llr_stride;
-  const bool    active = j < zc;
+  const uint32_t half = zc >> 1;
+  const bool    active = PAIR ? j < half : j < zc;
   const bool    pooled = p.nof_slots < gridDim.x; // fewer slots than codeblocks: claim one
   if (j == 0) { // (read after the barriers below; the claim's latency hides behind the loads)
     s_flag[3] = pooled ? acquire_slot(p.slot_flags, p.nof_slots, blockIdx.x) : blockIdx.x;
@@ -282,11 +470,6 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   // x^(bits after the word) mod g comes from the host.
   const CrcPoly  crc    = {p.crc_poly, p.crc_order};
   const uint32_t n_msg  = K - p.nof_filler;
-  uint32_t       w_bits = 0, w_factor = 0;
-  if (p.crc_order != 0 && 32u * j < n_msg) {
-    w_bits   = n_msg - 32u * j < 32u ? n_msg - 32u * j : 32u;
-    w_factor = p.crc_weight[j];
-  }
   const uint32_t jm = j - zc;
 
   if (input_size != 0) { // workgroup-uniform
@@ -298,22 +481,32 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
     cb_len          = ((cb_len + zc - 1u) / zc) * zc;
     const uint32_t nof_layers = cb_len / zc - p.bg_k;
 
+    typedef typename std::conditional<PAIR, uint4, uint2>::type Record; // a pair of checks per lane has a record of twice the size
+    Record*        recs        = reinterpret_cast<Record*>(rec);
+    const uint32_t rec_stride  = PAIR ? half : zc;                       // records of one layer
+    const uint32_t minus_half  = 0u - half;
     for (uint32_t it = 0; it != max_iterations && iterations == 0; ++it) {
-      uint2 next = make_uint2(0, 0);
+      Record next = {};
       if (it != 0 && active) {
-        next = rec[j];
+        next = recs[j];
       }
       for (uint32_t m = 0; m != nof_layers; ++m) {
         const uint32_t e0 = graph->row_ptr[m], deg = graph->row_ptr[m + 1u] - e0;
-        const uint2    old = next;
+        const Record   old = next;
         if (it != 0 && active && m + 1u != nof_layers) {
-          next = rec[(size_t)(m + 1u) * zc + j];
+          next = recs[(size_t)(m + 1u) * rec_stride + j];
         }
         if (active) {
           const auto* edge = graph->edge + e0;
-          const uint2 mine = it == 0 ? process_layer<true>(deg, soft, s_scaled, edge, zc, j, jm, old)
-                                     : process_layer<false>(deg, soft, s_scaled, edge, zc, j, jm, old);
-          store_record(&rec[(size_t)m * zc + j], mine);
+          if constexpr (PAIR) {
+            const uint4 mine = it == 0 ? process_layer_pair<true>(deg, soft, s_scaled, edge, half, minus_half, j, jm, old)
+                                       : process_layer_pair<false>(deg, soft, s_scaled, edge, half, minus_half, j, jm, old);
+            store_record(&recs[(size_t)m * rec_stride + j], mine);
+          } else {
+            const uint2 mine = it == 0 ? process_layer<true>(deg, soft, s_scaled, edge, zc, j, jm, old)
+                                       : process_layer<false>(deg, soft, s_scaled, edge, zc, j, jm, old);
+            store_record(&recs[(size_t)m * rec_stride + j], mine);
+          }
         }
         lds_barrier();
       }
@@ -326,10 +519,11 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
         lds_barrier();
         bool     zero_seen = false;
         uint32_t part      = 0;
-        if (j < nw_k) {
-          const uint32_t word = hard_word(soft, j, K, zero_seen);
-          if (w_bits != 0) {
-            part = crc_mulmod32(w_factor, word >> (32u - w_bits), crc);
+        for (uint32_t w = j; w < nw_k; w += T) { // thread w owns hard-bit word w (one trip, two with two checks per lane)
+          const uint32_t word = hard_word(soft, w, K, zero_seen);
+          if (32u * w < n_msg) {
+            const uint32_t w_bits = n_msg - 32u * w < 32u ? n_msg - 32u * w : 32u;
+            part ^= crc_mulmod32(p.crc_weight[w], word >> (32u - w_bits), crc);
           }
         }
         for (int o = WAVE / 2; o != 0; o >>= 1) {
@@ -363,14 +557,14 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   // Hard bits of the message, packed MSB first (all-zero input: soft <= 0 everywhere, every bit one as in
   // ldpc_decoder_impl.cpp:91-96).
   uint8_t* out = p.out + (size_t)blockIdx.x * p.out_stride;
-  if (j < nw_k) {
+  for (uint32_t w = j; w < nw_k; w += T) {
     bool           unused = false;
-    const uint32_t word   = hard_word(soft, j, K, unused) & topmask(K - 32u * j < 32u ? K - 32u * j : 32u);
+    const uint32_t word   = hard_word(soft, w, K, unused) & topmask(K - 32u * w < 32u ? K - 32u * w : 32u);
     const uint32_t nbytes = (K + 7u) / 8u;
 #pragma unroll
     for (uint32_t b = 0; b != 4; ++b) {
-      if (4u * j + b < nbytes) {
-        out[4u * j + b] = (uint8_t)(word >> (24u - 8u * b));
+      if (4u * w + b < nbytes) {
+        out[4u * w + b] = (uint8_t)(word >> (24u - 8u * b));
       }
     }
   }
@@ -380,6 +574,21 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   if (j == 0 && p.ok_flags && iterations != 0) {
     p.ok_flags[blockIdx.x] = 1;
   }
+}
+
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void ldpc_decode_kernel(LdpcDecodeLaunch p)
+{
+  ldpc_decode_body<false>(p);
+}
+
+// Two checks per lane: half the threads, registers for twice the values per lane (the launch is LDS-bound at six waves per
+// SIMD for the soft buffers of the receive chain anyway: 84 VGPRs cost nothing there).
+#ifndef NRPHY_DECODER_PAIR_WAVES
+#define NRPHY_DECODER_PAIR_WAVES 6
+#endif
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(NRPHY_DECODER_PAIR_WAVES))) void ldpc_decode_pairs_kernel(LdpcDecodeLaunch p)
+{
+  ldpc_decode_body<true>(p);
 }
 
 size_t ldpc_decode_lds_bytes(const LdpcDecodeLaunch& p)
@@ -392,16 +601,24 @@ hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStrea
   if (n_cb == 0) {
     return hipSuccess;
   }
-  const uint32_t threads = ((p.zc + WAVE - 1) / WAVE) * WAVE;
-  const size_t   lds     = ldpc_decode_lds_bytes(p);
+  // NRPHY_DECODER_PAIRS=0: one check per lane whatever the lifting size (A/B runs; the results are identical).
+  static const char* pairs_env = std::getenv("NRPHY_DECODER_PAIRS");
+  const bool         pairs     = (p.zc & 1u) == 0 && p.zc >= 4u && !(pairs_env != nullptr && pairs_env[0] == '0');
+  const uint32_t     checks    = pairs ? p.zc / 2u : p.zc;
+  const uint32_t     threads   = ((checks + WAVE - 1) / WAVE) * WAVE;
+  const size_t       lds       = ldpc_decode_lds_bytes(p);
+  const void*        kernel    = pairs ? reinterpret_cast<const void*>(ldpc_decode_pairs_kernel) : reinterpret_cast<const void*>(ldpc_decode_kernel);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ldpc_decode_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       return e;
     }
   }
-  hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
+  if (pairs) {
+    hipLaunchKernelGGL(ldpc_decode_pairs_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
+  } else {
+    hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
+  }
   return hipGetLastError();
 }
 

@@ -395,6 +395,8 @@ struct nrphy_pdsch_plan {
   uint32_t              timed_runs = 0, max_timed_runs = 0;
 };
 
+static bool plan_side_streams(nrphy_pdsch_plan* plan, uint32_t want);
+
 struct nrphy_ofdm_plan {
   nrphy_ctx*          ctx = nullptr;
   nrphy_ofdm_config_t cfg;
@@ -1369,6 +1371,19 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
     plan->d_scr    = (uint32_t*)scratch;
     plan->d_tb_crc = plan->d_scr + scr_alloc;
   }
+  {
+    // A batch that mixes modulations and is big enough for one launch per bucket (launch_codeblocks) runs those launches side by
+    // side: its side streams exist from here on, so that a run makes no HIP object and can be captured in a graph.
+    uint32_t nof_buckets = 0;
+    for (uint32_t b = 0; b != CB_BUCKETS; ++b) {
+      nof_buckets += plan->bucket_begin[b + 1] != plan->bucket_begin[b] ? 1U : 0U;
+    }
+    if (place == nullptr && nof_buckets > 1 && plan->n_work >= CB_MIXED_MAX_WORK &&
+        !plan_side_streams(plan, std::min<uint32_t>(nof_buckets - 1, nrphy_pdsch_plan::MAX_AUX))) {
+      nrphy_pdsch_plan_destroy(plan);
+      return NRPHY_ERR_DEVICE;
+    }
+  }
   // The dynamic LDS of the codeblock launch also serves the DM-RS waves it may carry.
   plan->lds_lin_words = std::max<uint32_t>(plan->lds_lin_words, 64);
   // The scratch region the stages of a codeblock wave share (pdsch_kernels.hip, CbShared): CRC tables, then doubled
@@ -1379,6 +1394,26 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
 }
 
 } // namespace
+
+// The plan's side streams and fork / join events for bucket launches that run side by side (nrphy_pdsch_run).
+static bool plan_side_streams(nrphy_pdsch_plan* plan, uint32_t want)
+{
+  while (plan->n_aux < want) {
+    const uint32_t k = plan->n_aux;
+    if (plan->fork_event == nullptr && hipEventCreateWithFlags(&plan->fork_event, hipEventDisableTiming) != hipSuccess) {
+      return false;
+    }
+    if (hipStreamCreateWithFlags(&plan->aux_stream[k], hipStreamNonBlocking) != hipSuccess) {
+      return false;
+    }
+    if (hipEventCreateWithFlags(&plan->join_event[k], hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(plan->aux_stream[k]);
+      return false;
+    }
+    ++plan->n_aux;
+  }
+  return true;
+}
 
 extern "C" int nrphy_pdsch_plan_destroy(nrphy_pdsch_plan_t* plan)
 {
@@ -1486,14 +1521,10 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     uint32_t    n_streams = 1;
     if (codeblocks_take_bucket_launches(p, plan->bucket_begin, dispatch, &nof_buckets) && nof_buckets > 1) {
       const uint32_t want = std::min<uint32_t>(nof_buckets - 1, nrphy_pdsch_plan::MAX_AUX);
-      while (plan->n_aux < want) { // first run of this kind: the plan's side streams and events
-        const uint32_t k = plan->n_aux;
-        if ((plan->fork_event == nullptr && hipEventCreateWithFlags(&plan->fork_event, hipEventDisableTiming) != hipSuccess) ||
-            hipStreamCreateWithFlags(&plan->aux_stream[k], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&plan->join_event[k], hipEventDisableTiming) != hipSuccess) {
-          return NRPHY_ERR_DEVICE;
-        }
-        ++plan->n_aux;
+      // (made at plan creation for a plan that takes bucket launches by its shape; here only when NRPHY_CB_DISPATCH forces
+      // them on a small one -- such a first run creates streams and is not for graph capture)
+      if (!plan_side_streams(plan, want)) {
+        return NRPHY_ERR_DEVICE;
       }
       HIP_TRY(hipEventRecord(plan->fork_event, s));
       for (uint32_t k = 0; k != want; ++k) {

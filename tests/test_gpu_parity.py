@@ -1003,6 +1003,74 @@ def test_device_entry_points_in_a_hip_graph(gpu_ctx, oracle):
     oplan.close()
 
 
+def test_mixed_modulation_batch_takes_bucket_launches_side_by_side(gpu_ctx, oracle):
+    """A batch big enough and mixed enough for one codeblock launch per (modulation, layers) bucket: 80 cell-slots of BASELINE
+    config 4 (QPSK / 16 / 64 / 256-QAM on 68 PRB each: four buckets, 4,400 work items) plus a few one- and two-layer PDUs in
+    grids of their own (more buckets than side streams).  The bucket launches run side by side on streams of the plan, forked
+    from and joined to the caller's stream; the run is capturable (the streams exist since plan creation).  Sampled grids
+    bit-exact against the oracle, eagerly and from a graph replay on new transport blocks."""
+    import torch
+    rng = np.random.default_rng(4044)
+    pdus, grid_of = [], []
+    nof_ports, nof_subc = 4, 273 * 12
+    for g in range(80):
+        cell, _, _ = cases.mixed_cell(g % 4, slot_index=g % 20)
+        pdus += cell
+        grid_of += [g] * len(cell)
+    w1, w2 = cases.codebook("single_port"), cases.codebook("two_layer_two_ports_0")
+    for k, (qm, w) in enumerate(((2, w1), (6, w2), (8, w1))):
+        layers = w.shape[2]
+        tb_bits = cases.tbs(12, 36, qm, 600, layers, 60)
+        pdus.append(abi.make_pdu(slot_index=k, rnti=77 + k, n_id=5, bwp_size_rb=273, qm=qm, dmrs_symbols=(2, 7, 11),
+                                 prb_start=10 * k, prb_count=60, nof_symbols=12, base_graph=1, precoding=w,
+                                 tb_size_bytes=tb_bits // 8))
+        grid_of.append(80 + k)
+    nof_grids = 83
+    tb_offsets, off = [], 0
+    for q in pdus:
+        tb_offsets.append(off)
+        off += (q.tb_size_bytes + 7) & ~3
+    plan = lib.PdschPlan(gpu_ctx, pdus, tb_offsets, grid_of, nof_grids, nof_ports, nof_subc)
+    d_tb = torch.zeros(off, dtype=torch.uint8, device="cuda")
+    d_grid = torch.zeros((nof_grids, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
+
+    def fresh_blocks():
+        h = np.zeros(off, np.uint8)
+        for q, o in zip(pdus, tb_offsets):
+            h[o: o + q.tb_size_bytes] = cases.random_tb(rng, q)
+        d_tb.copy_(torch.from_numpy(h))
+        return h
+
+    def check(h, grids):
+        for g in grids:
+            want = None
+            for q, o, gi in zip(pdus, tb_offsets, grid_of):
+                if gi == g:
+                    part = oracle.pdsch_process(q, h[o: o + q.tb_size_bytes], nof_ports, nof_subc)
+                    want = part if want is None else np.bitwise_or(want, part)
+            got = d_grid[g].cpu().numpy().view(np.uint16).reshape(want.shape)
+            assert np.array_equal(got, want), g
+
+    s = torch.cuda.Stream()
+    h = fresh_blocks()
+    torch.cuda.synchronize()
+    plan.run(d_tb, d_grid, zero_grids=True, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    check(h, (0, 37, 79, 80, 81, 82))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        plan.run(d_tb, d_grid, zero_grids=True, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        h = fresh_blocks()
+        d_grid.fill_(-1)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        check(h, (1, 42, 78, 80, 82))
+    plan.close()
+
+
 def test_single_run_graph_replay_and_eager_interleaved(gpu_ctx, oracle):
     """Every run of a plan is self-contained (no TB-CRC state is carried between runs): a graph holding ONE run -- the
     natural step -- replays correctly any number of times, also with eager runs of the same plan in between."""
