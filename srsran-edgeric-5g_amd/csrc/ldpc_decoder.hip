@@ -146,8 +146,10 @@ __device__ __forceinline__ uint2 process_layer(uint32_t deg, int8_t* soft, const
 // halves of one register: the arithmetic of the min-sum rule (subtractions, clamps, magnitudes, the two running minima as
 // 16-bit keys, the promotion of the new soft bit) is one packed instruction for both checks, the sign and minimum-owner masks
 // of an edge come out of the record with two packed shifts for both, and the second check's soft-bit address is the first's
-// plus or minus Zc / 2.  Per check and edge that is about 22 vector instructions instead of 31 -- the kernel is bound by vector
-// issue -- for exactly the same values: every operation is the 16-bit image of the one in process_check (values stay within
+// plus or minus Zc / 2.  Per check and edge that is about 22 vector instructions instead of 31 (PMC: 93.8 k instead of 114.7 k
+// per config-3 codeblock and 8 iterations; the per-layer work of a lane -- record, table look-ups, parity -- does not shrink)
+// -- the kernel is bound by vector issue -- for exactly the same values: every operation is the 16-bit image of the one in
+// process_check (values stay within
 // +-633, keys within 16 bits because magnitudes beyond 255 -- an infinite soft bit's -- are clamped to 255, which like them is
 // above LLR_MAX and never a minimum).
 //
@@ -581,10 +583,12 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void l
   ldpc_decode_body<false>(p);
 }
 
-// Two checks per lane: half the threads, registers for twice the values per lane (the launch is LDS-bound at six waves per
-// SIMD for the soft buffers of the receive chain anyway: 84 VGPRs cost nothing there).
+// Two checks per lane: half the threads, registers for twice the values per lane (two address arrays, one packed value
+// array of 19 edges each).  Measured on one box, BASELINE config 5 with 8 fixed iterations, nrphy_pusch_decode_batch per 256
+// slots (profiles/r03_decoder_pairs.txt): one check per lane 6.14 ms; two per lane with the registers of 6 waves per SIMD
+// (80 VGPRs, 26 spilled) 5.69, of 5 waves (96, 19 spilled) 5.35, of 4 waves (128, 6 spilled) 5.24, of 3 (153, none) 5.27.
 #ifndef NRPHY_DECODER_PAIR_WAVES
-#define NRPHY_DECODER_PAIR_WAVES 6
+#define NRPHY_DECODER_PAIR_WAVES 4
 #endif
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(NRPHY_DECODER_PAIR_WAVES))) void ldpc_decode_pairs_kernel(LdpcDecodeLaunch p)
 {
