@@ -49,9 +49,23 @@ __device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t re
 // Blocks [0, n_scr_work): a share of the scrambling sequence of one PDU, and its DM-RS sequences (TS 38.211 Sections 7.3.1.1, 7.4.1.1.1;
 // reference: pdsch_modulator_impl.cpp:43-60, dmrs_pdsch_processor_impl.cpp:84-106).  The blocks after them:
 // transport-block CRC.
-__global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
+__device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid, uint32_t lane);
+
+__global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
+                                                                 uint32_t* __restrict__ d_grid)
 {
   __shared__ uint32_t lds[GOLD_RING_WORDS]; // Gold ring, or the CRC role's two tables and partials
+  // Third role, the workgroups behind the other two: the zero-fill waves (p.n_zero_in_prologue of them, four per workgroup)
+  // when they ride here instead of at the tail of the codeblock launch -- they depend on nothing, and this launch leaves
+  // most of the memory bandwidth unused.
+  if (blockIdx.x >= p.n_scr_work + p.n_crc_work) { // workgroup-uniform
+    const uint32_t item = (blockIdx.x - p.n_scr_work - p.n_crc_work) * (TB_CRC_THREADS / WAVE) +
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    if (item < p.n_zero_in_prologue) {
+      zero_wave(p, item, d_grid, threadIdx.x % WAVE);
+    }
+    return;
+  }
   static_assert(GOLD_RING_WORDS >= 2 * 1024 + TB_CRC_THREADS, "LDS of the CRC role");
   const uint32_t tid = threadIdx.x;
 
@@ -146,12 +160,14 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   }
 }
 
-hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream)
+hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, uint32_t* d_grid, hipStream_t stream)
 {
-  if (p.n_crc_work + p.n_scr_work == 0) {
+  const uint32_t zero_blocks = (p.n_zero_in_prologue + TB_CRC_THREADS / WAVE - 1u) / (TB_CRC_THREADS / WAVE);
+  if (p.n_crc_work + p.n_scr_work + zero_blocks == 0) {
     return hipSuccess;
   }
-  hipLaunchKernelGGL(prologue_kernel, dim3(p.n_crc_work + p.n_scr_work), dim3(TB_CRC_THREADS), 0, stream, p, d_tb);
+  hipLaunchKernelGGL(prologue_kernel, dim3(p.n_crc_work + p.n_scr_work + zero_blocks), dim3(TB_CRC_THREADS), 0, stream, p, d_tb,
+                     d_grid);
   return hipGetLastError();
 }
 
@@ -981,24 +997,35 @@ __device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_in
   const auto*    wkc  = to_constant(&p.zero_work[item_index]);
   const uint32_t seg_begin = wkc->seg_begin, seg_count = wkc->seg_count, seg_long = wkc->seg_long;
   uint32_t*      base = d_grid + ((size_t)wkc->grid * p.grid_nof_ports + wkc->port) * NRPHY_NSYMB * p.grid_nof_subc;
-  for (uint32_t i = 0; i != seg_long; ++i) { // long runs: the wave clears each one together, 16 bytes per lane and store
-    const auto*    sgc   = to_constant(&p.zero_segs[seg_begin + i]);
-    const uint32_t count = sgc->count;
-    uint32_t*      row   = base + (size_t)sgc->symbol * p.grid_nof_subc + sgc->k0;
-    // 16-byte chunks counted from the aligned address at or below the run's first word; the two chunks at the ends may
-    // be partial and go word by word.
-    const uint32_t off      = (uint32_t)((reinterpret_cast<uintptr_t>(row) >> 2) & 3u);
-    uint32_t*      aligned  = row - off;
-    const uint32_t n_chunks = (off + count + 3u) >> 2;
-    for (uint32_t c = lane; c < n_chunks; c += WAVE) {
-      const uint32_t lo = 4u * c;
-      if (lo >= off && lo + 4u <= off + count) {
-        *reinterpret_cast<uint4*>(aligned + lo) = make_uint4(0u, 0u, 0u, 0u);
-      } else {
+  // Long runs: the wave clears each one together, 16 bytes per lane and store.  The run descriptors are fetched 64 at a time,
+  // one per lane, and handed round with v_readlane: read one by one through the scalar cache, every run began with a trip to
+  // memory (a wave's two dozen runs took 30 us, and the zero-fill waves are the tail of their launch).
+  static_assert(sizeof(ZeroSeg) == 8, "one run descriptor per lane as two dwords");
+  for (uint32_t first = 0; first < seg_long; first += WAVE) {
+    const uint32_t n = seg_long - first < WAVE ? seg_long - first : WAVE;
+    uint2          d = make_uint2(0u, 0u);
+    if (lane < n) {
+      d = *reinterpret_cast<const uint2*>(&p.zero_segs[seg_begin + first + lane]);
+    }
+    for (uint32_t i = 0; i != n; ++i) {
+      const uint32_t lo_word = (uint32_t)__builtin_amdgcn_readlane((int)d.x, (int)i); // symbol | k0 << 16
+      const uint32_t count   = (uint32_t)__builtin_amdgcn_readlane((int)d.y, (int)i) & 0xFFFFu;
+      uint32_t*      row     = base + (size_t)(lo_word & 0xFFFFu) * p.grid_nof_subc + (lo_word >> 16);
+      // 16-byte chunks counted from the aligned address at or below the run's first word; the two chunks at the ends may
+      // be partial and go word by word.
+      const uint32_t off      = (uint32_t)((reinterpret_cast<uintptr_t>(row) >> 2) & 3u);
+      uint32_t*      aligned  = row - off;
+      const uint32_t n_chunks = (off + count + 3u) >> 2;
+      for (uint32_t c = lane; c < n_chunks; c += WAVE) {
+        const uint32_t lo = 4u * c;
+        if (lo >= off && lo + 4u <= off + count) {
+          *reinterpret_cast<uint4*>(aligned + lo) = make_uint4(0u, 0u, 0u, 0u);
+        } else {
 #pragma unroll
-        for (uint32_t w = 0; w != 4; ++w) {
-          if (lo + w >= off && lo + w < off + count) {
-            aligned[lo + w] = 0u;
+          for (uint32_t w = 0; w != 4; ++w) {
+            if (lo + w >= off && lo + w < off + count) {
+              aligned[lo + w] = 0u;
+            }
           }
         }
       }
