@@ -1482,15 +1482,6 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.zero_segs          = plan->d_zero_segs;
   p.scr                = plan->d_scr;
   p.n_zero_work        = (d_grid != nullptr && zero_grids) ? plan->n_zero_work : 0;
-  p.n_zero_in_prologue = 0;
-  {
-    // NRPHY_ZERO_IN_PROLOGUE=1: the zero-fill waves in the prologue launch instead of at the tail of the codeblock launch.
-    static const char* zp_env = std::getenv("NRPHY_ZERO_IN_PROLOGUE");
-    if (zp_env != nullptr && zp_env[0] == '1') {
-      p.n_zero_in_prologue = p.n_zero_work;
-      p.n_zero_work        = 0;
-    }
-  }
   p.n_dmrs_in_launch   = merge_dmrs ? plan->n_dmrs : 0;
   p.n_pdu          = (uint32_t)plan->pdus.size();
   p.n_work         = plan->n_work;
@@ -1516,7 +1507,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     ev = &plan->events[4 * plan->timed_runs++];
     HIP_TRY(hipEventRecord(ev[0], s));
   }
-  HIP_TRY(launch_prologue(p, d_tb, (uint32_t*)d_grid, s));
+  HIP_TRY(launch_prologue(p, d_tb, s));
   if (ev) {
     HIP_TRY(hipEventRecord(ev[1], s));
   }

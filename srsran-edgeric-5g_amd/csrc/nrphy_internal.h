@@ -195,8 +195,7 @@ struct ZeroWork {
 struct PdschLaunch {
   const ZeroWork*    zero_work;
   const ZeroSeg*     zero_segs;
-  uint32_t           n_zero_work;     // zero-fill waves appended to the codeblock launch (0: caller cleared the grids, or ...)
-  uint32_t           n_zero_in_prologue; // ... the zero-fill waves ride in the prologue launch instead
+  uint32_t           n_zero_work;     // zero-fill waves appended to the codeblock launch (0: caller cleared the grids)
   uint32_t           n_dmrs_in_launch; // DM-RS waves appended to the codeblock launch (0: separate launch)
   uint32_t*          scr;             // scrambling sequences c(n) of every PDU, MSB-first words (prologue -> codeblocks)
   const PduDev*      pdus;
@@ -224,7 +223,7 @@ struct PdschLaunch {
 };
 
 // Kernel launchers (defined in the .hip files).
-hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, uint32_t* d_grid, hipStream_t stream);
+hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream);
 // Work items are sorted by bucket = (modulation order, layers): one output-stage specialisation each.
 constexpr uint32_t CB_BUCKETS        = 16;
 constexpr uint32_t CB_MIXED_MAX_WORK = 4096; // a mixed plan below this many work items takes the one-launch mixed kernel

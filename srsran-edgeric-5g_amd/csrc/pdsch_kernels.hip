@@ -49,23 +49,9 @@ __device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t re
 // Blocks [0, n_scr_work): a share of the scrambling sequence of one PDU, and its DM-RS sequences (TS 38.211 Sections 7.3.1.1, 7.4.1.1.1;
 // reference: pdsch_modulator_impl.cpp:43-60, dmrs_pdsch_processor_impl.cpp:84-106).  The blocks after them:
 // transport-block CRC.
-__device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_index, uint32_t* __restrict__ d_grid, uint32_t lane);
-
-__global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
-                                                                 uint32_t* __restrict__ d_grid)
+__global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
 {
   __shared__ uint32_t lds[GOLD_RING_WORDS]; // Gold ring, or the CRC role's two tables and partials
-  // Third role, the workgroups behind the other two: the zero-fill waves (p.n_zero_in_prologue of them, four per workgroup)
-  // when they ride here instead of at the tail of the codeblock launch -- they depend on nothing, and this launch leaves
-  // most of the memory bandwidth unused.
-  if (blockIdx.x >= p.n_scr_work + p.n_crc_work) { // workgroup-uniform
-    const uint32_t item = (blockIdx.x - p.n_scr_work - p.n_crc_work) * (TB_CRC_THREADS / WAVE) +
-                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
-    if (item < p.n_zero_in_prologue) {
-      zero_wave(p, item, d_grid, threadIdx.x % WAVE);
-    }
-    return;
-  }
   static_assert(GOLD_RING_WORDS >= 2 * 1024 + TB_CRC_THREADS, "LDS of the CRC role");
   const uint32_t tid = threadIdx.x;
 
@@ -160,14 +146,15 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   }
 }
 
-hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, uint32_t* d_grid, hipStream_t stream)
+hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream)
 {
-  const uint32_t zero_blocks = (p.n_zero_in_prologue + TB_CRC_THREADS / WAVE - 1u) / (TB_CRC_THREADS / WAVE);
-  if (p.n_crc_work + p.n_scr_work + zero_blocks == 0) {
+  if (p.n_crc_work + p.n_scr_work == 0) {
     return hipSuccess;
   }
-  hipLaunchKernelGGL(prologue_kernel, dim3(p.n_crc_work + p.n_scr_work + zero_blocks), dim3(TB_CRC_THREADS), 0, stream, p, d_tb,
-                     d_grid);
+  // (The zero-fill waves were tried as a third role of this launch, which leaves most of the memory bandwidth unused: the
+  // prologue 0.084 -> 0.095 ms, the codeblock launch 0.303 -> 0.352 ms, the OFDM launch 0.50 -> 0.475 ms, the whole step
+  // -4 %: profiles/r03_codeblock_experiments.txt.  They stay at the tail of the codeblock launch.)
+  hipLaunchKernelGGL(prologue_kernel, dim3(p.n_crc_work + p.n_scr_work), dim3(TB_CRC_THREADS), 0, stream, p, d_tb);
   return hipGetLastError();
 }
 
