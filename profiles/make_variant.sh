@@ -13,8 +13,9 @@ for SRC in $SRCS; do
   CONTRACT=-ffp-contract=off
   [ "$SRC" = ofdm_kernels.hip ] && CONTRACT=-ffp-contract=fast
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Iinclude -I$C $CONTRACT $EXTRA -x hip -c $C/$SRC -o build/variants/$NAME.${SRC%.*}.o
-  OBJS=$(echo "$OBJS" | grep -v "/${SRC%.*}.o")
-  OBJS="$OBJS build/variants/$NAME.${SRC%.*}.o"
+  OBJS=$(echo "$OBJS" | tr ' ' '\n' | grep -v "/${SRC%.*}.o$")
+  OBJS="$OBJS
+build/variants/$NAME.${SRC%.*}.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/$NAME.so $OBJS
 rm -f build/variants/$NAME.*.o

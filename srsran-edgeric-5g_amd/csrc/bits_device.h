@@ -265,8 +265,11 @@ __device__ inline void gold_sequence_wave(const GoldTables* gold, const uint32_t
 // m = 64 on every step produces 1792 words from a 4096-word LDS ring.  The steps synchronise on LDS only; the x1
 // words of a block are requested one step before they are needed and the block is written out one step after it was
 // computed, so no step waits for global memory.
-constexpr uint32_t GOLD_RING_WORDS = 4096;
-constexpr uint32_t GOLD_MAX_LEVEL  = 64;
+#ifndef NRPHY_GOLD_LEVEL
+#define NRPHY_GOLD_LEVEL 64 // top level m of the lifted recurrence: 28 m words per step from a ring of 64 m words (>= 59 m)
+#endif
+constexpr uint32_t GOLD_MAX_LEVEL  = NRPHY_GOLD_LEVEL;
+constexpr uint32_t GOLD_RING_WORDS = 64 * GOLD_MAX_LEVEL;
 
 // Workgroup barrier that orders LDS accesses only (a __syncthreads() would also drain the global loads and stores).
 __device__ __forceinline__ void lds_barrier()
