@@ -440,6 +440,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary entries (configs 2, 4, 5, wire format)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch, sharding and aggregation only (gloo, no device work): the N-rank path on a machine without GPUs")
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="rehearsal of the N-rank path on a ONE-GPU box: every rank works on cuda:0 and the process group is gloo "
+                         "(RCCL refuses two ranks on one device); the line says so and is not a scaling measurement")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be at least 1")
@@ -473,15 +476,20 @@ def main():
     import cases
     lib = backends.pkg.lib
 
+    if args.rehearse_one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
         # under torch.distributed.run, also at N=1: RCCL initialisation, barrier and the totals' all-reduce all run
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     env = {"torch": torch, "lib": lib, "abi": backends.abi, "cases": cases, "sharding": backends.pkg.sharding,
            "ctx": lib.Context(local_rank), "dist": dist, "rank": rank, "world": world,
-           "device": torch.device("cuda", local_rank)}
+           "device": torch.device("cpu") if args.rehearse_one_device else torch.device("cuda", local_rank)}
 
     head = run_downlink(env, args.config, args.slots, args.steps, args.warmup, wire=args.wire)
     if rank == 0:
@@ -494,7 +502,9 @@ def main():
             "data": "synthetic",
         }
         out.update({k: v for k, v in head.items() if k not in out})
-        out["collective_backend"] = "rccl (torch.distributed nccl)" if dist is not None else "none (single process)"
+        out["collective_backend"] = ("none (single process)" if dist is None else
+                                     "gloo (rehearsal: %d ranks on ONE device, not a scaling measurement)" % world
+                                     if args.rehearse_one_device else "rccl (torch.distributed nccl)")
     sec = {}
     s_steps, s_warm = max(3, args.steps), max(3, args.warmup)  # the same count as the headline: short runs read 5-10 % slow
     if world == 1 and not args.no_secondary and args.config == 3 and not args.wire:
