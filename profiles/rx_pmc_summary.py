@@ -17,7 +17,7 @@ def decoder_means(d):
     for path in glob.glob("%s/%s/*/*counter_collection.csv" % (root, d)):
         per = defaultdict(float)
         for row in csv.DictReader(open(path)):
-            if "ldpc_decode_kernel" in row["Kernel_Name"]:
+            if "ldpc_decode" in row["Kernel_Name"]:
                 per[(row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
         for (disp, c), v in per.items():
             acc[c].append(v)
