@@ -1494,6 +1494,13 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     // Profiling aid: stop the codeblock waves after a stage to time the stages apart (outputs are then incomplete).
     static const char* stage_env = std::getenv("NRPHY_PROFILE_STAGE");
     p.profile_stage              = stage_env ? (uint32_t)std::atoi(stage_env) : 0;
+    // Store policy of the DM-RS / zero-fill waves at the tail of the codeblock launch: NRPHY_EXTRAS_NT=1 makes them non-temporal.
+    // Off by default -- A/B on two boxes (profiles/r03_codeblock_experiments.txt): it moves time from the OFDM launch to the
+    // codeblock launch (+0.013 / -0.024 ms on a box with a slow OFDM launch: whole step +1.2 %; on a fast one and on config 4: 0 ... -1 %).
+    // (Placing those waves first or between the codeblock waves instead: the codeblock launch 0.44 / 0.46 ms -- their stores push
+    // the transport blocks and sequences out of the cache.)
+    static const char* nt_env = std::getenv("NRPHY_EXTRAS_NT");
+    p.extras_nt               = nt_env ? (uint32_t)std::atoi(nt_env) : 0;
   }
   const size_t cw_bytes = (size_t)(plan->cw_bits / 8);
   if (d_cw_rm) {

@@ -870,13 +870,21 @@ __device__ __forceinline__ void dmrs_port_words(float dr, float di, bool odd, ui
 
 // Both CDM groups of a pilot position are neighbours in the grid (subcarriers 2k', 2k' + 1, 8-byte aligned): one
 // 8-byte store per lane makes the wave's store contiguous instead of every other word.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// nt: non-temporal (the launch's DM-RS and zero-fill stores: see PdschLaunch::extras_nt).
 template <int L>
-__device__ __forceinline__ void dmrs_store(uint32_t* out, const uint32_t (&word)[(L + 1) / 2], bool zero_other_group)
+__device__ __forceinline__ void dmrs_store(uint32_t* out, const uint32_t (&word)[(L + 1) / 2], bool zero_other_group, bool nt = false)
 {
-  if ((L + 1) / 2 == 2) {
-    *reinterpret_cast<uint2*>(out) = make_uint2(word[0], word[(L + 1) / 2 - 1]);
-  } else if (zero_other_group) { // wave-uniform: the reserved, pilot-less neighbour RE is zero
-    *reinterpret_cast<uint2*>(out) = make_uint2(word[0], 0u);
+  if ((L + 1) / 2 == 2 || zero_other_group) { // (zero_other_group is wave-uniform: the reserved, pilot-less neighbour RE is zero)
+    const u32x2_t v = {word[0], (L + 1) / 2 == 2 ? word[(L + 1) / 2 - 1] : 0u};
+    if (nt) {
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x2_t*>(out));
+    } else {
+      *reinterpret_cast<u32x2_t*>(out) = v;
+    }
+  } else if (nt) {
+    __builtin_nontemporal_store(word[0], out);
   } else {
     out[0] = word[0];
   }
@@ -943,7 +951,7 @@ __device__ __forceinline__ void dmrs_items(const PdschLaunch& p, PduRef pd, cons
         if ((L + 1) / 2 == 2) {
           words[(L + 1) / 2 - 1] = tab[(variant * NRPHY_MAX_PORTS + port) * 2u + 1u];
         }
-        dmrs_store<L>(out + port * port_stride, words, zero_other);
+        dmrs_store<L>(out + port * port_stride, words, zero_other, p.extras_nt != 0);
       }
       continue;
     }
@@ -1006,7 +1014,11 @@ __device__ __forceinline__ void zero_wave(const PdschLaunch& p, uint32_t item_in
       for (uint32_t c = lane; c < n_chunks; c += WAVE) {
         const uint32_t lo = 4u * c;
         if (lo >= off && lo + 4u <= off + count) {
+          if (p.extras_nt != 0) {
+          __builtin_nontemporal_store(u32x4_t{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4_t*>(aligned + lo));
+        } else {
           *reinterpret_cast<uint4*>(aligned + lo) = make_uint4(0u, 0u, 0u, 0u);
+        }
         } else {
 #pragma unroll
           for (uint32_t w = 0; w != 4; ++w) {
