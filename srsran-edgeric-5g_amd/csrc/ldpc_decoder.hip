@@ -606,7 +606,7 @@ hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStrea
     return hipSuccess;
   }
   // NRPHY_DECODER_PAIRS=0: one check per lane whatever the lifting size (A/B runs; the results are identical).
-  static const char* pairs_env = std::getenv("NRPHY_DECODER_PAIRS");
+  const char*        pairs_env = std::getenv("NRPHY_DECODER_PAIRS"); // (read per launch: the tests run both kernels in one process)
   const bool         pairs     = (p.zc & 1u) == 0 && p.zc >= 4u && !(pairs_env != nullptr && pairs_env[0] == '0');
   const uint32_t     checks    = pairs ? p.zc / 2u : p.zc;
   const uint32_t     threads   = ((checks + WAVE - 1) / WAVE) * WAVE;

@@ -682,8 +682,15 @@ def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
 # LDPC decoder ("next" row, receive side): bit-exact hard bits and iteration counts against the oracle, which is pinned
 # to the reference's generic decoder (tests/test_oracle.py)
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pairs", [None, "0"])
 @pytest.mark.parametrize("case", cases.LDPC_DECODE_CASES)
-def test_ldpc_decoder_vs_oracle(gpu_ctx, oracle, case):
+def test_ldpc_decoder_vs_oracle(gpu_ctx, oracle, case, pairs, monkeypatch):
+    """Both decoder kernels: two checks per lane in packed 16-bit arithmetic (the default for even lifting sizes) and one check
+    per lane (NRPHY_DECODER_PAIRS=0, read per launch) -- hard bits and iteration counts of both equal the oracle's."""
+    if pairs is None:
+        monkeypatch.delenv("NRPHY_DECODER_PAIRS", raising=False)
+    else:
+        monkeypatch.setenv("NRPHY_DECODER_PAIRS", pairs)
     bg, zc, extra, tail, crc_id, filler, amp, sigma = case
     rng = np.random.default_rng(zc * 1000 + extra)
     nof_llr = cases.ldpc_decode_nof_llr(case)
