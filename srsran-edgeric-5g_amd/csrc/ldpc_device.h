@@ -79,6 +79,34 @@ __device__ __forceinline__ void stage_graph(const LiftedGraph* g, uint32_t nof_r
   }
 }
 
+// The same in two halves, so that the trip to memory can be started long before the LDS region is free: fetch() requests the
+// rows into registers, store() puts them into LDS.
+struct GraphRows {
+  static constexpr uint32_t TRIPS = (MAX_BG_EDGES + WAVE - 1) / WAVE; // 5
+  uint32_t row_ptr, nedges, edge[TRIPS];
+  __device__ __forceinline__ void fetch(const LiftedGraph* g, uint32_t nof_rows, uint32_t lane)
+  {
+    row_ptr = lane <= nof_rows ? g->row_ptr[lane] : 0u;
+    nedges  = g->row_ptr[nof_rows];
+#pragma unroll
+    for (uint32_t k = 0; k != TRIPS; ++k) {
+      edge[k] = lane + WAVE * k < nedges ? g->edge[lane + WAVE * k] : 0u;
+    }
+  }
+  __device__ __forceinline__ void store(uint32_t nof_rows, uint32_t* gbuf, uint32_t lane) const
+  {
+    if (lane <= nof_rows) {
+      gbuf[lane] = row_ptr;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k != TRIPS; ++k) {
+      if (lane + WAVE * k < nedges) {
+        gbuf[LDPC_GRAPH_ROWPTR + lane + WAVE * k] = edge[k];
+      }
+    }
+  }
+};
+
 // XOR over the edges of check row m of the rotated blocks, word j.
 template <bool ALIGNED>
 __device__ __forceinline__ uint32_t row_word(const uint32_t* gbuf, const uint32_t* lin, uint32_t zc, uint32_t m,

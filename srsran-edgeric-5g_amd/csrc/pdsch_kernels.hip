@@ -481,6 +481,13 @@ __device__ __forceinline__ void phase_a(const PdschLaunch& p, PduRef pd, const C
   const RmIndex  rm   = rm_index_init(pd);
   const uint32_t s0   = wk.re_begin * L;             // first modulation symbol of the chunk (multiple of 32)
   const uint32_t nblk = (wk.re_count * L + 31u) >> 5;
+  // The modulation table's trip to memory starts here and ends behind the two passes below.
+  constexpr uint32_t LUT_TRIPS = ((1u << QM) + WAVE - 1u) / WAVE;
+  float2             lut[LUT_TRIPS];
+#pragma unroll
+  for (uint32_t k = 0; k != LUT_TRIPS; ++k) {
+    lut[k] = lane + WAVE * k < (1u << QM) ? p.gold->qam_lut[QM / 2 - 1][lane + WAVE * k] : make_float2(0.f, 0.f);
+  }
 #if NRPHY_PHASE_A_STAGED
   // Two passes over the wave's 64 lanes instead of one lane per block (a 281-RE codeblock has 36 blocks: 36 busy lanes doing
   // Qm gathers and four transpositions each).  First the Qm * nblk row words, one gather per item, into the block's eight
@@ -530,9 +537,12 @@ __device__ __forceinline__ void phase_a(const PdschLaunch& p, PduRef pd, const C
   if (lane < 8) {
     sh.symb[8u * nblk + lane] = 0; // read-ahead padding
   }
-  // Modulation table (the CRC table it shares LDS with is no longer needed).
-  for (uint32_t i = lane; i < (1u << QM); i += WAVE) {
-    reinterpret_cast<float2*>(sh.u)[i] = p.gold->qam_lut[QM / 2 - 1][i];
+  // Modulation table, requested before the gathers (`lut` above), into the scratch region behind the symbol bytes' use of it.
+#pragma unroll
+  for (uint32_t k = 0; k != LUT_TRIPS; ++k) {
+    if (lane + WAVE * k < (1u << QM)) {
+      reinterpret_cast<float2*>(sh.u)[lane + WAVE * k] = lut[k];
+    }
   }
   wave_sync();
 }
@@ -1115,14 +1125,16 @@ __device__ __forceinline__ bool codeblock_front(const PdschLaunch& p, PduRef pd,
     return false;
   }
   const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
+  // The graph rows are requested now and stored where the CRC tables were once the codeblock is built: their trip to memory
+  // rides under the segmentation and the CRC instead of standing between the CRC and the encoder.
+  GraphRows rows;
+  rows.fetch(&p.graphs[pd.graph], pd.nof_rows, lane);
   build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), p.tb_crc_part, p.gold, &sh,
                   total_words, lane, p.profile_stage);
   if (p.profile_stage == 1 || p.profile_stage == 7) {
     return false;
   }
-  // The graph rows go where the CRC tables were (build_codeblock ends with a wave barrier); ldpc_encode_wave synchronises
-  // before it reads them.
-  stage_graph(&p.graphs[pd.graph], pd.nof_rows, sh.graph, lane);
+  rows.store(pd.nof_rows, sh.graph, lane); // (build_codeblock ends with a wave barrier; ldpc_encode_wave synchronises before it reads)
   ldpc_encode_wave(&p.graphs[pd.graph], sh.graph, kb, zc, pd.nof_rows, sh.lin, sh.u, sh.ldpc, lane);
   return p.profile_stage != 2;
 }
