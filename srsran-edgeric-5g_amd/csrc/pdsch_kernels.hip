@@ -208,6 +208,13 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
   const uint32_t used    = pd.info_bits - (last ? pd.tb_crc_bits + pd.zero_pad : 0u);
   const uint32_t tb_pos  = cb * pd.info_bits;
   const uint32_t tb_bits = pd.tb_bytes * 8u;
+  // The CRC's byte tables (16 bytes per lane and step) are requested first and stored behind the segmentation
+  // (unconditionally: a transport block of one codeblock carries no codeblock CRC and simply does not use them).
+  const uint4* crc_src = reinterpret_cast<const uint4*>(&tables->crc24b_slice[0][0]);
+  const uint4  crc_tab0 = crc_src[lane], crc_tab1 = crc_src[lane + WAVE], crc_tab2 = crc_src[lane + 2 * WAVE];
+#if NRPHY_CRC_SLICES == 4
+  const uint4 crc_tab3 = crc_src[lane + 3 * WAVE];
+#endif
   // The transport-block words of SEG_UNROLL trips are requested before the first is used: taken trip by trip, every trip
   // waited out a trip to memory (stage timing: this loop alone cost 0.045 ms per 1024 slots for a hundred instructions).
   constexpr uint32_t SEG_UNROLL = 5; // 320 words: a whole high-rate codeblock with its four core parity blocks
@@ -243,13 +250,14 @@ __device__ inline void build_codeblock(PduRef pd, uint32_t cb, const uint32_t* t
       }
     }
   }
-  if (pd.cb_crc_bits) { // the CRC's byte tables, 16 bytes per lane and step
-    const uint4* src = reinterpret_cast<const uint4*>(&tables->crc24b_slice[0][0]);
-    uint4*       dst = reinterpret_cast<uint4*>(sh->u);
-#pragma unroll
-    for (int k = 0; k != NRPHY_CRC_SLICES; ++k) {
-      dst[lane + WAVE * k] = src[lane + WAVE * k];
-    }
+  {
+    uint4* dst           = reinterpret_cast<uint4*>(sh->u);
+    dst[lane]            = crc_tab0;
+    dst[lane + WAVE]     = crc_tab1;
+    dst[lane + 2 * WAVE] = crc_tab2;
+#if NRPHY_CRC_SLICES == 4
+    dst[lane + 3 * WAVE] = crc_tab3;
+#endif
   }
   wave_sync();
   if (profile_stage == 7) {
@@ -587,12 +595,35 @@ __device__ __forceinline__ void re_bits(const PdschLaunch& p, const uint32_t* __
   }
 }
 
+// The L * Qm scrambling bits of RE r of the chunk (the prologue's x2 part + the shared x1 part; MSB first), zero beyond the
+// chunk.  L * Qm = 32 with a word-aligned chunk (the headline shape) makes them one word of each.
+template <int QM, int L>
+__device__ __forceinline__ uint32_t scrambling_bits(const PdschLaunch& p, const uint32_t* __restrict__ scr, const ChunkGeom& g,
+                                                    const ChunkMap& cm, uint32_t re_count, uint32_t r)
+{
+  uint32_t bits = 0;
+  if (r < re_count) {
+    if (QM * L == 32 && cm.aligned) { // wave-uniform: scalar base, small per-lane index
+      bits = (scr + cm.word0)[r];
+      if (NRPHY_SCR_X2_ONLY) {
+        bits ^= (p.x1_words + cm.word0)[r];
+      }
+    } else {
+      bits = ext32(scr, g.bit0 + r * (uint32_t)(QM * L));
+      if (NRPHY_SCR_X2_ONLY) {
+        bits ^= ext32(p.x1_words, g.bit0 + r * (uint32_t)(QM * L));
+      }
+    }
+  }
+  return bits;
+}
+
 // The grid loop of phase B for P ports with wideband precoding (every weight in a scalar register pair for the whole
 // loop, no guards, no loads), or -- P = 0 -- for any port count with weights per PRG read from memory per RE.
 template <int QM, int L, int P>
 __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, const PduDev* __restrict__ pd_global,
                                              const CbWork& wk, const CbShared& sh, const ChunkGeom& g, const ChunkMap& cm,
-                                             uint32_t lane, uint32_t* __restrict__ d_grid)
+                                             uint32_t first_gbits, uint32_t lane, uint32_t* __restrict__ d_grid)
 {
   const uint32_t* __restrict__ scr = p.scr + pd.scr_offset;
   const size_t   grid_base   = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
@@ -631,36 +662,14 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
   uint32_t cur_start = pd.sym_re_start[l_cur], cur_end = pd.sym_re_start[l_cur + 1u];
   uint32_t cur_arg = pd.sym_arg[l_cur], cur_row = l_cur * p.grid_nof_subc;
   bool     cur_table = pd.sym_kind[l_cur] == SYM_TABLE;
-  // The chunk's scrambling words: scalar base, small per-lane index.
-  const uint32_t* __restrict__ scr_chunk = scr + cm.word0;
-  const uint32_t* __restrict__ x1_chunk  = p.x1_words + cm.word0;
-
-  // The RE's L * Qm scrambling bits (the prologue's x2 part + the shared x1 part; MSB first).  L * Qm = 32 with a word-aligned
-  // chunk (the headline shape) makes them one word of each.  They come from global memory (L2), so the words of the NEXT
-  // 64 RE are requested before this trip's arithmetic starts.
-  auto scrambling_bits = [&](uint32_t r) -> uint32_t {
-    uint32_t bits = 0;
-    if (r < wk.re_count) {
-      if (QM * L == 32 && cm.aligned) { // wave-uniform
-        bits = scr_chunk[r];
-        if (NRPHY_SCR_X2_ONLY) {
-          bits ^= x1_chunk[r];
-        }
-      } else {
-        bits = ext32(scr, g.bit0 + r * (uint32_t)(QM * L));
-        if (NRPHY_SCR_X2_ONLY) {
-          bits ^= ext32(p.x1_words, g.bit0 + r * (uint32_t)(QM * L));
-        }
-      }
-    }
-    return bits;
-  };
-  uint32_t gbits_next = scrambling_bits(lane);
+  // The scrambling bits come from global memory (L2): the words of the NEXT 64 RE are requested before a trip's arithmetic
+  // starts, those of the first 64 RE were requested before rate matching (map_chunk).
+  uint32_t gbits_next = first_gbits;
 
   for (uint32_t r0 = 0; r0 < wk.re_count; r0 += WAVE) { // r0 is wave-uniform
     const uint32_t r        = r0 + lane;
     const uint32_t gbits    = gbits_next;
-    gbits_next              = scrambling_bits(r + WAVE);
+    gbits_next              = scrambling_bits<QM, L>(p, scr, g, cm, wk.re_count, r + WAVE);
     const uint32_t re_first = cm.re0 + r0;
     const uint32_t re_last  = re_first + ((wk.re_count - r0 < WAVE ? wk.re_count - r0 : WAVE) - 1u);
     if (re_first >= cur_end && l_cur + 1u < NRPHY_NSYMB) { // wave-uniform
@@ -753,15 +762,11 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
 
 template <int QM, int L>
 __device__ __forceinline__ void phase_b(const PdschLaunch& p, PduRef pd, const PduDev* __restrict__ pd_global,
-                                        const CbWork& wk, const CbShared& sh, const ChunkGeom& g, uint32_t lane,
-                                        uint32_t* __restrict__ d_grid, uint32_t* __restrict__ d_cw_rm,
-                                        uint32_t* __restrict__ d_cw_scr)
+                                        const CbWork& wk, const CbShared& sh, const ChunkGeom& g, const ChunkMap& cm,
+                                        uint32_t first_gbits, uint32_t lane, uint32_t* __restrict__ d_grid,
+                                        uint32_t* __restrict__ d_cw_rm, uint32_t* __restrict__ d_cw_scr)
 {
   constexpr uint32_t LQ = QM * L;
-  ChunkMap           cm;
-  cm.re0     = g.cw_cb / LQ + wk.re_begin;
-  cm.word0   = g.bit0 >> 5;
-  cm.aligned = (g.bit0 & 31u) == 0;
   // Codeword taps (parity tests, seam B): a loop of their own, so that the grid loop carries none of this.
   if (d_cw_rm != nullptr || d_cw_scr != nullptr) { // wave-uniform
     const uint32_t* __restrict__ scr = p.scr + pd.scr_offset;
@@ -789,15 +794,15 @@ __device__ __forceinline__ void phase_b(const PdschLaunch& p, PduRef pd, const P
   // One copy of the grid loop per port count (wave-uniform): straight-line port code with its weights in registers.
   const uint32_t nof_ports = pd.nof_prg == 1 ? pd.nof_ports : 0u;
   if (nof_ports == 4u) {
-    phase_b_grid<QM, L, 4>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid);
+    phase_b_grid<QM, L, 4>(p, pd, pd_global, wk, sh, g, cm, first_gbits, lane, d_grid);
   } else if (L <= 3 && nof_ports == 3u) {
-    phase_b_grid<QM, (L <= 3 ? L : 1), 3>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid);
+    phase_b_grid<QM, (L <= 3 ? L : 1), 3>(p, pd, pd_global, wk, sh, g, cm, first_gbits, lane, d_grid);
   } else if (L <= 2 && nof_ports == 2u) {
-    phase_b_grid<QM, (L <= 2 ? L : 1), 2>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid);
+    phase_b_grid<QM, (L <= 2 ? L : 1), 2>(p, pd, pd_global, wk, sh, g, cm, first_gbits, lane, d_grid);
   } else if (L == 1 && nof_ports == 1u) {
-    phase_b_grid<QM, 1, 1>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid);
+    phase_b_grid<QM, 1, 1>(p, pd, pd_global, wk, sh, g, cm, first_gbits, lane, d_grid);
   } else {
-    phase_b_grid<QM, L, 0>(p, pd, pd_global, wk, sh, g, cm, lane, d_grid); // weights per PRG (or fewer ports than layers)
+    phase_b_grid<QM, L, 0>(p, pd, pd_global, wk, sh, g, cm, first_gbits, lane, d_grid); // weights per PRG (or fewer ports than layers)
   }
 }
 
@@ -815,6 +820,12 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   if (p.profile_stage == 3) {
     return;
   }
+  ChunkMap cm;
+  cm.re0     = g.cw_cb / (uint32_t)(QM * L) + wk.re_begin;
+  cm.word0   = g.bit0 >> 5;
+  cm.aligned = (g.bit0 & 31u) == 0;
+  // The scrambling bits of the chunk's first 64 RE are requested here: their trip to memory rides under rate matching.
+  const uint32_t first_gbits = scrambling_bits<QM, L>(p, p.scr + pd.scr_offset, g, cm, wk.re_count, lane);
   {
     const RmIndex rm = rm_index_init(pd);
     if (rm.rank0 + g.E > rm.n_valid) { // wave-uniform: the selection wraps around Ncb
@@ -826,7 +837,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   if (p.profile_stage == 4) {
     return;
   }
-  phase_b<QM, L>(p, pd, pd_global, wk, sh, g, lane, d_grid, d_cw_rm, d_cw_scr);
+  phase_b<QM, L>(p, pd, pd_global, wk, sh, g, cm, first_gbits, lane, d_grid, d_cw_rm, d_cw_scr);
 }
 
 template <int QM>
