@@ -220,6 +220,31 @@ __device__ __forceinline__ void pair_one_hot(uint32_t y, uint32_t& hot0, uint32_
   hot1              = (ha >> 16) | (hb & 0xFFFF0000u);
 }
 
+// The soft bits (or messages) of both checks on edges B .. B + 9 of a layer, read together and combined into packed pairs
+// (low halves: A | B << 16).  The empty asm statement makes all twenty values be in their registers at one point: without it
+// the compiler's scheduler sinks every pair of LDS reads to its use and reuses two temporaries -- a chain of DEG dependent LDS
+// round trips per pass (read, wait for everything, combine, read ...) instead of twenty reads in flight.
+template <uint32_t DEG, uint32_t B, typename AddrA, typename AddrB>
+__device__ __forceinline__ void load_pairs10(uint32_t (&out)[DEG], const int8_t* base, AddrA addr_a, AddrB addr_b)
+{
+  if constexpr (B < DEG) {
+    constexpr uint32_t N = DEG - B < 10u ? DEG - B : 10u;
+    uint32_t           va[10], vb[10];
+#pragma unroll
+    for (uint32_t k = 0; k != 10; ++k) {
+      const uint32_t t = k < N ? B + k : B + N - 1u;
+      va[k]            = (uint32_t)(int)base[addr_a(t)];
+      vb[k]            = (uint32_t)(int)base[addr_b(t)];
+    }
+    asm volatile("" ::"v"(va[0]), "v"(vb[0]), "v"(va[1]), "v"(vb[1]), "v"(va[2]), "v"(vb[2]), "v"(va[3]), "v"(vb[3]), "v"(va[4]), "v"(vb[4]),
+                 "v"(va[5]), "v"(vb[5]), "v"(va[6]), "v"(vb[6]), "v"(va[7]), "v"(vb[7]), "v"(va[8]), "v"(vb[8]), "v"(va[9]), "v"(vb[9]));
+#pragma unroll
+    for (uint32_t k = 0; k != N; ++k) {
+      out[B + k] = __builtin_amdgcn_perm(vb[k], va[k], 0x05040100u);
+    }
+  }
+}
+
 template <uint32_t DEG, uint32_t T, bool FIRST>
 struct PairEdges {
   // Pass 1 over edges T .. DEG - 1: v2c messages, running minima, sign bits.
@@ -273,11 +298,8 @@ __device__ __forceinline__ uint4 process_check_pair(int8_t* soft, const uint8_t*
     addr1[t]           = (e >> 16) + pos;              // the graph holds node * Zc
     addr2[t]           = addr1[t] + (pos < half ? half : minus_half); // (j + Zc / 2 + shift) mod Zc
   }
-#pragma unroll
-  for (uint32_t t = 0; t != DEG; ++t) {
-    const int va = soft[addr1[t]], vb = soft[addr2[t]];
-    a[t]         = __builtin_amdgcn_perm((uint32_t)vb, (uint32_t)va, 0x05040100u); // low halves: A | B << 16
-  }
+  load_pairs10<DEG, 0>(a, soft, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
+  load_pairs10<DEG, 10>(a, soft, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
   uint32_t m1 = 0, m2 = 0, hot0 = 0, hot1 = 0;
   if (!FIRST) {
     m1 = old.x & 0x00FF00FFu;
@@ -316,6 +338,197 @@ __device__ __forceinline__ uint4 process_layer_pair(uint32_t deg, int8_t* soft, 
     case 9: return process_check_pair<9, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
     case 10: return process_check_pair<10, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
     default: return process_check_pair<19, FIRST>(soft, scaled, edge, half, minus_half, j, jm, old);
+  }
+}
+
+// ---- Two checks per lane, check-to-variable messages kept per edge in LDS ------------------------------------------------
+// When the layers a codeblock needs are few enough (high code rates: BASELINE config 5 runs 4 layers of degree 19), the
+// messages of every edge fit the LDS next to the soft bits: one byte per (edge, check), the messages of two edges and the
+// two checks of a lane in one word -- bytes (edge t: check j, check j + Zc / 2; edge t + 1: the same), word r = t / 2 of a
+// layer at its row r, lane j.  The edge passes then read the old message instead of rebuilding it from a compressed record
+// (7 vector instructions per pair of checks and edge in the forward pass), the sign of a new message comes from the sign of
+// the variable-to-check value it answers (new = P * sign(x) * magnitude with P the parity of all signs, folded into the two
+// magnitudes once per layer), no record is packed, stored or prefetched, and the scaling of the minima is arithmetic where the
+// host has checked that it equals the table (a table look-up is one more LDS round trip per layer, and under this kernel's
+// LDS load a round trip costs several hundred cycles).  Same values as process_check_pair, operation for operation.
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c)
+{
+  uint32_t r;
+  asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+// llr_sub for both halves with the shift and the addition as one multiply-add.
+__device__ __forceinline__ s16x2 llr_sub_pair_mad(s16x2 a, s16x2 c, uint32_t k512)
+{
+  const s16x2 d   = clamp_s16x2(a - c, LLR_MAX_V);
+  const s16x2 big = a - clamp_s16x2(a, LLR_MAX_V); // 0, or +-1 for an infinite soft bit
+  return as_s16x2(pk_mad_i16(as_word(big), k512, as_word(d)));
+}
+__device__ __forceinline__ s16x2 llr_sub_pair_first_mad(s16x2 a, uint32_t k512)
+{
+  const s16x2 d = clamp_s16x2(a, LLR_MAX_V);
+  return as_s16x2(pk_mad_i16(as_word(a - d), k512, as_word(d)));
+}
+
+// scale_llr (ldpc_decoder_generic.cpp:69-79) of the magnitudes in bytes 1 and 3 of a pair of keys: A | B << 16.
+struct ScaleRule {
+  const uint8_t* table;      // round(m * scaling_factor), m = 0 .. LLR_MAX
+  float          factor;
+  bool           arithmetic; // (unsigned)(m * factor + 0.5f) equals the table for every m (checked by the host)
+  __device__ __forceinline__ uint32_t operator()(uint32_t keys) const
+  {
+    if (arithmetic) {
+      const float    a  = (float)((keys >> 8) & 0xFFu), b = (float)(keys >> 24);
+      const uint32_t ra = (uint32_t)__fadd_rn(__fmul_rn(a, factor), 0.5f), rb = (uint32_t)__fadd_rn(__fmul_rn(b, factor), 0.5f);
+      return ra | (rb << 16);
+    }
+    const uint32_t sa = table[(keys >> 8) & 0xFFu], sb = table[keys >> 24];
+    return sa | (sb << 16);
+  }
+};
+
+#ifdef NRPHY_DEC_TRACE
+struct Trace { uint64_t acc[10]; uint64_t last; };
+#define TR(k)                                                                                                        \
+  do {                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    if (tr != nullptr) {                                                                                             \
+      const uint64_t t_ = __builtin_readcyclecounter();                                                              \
+      tr->acc[k] += t_ - tr->last;                                                                                   \
+      tr->last = t_;                                                                                                 \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  } while (0)
+#else
+struct Trace;
+#define TR(k)
+#endif
+
+template <uint32_t DEG, uint32_t T, bool FIRST>
+struct LmEdges {
+  static __device__ __forceinline__ void forward(const uint32_t (&c)[DEG], uint32_t (&x)[DEG], uint32_t k512, uint32_t& k1, uint32_t& k2,
+                                                 uint32_t& par)
+  {
+    if constexpr (T < DEG) {
+      const s16x2 v = FIRST ? llr_sub_pair_first_mad(as_s16x2(x[T]), k512) : llr_sub_pair_mad(as_s16x2(x[T]), as_s16x2(c[T]), k512);
+      x[T]          = as_word(v);
+      const s16x2    mag = __builtin_elementwise_max(v, splat_s16(0) - v);
+      const uint32_t cap = as_word(__builtin_elementwise_min(as_u16x2(as_word(mag)), u16x2{255, 255}));
+      const uint32_t key = (cap << 8) | (T * 0x00010001u);
+      k2 = as_word(__builtin_elementwise_min(__builtin_elementwise_max(as_u16x2(key), as_u16x2(k1)), as_u16x2(k2)));
+      k1 = as_word(__builtin_elementwise_min(as_u16x2(key), as_u16x2(k1)));
+      par ^= as_word(v); // bit 15 of a half: parity of the negative values so far
+      LmEdges<DEG, T + 1, FIRST>::forward(c, x, k512, k1, k2, par);
+    }
+  }
+  // The new message of the pair on edge T and the soft bits it leads to; m1 / m2: the scaled minima of the pair with the
+  // parity of the signs applied (negative when odd).
+  static __device__ __forceinline__ uint32_t answer(int8_t* soft, const uint32_t (&addr1)[DEG], const uint32_t (&addr2)[DEG],
+                                                    const uint32_t (&x)[DEG], uint32_t m1, uint32_t m2, uint32_t hot0, uint32_t hot1)
+  {
+    const uint32_t s   = as_word(as_s16x2(x[T]) >> splat_s16(15)) | 0x00010001u; // -1 / +1: the sign of the value answered
+    const uint32_t sel = half_masks(T < 16u ? hot0 : hot1, T & 15u);
+    const uint32_t mag = __builtin_amdgcn_bitop3_b32(sel, m2, m1, 0xCA);
+    const s16x2    msg = as_s16x2(as_word(as_u16x2(mag) * as_u16x2(s)));
+    const uint32_t out = as_word(clamp_s16x2(msg + as_s16x2(x[T]), LLR_INF_V));
+    soft[addr1[T]]     = (int8_t)out;
+    soft[addr2[T]]     = (int8_t)(out >> 16);
+    return as_word(msg);
+  }
+  // Edges T and T + 1 (T even): new soft bits, and the word of their messages.
+  static __device__ __forceinline__ void backward(int8_t* soft, uint32_t* mrow, uint32_t row_words, const uint32_t (&addr1)[DEG],
+                                                  const uint32_t (&addr2)[DEG], const uint32_t (&x)[DEG], uint32_t m1, uint32_t m2,
+                                                  uint32_t hot0, uint32_t hot1)
+  {
+    if constexpr (T < DEG) {
+      const uint32_t lo = answer(soft, addr1, addr2, x, m1, m2, hot0, hot1);
+      uint32_t       hi = 0;
+      if constexpr (T + 1 < DEG) {
+        hi = LmEdges<DEG, T + 1, FIRST>::answer(soft, addr1, addr2, x, m1, m2, hot0, hot1);
+      }
+      mrow[(T / 2u) * row_words] = __builtin_amdgcn_perm(hi, lo, 0x06040200u); // bytes: A(T), B(T), A(T + 1), B(T + 1)
+      LmEdges<DEG, T + 2, FIRST>::backward(soft, mrow, row_words, addr1, addr2, x, m1, m2, hot0, hot1);
+    }
+  }
+};
+
+// mrow: the lane's word of the layer's first row of messages; row_words = Zc / 2 words per row.
+template <uint32_t DEG, bool FIRST>
+__device__ __forceinline__ void process_check_pair_lm(int8_t* soft, uint32_t* mrow, uint32_t row_words, const ScaleRule& scale,
+                                                      const NRPHY_CONSTANT uint32_t* edge, uint32_t half, uint32_t minus_half, uint32_t j,
+                                                      uint32_t jm, uint32_t k512, Trace* tr)
+{
+  constexpr uint32_t NP = (DEG + 1u) / 2u;
+  uint32_t           addr1[DEG], addr2[DEG], x[DEG], c[DEG], w[NP];
+  TR(0);
+  if (!FIRST) { // the lane's own words of old messages: on their way while the addresses are computed
+#pragma unroll
+    for (uint32_t r = 0; r != NP; ++r) {
+      w[r] = mrow[r * row_words];
+    }
+  }
+#pragma unroll
+  for (uint32_t t = 0; t != DEG; ++t) {
+    const uint32_t e = edge[t], shift = e & 0xFFFFu;
+    const uint32_t pos = min(j + shift, jm + shift);   // (j + shift) mod Zc
+    addr1[t]           = (e >> 16) + pos;              // the graph holds node * Zc
+    addr2[t]           = addr1[t] + (pos < half ? half : minus_half); // (j + Zc / 2 + shift) mod Zc
+  }
+  TR(1);
+  load_pairs10<DEG, 0>(x, soft, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
+  load_pairs10<DEG, 10>(x, soft, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
+  TR(2);
+  if (!FIRST) {
+#define NRPHY_IX(k) ((k) < NP ? (k) : NP - 1u)
+    asm volatile("" ::"v"(w[NRPHY_IX(0)]), "v"(w[NRPHY_IX(1)]), "v"(w[NRPHY_IX(2)]), "v"(w[NRPHY_IX(3)]), "v"(w[NRPHY_IX(4)]),
+                 "v"(w[NRPHY_IX(5)]), "v"(w[NRPHY_IX(6)]), "v"(w[NRPHY_IX(7)]), "v"(w[NRPHY_IX(8)]), "v"(w[NRPHY_IX(9)]));
+#undef NRPHY_IX
+    // bytes to packed 16-bit pairs, sign-extended by the permute itself: it takes a sign from bytes 1, 3, 5, 7 of its two
+    // sources, which the word and the word shifted by a byte place all four messages on
+#pragma unroll
+    for (uint32_t r = 0; r != NP; ++r) {
+      const uint32_t ws = w[r] << 8;
+      c[2u * r]         = __builtin_amdgcn_perm(w[r], ws, 0x0A050804u);
+      if (2u * r + 1u < DEG) {
+        c[2u * r + 1u] = __builtin_amdgcn_perm(w[r], ws, 0x0B070906u);
+      }
+    }
+  } else {
+#pragma unroll
+    for (uint32_t t = 0; t != DEG; ++t) {
+      c[t] = 0;
+    }
+  }
+  TR(3);
+  uint32_t k1 = (((uint32_t)LLR_MAX_V << 8) | 0xFFu) * 0x00010001u, k2 = k1, par = 0;
+  LmEdges<DEG, 0, FIRST>::forward(c, x, k512, k1, k2, par);
+  TR(4);
+  // scale_llr of the four minima; the sign of a message = parity of the OTHER signs
+  const uint32_t n1 = scale(k1), n2 = scale(k2);
+  const uint32_t pm = as_word(as_s16x2(par) >> splat_s16(15)); // 0xFFFF in a half with an odd number of negative values
+  const uint32_t m1 = as_word(as_s16x2(n1 ^ pm) - as_s16x2(pm)), m2 = as_word(as_s16x2(n2 ^ pm) - as_s16x2(pm));
+  uint32_t       hot0, hot1;
+  pair_one_hot(k1 & 0x00FF00FFu, hot0, hot1);
+  TR(5);
+  LmEdges<DEG, 0, FIRST>::backward(soft, mrow, row_words, addr1, addr2, x, m1, m2, hot0, hot1);
+  TR(6);
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void process_layer_pair_lm(uint32_t deg, int8_t* soft, uint32_t* mrow, uint32_t row_words, const ScaleRule& scale,
+                                                      const NRPHY_CONSTANT uint32_t* edge, uint32_t half, uint32_t minus_half, uint32_t j,
+                                                      uint32_t jm, uint32_t k512, Trace* tr)
+{
+  switch (deg) {
+    case 3: return process_check_pair_lm<3, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 4: return process_check_pair_lm<4, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 5: return process_check_pair_lm<5, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 6: return process_check_pair_lm<6, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 7: return process_check_pair_lm<7, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 8: return process_check_pair_lm<8, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 9: return process_check_pair_lm<9, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 10: return process_check_pair_lm<10, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
+    default: return process_check_pair_lm<19, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
   }
 }
 
@@ -384,7 +597,9 @@ __device__ __forceinline__ void store_record(uint4* rec, uint4 v) // a pair of c
 }
 
 // PAIR: two checks per lane (even lifting sizes: Zc / 2 threads per codeblock), see process_check_pair.
-template <bool PAIR>
+// LM: with the messages-per-edge-in-LDS path (for launches whose LDS was sized for it); both forms of the pair kernel hold the
+// record path, which a codeblock that needs more layers than expected falls back to.
+template <bool PAIR, bool LM = false>
 __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
 {
   extern __shared__ __attribute__((aligned(16))) int8_t dec_lds[];
@@ -401,8 +616,11 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
   const uint32_t half = zc >> 1;
   const bool    active = PAIR ? j < half : j < zc;
   const bool    pooled = p.nof_slots < gridDim.x; // fewer slots than codeblocks: claim one
-  if (j == 0) { // (read after the barriers below; the claim's latency hides behind the loads)
-    s_flag[3] = pooled ? acquire_slot(p.slot_flags, p.nof_slots, blockIdx.x) : blockIdx.x;
+  // With two checks per lane the messages may live in LDS instead (decided below, once the layers are known): the claim
+  // then waits until it is known to be needed; otherwise its latency hides behind the loads.
+  const bool    claim_late = LM && p.lm_lds_bytes != 0;
+  if (j == 0) { // (read after the barriers below)
+    s_flag[3] = pooled ? (claim_late ? 0xFFFFFFFFu : acquire_slot(p.slot_flags, p.nof_slots, blockIdx.x)) : blockIdx.x;
   }
 
   // load_soft_bits (ldpc_decoder_impl.cpp:128-164): two punctured nodes, then the input.  The last non-zero soft bit
@@ -411,32 +629,80 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
   const uint32_t T         = blockDim.x;
   const uint32_t clamp_end = (p.nof_llr / zc) * zc; // whole nodes
   const uint32_t lds_bytes = p.nof_nodes * zc + 48u;
-  for (uint32_t i = j; i < 2u * zc; i += T) {
-    soft[i] = 0;
+  if ((zc & 3u) == 0) { // (lds_bytes is a multiple of four then)
+    for (uint32_t i = 4u * j; i < 2u * zc; i += 4u * T) {
+      *reinterpret_cast<uint32_t*>(soft + i) = 0;
+    }
+    const uint32_t end = 2u * zc + p.nof_llr, up = (end + 3u) & ~3u;
+    if (j < up - end) {
+      soft[end + j] = 0;
+    }
+    for (uint32_t i = up + 4u * j; i < lds_bytes; i += 4u * T) {
+      *reinterpret_cast<uint32_t*>(soft + i) = 0;
+    }
+  } else {
+    for (uint32_t i = j; i < 2u * zc; i += T) {
+      soft[i] = 0;
+    }
+    for (uint32_t i = 2u * zc + p.nof_llr + j; i < lds_bytes; i += T) {
+      soft[i] = 0;
+    }
   }
-  for (uint32_t i = 2u * zc + p.nof_llr + j; i < lds_bytes; i += T) {
-    soft[i] = 0;
-  }
-  if (((reinterpret_cast<uintptr_t>(llr) | zc) & 3u) == 0) {
+  // One word of four soft bits (index `first` .. first + 3) as it goes into LDS.
+  auto convert_word = [&](uint32_t x, uint32_t first) -> uint32_t {
+    if (x == 0) { // (at high code rates most of the buffer: nothing received there yet)
+      return 0;
+    }
+    last_nz    = max(last_nz, first + 4u - ((uint32_t)__clz(x) >> 3));
+    uint32_t y = 0;
+#pragma unroll
+    for (uint32_t b = 0; b != 4; ++b) {
+      const int v = load_soft((int)(int8_t)(x >> (8u * b)), first + b < clamp_end);
+      y |= ((uint32_t)v & 0xFFu) << (8u * b);
+    }
+    return y;
+  };
+  if (((reinterpret_cast<uintptr_t>(llr) & 15u) | (zc & 7u)) == 0) {
+    // sixteen soft bits per lane and load, up to twelve (four) loads of a lane in flight: the whole codeblock in one or two trips to
+    // memory (four-byte loads unrolled by four took eight trips for a config-3 codeblock)
+    constexpr uint32_t U   = PAIR ? 12 : 4; // (the one-check kernel runs at 64 registers)
+    const uint32_t     nq  = p.nof_llr >> 4;
+    const uint4*       src = reinterpret_cast<const uint4*>(llr);
+    uint4*             dst = reinterpret_cast<uint4*>(soft + 2u * zc);
+    for (uint32_t q0 = j; q0 < nq; q0 += U * T) {
+      uint4 v[U];
+#pragma unroll
+      for (uint32_t u = 0; u != U; ++u) {
+        const uint32_t q = q0 + u * T;
+        v[u]             = q < nq ? src[q] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u != U; ++u) {
+        const uint32_t q = q0 + u * T;
+        if (q < nq) {
+          uint4 y = make_uint4(0, 0, 0, 0);
+          if ((v[u].x | v[u].y | v[u].z | v[u].w) != 0) {
+            y = make_uint4(convert_word(v[u].x, 16u * q), convert_word(v[u].y, 16u * q + 4u), convert_word(v[u].z, 16u * q + 8u),
+                           convert_word(v[u].w, 16u * q + 12u));
+          }
+          dst[q] = y;
+        }
+      }
+    }
+    const uint32_t i = 16u * nq + j; // (fewer than sixteen left)
+    if (i < p.nof_llr) {
+      const int v = llr[i];
+      last_nz     = v != 0 ? max(last_nz, i + 1u) : last_nz;
+      soft[2u * zc + i] = (int8_t)load_soft(v, i < clamp_end);
+    }
+  } else if (((reinterpret_cast<uintptr_t>(llr) | zc) & 3u) == 0) {
     // four soft bits per lane and load
     const uint32_t  nd  = p.nof_llr >> 2;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(llr);
     uint32_t*       dst = reinterpret_cast<uint32_t*>(soft + 2u * zc);
 #pragma unroll 4
     for (uint32_t d = j; d < nd; d += T) {
-      const uint32_t x = src[d];
-      if (x == 0) { // (at high code rates most of the buffer: nothing received there yet)
-        dst[d] = 0;
-        continue;
-      }
-      last_nz    = max(last_nz, 4u * d + 4u - ((uint32_t)__clz(x) >> 3));
-      uint32_t y = 0;
-#pragma unroll
-      for (uint32_t b = 0; b != 4; ++b) {
-        const int v = load_soft((int)(int8_t)(x >> (8u * b)), 4u * d + b < clamp_end);
-        y |= ((uint32_t)v & 0xFFu) << (8u * b);
-      }
-      dst[d] = y;
+      dst[d] = convert_word(src[d], 4u * d);
     }
     const uint32_t i = 4u * nd + j;
     if (i < p.nof_llr) {
@@ -475,25 +741,72 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
   const uint32_t jm = j - zc;
 
   if (input_size != 0) { // workgroup-uniform
-    const uint32_t slot = s_flag[3];
-    uint2*         rec  = p.scratch + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * p.nof_layers_max * zc;
-    const uint32_t max_iterations = slot == 0xFFFFFFFFu ? 0u : p.max_iterations; // no slot: reported as not decoded
     uint32_t cb_len = input_size + 2u * zc;
     cb_len          = cb_len < K + 4u * zc ? K + 4u * zc : cb_len;
     cb_len          = ((cb_len + zc - 1u) / zc) * zc;
     const uint32_t nof_layers = cb_len / zc - p.bg_k;
+    // Messages per edge in LDS (process_check_pair_lm) when the layers this codeblock runs leave room for them behind the
+    // soft bits those layers touch (the rows beyond are all zero and never read again): workgroup-uniform, decided per
+    // codeblock from its own soft bits, so the result never depends on the launch's LDS budget.
+    const uint32_t msg_off = (cb_len + 48u + 15u) & ~15u;
+    const bool     lm      = LM && p.lm_lds_bytes != 0 && msg_off + graph->pair_ptr[nof_layers] * 2u * zc <= p.lm_lds_bytes;
+    if (claim_late && !lm && pooled) {
+      if (j == 0) {
+        s_flag[3] = acquire_slot(p.slot_flags, p.nof_slots, blockIdx.x);
+      }
+      __syncthreads();
+    }
+    const uint32_t slot = lm ? 0u : s_flag[3];
+    uint2*         rec  = p.scratch + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * p.nof_layers_max * zc;
+    const uint32_t max_iterations = slot == 0xFFFFFFFFu ? 0u : p.max_iterations; // no slot: reported as not decoded
+    uint32_t*       msgs  = reinterpret_cast<uint32_t*>(soft + msg_off) + j; // [row of two edges][lane]: four bytes
+    const uint32_t  k512  = 0x02000200u;
+    const ScaleRule scale = {s_scaled, p.scaling_factor, p.scale_arithmetic != 0};
+#ifdef NRPHY_DEC_TRACE
+    Trace  trace = {};
+    Trace* tr    = (blockIdx.x == gridDim.x / 2u && j < 64u) ? &trace : nullptr;
+    if (tr) trace.last = __builtin_readcyclecounter();
+#else
+    Trace* tr = nullptr;
+#endif
 
     typedef typename std::conditional<PAIR, uint4, uint2>::type Record; // a pair of checks per lane has a record of twice the size
     Record*        recs        = reinterpret_cast<Record*>(rec);
     const uint32_t rec_stride  = PAIR ? half : zc;                       // records of one layer
     const uint32_t minus_half  = 0u - half;
     for (uint32_t it = 0; it != max_iterations && iterations == 0; ++it) {
+      if constexpr (LM) {
+        if (lm) { // workgroup-uniform
+          uint32_t e0 = graph->row_ptr[0], e1 = graph->row_ptr[1], rows = 0;
+          for (uint32_t m = 0; m != nof_layers; ++m) {
+            const uint32_t e2  = graph->row_ptr[m + 2u]; // (the array has a spare element) a layer ahead: off the critical path
+            const uint32_t deg = e1 - e0;
+            if (active) {
+              const auto* edge = graph->edge + e0;
+              if (it == 0) {
+                process_layer_pair_lm<true>(deg, soft, msgs + rows * half, half, scale, edge, half, minus_half, j, jm, k512, nullptr);
+              } else {
+                process_layer_pair_lm<false>(deg, soft, msgs + rows * half, half, scale, edge, half, minus_half, j, jm, k512, tr);
+              }
+            }
+            rows += (deg + 1u) >> 1;
+            lds_barrier();
+#ifdef NRPHY_DEC_TRACE
+            if (it != 0) { TR(7); } else if (tr) { tr->last = __builtin_readcyclecounter(); }
+#endif
+            e0 = e1;
+            e1 = e2;
+          }
+        }
+      }
       Record next = {};
-      if (it != 0 && active) {
+      if (!lm && it != 0 && active) {
         next = recs[j];
       }
-      for (uint32_t m = 0; m != nof_layers; ++m) {
-        const uint32_t e0 = graph->row_ptr[m], deg = graph->row_ptr[m + 1u] - e0;
+      uint32_t e0 = graph->row_ptr[0], e1 = graph->row_ptr[1];
+      for (uint32_t m = 0; m != (lm ? 0u : nof_layers); ++m) {
+        const uint32_t e2  = graph->row_ptr[m + 2u]; // (the array has a spare element) a layer ahead: off the critical path
+        const uint32_t deg = e1 - e0;
         const Record   old = next;
         if (it != 0 && active && m + 1u != nof_layers) {
           next = recs[(size_t)(m + 1u) * rec_stride + j];
@@ -511,6 +824,8 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
           }
         }
         lds_barrier();
+        e0 = e1;
+        e1 = e2;
       }
       // Early stop (ldpc_decoder_impl.cpp:118-126): every hard bit decided and the CRC of the significant bits zero.
       // crc_at_end (pusch_codeblock_decoder.cpp:59-68): no check until the last iteration, then the CRC alone decides.
@@ -544,6 +859,13 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
         lds_barrier(); // the flags are cleared again at the top of the next check
       }
     }
+#ifdef NRPHY_DEC_TRACE
+    if (tr && j == 0) {
+      for (int k = 0; k != 10; ++k) {
+        reinterpret_cast<uint64_t*>(p.scratch)[k] = trace.acc[k];
+      }
+    }
+#endif
   }
   if (pooled && s_flag[3] != 0xFFFFFFFFu) { // workgroup-uniform
     // Give the slot back once every record store of this workgroup has completed (see acquire_slot): every wave waits for
@@ -594,31 +916,56 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(NRPHY_DECOD
 {
   ldpc_decode_body<true>(p);
 }
+// ... with the messages per edge in LDS: the LDS of such a launch holds three waves per SIMD at most (four workgroups of
+// three waves per CU at BASELINE config 5), so the kernel takes their registers -- with 128 the compiler serialises the LDS
+// reads of an edge pass through two temporaries.
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void ldpc_decode_pairs_lm_kernel(LdpcDecodeLaunch p)
+{
+  ldpc_decode_body<true, true>(p);
+}
 
 size_t ldpc_decode_lds_bytes(const LdpcDecodeLaunch& p)
 {
   return (((size_t)p.nof_nodes * p.zc + 15u) & ~(size_t)15u) + 48u;
 }
 
-hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStream_t stream)
+hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p_in, uint32_t n_cb, hipStream_t stream)
 {
   if (n_cb == 0) {
     return hipSuccess;
   }
+  LdpcDecodeLaunch p = p_in;
   // NRPHY_DECODER_PAIRS=0: one check per lane whatever the lifting size (A/B runs; the results are identical).
   const char*        pairs_env = std::getenv("NRPHY_DECODER_PAIRS"); // (read per launch: the tests run both kernels in one process)
   const bool         pairs     = (p.zc & 1u) == 0 && p.zc >= 4u && !(pairs_env != nullptr && pairs_env[0] == '0');
   const uint32_t     checks    = pairs ? p.zc / 2u : p.zc;
   const uint32_t     threads   = ((checks + WAVE - 1) / WAVE) * WAVE;
-  const size_t       lds       = ldpc_decode_lds_bytes(p);
-  const void*        kernel    = pairs ? reinterpret_cast<const void*>(ldpc_decode_pairs_kernel) : reinterpret_cast<const void*>(ldpc_decode_kernel);
+  size_t             lds       = ldpc_decode_lds_bytes(p);
+  // Messages per edge in LDS (NRPHY_DECODER_LDSMSG=0: never): taken when the expected layers leave the CU at least twelve
+  // wavefronts (three per SIMD, where the pair kernel's edge passes still hide their LDS round trips).
+  // NRPHY_DECODER_LDSMSG=2: whenever a workgroup's LDS can hold them at all (tests).
+  const char*        lm_env    = std::getenv("NRPHY_DECODER_LDSMSG");
+  const uint32_t     waves     = threads / WAVE;
+  const uint32_t     lm_cap    = (lm_env != nullptr && lm_env[0] == '2') ? 160u * 1024u : ((160u * 1024u) / ((12u + waves - 1u) / waves)) & ~255u;
+  if (pairs && p.lm_lds_bytes != 0 && p.lm_lds_bytes <= lm_cap && !(lm_env != nullptr && lm_env[0] == '0')) {
+    lds            = lds > p.lm_lds_bytes ? lds : (size_t)p.lm_lds_bytes;
+    p.lm_lds_bytes = (uint32_t)lds;
+  } else {
+    p.lm_lds_bytes = 0;
+  }
+  const bool         lm        = p.lm_lds_bytes != 0;
+  const void*        kernel    = lm      ? reinterpret_cast<const void*>(ldpc_decode_pairs_lm_kernel)
+                                 : pairs ? reinterpret_cast<const void*>(ldpc_decode_pairs_kernel)
+                                         : reinterpret_cast<const void*>(ldpc_decode_kernel);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       return e;
     }
   }
-  if (pairs) {
+  if (lm) {
+    hipLaunchKernelGGL(ldpc_decode_pairs_lm_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
+  } else if (pairs) {
     hipLaunchKernelGGL(ldpc_decode_pairs_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
   } else {
     hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n_cb), dim3(threads), lds, stream, p);

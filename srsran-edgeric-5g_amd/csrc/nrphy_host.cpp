@@ -2199,7 +2199,7 @@ const DecoderGraph* get_decoder_graph(nrphy_ctx* ctx, unsigned bg, unsigned zc)
     const int             ils     = lifting_set_index(zc);
     unsigned              count   = 0;
     for (unsigned m = 0; m != rows; ++m) {
-      g[0].row_ptr[m] = (uint16_t)count;
+      g[0].row_ptr[m] = count;
       for (unsigned e = 0; e != n_edges; ++e) {
         if (edges[e].row == m) {
           g[0].edge[count++] = (((uint32_t)edges[e].col * zc) << 16) | (edges[e].shift[ils] % zc); // 67 * 384 < 2^16
@@ -2207,7 +2207,11 @@ const DecoderGraph* get_decoder_graph(nrphy_ctx* ctx, unsigned bg, unsigned zc)
       }
     }
     for (unsigned m = rows; m != MAX_BG_ROWS + 2; ++m) {
-      g[0].row_ptr[m] = (uint16_t)count;
+      g[0].row_ptr[m] = count;
+    }
+    for (unsigned m = 0, pairs = 0; m != MAX_BG_ROWS + 2; ++m) {
+      g[0].pair_ptr[m] = pairs;
+      pairs += m + 1 < MAX_BG_ROWS + 2 ? (g[0].row_ptr[m + 1] - g[0].row_ptr[m] + 1) / 2 : 0;
     }
     for (unsigned m = 0; m != rows; ++m) {
       // the kernel is specialised for the row degrees the two base graphs have
@@ -2251,9 +2255,12 @@ const uint32_t* get_decoder_crc_weights(nrphy_ctx* ctx, uint32_t poly, uint32_t 
 
 namespace {
 // skip / ok_flags: per-codeblock HARQ state of a transport-block decoder; crc_at_end: no early stop.
+// expected_extent: how many of the nof_llr soft bits the caller expects to be in use (the rest zero), 0 = all of them; it
+// only sizes the launch's LDS (messages per edge in LDS when the layers that extent needs are few), never the result.
 int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb, const int8_t* d_llr,
                       uint32_t llr_stride_bytes, uint8_t* d_out, uint32_t out_stride_bytes, uint32_t* d_iterations,
-                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* d_scratch, void* stream);
+                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* d_scratch, void* stream,
+                      uint32_t expected_extent = 0);
 
 // The caller-owned scratch of a decoder launch: a pool of check-record slots + the bitmap that hands them out.
 struct DecoderScratch {
@@ -2332,7 +2339,8 @@ namespace {
 
 int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uint32_t n_cb, const int8_t* d_llr,
                       uint32_t llr_stride_bytes, uint8_t* d_out, uint32_t out_stride_bytes, uint32_t* d_iterations,
-                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* d_scratch, void* stream)
+                      const uint8_t* d_skip, uint8_t* d_ok_flags, bool crc_at_end, void* d_scratch, void* stream,
+                      uint32_t expected_extent)
 {
   if (ctx == nullptr || cfg == nullptr || d_llr == nullptr || d_out == nullptr || d_scratch == nullptr ||
       (cfg->base_graph != 1 && cfg->base_graph != 2) || cfg->max_iterations == 0 ||
@@ -2374,6 +2382,36 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
   p.skip           = d_skip;
   p.ok_flags       = d_ok_flags;
   p.crc_at_end     = crc_at_end ? 1U : 0U;
+  {
+    // LDS for the messages-per-edge form (ldpc_decoder.hip) at the expected extent: the soft bits of the layers it needs (the
+    // kernel's own rule: ldpc_decoder_impl.cpp:88-116), then one byte per edge and lifted check of those layers.
+    const uint32_t extent = (expected_extent == 0 || expected_extent > cfg->nof_llr) ? cfg->nof_llr : expected_extent;
+    uint32_t       cb_len = std::max<uint32_t>(extent + 2 * zc, K + 4 * zc);
+    cb_len                = divide_ceil(cb_len, zc) * zc;
+    const uint32_t        layers  = cb_len / zc - bg_k;
+    const nr_ldpc_edge_t* edges   = (cfg->base_graph == 1) ? NR_LDPC_BG1_EDGES : NR_LDPC_BG2_EDGES;
+    const unsigned        n_edges = (cfg->base_graph == 1) ? NR_LDPC_BG1_NOF_EDGES : NR_LDPC_BG2_NOF_EDGES;
+    std::vector<uint32_t> degree(layers, 0);
+    for (unsigned e = 0; e != n_edges; ++e) {
+      if (edges[e].row < layers) {
+        ++degree[edges[e].row];
+      }
+    }
+    uint32_t rows = 0; // of two edges each
+    for (uint32_t dg : degree) {
+      rows += (dg + 1) / 2;
+    }
+    p.lm_lds_bytes = ((cb_len + 48U + 15U) & ~15U) + rows * 2 * zc;
+    // The scaling of the minima by arithmetic instead of a table look-up, where it gives the table's values
+    // (round half away from zero: ldpc_decoder_generic.cpp:69-79).
+    p.scale_arithmetic = 1;
+    for (unsigned m = 0; m <= 120; ++m) {
+      const float x = (float)m * cfg->scaling_factor;
+      if ((uint32_t)(x + 0.5F) != (uint32_t)(uint8_t)roundf(x)) {
+        p.scale_arithmetic = 0;
+      }
+    }
+  }
   p.crc_weight     = nullptr;
   if (p.crc_order != 0) {
     // Uploaded by nrphy_ldpc_decoder_prepare(); a first use without it allocates and copies here (not capturable).
@@ -2698,8 +2736,30 @@ extern "C" int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_deco
     return rc;
   }
   const nrphy_ldpc_decoder_cfg_t dec = pusch_ldpc_cfg(*cfg, d);
+  // How far into the soft buffers a first transmission reaches (filler bits included): what the decoder can expect to be in
+  // use when the buffers held nothing else -- a hint for the launch's LDS size only (see ldpc_decode_batch).
+  uint32_t expected_extent = 0;
+  if (cfg->new_data) {
+    const unsigned bg_k = (cfg->base_graph == 1) ? 22 : 10, zc = d.lifting_size;
+    const unsigned buffer_length = (d.n_ref > 0 && d.n_ref < N) ? d.n_ref : N;
+    static const double shift_bg1[4] = {0, 17, 33, 56}, shift_bg2[4] = {0, 13, 25, 43};
+    const double   frac = (((cfg->base_graph == 1) ? shift_bg1 : shift_bg2)[cfg->rv] * buffer_length) / N;
+    const unsigned k0   = (unsigned)((uint16_t)std::floor(frac)) * zc;
+    std::vector<DematchOp> ops;
+    for (uint32_t e : {d.rm_length_short, d.rm_length_long}) {
+      if (e == 0) {
+        continue;
+      }
+      build_dematch_ops(ops, N, buffer_length, k0, (bg_k - 2) * zc, d.nof_filler_bits, e, true);
+      for (const DematchOp& op : ops) {
+        if (op.kind != DEMATCH_ZERO) {
+          expected_extent = std::max<uint32_t>(expected_extent, op.begin + op.count);
+        }
+      }
+    }
+  }
   rc = ldpc_decode_batch(ctx, &dec, (uint32_t)n_cb, d_soft, N, msg, l.msg_stride, iter, skip, ok, cfg->use_early_stop == 0,
-                         d_scratch, s);
+                         d_scratch, s, expected_extent);
   if (rc != NRPHY_OK) {
     return rc;
   }

@@ -244,7 +244,8 @@ hipError_t launch_ldpc_encode(const LiftedGraph* graphs, uint32_t graph, uint32_
 // The whole lifted graph of one (base graph, lifting size) for the decoder: every edge of every check row in
 // adjacency order (ascending variable index, the order that breaks ties between equal minima).
 struct DecoderGraph {
-  uint16_t row_ptr[MAX_BG_ROWS + 2];
+  uint32_t row_ptr[MAX_BG_ROWS + 2]; // 32-bit: read with scalar loads (a 16-bit element goes through a vector load and a round trip to L2)
+  uint32_t pair_ptr[MAX_BG_ROWS + 2]; // rows of two edges before row m: sum of ceil(degree / 2) (messages per edge in LDS)
   uint32_t edge[MAX_BG_EDGES]; // (variable node * Zc) << 16 | lifted shift
 };
 
@@ -265,6 +266,11 @@ struct LdpcDecodeLaunch {
   uint32_t            crc_poly, crc_order; // order 0: no early stop
   uint32_t            max_iterations;
   float               scaling_factor;
+  // Two checks per lane with the messages per edge in LDS: in = the LDS bytes that takes for the layers the caller expects
+  // (0: not wanted); launch_ldpc_decode() turns it into the launch's LDS size, or 0 when the kernel keeps to its records.
+  // Each codeblock decides by the layers its own soft bits ask for whether it fits.
+  uint32_t            lm_lds_bytes;
+  uint32_t            scale_arithmetic; // 1: (unsigned)(m * scaling_factor + 0.5f) == round(m * scaling_factor) for m = 0 .. 120
 };
 hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStream_t stream);
 

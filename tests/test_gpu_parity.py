@@ -682,15 +682,28 @@ def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
 # LDPC decoder ("next" row, receive side): bit-exact hard bits and iteration counts against the oracle, which is pinned
 # to the reference's generic decoder (tests/test_oracle.py)
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("pairs", [None, "0"])
+DECODER_KERNELS = {  # environment of a launch (read per launch) -> which form of the decoder runs
+    "default": {},                                # two checks per lane; messages per edge in LDS where the occupancy rule allows
+    "lds-messages": {"NRPHY_DECODER_LDSMSG": "2"},  # ... wherever a workgroup's LDS can hold them
+    "records": {"NRPHY_DECODER_LDSMSG": "0"},       # two checks per lane, compressed records in the caller's scratch
+    "one-check": {"NRPHY_DECODER_PAIRS": "0"},      # one check per lane (what odd lifting sizes always take)
+}
+
+
+def select_decoder_kernel(monkeypatch, kernel):
+    for name in ("NRPHY_DECODER_PAIRS", "NRPHY_DECODER_LDSMSG"):
+        monkeypatch.delenv(name, raising=False)
+    for name, value in DECODER_KERNELS[kernel].items():
+        monkeypatch.setenv(name, value)
+
+
+@pytest.mark.parametrize("kernel", list(DECODER_KERNELS))
 @pytest.mark.parametrize("case", cases.LDPC_DECODE_CASES)
-def test_ldpc_decoder_vs_oracle(gpu_ctx, oracle, case, pairs, monkeypatch):
-    """Both decoder kernels: two checks per lane in packed 16-bit arithmetic (the default for even lifting sizes) and one check
-    per lane (NRPHY_DECODER_PAIRS=0, read per launch) -- hard bits and iteration counts of both equal the oracle's."""
-    if pairs is None:
-        monkeypatch.delenv("NRPHY_DECODER_PAIRS", raising=False)
-    else:
-        monkeypatch.setenv("NRPHY_DECODER_PAIRS", pairs)
+def test_ldpc_decoder_vs_oracle(gpu_ctx, oracle, case, kernel, monkeypatch):
+    """Every form of the decoder kernel: two checks per lane in packed 16-bit arithmetic (even lifting sizes) with the messages
+    per edge in LDS or as compressed records, and one check per lane -- hard bits and iteration counts of all equal the
+    oracle's."""
+    select_decoder_kernel(monkeypatch, kernel)
     bg, zc, extra, tail, crc_id, filler, amp, sigma = case
     rng = np.random.default_rng(zc * 1000 + extra)
     nof_llr = cases.ldpc_decode_nof_llr(case)
