@@ -44,6 +44,27 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
   return r;
 }
 
+// LDS accesses of the pair kernels by LDS address (an integer): through a pointer into the kernel's LDS array every access
+// carries an addition of the array's (link-time) address -- "v_add 0, x" once per soft bit read and written.
+typedef __attribute__((address_space(3))) int8_t   lds_i8_t;
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+__device__ __forceinline__ int lds_load_i8(uint32_t addr)
+{
+  return *reinterpret_cast<const lds_i8_t*>((uintptr_t)addr);
+}
+__device__ __forceinline__ void lds_store_i8(uint32_t addr, uint32_t v)
+{
+  *reinterpret_cast<lds_i8_t*>((uintptr_t)addr) = (int8_t)v;
+}
+__device__ __forceinline__ uint32_t lds_load_u32(uint32_t addr)
+{
+  return *reinterpret_cast<const lds_u32_t*>((uintptr_t)addr);
+}
+__device__ __forceinline__ void lds_store_u32(uint32_t addr, uint32_t v)
+{
+  *reinterpret_cast<lds_u32_t*>((uintptr_t)addr) = v;
+}
+
 // Variable-to-check message a - c.  An infinite soft bit yields a value far beyond the finite range with the sign of
 // a (+-512 on top): never a minimum, the right sign, and llr_add_promote() turns it back into an infinite soft bit.
 __device__ __forceinline__ int llr_sub(int a, int c)
@@ -225,7 +246,7 @@ __device__ __forceinline__ void pair_one_hot(uint32_t y, uint32_t& hot0, uint32_
 // the compiler's scheduler sinks every pair of LDS reads to its use and reuses two temporaries -- a chain of DEG dependent LDS
 // round trips per pass (read, wait for everything, combine, read ...) instead of twenty reads in flight.
 template <uint32_t DEG, uint32_t B, typename AddrA, typename AddrB>
-__device__ __forceinline__ void load_pairs10(uint32_t (&out)[DEG], const int8_t* base, AddrA addr_a, AddrB addr_b)
+__device__ __forceinline__ void load_pairs10(uint32_t (&out)[DEG], AddrA addr_a, AddrB addr_b)
 {
   if constexpr (B < DEG) {
     constexpr uint32_t N = DEG - B < 10u ? DEG - B : 10u;
@@ -233,8 +254,8 @@ __device__ __forceinline__ void load_pairs10(uint32_t (&out)[DEG], const int8_t*
 #pragma unroll
     for (uint32_t k = 0; k != 10; ++k) {
       const uint32_t t = k < N ? B + k : B + N - 1u;
-      va[k]            = (uint32_t)(int)base[addr_a(t)];
-      vb[k]            = (uint32_t)(int)base[addr_b(t)];
+      va[k]            = (uint32_t)lds_load_i8(addr_a(t));
+      vb[k]            = (uint32_t)lds_load_i8(addr_b(t));
     }
     asm volatile("" ::"v"(va[0]), "v"(vb[0]), "v"(va[1]), "v"(vb[1]), "v"(va[2]), "v"(vb[2]), "v"(va[3]), "v"(vb[3]), "v"(va[4]), "v"(vb[4]),
                  "v"(va[5]), "v"(vb[5]), "v"(va[6]), "v"(vb[6]), "v"(va[7]), "v"(vb[7]), "v"(va[8]), "v"(vb[8]), "v"(va[9]), "v"(vb[9]));
@@ -271,23 +292,23 @@ struct PairEdges {
     }
   }
   // Pass 2: new soft bits = new message + v2c message, promoted, back to where they came from.
-  static __device__ __forceinline__ void backward(int8_t* soft, const uint32_t (&addr1)[DEG], const uint32_t (&addr2)[DEG],
+  static __device__ __forceinline__ void backward(const uint32_t (&addr1)[DEG], const uint32_t (&addr2)[DEG],
                                                   const uint32_t (&x)[DEG], uint32_t m1, uint32_t m2, uint32_t hot0, uint32_t hot1,
                                                   uint32_t z, uint32_t w)
   {
     if constexpr (T < DEG) {
       const s16x2    sum = pair_message<T>(m1, m2, hot0, hot1, z, w) + as_s16x2(x[T]);
       const uint32_t out = as_word(clamp_s16x2(sum, LLR_INF_V));
-      soft[addr1[T]]     = (int8_t)out;
-      soft[addr2[T]]     = (int8_t)(out >> 16);
-      PairEdges<DEG, T + 1, FIRST>::backward(soft, addr1, addr2, x, m1, m2, hot0, hot1, z, w);
+      lds_store_i8(addr1[T], out);
+      lds_store_i8(addr2[T], out >> 16);
+      PairEdges<DEG, T + 1, FIRST>::backward(addr1, addr2, x, m1, m2, hot0, hot1, z, w);
     }
   }
 };
 
 // Checks j and j + half of one layer (degree DEG); j < half = Zc / 2; jm = j - Zc (wraps).
 template <uint32_t DEG, bool FIRST>
-__device__ __forceinline__ uint4 process_check_pair(int8_t* soft, const uint8_t* scaled, const NRPHY_CONSTANT uint32_t* edge,
+__device__ __forceinline__ uint4 process_check_pair(uint32_t soft, const uint8_t* scaled, const NRPHY_CONSTANT uint32_t* edge,
                                                     uint32_t half, uint32_t minus_half, uint32_t j, uint32_t jm, uint4 old)
 {
   uint32_t addr1[DEG], addr2[DEG], a[DEG], x[DEG];
@@ -295,11 +316,11 @@ __device__ __forceinline__ uint4 process_check_pair(int8_t* soft, const uint8_t*
   for (uint32_t t = 0; t != DEG; ++t) {
     const uint32_t e = edge[t], shift = e & 0xFFFFu;
     const uint32_t pos = min(j + shift, jm + shift);   // (j + shift) mod Zc
-    addr1[t]           = (e >> 16) + pos;              // the graph holds node * Zc
+    addr1[t]           = (soft + (e >> 16)) + pos;     // LDS address (the graph holds node * Zc; the sum in brackets is scalar)
     addr2[t]           = addr1[t] + (pos < half ? half : minus_half); // (j + Zc / 2 + shift) mod Zc
   }
-  load_pairs10<DEG, 0>(a, soft, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
-  load_pairs10<DEG, 10>(a, soft, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
+  load_pairs10<DEG, 0>(a, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
+  load_pairs10<DEG, 10>(a, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
   uint32_t m1 = 0, m2 = 0, hot0 = 0, hot1 = 0;
   if (!FIRST) {
     m1 = old.x & 0x00FF00FFu;
@@ -319,12 +340,12 @@ __device__ __forceinline__ uint4 process_check_pair(int8_t* soft, const uint8_t*
   const uint4 mine = make_uint4(n1 | (n2 << 8), k1 & 0x00FF00FFu, nz, nw);
   uint32_t    nh0, nh1;
   pair_one_hot(mine.y, nh0, nh1);
-  PairEdges<DEG, 0, FIRST>::backward(soft, addr1, addr2, x, n1, n2, nh0, nh1, nz, nw);
+  PairEdges<DEG, 0, FIRST>::backward(addr1, addr2, x, n1, n2, nh0, nh1, nz, nw);
   return mine;
 }
 
 template <bool FIRST>
-__device__ __forceinline__ uint4 process_layer_pair(uint32_t deg, int8_t* soft, const uint8_t* scaled,
+__device__ __forceinline__ uint4 process_layer_pair(uint32_t deg, uint32_t soft, const uint8_t* scaled,
                                                     const NRPHY_CONSTANT uint32_t* edge, uint32_t half, uint32_t minus_half, uint32_t j,
                                                     uint32_t jm, uint4 old)
 {
@@ -423,7 +444,7 @@ struct LmEdges {
   }
   // The new message of the pair on edge T and the soft bits it leads to; m1 / m2: the scaled minima of the pair with the
   // parity of the signs applied (negative when odd).
-  static __device__ __forceinline__ uint32_t answer(int8_t* soft, const uint32_t (&addr1)[DEG], const uint32_t (&addr2)[DEG],
+  static __device__ __forceinline__ uint32_t answer(const uint32_t (&addr1)[DEG], const uint32_t (&addr2)[DEG],
                                                     const uint32_t (&x)[DEG], uint32_t m1, uint32_t m2, uint32_t hot0, uint32_t hot1)
   {
     const uint32_t s   = as_word(as_s16x2(x[T]) >> splat_s16(15)) | 0x00010001u; // -1 / +1: the sign of the value answered
@@ -431,30 +452,30 @@ struct LmEdges {
     const uint32_t mag = __builtin_amdgcn_bitop3_b32(sel, m2, m1, 0xCA);
     const s16x2    msg = as_s16x2(as_word(as_u16x2(mag) * as_u16x2(s)));
     const uint32_t out = as_word(clamp_s16x2(msg + as_s16x2(x[T]), LLR_INF_V));
-    soft[addr1[T]]     = (int8_t)out;
-    soft[addr2[T]]     = (int8_t)(out >> 16);
+    lds_store_i8(addr1[T], out);
+    lds_store_i8(addr2[T], out >> 16);
     return as_word(msg);
   }
   // Edges T and T + 1 (T even): new soft bits, and the word of their messages.
-  static __device__ __forceinline__ void backward(int8_t* soft, uint32_t* mrow, uint32_t row_words, const uint32_t (&addr1)[DEG],
+  static __device__ __forceinline__ void backward(uint32_t mrow, uint32_t row_bytes, const uint32_t (&addr1)[DEG],
                                                   const uint32_t (&addr2)[DEG], const uint32_t (&x)[DEG], uint32_t m1, uint32_t m2,
                                                   uint32_t hot0, uint32_t hot1)
   {
     if constexpr (T < DEG) {
-      const uint32_t lo = answer(soft, addr1, addr2, x, m1, m2, hot0, hot1);
+      const uint32_t lo = answer(addr1, addr2, x, m1, m2, hot0, hot1);
       uint32_t       hi = 0;
       if constexpr (T + 1 < DEG) {
-        hi = LmEdges<DEG, T + 1, FIRST>::answer(soft, addr1, addr2, x, m1, m2, hot0, hot1);
+        hi = LmEdges<DEG, T + 1, FIRST>::answer(addr1, addr2, x, m1, m2, hot0, hot1);
       }
-      mrow[(T / 2u) * row_words] = __builtin_amdgcn_perm(hi, lo, 0x06040200u); // bytes: A(T), B(T), A(T + 1), B(T + 1)
-      LmEdges<DEG, T + 2, FIRST>::backward(soft, mrow, row_words, addr1, addr2, x, m1, m2, hot0, hot1);
+      lds_store_u32(mrow + (T / 2u) * row_bytes, __builtin_amdgcn_perm(hi, lo, 0x06040200u)); // bytes: A(T), B(T), A(T + 1), B(T + 1)
+      LmEdges<DEG, T + 2, FIRST>::backward(mrow, row_bytes, addr1, addr2, x, m1, m2, hot0, hot1);
     }
   }
 };
 
-// mrow: the lane's word of the layer's first row of messages; row_words = Zc / 2 words per row.
+// soft, mrow: LDS addresses of the soft bits and of the lane's word in the layer's first row of messages; row_bytes = 2 Zc.
 template <uint32_t DEG, bool FIRST>
-__device__ __forceinline__ void process_check_pair_lm(int8_t* soft, uint32_t* mrow, uint32_t row_words, const ScaleRule& scale,
+__device__ __forceinline__ void process_check_pair_lm(uint32_t soft, uint32_t mrow, uint32_t row_bytes, const ScaleRule& scale,
                                                       const NRPHY_CONSTANT uint32_t* edge, uint32_t half, uint32_t minus_half, uint32_t j,
                                                       uint32_t jm, uint32_t k512, Trace* tr)
 {
@@ -464,19 +485,19 @@ __device__ __forceinline__ void process_check_pair_lm(int8_t* soft, uint32_t* mr
   if (!FIRST) { // the lane's own words of old messages: on their way while the addresses are computed
 #pragma unroll
     for (uint32_t r = 0; r != NP; ++r) {
-      w[r] = mrow[r * row_words];
+      w[r] = lds_load_u32(mrow + r * row_bytes);
     }
   }
 #pragma unroll
   for (uint32_t t = 0; t != DEG; ++t) {
     const uint32_t e = edge[t], shift = e & 0xFFFFu;
     const uint32_t pos = min(j + shift, jm + shift);   // (j + shift) mod Zc
-    addr1[t]           = (e >> 16) + pos;              // the graph holds node * Zc
+    addr1[t]           = (soft + (e >> 16)) + pos;     // LDS address (the graph holds node * Zc; the sum in brackets is scalar)
     addr2[t]           = addr1[t] + (pos < half ? half : minus_half); // (j + Zc / 2 + shift) mod Zc
   }
   TR(1);
-  load_pairs10<DEG, 0>(x, soft, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
-  load_pairs10<DEG, 10>(x, soft, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
+  load_pairs10<DEG, 0>(x, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
+  load_pairs10<DEG, 10>(x, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
   TR(2);
   if (!FIRST) {
 #define NRPHY_IX(k) ((k) < NP ? (k) : NP - 1u)
@@ -510,25 +531,25 @@ __device__ __forceinline__ void process_check_pair_lm(int8_t* soft, uint32_t* mr
   uint32_t       hot0, hot1;
   pair_one_hot(k1 & 0x00FF00FFu, hot0, hot1);
   TR(5);
-  LmEdges<DEG, 0, FIRST>::backward(soft, mrow, row_words, addr1, addr2, x, m1, m2, hot0, hot1);
+  LmEdges<DEG, 0, FIRST>::backward(mrow, row_bytes, addr1, addr2, x, m1, m2, hot0, hot1);
   TR(6);
 }
 
 template <bool FIRST>
-__device__ __forceinline__ void process_layer_pair_lm(uint32_t deg, int8_t* soft, uint32_t* mrow, uint32_t row_words, const ScaleRule& scale,
+__device__ __forceinline__ void process_layer_pair_lm(uint32_t deg, uint32_t soft, uint32_t mrow, uint32_t row_bytes, const ScaleRule& scale,
                                                       const NRPHY_CONSTANT uint32_t* edge, uint32_t half, uint32_t minus_half, uint32_t j,
                                                       uint32_t jm, uint32_t k512, Trace* tr)
 {
   switch (deg) {
-    case 3: return process_check_pair_lm<3, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 4: return process_check_pair_lm<4, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 5: return process_check_pair_lm<5, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 6: return process_check_pair_lm<6, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 7: return process_check_pair_lm<7, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 8: return process_check_pair_lm<8, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 9: return process_check_pair_lm<9, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 10: return process_check_pair_lm<10, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
-    default: return process_check_pair_lm<19, FIRST>(soft, mrow, row_words, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 3: return process_check_pair_lm<3, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 4: return process_check_pair_lm<4, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 5: return process_check_pair_lm<5, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 6: return process_check_pair_lm<6, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 7: return process_check_pair_lm<7, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 8: return process_check_pair_lm<8, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 9: return process_check_pair_lm<9, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 10: return process_check_pair_lm<10, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
+    default: return process_check_pair_lm<19, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
   }
 }
 
@@ -539,7 +560,9 @@ __device__ __forceinline__ int load_soft(int v, bool whole_node)
   return whole_node ? med3(v, -64, 64) : med3(v, -LLR_INF_V, LLR_INF_V);
 }
 
-// Hard bits [32 w, 32 w + 32) of the soft bits (MSB first); zero_seen: an undecided one among the first `limit`.
+// Hard bits [32 w, 32 w + 32) of the soft bits (MSB first; a soft bit <= 0 decides for one); zero_seen: an undecided one among
+// the first `limit`.  Four soft bits of a word at a time: bit 7 of a byte of ((x & 0x7F..) + 0x7F..) | x says "not zero", the
+// sign says "negative", and a dot product with the weights 128 .. 1 gathers eight of them into a byte.
 __device__ __forceinline__ uint32_t hard_word(const int8_t* soft, uint32_t w, uint32_t limit, bool& zero_seen)
 {
   const uint4    lo = *reinterpret_cast<const uint4*>(soft + 32u * w);
@@ -547,10 +570,17 @@ __device__ __forceinline__ uint32_t hard_word(const int8_t* soft, uint32_t w, ui
   const uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   uint32_t       word = 0, zeros = 0;
 #pragma unroll
-  for (uint32_t i = 0; i != 32; ++i) {
-    const int v = (int)(int8_t)(x[i >> 2] >> (8u * (i & 3u)));
-    word |= (v <= 0 ? 1u : 0u) << (31u - i);
-    zeros |= (v == 0 ? 1u : 0u) << (31u - i);
+  for (uint32_t k = 0; k != 8; k += 2) {
+    uint32_t one[2], zero[2];
+#pragma unroll
+    for (uint32_t h = 0; h != 2; ++h) {
+      const uint32_t nz = ((x[k + h] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x[k + h]; // bit 7 of a byte: the soft bit is not zero
+      zero[h]           = (~nz & 0x80808080u) >> 7;
+      one[h]            = ((x[k + h] | ~nz) & 0x80808080u) >> 7;              // negative or zero
+    }
+    const uint32_t shift = 24u - 4u * k;
+    word |= __builtin_amdgcn_udot4(one[0], 0x10204080u, __builtin_amdgcn_udot4(one[1], 0x01020408u, 0u, false), false) << shift;
+    zeros |= __builtin_amdgcn_udot4(zero[0], 0x10204080u, __builtin_amdgcn_udot4(zero[1], 0x01020408u, 0u, false), false) << shift;
   }
   const uint32_t valid = limit > 32u * w ? topmask(limit - 32u * w < 32u ? limit - 32u * w : 32u) : 0u;
   zero_seen |= (zeros & valid) != 0;
@@ -602,11 +632,14 @@ __device__ __forceinline__ void store_record(uint4* rec, uint4 v) // a pair of c
 template <bool PAIR, bool LM = false>
 __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
 {
+  // All of the kernel's LDS is the launch's dynamic allocation, the soft bits at its start: with a static variable in front
+  // of them every soft-bit address would carry the variable's size as an extra addition (two per edge and pass).
   extern __shared__ __attribute__((aligned(16))) int8_t dec_lds[];
-  __shared__ uint32_t s_flag[4];
-  __shared__ uint8_t  s_scaled[128];
+  uint32_t* const s_flag   = reinterpret_cast<uint32_t*>(dec_lds + p.lds_tail_off); // [4]
+  uint8_t* const  s_scaled = reinterpret_cast<uint8_t*>(dec_lds + p.lds_tail_off + 16u); // [128]
   const uint32_t zc = p.zc, j = threadIdx.x;
   int8_t*        soft = dec_lds; // [nof_nodes][zc] (+ 32 bytes of slack for the word reads of the last hard bits)
+  const uint32_t soft_a = (uint32_t)(uintptr_t)(lds_i8_t*)dec_lds; // ... as an LDS address (see lds_load_i8)
 
   if (p.skip != nullptr && p.skip[blockIdx.x] != 0) { // workgroup-uniform: decoded in an earlier transmission
     return;
@@ -662,6 +695,16 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
     }
     return y;
   };
+  // The same for a word that lies on one side of clamp_end (lifting sizes that are multiples of four), in packed 16-bit
+  // arithmetic and without a branch: the sixteen-byte loads below run it on every word of a non-zero quadruple.
+  auto convert_word_aligned = [&](uint32_t x, uint32_t first) -> uint32_t {
+    last_nz = x != 0 ? max(last_nz, first + 4u - ((uint32_t)__clz(x) >> 3)) : last_nz;
+    const int      lim = first < clamp_end ? 64 : LLR_INF_V;
+    const uint32_t xs  = x << 8;
+    const s16x2    lo  = clamp_s16x2(as_s16x2(__builtin_amdgcn_perm(x, xs, 0x0A050804u)), lim); // bytes 0, 1 sign-extended
+    const s16x2    hi  = clamp_s16x2(as_s16x2(__builtin_amdgcn_perm(x, xs, 0x0B070906u)), lim); // bytes 2, 3
+    return __builtin_amdgcn_perm(as_word(hi), as_word(lo), 0x06040200u);
+  };
   if (((reinterpret_cast<uintptr_t>(llr) & 15u) | (zc & 7u)) == 0) {
     // sixteen soft bits per lane and load, up to twelve (four) loads of a lane in flight: the whole codeblock in one or two trips to
     // memory (four-byte loads unrolled by four took eight trips for a config-3 codeblock)
@@ -682,8 +725,8 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
         if (q < nq) {
           uint4 y = make_uint4(0, 0, 0, 0);
           if ((v[u].x | v[u].y | v[u].z | v[u].w) != 0) {
-            y = make_uint4(convert_word(v[u].x, 16u * q), convert_word(v[u].y, 16u * q + 4u), convert_word(v[u].z, 16u * q + 8u),
-                           convert_word(v[u].w, 16u * q + 12u));
+            y = make_uint4(convert_word_aligned(v[u].x, 16u * q), convert_word_aligned(v[u].y, 16u * q + 4u),
+                           convert_word_aligned(v[u].z, 16u * q + 8u), convert_word_aligned(v[u].w, 16u * q + 12u));
           }
           dst[q] = y;
         }
@@ -759,7 +802,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
     const uint32_t slot = lm ? 0u : s_flag[3];
     uint2*         rec  = p.scratch + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * p.nof_layers_max * zc;
     const uint32_t max_iterations = slot == 0xFFFFFFFFu ? 0u : p.max_iterations; // no slot: reported as not decoded
-    uint32_t*       msgs  = reinterpret_cast<uint32_t*>(soft + msg_off) + j; // [row of two edges][lane]: four bytes
+    const uint32_t  msgs  = soft_a + msg_off + 4u * j; // LDS address of the lane's word: [row of two edges][lane], four bytes
     const uint32_t  k512  = 0x02000200u;
     const ScaleRule scale = {s_scaled, p.scaling_factor, p.scale_arithmetic != 0};
 #ifdef NRPHY_DEC_TRACE
@@ -784,9 +827,9 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
             if (active) {
               const auto* edge = graph->edge + e0;
               if (it == 0) {
-                process_layer_pair_lm<true>(deg, soft, msgs + rows * half, half, scale, edge, half, minus_half, j, jm, k512, nullptr);
+                process_layer_pair_lm<true>(deg, soft_a, msgs + rows * 2u * zc, 2u * zc, scale, edge, half, minus_half, j, jm, k512, nullptr);
               } else {
-                process_layer_pair_lm<false>(deg, soft, msgs + rows * half, half, scale, edge, half, minus_half, j, jm, k512, tr);
+                process_layer_pair_lm<false>(deg, soft_a, msgs + rows * 2u * zc, 2u * zc, scale, edge, half, minus_half, j, jm, k512, tr);
               }
             }
             rows += (deg + 1u) >> 1;
@@ -814,8 +857,8 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
         if (active) {
           const auto* edge = graph->edge + e0;
           if constexpr (PAIR) {
-            const uint4 mine = it == 0 ? process_layer_pair<true>(deg, soft, s_scaled, edge, half, minus_half, j, jm, old)
-                                       : process_layer_pair<false>(deg, soft, s_scaled, edge, half, minus_half, j, jm, old);
+            const uint4 mine = it == 0 ? process_layer_pair<true>(deg, soft_a, s_scaled, edge, half, minus_half, j, jm, old)
+                                       : process_layer_pair<false>(deg, soft_a, s_scaled, edge, half, minus_half, j, jm, old);
             store_record(&recs[(size_t)m * rec_stride + j], mine);
           } else {
             const uint2 mine = it == 0 ? process_layer<true>(deg, soft, s_scaled, edge, zc, j, jm, old)
@@ -924,6 +967,8 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void l
   ldpc_decode_body<true, true>(p);
 }
 
+constexpr uint32_t LDS_TAIL_BYTES = 16u + 128u;
+
 size_t ldpc_decode_lds_bytes(const LdpcDecodeLaunch& p)
 {
   return (((size_t)p.nof_nodes * p.zc + 15u) & ~(size_t)15u) + 48u;
@@ -947,12 +992,14 @@ hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p_in, uint32_t n_cb, hipSt
   const char*        lm_env    = std::getenv("NRPHY_DECODER_LDSMSG");
   const uint32_t     waves     = threads / WAVE;
   const uint32_t     lm_cap    = (lm_env != nullptr && lm_env[0] == '2') ? 160u * 1024u : ((160u * 1024u) / ((12u + waves - 1u) / waves)) & ~255u;
-  if (pairs && p.lm_lds_bytes != 0 && p.lm_lds_bytes <= lm_cap && !(lm_env != nullptr && lm_env[0] == '0')) {
+  if (pairs && p.lm_lds_bytes != 0 && p.lm_lds_bytes + LDS_TAIL_BYTES <= lm_cap && !(lm_env != nullptr && lm_env[0] == '0')) {
     lds            = lds > p.lm_lds_bytes ? lds : (size_t)p.lm_lds_bytes;
     p.lm_lds_bytes = (uint32_t)lds;
   } else {
     p.lm_lds_bytes = 0;
   }
+  p.lds_tail_off = (uint32_t)lds; // the flags and the scaling table behind the soft bits (and messages)
+  lds += LDS_TAIL_BYTES;
   const bool         lm        = p.lm_lds_bytes != 0;
   const void*        kernel    = lm      ? reinterpret_cast<const void*>(ldpc_decode_pairs_lm_kernel)
                                  : pairs ? reinterpret_cast<const void*>(ldpc_decode_pairs_kernel)

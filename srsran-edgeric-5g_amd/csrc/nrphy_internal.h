@@ -270,6 +270,7 @@ struct LdpcDecodeLaunch {
   // (0: not wanted); launch_ldpc_decode() turns it into the launch's LDS size, or 0 when the kernel keeps to its records.
   // Each codeblock decides by the layers its own soft bits ask for whether it fits.
   uint32_t            lm_lds_bytes;
+  uint32_t            lds_tail_off;     // set by launch_ldpc_decode(): where the kernel's flags and scaling table sit in its LDS
   uint32_t            scale_arithmetic; // 1: (unsigned)(m * scaling_factor + 0.5f) == round(m * scaling_factor) for m = 0 .. 120
 };
 hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStream_t stream);
