@@ -435,7 +435,8 @@ struct LmEdges {
       x[T]          = as_word(v);
       const s16x2    mag = __builtin_elementwise_max(v, splat_s16(0) - v);
       const uint32_t cap = as_word(__builtin_elementwise_min(as_u16x2(as_word(mag)), u16x2{255, 255}));
-      const uint32_t key = (cap << 8) | (T * 0x00010001u);
+      uint32_t key; // cap * 256 + T in both halves: the edge index as an inline constant (as (cap << 8) | literal it costs a move)
+      asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(key) : "v"(cap), "s"(k512 >> 1), "n"(T));
       k2 = as_word(__builtin_elementwise_min(__builtin_elementwise_max(as_u16x2(key), as_u16x2(k1)), as_u16x2(k2)));
       k1 = as_word(__builtin_elementwise_min(as_u16x2(key), as_u16x2(k1)));
       par ^= as_word(v); // bit 15 of a half: parity of the negative values so far
@@ -473,11 +474,12 @@ struct LmEdges {
   }
 };
 
-// soft, mrow: LDS addresses of the soft bits and of the lane's word in the layer's first row of messages; row_bytes = 2 Zc.
+// mrow: LDS address of the lane's word in the layer's first row of messages; row_bytes = 2 Zc.  aq: the lane's soft-bit
+// addresses on the layer's edges from the graph's table (LdpcDecodeLaunch::pair_addr; the kernel's soft bits start at LDS
+// address 0), four edges per element: check j in the low half, check j + Zc / 2 in the high half.
 template <uint32_t DEG, bool FIRST>
-__device__ __forceinline__ void process_check_pair_lm(uint32_t soft, uint32_t mrow, uint32_t row_bytes, const ScaleRule& scale,
-                                                      const NRPHY_CONSTANT uint32_t* edge, uint32_t half, uint32_t minus_half, uint32_t j,
-                                                      uint32_t jm, uint32_t k512, Trace* tr)
+__device__ __forceinline__ void process_check_pair_lm(uint32_t mrow, uint32_t row_bytes, const ScaleRule& scale, const uint4 (&aq)[5],
+                                                      uint32_t k512, Trace* tr)
 {
   constexpr uint32_t NP = (DEG + 1u) / 2u;
   uint32_t           addr1[DEG], addr2[DEG], x[DEG], c[DEG], w[NP];
@@ -490,14 +492,14 @@ __device__ __forceinline__ void process_check_pair_lm(uint32_t soft, uint32_t mr
   }
 #pragma unroll
   for (uint32_t t = 0; t != DEG; ++t) {
-    const uint32_t e = edge[t], shift = e & 0xFFFFu;
-    const uint32_t pos = min(j + shift, jm + shift);   // (j + shift) mod Zc
-    addr1[t]           = (soft + (e >> 16)) + pos;     // LDS address (the graph holds node * Zc; the sum in brackets is scalar)
-    addr2[t]           = addr1[t] + (pos < half ? half : minus_half); // (j + Zc / 2 + shift) mod Zc
+    const uint4&   q = aq[t / 4u];
+    const uint32_t a = (t % 4u) == 0 ? q.x : (t % 4u) == 1 ? q.y : (t % 4u) == 2 ? q.z : q.w;
+    addr1[t]         = a & 0xFFFFu;
+    addr2[t]         = a >> 16;
   }
   TR(1);
-  load_pairs10<DEG, 0>(x, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
-  load_pairs10<DEG, 10>(x, [&](uint32_t t) { return addr1[t]; }, [&](uint32_t t) { return addr2[t]; });
+  load_pairs10<DEG, 0>(x, [&](uint32_t u) { return addr1[u]; }, [&](uint32_t u) { return addr2[u]; });
+  load_pairs10<DEG, 10>(x, [&](uint32_t u) { return addr1[u]; }, [&](uint32_t u) { return addr2[u]; });
   TR(2);
   if (!FIRST) {
 #define NRPHY_IX(k) ((k) < NP ? (k) : NP - 1u)
@@ -536,20 +538,19 @@ __device__ __forceinline__ void process_check_pair_lm(uint32_t soft, uint32_t mr
 }
 
 template <bool FIRST>
-__device__ __forceinline__ void process_layer_pair_lm(uint32_t deg, uint32_t soft, uint32_t mrow, uint32_t row_bytes, const ScaleRule& scale,
-                                                      const NRPHY_CONSTANT uint32_t* edge, uint32_t half, uint32_t minus_half, uint32_t j,
-                                                      uint32_t jm, uint32_t k512, Trace* tr)
+__device__ __forceinline__ void process_layer_pair_lm(uint32_t deg, uint32_t mrow, uint32_t row_bytes, const ScaleRule& scale,
+                                                      const uint4 (&aq)[5], uint32_t k512, Trace* tr)
 {
   switch (deg) {
-    case 3: return process_check_pair_lm<3, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 4: return process_check_pair_lm<4, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 5: return process_check_pair_lm<5, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 6: return process_check_pair_lm<6, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 7: return process_check_pair_lm<7, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 8: return process_check_pair_lm<8, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 9: return process_check_pair_lm<9, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
-    case 10: return process_check_pair_lm<10, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
-    default: return process_check_pair_lm<19, FIRST>(soft, mrow, row_bytes, scale, edge, half, minus_half, j, jm, k512, tr);
+    case 3: return process_check_pair_lm<3, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
+    case 4: return process_check_pair_lm<4, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
+    case 5: return process_check_pair_lm<5, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
+    case 6: return process_check_pair_lm<6, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
+    case 7: return process_check_pair_lm<7, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
+    case 8: return process_check_pair_lm<8, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
+    case 9: return process_check_pair_lm<9, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
+    case 10: return process_check_pair_lm<10, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
+    default: return process_check_pair_lm<19, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
   }
 }
 
@@ -792,7 +793,9 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
     // soft bits those layers touch (the rows beyond are all zero and never read again): workgroup-uniform, decided per
     // codeblock from its own soft bits, so the result never depends on the launch's LDS budget.
     const uint32_t msg_off = (cb_len + 48u + 15u) & ~15u;
-    const bool     lm      = LM && p.lm_lds_bytes != 0 && msg_off + graph->pair_ptr[nof_layers] * 2u * zc <= p.lm_lds_bytes;
+    // (the table of soft-bit addresses counts from LDS address 0, where this kernel's only LDS array starts)
+    const bool     lm      = LM && p.lm_lds_bytes != 0 && soft_a == 0 && p.pair_addr != nullptr &&
+                             msg_off + graph->pair_ptr[nof_layers] * 2u * zc <= p.lm_lds_bytes;
     if (claim_late && !lm && pooled) {
       if (j == 0) {
         s_flag[3] = acquire_slot(p.slot_flags, p.nof_slots, blockIdx.x);
@@ -817,19 +820,41 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
     Record*        recs        = reinterpret_cast<Record*>(rec);
     const uint32_t rec_stride  = PAIR ? half : zc;                       // records of one layer
     const uint32_t minus_half  = 0u - half;
+    uint4 wrap[5] = {}; // (messages in LDS) the first layer's soft-bit addresses, requested at the end of the previous iteration
     for (uint32_t it = 0; it != max_iterations && iterations == 0; ++it) {
       if constexpr (LM) {
         if (lm) { // workgroup-uniform
-          uint32_t e0 = graph->row_ptr[0], e1 = graph->row_ptr[1], rows = 0;
-          for (uint32_t m = 0; m != nof_layers; ++m) {
+          // The lane's soft-bit addresses of a layer: five rows of the table (sixteen bytes per lane and row: four edges),
+          // requested a layer ahead.
+          const uint4* atab = reinterpret_cast<const uint4*>(p.pair_addr) + j;
+          uint4        cur[5];
+          if (it == 0) {
+#pragma unroll
+            for (uint32_t q = 0; q != 5; ++q) {
+              cur[q] = atab[q * half];
+            }
+          } else {
+#pragma unroll
+            for (uint32_t q = 0; q != 5; ++q) {
+              cur[q] = wrap[q];
+            }
+          }
+          uint32_t e0 = graph->row_ptr[0], e1 = graph->row_ptr[1], rows = 0, quads = 0;
+          // One layer with the addresses in `now`; the next layer's (after the last: the first's, for the next iteration)
+          // are requested into `next` before the layer starts.  Two calls per trip with the arrays swapped: no copies.
+          auto layer = [&](uint32_t m, const uint4 (&now)[5], uint4 (&next)[5]) __attribute__((always_inline)) {
             const uint32_t e2  = graph->row_ptr[m + 2u]; // (the array has a spare element) a layer ahead: off the critical path
             const uint32_t deg = e1 - e0;
+            quads              = m + 1u != nof_layers ? quads + ((deg + 3u) >> 2) : 0u;
+#pragma unroll
+            for (uint32_t q = 0; q != 5; ++q) {
+              next[q] = atab[(quads + q) * half];
+            }
             if (active) {
-              const auto* edge = graph->edge + e0;
               if (it == 0) {
-                process_layer_pair_lm<true>(deg, soft_a, msgs + rows * 2u * zc, 2u * zc, scale, edge, half, minus_half, j, jm, k512, nullptr);
+                process_layer_pair_lm<true>(deg, msgs + rows * 2u * zc, 2u * zc, scale, now, k512, nullptr);
               } else {
-                process_layer_pair_lm<false>(deg, soft_a, msgs + rows * 2u * zc, 2u * zc, scale, edge, half, minus_half, j, jm, k512, tr);
+                process_layer_pair_lm<false>(deg, msgs + rows * 2u * zc, 2u * zc, scale, now, k512, tr);
               }
             }
             rows += (deg + 1u) >> 1;
@@ -839,6 +864,22 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
 #endif
             e0 = e1;
             e1 = e2;
+          };
+          uint4 alt[5];
+          for (uint32_t m = 0; m < nof_layers; m += 2u) {
+            layer(m, cur, alt);
+            if (m + 1u != nof_layers) {
+              layer(m + 1u, alt, cur);
+            } else {
+#pragma unroll
+              for (uint32_t q = 0; q != 5; ++q) {
+                cur[q] = alt[q];
+              }
+            }
+          }
+#pragma unroll
+          for (uint32_t q = 0; q != 5; ++q) {
+            wrap[q] = cur[q];
           }
         }
       }

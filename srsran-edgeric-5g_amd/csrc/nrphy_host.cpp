@@ -759,6 +759,9 @@ extern "C" int nrphy_destroy(nrphy_ctx_t* ctx)
   for (DecoderGraph* g : ctx->d_dec_graph) {
     (void)hipFree(g);
   }
+  for (uint32_t* a : ctx->d_dec_addr) {
+    (void)hipFree(a);
+  }
   for (auto& kv : ctx->d_dec_crc) {
     (void)hipFree(kv.second);
   }
@@ -2220,11 +2223,43 @@ const DecoderGraph* get_decoder_graph(nrphy_ctx* ctx, unsigned bg, unsigned zc)
         return nullptr;
       }
     }
+    for (unsigned m = 0, quads = 0; m != MAX_BG_ROWS + 2; ++m) {
+      g[0].quad_ptr[m] = quads;
+      quads += m + 1 < MAX_BG_ROWS + 2 ? (g[0].row_ptr[m + 1] - g[0].row_ptr[m] + 3) / 4 : 0;
+    }
+    if ((zc & 1U) == 0) {
+      // Two checks per lane with the messages in LDS: where lane j finds the soft bits of checks j and j + Zc / 2 on every edge
+      // -- (variable node * Zc + (check + shift) mod Zc), the first in the low half of a word, the second in the high half --
+      // as [row of four edges][lane][edge in the row]: the same for every codeblock and iteration, so the kernel reads the
+      // words of a layer (sixteen bytes per lane and row, a layer ahead) instead of computing them (7 vector instructions per
+      // edge and pass).  Five spare rows: the kernel always reads five rows from a layer's first.
+      const unsigned        half = zc / 2, total = g[0].quad_ptr[rows] + 5;
+      std::vector<uint32_t> addr((size_t)total * half * 4, 0);
+      for (unsigned m = 0; m != rows; ++m) {
+        const unsigned e0 = g[0].row_ptr[m], deg = g[0].row_ptr[m + 1] - e0;
+        for (unsigned t = 0; t != deg; ++t) {
+          const unsigned base = g[0].edge[e0 + t] >> 16, shift = g[0].edge[e0 + t] & 0xFFFFU;
+          for (unsigned j = 0; j != half; ++j) {
+            const unsigned a1 = base + (j + shift) % zc, a2 = base + (j + half + shift) % zc; // < 68 * 384 < 2^16
+            addr[((size_t)(g[0].quad_ptr[m] + t / 4) * half + j) * 4 + t % 4] = a1 | (a2 << 16);
+          }
+        }
+      }
+      if (upload(&ctx->d_dec_addr[slot], addr.data(), addr.size() * sizeof(uint32_t)) != hipSuccess) {
+        return nullptr;
+      }
+    }
     if (upload(&ctx->d_dec_graph[slot], g.data(), sizeof(DecoderGraph)) != hipSuccess) {
       return nullptr;
     }
   }
   return ctx->d_dec_graph[slot];
+}
+
+const uint32_t* get_decoder_pair_addresses(nrphy_ctx* ctx, unsigned bg, unsigned zc)
+{
+  const int pos = lifting_position(zc);
+  return pos < 0 ? nullptr : ctx->d_dec_addr[(bg - 1) * NOF_LIFTING_SIZES + (unsigned)pos];
 }
 
 // Early-stop weights: word w of the n-bit message (32 bits, the last one n mod 32) is followed by n - 32 w - bits(w)
@@ -2359,7 +2394,8 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
   LdpcDecodeLaunch p;
   {
     std::lock_guard<std::recursive_mutex> lock(ctx->host_mutex);
-    p.graph = get_decoder_graph(ctx, cfg->base_graph, zc);
+    p.graph     = get_decoder_graph(ctx, cfg->base_graph, zc);
+    p.pair_addr = get_decoder_pair_addresses(ctx, cfg->base_graph, zc);
   }
   if (p.graph == nullptr) {
     return NRPHY_ERR_DEVICE;

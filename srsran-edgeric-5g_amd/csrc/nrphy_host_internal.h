@@ -85,6 +85,7 @@ struct nrphy_ctx {
   uint32_t*    d_x1     = nullptr;
   std::map<uint32_t, float2*> d_twiddle; // exp(+j 2 pi k / N) per DFT size, built on first use (under host_mutex)
   DecoderGraph* d_dec_graph[NOF_GRAPHS] = {}; // decoder graphs, built on first use
+  uint32_t*     d_dec_addr[NOF_GRAPHS]  = {}; // ... and, for even lifting sizes, the soft-bit addresses of every (edge, pair of checks)
   std::map<uint64_t, uint32_t*> d_dec_crc;     // early-stop CRC weights per (polynomial, message length)
   std::map<uint32_t, uint32_t*> d_tb_crc_w;    // transport-block CRC weights of the PUSCH assembly kernel per block size
   std::vector<LiftedGraph> graphs; // host copy (plan creation sizes the LDS staging of graph rows from it)

@@ -246,11 +246,13 @@ hipError_t launch_ldpc_encode(const LiftedGraph* graphs, uint32_t graph, uint32_
 struct DecoderGraph {
   uint32_t row_ptr[MAX_BG_ROWS + 2]; // 32-bit: read with scalar loads (a 16-bit element goes through a vector load and a round trip to L2)
   uint32_t pair_ptr[MAX_BG_ROWS + 2]; // rows of two edges before row m: sum of ceil(degree / 2) (messages per edge in LDS)
+  uint32_t quad_ptr[MAX_BG_ROWS + 2]; // rows of four edges before row m: sum of ceil(degree / 4) (the table of soft-bit addresses)
   uint32_t edge[MAX_BG_EDGES]; // (variable node * Zc) << 16 | lifted shift
 };
 
 struct LdpcDecodeLaunch {
   const DecoderGraph* graph;
+  const uint32_t*     pair_addr;  // even lifting sizes: soft-bit addresses of (edge, pair of checks), [row of four edges][lane][4]; else null
   const int8_t*       llr;        // per codeblock: nof_llr soft bits (the codeblock without its first 2 Zc bits)
   uint2*              scratch;    // check records of 8 bytes: nof_slots slots of nof_layers_max * Zc records
   uint32_t*           slot_flags;  // one word per slot (0 = free), all clear at launch; unused when every codeblock has a slot of its own
