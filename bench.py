@@ -467,7 +467,7 @@ def main():
             sys.exit(2)
         import rx_chain_bench
         print(json.dumps(rx_chain_bench.run(argparse.Namespace(
-            slots=args.slots if args.slots != 1024 else 256, iterations=8, steps=args.steps, warmup=args.warmup, snr_db=32.0))),
+            slots=args.slots, iterations=8, steps=args.steps, warmup=args.warmup, snr_db=32.0))),
             flush=True)
         return
 

@@ -826,7 +826,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
         if (lm) { // workgroup-uniform
           // The lane's soft-bit addresses of a layer: five rows of the table (sixteen bytes per lane and row: four edges),
           // requested a layer ahead.
-          const uint4* atab = reinterpret_cast<const uint4*>(p.pair_addr) + j;
+          const uint4* atab = reinterpret_cast<const uint4*>(p.pair_addr) + (active ? j : half - 1u); // (idle lanes stay inside the table)
           uint4        cur[5];
           if (it == 0) {
 #pragma unroll
