@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Phase timeline of one wave of the LDS-message decoder (ldpc_decode_pairs_lm_kernel): build the library with -DNRPHY_DEC_TRACE
+(add it to FLAGS in srsran-edgeric-5g_amd/build.py, `build.py --force`), then on the GPU box: python3 profiles/probes/decoder_trace_run.py
+Prints the cycles one wave of the middle codeblock spent between the marks TR(k) of ldpc_decoder.hip, summed over the layers
+of iterations 2 .. 8 (28 layers); every mark costs ~300 cycles of its own (s_memtime + wait)."""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import importlib

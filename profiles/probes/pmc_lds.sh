@@ -1,4 +1,5 @@
 #!/bin/bash
+# LDS counters of the decoder launch (conflicts, pipe activity, waits): pmc_lds.sh <outdir> [NAME=VALUE ...]   (see rx_pmc_env.sh)
 OUT=$(realpath -m "$1"); shift; mkdir -p "$OUT"; ROOT=$PWD
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp

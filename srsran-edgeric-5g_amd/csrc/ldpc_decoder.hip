@@ -14,6 +14,11 @@
 // scaled magnitudes, the edge holding the minimum and one sign bit per edge: 8 bytes instead of up to 19 -- read and
 // written only by the thread that owns the check (coalesced, L2 resident; the next layer's record is prefetched).
 // This is the reference's arithmetic re-indexed by check instead of by variable position; the values are the same.
+//
+// Three forms of the kernel, same values in each: one check per lane (ldpc_decode_kernel: odd lifting sizes); two checks per
+// lane in packed 16-bit arithmetic (ldpc_decode_pairs_kernel); and two checks per lane with the messages of every edge kept in
+// LDS and the soft-bit addresses read from a table (ldpc_decode_pairs_lm_kernel: codeblocks that run few layers -- high code
+// rates --, decided per codeblock; see "messages kept per edge in LDS" below).
 #include "bits_device.h"
 
 #include <cstdlib>
@@ -408,6 +413,8 @@ struct ScaleRule {
   }
 };
 
+// -DNRPHY_DEC_TRACE (profiles/probes/decoder_trace_run.py): one wave of one codeblock adds up the cycles between the marks TR(k) of
+// a layer (s_memtime; ~300 cycles of its own per mark) and leaves the sums in the launch's scratch.
 #ifdef NRPHY_DEC_TRACE
 struct Trace { uint64_t acc[10]; uint64_t last; };
 #define TR(k)                                                                                                        \
