@@ -177,6 +177,9 @@ def roof(name, ms, nbytes, slots=None, config=None, wire=False):
     return out
 
 
+EVENT_STRIDE = 4  # every fourth step of the timed region carries the HIP events of the kernel durations
+
+
 def run_downlink(env, config, slots, steps, warmup, wire=False):
     """Builds the workload of BASELINE config 2, 3 or 4 for this rank, times `steps` steps and returns the measurement (on
     rank 0: the JSON fields; elsewhere None)."""
@@ -265,8 +268,12 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
     for _ in range(warmup):
         step()
     ctx.synchronize()
-    plan.enable_timing(steps)
-    oplan.enable_timing(steps)
+    # Kernel durations by HIP events on every fourth step of the timed region: an event between two launches costs the stream
+    # 4-5 us, six per step 0.02 ms of a 0.88 ms step (profiles/r03_codeblock_experiments.txt, "events").
+    # NRPHY_BENCH_NO_KERNEL_EVENTS=1: none (the probe that measured it).
+    if os.environ.get("NRPHY_BENCH_NO_KERNEL_EVENTS") != "1":
+        plan.enable_timing(steps, stride=EVENT_STRIDE)
+        oplan.enable_timing(steps, stride=EVENT_STRIDE)
     barrier()
     torch.cuda.synchronize()
     ctx.synchronize()

@@ -450,8 +450,8 @@ ABI_SYMBOLS = [
     "nrphy_pdsch_validate", "nrphy_pdsch_derive", "nrphy_tbs_calculate", "nrphy_ofdm_symbol_size",
     "nrphy_ofdm_slot_size", "nrphy_pdsch_plan_create", "nrphy_pdsch_plan_destroy",
     "nrphy_pdsch_plan_nof_codeblocks", "nrphy_pdsch_plan_codeword_bits", "nrphy_pdsch_plan_codeword_offset",
-    "nrphy_pdsch_run", "nrphy_pdsch_plan_enable_timing", "nrphy_pdsch_plan_kernel_times",
-    "nrphy_ofdm_plan_enable_timing", "nrphy_ofdm_plan_kernel_time", "nrphy_pdsch_process_host", "nrphy_pdsch_encode_host", "nrphy_ldpc_encode", "nrphy_ofdm_plan_create",
+    "nrphy_pdsch_run", "nrphy_pdsch_plan_enable_timing", "nrphy_pdsch_plan_kernel_times", "nrphy_pdsch_plan_timing_stride",
+    "nrphy_ofdm_plan_enable_timing", "nrphy_ofdm_plan_kernel_time", "nrphy_ofdm_plan_timing_stride", "nrphy_pdsch_process_host", "nrphy_pdsch_encode_host", "nrphy_ldpc_encode", "nrphy_ofdm_plan_create",
     "nrphy_ofdm_plan_destroy", "nrphy_ofdm_plan_slot_stride", "nrphy_ofdm_run",
     "nrphy_ofdm_modulate_symbol_host", "nrphy_ofdm_modulate_slot_host", "nrphy_dft_run", "nrphy_dft_run_host",
     "nrphy_ofdm_demod_run", "nrphy_ofdm_demodulate_slot_host", "nrphy_ofdm_demodulate_symbol_host",

@@ -391,8 +391,10 @@ struct nrphy_pdsch_plan {
   hipStream_t           aux_stream[MAX_AUX] = {};
   hipEvent_t            fork_event = nullptr, join_event[MAX_AUX] = {};
   uint32_t              n_aux = 0;
-  std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs
+  std::vector<hipEvent_t> events; // 4 per recorded run: start, after tb_crc, after codeblocks, after dmrs (only when a DM-RS launch follows)
+  std::vector<uint8_t>  timed_dmrs; // per recorded run: its fourth event was recorded
   uint32_t              timed_runs = 0, max_timed_runs = 0;
+  uint32_t              timing_stride = 1, timing_counter = 0; // every timing_stride-th run is recorded
 };
 
 static bool plan_side_streams(nrphy_pdsch_plan* plan, uint32_t want);
@@ -411,6 +413,7 @@ struct nrphy_ofdm_plan {
   std::mutex          window_mutex;           // guards the map (the host-span entry points already hold ctx->host_mutex)
   std::vector<hipEvent_t> events; // 2 per recorded run
   uint32_t            timed_runs = 0, max_timed_runs = 0;
+  uint32_t            timing_stride = 1, timing_counter = 0; // every timing_stride-th run is recorded
   uint4*              d_wire_partials = nullptr; // wire-format runs with measurements: one record per workgroup
   size_t              wire_partials_cap = 0;     // records
 };
@@ -1513,7 +1516,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     HIP_TRY(hipMemsetAsync(d_cw_scrambled, 0, cw_bytes, s));
   }
   hipEvent_t* ev = nullptr;
-  if (plan->timed_runs < plan->max_timed_runs) {
+  if (plan->timed_runs < plan->max_timed_runs && plan->timing_counter++ % plan->timing_stride == 0) {
     ev = &plan->events[4 * plan->timed_runs++];
     HIP_TRY(hipEventRecord(ev[0], s));
   }
@@ -1556,9 +1559,12 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     // After the data: when data RE share a CDM group with DM-RS the reference lets DM-RS overwrite them.
     const TraceRange trace_dmrs("process_dmrs");
     HIP_TRY(launch_dmrs(p, (uint32_t*)d_grid, s));
+    if (ev) {
+      HIP_TRY(hipEventRecord(ev[3], s));
+    }
   }
-  if (ev) {
-    HIP_TRY(hipEventRecord(ev[3], s));
+  if (ev) { // (an event between two launches costs the stream a few microseconds: none where no launch follows)
+    plan->timed_dmrs[plan->timed_runs - 1] = (d_grid && !merge_dmrs) ? 1 : 0;
   }
   return NRPHY_OK;
 }
@@ -1575,8 +1581,20 @@ extern "C" int nrphy_pdsch_plan_enable_timing(nrphy_pdsch_plan_t* plan, uint32_t
   for (hipEvent_t& e : plan->events) {
     HIP_TRY(hipEventCreate(&e));
   }
+  plan->timed_dmrs.assign(max_runs, 0);
   plan->max_timed_runs = max_runs;
   plan->timed_runs     = 0;
+  plan->timing_counter = 0;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_pdsch_plan_timing_stride(nrphy_pdsch_plan_t* plan, uint32_t stride)
+{
+  if (plan == nullptr || stride == 0) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  plan->timing_stride  = stride;
+  plan->timing_counter = 0;
   return NRPHY_OK;
 }
 
@@ -1587,14 +1605,15 @@ extern "C" int nrphy_pdsch_plan_kernel_times(nrphy_pdsch_plan_t* plan, float avg
   }
   double sum[4] = {0, 0, 0, 0};
   for (uint32_t r = 0; r != plan->timed_runs; ++r) {
-    hipEvent_t* ev = &plan->events[4 * r];
-    HIP_TRY(hipEventSynchronize(ev[3]));
+    hipEvent_t*    ev   = &plan->events[4 * r];
+    const unsigned last = plan->timed_dmrs[r] ? 3 : 2;
+    HIP_TRY(hipEventSynchronize(ev[last]));
     float ms = 0;
-    for (int k = 0; k != 3; ++k) {
+    for (unsigned k = 0; k != last; ++k) {
       HIP_TRY(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
       sum[k] += ms;
     }
-    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[last]));
     sum[3] += ms;
   }
   for (int k = 0; k != 4; ++k) {
@@ -3206,7 +3225,7 @@ int ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid, co
     }
   }
   hipEvent_t* ev = nullptr;
-  if (plan->timed_runs < plan->max_timed_runs) {
+  if (plan->timed_runs < plan->max_timed_runs && plan->timing_counter++ % plan->timing_stride == 0) {
     ev = &plan->events[2 * plan->timed_runs++];
     HIP_TRY(hipEventRecord(ev[0], s));
   }
@@ -3573,6 +3592,17 @@ extern "C" int nrphy_ofdm_plan_enable_timing(nrphy_ofdm_plan_t* plan, uint32_t m
   }
   plan->max_timed_runs = max_runs;
   plan->timed_runs     = 0;
+  plan->timing_counter = 0;
+  return NRPHY_OK;
+}
+
+extern "C" int nrphy_ofdm_plan_timing_stride(nrphy_ofdm_plan_t* plan, uint32_t stride)
+{
+  if (plan == nullptr || stride == 0) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  plan->timing_stride  = stride;
+  plan->timing_counter = 0;
   return NRPHY_OK;
 }
 

@@ -397,8 +397,10 @@ class PdschPlan:
         _check(self.ctx.lib.nrphy_pdsch_run(self.handle, _dptr(d_tb), _dptr(d_grid), _dptr(d_cw_rm), _dptr(d_cw_scr),
                                             int(zero_grids), _stream(stream)), "nrphy_pdsch_run")
 
-    def enable_timing(self, max_runs):
+    def enable_timing(self, max_runs, stride=1):
+        """Records HIP events around the kernels of the next runs: every `stride`-th one, up to max_runs of them."""
         _check(self.ctx.lib.nrphy_pdsch_plan_enable_timing(self.handle, max_runs), "nrphy_pdsch_plan_enable_timing")
+        _check(self.ctx.lib.nrphy_pdsch_plan_timing_stride(self.handle, stride), "nrphy_pdsch_plan_timing_stride")
 
     def kernel_times(self):
         """Average ms of (tb_crc, codeblock, dmrs, whole run) over the recorded runs, and the run count."""
@@ -512,8 +514,9 @@ class OfdmPlan:
         _check(self.ctx.lib.nrphy_ofdm_run_ci16(self.handle, nof_grids, _dptr(d_grid), _dptr(d_slot_index), C.byref(wire_cfg),
                                                 _dptr(d_iq16), _dptr(d_stats), _stream(stream)), "nrphy_ofdm_run_ci16")
 
-    def enable_timing(self, max_runs):
+    def enable_timing(self, max_runs, stride=1):
         _check(self.ctx.lib.nrphy_ofdm_plan_enable_timing(self.handle, max_runs), "nrphy_ofdm_plan_enable_timing")
+        _check(self.ctx.lib.nrphy_ofdm_plan_timing_stride(self.handle, stride), "nrphy_ofdm_plan_timing_stride")
 
     def kernel_time(self):
         ms = C.c_float(0)
