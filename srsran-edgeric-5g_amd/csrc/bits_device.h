@@ -8,6 +8,30 @@ namespace nrphy {
 
 constexpr int WAVE = 64;
 
+// Workgroup timeline of the prologue launch (profiles/prologue_trace.py; a variant build with -DNRPHY_WG_TRACE, never the
+// product): thread 0 of every workgroup records the 100 MHz wall clock at its start (slot 0), at up to five points on
+// the way (1-5) and at its end (6), and where it ran (7: HW_ID, XCC_ID).
+#ifdef NRPHY_WG_TRACE
+constexpr uint32_t WG_TRACE_MAX = 16384;
+__device__ uint64_t g_wg_trace[8 * WG_TRACE_MAX];
+#define NRPHY_WG_TRACE_MARK(slot)                                              \
+  do {                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < WG_TRACE_MAX) {                       \
+      g_wg_trace[8 * blockIdx.x + (slot)] = wall_clock64();                    \
+    }                                                                          \
+  } while (0)
+#define NRPHY_WG_TRACE_WHERE(role)                                                                              \
+  do {                                                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x < WG_TRACE_MAX) {                                                        \
+      const uint64_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20); \
+      g_wg_trace[8 * blockIdx.x + 7] = ((uint64_t)(role) << 60) | ((xcc & 0xFu) << 32) | hw;                     \
+    }                                                                                                           \
+  } while (0)
+#else
+#define NRPHY_WG_TRACE_MARK(slot) ((void)0)
+#define NRPHY_WG_TRACE_WHERE(role) ((void)0)
+#endif
+
 // Plan tables (PDU descriptors, work lists) never change while a kernel runs.  Reading them through the constant
 // address space tells the compiler so: wave-uniform reads become scalar loads into SGPRs (one s_load_dwordx16 for
 // sixteen fields) instead of vector loads + v_readfirstlane with a full memory round trip each.
@@ -402,6 +426,117 @@ __device__ inline void gold_sequence_workgroup(const GoldTables* gold, const uin
     }
   }
   lds_barrier(); // the ring is reused by the caller's next sequence
+}
+
+// Long sequence generated by ONE wavefront with the recurrence in registers: c(n) (x2 part alone unless WITH_X1) for
+// n in [32 first_word, 32 (first_word + nwords)) into global memory (out[0] is word first_word).
+//
+// At level m = 64 the lifted recurrence W[k] = W[k - 28 m] ^ W[k - 29 m] ^ W[k - 30 m] ^ W[k - 31 m] relates words that are
+// whole rows of 64 apart: with word 64 r + l in lane l, row r = row(r-28) ^ row(r-29) ^ row(r-30) ^ row(r-31) lane by
+// lane.  The wave keeps the last 31 rows in 31 registers and produces a row -- 64 words, one 256-byte store -- with one
+// v_bitop3 (three-way XOR), one v_xor and the store: no LDS, no barrier, no address arithmetic, and 28 rows between a
+// value and its first use.  The 31 seed rows (1984 words) come from the scheme of gold_sequence_wave() with the level
+// doubling in `seed` (1984 words of LDS private to the wave): jump, 31 head words, then levels 1, 1, 2, 4, 8, 8, 16, 32.
+// (The workgroup form above spent 27 vector instructions per word and thread -- four ring reads with their addresses, a
+// ring write, bounds -- and a barrier per 1792 words; this one spends 3 per 64 words after a seed of about 650.)
+constexpr uint32_t GOLD_SEED_ROWS  = 31;
+constexpr uint32_t GOLD_SEED_WORDS = GOLD_SEED_ROWS * WAVE;
+
+template <bool WITH_X1>
+__device__ inline void gold_sequence_rows_wave(const GoldTables* gold, const uint32_t* x1_words, uint32_t c_init,
+                                               uint32_t first_word, uint32_t nwords, uint32_t* __restrict__ out,
+                                               uint32_t* seed, uint32_t lane)
+{
+  if (nwords == 0) { // wave-uniform
+    return;
+  }
+  // 1. The state at the part's offset (wave-uniform chain of ballots; every matrix row requested before the first use).
+  uint32_t state = c_init & 0x7FFFFFFFu;
+  {
+    const uint32_t offset = 1600u + 32u * first_word;
+    uint32_t       row[GOLD_JUMP_BITS];
+#pragma unroll
+    for (uint32_t k = 0; k != GOLD_JUMP_BITS; ++k) {
+      row[k] = ((offset >> k) & 1u) ? gold->x2_jump[k][lane & 31u] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k != GOLD_JUMP_BITS; ++k) {
+      if ((offset >> k) & 1u) { // wave-uniform
+        const uint32_t bit = (lane < 31u) ? (__popc(row[k] & state) & 1u) : 0u;
+        state              = (uint32_t)__ballot(bit != 0) & 0x7FFFFFFFu;
+      }
+    }
+  }
+  NRPHY_WG_TRACE_MARK(1);
+  // 2. The first 31 words, lane w the 32 parities of word w.
+  if (lane < 31u) {
+    uint32_t head[32];
+#pragma unroll
+    for (uint32_t t = 0; t != 32; ++t) {
+      head[t] = gold->x2_head[t][lane];
+    }
+    uint32_t word = 0;
+#pragma unroll
+    for (uint32_t t = 0; t != 32; ++t) {
+      word |= (__popc(head[t] & state) & 1u) << (31u - t);
+    }
+    seed[lane] = word;
+  }
+  wave_lds_fence();
+  NRPHY_WG_TRACE_MARK(2);
+  // 3. Level doubling in LDS up to the 31 seed rows (or the whole sequence if it is shorter).
+  const uint32_t need = nwords < GOLD_SEED_WORDS ? nwords : GOLD_SEED_WORDS;
+  for (uint32_t have = 31u, m = 1u; have < need;) { // wave-uniform
+    while (m < 32u && have >= 62u * m) {
+      m *= 2u;
+    }
+    const uint32_t end = have + 28u * m < need ? have + 28u * m : need;
+    for (uint32_t k = have + lane; k < end; k += WAVE) {
+      seed[k] = __builtin_amdgcn_bitop3_b32(seed[k - 28u * m], seed[k - 29u * m], seed[k - 30u * m], 0x96) ^
+                seed[k - 31u * m];
+    }
+    wave_lds_fence();
+    have = end;
+  }
+  NRPHY_WG_TRACE_MARK(3);
+  // 4. Rows in registers.
+  const uint32_t* x1 = x1_words + first_word + lane;
+  uint32_t*       o  = out + lane;
+  uint32_t        w[GOLD_SEED_ROWS];
+#pragma unroll
+  for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
+    const uint32_t k = i * WAVE + lane;
+    w[i]             = (k < need) ? seed[k] : 0u;
+    if (k < nwords) {
+      o[i * WAVE] = WITH_X1 ? (w[i] ^ x1[i * WAVE]) : w[i];
+    }
+  }
+  NRPHY_WG_TRACE_MARK(4);
+  const uint32_t rows = (nwords + WAVE - 1u) / WAVE;
+  uint32_t       base = GOLD_SEED_ROWS;
+  // whole blocks of 31 rows: no bounds
+  for (; (base + GOLD_SEED_ROWS) * WAVE <= nwords; base += GOLD_SEED_ROWS) { // wave-uniform
+    uint32_t*       ob = o + base * WAVE;
+    const uint32_t* xb = x1 + base * WAVE;
+#pragma unroll
+    for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
+      w[i] ^= __builtin_amdgcn_bitop3_b32(w[(i + 1u) % GOLD_SEED_ROWS], w[(i + 2u) % GOLD_SEED_ROWS],
+                                          w[(i + 3u) % GOLD_SEED_ROWS], 0x96);
+      ob[i * WAVE] = WITH_X1 ? (w[i] ^ xb[i * WAVE]) : w[i];
+    }
+  }
+  if (base < rows) { // the last, partial block
+    uint32_t*       ob = o + base * WAVE;
+    const uint32_t* xb = x1 + base * WAVE;
+#pragma unroll
+    for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
+      w[i] ^= __builtin_amdgcn_bitop3_b32(w[(i + 1u) % GOLD_SEED_ROWS], w[(i + 2u) % GOLD_SEED_ROWS],
+                                          w[(i + 3u) % GOLD_SEED_ROWS], 0x96);
+      if ((base + i) * WAVE + lane < nwords) {
+        ob[i * WAVE] = WITH_X1 ? (w[i] ^ xb[i * WAVE]) : w[i];
+      }
+    }
+  }
 }
 
 // round-to-nearest-even float -> bf16 exactly as the reference stores the grid

@@ -1187,7 +1187,9 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
       // A big batch has enough PDUs to fill the device with one workgroup each (seeding a generator is the costly
       // part: measured 0.111 / 0.098 / 0.096 ms per 1024 config-3 PDUs with 4 / 2 / 1 parts); a small one is split
       // for latency.
-      const uint32_t parts_max = n_pdu >= 128 ? 1U : SCR_PARTS;
+      static const char* parts_env = std::getenv("NRPHY_SCR_PARTS_BIG"); // (A/B knob: parts of a sequence in a big batch)
+      const uint32_t     parts_big = parts_env ? std::max(1, std::min((int)SCR_PARTS, std::atoi(parts_env))) : 1U;
+      const uint32_t parts_max = n_pdu >= 128 ? parts_big : SCR_PARTS;
       const uint32_t parts     = std::min<uint32_t>(parts_max, std::max<uint32_t>(1, pd.scr_words >> 11));
       const uint32_t chunk = divide_ceil(pd.scr_words, parts);
       for (uint32_t first = 0, k = 0; first < pd.scr_words; first += chunk, ++k) {
@@ -1507,6 +1509,8 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     // the transport blocks and sequences out of the cache.)
     static const char* nt_env = std::getenv("NRPHY_EXTRAS_NT");
     p.extras_nt               = nt_env ? (uint32_t)std::atoi(nt_env) : 0;
+    static const char* order_env = std::getenv("NRPHY_PROLOGUE_ORDER");
+    p.prologue_order             = order_env ? (uint32_t)std::atoi(order_env) : 0;
   }
   const size_t cw_bytes = (size_t)(plan->cw_bits / 8);
   if (d_cw_rm) {

@@ -221,6 +221,7 @@ struct PdschLaunch {
   uint32_t           lds_u_words;    // ... and the scratch region its stages share (pdsch_kernels.hip, CbShared)
   uint32_t           profile_stage; // 0 = run everything; n > 0 = codeblock waves stop after stage n (NRPHY_PROFILE_STAGE)
   uint32_t           extras_nt;     // 1: the stores of the DM-RS / zero-fill waves are non-temporal (NRPHY_EXTRAS_NT)
+  uint32_t           prologue_order; // 0: sequence workgroups first; 1: spread among the CRC workgroups (NRPHY_PROLOGUE_ORDER)
 };
 
 // Kernel launchers (defined in the .hip files).

@@ -37,12 +37,20 @@ namespace nrphy {
 // Scrambling and DM-RS sequences: see gold_sequence_workgroup().
 // ================================================================================================================
 constexpr int TB_CRC_THREADS = 256;
+
 constexpr int TB_CRC_WPT = NRPHY_CRC_WORDS_PER_THREAD;
 static_assert(TB_CRC_REGION_WORDS == TB_CRC_WPT * TB_CRC_THREADS, "words per thread");
 
 // reg * y mod g for a 32-bit partial, y's table in LDS: tab[k * 256 + b] = (b x^(8k)) y mod g.
 __device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t reg)
 {
+#if defined(NRPHY_CRC_PROBE) && NRPHY_CRC_PROBE == 1 // timing probe (wrong results): the four look-ups without bank conflicts
+  const uint32_t t = threadIdx.x & 0xFFu;
+  return tab[(t + (reg & 1u)) & 0xFFu] ^ tab[256u + ((t + ((reg >> 8) & 1u)) & 0xFFu)] ^
+         tab[512u + ((t + ((reg >> 16) & 1u)) & 0xFFu)] ^ tab[768u + ((t + (reg >> 31)) & 0xFFu)];
+#elif defined(NRPHY_CRC_PROBE) && NRPHY_CRC_PROBE == 2 // timing probe (wrong results): no look-ups at all
+  return (reg << 1) ^ (reg >> 3);
+#endif
   return tab[reg & 0xFFu] ^ tab[256u + ((reg >> 8) & 0xFFu)] ^ tab[512u + ((reg >> 16) & 0xFFu)] ^ tab[768u + (reg >> 24)];
 }
 
@@ -55,12 +63,30 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   static_assert(GOLD_RING_WORDS >= 2 * 1024 + TB_CRC_THREADS, "LDS of the CRC role");
   const uint32_t tid = threadIdx.x;
 
-  // Sequence workgroups first, then the CRC workgroups: measured against CRC first (+11 % on this launch) and against one
-  // sequence workgroup after every few CRC workgroups (+95 %: the two roles' LDS traffic -- a ring walked in order, byte
-  // tables hit at random -- slow each other down when they share a CU).  profiles/r02_codeblock_experiments.txt.
-  const uint32_t scr_index = blockIdx.x, crc_index = blockIdx.x - p.n_scr_work;
-  const bool     scr_role  = blockIdx.x < p.n_scr_work;
-  if (scr_role) { // workgroup-uniform; first in the grid: the longest dependent chains
+  // Order of the two roles in the grid (p.prologue_order, NRPHY_PROLOGUE_ORDER):
+  //  0  sequence workgroups first, then the CRC workgroups;
+  //  1  the sequence workgroups spread evenly among the CRC workgroups, every XCD taking a contiguous run of that list
+  //     (block b runs on XCD b % 8).  A sequence workgroup is one long wave that waits for its own stores (plus three short
+  //     DM-RS waves) and holds its slot on the CU for the whole time; taken first, a thousand of them leave the CRC
+  //     workgroups half the slots for most of the launch.
+  // (With the workgroup-wide generator of rounds 1-3 -- a ring in LDS walked by all four waves -- interleaving cost +95 %:
+  // ring and byte tables slowed each other down; and CRC first +11 %.  profiles/r02_codeblock_experiments.txt.)
+  uint32_t scr_index = blockIdx.x, crc_index = blockIdx.x - p.n_scr_work;
+  bool     scr_role  = blockIdx.x < p.n_scr_work;
+  if (p.prologue_order == 1 && p.n_scr_work != 0 && p.n_crc_work != 0) {
+    const uint32_t total = p.n_scr_work + p.n_crc_work;
+    const uint32_t xcd = blockIdx.x & 7u, turn = blockIdx.x >> 3, q = total >> 3, r = total & 7u;
+    const uint32_t pos = xcd * q + (xcd < r ? xcd : r) + turn; // position in the interleaved list
+    // sequence workgroups before position x: ceil(x n_scr / total)
+    const uint32_t s0 = (uint32_t)(((uint64_t)pos * p.n_scr_work + total - 1u) / total);
+    const uint32_t s1 = (uint32_t)(((uint64_t)(pos + 1u) * p.n_scr_work + total - 1u) / total);
+    scr_role  = s1 > s0;
+    scr_index = s0;
+    crc_index = pos - s0;
+  }
+  NRPHY_WG_TRACE_MARK(0);
+  NRPHY_WG_TRACE_WHERE(scr_role ? 1 : 2);
+  if (scr_role) { // workgroup-uniform
     if (p.profile_stage == 8) {
       return;
     }
@@ -68,23 +94,28 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
     const uint32_t first = swc->first, count = swc->count;
     const bool     with_dmrs = swc->with_dmrs != 0;
     PduRef         pd    = *to_constant(&p.pdus[swc->pdu]);
-    // The scrambling sequence goes out as its x2 part (NRPHY_SCR_X2_ONLY): map_chunk adds the x1 words, which every sequence
-    // shares, when it reads the scrambling bits.
-    gold_sequence_workgroup<TB_CRC_THREADS, !NRPHY_SCR_X2_ONLY>(p.gold, p.x1_words, pd.c_init, first, count,
-                                                                 p.scr + pd.scr_offset + first, lds, tid);
-    // The DM-RS sequences, from bit 0 to the last allocated PRB: short, so one wave generates one (the four waves of
-    // the PDU's first workgroup take the DM-RS symbols in turn, each with its own quarter of the LDS as scratch).
-    if (with_dmrs) {
-      const uint32_t wave = tid / WAVE, lane = tid % WAVE;
-      static_assert(GOLD_RING_WORDS / (TB_CRC_THREADS / WAVE) >= 1024, "DM-RS scratch per wave");
-      if (pd.dmrs_seq_words <= 1024u) {
-        uint32_t ordinal = 0;
-        for (uint32_t mask = pd.dmrs_symbol_mask; mask != 0; mask &= mask - 1u, ++ordinal) { // uniform
-          if (ordinal % (TB_CRC_THREADS / WAVE) == wave) {
-            const uint32_t l = (uint32_t)__ffs(mask) - 1u;
-            gold_sequence_wave(p.gold, p.x1_words, pd.dmrs_c_init[l], pd.dmrs_seq_words,
-                               p.scr + pd.dmrs_seq_offset + ordinal * pd.dmrs_seq_words, lds + wave * 1024u, lane);
-          }
+    const uint32_t wave = tid / WAVE, lane = tid % WAVE;
+    // The four waves of the workgroup work on their own, each on LDS of its own, without a barrier.  Wave 0: the part's
+    // scrambling sequence with the recurrence in registers (gold_sequence_rows_wave: 3 vector instructions per 64 words).
+    // It goes out as its x2 part (NRPHY_SCR_X2_ONLY): map_chunk adds the x1 words, which every sequence shares, when it
+    // reads the scrambling bits.
+    constexpr uint32_t DMRS_WAVES = TB_CRC_THREADS / WAVE - 1, DMRS_SCRATCH = (GOLD_RING_WORDS - 2048u) / DMRS_WAVES;
+    static_assert(GOLD_SEED_WORDS <= 2048u && GOLD_RING_WORDS > 2048u, "LDS of the sequence role");
+    static_assert((12u * NRPHY_MAX_RB + 31u) / 32u + 1u <= DMRS_SCRATCH, "DM-RS scratch per wave");
+    if (wave == 0) {
+      gold_sequence_rows_wave<!NRPHY_SCR_X2_ONLY>(p.gold, p.x1_words, pd.c_init, first, count,
+                                                  p.scr + pd.scr_offset + first, lds, lane);
+      NRPHY_WG_TRACE_MARK(6);
+    } else if (with_dmrs && pd.dmrs_seq_words <= DMRS_SCRATCH) {
+      // Waves 1-3 of the PDU's first workgroup: the DM-RS sequences, from bit 0 to the last allocated PRB -- short, so one
+      // wave generates one; the waves take the DM-RS symbols in turn.
+      uint32_t ordinal = 0;
+      for (uint32_t mask = pd.dmrs_symbol_mask; mask != 0; mask &= mask - 1u, ++ordinal) { // uniform
+        if (ordinal % DMRS_WAVES == wave - 1u) {
+          const uint32_t l = (uint32_t)__ffs(mask) - 1u;
+          gold_sequence_wave(p.gold, p.x1_words, pd.dmrs_c_init[l], pd.dmrs_seq_words,
+                             p.scr + pd.dmrs_seq_offset + ordinal * pd.dmrs_seq_words,
+                             lds + 2048u + (wave - 1u) * DMRS_SCRATCH, lane);
         }
       }
     }
@@ -101,6 +132,10 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   const CrcPoly   c   = sel ? crc16() : crc24a();
   const uint32_t  n   = pd.tb_bytes;
   const uint32_t* tbw = reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset);
+#ifdef NRPHY_WG_TRACE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (trace builds: the descriptors have arrived)
+  NRPHY_WG_TRACE_MARK(3);
+#endif
   uint32_t*       y1  = lds;
   uint32_t*       y2  = lds + 1024;
   uint32_t*       msg = lds + 2048;
@@ -123,6 +158,10 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
     y2[k * 256 + tid] = p.tbcrc->y2[sel][k][tid];
   }
   __syncthreads();
+#ifdef NRPHY_WG_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (trace builds: tables in LDS, the region's words in registers)
+  NRPHY_WG_TRACE_MARK(2);
+#endif
   uint32_t reg = w[0];
 #pragma unroll
   for (int i = 1; i != TB_CRC_WPT; ++i) {
@@ -130,6 +169,7 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   }
   msg[tid] = reg;
   __syncthreads();
+  NRPHY_WG_TRACE_MARK(1);
   if (tid < WAVE) {
     uint32_t r = msg[tid];
 #pragma unroll
@@ -144,7 +184,16 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
       p.tb_crc_part[crc_index] = crc_mulmod(r, wk_factor, c);
     }
   }
+  NRPHY_WG_TRACE_MARK(6);
 }
+
+#ifdef NRPHY_WG_TRACE
+extern "C" int nrphy_debug_wg_trace(uint64_t* out, uint32_t nof_blocks)
+{
+  const size_t n = 8 * (size_t)(nof_blocks < WG_TRACE_MAX ? nof_blocks : WG_TRACE_MAX) * sizeof(uint64_t);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_trace), n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 hipError_t launch_prologue(const PdschLaunch& p, const uint8_t* d_tb, hipStream_t stream)
 {
