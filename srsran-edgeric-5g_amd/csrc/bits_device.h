@@ -500,9 +500,50 @@ __device__ inline void gold_sequence_rows_wave(const GoldTables* gold, const uin
   }
   NRPHY_WG_TRACE_MARK(3);
   // 4. Rows in registers.
+  uint32_t       w[GOLD_SEED_ROWS];
+  const uint32_t rows = (nwords + WAVE - 1u) / WAVE;
+  if (!WITH_X1 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) { // wave-uniform
+    // Blocks of 31 rows (1984 words, a multiple of 16 bytes) go through the seed area and out with 16-byte stores: 8 store
+    // instructions of up to 1 KB per block instead of 31 of 256 bytes.  A wave has at most 63 stores in flight, and with a
+    // few microseconds until a store is acknowledged 4 bytes per lane and store held one PDU's sequence (118 KB) to 23 us
+    // (profiles/r03_prologue_trace.txt).  The LDS executes a wave's instructions in order: no wait between the row writes,
+    // the 16-byte reads and the next block's writes.
+    auto flush = [&](uint32_t base_word) {
+      const uint32_t avail = nwords - base_word < GOLD_SEED_WORDS ? nwords - base_word : GOLD_SEED_WORDS;
+      const uint32_t n4    = avail >> 2;
+      typedef uint32_t words4 __attribute__((ext_vector_type(4), may_alias)); // (the same bytes are written as single words)
+      const words4*  src   = reinterpret_cast<const words4*>(seed);
+      words4*        dst   = reinterpret_cast<words4*>(out + base_word);
+#pragma unroll
+      for (uint32_t q = 0; q != (GOLD_SEED_WORDS / 4u + WAVE - 1u) / WAVE; ++q) {
+        const uint32_t idx = q * WAVE + lane;
+        if (idx < n4) {
+          dst[idx] = src[idx];
+        }
+      }
+      if ((n4 << 2) + lane < avail) { // the last one to three words of the sequence
+        out[base_word + (n4 << 2) + lane] = seed[(n4 << 2) + lane];
+      }
+    };
+    flush(0);
+    NRPHY_WG_TRACE_MARK(4);
+#pragma unroll
+    for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
+      w[i] = seed[i * WAVE + lane];
+    }
+    for (uint32_t base = GOLD_SEED_ROWS; base < rows; base += GOLD_SEED_ROWS) { // wave-uniform
+#pragma unroll
+      for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
+        w[i] ^= __builtin_amdgcn_bitop3_b32(w[(i + 1u) % GOLD_SEED_ROWS], w[(i + 2u) % GOLD_SEED_ROWS],
+                                            w[(i + 3u) % GOLD_SEED_ROWS], 0x96);
+        seed[i * WAVE + lane] = w[i];
+      }
+      flush(base * WAVE);
+    }
+    return;
+  }
   const uint32_t* x1 = x1_words + first_word + lane;
   uint32_t*       o  = out + lane;
-  uint32_t        w[GOLD_SEED_ROWS];
 #pragma unroll
   for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
     const uint32_t k = i * WAVE + lane;
@@ -512,8 +553,7 @@ __device__ inline void gold_sequence_rows_wave(const GoldTables* gold, const uin
     }
   }
   NRPHY_WG_TRACE_MARK(4);
-  const uint32_t rows = (nwords + WAVE - 1u) / WAVE;
-  uint32_t       base = GOLD_SEED_ROWS;
+  uint32_t base = GOLD_SEED_ROWS;
   // whole blocks of 31 rows: no bounds
   for (; (base + GOLD_SEED_ROWS) * WAVE <= nwords; base += GOLD_SEED_ROWS) { // wave-uniform
     uint32_t*       ob = o + base * WAVE;

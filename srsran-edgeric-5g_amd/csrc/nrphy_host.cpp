@@ -166,15 +166,17 @@ void build_tbcrc_tables(TbCrcTables& t)
   const CrcField* field[2] = {&CRC24A_FIELD, &CRC16_FIELD};
   for (unsigned s = 0; s != 2; ++s) {
     const CrcField& f  = *field[s];
-    const uint32_t  y1 = f.xpow(32 * 256), y2 = f.xpow(32 * 64);
+    const uint32_t  y32 = f.xpow(32), y1k = f.xpow(32 * 1024), y8k = f.xpow(128 * 64), yz = f.xpow(8 * (int64_t)TB_CRC_REGION_BYTES);
     for (unsigned k = 0; k != 4; ++k) {
       for (uint32_t b = 0; b != 256; ++b) {
-        t.y1[s][k][b] = f.mul(y1, b << (8 * k));
-        t.y2[s][k][b] = f.mul(y2, b << (8 * k));
+        t.y32[s][k][b] = f.mul(y32, b << (8 * k));
+        t.y1k[s][k][b] = f.mul(y1k, b << (8 * k));
+        t.y8k[s][k][b] = f.mul(y8k, b << (8 * k));
+        t.yz[s][k][b]  = f.mul(yz, b << (8 * k));
       }
     }
     for (unsigned l = 0; l != 64; ++l) {
-      t.lane[s][l] = f.xpow(32 * (63 - (int)l));
+      t.lane[s][l] = f.xpow(128 * (63 - (int)l));
     }
   }
 }
@@ -1144,19 +1146,30 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
       plan->dmrs_separate = true; // data is mapped on RE that also carry DM-RS: the reference lets DM-RS win
     }
     pdus_of_grid[g].push_back(i);
-    // TB-CRC work: one workgroup per 16 KiB region of the transport block.
+    // TB-CRC work: the transport block in 16 KiB regions, a workgroup per run of regions.  A small batch gets a workgroup
+    // per region (latency); a big one has workgroups enough and lets each walk several regions, the next one's words in
+    // flight while it reduces the current one (a workgroup per region spent two thirds of its time waiting for its loads:
+    // profiles/r03_prologue_trace.txt).
     {
       const CrcField& f = (d.nof_tb_crc_bits == 16) ? CRC16_FIELD : CRC24A_FIELD;
       const uint32_t  n = pdu.tb_size_bytes;
+      const uint32_t  regions = divide_ceil(n, TB_CRC_REGION_BYTES);
+      static const char* per_env = std::getenv("NRPHY_CRC_REGIONS"); // (A/B knob: regions per workgroup)
+      const uint32_t  want  = std::max<uint32_t>(1, std::min<uint32_t>(regions, TB_CRC_TARGET_WORK / std::max<uint32_t>(1, n_pdu)));
+      uint32_t        per   = std::min<uint32_t>(TB_CRC_MAX_REGIONS_PER_WORK, divide_ceil(regions, want));
+      if (per_env) {
+        per = std::max(1, std::min((int)TB_CRC_MAX_REGIONS_PER_WORK, std::atoi(per_env)));
+      }
       pd.crc_first      = (uint32_t)crc_work.size();
-      pd.crc_count      = divide_ceil(n, TB_CRC_REGION_BYTES);
+      pd.crc_count      = divide_ceil(regions, per);
       if (pd.crc_count > 64) { // one lane of the attaching wave per share
         status = NRPHY_ERR_INVALID_PDU;
         break;
       }
-      for (uint32_t region = 0; region * TB_CRC_REGION_BYTES < n; ++region) {
-        const int64_t region_end = (int64_t)(region + 1) * TB_CRC_REGION_BYTES;
-        crc_work.push_back({i, region, f.xpow((int64_t)f.order + 8 * ((int64_t)n - region_end)), 0});
+      for (uint32_t region = 0; region < regions; region += per) {
+        const uint32_t count      = std::min(per, regions - region);
+        const int64_t  region_end = (int64_t)(region + count) * TB_CRC_REGION_BYTES;
+        crc_work.push_back({i, region, f.xpow((int64_t)f.order + 8 * ((int64_t)n - region_end)), count});
       }
     }
     // Work items: every codeblock owns a whole number of RE (rm_length is a multiple of nof_layers * Qm).

@@ -137,13 +137,18 @@ constexpr int DMRS_PRB_CHUNK = 32; // PRBs per DM-RS wavefront
 constexpr uint32_t TB_CRC_REGION_WORDS = 256 * NRPHY_CRC_WORDS_PER_THREAD;
 constexpr uint32_t TB_CRC_REGION_BYTES = 4 * TB_CRC_REGION_WORDS;
 
-// Tables of the transport-block CRC, per polynomial ([0] CRC24A, [1] CRC16).  Thread t of a workgroup owns the words
-// t, t + 256, ... of the region and runs Horner's rule in y1 = x^(32 * 256); 64 lanes then fold the 256 partials with
-// y2 = x^(32 * 64).  y[k][b] = (b x^(8k)) y mod g, so that a 32-bit partial advances with four independent look-ups.
+// Tables of the transport-block CRC, per polynomial ([0] CRC24A, [1] CRC16).  A workgroup takes a 16 KiB region in four
+// rounds of 16-byte loads: thread t owns the words 1024 i + 4 t + j (round i, j = 0..3).  It folds the four words of a round
+// with Horner's rule in x^32 (table y32), the four rounds with y1k = x^(32 * 1024); the 256 partials, 128 bits apart, are
+// folded by 64 lanes with y8k = x^(128 * 64), and a workgroup that walks several regions steps from one to the next with
+// yz = x^(8 * TB_CRC_REGION_BYTES).  y[k][b] = (b x^(8k)) y mod g, so that a 32-bit partial advances with four independent
+// look-ups.
 struct TbCrcTables {
-  uint32_t y1[2][4][256];
-  uint32_t y2[2][4][256];
-  uint32_t lane[2][64]; // x^(32 (63 - l)) mod g
+  uint32_t y32[2][4][256];
+  uint32_t y1k[2][4][256];
+  uint32_t y8k[2][4][256];
+  uint32_t yz[2][4][256];
+  uint32_t lane[2][64]; // x^(128 (63 - l)) mod g
 };
 
 struct DmrsWork {
@@ -163,16 +168,19 @@ struct ScrWork {
   uint32_t with_dmrs;
 };
 
-// One 256-thread workgroup of the TB-CRC role: region `region` (16 KiB) of the PDU's transport block.  The region
-// is reduced as if the transport block were zero-extended to the region's end; `factor` = x^(order + 8 (bytes - region
-// end)) mod g (a negative exponent for the last region: x is invertible mod g) turns that into the region's share of
-// the CRC.
+// One 256-thread workgroup of the TB-CRC role: regions [region, region + count) (16 KiB each) of the PDU's transport
+// block, one after the other with the next region's words requested while the current one is reduced.  A region is
+// reduced as if the transport block were zero-extended to the region's end; `factor` = x^(order + 8 (bytes - end of the
+// LAST region)) mod g (a negative exponent for the last region of the block: x is invertible mod g) turns the workgroup's
+// running remainder into its share of the CRC.
 struct CrcWork {
   uint32_t pdu;
   uint32_t region;
   uint32_t factor;
-  uint32_t pad_;
+  uint32_t count;
 };
+constexpr uint32_t TB_CRC_MAX_REGIONS_PER_WORK = 8;
+constexpr uint32_t TB_CRC_TARGET_WORK          = 1024; // workgroups of the TB-CRC role a big batch aims at (4 per compute unit)
 
 // Grid words no PDU of the plan maps must read as zero (resource_grid::set_all_zero in the reference).  Instead of
 // clearing whole grids and overwriting most of them, the plan lists the uncovered runs and a few waves of the

@@ -27,14 +27,16 @@ namespace nrphy {
 // Prologue: per-PDU work the codeblock waves consume.
 //
 // Transport block CRC (TS 38.212 Section 5.1; reference: ldpc_segmenter_impl.cpp:126, crc_calculator_lut_impl.cpp).
-// A CRC is the remainder of a polynomial, so it splits: the transport block is cut into 16 KiB regions (one
-// workgroup each, any number per PDU, combined with an atomic XOR); inside a region thread t owns the words
-// t, t + 256, ... (coalesced loads straight from HBM, no staging) and evaluates them with Horner's rule in
-// y1 = x^(32 * 256) -- the same recurrence in every thread, four independent table look-ups per word; the 256
-// partials are the words of a 256-word message that one wavefront folds the same way with y2 = x^(32 * 64), and
-// only those 64 lanes pay for a multiplication by a per-lane constant.
+// A CRC is the remainder of a polynomial, so it splits: the transport block is cut into 16 KiB regions, a workgroup
+// takes a run of them (CrcWork: one region each in a small batch, up to eight in a big one, the next region's words in
+// flight while the current one is reduced) and the codeblock wave that attaches the CRC adds the workgroups' shares up.
+// Inside a region thread t owns four groups of four consecutive words (16-byte loads, coalesced, straight from HBM):
+// Horner's rule in x^32 inside a group, in y1k = x^(32 * 1024) across the groups -- four independent table look-ups per
+// word; the 256 partials are folded by one wavefront the same way with y8k = x^(128 * 64); from region to region those
+// 64 lanes step with yz = x^(8 * 16384), and only once per workgroup do they pay for a multiplication by a per-lane
+// constant.
 //
-// Scrambling and DM-RS sequences: see gold_sequence_workgroup().
+// Scrambling and DM-RS sequences: see gold_sequence_rows_wave() and gold_sequence_wave().
 // ================================================================================================================
 constexpr int TB_CRC_THREADS = 256;
 
@@ -59,8 +61,9 @@ __device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t re
 // transport-block CRC.
 __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
 {
-  __shared__ uint32_t lds[GOLD_RING_WORDS]; // Gold ring, or the CRC role's two tables and partials
-  static_assert(GOLD_RING_WORDS >= 2 * 1024 + TB_CRC_THREADS, "LDS of the CRC role");
+  constexpr uint32_t LDS_WORDS = 4 * 1024 + 2 * TB_CRC_THREADS; // CRC role: four tables and two buffers of partials (18 KB: 8 workgroups per CU)
+  __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_WORDS]; // sequence role: seed rows + DM-RS scratch
+  static_assert(LDS_WORDS >= GOLD_RING_WORDS, "LDS of the sequence role");
   const uint32_t tid = threadIdx.x;
 
   // Order of the two roles in the grid (p.prologue_order, NRPHY_PROLOGUE_ORDER):
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
     return;
   }
   const auto*     wkc = to_constant(&p.crc_work[crc_index]);
-  const uint32_t  wk_pdu = wkc->pdu, wk_region = wkc->region, wk_factor = wkc->factor;
+  const uint32_t  wk_pdu = wkc->pdu, wk_region = wkc->region, wk_factor = wkc->factor, wk_count = wkc->count;
   PduRef          pd  = *to_constant(&p.pdus[wk_pdu]);
   const uint32_t  sel = (pd.tb_crc_bits == 16) ? 1u : 0u;
   const CrcPoly   c   = sel ? crc16() : crc24a();
@@ -136,50 +139,104 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (trace builds: the descriptors have arrived)
   NRPHY_WG_TRACE_MARK(3);
 #endif
-  uint32_t*       y1  = lds;
-  uint32_t*       y2  = lds + 1024;
-  uint32_t*       msg = lds + 2048;
+  uint32_t*       y32 = lds;
+  uint32_t*       y1k = lds + 1024;
+  uint32_t*       y8k = lds + 2048;
+  uint32_t*       yz  = lds + 3072;
+  uint32_t*       msg = lds + 4096; // two buffers of 256 partials, used in turn: one barrier per region
 
-  // The region's words (zero beyond the transport block, bytes beyond its end masked off).
-  const uint32_t nwords = (n + 3u) >> 2;
-  const uint32_t word0  = wk_region * TB_CRC_REGION_WORDS + tid;
-  uint32_t       w[TB_CRC_WPT];
+  // A region's words, big-endian (zero beyond the transport block, bytes beyond its end masked off): round i of thread t is
+  // the 16 bytes at word 1024 i + 4 t of the region.  16-byte loads: with one word per lane and load the same bytes took
+  // three times as long to arrive (8.6 against 2.6 us per region, the launch 85 against 54 us: profiles/r03_prologue_trace.txt).
+  // A transport block that does not start on a 16-byte boundary, and the 16 bytes that hold its end, take single words.
+  constexpr int   ROUNDS = TB_CRC_WPT / 4;
+  static_assert(TB_CRC_WPT == 16, "the tables assume four rounds of four words (y1k, y8k)");
+  const uint32_t  nwords  = (n + 3u) >> 2;
+  const bool      aligned = (reinterpret_cast<uintptr_t>(tbw) & 15u) == 0; // workgroup-uniform
+  auto load_region = [&](uint32_t region, uint32_t (&w)[TB_CRC_WPT]) {
 #pragma unroll
-  for (int i = 0; i != TB_CRC_WPT; ++i) {
-    const uint32_t idx = word0 + (uint32_t)i * TB_CRC_THREADS;
-    w[i]               = (idx < nwords) ? be_word(tbw, idx) : 0u;
-    if ((n & 3u) != 0 && idx + 1u == nwords) {
-      w[i] &= 0xFFFFFFFFu << (8u * (4u - (n & 3u)));
+    for (int i = 0; i != ROUNDS; ++i) {
+      const uint32_t idx = region * TB_CRC_REGION_WORDS + ((uint32_t)i * TB_CRC_THREADS + tid) * 4u;
+      if (aligned && idx + 4u <= nwords && !((n & 3u) != 0 && idx + 4u == nwords)) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tbw + idx);
+        w[4 * i] = __builtin_bswap32(v.x), w[4 * i + 1] = __builtin_bswap32(v.y);
+        w[4 * i + 2] = __builtin_bswap32(v.z), w[4 * i + 3] = __builtin_bswap32(v.w);
+      } else {
+#pragma unroll
+        for (int k = 0; k != 4; ++k) {
+          uint32_t x = (idx + k < nwords) ? be_word(tbw, idx + k) : 0u;
+          if ((n & 3u) != 0 && idx + k + 1u == nwords) {
+            x &= 0xFFFFFFFFu << (8u * (4u - (n & 3u)));
+          }
+          w[4 * i + k] = x;
+        }
+      }
     }
-  }
+  };
+  uint32_t w[TB_CRC_WPT], wn[TB_CRC_WPT];
+  load_region(wk_region, w);
 #pragma unroll
   for (int k = 0; k != 4; ++k) {
-    y1[k * 256 + tid] = p.tbcrc->y1[sel][k][tid];
-    y2[k * 256 + tid] = p.tbcrc->y2[sel][k][tid];
+    y32[k * 256 + tid] = p.tbcrc->y32[sel][k][tid];
+    y1k[k * 256 + tid] = p.tbcrc->y1k[sel][k][tid];
+    y8k[k * 256 + tid] = p.tbcrc->y8k[sel][k][tid];
+    yz[k * 256 + tid]  = p.tbcrc->yz[sel][k][tid];
   }
   __syncthreads();
 #ifdef NRPHY_WG_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (trace builds: tables in LDS, the region's words in registers)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (trace builds: tables in LDS, the first region's words in registers)
   NRPHY_WG_TRACE_MARK(2);
 #endif
-  uint32_t reg = w[0];
+  // The workgroup's regions one after the other.  Lane l of wave 0 carries acc = sum over the regions so far of (its four
+  // partials of the region, folded with y8k) * yz^(regions that follow): one more table product per region and lane, and the
+  // two multiplications without a table -- by the lane's constant and by the share factor -- once per workgroup.
+  uint32_t acc = 0;
+  for (uint32_t j = 0; j != wk_count; ++j) { // workgroup-uniform
+    if (j + 1u != wk_count) {
+      load_region(wk_region + j + 1u, wn); // in flight while this region is reduced
+    }
+    // four independent chains of three products (the words of a round), then three products across the rounds
+    uint32_t v[ROUNDS];
 #pragma unroll
-  for (int i = 1; i != TB_CRC_WPT; ++i) {
-    reg = crc_advance(y1, reg) ^ w[i];
+    for (int i = 0; i != ROUNDS; ++i) {
+      v[i] = w[4 * i];
+    }
+#pragma unroll
+    for (int k = 1; k != 4; ++k) {
+#pragma unroll
+      for (int i = 0; i != ROUNDS; ++i) {
+        v[i] = crc_advance(y32, v[i]) ^ w[4 * i + k];
+      }
+    }
+    uint32_t reg = v[0];
+#pragma unroll
+    for (int i = 1; i != ROUNDS; ++i) {
+      reg = crc_advance(y1k, reg) ^ v[i];
+    }
+    uint32_t* m = msg + (j & 1u) * TB_CRC_THREADS;
+    m[tid]      = reg;
+    lds_barrier();
+    if (tid < WAVE) {
+      uint32_t r = m[tid];
+#pragma unroll
+      for (int k = 1; k != 4; ++k) {
+        r = crc_advance(y8k, r) ^ m[tid + WAVE * k];
+      }
+      acc = (j != 0 ? crc_advance(yz, acc) : 0u) ^ r;
+    }
+    if (j + 1u != wk_count) {
+#pragma unroll
+      for (int i = 0; i != TB_CRC_WPT; ++i) {
+        w[i] = wn[i];
+      }
+    }
   }
-  msg[tid] = reg;
-  __syncthreads();
   NRPHY_WG_TRACE_MARK(1);
   if (tid < WAVE) {
-    uint32_t r = msg[tid];
-#pragma unroll
-    for (int j = 1; j != 4; ++j) {
-      r = crc_advance(y2, r) ^ msg[tid + WAVE * j];
-    }
-    r = crc_mulmod32(p.tbcrc->lane[sel][tid], r, c);
-    r = wave_xor(r);
+    uint32_t r = crc_mulmod32(p.tbcrc->lane[sel][tid], acc, c);
+    r          = wave_xor(r);
     if (tid == 0) {
-      // The region's share of the PDU's CRC in a slot of its own: the codeblock wave that attaches the CRC adds the
+      // The workgroup's share of the PDU's CRC in a slot of its own: the codeblock wave that attaches the CRC adds the
       // shares up, so a run neither relies on nor leaves behind any accumulator state.
       p.tb_crc_part[crc_index] = crc_mulmod(r, wk_factor, c);
     }
