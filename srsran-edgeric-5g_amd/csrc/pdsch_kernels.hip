@@ -46,13 +46,6 @@ static_assert(TB_CRC_REGION_WORDS == TB_CRC_WPT * TB_CRC_THREADS, "words per thr
 // reg * y mod g for a 32-bit partial, y's table in LDS: tab[k * 256 + b] = (b x^(8k)) y mod g.
 __device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t reg)
 {
-#if defined(NRPHY_CRC_PROBE) && NRPHY_CRC_PROBE == 1 // timing probe (wrong results): the four look-ups without bank conflicts
-  const uint32_t t = threadIdx.x & 0xFFu;
-  return tab[(t + (reg & 1u)) & 0xFFu] ^ tab[256u + ((t + ((reg >> 8) & 1u)) & 0xFFu)] ^
-         tab[512u + ((t + ((reg >> 16) & 1u)) & 0xFFu)] ^ tab[768u + ((t + (reg >> 31)) & 0xFFu)];
-#elif defined(NRPHY_CRC_PROBE) && NRPHY_CRC_PROBE == 2 // timing probe (wrong results): no look-ups at all
-  return (reg << 1) ^ (reg >> 3);
-#endif
   return tab[reg & 0xFFu] ^ tab[256u + ((reg >> 8) & 0xFFu)] ^ tab[512u + ((reg >> 16) & 0xFFu)] ^ tab[768u + (reg >> 24)];
 }
 
