@@ -62,6 +62,20 @@ def main():
     end = (t[:, 6] - t0).astype(np.int64) / 100.0
     print("# %d workgroups traced (%s), launch spans %.1f us from the first start to the last end; %d distinct (xcc, se, cu)"
           % (len(t), "behind an OFDM launch" if with_ofdm else "PDSCH runs back to back", end.max(), len(set(cuid.tolist()))))
+    m = role == 3
+    if m.any():  # the codeblock launch ran last and its workgroups overwrote the prologue's records
+        marks = [(t[m, k].astype(np.int64) - t[m, 0].astype(np.int64)) / 100.0 for k in (1, 2, 3, 6)]
+        names = ("codeblock built", "encoded", "rate matched", "mapped and stored")
+        print("codeblock waves (wave 0 of the first %d workgroups), us after the wave's start:" % m.sum())
+        prev = None
+        for nm, x in zip(names, marks):
+            d = x if prev is None else x - prev
+            print("  %-18s at p50 %6.2f p90 %6.2f | stage p50 %6.2f p90 %6.2f us" % (nm, np.percentile(x, 50), np.percentile(x, 90),
+                                                                                  np.percentile(d, 50), np.percentile(d, 90)))
+            prev = x
+        life = (end[m] - start[m])
+        print("  wave life p50 %.2f p90 %.2f us; launch spans %.1f us for these workgroups" % (np.percentile(life, 50), np.percentile(life, 90), end[m].max()))
+        return
     for r, name in ((1, "sequence"), (2, "tb crc")):
         m = role == r
         if not m.any():

@@ -936,6 +936,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   if (p.profile_stage == 4) {
     return;
   }
+  NRPHY_WG_TRACE_MARK(3); // rate matched and interleaved
   phase_b<QM, L>(p, pd, pd_global, wk, sh, g, cm, first_gbits, lane, d_grid, d_cw_rm, d_cw_scr);
 }
 
@@ -1244,8 +1245,10 @@ __device__ __forceinline__ bool codeblock_front(const PdschLaunch& p, PduRef pd,
   if (p.profile_stage == 1 || p.profile_stage == 7) {
     return false;
   }
+  NRPHY_WG_TRACE_MARK(1); // codeblock built (segmentation, CRCs)
   rows.store(pd.nof_rows, sh.graph, lane); // (build_codeblock ends with a wave barrier; ldpc_encode_wave synchronises before it reads)
   ldpc_encode_wave(&p.graphs[pd.graph], sh.graph, kb, zc, pd.nof_rows, sh.lin, sh.u, sh.ldpc, lane);
+  NRPHY_WG_TRACE_MARK(2); // encoded
   return p.profile_stage != 2;
 }
 
@@ -1270,6 +1273,8 @@ __global__ __launch_bounds__(WAVE * CB_WAVES) void codeblock_kernel_t(PdschLaunc
   if (item == p.n_work) { // wave-uniform: the last workgroup's spare waves
     return;
   }
+  NRPHY_WG_TRACE_MARK(0);
+  NRPHY_WG_TRACE_WHERE(3);
   const auto*  wkc = to_constant(&p.work[item]);
   const CbWork wk  = {wkc->pdu, wkc->cb, wkc->re_begin, wkc->re_count};
   PduRef       pd  = *to_constant(&p.pdus[wk.pdu]);
@@ -1277,6 +1282,7 @@ __global__ __launch_bounds__(WAVE * CB_WAVES) void codeblock_kernel_t(PdschLaunc
     return;
   }
   map_chunk<QM, L>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+  NRPHY_WG_TRACE_MARK(6);
 }
 
 __global__ __launch_bounds__(WAVE * CB_WAVES) void codeblock_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb,
