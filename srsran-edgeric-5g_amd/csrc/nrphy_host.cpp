@@ -1515,13 +1515,15 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
     // Profiling aid: stop the codeblock waves after a stage to time the stages apart (outputs are then incomplete).
     static const char* stage_env = std::getenv("NRPHY_PROFILE_STAGE");
     p.profile_stage              = stage_env ? (uint32_t)std::atoi(stage_env) : 0;
-    // Store policy of the DM-RS / zero-fill waves at the tail of the codeblock launch: NRPHY_EXTRAS_NT=1 makes them non-temporal.
-    // Off by default -- A/B on two boxes (profiles/r03_codeblock_experiments.txt): it moves time from the OFDM launch to the
-    // codeblock launch (+0.013 / -0.024 ms on a box with a slow OFDM launch: whole step +1.2 %; on a fast one and on config 4: 0 ... -1 %).
+    // Store policy of the DM-RS / zero-fill waves at the tail of the codeblock launch: non-temporal (NRPHY_EXTRAS_NT=0: default
+    // policy).  It moves time from the OFDM launch that follows to the codeblock launch.  Before the OFDM launch took its grids
+    // last to first the balance depended on the box (+1.2 % whole step where the OFDM launch is slow, 0 ... -1 % where it is
+    // fast); with that order, A/B on one box, two rounds (profiles/r03_codeblock_experiments.txt): codeblock 0.301 -> 0.314 ms,
+    // OFDM 0.500 -> 0.466 ms, whole step +2.0 %.
     // (Placing those waves first or between the codeblock waves instead: the codeblock launch 0.44 / 0.46 ms -- their stores push
     // the transport blocks and sequences out of the cache.)
     static const char* nt_env = std::getenv("NRPHY_EXTRAS_NT");
-    p.extras_nt               = nt_env ? (uint32_t)std::atoi(nt_env) : 0;
+    p.extras_nt               = nt_env ? (uint32_t)std::atoi(nt_env) : 1;
     static const char* order_env = std::getenv("NRPHY_PROLOGUE_ORDER");
     p.prologue_order             = order_env ? (uint32_t)std::atoi(order_env) : 0;
   }

@@ -727,8 +727,13 @@ __global__ __launch_bounds__(Plan<N>::T) OFDM_OCCUPANCY void ofdm_kernel(OfdmLau
   const uint32_t    tid  = threadIdx.x;
   const uint32_t    l0   = blockIdx.x * SPW;
   const uint32_t    l1   = (l0 + SPW < p.nsymb) ? l0 + SPW : p.nsymb;
-  const uint32_t    gp   = blockIdx.z * p.nof_ports + blockIdx.y; // grid * nof_ports + port
-  const uint32_t    slot = d_slot_index ? to_constant(d_slot_index)[blockIdx.z] : 0u;
+  // The grids are taken last to first: the launch usually follows the one that wrote them first to last, and what the
+  // memory-side cache still holds of them is the end (A/B on one box, three rounds: this launch 0.504 -> 0.496 ms, the whole
+  // step +1.1 %; with non-temporal DM-RS / zero-fill stores 0.481 -> 0.467 ms; profiles/r03_codeblock_experiments.txt).
+  // NRPHY_OFDM_PROBE bit 2 restores first to last.
+  const uint32_t    gz   = (p.probe & 4u) ? blockIdx.z : gridDim.z - 1u - blockIdx.z;
+  const uint32_t    gp   = gz * p.nof_ports + blockIdx.y; // grid * nof_ports + port
+  const uint32_t    slot = d_slot_index ? to_constant(d_slot_index)[gz] : 0u;
   const uint32_t    t4   = (tid + (p.rg_size >> 1)) * 4u;
   const uint32_t*   rows = d_grid + (size_t)gp * NRPHY_NSYMB * p.rg_size;
   float2*           iq   = d_iq + (size_t)gp * p.slot_stride;
