@@ -1154,7 +1154,7 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
       const CrcField& f = (d.nof_tb_crc_bits == 16) ? CRC16_FIELD : CRC24A_FIELD;
       const uint32_t  n = pdu.tb_size_bytes;
       const uint32_t  regions = divide_ceil(n, TB_CRC_REGION_BYTES);
-      static const char* per_env = std::getenv("NRPHY_CRC_REGIONS"); // (A/B knob: regions per workgroup)
+      const char*     per_env = std::getenv("NRPHY_CRC_REGIONS"); // (A/B and test knob, read per plan: regions per workgroup)
       const uint32_t  want  = std::max<uint32_t>(1, std::min<uint32_t>(regions, TB_CRC_TARGET_WORK / std::max<uint32_t>(1, n_pdu)));
       uint32_t        per   = std::min<uint32_t>(TB_CRC_MAX_REGIONS_PER_WORK, divide_ceil(regions, want));
       if (per_env) {
@@ -1200,7 +1200,7 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
       // A big batch has enough PDUs to fill the device with one workgroup each (seeding a generator is the costly
       // part: measured 0.111 / 0.098 / 0.096 ms per 1024 config-3 PDUs with 4 / 2 / 1 parts); a small one is split
       // for latency.
-      static const char* parts_env = std::getenv("NRPHY_SCR_PARTS_BIG"); // (A/B knob: parts of a sequence in a big batch)
+      const char*        parts_env = std::getenv("NRPHY_SCR_PARTS_BIG"); // (A/B and test knob, read per plan: parts of a sequence in a big batch)
       const uint32_t     parts_big = parts_env ? std::max(1, std::min((int)SCR_PARTS, std::atoi(parts_env))) : 1U;
       const uint32_t parts_max = n_pdu >= 128 ? parts_big : SCR_PARTS;
       const uint32_t parts     = std::min<uint32_t>(parts_max, std::max<uint32_t>(1, pd.scr_words >> 11));

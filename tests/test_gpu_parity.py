@@ -261,6 +261,61 @@ def test_pdsch_batched_plan_mixed_cell(gpu_ctx, oracle):
     plan.close()
 
 
+@pytest.mark.parametrize("regions", ["1", "2", "3", "8"])
+@pytest.mark.parametrize("parts", ["1", "4"])
+def test_pdsch_prologue_work_split(gpu_ctx, oracle, regions, parts, monkeypatch):
+    """The prologue's work lists however they are cut (knobs read per plan): a TB-CRC workgroup per 1 / 2 / 3 / 8 regions of
+    16 KiB (the next region's words in flight), a scrambling sequence in one or four parts -- transport blocks of one and of
+    many regions, with CRC16 and CRC24A, lengths that are no multiple of four bytes, on 16-byte boundaries (16-byte loads) and
+    off them (single words); >= 128 PDUs so that the big-batch rules apply.  Rate-matched codeword (carries the CRCs) and grid
+    equal the oracle's."""
+    import torch
+    monkeypatch.setenv("NRPHY_CRC_REGIONS", regions)
+    monkeypatch.setenv("NRPHY_SCR_PARTS_BIG", parts)
+    rng = np.random.default_rng(int(regions) * 10 + int(parts))
+    big, nof_ports, nof_subc, _ = cases.baseline_config(3)       # 108,573 bytes: 7 regions, an odd length
+    shapes = [big]
+    # a mid-sized block (64-QAM on 60 PRB, ~2.6 regions) and a tiny one with CRC16
+    shapes.append(cases.abi.make_pdu(slot_index=3, rnti=7, n_id=5, bwp_start_rb=0, bwp_size_rb=273, qm=6, dmrs_symbols=(2, 7, 11),
+                                     nof_cdm_groups_without_data=2, prb_start=4, prb_count=60, start_symbol=0, nof_symbols=12,
+                                     base_graph=1, precoding=cases.codebook("four_layer_four_ports_0_0"),
+                                     tb_size_bytes=cases.tbs(12, 36, 6, 873, 4, 60) // 8))
+    shapes.append(cases.abi.make_pdu(slot_index=5, rnti=9, n_id=2, bwp_start_rb=0, bwp_size_rb=273, qm=2, dmrs_symbols=(2, 7, 11),
+                                     nof_cdm_groups_without_data=2, prb_start=100, prb_count=3, start_symbol=0, nof_symbols=12,
+                                     base_graph=2, precoding=cases.codebook("four_layer_four_ports_0_0"),
+                                     tb_size_bytes=cases.tbs(12, 36, 2, 120, 4, 3) // 8))
+    n = 132
+    pdus = [shapes[0] if i % 44 == 0 else shapes[1 + i % 2] for i in range(n)]
+    # grids: every PDU its own (the three shapes overlap in frequency)
+    offs, tbs, pos = [], [], 0
+    for i, p in enumerate(pdus):
+        tb = cases.random_tb(rng, p)
+        pos = (pos + 15) & ~15
+        if i % 3 == 1:
+            pos += 4 * (1 + i % 3)  # off the 16-byte boundary (a multiple of four, as the interface asks)
+        offs.append(pos)
+        tbs.append(tb)
+        pos += len(tb)
+    buf = np.zeros(pos + 32, np.uint8)
+    for o, tb in zip(offs, tbs):
+        buf[o:o + len(tb)] = tb
+    plan = lib.PdschPlan(gpu_ctx, pdus, offs, list(range(n)), n, nof_ports, nof_subc)
+    d_grid = torch.full((n, nof_ports, 14, nof_subc), 0x7FFF7FFF, dtype=torch.int32, device="cuda")
+    d_rm = torch.zeros(plan.codeword_bits // 8, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    plan.run(dev(buf), d_grid, d_cw_rm=d_rm, zero_grids=True)
+    gpu_ctx.synchronize()
+    rm = d_rm.cpu().numpy()
+    grids = d_grid.cpu().numpy().view(np.uint16).reshape(n, nof_ports, 14, nof_subc, 2)
+    for i in list(range(0, n, 11)) + [44, 88, n - 1]:
+        d = oracle.derive(pdus[i])
+        g, orm, _ = oracle.pdsch_process(pdus[i], tbs[i], nof_ports, nof_subc, taps=True, codeword_bits=d["codeword_bits"])
+        o = plan.codeword_offset(i) // 8
+        assert np.array_equal(rm[o:o + len(orm)], orm), i
+        assert np.array_equal(grids[i], g), i
+    plan.close()
+
+
 def test_pdsch_full_size_batch_properties(gpu_ctx, oracle):
     """At BASELINE size (config 3, 64 slots in one launch): identical inputs give identical grids (no cross-slot
     interference), different TBs differ, and one slot of the batch matches the oracle bit for bit."""
