@@ -428,24 +428,28 @@ __device__ inline void gold_sequence_workgroup(const GoldTables* gold, const uin
   lds_barrier(); // the ring is reused by the caller's next sequence
 }
 
-// Long sequence generated by ONE wavefront with the recurrence in registers: c(n) (x2 part alone unless WITH_X1) for
-// n in [32 first_word, 32 (first_word + nwords)) into global memory (out[0] is word first_word).
+// Long sequence generated by ONE wavefront with the recurrence in registers: the x2 part of c(n) for
+// n in [32 first_word, 32 (first_word + nwords)), handed to the caller block by block in LDS.
 //
 // At level m = 64 the lifted recurrence W[k] = W[k - 28 m] ^ W[k - 29 m] ^ W[k - 30 m] ^ W[k - 31 m] relates words that are
 // whole rows of 64 apart: with word 64 r + l in lane l, row r = row(r-28) ^ row(r-29) ^ row(r-30) ^ row(r-31) lane by
-// lane.  The wave keeps the last 31 rows in 31 registers and produces a row -- 64 words, one 256-byte store -- with one
-// v_bitop3 (three-way XOR), one v_xor and the store: no LDS, no barrier, no address arithmetic, and 28 rows between a
-// value and its first use.  The 31 seed rows (1984 words) come from the scheme of gold_sequence_wave() with the level
-// doubling in `seed` (1984 words of LDS private to the wave): jump, 31 head words, then levels 1, 1, 2, 4, 8, 8, 16, 32.
+// lane.  The wave keeps the last 31 rows in 31 registers and produces a row with one v_bitop3 (three-way XOR) and one
+// v_xor: no barrier, no address arithmetic, and 28 rows between a value and its first use.  The 31 seed rows (1984 words)
+// come from the scheme of gold_sequence_wave() with the level doubling in `area` (1984 words of LDS private to the
+// wave): jump, 31 head words, then levels 1, 1, 2, 4, 8, 8, 16, 32.  Every block of 31 rows is written to `area` (the
+// seed rows are there already) and `on_block(base, avail)` is called with area[0, avail) = words [base, base + avail) of
+// the part: the caller takes what it needs of them (the prologue: 31 words per codeblock work item; a 16-byte copy of
+// everything to global memory was the first form -- 121 MB per 1024 config-3 slots written here and read back by the
+// codeblock waves).  The LDS executes a wave's instructions in order: the caller's reads need no wait before the next
+// block's writes.
 // (The workgroup form above spent 27 vector instructions per word and thread -- four ring reads with their addresses, a
-// ring write, bounds -- and a barrier per 1792 words; this one spends 3 per 64 words after a seed of about 650.)
+// ring write, bounds -- and a barrier per 1792 words; this one spends 2 per 64 words after a seed of about 650.)
 constexpr uint32_t GOLD_SEED_ROWS  = 31;
 constexpr uint32_t GOLD_SEED_WORDS = GOLD_SEED_ROWS * WAVE;
 
-template <bool WITH_X1>
-__device__ inline void gold_sequence_rows_wave(const GoldTables* gold, const uint32_t* x1_words, uint32_t c_init,
-                                               uint32_t first_word, uint32_t nwords, uint32_t* __restrict__ out,
-                                               uint32_t* seed, uint32_t lane)
+template <class OnBlock>
+__device__ inline void gold_sequence_blocks_wave(const GoldTables* gold, uint32_t c_init, uint32_t first_word, uint32_t nwords,
+                                                 uint32_t* area, uint32_t lane, OnBlock&& on_block)
 {
   if (nwords == 0) { // wave-uniform
     return;
@@ -480,7 +484,7 @@ __device__ inline void gold_sequence_rows_wave(const GoldTables* gold, const uin
     for (uint32_t t = 0; t != 32; ++t) {
       word |= (__popc(head[t] & state) & 1u) << (31u - t);
     }
-    seed[lane] = word;
+    area[lane] = word;
   }
   wave_lds_fence();
   NRPHY_WG_TRACE_MARK(2);
@@ -492,91 +496,79 @@ __device__ inline void gold_sequence_rows_wave(const GoldTables* gold, const uin
     }
     const uint32_t end = have + 28u * m < need ? have + 28u * m : need;
     for (uint32_t k = have + lane; k < end; k += WAVE) {
-      seed[k] = __builtin_amdgcn_bitop3_b32(seed[k - 28u * m], seed[k - 29u * m], seed[k - 30u * m], 0x96) ^
-                seed[k - 31u * m];
+      area[k] = __builtin_amdgcn_bitop3_b32(area[k - 28u * m], area[k - 29u * m], area[k - 30u * m], 0x96) ^
+                area[k - 31u * m];
     }
     wave_lds_fence();
     have = end;
   }
   NRPHY_WG_TRACE_MARK(3);
-  // 4. Rows in registers.
-  uint32_t       w[GOLD_SEED_ROWS];
+  on_block(0u, need);
+  NRPHY_WG_TRACE_MARK(4);
+  // 4. Rows in registers, a block of 31 at a time through the same area.
   const uint32_t rows = (nwords + WAVE - 1u) / WAVE;
-  if (!WITH_X1 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) { // wave-uniform
-    // Blocks of 31 rows (1984 words, a multiple of 16 bytes) go through the seed area and out with 16-byte stores: 8 store
-    // instructions of up to 1 KB per block instead of 31 of 256 bytes.  A wave has at most 63 stores in flight, and with a
-    // few microseconds until a store is acknowledged 4 bytes per lane and store held one PDU's sequence (118 KB) to 23 us
-    // (profiles/r03_prologue_trace.txt).  The LDS executes a wave's instructions in order: no wait between the row writes,
-    // the 16-byte reads and the next block's writes.
-    auto flush = [&](uint32_t base_word) {
-      const uint32_t avail = nwords - base_word < GOLD_SEED_WORDS ? nwords - base_word : GOLD_SEED_WORDS;
-      const uint32_t n4    = avail >> 2;
-      typedef uint32_t words4 __attribute__((ext_vector_type(4), may_alias)); // (the same bytes are written as single words)
-      const words4*  src   = reinterpret_cast<const words4*>(seed);
-      words4*        dst   = reinterpret_cast<words4*>(out + base_word);
-#pragma unroll
-      for (uint32_t q = 0; q != (GOLD_SEED_WORDS / 4u + WAVE - 1u) / WAVE; ++q) {
-        const uint32_t idx = q * WAVE + lane;
-        if (idx < n4) {
-          dst[idx] = src[idx];
-        }
-      }
-      if ((n4 << 2) + lane < avail) { // the last one to three words of the sequence
-        out[base_word + (n4 << 2) + lane] = seed[(n4 << 2) + lane];
-      }
-    };
-    flush(0);
-    NRPHY_WG_TRACE_MARK(4);
-#pragma unroll
-    for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
-      w[i] = seed[i * WAVE + lane];
-    }
-    for (uint32_t base = GOLD_SEED_ROWS; base < rows; base += GOLD_SEED_ROWS) { // wave-uniform
-#pragma unroll
-      for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
-        w[i] ^= __builtin_amdgcn_bitop3_b32(w[(i + 1u) % GOLD_SEED_ROWS], w[(i + 2u) % GOLD_SEED_ROWS],
-                                            w[(i + 3u) % GOLD_SEED_ROWS], 0x96);
-        seed[i * WAVE + lane] = w[i];
-      }
-      flush(base * WAVE);
-    }
+  if (rows <= GOLD_SEED_ROWS) { // wave-uniform
     return;
   }
-  const uint32_t* x1 = x1_words + first_word + lane;
-  uint32_t*       o  = out + lane;
+  uint32_t w[GOLD_SEED_ROWS];
 #pragma unroll
   for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
-    const uint32_t k = i * WAVE + lane;
-    w[i]             = (k < need) ? seed[k] : 0u;
-    if (k < nwords) {
-      o[i * WAVE] = WITH_X1 ? (w[i] ^ x1[i * WAVE]) : w[i];
-    }
+    w[i] = area[i * WAVE + lane];
   }
-  NRPHY_WG_TRACE_MARK(4);
-  uint32_t base = GOLD_SEED_ROWS;
-  // whole blocks of 31 rows: no bounds
-  for (; (base + GOLD_SEED_ROWS) * WAVE <= nwords; base += GOLD_SEED_ROWS) { // wave-uniform
-    uint32_t*       ob = o + base * WAVE;
-    const uint32_t* xb = x1 + base * WAVE;
+  for (uint32_t base = GOLD_SEED_ROWS; base < rows; base += GOLD_SEED_ROWS) { // wave-uniform
 #pragma unroll
     for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
       w[i] ^= __builtin_amdgcn_bitop3_b32(w[(i + 1u) % GOLD_SEED_ROWS], w[(i + 2u) % GOLD_SEED_ROWS],
                                           w[(i + 3u) % GOLD_SEED_ROWS], 0x96);
-      ob[i * WAVE] = WITH_X1 ? (w[i] ^ xb[i * WAVE]) : w[i];
+      area[i * WAVE + lane] = w[i];
     }
+    wave_lds_fence(); // (orders the compiler; the hardware needs nothing between the writes and the caller's reads)
+    const uint32_t left = nwords - base * WAVE;
+    on_block(base * WAVE, left < GOLD_SEED_WORDS ? left : GOLD_SEED_WORDS);
   }
-  if (base < rows) { // the last, partial block
-    uint32_t*       ob = o + base * WAVE;
-    const uint32_t* xb = x1 + base * WAVE;
+}
+
+// The other end of the seeds: x2[0, need) = the x2 words that follow a 31-word seed (lane l < 31 holds word l), by level
+// doubling in LDS private to the wave.  The levels are a fixed schedule -- 1, 1, 2, 4, 8, 8 reach 703 words, more than a
+// work item of RE_CHUNK resource elements needs -- so that every step has its level as a compile-time constant: one address
+// per lane and 64 words (the four reads and the write are immediate offsets from it) instead of five computed ones.
+constexpr uint32_t GOLD_EXPAND_MAX_WORDS = 703;
+
+template <uint32_t M>
+__device__ __forceinline__ uint32_t gold_expand_step(uint32_t* x2, uint32_t have, uint32_t need, uint32_t lane)
+{
+  if (have >= need) { // wave-uniform
+    return have;
+  }
+  const uint32_t end = have + 28u * M < need ? have + 28u * M : need;
 #pragma unroll
-    for (uint32_t i = 0; i != GOLD_SEED_ROWS; ++i) {
-      w[i] ^= __builtin_amdgcn_bitop3_b32(w[(i + 1u) % GOLD_SEED_ROWS], w[(i + 2u) % GOLD_SEED_ROWS],
-                                          w[(i + 3u) % GOLD_SEED_ROWS], 0x96);
-      if ((base + i) * WAVE + lane < nwords) {
-        ob[i * WAVE] = WITH_X1 ? (w[i] ^ xb[i * WAVE]) : w[i];
-      }
+  for (uint32_t s = 0; s != (28u * M + WAVE - 1u) / WAVE; ++s) {
+    if (have + WAVE * s >= end) { // wave-uniform
+      break;
+    }
+    const uint32_t k = have + lane + WAVE * s;
+    if (k < end) {
+      uint32_t* b = x2 + (k - 31u * M); // b[0], b[M], b[2 M], b[3 M] -> b[31 M]
+      b[31u * M]  = __builtin_amdgcn_bitop3_b32(b[3u * M], b[2u * M], b[M], 0x96) ^ b[0];
     }
   }
+  wave_lds_fence();
+  return end;
+}
+
+__device__ inline void gold_expand_seed_wave(uint32_t* x2, uint32_t seed_word, uint32_t need, uint32_t lane)
+{
+  if (lane < 31u) {
+    x2[lane] = seed_word;
+  }
+  wave_lds_fence();
+  uint32_t have = 31u;
+  have = gold_expand_step<1>(x2, have, need, lane); //  59
+  have = gold_expand_step<1>(x2, have, need, lane); //  87
+  have = gold_expand_step<2>(x2, have, need, lane); // 143
+  have = gold_expand_step<4>(x2, have, need, lane); // 255
+  have = gold_expand_step<8>(x2, have, need, lane); // 479
+  have = gold_expand_step<8>(x2, have, need, lane); // 703
 }
 
 // round-to-nearest-even float -> bf16 exactly as the reference stores the grid

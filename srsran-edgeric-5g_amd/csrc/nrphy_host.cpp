@@ -380,7 +380,8 @@ struct nrphy_pdsch_plan {
   ZeroWork*             d_zero_work = nullptr;
   ZeroSeg*              d_zero_segs = nullptr;
   uint32_t*             d_scr = nullptr;    // scrambling sequences, rewritten by every run's prologue
-  uint64_t              scr_words = 0;
+  uint64_t              scr_words = 0;   // words of the run's scratch: DM-RS sequences, then the work items' seeds
+  uint64_t              seed_offset = 0; // where the seeds start
   uint32_t              n_zero_work = 0;
   bool                  encode_only = false;   // seam B plan: no RE mapping, nrphy_pdsch_run only with d_grid = NULL
   bool                  dmrs_separate = false; // DM-RS must overwrite data RE: keep it in its own, later launch
@@ -1179,6 +1180,16 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
       for (unsigned begin = 0; begin < nre; begin += RE_CHUNK) {
         const unsigned count = std::min<unsigned>(RE_CHUNK, nre - begin);
         work.push_back({i, cb, begin, count});
+        {
+          // The wave expands its scrambling words from a 31-word seed into the LDS that held the codeblock: room for them
+          // (the chunk's words from the one its first bit lies in, plus the word a misaligned read runs into).
+          const uint64_t bit0 = (uint64_t)(cb < d.nof_short_segments ? cb * d.rm_length_short
+                                                                     : d.nof_short_segments * d.rm_length_short +
+                                                                           (cb - d.nof_short_segments) * d.rm_length_long) +
+                                (uint64_t)begin * lq;
+          const uint32_t need = std::max<uint32_t>(31U, (uint32_t)(((bit0 & 31U) + (uint64_t)count * lq + 31U) / 32U) + 1U);
+          plan->lds_lin_words = std::max<uint32_t>(plan->lds_lin_words, (need + 3U) & ~3U);
+        }
         // LDS the wave needs for the symbol bytes (32 per block + 8 words).
         plan->lds_symb_words = std::max<uint32_t>(plan->lds_symb_words,
                                                   (((count * pdu.nof_layers + 31) / 32) * 8 + 8 + 3) & ~3U);
@@ -1188,11 +1199,11 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
                                              ((((kb + pd.nof_rows) * d.lifting_size + 31) / 32) + 2 + 3) & ~3U);
     plan->lds_graph_words = std::max<uint32_t>(
         plan->lds_graph_words, (48U + ctx->graphs[pd.graph].row_ptr[std::min<uint32_t>(pd.nof_rows, MAX_BG_ROWS)] + 3U) & ~3U);
-    // Scrambling sequence of the PDU: one word per 32 codeword bits plus the word a misaligned read runs into.
-    pd.scr_offset = (uint32_t)plan->scr_words;
-    pd.scr_words  = (d.codeword_bits + 31U) / 32U + 1U;
-    plan->scr_words += (pd.scr_words + 3U) & ~3ULL;
-    // ... followed by one DM-RS sequence per DM-RS symbol.
+    // Scrambling sequence of the PDU: one word per 32 codeword bits plus the word a misaligned read runs into, plus the
+    // length of a seed (the last work item's 31 words may reach beyond the codeword; the sequence simply goes on).  Only
+    // the work items' seeds are stored (behind the DM-RS sequences, below).
+    pd.scr_words  = (d.codeword_bits + 31U) / 32U + 1U + 31U;
+    // One DM-RS sequence per DM-RS symbol.
     pd.dmrs_seq_offset = (uint32_t)plan->scr_words;
     pd.dmrs_seq_words  = (12U * (pd.end_prb - pd.dmrs_ref_rb) + 31U) / 32U + 1U;
     plan->scr_words += ((uint64_t)pd.dmrs_seq_words * (unsigned)__builtin_popcount(pdu.dmrs_symbol_mask) + 3U) & ~3ULL;
@@ -1354,6 +1365,14 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
     for (uint32_t b = 0; b != CB_BUCKETS; ++b) {
       plan->bucket_begin[b + 1] += plan->bucket_begin[b];
     }
+    // A PDU's work items stay together and in order (one bucket per PDU, stable sort): where they start.
+    for (size_t k = work.size(); k-- != 0;) {
+      plan->pdus[work[k].pdu].item_first = (uint32_t)k;
+    }
+    // The seeds of the work items' scrambling sequences: 32 words each, behind the DM-RS sequences.
+    plan->scr_words  = (plan->scr_words + 3U) & ~3ULL;
+    plan->seed_offset = plan->scr_words;
+    plan->scr_words += 32ULL * work.size();
     // The codeblock waves load 2 * NRPHY_MAX_PORTS * layers weights whatever the port count (pdsch_kernels.hip, phase_b).
     weights.insert(weights.end(), 2 * NRPHY_MAX_PORTS * NRPHY_MAX_PORTS, 0.0F);
   }
@@ -1502,10 +1521,12 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.zero_work          = plan->d_zero_work;
   p.zero_segs          = plan->d_zero_segs;
   p.scr                = plan->d_scr;
+  p.scr_seed           = plan->d_scr + plan->seed_offset;
   p.n_zero_work        = (d_grid != nullptr && zero_grids) ? plan->n_zero_work : 0;
   p.n_dmrs_in_launch   = merge_dmrs ? plan->n_dmrs : 0;
   p.n_pdu          = (uint32_t)plan->pdus.size();
   p.n_work         = plan->n_work;
+  p.work_base      = 0;
   p.n_dmrs_work    = plan->n_dmrs;
   p.grid_nof_ports = plan->grid_nof_ports;
   p.grid_nof_subc  = plan->grid_nof_subc;

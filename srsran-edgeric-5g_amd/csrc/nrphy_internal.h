@@ -93,8 +93,8 @@ struct PduDev {
   uint32_t nof_layers;
   uint32_t nof_ports;
   uint32_t c_init;         // scrambling sequence initialisation
-  uint32_t scr_offset;     // word offset of the PDU's scrambling sequence in the plan's buffer
-  uint32_t scr_words;      // words of it the prologue generates: ceil(G / 32) + read-ahead
+  uint32_t item_first;     // index of the PDU's first work item in the plan's (bucket-sorted) work list; its items follow in codeblock / chunk order
+  uint32_t scr_words;      // words of the scrambling sequence the prologue walks: ceil(G / 32) + read-ahead + a seed's length
   uint32_t nof_re;
   uint32_t weights_offset; // floats: data weights (scaled) [nof_prg][P][L][2] in the plan's weight array
   uint32_t dmrs_weights_offset; // floats: unscaled weights, same shape
@@ -158,9 +158,9 @@ struct DmrsWork {
   uint32_t prb_end;
 };
 
-// One 256-thread workgroup of the sequence role: words [first, first + count) of the PDU's scrambling sequence; the
-// PDU's first workgroup also generates its DM-RS sequences.  Long sequences are split over up to SCR_PARTS workgroups
-// (seeding a generator costs about as much as 2,000 words, so short ones are not).
+// One 256-thread workgroup of the sequence role: wave 0 walks words [first, first + count) of the PDU's scrambling sequence
+// and stores the seeds of the work items that start there; the PDU's first workgroup also generates its DM-RS sequences
+// (waves 1-3).  Long sequences are split over up to SCR_PARTS workgroups in a small batch.
 struct ScrWork {
   uint32_t pdu;
   uint32_t first;
@@ -205,7 +205,9 @@ struct PdschLaunch {
   const ZeroSeg*     zero_segs;
   uint32_t           n_zero_work;     // zero-fill waves appended to the codeblock launch (0: caller cleared the grids)
   uint32_t           n_dmrs_in_launch; // DM-RS waves appended to the codeblock launch (0: separate launch)
-  uint32_t*          scr;             // scrambling sequences c(n) of every PDU, MSB-first words (prologue -> codeblocks)
+  uint32_t*          scr;             // DM-RS sequences c(n) of every PDU, MSB-first words (prologue -> DM-RS waves)
+  uint32_t*          scr_seed;        // [n_work][32]: the first 31 words of the x2 part of the scrambling sequence of every work item
+                                      // (prologue -> codeblock waves, which expand them: gold_expand_seed_wave)
   const PduDev*      pdus;
   const CbWork*      work;
   const DmrsWork*    dmrs_work;
@@ -222,6 +224,7 @@ struct PdschLaunch {
   uint32_t*          tb_crc_part; // [n_crc_work] share of every 16 KiB region in its PDU's CRC, rewritten by every run
   uint32_t           n_pdu;
   uint32_t           n_work;
+  uint32_t           work_base;      // index of work[0] in the plan's whole work list (a bucket launch starts inside it): the seeds' index
   uint32_t           n_dmrs_work;
   uint32_t           grid_nof_ports;
   uint32_t           grid_nof_subc;

@@ -17,9 +17,6 @@
 #ifndef NRPHY_PHASE_A_STAGED
 #define NRPHY_PHASE_A_STAGED 1
 #endif
-#ifndef NRPHY_SCR_X2_ONLY
-#define NRPHY_SCR_X2_ONLY 1 // the prologue writes the x2 part of the scrambling sequences, map_chunk adds x1 (see there)
-#endif
 
 namespace nrphy {
 
@@ -36,7 +33,7 @@ namespace nrphy {
 // 64 lanes step with yz = x^(8 * 16384), and only once per workgroup do they pay for a multiplication by a per-lane
 // constant.
 //
-// Scrambling and DM-RS sequences: see gold_sequence_rows_wave() and gold_sequence_wave().
+// Scrambling sequences (seeds per work item) and DM-RS sequences: see gold_sequence_blocks_wave() and gold_sequence_wave().
 // ================================================================================================================
 constexpr int TB_CRC_THREADS = 256;
 
@@ -91,16 +88,50 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
     const bool     with_dmrs = swc->with_dmrs != 0;
     PduRef         pd    = *to_constant(&p.pdus[swc->pdu]);
     const uint32_t wave = tid / WAVE, lane = tid % WAVE;
-    // The four waves of the workgroup work on their own, each on LDS of its own, without a barrier.  Wave 0: the part's
-    // scrambling sequence with the recurrence in registers (gold_sequence_rows_wave: 3 vector instructions per 64 words).
-    // It goes out as its x2 part (NRPHY_SCR_X2_ONLY): map_chunk adds the x1 words, which every sequence shares, when it
-    // reads the scrambling bits.
+    // The four waves of the workgroup work on their own, each on LDS of its own, without a barrier.  Wave 0 walks the part's
+    // scrambling sequence (its x2 part: the codeblock waves add the x1 words, which every sequence shares) with the
+    // recurrence in registers (gold_sequence_blocks_wave) and stores, for every work item of the PDU, the 31 words that
+    // start at the word the item's first codeword bit lies in: the codeblock wave expands them to the few hundred words it
+    // needs (gold_expand_seed_wave).  13 MB of seeds per 1024 config-3 slots instead of 121 MB of sequences out and back.
     constexpr uint32_t DMRS_WAVES = TB_CRC_THREADS / WAVE - 1, DMRS_SCRATCH = (GOLD_RING_WORDS - 2048u) / DMRS_WAVES;
     static_assert(GOLD_SEED_WORDS <= 2048u && GOLD_RING_WORDS > 2048u, "LDS of the sequence role");
     static_assert((12u * NRPHY_MAX_RB + 31u) / 32u + 1u <= DMRS_SCRATCH, "DM-RS scratch per wave");
     if (wave == 0) {
-      gold_sequence_rows_wave<!NRPHY_SCR_X2_ONLY>(p.gold, p.x1_words, pd.c_init, first, count,
-                                                  p.scr + pd.scr_offset + first, lds, lane);
+      // The PDU's work items in the order the plan lists them (nrphy_host.cpp: codeblock by codeblock, RE_CHUNK resource
+      // elements per item), walked with scalar arithmetic alongside the blocks: w0 = the word of the item's first bit.
+      const uint32_t lq = pd.qm * pd.nof_layers, n_short = pd.n_short, e_short = pd.e_short, e_long = pd.e_long, C = pd.C;
+      const uint32_t nre_short = e_short / lq, nre_long = e_long / lq; // (the only divisions: the walk itself has none)
+      uint32_t       cb = 0, re_begin = 0, item = pd.item_first, bit_cb = 0;
+      uint32_t       nre = n_short != 0 ? nre_short : nre_long;
+      auto           next_item = [&]() {
+        re_begin += RE_CHUNK;
+        if (re_begin >= nre) {
+          bit_cb += cb < n_short ? e_short : e_long;
+          ++cb;
+          re_begin = 0;
+          nre      = cb < n_short ? nre_short : nre_long;
+        }
+        ++item;
+      };
+      gold_sequence_blocks_wave(p.gold, pd.c_init, first, count, lds, lane, [&](uint32_t base, uint32_t avail) {
+        const uint32_t lo = first + base, hi = lo + avail; // the block holds words [lo, hi) of the PDU's sequence
+        while (cb < C) {                                   // wave-uniform
+          const uint32_t w0 = (bit_cb + re_begin * lq) >> 5;
+          if (w0 >= hi) {
+            break;
+          }
+          if (w0 + 31u > lo) {
+            const uint32_t k = w0 + lane;
+            if (lane < 31u && k >= lo && k < hi) {
+              p.scr_seed[(size_t)item * 32u + lane] = lds[k - lo];
+            }
+          }
+          if (w0 + 31u > hi) {
+            break; // the rest of this item's seed is in the next block (or in the next part's first)
+          }
+          next_item();
+        }
+      });
       NRPHY_WG_TRACE_MARK(6);
     } else if (with_dmrs && pd.dmrs_seq_words <= DMRS_SCRATCH) {
       // Waves 1-3 of the PDU's first workgroup: the DM-RS sequences, from bit 0 to the last allocated PRB -- short, so one
@@ -183,6 +214,8 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   // The workgroup's regions one after the other.  Lane l of wave 0 carries acc = sum over the regions so far of (its four
   // partials of the region, folded with y8k) * yz^(regions that follow): one more table product per region and lane, and the
   // two multiplications without a table -- by the lane's constant and by the share factor -- once per workgroup.
+  // (Two regions' loads ahead instead of one -- three register sets in rotation -- changed nothing: with the sequences no
+  // longer written out the workgroup waits for its turn at the vector unit and the LDS, not for its loads.)
   uint32_t acc = 0;
   for (uint32_t j = 0; j != wk_count; ++j) { // workgroup-uniform
     if (j + 1u != wk_count) {
@@ -668,53 +701,44 @@ struct ChunkMap {
   bool     aligned;  // L * Qm = 32 and the chunk starts on a word boundary: one scrambling word per RE
 };
 
-// The RE's L symbol bytes (first in the MSB) and its L*Qm scrambling bits (prologue; MSB first).  Four layers make the
-// first a whole word; L*Qm = 32 with a word-aligned chunk (the headline shape) makes the second one too.
+// The L * Qm scrambling bits of RE r of the chunk (MSB first) are the XOR of two parts.  x1 is the same for every sequence:
+// a table in global memory (L2), requested a trip ahead; zero beyond the chunk.  L * Qm = 32 with a word-aligned chunk (the
+// headline shape) makes the bits one word of each part.
 template <int QM, int L>
-__device__ __forceinline__ void re_bits(const PdschLaunch& p, const uint32_t* __restrict__ scr, const CbShared& sh,
-                                        const ChunkGeom& g, const ChunkMap& cm, uint32_t r, uint32_t& bytes,
-                                        uint32_t& gbits)
+__device__ __forceinline__ uint32_t x1_bits(const PdschLaunch& p, const ChunkGeom& g, const ChunkMap& cm, uint32_t re_count,
+                                            uint32_t r)
 {
-  constexpr uint32_t LQ = QM * L;
+  uint32_t bits = 0;
+  if (r < re_count) {
+    if (QM * L == 32 && cm.aligned) { // wave-uniform: scalar base, small per-lane index
+      bits = (p.x1_words + cm.word0)[r];
+    } else {
+      bits = ext32(p.x1_words, g.bit0 + r * (uint32_t)(QM * L));
+    }
+  }
+  return bits;
+}
+// x2 depends on the PDU: the wave has expanded its seed into LDS, x2[0] = the word the chunk's first bit lies in (r < re_count).
+template <int QM, int L>
+__device__ __forceinline__ uint32_t x2_bits(const uint32_t* x2, const ChunkGeom& g, const ChunkMap& cm, uint32_t r)
+{
+  if (QM * L == 32 && cm.aligned) { // wave-uniform
+    return x2[r];
+  }
+  return ext32(x2, (g.bit0 & 31u) + r * (uint32_t)(QM * L));
+}
+
+// The RE's L symbol bytes (first in the MSB) and its L*Qm scrambling bits.  Four layers make the first a whole word.
+template <int QM, int L>
+__device__ __forceinline__ void re_bits(const PdschLaunch& p, const CbShared& sh, const ChunkGeom& g, const ChunkMap& cm,
+                                        uint32_t re_count, uint32_t r, uint32_t& bytes, uint32_t& gbits)
+{
   if constexpr (L == 4) {
     bytes = sh.symb[r];
   } else {
     bytes = ext32(sh.symb, 8u * r * L);
   }
-  if (LQ == 32 && cm.aligned) { // wave-uniform
-    gbits = scr[cm.word0 + r];
-    if (NRPHY_SCR_X2_ONLY) {
-      gbits ^= p.x1_words[cm.word0 + r];
-    }
-  } else {
-    gbits = ext32(scr, g.bit0 + r * LQ);
-    if (NRPHY_SCR_X2_ONLY) {
-      gbits ^= ext32(p.x1_words, g.bit0 + r * LQ);
-    }
-  }
-}
-
-// The L * Qm scrambling bits of RE r of the chunk (the prologue's x2 part + the shared x1 part; MSB first), zero beyond the
-// chunk.  L * Qm = 32 with a word-aligned chunk (the headline shape) makes them one word of each.
-template <int QM, int L>
-__device__ __forceinline__ uint32_t scrambling_bits(const PdschLaunch& p, const uint32_t* __restrict__ scr, const ChunkGeom& g,
-                                                    const ChunkMap& cm, uint32_t re_count, uint32_t r)
-{
-  uint32_t bits = 0;
-  if (r < re_count) {
-    if (QM * L == 32 && cm.aligned) { // wave-uniform: scalar base, small per-lane index
-      bits = (scr + cm.word0)[r];
-      if (NRPHY_SCR_X2_ONLY) {
-        bits ^= (p.x1_words + cm.word0)[r];
-      }
-    } else {
-      bits = ext32(scr, g.bit0 + r * (uint32_t)(QM * L));
-      if (NRPHY_SCR_X2_ONLY) {
-        bits ^= ext32(p.x1_words, g.bit0 + r * (uint32_t)(QM * L));
-      }
-    }
-  }
-  return bits;
+  gbits = x1_bits<QM, L>(p, g, cm, re_count, r) ^ x2_bits<QM, L>(sh.lin, g, cm, r);
 }
 
 // The grid loop of phase B for P ports with wideband precoding (every weight in a scalar register pair for the whole
@@ -724,7 +748,6 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
                                              const CbWork& wk, const CbShared& sh, const ChunkGeom& g, const ChunkMap& cm,
                                              uint32_t first_gbits, uint32_t lane, uint32_t* __restrict__ d_grid)
 {
-  const uint32_t* __restrict__ scr = p.scr + pd.scr_offset;
   const size_t   grid_base   = (size_t)pd.grid_index * p.grid_nof_ports * NRPHY_NSYMB * p.grid_nof_subc;
   const uint32_t plane_words = NRPHY_NSYMB * p.grid_nof_subc;
   // The PDU's grid through a buffer descriptor (scalar base, 32-bit per-lane offsets, the port plane in the scalar offset):
@@ -761,14 +784,15 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
   uint32_t cur_start = pd.sym_re_start[l_cur], cur_end = pd.sym_re_start[l_cur + 1u];
   uint32_t cur_arg = pd.sym_arg[l_cur], cur_row = l_cur * p.grid_nof_subc;
   bool     cur_table = pd.sym_kind[l_cur] == SYM_TABLE;
-  // The scrambling bits come from global memory (L2): the words of the NEXT 64 RE are requested before a trip's arithmetic
-  // starts, those of the first 64 RE were requested before rate matching (map_chunk).
+  // The x1 part of the scrambling bits comes from global memory (L2): the words of the NEXT 64 RE are requested before a
+  // trip's arithmetic starts, those of the first 64 RE were requested before rate matching (map_chunk).  The x2 part is in
+  // LDS (sh.lin, expanded from the work item's seed).
   uint32_t gbits_next = first_gbits;
 
   for (uint32_t r0 = 0; r0 < wk.re_count; r0 += WAVE) { // r0 is wave-uniform
     const uint32_t r        = r0 + lane;
-    const uint32_t gbits    = gbits_next;
-    gbits_next              = scrambling_bits<QM, L>(p, scr, g, cm, wk.re_count, r + WAVE);
+    const uint32_t x1       = gbits_next;
+    gbits_next              = x1_bits<QM, L>(p, g, cm, wk.re_count, r + WAVE);
     const uint32_t re_first = cm.re0 + r0;
     const uint32_t re_last  = re_first + ((wk.re_count - r0 < WAVE ? wk.re_count - r0 : WAVE) - 1u);
     if (re_first >= cur_end && l_cur + 1u < NRPHY_NSYMB) { // wave-uniform
@@ -786,6 +810,7 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
       continue;
     }
     __builtin_assume(r < (uint32_t)RE_CHUNK + WAVE);
+    const uint32_t gbits = x1 ^ x2_bits<QM, L>(sh.lin, g, cm, r);
     // The RE's L symbol bytes (first in the MSB): four layers make them a whole word.
     uint32_t bytes;
     if constexpr (L == 4) {
@@ -868,11 +893,10 @@ __device__ __forceinline__ void phase_b(const PdschLaunch& p, PduRef pd, const P
   constexpr uint32_t LQ = QM * L;
   // Codeword taps (parity tests, seam B): a loop of their own, so that the grid loop carries none of this.
   if (d_cw_rm != nullptr || d_cw_scr != nullptr) { // wave-uniform
-    const uint32_t* __restrict__ scr = p.scr + pd.scr_offset;
     const uint64_t cw_bit0 = pd.cw_bit_offset + g.cw_cb + (uint64_t)wk.re_begin * LQ;
     for (uint32_t r = lane; r < wk.re_count; r += WAVE) {
       uint32_t bytes, gbits;
-      re_bits<QM, L>(p, scr, sh, g, cm, r, bytes, gbits);
+      re_bits<QM, L>(p, sh, g, cm, wk.re_count, r, bytes, gbits);
       uint32_t v_rm = 0;
 #pragma unroll
       for (int l = 0; l != L; ++l) {
@@ -908,8 +932,8 @@ __device__ __forceinline__ void phase_b(const PdschLaunch& p, PduRef pd, const P
 // Stages 3 and 4 of a codeblock wave for one (Qm, layers): this wave's slice of the codeword, rate matching ... RE mapping.
 template <int QM, int L>
 __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const PduDev* pd_global, const CbWork& wk,
-                                          const CbShared& sh, uint32_t lane, uint32_t* d_grid, uint32_t* d_cw_rm,
-                                          uint32_t* d_cw_scr)
+                                          uint32_t item, const CbShared& sh, uint32_t lane, uint32_t* d_grid,
+                                          uint32_t* d_cw_rm, uint32_t* d_cw_scr)
 {
   const bool is_long = wk.cb >= pd.n_short;
   ChunkGeom  g;
@@ -923,8 +947,10 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   cm.re0     = g.cw_cb / (uint32_t)(QM * L) + wk.re_begin;
   cm.word0   = g.bit0 >> 5;
   cm.aligned = (g.bit0 & 31u) == 0;
-  // The scrambling bits of the chunk's first 64 RE are requested here: their trip to memory rides under rate matching.
-  const uint32_t first_gbits = scrambling_bits<QM, L>(p, p.scr + pd.scr_offset, g, cm, wk.re_count, lane);
+  // The work item's seed (the 31 x2 words from the one its first bit lies in; prologue) and the x1 words of the chunk's
+  // first 64 RE are requested here: their trip to memory rides under rate matching.
+  const uint32_t seed_word   = lane < 31u ? p.scr_seed[(size_t)item * 32u + lane] : 0u;
+  const uint32_t first_gbits = x1_bits<QM, L>(p, g, cm, wk.re_count, lane);
   {
     const RmIndex rm = rm_index_init(pd);
     if (rm.rank0 + g.E > rm.n_valid) { // wave-uniform: the selection wraps around Ncb
@@ -937,26 +963,30 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
     return;
   }
   NRPHY_WG_TRACE_MARK(3); // rate matched and interleaved
+  // The codeblock's LDS is free now: the chunk's x2 words go there, from the word its first bit lies in up to the word a
+  // misaligned read of its last bits runs into (the plan sized the region for it).
+  static_assert((31u + (uint32_t)RE_CHUNK * 32u + 31u) / 32u + 1u <= GOLD_EXPAND_MAX_WORDS, "a work item's scrambling words");
+  gold_expand_seed_wave(sh.lin, seed_word, ((g.bit0 & 31u) + wk.re_count * (uint32_t)(QM * L) + 31u) / 32u + 1u, lane);
   phase_b<QM, L>(p, pd, pd_global, wk, sh, g, cm, first_gbits, lane, d_grid, d_cw_rm, d_cw_scr);
 }
 
 template <int QM>
 __device__ __forceinline__ void map_chunk_layers(const PdschLaunch& p, PduRef pd, const PduDev* pd_global,
-                                                 const CbWork& wk, const CbShared& sh, uint32_t lane, uint32_t* d_grid,
-                                                 uint32_t* d_cw_rm, uint32_t* d_cw_scr)
+                                                 const CbWork& wk, uint32_t item, const CbShared& sh, uint32_t lane,
+                                                 uint32_t* d_grid, uint32_t* d_cw_rm, uint32_t* d_cw_scr)
 {
   switch (pd.nof_layers) { // wave-uniform
     case 1:
-      map_chunk<QM, 1>(p, pd, pd_global, wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk<QM, 1>(p, pd, pd_global, wk, item, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     case 2:
-      map_chunk<QM, 2>(p, pd, pd_global, wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk<QM, 2>(p, pd, pd_global, wk, item, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     case 3:
-      map_chunk<QM, 3>(p, pd, pd_global, wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk<QM, 3>(p, pd, pd_global, wk, item, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     default:
-      map_chunk<QM, 4>(p, pd, pd_global, wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk<QM, 4>(p, pd, pd_global, wk, item, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
   }
 }
@@ -1281,7 +1311,7 @@ __global__ __launch_bounds__(WAVE * CB_WAVES) void codeblock_kernel_t(PdschLaunc
   if (!codeblock_front(p, pd, wk, sh, d_tb, lane)) {
     return;
   }
-  map_chunk<QM, L>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+  map_chunk<QM, L>(p, pd, &p.pdus[wk.pdu], wk, p.work_base + item, sh, lane, d_grid, d_cw_rm, d_cw_scr);
   NRPHY_WG_TRACE_MARK(6);
 }
 
@@ -1313,16 +1343,16 @@ __global__ __launch_bounds__(WAVE * CB_WAVES) void codeblock_kernel(PdschLaunch 
   }
   switch (pd.qm) { // wave-uniform
     case 2:
-      map_chunk_layers<2>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk_layers<2>(p, pd, &p.pdus[wk.pdu], wk, p.work_base + item, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     case 4:
-      map_chunk_layers<4>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk_layers<4>(p, pd, &p.pdus[wk.pdu], wk, p.work_base + item, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     case 6:
-      map_chunk_layers<6>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk_layers<6>(p, pd, &p.pdus[wk.pdu], wk, p.work_base + item, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
     default:
-      map_chunk_layers<8>(p, pd, &p.pdus[wk.pdu], wk, sh, lane, d_grid, d_cw_rm, d_cw_scr);
+      map_chunk_layers<8>(p, pd, &p.pdus[wk.pdu], wk, p.work_base + item, sh, lane, d_grid, d_cw_rm, d_cw_scr);
       break;
   }
 }
@@ -1383,6 +1413,7 @@ hipError_t launch_codeblocks(const PdschLaunch& p, const uint32_t* bucket_begin,
     const uint32_t b = order[i], n = bucket_begin[b + 1] - bucket_begin[b];
     PdschLaunch    q = p;
     q.work           = p.work + bucket_begin[b];
+    q.work_base      = bucket_begin[b];
     q.n_work         = n;
     if (i != 0) { // the DM-RS and zero-fill waves ride at the end of the biggest bucket's launch
       q.n_dmrs_in_launch = 0;
