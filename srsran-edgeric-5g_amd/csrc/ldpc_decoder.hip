@@ -785,9 +785,8 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
   const uint32_t nw_k       = (K + 31u) >> 5;
   uint32_t       iterations = 0;
 
-  // Early stop: the message is a multiple of the generator polynomial.  Thread w owns hard-bit word w; its weight
-  // x^(bits after the word) mod g comes from the host.
-  const CrcPoly  crc    = {p.crc_poly, p.crc_order};
+  // Early stop: the message is a multiple of the generator polynomial.  Thread w owns hard-bit word w; the tables of its
+  // weight x^(bits after the word) mod g come from the host.
   const uint32_t n_msg  = K - p.nof_filler;
   const uint32_t jm = j - zc;
 
@@ -931,7 +930,11 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
           const uint32_t word = hard_word(soft, w, K, zero_seen);
           if (32u * w < n_msg) {
             const uint32_t w_bits = n_msg - 32u * w < 32u ? n_msg - 32u * w : 32u;
-            part ^= crc_mulmod32(p.crc_weight[w], word >> (32u - w_bits), crc);
+            // word * x^(bits after it) mod g: eight nibble tables of this word (L2), independent look-ups
+            const uint32_t  v = word >> (32u - w_bits);
+            const uint32_t* t = p.crc_weight + (size_t)w * DEC_CRC_TABLE_WORDS;
+            part ^= t[v & 15u] ^ t[16u + ((v >> 4) & 15u)] ^ t[32u + ((v >> 8) & 15u)] ^ t[48u + ((v >> 12) & 15u)] ^
+                    t[64u + ((v >> 16) & 15u)] ^ t[80u + ((v >> 20) & 15u)] ^ t[96u + ((v >> 24) & 15u)] ^ t[112u + (v >> 28)];
           }
         }
         for (int o = WAVE / 2; o != 0; o >>= 1) {

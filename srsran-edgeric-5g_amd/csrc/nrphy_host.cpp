@@ -2321,8 +2321,10 @@ const uint32_t* get_decoder_pair_addresses(nrphy_ctx* ctx, unsigned bg, unsigned
   return pos < 0 ? nullptr : ctx->d_dec_addr[(bg - 1) * NOF_LIFTING_SIZES + (unsigned)pos];
 }
 
-// Early-stop weights: word w of the n-bit message (32 bits, the last one n mod 32) is followed by n - 32 w - bits(w)
-// bits; the message is a multiple of the generator g iff the sum of word(w) * x^(that) vanishes mod g.
+// Early-stop tables: word w of the n-bit message (32 bits, the last one n mod 32) is followed by n - 32 w - bits(w)
+// bits; the message is a multiple of the generator g iff the sum of word(w) * x^(that) vanishes mod g.  Per word eight
+// nibble tables, tab[w][k][v] = (v x^(4 k)) * x^(bits after word w) mod g: the product is eight independent look-ups
+// instead of a 32-step shift-and-add per word and iteration (which was about 15 % of an early-stop iteration).
 const uint32_t* get_decoder_crc_weights(nrphy_ctx* ctx, uint32_t poly, uint32_t order, uint32_t n_msg)
 {
   const uint64_t key = ((uint64_t)poly << 32) | n_msg;
@@ -2332,13 +2334,18 @@ const uint32_t* get_decoder_crc_weights(nrphy_ctx* ctx, uint32_t poly, uint32_t 
   }
   const CrcField        field = {poly, order};
   const uint32_t        nw    = (n_msg + 31) / 32;
-  std::vector<uint32_t> w(nw);
+  std::vector<uint32_t> w((size_t)nw * DEC_CRC_TABLE_WORDS);
   for (uint32_t i = 0; i != nw; ++i) {
-    const uint32_t bits = std::min<uint32_t>(32, n_msg - 32 * i);
-    w[i]                = field.xpow((int64_t)n_msg - 32 * i - bits);
+    const uint32_t bits   = std::min<uint32_t>(32, n_msg - 32 * i);
+    const uint32_t weight = field.xpow((int64_t)n_msg - 32 * i - bits);
+    for (uint32_t k = 0; k != 8; ++k) {
+      for (uint32_t v = 0; v != 16; ++v) {
+        w[(size_t)i * DEC_CRC_TABLE_WORDS + 16 * k + v] = field.mul(weight, v << (4 * k));
+      }
+    }
   }
   uint32_t* d = nullptr;
-  if (upload(&d, w.data(), nw * sizeof(uint32_t)) != hipSuccess) {
+  if (upload(&d, w.data(), w.size() * sizeof(uint32_t)) != hipSuccess) {
     return nullptr;
   }
   ctx->d_dec_crc[key] = d;

@@ -262,6 +262,8 @@ struct DecoderGraph {
   uint32_t edge[MAX_BG_EDGES]; // (variable node * Zc) << 16 | lifted shift
 };
 
+constexpr uint32_t DEC_CRC_TABLE_WORDS = 8 * 16; // early-stop CRC: eight nibble tables per message word
+
 struct LdpcDecodeLaunch {
   const DecoderGraph* graph;
   const uint32_t*     pair_addr;  // even lifting sizes: soft-bit addresses of (edge, pair of checks), [row of four edges][lane][4]; else null
@@ -271,7 +273,7 @@ struct LdpcDecodeLaunch {
   uint32_t            nof_slots;  // >= the workgroups of this kernel the device can hold at once, <= codeblocks
   uint8_t*            out;        // per codeblock: Kb * Zc hard bits, packed MSB first
   uint32_t*           iterations; // per codeblock: iterations until the CRC passed, 0 = it did not (may be null)
-  const uint32_t*     crc_weight; // per 32-bit word of the message: x^(bits after the word) mod the CRC polynomial
+  const uint32_t*     crc_weight; // per 32-bit word of the message DEC_CRC_TABLE_WORDS words: [nibble k][value v] = (v x^(4k)) x^(bits after the word) mod the CRC polynomial
   const uint8_t*      skip;       // per codeblock (may be null): non-zero = leave it alone (decoded earlier)
   uint8_t*            ok_flags;   // per codeblock (may be null): set to 1 when the CRC passed
   uint32_t            crc_at_end; // 1: check the CRC once, after max_iterations (no early stop)

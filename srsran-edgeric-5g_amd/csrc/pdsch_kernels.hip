@@ -101,35 +101,46 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
       // elements per item), walked with scalar arithmetic alongside the blocks: w0 = the word of the item's first bit.
       const uint32_t lq = pd.qm * pd.nof_layers, n_short = pd.n_short, e_short = pd.e_short, e_long = pd.e_long, C = pd.C;
       const uint32_t nre_short = e_short / lq, nre_long = e_long / lq; // (the only divisions: the walk itself has none)
-      uint32_t       cb = 0, re_begin = 0, item = pd.item_first, bit_cb = 0;
-      uint32_t       nre = n_short != 0 ? nre_short : nre_long;
-      auto           next_item = [&]() {
-        re_begin += RE_CHUNK;
-        if (re_begin >= nre) {
-          bit_cb += cb < n_short ? e_short : e_long;
-          ++cb;
-          re_begin = 0;
-          nre      = cb < n_short ? nre_short : nre_long;
+      struct Cursor {
+        uint32_t cb, re_begin, item, bit_cb, nre;
+      };
+      Cursor resume = {0u, 0u, pd.item_first, 0u, n_short != 0 ? nre_short : nre_long}; // the first item whose seed is not complete yet
+      auto   advance = [&](Cursor& c) {
+        c.re_begin += RE_CHUNK;
+        if (c.re_begin >= c.nre) {
+          c.bit_cb += c.cb < n_short ? e_short : e_long;
+          ++c.cb;
+          c.re_begin = 0;
+          c.nre      = c.cb < n_short ? nre_short : nre_long;
         }
-        ++item;
+        ++c.item;
       };
       gold_sequence_blocks_wave(p.gold, pd.c_init, first, count, lds, lane, [&](uint32_t base, uint32_t avail) {
         const uint32_t lo = first + base, hi = lo + avail; // the block holds words [lo, hi) of the PDU's sequence
-        while (cb < C) {                                   // wave-uniform
-          const uint32_t w0 = (bit_cb + re_begin * lq) >> 5;
+        // Every item whose 31 words meet the block gets what the block holds of them.  Seeds of neighbouring items overlap
+        // when an item is short (the tail of a codeblock cut into RE_CHUNK pieces): an item that runs beyond the block does not
+        // end the walk, it only marks where the next block (or the next part's first) takes it up again.
+        Cursor c        = resume;
+        bool   resuming = false;
+        while (c.cb < C) { // wave-uniform
+          const uint32_t w0 = (c.bit_cb + c.re_begin * lq) >> 5;
           if (w0 >= hi) {
             break;
           }
           if (w0 + 31u > lo) {
             const uint32_t k = w0 + lane;
             if (lane < 31u && k >= lo && k < hi) {
-              p.scr_seed[(size_t)item * 32u + lane] = lds[k - lo];
+              p.scr_seed[(size_t)c.item * 32u + lane] = lds[k - lo];
             }
           }
-          if (w0 + 31u > hi) {
-            break; // the rest of this item's seed is in the next block (or in the next part's first)
+          if (w0 + 31u > hi && !resuming) {
+            resume   = c;
+            resuming = true;
           }
-          next_item();
+          advance(c);
+        }
+        if (!resuming) {
+          resume = c;
         }
       });
       NRPHY_WG_TRACE_MARK(6);

@@ -316,6 +316,22 @@ def test_pdsch_prologue_work_split(gpu_ctx, oracle, regions, parts, monkeypatch)
     plan.close()
 
 
+def test_pdsch_overlapping_scrambling_seeds(gpu_ctx, oracle):
+    """A shape a seeded sweep found: 64-QAM on three layers, codeblocks of 518 resource elements -- a work item of 512 and one of
+    6, whose 31-word scrambling seeds overlap the next codeblock's -- and a sequence long enough to be walked in two parts: the
+    seed of the item behind one that runs past the end of a part (or of a block of 31 rows) got none of its words from that part.
+    Codeword taps and grid equal the oracle's."""
+    rng = np.random.default_rng(1001)
+    pdu, nof_ports, nof_subc = list(cases.random_pdus(oracle.tbs, rng, 80))[52]
+    d = oracle.derive(pdu)
+    assert (pdu.qm, pdu.nof_layers) == (6, 3) and d["rm_length_short"] // 18 > 512, "the generator changed: pick the shape by hand"
+    tb = cases.random_tb(np.random.default_rng(7), pdu)
+    want, orm, oscr = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc, taps=True, codeword_bits=d["codeword_bits"])
+    got, rm, scr = gpu_ctx.pdsch_process_host(pdu, tb, nof_ports, nof_subc, taps=True)
+    assert np.array_equal(rm, orm) and np.array_equal(scr, oscr)
+    assert np.array_equal(got, want)
+
+
 def test_pdsch_full_size_batch_properties(gpu_ctx, oracle):
     """At BASELINE size (config 3, 64 slots in one launch): identical inputs give identical grids (no cross-slot
     interference), different TBs differ, and one slot of the batch matches the oracle bit for bit."""
