@@ -1,3 +1,8 @@
+"""Repro aid for a seeded-sweep mismatch (profiles/fuzz_sweep.py leg `pdsch`, base 0): re-runs the leg's PDUs one by one on the
+device, and for a PDU whose grid or codeword taps differ from the oracle's prints its shape and which codeblocks / resource
+elements differ.  It found the seed walk bug of round 3 (an item whose 31-word scrambling seed ran past the end of a sequence
+part hid the item behind it; tests/test_gpu_parity.py::test_pdsch_overlapping_scrambling_seeds).
+Usage (GPU box, repository root): python3 profiles/probes/repro_seed.py"""
 import os, sys
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
