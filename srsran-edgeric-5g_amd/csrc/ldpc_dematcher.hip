@@ -199,11 +199,35 @@ __global__ __launch_bounds__(DEMATCH_LDS_THREADS) void ldpc_dematch_lds_kernel(D
 }
 
 // Direct form for operation lists whose destination ranges do not overlap (p.disjoint: no repetition that wraps onto itself -- every
-// first transmission and every retransmission of a codeblock shorter than its buffer): nothing is staged.  A thread takes one
-// received symbol -- its Qm soft bits are row 0 .. Qm-1 of one column of the deinterleaver table, contiguous in the input -- and
-// stores each of them where the operation covering that element puts it: the lanes of a wavefront write 64 consecutive soft bits
-// of every row.  Clearing and filling run as dword stores.  Soft bits no operation covers are never touched, and the buffer is
-// read only where an operation combines.
+// first transmission and every retransmission of a codeblock shorter than its buffer): nothing is staged.  A thread takes FOUR
+// neighbouring received symbols -- the Qm soft bits of a symbol are row 0 .. Qm-1 of one column of the deinterleaver table,
+// contiguous in the input -- transposes their bytes into one word per row (v_perm) and stores each word where the operation
+// covering those four elements puts it: the lanes of a wavefront write 256 consecutive soft bits of every row with one store
+// (byte-aligned dwords; one symbol per thread and a byte per store was a 64-byte store per wavefront and row).  Elements at the
+// edge of an operation's range, or of the input, go one by one.  Clearing and filling run as dword stores.  Soft bits no
+// operation covers are never touched, and the buffer is read only where an operation combines.
+typedef uint32_t dematch_u32_bytewise __attribute__((aligned(1)));
+
+// Byte b of the little-endian byte stream held in dw (compile-time index after unrolling).
+template <uint32_t B>
+__device__ __forceinline__ uint32_t dematch_byte(const uint32_t (&dw)[8])
+{
+  return (dw[B >> 2] >> (8u * (B & 3u))) & 0xFFu;
+}
+template <uint32_t QM, uint32_t J>
+__device__ __forceinline__ void dematch_rows_from(const uint32_t (&dw)[8], uint32_t (&w)[8])
+{
+  if constexpr (J < QM) {
+    w[J] = dematch_byte<J>(dw) | (dematch_byte<QM + J>(dw) << 8) | (dematch_byte<2 * QM + J>(dw) << 16) | (dematch_byte<3 * QM + J>(dw) << 24);
+    dematch_rows_from<QM, J + 1>(dw, w);
+  }
+}
+template <uint32_t QM>
+__device__ __forceinline__ void dematch_rows(const uint32_t (&dw)[8], uint32_t (&w)[8])
+{
+  dematch_rows_from<QM, 0>(dw, w);
+}
+
 template <bool EXT>
 __global__ __launch_bounds__(256) void ldpc_dematch_scatter_kernel(DematchLaunch p)
 {
@@ -211,25 +235,49 @@ __global__ __launch_bounds__(256) void ldpc_dematch_scatter_kernel(DematchLaunch
   int8_t*        out_row = p.out + (size_t)blockIdx.z * p.out_stride_outer + (size_t)blockIdx.y * p.out_stride;
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, gsize = gridDim.x * blockDim.x;
   const uint32_t qm = p.qm, cols = p.cols;
-  // the thread's symbol
-  uint32_t lo = 0, hi = 0;
-  if (gtid < cols) {
-    const int8_t* src = in + (size_t)gtid * qm;
-    if (qm == 8 && (reinterpret_cast<uintptr_t>(src) & 7u) == 0) {
-      const uint2 w = *reinterpret_cast<const uint2*>(src);
-      lo = w.x, hi = w.y;
-    } else if (qm == 4 && (reinterpret_cast<uintptr_t>(src) & 3u) == 0) {
-      lo = *reinterpret_cast<const uint32_t*>(src);
+  // the thread's symbols i0 .. i0 + nsym - 1: their 4 * Qm input bytes are contiguous (Qm dwords when all four exist)
+  const uint32_t i0   = 4u * gtid;
+  const uint32_t nsym = i0 < cols ? (cols - i0 < 4u ? cols - i0 : 4u) : 0u;
+  uint32_t       dw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    const int8_t* src = in + (size_t)i0 * qm;
+    if (nsym == 4u && qm == 8 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+      const uint4 a = reinterpret_cast<const uint4*>(src)[0], b = reinterpret_cast<const uint4*>(src)[1];
+      dw[0] = a.x, dw[1] = a.y, dw[2] = a.z, dw[3] = a.w, dw[4] = b.x, dw[5] = b.y, dw[6] = b.z, dw[7] = b.w;
+    } else if (nsym == 4u && (reinterpret_cast<uintptr_t>(src) & 3u) == 0) {
+#pragma unroll
+      for (uint32_t k = 0; k != 8; ++k) {
+        if (k < qm) {
+          dw[k] = reinterpret_cast<const uint32_t*>(src)[k];
+        }
+      }
     } else {
-      for (uint32_t j = 0; j != qm; ++j) {
-        const uint32_t b = (uint32_t)(uint8_t)src[j];
-        if (j < 4) {
-          lo |= b << (8u * j);
-        } else {
-          hi |= b << (8u * (j - 4u));
+#pragma unroll
+      for (uint32_t b = 0; b != 32; ++b) { // (constant register indices: the last threads of a row, or an unaligned input)
+        if (b < nsym * qm) {
+          dw[b >> 2] |= (uint32_t)(uint8_t)src[b] << (8u * (b & 3u));
         }
       }
     }
+  }
+  // row words: w[j] = row j of the four symbols, first symbol in the low byte: byte k * Qm + j of the input is symbol k, row j
+  uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  switch (qm) { // uniform
+    case 8:
+      dematch_rows<8>(dw, w);
+      break;
+    case 6:
+      dematch_rows<6>(dw, w);
+      break;
+    case 4:
+      dematch_rows<4>(dw, w);
+      break;
+    case 2:
+      dematch_rows<2>(dw, w);
+      break;
+    default:
+      dematch_rows<1>(dw, w);
+      break;
   }
   for (uint32_t k = 0; k != p.n_ops; ++k) { // uniform
     const DematchOp op  = EXT ? p.ops_ext[k] : p.ops[k];
@@ -251,16 +299,39 @@ __global__ __launch_bounds__(256) void ldpc_dematch_scatter_kernel(DematchLaunch
       }
       continue;
     }
-    if (gtid >= cols) {
+    if (nsym == 0u) {
       continue;
     }
-    // element j * cols + i of the deinterleaved input, for the rows the operation's source range [src, src + count) reaches
-    for (uint32_t j = 0; j != qm; ++j) {
-      const uint32_t s = j * cols + gtid;
-      if (s - op.src < op.count) { // (unsigned: also false for s < src)
-        const int v = (int)(int8_t)((j < 4 ? lo >> (8u * j) : hi >> (8u * (j - 4u))) & 0xFFu);
-        int8_t*   d = dst + (s - op.src);
-        *d          = (int8_t)(op.kind == DEMATCH_COPY ? v : dematch_sum(v, (int)*d));
+    // elements j * cols + i0 .. + nsym - 1 of the deinterleaved input, for the rows the operation's source range reaches
+#pragma unroll
+    for (uint32_t j = 0; j != 8; ++j) {
+      if (j >= qm) { // uniform
+        break;
+      }
+      const uint32_t rel = j * cols + i0 - op.src; // (unsigned: huge when the first element lies before the range)
+      if (nsym == 4u && rel < op.count && op.count - rel >= 4u) {
+        int8_t* d = dst + rel;
+        if (op.kind == DEMATCH_COPY) {
+          *reinterpret_cast<dematch_u32_bytewise*>(d) = w[j];
+        } else {
+          const uint32_t old = *reinterpret_cast<const dematch_u32_bytewise*>(d);
+          uint32_t       r   = 0;
+#pragma unroll
+          for (uint32_t e = 0; e != 4; ++e) {
+            const int v = (int)(int8_t)((w[j] >> (8u * e)) & 0xFFu), o = (int)(int8_t)((old >> (8u * e)) & 0xFFu);
+            r |= ((uint32_t)dematch_sum(v, o) & 0xFFu) << (8u * e);
+          }
+          *reinterpret_cast<dematch_u32_bytewise*>(d) = r;
+        }
+      } else {
+#pragma unroll
+        for (uint32_t e = 0; e != 4; ++e) {
+          if (e < nsym && rel + e < op.count) { // (rel + e wraps back into range exactly for the elements at or behind op.src)
+            const int v = (int)(int8_t)((w[j] >> (8u * e)) & 0xFFu);
+            int8_t*   d = dst + (rel + e);
+            *d          = (int8_t)(op.kind == DEMATCH_COPY ? v : dematch_sum(v, (int)*d));
+          }
+        }
       }
     }
   }
@@ -274,7 +345,7 @@ static void launch_dematch_variant(const DematchLaunch& p, uint32_t n_cb, uint32
   const uint32_t e    = p.cols * p.qm;
   const uint32_t lds  = ((e + 15u) & ~15u) + ((p.block_length + 15u) & ~15u);
   if (vec4 && p.disjoint) {
-    hipLaunchKernelGGL(ldpc_dematch_scatter_kernel<EXT>, dim3((p.cols + 255u) / 256u, n_cb, n_outer), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(ldpc_dematch_scatter_kernel<EXT>, dim3(((p.cols + 3u) / 4u + 255u) / 256u, n_cb, n_outer), dim3(256), 0, stream, p);
   } else if (vec4 && lds <= 64u * 1024u) {
     hipLaunchKernelGGL(ldpc_dematch_lds_kernel<EXT>, dim3(n_cb, n_outer), dim3(DEMATCH_LDS_THREADS), lds, stream, p);
   } else if (vec4) {
