@@ -174,6 +174,13 @@ def roof(name, ms, nbytes, slots=None, config=None, wire=False):
                         "valu_insts_per_launch": int(valu),
                         "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(gbs / HBM_PEAK_GBS, 4)}})
+        elif valu and name == "prologue_kernel" and ms > 0:
+            # neither roof binds this launch: both figures, and what the workgroup timeline shows
+            ginst = valu / (ms * 1e-3) / 1e9
+            out["valu"] = {"achieved": round(ginst, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s",
+                           "frac": round(ginst / VALU_PEAK_GINST, 4), "valu_insts_per_launch": int(valu)}
+            out["note"] = ("bound by its two dependent chains, whose waves take turns at the SIMDs and the LDS: a TB-CRC workgroup's "
+                           "regions (byte-table look-ups) and a sequence wave's blocks of 31 rows (profiles/r03_prologue_trace.txt)")
     return out
 
 
