@@ -1,8 +1,8 @@
 // PDSCH processor kernels for gfx950 (MI355X).
 //
-//   prologue_kernel    per-PDU work the codeblock waves consume: the transport-block CRC (every thread reduces a
-//                      4-byte-aligned chunk with a byte table, scales its remainder by x^(8 * bytes after) -- table
-//                      built at plan time -- and XORs it into the result) and the PDU's scrambling sequence
+//   prologue_kernel    per-PDU work the codeblock waves consume: the transport-block CRC (a workgroup per run of 16 KiB
+//                      regions, Horner's rule through byte tables in LDS, one share per workgroup), a 31-word seed of
+//                      the scrambling sequence per codeblock work item, and the DM-RS sequences
 //   codeblock_kernel   one wavefront per codeblock (or per 512-RE chunk of it): segmentation, CB-CRC, LDPC
 //                      base-graph expansion in LDS, rate matching + bit interleaving as a word-level bit-matrix
 //                      transposition, Gold scrambling, QAM mapping through an LDS table, layer mapping, precoding
@@ -46,9 +46,9 @@ __device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t re
   return tab[reg & 0xFFu] ^ tab[256u + ((reg >> 8) & 0xFFu)] ^ tab[512u + ((reg >> 16) & 0xFFu)] ^ tab[768u + (reg >> 24)];
 }
 
-// Blocks [0, n_scr_work): a share of the scrambling sequence of one PDU, and its DM-RS sequences (TS 38.211 Sections 7.3.1.1, 7.4.1.1.1;
-// reference: pdsch_modulator_impl.cpp:43-60, dmrs_pdsch_processor_impl.cpp:84-106).  The blocks after them:
-// transport-block CRC.
+// Blocks [0, n_scr_work): the seeds of the scrambling sequence of one PDU (a part of them in a small batch) and its DM-RS
+// sequences (TS 38.211 Sections 7.3.1.1, 7.4.1.1.1; reference: pdsch_modulator_impl.cpp:43-60,
+// dmrs_pdsch_processor_impl.cpp:84-106).  The blocks after them: transport-block CRC.
 __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
 {
   constexpr uint32_t LDS_WORDS = 4 * 1024 + 2 * TB_CRC_THREADS; // CRC role: four tables and two buffers of partials (18 KB: 8 workgroups per CU)
@@ -59,9 +59,8 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   // Order of the two roles in the grid (p.prologue_order, NRPHY_PROLOGUE_ORDER):
   //  0  sequence workgroups first, then the CRC workgroups;
   //  1  the sequence workgroups spread evenly among the CRC workgroups, every XCD taking a contiguous run of that list
-  //     (block b runs on XCD b % 8).  A sequence workgroup is one long wave that waits for its own stores (plus three short
-  //     DM-RS waves) and holds its slot on the CU for the whole time; taken first, a thousand of them leave the CRC
-  //     workgroups half the slots for most of the launch.
+  //     (block b runs on XCD b % 8).  A sequence workgroup is one long wave (plus three short DM-RS waves) and holds its slot
+  //     on the CU for the whole time.  Measured: within 1 % of order 0 (profiles/r03_prologue_trace.txt); an A/B aid.
   // (With the workgroup-wide generator of rounds 1-3 -- a ring in LDS walked by all four waves -- interleaving cost +95 %:
   // ring and byte tables slowed each other down; and CRC first +11 %.  profiles/r02_codeblock_experiments.txt.)
   uint32_t scr_index = blockIdx.x, crc_index = blockIdx.x - p.n_scr_work;
