@@ -571,6 +571,135 @@ __device__ inline void gold_expand_seed_wave(uint32_t* x2, uint32_t seed_word, u
   have = gold_expand_step<8>(x2, have, need, lane); // 703
 }
 
+// ---- Transport-block CRC by regions (prologue_kernel's TB-CRC role; the receive side's transport-block check) ----------
+// A CRC is the remainder of a polynomial, so it splits: the block is cut into 16 KiB regions; a 256-thread workgroup
+// reduces regions [region0, region0 + count) one after the other, the next region's words in flight while the current one
+// is reduced, and returns (in thread 0) remainder * factor, factor = x^(order + 8 (bytes - end of the last region)) mod g:
+// its share of the block's CRC.  Inside a region thread t owns four groups of four consecutive words (16-byte loads,
+// coalesced, straight from HBM): Horner's rule in x^32 inside a group, in y1k = x^(32 * 1024) across the groups -- four
+// independent table look-ups per word; the 256 partials are folded by one wavefront the same way with y8k = x^(128 * 64);
+// from region to region those 64 lanes step with yz = x^(8 * 16384), and only once per workgroup do they pay for a
+// multiplication by a per-lane constant.  `lds`: TB_CRC_LDS_WORDS words.  Workgroup-uniform arguments.
+constexpr int TB_CRC_THREADS = 256;
+
+constexpr int TB_CRC_WPT = NRPHY_CRC_WORDS_PER_THREAD;
+static_assert(TB_CRC_REGION_WORDS == TB_CRC_WPT * TB_CRC_THREADS, "words per thread");
+
+// reg * y mod g for a 32-bit partial, y's table in LDS: tab[k * 256 + b] = (b x^(8k)) y mod g.
+__device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t reg)
+{
+  return tab[reg & 0xFFu] ^ tab[256u + ((reg >> 8) & 0xFFu)] ^ tab[512u + ((reg >> 16) & 0xFFu)] ^ tab[768u + (reg >> 24)];
+}
+
+constexpr uint32_t TB_CRC_LDS_WORDS = 4 * 1024 + 2 * TB_CRC_THREADS;
+
+__device__ inline uint32_t tbcrc_regions_workgroup(const TbCrcTables* tables, uint32_t sel, CrcPoly c, const uint32_t* tbw, uint32_t n,
+                                                   uint32_t region0, uint32_t count, uint32_t factor, uint32_t* lds, uint32_t tid)
+{
+  uint32_t*       y32 = lds;
+  uint32_t*       y1k = lds + 1024;
+  uint32_t*       y8k = lds + 2048;
+  uint32_t*       yz  = lds + 3072;
+  uint32_t*       msg = lds + 4096; // two buffers of 256 partials, used in turn: one barrier per region
+
+  // A region's words, big-endian (zero beyond the transport block, bytes beyond its end masked off): round i of thread t is
+  // the 16 bytes at word 1024 i + 4 t of the region.  16-byte loads: with one word per lane and load the same bytes took
+  // three times as long to arrive (8.6 against 2.6 us per region, the launch 85 against 54 us: profiles/r03_prologue_trace.txt).
+  // A transport block that does not start on a 16-byte boundary, and the 16 bytes that hold its end, take single words.
+  constexpr int   ROUNDS = TB_CRC_WPT / 4;
+  static_assert(TB_CRC_WPT == 16, "the tables assume four rounds of four words (y1k, y8k)");
+  const uint32_t  nwords  = (n + 3u) >> 2;
+  const bool      aligned = (reinterpret_cast<uintptr_t>(tbw) & 15u) == 0; // workgroup-uniform
+  auto load_region = [&](uint32_t region, uint32_t (&w)[TB_CRC_WPT]) {
+#pragma unroll
+    for (int i = 0; i != ROUNDS; ++i) {
+      const uint32_t idx = region * TB_CRC_REGION_WORDS + ((uint32_t)i * TB_CRC_THREADS + tid) * 4u;
+      if (aligned && idx + 4u <= nwords && !((n & 3u) != 0 && idx + 4u == nwords)) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tbw + idx);
+        w[4 * i] = __builtin_bswap32(v.x), w[4 * i + 1] = __builtin_bswap32(v.y);
+        w[4 * i + 2] = __builtin_bswap32(v.z), w[4 * i + 3] = __builtin_bswap32(v.w);
+      } else {
+#pragma unroll
+        for (int k = 0; k != 4; ++k) {
+          uint32_t x = (idx + k < nwords) ? be_word(tbw, idx + k) : 0u;
+          if ((n & 3u) != 0 && idx + k + 1u == nwords) {
+            x &= 0xFFFFFFFFu << (8u * (4u - (n & 3u)));
+          }
+          w[4 * i + k] = x;
+        }
+      }
+    }
+  };
+  uint32_t w[TB_CRC_WPT], wn[TB_CRC_WPT];
+  load_region(region0, w);
+#pragma unroll
+  for (int k = 0; k != 4; ++k) {
+    y32[k * 256 + tid] = tables->y32[sel][k][tid];
+    y1k[k * 256 + tid] = tables->y1k[sel][k][tid];
+    y8k[k * 256 + tid] = tables->y8k[sel][k][tid];
+    yz[k * 256 + tid]  = tables->yz[sel][k][tid];
+  }
+  __syncthreads();
+#ifdef NRPHY_WG_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (trace builds: tables in LDS, the first region's words in registers)
+  NRPHY_WG_TRACE_MARK(2);
+#endif
+  // The workgroup's regions one after the other.  Lane l of wave 0 carries acc = sum over the regions so far of (its four
+  // partials of the region, folded with y8k) * yz^(regions that follow): one more table product per region and lane, and the
+  // two multiplications without a table -- by the lane's constant and by the share factor -- once per workgroup.
+  // (Two regions' loads ahead instead of one -- three register sets in rotation -- changed nothing: with the sequences no
+  // longer written out the workgroup waits for its turn at the vector unit and the LDS, not for its loads.)
+  uint32_t acc = 0;
+  for (uint32_t j = 0; j != count; ++j) { // workgroup-uniform
+    if (j + 1u != count) {
+      load_region(region0 + j + 1u, wn); // in flight while this region is reduced
+    }
+    // four independent chains of three products (the words of a round), then three products across the rounds
+    uint32_t v[ROUNDS];
+#pragma unroll
+    for (int i = 0; i != ROUNDS; ++i) {
+      v[i] = w[4 * i];
+    }
+#pragma unroll
+    for (int k = 1; k != 4; ++k) {
+#pragma unroll
+      for (int i = 0; i != ROUNDS; ++i) {
+        v[i] = crc_advance(y32, v[i]) ^ w[4 * i + k];
+      }
+    }
+    uint32_t reg = v[0];
+#pragma unroll
+    for (int i = 1; i != ROUNDS; ++i) {
+      reg = crc_advance(y1k, reg) ^ v[i];
+    }
+    uint32_t* m = msg + (j & 1u) * TB_CRC_THREADS;
+    m[tid]      = reg;
+    lds_barrier();
+    if (tid < WAVE) {
+      uint32_t r = m[tid];
+#pragma unroll
+      for (int k = 1; k != 4; ++k) {
+        r = crc_advance(y8k, r) ^ m[tid + WAVE * k];
+      }
+      acc = (j != 0 ? crc_advance(yz, acc) : 0u) ^ r;
+    }
+    if (j + 1u != count) {
+#pragma unroll
+      for (int i = 0; i != TB_CRC_WPT; ++i) {
+        w[i] = wn[i];
+      }
+    }
+  }
+  NRPHY_WG_TRACE_MARK(1);
+  uint32_t share = 0;
+  if (tid < WAVE) {
+    uint32_t r = crc_mulmod32(tables->lane[sel][tid], acc, c);
+    r          = wave_xor(r);
+    share      = crc_mulmod(r, factor, c);
+  }
+  return share;
+}
+
 // round-to-nearest-even float -> bf16 exactly as the reference stores the grid
 // (to_bf16, R/include/srsran/adt/bf16.h:39-56); values here are finite.
 __device__ __forceinline__ uint32_t to_bf16_bits(float v)

@@ -2885,6 +2885,12 @@ extern "C" int nrphy_pusch_decode_batch(nrphy_ctx_t* ctx, const nrphy_pusch_deco
   a.tb_bytes       = cfg->tb_size_bytes;
   a.cb_info_bits   = d.cb_info_bits;
   a.max_iterations = cfg->max_iterations;
+  // The transport-block check by 16 KiB regions (tbcrc_regions_workgroup, the transmit side's TB-CRC role): the context's
+  // tables and the factor that turns the remainder of the zero-extended block into the block's CRC24A.
+  a.tbcrc          = ctx->d_tbcrc;
+  a.crc_factor     = CRC24A_FIELD.xpow((int64_t)CRC24A_FIELD.order +
+                                   8 * ((int64_t)cfg->tb_size_bytes -
+                                        (int64_t)divide_ceil(cfg->tb_size_bytes, TB_CRC_REGION_BYTES) * TB_CRC_REGION_BYTES));
   HIP_TRY(launch_pusch_assemble(a, n_tb, s));
   return NRPHY_OK;
 }

@@ -319,7 +319,9 @@ struct PuschAssembleLaunch {
   const uint8_t* skipped;     // [n_tb][C] 1 where this call did not run the decoder (CRC ok since an earlier transmission)
   uint8_t*       tb;          // [n_tb][tb_stride] transport blocks out
   uint32_t*      result;      // [n_tb][4]: tb_crc_ok, codeblocks with CRC ok, sum and max of iterations over decoded codeblocks
-  const uint32_t* crc_weight; // [PUSCH_ASSEMBLE_THREADS] x^(8 * bytes behind thread t's run of the block) mod CRC24A
+  const uint32_t* crc_weight; // [PUSCH_ASSEMBLE_THREADS] x^(8 * bytes behind run t of the block) mod CRC24A (the byte-wise form: unaligned blocks)
+  const TbCrcTables* tbcrc;   // the context's TB-CRC tables and ...
+  uint32_t       crc_factor;  // ... x^(24 + 8 (tb_bytes - end of the last 16 KiB region)) mod CRC24A (the form by regions)
   uint32_t       C, msg_stride, tb_stride, tb_bytes, cb_info_bits, max_iterations;
 };
 constexpr uint32_t PUSCH_ASSEMBLE_THREADS = 1024;

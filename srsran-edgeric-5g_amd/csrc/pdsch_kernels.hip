@@ -35,23 +35,12 @@ namespace nrphy {
 //
 // Scrambling sequences (seeds per work item) and DM-RS sequences: see gold_sequence_blocks_wave() and gold_sequence_wave().
 // ================================================================================================================
-constexpr int TB_CRC_THREADS = 256;
-
-constexpr int TB_CRC_WPT = NRPHY_CRC_WORDS_PER_THREAD;
-static_assert(TB_CRC_REGION_WORDS == TB_CRC_WPT * TB_CRC_THREADS, "words per thread");
-
-// reg * y mod g for a 32-bit partial, y's table in LDS: tab[k * 256 + b] = (b x^(8k)) y mod g.
-__device__ __forceinline__ uint32_t crc_advance(const uint32_t* tab, uint32_t reg)
-{
-  return tab[reg & 0xFFu] ^ tab[256u + ((reg >> 8) & 0xFFu)] ^ tab[512u + ((reg >> 16) & 0xFFu)] ^ tab[768u + (reg >> 24)];
-}
-
 // Blocks [0, n_scr_work): the seeds of the scrambling sequence of one PDU (a part of them in a small batch) and its DM-RS
 // sequences (TS 38.211 Sections 7.3.1.1, 7.4.1.1.1; reference: pdsch_modulator_impl.cpp:43-60,
 // dmrs_pdsch_processor_impl.cpp:84-106).  The blocks after them: transport-block CRC.
 __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p, const uint8_t* __restrict__ d_tb)
 {
-  constexpr uint32_t LDS_WORDS = 4 * 1024 + 2 * TB_CRC_THREADS; // CRC role: four tables and two buffers of partials (18 KB: 8 workgroups per CU)
+  constexpr uint32_t LDS_WORDS = TB_CRC_LDS_WORDS; // CRC role: four tables and two buffers of partials (18 KB: 8 workgroups per CU)
   __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_WORDS]; // sequence role: seed rows + DM-RS scratch
   static_assert(LDS_WORDS >= GOLD_RING_WORDS, "LDS of the sequence role");
   const uint32_t tid = threadIdx.x;
@@ -173,109 +162,11 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (trace builds: the descriptors have arrived)
   NRPHY_WG_TRACE_MARK(3);
 #endif
-  uint32_t*       y32 = lds;
-  uint32_t*       y1k = lds + 1024;
-  uint32_t*       y8k = lds + 2048;
-  uint32_t*       yz  = lds + 3072;
-  uint32_t*       msg = lds + 4096; // two buffers of 256 partials, used in turn: one barrier per region
-
-  // A region's words, big-endian (zero beyond the transport block, bytes beyond its end masked off): round i of thread t is
-  // the 16 bytes at word 1024 i + 4 t of the region.  16-byte loads: with one word per lane and load the same bytes took
-  // three times as long to arrive (8.6 against 2.6 us per region, the launch 85 against 54 us: profiles/r03_prologue_trace.txt).
-  // A transport block that does not start on a 16-byte boundary, and the 16 bytes that hold its end, take single words.
-  constexpr int   ROUNDS = TB_CRC_WPT / 4;
-  static_assert(TB_CRC_WPT == 16, "the tables assume four rounds of four words (y1k, y8k)");
-  const uint32_t  nwords  = (n + 3u) >> 2;
-  const bool      aligned = (reinterpret_cast<uintptr_t>(tbw) & 15u) == 0; // workgroup-uniform
-  auto load_region = [&](uint32_t region, uint32_t (&w)[TB_CRC_WPT]) {
-#pragma unroll
-    for (int i = 0; i != ROUNDS; ++i) {
-      const uint32_t idx = region * TB_CRC_REGION_WORDS + ((uint32_t)i * TB_CRC_THREADS + tid) * 4u;
-      if (aligned && idx + 4u <= nwords && !((n & 3u) != 0 && idx + 4u == nwords)) {
-        const uint4 v = *reinterpret_cast<const uint4*>(tbw + idx);
-        w[4 * i] = __builtin_bswap32(v.x), w[4 * i + 1] = __builtin_bswap32(v.y);
-        w[4 * i + 2] = __builtin_bswap32(v.z), w[4 * i + 3] = __builtin_bswap32(v.w);
-      } else {
-#pragma unroll
-        for (int k = 0; k != 4; ++k) {
-          uint32_t x = (idx + k < nwords) ? be_word(tbw, idx + k) : 0u;
-          if ((n & 3u) != 0 && idx + k + 1u == nwords) {
-            x &= 0xFFFFFFFFu << (8u * (4u - (n & 3u)));
-          }
-          w[4 * i + k] = x;
-        }
-      }
-    }
-  };
-  uint32_t w[TB_CRC_WPT], wn[TB_CRC_WPT];
-  load_region(wk_region, w);
-#pragma unroll
-  for (int k = 0; k != 4; ++k) {
-    y32[k * 256 + tid] = p.tbcrc->y32[sel][k][tid];
-    y1k[k * 256 + tid] = p.tbcrc->y1k[sel][k][tid];
-    y8k[k * 256 + tid] = p.tbcrc->y8k[sel][k][tid];
-    yz[k * 256 + tid]  = p.tbcrc->yz[sel][k][tid];
-  }
-  __syncthreads();
-#ifdef NRPHY_WG_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (trace builds: tables in LDS, the first region's words in registers)
-  NRPHY_WG_TRACE_MARK(2);
-#endif
-  // The workgroup's regions one after the other.  Lane l of wave 0 carries acc = sum over the regions so far of (its four
-  // partials of the region, folded with y8k) * yz^(regions that follow): one more table product per region and lane, and the
-  // two multiplications without a table -- by the lane's constant and by the share factor -- once per workgroup.
-  // (Two regions' loads ahead instead of one -- three register sets in rotation -- changed nothing: with the sequences no
-  // longer written out the workgroup waits for its turn at the vector unit and the LDS, not for its loads.)
-  uint32_t acc = 0;
-  for (uint32_t j = 0; j != wk_count; ++j) { // workgroup-uniform
-    if (j + 1u != wk_count) {
-      load_region(wk_region + j + 1u, wn); // in flight while this region is reduced
-    }
-    // four independent chains of three products (the words of a round), then three products across the rounds
-    uint32_t v[ROUNDS];
-#pragma unroll
-    for (int i = 0; i != ROUNDS; ++i) {
-      v[i] = w[4 * i];
-    }
-#pragma unroll
-    for (int k = 1; k != 4; ++k) {
-#pragma unroll
-      for (int i = 0; i != ROUNDS; ++i) {
-        v[i] = crc_advance(y32, v[i]) ^ w[4 * i + k];
-      }
-    }
-    uint32_t reg = v[0];
-#pragma unroll
-    for (int i = 1; i != ROUNDS; ++i) {
-      reg = crc_advance(y1k, reg) ^ v[i];
-    }
-    uint32_t* m = msg + (j & 1u) * TB_CRC_THREADS;
-    m[tid]      = reg;
-    lds_barrier();
-    if (tid < WAVE) {
-      uint32_t r = m[tid];
-#pragma unroll
-      for (int k = 1; k != 4; ++k) {
-        r = crc_advance(y8k, r) ^ m[tid + WAVE * k];
-      }
-      acc = (j != 0 ? crc_advance(yz, acc) : 0u) ^ r;
-    }
-    if (j + 1u != wk_count) {
-#pragma unroll
-      for (int i = 0; i != TB_CRC_WPT; ++i) {
-        w[i] = wn[i];
-      }
-    }
-  }
-  NRPHY_WG_TRACE_MARK(1);
-  if (tid < WAVE) {
-    uint32_t r = crc_mulmod32(p.tbcrc->lane[sel][tid], acc, c);
-    r          = wave_xor(r);
-    if (tid == 0) {
-      // The workgroup's share of the PDU's CRC in a slot of its own: the codeblock wave that attaches the CRC adds the
-      // shares up, so a run neither relies on nor leaves behind any accumulator state.
-      p.tb_crc_part[crc_index] = crc_mulmod(r, wk_factor, c);
-    }
+  const uint32_t share = tbcrc_regions_workgroup(p.tbcrc, sel, c, tbw, n, wk_region, wk_count, wk_factor, lds, tid);
+  if (tid == 0) {
+    // The workgroup's share of the PDU's CRC in a slot of its own: the codeblock wave that attaches the CRC adds the
+    // shares up, so a run neither relies on nor leaves behind any accumulator state.
+    p.tb_crc_part[crc_index] = share;
   }
   NRPHY_WG_TRACE_MARK(6);
 }
