@@ -59,7 +59,8 @@ enum {
   NRPHY_ERR_INVALID_PDU  = 1, /* pdsch_pdu_validator::is_valid() == false */
   NRPHY_ERR_ARGUMENT     = 2, /* size mismatch, null pointer, unsupported size */
   NRPHY_ERR_DEVICE       = 3, /* HIP runtime error (no GPU, launch failure) */
-  NRPHY_ERR_CAPACITY     = 4  /* batch exceeds the plan/context limits */
+  NRPHY_ERR_CAPACITY     = 4, /* batch exceeds the plan/context limits */
+  NRPHY_ERR_NOT_READY    = 5  /* nrphy_dl_slot_poll: the slot's IQ has not reached the host yet */
 };
 
 /* RE pattern: {prb_mask, re_mask, symbols} of R/include/srsran/phy/support/re_pattern.h:40-77.
@@ -758,6 +759,76 @@ int nrphy_dft_run(nrphy_ctx_t* ctx, uint32_t size, int inverse, uint32_t batch, 
                   void* stream);
 /* Host-span form of dft_processor::run for one transform (blocking). */
 int nrphy_dft_run_host(nrphy_ctx_t* ctx, uint32_t size, int inverse, const float* in, float* out);
+
+/* ---- seams A and C on ONE device-resident grid: the downlink slot pipeline ----------------------------------------
+ * What the reference does per slot -- the upper PHY's channel processors fill a resource grid
+ * (R/lib/phy/upper/downlink_processor_single_executor_impl.cpp:52-215: configure_resource_grid, process_pdcch / _pdsch /
+ * _ssb / _nzp_csi_rs, finish_processing_pdus -> send_resource_grid), the grid is handed to the lower PHY
+ * (pdxch_processor_request_handler::handle_request, R/lib/phy/lower/processors/downlink/pdxch/pdxch_processor_impl.cpp:
+ * 97-112) and the real-time thread asks for it one OFDM symbol at a time (pdxch_processor_baseband::process_symbol,
+ * pdxch_processor_impl.cpp:47-95, calling ofdm_symbol_modulator::modulate per port) -- with the grid staying in HBM
+ * from the first channel written to the last sample modulated: per slot the transport blocks go down and the IQ comes up,
+ * the grid crosses PCIe only if the host asks for it (nrphy_dl_slot_read_grid).
+ *
+ * A pool owns `depth` slots, each with a stream, a device grid, pinned staging for transport blocks + plan tables and a
+ * pinned IQ buffer.  Everything a slot is asked to do is enqueued on its stream in call order; no call allocates device
+ * memory or waits for the device unless it says so.  Calls on ONE slot are serialised by the library (a lock per slot);
+ * different slots may be driven from different threads.
+ *
+ *   nrphy_dl_slot_open      resource_grid::set_all_zero + a free slot: NRPHY_ERR_CAPACITY when all `depth` slots are open
+ *   nrphy_dl_slot_pdsch     seam A for n PDUs of the slot (one plan, one launch; may be called more than once per slot --
+ *                           pdsch_processor::process arrives PDU by PDU): the transport blocks are copied at the call
+ *   nrphy_dl_slot_pdcch / _ssb / _csi_rs / _put    the other grid writers, as nrphy_pdcch_process ... on the slot's grid
+ *   nrphy_dl_slot_load_grid a grid computed elsewhere (host span) replaces the slot's grid: seam C alone
+ *   nrphy_dl_slot_modulate  seam C, submitted at grid hand-over: every symbol of every port of the slot is modulated
+ *                           (nrphy_ofdm_run, or nrphy_ofdm_run_ci16 for a pool created with iq_format 1), ONE
+ *                           device-to-host copy brings the IQ into the slot's pinned buffer, then `done(user, status,
+ *                           slot_id)` runs on a thread of the HIP runtime (it must not call HIP or this library except
+ *                           nrphy_dl_slot_iq / _poll).  Once per open.
+ *   nrphy_dl_slot_poll      NRPHY_OK: the IQ is on the host; NRPHY_ERR_NOT_READY: not yet (or no modulate submitted);
+ *                           an error code: the slot's stream failed.  An atomic load: what process_symbol calls.
+ *   nrphy_dl_slot_wait      blocks until the modulate submitted for the slot has completed, returns its status
+ *   nrphy_dl_slot_iq        pinned host samples of `port`: nof_samples = nrphy_ofdm_slot_size(cfg, slot index) complex
+ *                           values (float32 pairs, or int16 pairs), symbols back to back, cyclic prefix first; valid from
+ *                           completion until the slot is closed.  Pointer arithmetic only.
+ *   nrphy_dl_slot_read_grid blocking: everything enqueued so far, then the grid [nof_ports][14][12 * bw_rb] cbf16 to the
+ *                           host (resource_grid::get_reader() on a device-mirrored grid)
+ *   nrphy_dl_slot_close     gives the slot back; waits for what it still has in flight
+ * Statuses: NRPHY_ERR_ARGUMENT for a slot id that is not open or a call out of order (modulate twice, a writer after
+ * modulate), NRPHY_ERR_INVALID_PDU as nrphy_pdsch_plan_create, NRPHY_ERR_CAPACITY when the slot's staging cannot take the
+ * transport blocks (max_tb_bytes is per slot, all PDSCH calls together). */
+typedef struct nrphy_dl_slots nrphy_dl_slots_t;
+typedef void (*nrphy_dl_slot_done_fn)(void* user, int status, uint32_t slot_id);
+typedef struct nrphy_dl_slots_cfg {
+  nrphy_ofdm_config_t ofdm;         /* the lower PHY's modulator configuration (pdxch_processor_factories.cpp:41-48) */
+  uint32_t            nof_ports;    /* grid ports = transmit ports */
+  uint32_t            depth;        /* slots that can be open at once, 1..64 (the reference's request pool holds 16) */
+  uint32_t            max_tb_bytes; /* transport-block bytes per slot, all PDUs together */
+  uint32_t            iq_format;    /* 0 = complex float32 (baseband_gateway_buffer), 1 = complex int16 after the amplitude controller */
+  nrphy_iq_wire_cfg_t wire;         /* iq_format 1 only */
+} nrphy_dl_slots_cfg_t;
+int nrphy_dl_slots_create(nrphy_ctx_t* ctx, const nrphy_dl_slots_cfg_t* cfg, nrphy_dl_slots_t** pool);
+int nrphy_dl_slots_destroy(nrphy_dl_slots_t* pool); /* waits for everything in flight, then frees */
+int nrphy_dl_slots_wait_free(nrphy_dl_slots_t* pool); /* blocks while all `depth` slots are open */
+int nrphy_dl_slot_open(nrphy_dl_slots_t* pool, uint32_t* slot_id);
+int nrphy_dl_slot_close(nrphy_dl_slots_t* pool, uint32_t slot_id);
+int nrphy_dl_slot_pdsch(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
+                        const uint8_t* const* tbs);
+int nrphy_dl_slot_put(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t n, const nrphy_grid_re_t* entries);
+int nrphy_dl_slot_load_grid(nrphy_dl_slots_t* pool, uint32_t slot_id, const void* grid);
+int nrphy_dl_slot_modulate(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t subframe_slot_index, nrphy_dl_slot_done_fn done,
+                           void* user);
+int nrphy_dl_slot_poll(nrphy_dl_slots_t* pool, uint32_t slot_id);
+int nrphy_dl_slot_wait(nrphy_dl_slots_t* pool, uint32_t slot_id);
+const void* nrphy_dl_slot_iq(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t port, uint32_t* nof_samples);
+int nrphy_dl_slot_read_grid(nrphy_dl_slots_t* pool, uint32_t slot_id, void* grid);
+/* For callers that keep more of the chain on the device: the slot's grid in HBM and the stream its work is ordered on. */
+void* nrphy_dl_slot_device_grid(nrphy_dl_slots_t* pool, uint32_t slot_id);
+void* nrphy_dl_slot_stream(nrphy_dl_slots_t* pool, uint32_t slot_id);
+int nrphy_dl_slot_pdcch(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t n, const nrphy_pdcch_pdu_t* pdus);
+int nrphy_dl_slot_ssb(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t n, const nrphy_ssb_pdu_t* pdus);
+int nrphy_dl_slot_csi_rs(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t n, const nrphy_csi_rs_cfg_t* cfgs);
+
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@ ERR_INVALID_PDU = 1
 ERR_ARGUMENT = 2
 ERR_DEVICE = 3
 ERR_CAPACITY = 4
+ERR_NOT_READY = 5
 
 TBS_LBRM_DEFAULT = 159749  # tbs_lbrm_default, include/srsran/ran/sch/sch_constants.h:47
 
@@ -255,6 +256,14 @@ class IqWireCfg(C.Structure):
     _fields_ = [("amplitude", AmplitudeCfg), ("ci16_scale", C.c_float)]
 
 
+class DlSlotsCfg(C.Structure):
+    """nrphy_dl_slots_cfg_t: the downlink slot pipeline (seams A and C on one device-resident grid)."""
+    # (_fields_ set below OfdmConfig)
+
+
+DL_SLOT_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_uint32)   # nrphy_dl_slot_done_fn
+
+
 class OfhCompressionCfg(C.Structure):
     """nrphy_ofh_compression_cfg_t (ru_compression_params + the compressor's iq_scaling)."""
     _fields_ = [("type", C.c_uint32), ("data_width", C.c_uint32), ("iq_scaling", C.c_float)]
@@ -269,6 +278,10 @@ class OfdmConfig(C.Structure):
         ("scale", C.c_float),
         ("center_freq_hz", C.c_double),
     ]
+
+
+DlSlotsCfg._fields_ = [("ofdm", OfdmConfig), ("nof_ports", C.c_uint32), ("depth", C.c_uint32), ("max_tb_bytes", C.c_uint32),
+                       ("iq_format", C.c_uint32), ("wire", IqWireCfg)]
 
 
 def prb_mask_words(prbs):
@@ -440,6 +453,24 @@ def declare(lib, prefix="nrphy_"):
     sig("pusch_decoder_sizes", i32, vp, P(PuschDecoderCfg), u32, P(u64), P(u64), P(u64), P(u32))
     sig("pusch_decoder_prepare", i32, vp, P(PuschDecoderCfg))
     sig("pusch_decode_batch", i32, vp, P(PuschDecoderCfg), u32, vp, u64, vp, vp, vp, vp, u32, vp, vp)
+    sig("dl_slots_create", i32, vp, P(DlSlotsCfg), P(vp))
+    sig("dl_slots_destroy", i32, vp)
+    sig("dl_slots_wait_free", i32, vp)
+    sig("dl_slot_open", i32, vp, P(u32))
+    sig("dl_slot_close", i32, vp, u32)
+    sig("dl_slot_pdsch", i32, vp, u32, u32, vp, vp)
+    sig("dl_slot_pdcch", i32, vp, u32, u32, P(PdcchPdu))
+    sig("dl_slot_ssb", i32, vp, u32, u32, P(SsbPdu))
+    sig("dl_slot_csi_rs", i32, vp, u32, u32, P(CsiRsCfg))
+    sig("dl_slot_put", i32, vp, u32, u32, P(GridRe))
+    sig("dl_slot_load_grid", i32, vp, u32, vp)
+    sig("dl_slot_modulate", i32, vp, u32, u32, vp, vp)
+    sig("dl_slot_poll", i32, vp, u32)
+    sig("dl_slot_wait", i32, vp, u32)
+    sig("dl_slot_iq", vp, vp, u32, u32, P(u32))
+    sig("dl_slot_read_grid", i32, vp, u32, vp)
+    sig("dl_slot_device_grid", vp, vp, u32)
+    sig("dl_slot_stream", vp, vp, u32)
     sig("pusch_decode_codeblock_host", i32, vp, P(LdpcRateDematcherCfg), u32, u32, C.c_float, vp, vp, i32, u8p, P(u32))
     return lib
 
@@ -468,4 +499,8 @@ ABI_SYMBOLS = [
     "nrphy_amplitude_control", "nrphy_amplitude_metrics", "nrphy_amplitude_control_host", "nrphy_iq_convert_ci16",
     "nrphy_iq_convert_ci16_host", "nrphy_ofdm_run_ci16", "nrphy_ofh_compressed_prb_bytes", "nrphy_ofh_compress",
     "nrphy_ofh_compress_host",
+    "nrphy_dl_slots_create", "nrphy_dl_slots_destroy", "nrphy_dl_slots_wait_free", "nrphy_dl_slot_open", "nrphy_dl_slot_close",
+    "nrphy_dl_slot_pdsch", "nrphy_dl_slot_pdcch", "nrphy_dl_slot_ssb", "nrphy_dl_slot_csi_rs", "nrphy_dl_slot_put",
+    "nrphy_dl_slot_load_grid", "nrphy_dl_slot_modulate", "nrphy_dl_slot_poll", "nrphy_dl_slot_wait", "nrphy_dl_slot_iq",
+    "nrphy_dl_slot_read_grid", "nrphy_dl_slot_device_grid", "nrphy_dl_slot_stream",
 ]

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmi355nrphy.so")
-SOURCES = ["nrphy_host.cpp", "dl_control_host.cpp", "pdsch_async.cpp", "pdsch_kernels.hip", "ofdm_kernels.hip", "ldpc_decoder.hip",
+SOURCES = ["nrphy_host.cpp", "dl_control_host.cpp", "pdsch_async.cpp", "dl_slot_async.cpp", "pdsch_kernels.hip", "ofdm_kernels.hip", "ldpc_decoder.hip",
            "ldpc_dematcher.hip", "pusch_decoder.hip", "csi_rs_kernels.hip", "dl_control_kernels.hip", "lower_phy_kernels.hip", "demod_kernels.hip"]
 HEADERS = ["nrphy_internal.h", "nrphy_host_internal.h", "nrphy_trace.h", "bits_device.h", "ldpc_device.h", "nr_ldpc_bg.inc", "nr_polar_tables.inc",
            os.path.join(ROOT, "include", "mi355_nrphy.h")]

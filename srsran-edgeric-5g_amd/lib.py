@@ -492,6 +492,108 @@ class PdschAsyncQueue:
             pass
 
 
+class DlSlotPool:
+    """nrphy_dl_slots: the downlink slot pipeline -- every channel of a slot written into ONE device-resident grid, the
+    whole slot modulated at grid hand-over, IQ served from pinned host memory (pdxch_processor_impl.cpp:47-112)."""
+
+    def __init__(self, ctx, ofdm_cfg, nof_ports, depth, max_tb_bytes, wire_cfg=None):
+        self.ctx, self.cfg, self.nof_ports = ctx, ofdm_cfg, nof_ports
+        self.nof_subc = 12 * ofdm_cfg.bw_rb
+        c = abi.DlSlotsCfg()
+        c.ofdm, c.nof_ports, c.depth, c.max_tb_bytes = ofdm_cfg, nof_ports, depth, max_tb_bytes
+        c.iq_format = 0 if wire_cfg is None else 1
+        if wire_cfg is not None:
+            c.wire = wire_cfg
+        self.wire = wire_cfg is not None
+        h = C.c_void_p()
+        _check(ctx.lib.nrphy_dl_slots_create(ctx.handle, C.byref(c), C.byref(h)), "nrphy_dl_slots_create")
+        self.handle = h
+        self._keep = {}
+
+    def open(self):
+        """A free slot with an all-zero grid, or None when all `depth` slots are open."""
+        sid = C.c_uint32()
+        rc = self.ctx.lib.nrphy_dl_slot_open(self.handle, C.byref(sid))
+        if rc == abi.ERR_CAPACITY:
+            return None
+        _check(rc, "nrphy_dl_slot_open")
+        return sid.value
+
+    def close(self, sid):
+        _check(self.ctx.lib.nrphy_dl_slot_close(self.handle, sid), "nrphy_dl_slot_close")
+        self._keep.pop(sid, None)
+
+    def wait_free(self):
+        _check(self.ctx.lib.nrphy_dl_slots_wait_free(self.handle), "nrphy_dl_slots_wait_free")
+
+    def pdsch(self, sid, pdus, tbs):
+        n = len(pdus)
+        arr = (abi.PdschPdu * n)(*pdus)
+        keep = [np.ascontiguousarray(t, dtype=np.uint8) for t in tbs]
+        ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in keep])
+        return self.ctx.lib.nrphy_dl_slot_pdsch(self.handle, sid, n, arr, ptrs)
+
+    def pdcch(self, sid, pdus):
+        arr = (abi.PdcchPdu * len(pdus))(*pdus)
+        _check(self.ctx.lib.nrphy_dl_slot_pdcch(self.handle, sid, len(pdus), arr), "nrphy_dl_slot_pdcch")
+
+    def ssb(self, sid, pdus):
+        arr = (abi.SsbPdu * len(pdus))(*pdus)
+        _check(self.ctx.lib.nrphy_dl_slot_ssb(self.handle, sid, len(pdus), arr), "nrphy_dl_slot_ssb")
+
+    def csi_rs(self, sid, cfgs):
+        arr = (abi.CsiRsCfg * len(cfgs))(*cfgs)
+        _check(self.ctx.lib.nrphy_dl_slot_csi_rs(self.handle, sid, len(cfgs), arr), "nrphy_dl_slot_csi_rs")
+
+    def put(self, sid, entries):
+        arr = (abi.GridRe * len(entries))(*entries)
+        _check(self.ctx.lib.nrphy_dl_slot_put(self.handle, sid, len(entries), arr), "nrphy_dl_slot_put")
+
+    def load_grid(self, sid, grid):
+        grid = np.ascontiguousarray(grid, dtype=np.uint16)
+        assert grid.size == self.nof_ports * 14 * self.nof_subc * 2
+        _check(self.ctx.lib.nrphy_dl_slot_load_grid(self.handle, sid, grid.ctypes.data), "nrphy_dl_slot_load_grid")
+
+    def modulate(self, sid, subframe_slot_index, on_done=None):
+        """on_done(status, slot_id) runs on a HIP runtime thread when the slot's IQ is in pinned host memory."""
+        cb = None
+        if on_done is not None:
+            cb = abi.DL_SLOT_DONE_FN(lambda user, status, slot_id: on_done(status, slot_id))
+            self._keep[sid] = cb
+        return self.ctx.lib.nrphy_dl_slot_modulate(self.handle, sid, subframe_slot_index, cb, None)
+
+    def poll(self, sid):
+        return self.ctx.lib.nrphy_dl_slot_poll(self.handle, sid)
+
+    def wait(self, sid):
+        return self.ctx.lib.nrphy_dl_slot_wait(self.handle, sid)
+
+    def iq(self, sid, port):
+        """A copy of the slot's samples of `port`: complex64, or int16 pairs [n][2] for a wire-format pool."""
+        n = C.c_uint32()
+        ptr = self.ctx.lib.nrphy_dl_slot_iq(self.handle, sid, port, C.byref(n))
+        assert ptr
+        if self.wire:
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(n.value, 2)).copy()
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n.value, 2)).copy().view(np.complex64).reshape(-1)
+
+    def read_grid(self, sid):
+        grid = np.zeros((self.nof_ports, 14, self.nof_subc, 2), dtype=np.uint16)
+        _check(self.ctx.lib.nrphy_dl_slot_read_grid(self.handle, sid, grid.ctypes.data), "nrphy_dl_slot_read_grid")
+        return grid
+
+    def destroy(self):
+        if self.handle:
+            self.ctx.lib.nrphy_dl_slots_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class OfdmPlan:
     """nrphy_ofdm_plan: ofdm_modulator_configuration + port count."""
 

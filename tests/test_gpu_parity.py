@@ -1497,6 +1497,174 @@ def test_whole_downlink_slot_in_one_device_grid(gpu_ctx, oracle):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The downlink slot pipeline (nrphy_dl_slots_*): seams A and C on one device-resident grid, the slot modulated at grid
+# hand-over (pdxch_processor_impl.cpp:97-112), IQ served from pinned memory (process_symbol, :47-95)
+# ---------------------------------------------------------------------------------------------------------------------
+def _slot_writers(rng, nof_rb):
+    """The PDUs of test_whole_downlink_slot_in_one_device_grid: PDCCH x 2, PDSCH, SS/PBCH block, CSI-RS."""
+    w2 = cases.codebook("two_layer_two_ports_0")
+    tbs = lib.tbs_calculate(12, 12, 0, 4, 490, 2, 30)
+    pdsch = abi.make_pdu(bwp_size_rb=nof_rb, qm=4, rnti=17, n_id=5, dmrs_symbols=(2, 11), prb_start=22, prb_count=30,
+                         start_symbol=2, nof_symbols=12, precoding=w2, tb_size_bytes=tbs // 8, slot_index=0)
+    tb = cases.random_tb(rng, pdsch)
+    pdcch = [abi.make_pdcch(payload=rng.integers(0, 2, 41, dtype=np.uint8), rnti=17, cce_index=0, aggregation_level=4, duration=2,
+                            frequency_resources=tuple(range(8)), mapping="interleaved", reg_bundle_size=6, interleaver_size=2,
+                            shift_index=3, n_id_dmrs=5, n_id_data=5, n_rnti=17, bwp_size_rb=nof_rb,
+                            precoding=np.array([[1.0, 1.0j]], np.complex64) / np.sqrt(2)),
+             abi.make_pdcch(payload=rng.integers(0, 2, 39, dtype=np.uint8), rnti=0xFFFF, cce_index=4, aggregation_level=4, duration=2,
+                            frequency_resources=tuple(range(8)), mapping="interleaved", reg_bundle_size=6, interleaver_size=2,
+                            shift_index=3, n_id_dmrs=5, n_id_data=5, bwp_size_rb=nof_rb)]
+    ssb = abi.make_ssb(pattern_case="A", ssb_idx=0, L_max=4, phys_cell_id=5, payload=rng.integers(0, 2, 32, dtype=np.uint8),
+                       sfn=100, ports=(0,))
+    csi = abi.make_csi_rs(row=3, start_rb=0, nof_rb=nof_rb, k0=4, l0=13, density="one", scrambling_id=5,
+                          precoding=np.eye(2, dtype=np.complex64)[None])
+    return pdsch, tb, pdcch, ssb, csi
+
+
+def _merge(want, part):
+    mask = part.view(np.uint32) != 0
+    want.view(np.uint32)[mask] = part.view(np.uint32)[mask]
+    return want
+
+
+@pytest.mark.parametrize("first", ["pdcch", "pdsch"])
+def test_dl_slot_pipeline_whole_slot_tb_to_iq(gpu_ctx, oracle, first):
+    """Every grid writer of a slot through nrphy_dl_slot_* into the slot's device grid, the grid handed over with
+    nrphy_dl_slot_modulate, IQ read from the slot's pinned buffer: grid bit-exact (read back only to check), IQ <= 1e-5, the
+    completion handler called once from another thread, poll / wait / iq as process_symbol uses them.  `first` = which writer
+    meets the still undefined grid (a PDSCH run clears what it does not map itself, the others need the memset)."""
+    import threading
+    rng = np.random.default_rng(2718)
+    nof_ports, nof_rb = 2, 52
+    nof_subc = 12 * nof_rb
+    pdsch, tb, pdcch, ssb, csi = _slot_writers(rng, nof_rb)
+    ocfg = abi.OfdmConfig(0, nof_rb, 1024, 0, 1.0 / np.sqrt(1024), 2.4e9)
+    pool = lib.DlSlotPool(gpu_ctx, ocfg, nof_ports, 2, 65536)
+    want = np.zeros((nof_ports, 14, nof_subc, 2), np.uint16)
+    sid = pool.open()
+    assert sid is not None and pool.poll(sid) == abi.ERR_NOT_READY
+    if first == "pdcch":
+        pool.pdcch(sid, pdcch)
+        for p in pdcch:
+            want = oracle.pdcch_process(p, want)
+    assert pool.pdsch(sid, [pdsch], [tb]) == 0
+    want = _merge(want, oracle.pdsch_process(pdsch, tb, nof_ports, nof_subc))
+    if first != "pdcch":
+        pool.pdcch(sid, pdcch[:1])
+        pool.pdcch(sid, pdcch[1:])
+        for p in pdcch:
+            want = oracle.pdcch_process(p, want)
+    pool.ssb(sid, [ssb])
+    want = oracle.ssb_process(ssb, want)
+    pool.csi_rs(sid, [csi])
+    want = oracle.csi_rs_map(csi, want)
+    # a channel the library does not generate, merged from the host as sparse resource elements
+    entries = [abi.GridRe(1, 0, 600 + k, 0x3F800000 + k) for k in range(7)]
+    pool.put(sid, entries)
+    for e in entries:
+        want.view(np.uint32).reshape(nof_ports, 14, nof_subc)[e.port, e.symbol, e.subc] = e.value
+    calls, me = [], threading.get_ident()
+    assert pool.modulate(sid, 0, lambda status, slot_id: calls.append((status, slot_id, threading.get_ident()))) == 0
+    assert pool.modulate(sid, 0) == abi.ERR_ARGUMENT            # once per open
+    assert pool.pdsch(sid, [pdsch], [tb]) == abi.ERR_ARGUMENT   # the grid has been handed over
+    assert pool.wait(sid) == 0 and pool.poll(sid) == 0
+    assert len(calls) == 1 and calls[0][:2] == (0, sid) and calls[0][2] != me
+    want_iq = oracle.ofdm_slot(ocfg, want, 0)
+    for port in range(nof_ports):
+        assert rel_err(pool.iq(sid, port), want_iq[port]) < 1e-5
+    assert np.array_equal(pool.read_grid(sid), want)
+    pool.close(sid)
+    assert pool.poll(sid) == abi.ERR_ARGUMENT
+    pool.destroy()
+
+
+def test_dl_slot_pipeline_slots_in_flight_and_host_grids(gpu_ctx, oracle):
+    """Several slots open at once, BASELINE config 3's PDU in each with another transport block, slot index and RNTI; PDSCH
+    arriving PDU by PDU in two calls per slot; capacity statuses; a slot reused after close starts from zeros; and seam C
+    alone: a grid computed elsewhere loaded from a host span (nrphy_dl_slot_load_grid) and an untouched slot (silence)."""
+    rng = np.random.default_rng(4242)
+    pdu0, nof_ports, nof_subc, ocfg = cases.baseline_config(3)
+    depth = 3
+    # two PDUs per slot: the upper and the lower half of config 3's allocation, submitted in separate calls
+    def half(lo, count, rnti, slot_index):
+        tbs = cases.tbs(12, 36, 8, 948, 4, count)
+        return abi.make_pdu(bwp_size_rb=273, qm=8, rnti=rnti, n_id=7, dmrs_symbols=(2, 7, 11), prb_start=lo, prb_count=count,
+                            start_symbol=0, nof_symbols=12, precoding=cases.codebook("four_layer_four_ports_0_0"),
+                            tb_size_bytes=tbs // 8, slot_index=slot_index, nof_cdm_groups_without_data=2)
+    jobs, ids = [], []
+    for k in range(depth):
+        a, b = half(0, 130, 100 + k, k), half(130, 140, 200 + k, k)
+        jobs.append(((a, cases.random_tb(rng, a)), (b, cases.random_tb(rng, b))))
+    pool = lib.DlSlotPool(gpu_ctx, ocfg, nof_ports, depth, jobs[0][0][0].tb_size_bytes + jobs[0][1][0].tb_size_bytes + 16)
+    for k in range(depth):
+        sid = pool.open()
+        assert sid is not None
+        ids.append(sid)
+    assert pool.open() is None                                  # all `depth` slots are open
+    for k, sid in enumerate(ids):                               # interleaved across the slots, as concurrent slots would be
+        assert pool.pdsch(sid, [jobs[k][0][0]], [jobs[k][0][1]]) == 0
+    for k, sid in enumerate(ids):
+        assert pool.pdsch(sid, [jobs[k][1][0]], [jobs[k][1][1]]) == 0
+        assert pool.modulate(sid, k % 2) == 0
+    big = half(0, 270, 9, 0)
+    for k, sid in enumerate(ids):
+        assert pool.wait(sid) == 0
+        want = np.zeros((nof_ports, 14, nof_subc, 2), np.uint16)
+        for pdu, tb in jobs[k]:
+            want = _merge(want, oracle.pdsch_process(pdu, tb, nof_ports, nof_subc))
+        assert np.array_equal(pool.read_grid(sid), want), k
+        want_iq = oracle.ofdm_slot(ocfg, want, k % 2)
+        for port in range(nof_ports):
+            got = pool.iq(sid, port)
+            assert got.size == lib.slot_size(ocfg, k % 2) and rel_err(got, want_iq[port]) < 1e-5
+        pool.close(sid)
+    # reuse: nothing of the previous slot is left; more transport-block bytes than the slot holds are refused
+    sid = pool.open()
+    assert pool.pdsch(sid, [jobs[0][0][0]], [jobs[0][0][1]]) == 0
+    assert pool.pdsch(sid, [big], [cases.random_tb(rng, big)]) == abi.ERR_CAPACITY
+    want = oracle.pdsch_process(jobs[0][0][0], jobs[0][0][1], nof_ports, nof_subc)
+    assert np.array_equal(pool.read_grid(sid), want)
+    pool.close(sid)
+    # seam C alone: a host grid, and an untouched slot
+    grid = ((rng.standard_normal((nof_ports, 14, nof_subc, 2)) * 0.5).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    a, b = pool.open(), pool.open()
+    pool.load_grid(a, grid)
+    assert pool.modulate(a, 1) == 0 and pool.modulate(b, 0) == 0
+    assert pool.wait(a) == 0 and pool.wait(b) == 0
+    want_iq = oracle.ofdm_slot(ocfg, grid, 1)
+    for port in range(nof_ports):
+        assert rel_err(pool.iq(a, port), want_iq[port]) < 1e-5
+        assert not pool.iq(b, port).any()
+    pool.close(a)
+    pool.close(b)
+    pool.destroy()
+
+
+def test_dl_slot_pipeline_wire_format(gpu_ctx, oracle):
+    """A pool created with iq_format 1: the slot leaves the device as complex int16 after the amplitude controller
+    (nrphy_ofdm_run_ci16) -- half the bytes over PCIe; within one LSB of the oracle's chain."""
+    rng = np.random.default_rng(515)
+    nof_ports, nof_rb = 2, 106
+    ocfg = abi.OfdmConfig(0, nof_rb, 2048, 0, 1.0 / np.sqrt(2048), 3.5e9)
+    wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -10.0, 1.0, -6.0), 32767.0)
+    pool = lib.DlSlotPool(gpu_ctx, ocfg, nof_ports, 1, 65536, wire_cfg=wire)
+    pdu, _, nof_subc, _ = cases.baseline_config(2)
+    tb = cases.random_tb(rng, pdu)
+    sid = pool.open()
+    assert pool.pdsch(sid, [pdu], [tb]) == 0 and pool.modulate(sid, 0) == 0 and pool.wait(sid) == 0
+    grid = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc)
+    ref_iq = oracle.ofdm_slot(ocfg, grid, 0)
+    for port in range(nof_ports):
+        y, _ = oracle.amplitude_control(wire.amplitude, ref_iq[port])
+        want = oracle.iq_convert_ci16(y, wire.ci16_scale).reshape(-1, 2)
+        got = pool.iq(sid, port)
+        assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+        assert np.mean(got == want) > 0.999
+    pool.close(sid)
+    pool.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # Lower-PHY tail (SURVEY.md section 8f-3): amplitude controller, radio sample format, fronthaul compression
 # ---------------------------------------------------------------------------------------------------------------------
 def test_amplitude_controller_and_ci16_vs_oracle(gpu_ctx, oracle):
