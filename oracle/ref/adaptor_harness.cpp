@@ -13,6 +13,7 @@
 
 #include "lib/phy/generic_functions/dft_processor_generic_impl.h"
 #include "lib/phy/lower/modulation/ofdm_modulator_impl.h"
+#include "lib/phy/lower/processors/downlink/pdxch/pdxch_processor_impl.h"
 #include "lib/phy/support/resource_grid_impl.h"
 #include "lib/phy/upper/channel_coding/crc_calculator_lut_impl.h"
 #include "lib/phy/upper/channel_processors/pdsch_encoder_hw_impl.h"
@@ -27,6 +28,8 @@
 
 #include "../nrphy_oracle.h"
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -61,6 +64,24 @@ struct nrphy_pdsch_async {
   uint32_t                 in_flight = 0;
   std::vector<std::thread> threads;
 };
+
+// The slot pipeline: per slot a host grid the oracle's writers fill and a worker thread that "modulates" it after a
+// short sleep, so that a caller that does not wait sees NRPHY_ERR_NOT_READY first, as on the device.
+struct nrphy_dl_slots {
+  struct slot {
+    std::atomic<int>      state{0}; // 0 free, 1 open, 2 modulating, 3 done
+    std::vector<uint16_t> grid;
+    std::vector<float>    iq;
+    uint32_t              slot_index = 0;
+    std::thread           worker;
+  };
+  nrphy_dl_slots_cfg_t cfg;
+  uint32_t             nof_subc = 0, slot_stride = 0;
+  std::vector<slot>    slots;
+  std::mutex           mutex;
+  std::atomic<int>     nof_modulate{0}, nof_load_grid{0}, nof_read_grid{0}, nof_put{0};
+};
+static nrphy_dl_slots* g_last_pool = nullptr; // the tests look at the mock's call counters
 
 extern "C" {
 
@@ -276,6 +297,191 @@ int nrphy_ofh_compress_host(nrphy_ctx_t*, const nrphy_ofh_compression_cfg_t* cfg
   return oracle_ofh_compress(cfg, static_cast<const uint16_t*>(prbs), nof_prb, out) > 0 ? NRPHY_OK : NRPHY_ERR_ARGUMENT;
 }
 
+
+int nrphy_dl_slots_create(nrphy_ctx_t*, const nrphy_dl_slots_cfg_t* cfg, nrphy_dl_slots_t** out)
+{
+  nrphy_dl_slots* p = new nrphy_dl_slots;
+  p->cfg            = *cfg;
+  p->nof_subc       = 12 * cfg->ofdm.bw_rb;
+  p->slot_stride    = oracle_ofdm_slot_size(&cfg->ofdm, 0);
+  p->slots          = std::vector<nrphy_dl_slots::slot>(cfg->depth);
+  for (auto& s : p->slots) {
+    s.grid.assign((size_t)cfg->nof_ports * 14 * p->nof_subc * 2, 0);
+    s.iq.assign((size_t)cfg->nof_ports * p->slot_stride * 2, 0.f);
+  }
+  g_last_pool = p;
+  *out        = p;
+  return NRPHY_OK;
+}
+int nrphy_dl_slots_destroy(nrphy_dl_slots_t* p)
+{
+  if (p != nullptr) {
+    for (auto& s : p->slots) {
+      if (s.worker.joinable()) {
+        s.worker.join();
+      }
+    }
+    if (g_last_pool == p) {
+      g_last_pool = nullptr;
+    }
+    delete p;
+  }
+  return NRPHY_OK;
+}
+int nrphy_dl_slot_open(nrphy_dl_slots_t* p, uint32_t* id)
+{
+  std::lock_guard<std::mutex> lock(p->mutex);
+  for (uint32_t i = 0; i != p->slots.size(); ++i) {
+    if (p->slots[i].state.load() == 0) {
+      std::fill(p->slots[i].grid.begin(), p->slots[i].grid.end(), 0);
+      p->slots[i].state.store(1);
+      *id = i;
+      return NRPHY_OK;
+    }
+  }
+  return NRPHY_ERR_CAPACITY;
+}
+int nrphy_dl_slot_close(nrphy_dl_slots_t* p, uint32_t id)
+{
+  if (id >= p->slots.size() || p->slots[id].state.load() == 0) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  if (p->slots[id].worker.joinable()) {
+    p->slots[id].worker.join();
+  }
+  std::lock_guard<std::mutex> lock(p->mutex);
+  p->slots[id].state.store(0);
+  return NRPHY_OK;
+}
+static bool mock_slot_open(nrphy_dl_slots_t* p, uint32_t id)
+{
+  return id < p->slots.size() && p->slots[id].state.load() == 1;
+}
+int nrphy_dl_slot_pdsch(nrphy_dl_slots_t* p, uint32_t id, uint32_t n, const nrphy_pdsch_pdu_t* pdus, const uint8_t* const* tbs)
+{
+  if (!mock_slot_open(p, id)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  for (uint32_t i = 0; i != n; ++i) {
+    int rc = oracle_pdsch_process(&pdus[i], tbs[i], p->slots[id].grid.data(), p->cfg.nof_ports, p->nof_subc, nullptr, nullptr);
+    if (rc != NRPHY_OK) {
+      return rc;
+    }
+  }
+  return NRPHY_OK;
+}
+int nrphy_dl_slot_pdcch(nrphy_dl_slots_t* p, uint32_t id, uint32_t n, const nrphy_pdcch_pdu_t* pdus)
+{
+  if (!mock_slot_open(p, id)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  for (uint32_t i = 0; i != n; ++i) {
+    int rc = oracle_pdcch_process(&pdus[i], p->slots[id].grid.data(), p->cfg.nof_ports, p->nof_subc);
+    if (rc != NRPHY_OK) {
+      return rc;
+    }
+  }
+  return NRPHY_OK;
+}
+int nrphy_dl_slot_ssb(nrphy_dl_slots_t* p, uint32_t id, uint32_t n, const nrphy_ssb_pdu_t* pdus)
+{
+  if (!mock_slot_open(p, id)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  for (uint32_t i = 0; i != n; ++i) {
+    int rc = oracle_ssb_process(&pdus[i], p->slots[id].grid.data(), p->cfg.nof_ports, p->nof_subc);
+    if (rc != NRPHY_OK) {
+      return rc;
+    }
+  }
+  return NRPHY_OK;
+}
+int nrphy_dl_slot_csi_rs(nrphy_dl_slots_t* p, uint32_t id, uint32_t n, const nrphy_csi_rs_cfg_t* cfgs)
+{
+  if (!mock_slot_open(p, id)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  for (uint32_t i = 0; i != n; ++i) {
+    int rc = oracle_csi_rs_map(&cfgs[i], p->slots[id].grid.data(), p->cfg.nof_ports, p->nof_subc);
+    if (rc != NRPHY_OK) {
+      return rc;
+    }
+  }
+  return NRPHY_OK;
+}
+int nrphy_dl_slot_put(nrphy_dl_slots_t* p, uint32_t id, uint32_t n, const nrphy_grid_re_t* e)
+{
+  if (!mock_slot_open(p, id)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  ++p->nof_put;
+  uint32_t* g = reinterpret_cast<uint32_t*>(p->slots[id].grid.data());
+  for (uint32_t i = 0; i != n; ++i) {
+    if (e[i].port >= p->cfg.nof_ports || e[i].symbol >= 14 || e[i].subc >= p->nof_subc) {
+      return NRPHY_ERR_ARGUMENT;
+    }
+    g[((size_t)e[i].port * 14 + e[i].symbol) * p->nof_subc + e[i].subc] = e[i].value;
+  }
+  return NRPHY_OK;
+}
+int nrphy_dl_slot_load_grid(nrphy_dl_slots_t* p, uint32_t id, const void* grid)
+{
+  if (!mock_slot_open(p, id)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  ++p->nof_load_grid;
+  std::memcpy(p->slots[id].grid.data(), grid, p->slots[id].grid.size() * sizeof(uint16_t));
+  return NRPHY_OK;
+}
+int nrphy_dl_slot_modulate(nrphy_dl_slots_t* p, uint32_t id, uint32_t slot_index, nrphy_dl_slot_done_fn done, void* user)
+{
+  if (!mock_slot_open(p, id)) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  ++p->nof_modulate;
+  nrphy_dl_slots::slot& s = p->slots[id];
+  s.slot_index            = slot_index;
+  s.state.store(2);
+  s.worker = std::thread([p, &s, id, slot_index, done, user] {
+    std::this_thread::sleep_for(std::chrono::milliseconds(3));
+    const uint32_t     size = oracle_ofdm_slot_size(&p->cfg.ofdm, slot_index);
+    std::vector<float> iq((size_t)p->cfg.nof_ports * size * 2);
+    oracle_ofdm_modulate_slot(&p->cfg.ofdm, s.grid.data(), p->cfg.nof_ports, slot_index, iq.data());
+    for (uint32_t port = 0; port != p->cfg.nof_ports; ++port) { // [port][slot_stride] like the device buffer
+      std::memcpy(&s.iq[(size_t)port * p->slot_stride * 2], &iq[(size_t)port * size * 2], (size_t)size * 2 * sizeof(float));
+    }
+    s.state.store(3);
+    if (done != nullptr) {
+      done(user, NRPHY_OK, id);
+    }
+  });
+  return NRPHY_OK;
+}
+int nrphy_dl_slot_poll(nrphy_dl_slots_t* p, uint32_t id)
+{
+  if (id >= p->slots.size()) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  const int st = p->slots[id].state.load();
+  return st == 3 ? NRPHY_OK : st == 0 ? NRPHY_ERR_ARGUMENT : NRPHY_ERR_NOT_READY;
+}
+const void* nrphy_dl_slot_iq(nrphy_dl_slots_t* p, uint32_t id, uint32_t port, uint32_t* n)
+{
+  if (n != nullptr) {
+    *n = oracle_ofdm_slot_size(&p->cfg.ofdm, p->slots[id].slot_index);
+  }
+  return &p->slots[id].iq[(size_t)port * p->slot_stride * 2];
+}
+int nrphy_dl_slot_read_grid(nrphy_dl_slots_t* p, uint32_t id, void* grid)
+{
+  if (id >= p->slots.size() || p->slots[id].state.load() == 0) {
+    return NRPHY_ERR_ARGUMENT;
+  }
+  ++p->nof_read_grid;
+  std::memcpy(grid, p->slots[id].grid.data(), p->slots[id].grid.size() * sizeof(uint16_t));
+  return NRPHY_OK;
+}
+
 } // extern "C"
 
 // ====================================================================================================================
@@ -467,9 +673,7 @@ int adaptor_test_ofdm(const nrphy_ofdm_config_t* c, const uint16_t* grid_raw, un
   return (int)slot_size;
 }
 
-// nzp_csi_rs_generator_adaptor against nzp_csi_rs_generator_impl, both ways into the grid.
-int adaptor_test_csi_rs(const nrphy_csi_rs_cfg_t* c, unsigned nof_ports, unsigned nof_subc, int with_writer_access, const uint16_t* grid_init,
-                        uint16_t* grid_adaptor, uint16_t* grid_ref)
+static nzp_csi_rs_generator::config_t make_csi_rs_config(const nrphy_csi_rs_cfg_t* c)
 {
   nzp_csi_rs_generator::config_t cfg;
   cfg.slot                     = slot_point(4, 0, c->slot_index);
@@ -493,6 +697,14 @@ int adaptor_test_csi_rs(const nrphy_csi_rs_cfg_t* c, unsigned nof_ports, unsigne
       cfg.precoding.set_coefficient(cf_t(w[0], w[1]), l, p, 0);
     }
   }
+  return cfg;
+}
+
+// nzp_csi_rs_generator_adaptor against nzp_csi_rs_generator_impl, both ways into the grid.
+int adaptor_test_csi_rs(const nrphy_csi_rs_cfg_t* c, unsigned nof_ports, unsigned nof_subc, int with_writer_access, const uint16_t* grid_init,
+                        uint16_t* grid_adaptor, uint16_t* grid_ref)
+{
+  nzp_csi_rs_generator::config_t cfg = make_csi_rs_config(c);
   std::shared_ptr<mi355::context>     ctx = std::make_shared<mi355::context>(0);
   mi355::nzp_csi_rs_generator_adaptor adaptor(ctx, nof_ports, nof_subc);
   std::unique_ptr<resource_grid>      ga = make_grid(nof_ports, nof_subc, with_writer_access != 0), gr = make_grid(nof_ports, nof_subc, false);
@@ -722,6 +934,199 @@ int adaptor_test_fapi(unsigned n, const int* rows, const uint8_t* const* tbs, co
   store_grid(grid_ref, *g_ref, nof_ports, nof_subc);
   store_grid(grid_adaptor, *g_ad, nof_ports, nof_subc);
   return result;
+}
+
+
+namespace {
+
+// The reference's grids for device_resource_grid_factory's host layers.
+class reference_grid_factory : public resource_grid_factory
+{
+public:
+  std::unique_ptr<resource_grid> create(unsigned nof_ports, unsigned nof_symbols, unsigned nof_subc) override
+  {
+    return std::make_unique<resource_grid_impl>(nof_ports, nof_symbols, nof_subc, ref_make_precoder(1));
+  }
+};
+
+class late_counter : public pdxch_processor_notifier
+{
+public:
+  void             on_pdxch_request_late(const resource_grid_context&) override { ++count; }
+  std::atomic<int> count{0};
+};
+
+} // namespace
+
+// The downlink slot pipeline end to end on the reference's own objects: per slot a PDCCH, a PDSCH, (slot 0) an SS/PBCH
+// block and a CSI-RS through the adaptors of this repository into a grid of device_resource_grid_factory (mirrored != 0)
+// or a plain grid of the reference, plus a few resource elements written through the grid's own writer (a channel the
+// library does not generate); the grid handed to pdxch_processor_adaptor::handle_request; then the lower PHY's loop --
+// process_symbol for every symbol of every slot, as downlink_processor_baseband_impl::process_new_symbol calls it -- next
+// to the reference's pdxch_processor_impl + ofdm_symbol_modulator_impl fed by the reference's own processors.
+//   settle_ms: how long to wait between the requests and the symbol loop (0: the first symbol is asked for at once, the
+//              mock's modulation takes 3 ms -- the late path unless max_wait_us covers it).
+//   info[0..1] late notifications (adaptor, reference), info[2..3] process_symbol calls that returned true (adaptor,
+//   reference), info[4] longest adaptor process_symbol call in nanoseconds, info[5] PDSCH notifications received
+//   synchronously (before process() returned), info[6..9] the mock's modulate / load_grid / read_grid / put calls.
+int adaptor_test_dl_pipeline(unsigned                   n_slots,
+                             const nrphy_ofdm_config_t* c,
+                             unsigned                   nof_ports,
+                             const nrphy_pdsch_pdu_t*   pdsch,
+                             const uint8_t* const*      tbs,
+                             const nrphy_pdcch_pdu_t*   pdcch,
+                             const nrphy_ssb_pdu_t*     ssb,
+                             const nrphy_csi_rs_cfg_t*  csi,
+                             int                        mirrored,
+                             unsigned                   max_wait_us,
+                             unsigned                   settle_ms,
+                             uint16_t*                  grid_adaptor,
+                             uint16_t*                  grid_ref,
+                             float*                     iq_adaptor,
+                             float*                     iq_ref,
+                             int*                       info)
+{
+  const unsigned nof_subc = 12 * c->bw_rb;
+  const size_t   words    = (size_t)nof_ports * 14 * nof_subc * 2;
+  std::shared_ptr<mi355::context>      ctx  = std::make_shared<mi355::context>(0);
+  std::shared_ptr<mi355::dl_slot_pool> pool = std::make_shared<mi355::dl_slot_pool>(ctx, *c, nof_ports, n_slots + 1, 200000);
+  mi355::device_resource_grid_factory  grid_factory(pool, std::make_shared<reference_grid_factory>());
+  mi355::pdxch_processor_factory_adaptor pdxch_factory(pool, max_wait_us);
+  pdxch_processor_configuration          pc;
+  pc.cp             = c->cp ? cyclic_prefix::EXTENDED : cyclic_prefix::NORMAL;
+  pc.scs            = to_subcarrier_spacing(c->numerology);
+  pc.srate          = sampling_rate::from_kHz(15U * (1U << c->numerology) * c->dft_size);
+  pc.bandwidth_rb   = c->bw_rb;
+  pc.center_freq_Hz = c->center_freq_hz;
+  pc.nof_tx_ports   = nof_ports;
+  std::unique_ptr<pdxch_processor> adaptor = pdxch_factory.create(pc);
+  // the reference's processor over its own modulator (pdxch_processor_factories.cpp:38-58)
+  ofdm_modulator_configuration mod_cfg;
+  mod_cfg.numerology     = c->numerology;
+  mod_cfg.bw_rb          = c->bw_rb;
+  mod_cfg.dft_size       = c->dft_size;
+  mod_cfg.cp             = pc.cp;
+  mod_cfg.scale          = c->scale;
+  mod_cfg.center_freq_hz = c->center_freq_hz;
+  dft_processor::configuration dft_cfg;
+  dft_cfg.size = c->dft_size;
+  dft_cfg.dir  = dft_processor::direction::INVERSE;
+  ofdm_modulator_common_configuration common;
+  common.dft = std::make_unique<dft_processor_generic_impl>(dft_cfg);
+  pdxch_processor_impl::configuration ref_cfg;
+  ref_cfg.cp                 = pc.cp;
+  ref_cfg.nof_tx_ports       = nof_ports;
+  ref_cfg.request_queue_size = 16;
+  pdxch_processor_impl reference(std::make_unique<ofdm_symbol_modulator_impl>(common, mod_cfg), ref_cfg);
+  late_counter late_adaptor, late_ref;
+  adaptor->connect(late_adaptor);
+  reference.connect(late_ref);
+
+  mi355::pdsch_processor_adaptor      pdsch_adaptor(ctx, nof_ports, nof_subc, 2);
+  mi355::pdcch_processor_adaptor      pdcch_adaptor(ctx, nof_ports, nof_subc);
+  mi355::ssb_processor_adaptor        ssb_adaptor(ctx, nof_ports, nof_subc);
+  mi355::nzp_csi_rs_generator_adaptor csi_adaptor(ctx, nof_ports, nof_subc);
+  std::unique_ptr<pdsch_processor>    ref_pdsch = ref_make_pdsch_processor(1);
+  nzp_csi_rs_generator_impl           ref_csi(std::make_unique<pseudo_random_generator_impl>());
+
+  std::vector<std::unique_ptr<resource_grid>> grids, ref_grids;
+  int synchronous = 0;
+  for (unsigned i = 0; i != n_slots; ++i) {
+    grids.push_back(mirrored ? grid_factory.create(nof_ports, 14, nof_subc) : make_grid(nof_ports, nof_subc, false));
+    ref_grids.push_back(make_grid(nof_ports, nof_subc, false));
+    grids[i]->set_all_zero();
+    ref_grids[i]->set_all_zero();
+    const slot_point slot(c->numerology, 0, i);
+    // PDCCH
+    pdcch_processor::pdu_t cch = ref_make_pdcch_pdu(pdcch[i]);
+    pdcch_adaptor.process(grids[i]->get_mapper(), cch);
+    ref_make_pdcch_processor()->process(ref_grids[i]->get_mapper(), cch);
+    // PDSCH
+    pdsch_processor::pdu_t sch = ref_make_pdsch_pdu(pdsch[i]);
+    counting_notifier      done, ref_done;
+    static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data;
+    data.push_back(span<const uint8_t>(tbs[i], pdsch[i].tb_size_bytes));
+    pdsch_adaptor.process(grids[i]->get_mapper(), done, data, sch);
+    synchronous += done.count; // a device-mirrored grid: the PDU is enqueued and acknowledged at once
+    done.wait(1);
+    ref_pdsch->process(ref_grids[i]->get_mapper(), ref_done, data, sch);
+    if (i == 0) {
+      ssb_processor::pdu_t blk = ref_make_ssb_pdu(*ssb);
+      ssb_adaptor.process(grids[i]->get_writer(), blk);
+      ref_make_ssb_processor()->process(ref_grids[i]->get_writer(), blk);
+      nzp_csi_rs_generator::config_t rs = make_csi_rs_config(csi);
+      csi_adaptor.map(grids[i]->get_mapper(), rs);
+      ref_csi.map(ref_grids[i]->get_mapper(), rs);
+    }
+    // a channel the library does not generate: straight through the grid's writer on the host
+    std::vector<cf_t> extra(5);
+    for (unsigned k = 0; k != extra.size(); ++k) {
+      extra[k] = cf_t(0.25F * (float)(k + 1 + i), -0.5F);
+    }
+    grids[i]->get_writer().put(nof_ports - 1, 13, nof_subc - 5, span<const cf_t>(extra));
+    ref_grids[i]->get_writer().put(nof_ports - 1, 13, nof_subc - 5, span<const cf_t>(extra));
+    // hand-over (downlink_processor_single_executor_impl::send_resource_grid -> lower PHY)
+    resource_grid_context rg_context;
+    rg_context.slot   = slot;
+    rg_context.sector = 0;
+    adaptor->get_request_handler().handle_request(grids[i]->get_reader(), rg_context);
+    reference.get_request_handler().handle_request(ref_grids[i]->get_reader(), rg_context);
+  }
+  if (settle_ms != 0) {
+    std::this_thread::sleep_for(std::chrono::milliseconds(settle_ms));
+  }
+  // the real-time loop
+  const unsigned nsymb       = c->cp ? 12 : 14;
+  const unsigned slot_stride = oracle_ofdm_slot_size(c, 0);
+  int            processed_adaptor = 0, processed_ref = 0;
+  long long      longest_ns = 0;
+  for (unsigned i = 0; i != n_slots; ++i) {
+    const slot_point slot(c->numerology, 0, i);
+    unsigned         offset = 0;
+    for (unsigned l = 0; l != nsymb; ++l) {
+      const unsigned size = oracle_ofdm_symbol_size(c, slot.subframe_slot_index() * nsymb + l);
+      baseband_gateway_buffer_dynamic buffer_a(nof_ports, size), buffer_r(nof_ports, size);
+      pdxch_processor_baseband::symbol_context sc;
+      sc.slot   = slot;
+      sc.sector = 0;
+      sc.symbol = l;
+      const auto t0 = std::chrono::steady_clock::now();
+      const bool pa = adaptor->get_baseband().process_symbol(buffer_a.get_writer(), sc);
+      const auto t1 = std::chrono::steady_clock::now();
+      const bool pr = reference.get_baseband().process_symbol(buffer_r.get_writer(), sc);
+      longest_ns    = std::max<long long>(longest_ns, std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count());
+      processed_adaptor += pa ? 1 : 0;
+      processed_ref += pr ? 1 : 0;
+      for (unsigned p = 0; p != nof_ports; ++p) {
+        float* da = iq_adaptor + 2 * (((size_t)i * nof_ports + p) * slot_stride + offset);
+        float* dr = iq_ref + 2 * (((size_t)i * nof_ports + p) * slot_stride + offset);
+        if (pa) {
+          std::memcpy(da, buffer_a[p].data(), (size_t)size * sizeof(cf_t));
+        }
+        if (pr) {
+          std::memcpy(dr, buffer_r[p].data(), (size_t)size * sizeof(cf_t));
+        }
+      }
+      offset += size;
+    }
+  }
+  // the grids as a host reader sees them (a device-mirrored grid: one blocking read + the host layer on top)
+  for (unsigned i = 0; i != n_slots; ++i) {
+    store_grid(grid_adaptor + i * words, *grids[i], nof_ports, nof_subc);
+    store_grid(grid_ref + i * words, *ref_grids[i], nof_ports, nof_subc);
+  }
+  info[0] = late_adaptor.count;
+  info[1] = late_ref.count;
+  info[2] = processed_adaptor;
+  info[3] = processed_ref;
+  info[4] = (int)std::min<long long>(longest_ns, 2000000000LL);
+  info[5] = synchronous;
+  info[6] = g_last_pool ? g_last_pool->nof_modulate.load() : -1;
+  info[7] = g_last_pool ? g_last_pool->nof_load_grid.load() : -1;
+  info[8] = g_last_pool ? g_last_pool->nof_read_grid.load() : -1;
+  info[9] = g_last_pool ? g_last_pool->nof_put.load() : -1;
+  adaptor.reset(); // before the grids: it gives their slots back
+  return NRPHY_OK;
 }
 
 } // extern "C"

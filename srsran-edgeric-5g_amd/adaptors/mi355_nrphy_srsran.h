@@ -28,6 +28,13 @@
 #include "srsran/phy/lower/modulation/modulation_factories.h"
 #include "srsran/phy/lower/modulation/ofdm_demodulator.h"
 #include "srsran/phy/lower/modulation/ofdm_modulator.h"
+#include "srsran/gateways/baseband/buffer/baseband_gateway_buffer_writer.h"
+#include "srsran/phy/lower/processors/downlink/pdxch/pdxch_processor.h"
+#include "srsran/phy/lower/processors/downlink/pdxch/pdxch_processor_baseband.h"
+#include "srsran/phy/lower/processors/downlink/pdxch/pdxch_processor_factories.h"
+#include "srsran/phy/lower/processors/downlink/pdxch/pdxch_processor_notifier.h"
+#include "srsran/phy/lower/processors/downlink/pdxch/pdxch_processor_request_handler.h"
+#include "srsran/phy/support/resource_grid_context.h"
 #include "srsran/phy/support/resource_grid_mapper.h"
 #include "srsran/phy/upper/channel_coding/channel_coding_factories.h"
 #include "srsran/phy/support/resource_grid_reader.h"
@@ -54,10 +61,15 @@
 #include "srsran/phy/upper/vrb_to_prb_mapper.h"
 #include "srsran/ran/sch/sch_dmrs_power.h"
 
+#include <array>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
+#include <utility>
 #include <vector>
 
 namespace mi355 {
@@ -239,6 +251,345 @@ private:
   std::shared_ptr<srsran::resource_grid_factory> inner;
 };
 
+// (the device-mirrored grid of the downlink slot pipeline: see "the downlink slot pipeline" further down for the lower-PHY half)
+/// nrphy_dl_slots_t shared by the grid factory (upper PHY) and the pdxch factory (lower PHY) of one cell.
+class dl_slot_pool
+{
+public:
+  dl_slot_pool(std::shared_ptr<context> ctx_, const nrphy_ofdm_config_t& ofdm, unsigned nof_ports_, unsigned depth, unsigned max_tb_bytes) :
+    ctx(std::move(ctx_)), cfg(ofdm), nof_ports(nof_ports_), nof_subc(ofdm.bw_rb * srsran::NRE)
+  {
+    nrphy_dl_slots_cfg_t c;
+    std::memset(&c, 0, sizeof(c));
+    c.ofdm         = ofdm;
+    c.nof_ports    = nof_ports;
+    c.depth        = depth;
+    c.max_tb_bytes = max_tb_bytes;
+    c.iq_format    = 0; // baseband_gateway_buffer_writer carries cf_t
+    int rc         = nrphy_dl_slots_create(ctx->get(), &c, &pool);
+    report_failure("nrphy_dl_slots_create", rc);
+    srsran_assert(rc == NRPHY_OK, "nrphy_dl_slots_create failed.");
+  }
+  ~dl_slot_pool() { nrphy_dl_slots_destroy(pool); }
+  dl_slot_pool(const dl_slot_pool&)            = delete;
+  dl_slot_pool& operator=(const dl_slot_pool&) = delete;
+
+  nrphy_dl_slots_t*          get() const { return pool; }
+  const nrphy_ofdm_config_t& ofdm_config() const { return cfg; }
+  unsigned                   get_nof_ports() const { return nof_ports; }
+  unsigned                   get_nof_subc() const { return nof_subc; }
+
+private:
+  std::shared_ptr<context> ctx;
+  nrphy_dl_slots_t*        pool = nullptr;
+  nrphy_ofdm_config_t      cfg;
+  unsigned                 nof_ports;
+  unsigned                 nof_subc;
+};
+
+/// A resource grid whose accelerated channels live in a slot of the pool (HBM) and whose other channels -- whatever is
+/// written through get_writer() or mapped through get_mapper() by processors that are not adaptors of this header -- live
+/// in a host grid of the reference.  The two layers meet on the device when the grid is handed over (hand_over(): the host
+/// layer's non-zero resource elements are put into the slot's grid, nrphy_dl_slot_put; channels of one slot never share
+/// resource elements, so the order does not matter), or on the host if somebody reads the grid (get_reader().get...():
+/// one blocking device-to-host copy, then the host layer's elements over it).
+class device_resource_grid : public srsran::resource_grid
+{
+public:
+  device_resource_grid(std::shared_ptr<dl_slot_pool> pool_, std::unique_ptr<srsran::resource_grid> host_layer_, std::unique_ptr<srsran::resource_grid> merged_) :
+    pool(std::move(pool_)), host_layer(std::move(host_layer_)), merged(std::move(merged_)), mapper(*this), writer(*this), reader(*this)
+  {
+  }
+  ~device_resource_grid() override { release_slot(); }
+
+  // resource_grid
+  void set_all_zero() override
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    host_layer->set_all_zero();
+    release_slot_locked();
+    host_touched = false;
+    merged_valid = false;
+  }
+  srsran::resource_grid_writer&       get_writer() override { return writer; }
+  const srsran::resource_grid_reader& get_reader() const override { return reader; }
+  srsran::resource_grid_mapper&       get_mapper() override { return mapper; }
+
+  /// The mapper / writer / reader an adaptor is handed belong to a device-mirrored grid: this is how it finds out.
+  static device_resource_grid* from(srsran::resource_grid_mapper& m)
+  {
+    auto* p = dynamic_cast<mapper_type*>(&m);
+    return p ? &p->owner : nullptr;
+  }
+  static device_resource_grid* from(srsran::resource_grid_writer& w)
+  {
+    auto* p = dynamic_cast<writer_type*>(&w);
+    return p ? &p->owner : nullptr;
+  }
+  static const device_resource_grid* from(const srsran::resource_grid_reader& r)
+  {
+    auto* p = dynamic_cast<const reader_type*>(&r);
+    return p ? &p->owner : nullptr;
+  }
+
+  /// Runs `fn(pool, slot_id)` -- a writer of the device layer -- on the grid's slot, opening one at the first use.
+  /// NRPHY_ERR_CAPACITY when every slot of the pool is taken: the caller falls back to its host-span form.
+  template <typename Fn>
+  int on_device(Fn&& fn)
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    if (handed_over) {
+      return NRPHY_ERR_ARGUMENT;
+    }
+    if (!have_slot) {
+      int rc = nrphy_dl_slot_open(pool->get(), &slot_id);
+      if (rc != NRPHY_OK) {
+        return rc;
+      }
+      have_slot = true;
+    }
+    merged_valid = false;
+    return fn(pool->get(), slot_id);
+  }
+
+  /// Grid hand-over (pdxch_processor_request_handler::handle_request): merges the host layer into the slot's grid and
+  /// submits the slot's modulation.  Returns the slot to poll, or -1 when the grid is empty (nothing to transmit) or
+  /// no slot could be had (`status` then says why).  Runs on the caller's (upper PHY) thread; const because the
+  /// reference hands the grid over as a const reader.
+  int hand_over(unsigned subframe_slot_index, int& status) const
+  {
+    device_resource_grid& self = const_cast<device_resource_grid&>(*this);
+    std::lock_guard<std::mutex> lock(self.mutex);
+    status = NRPHY_OK;
+    if (!self.have_slot && self.host_layer->get_reader().is_empty()) {
+      return -1;
+    }
+    if (self.handed_over) { // the same grid requested twice for one slot: the IQ is (being) computed already
+      return static_cast<int>(self.slot_id);
+    }
+    if (!self.have_slot) {
+      status = nrphy_dl_slot_open(pool->get(), &self.slot_id);
+      if (status != NRPHY_OK) {
+        return -1;
+      }
+      self.have_slot = true;
+    }
+    status = self.flush_host_layer();
+    if (status == NRPHY_OK) {
+      status = nrphy_dl_slot_modulate(pool->get(), self.slot_id, subframe_slot_index, nullptr, nullptr);
+    }
+    if (status != NRPHY_OK) {
+      return -1;
+    }
+    self.handed_over = true;
+    return static_cast<int>(self.slot_id);
+  }
+
+  /// Gives the slot back (the slot has been transmitted, or was dropped): what the pdxch adaptor calls from the upper
+  /// PHY's thread.  The next set_all_zero() would do it too -- this makes the slot available a grid-pool cycle earlier.
+  void release_slot() const
+  {
+    device_resource_grid& self = const_cast<device_resource_grid&>(*this);
+    std::lock_guard<std::mutex> lock(self.mutex);
+    self.release_slot_locked();
+  }
+
+  const std::shared_ptr<dl_slot_pool>& get_pool() const { return pool; }
+
+private:
+  struct mapper_type : public srsran::resource_grid_mapper {
+    explicit mapper_type(device_resource_grid& o) : owner(o) {}
+    void map(const srsran::re_buffer_reader<srsran::cf_t>& input, const srsran::re_pattern& pattern, const srsran::precoding_configuration& precoding) override
+    {
+      owner.touch_host();
+      owner.host_layer->get_mapper().map(input, pattern, precoding);
+    }
+    void map(symbol_buffer& buffer, const srsran::re_pattern_list& pattern, const srsran::re_pattern_list& reserved, const srsran::precoding_configuration& precoding, unsigned re_skip = 0) override
+    {
+      owner.touch_host();
+      owner.host_layer->get_mapper().map(buffer, pattern, reserved, precoding, re_skip);
+    }
+    device_resource_grid& owner;
+  };
+  struct writer_type : public srsran::resource_grid_writer {
+    explicit writer_type(device_resource_grid& o) : owner(o) {}
+    unsigned get_nof_ports() const override { return owner.host_layer->get_writer().get_nof_ports(); }
+    unsigned get_nof_subc() const override { return owner.host_layer->get_writer().get_nof_subc(); }
+    unsigned get_nof_symbols() const override { return owner.host_layer->get_writer().get_nof_symbols(); }
+    srsran::span<const srsran::cf_t> put(unsigned port, unsigned l, unsigned k_init, const srsran::bounded_bitset<srsran::NRE * srsran::MAX_RB>& mask, srsran::span<const srsran::cf_t> symbols) override
+    {
+      owner.touch_host();
+      return owner.host_layer->get_writer().put(port, l, k_init, mask, symbols);
+    }
+    srsran::span<const srsran::cbf16_t> put(unsigned port, unsigned l, unsigned k_init, const srsran::bounded_bitset<srsran::NRE * srsran::MAX_RB>& mask, srsran::span<const srsran::cbf16_t> symbols) override
+    {
+      owner.touch_host();
+      return owner.host_layer->get_writer().put(port, l, k_init, mask, symbols);
+    }
+    void put(unsigned port, unsigned l, unsigned k_init, srsran::span<const srsran::cf_t> symbols) override
+    {
+      owner.touch_host();
+      owner.host_layer->get_writer().put(port, l, k_init, symbols);
+    }
+    void put(unsigned port, unsigned l, unsigned k_init, unsigned stride, srsran::span<const srsran::cbf16_t> symbols) override
+    {
+      owner.touch_host();
+      owner.host_layer->get_writer().put(port, l, k_init, stride, symbols);
+    }
+    srsran::span<srsran::cbf16_t> get_view(unsigned port, unsigned l) override
+    {
+      owner.touch_host();
+      return owner.host_layer->get_writer().get_view(port, l);
+    }
+    device_resource_grid& owner;
+  };
+  struct reader_type : public srsran::resource_grid_reader {
+    explicit reader_type(const device_resource_grid& o) : owner(o) {}
+    unsigned get_nof_ports() const override { return owner.host_layer->get_reader().get_nof_ports(); }
+    unsigned get_nof_subc() const override { return owner.host_layer->get_reader().get_nof_subc(); }
+    unsigned get_nof_symbols() const override { return owner.host_layer->get_reader().get_nof_symbols(); }
+    // No device access here: pdxch_processor_impl::process_symbol asks on the real-time thread.  A port the device layer
+    // may have written counts as not empty.
+    bool is_empty(unsigned port) const override { return !owner.have_slot && owner.host_layer->get_reader().is_empty(port); }
+    bool is_empty() const override { return !owner.have_slot && owner.host_layer->get_reader().is_empty(); }
+    srsran::span<srsran::cf_t> get(srsran::span<srsran::cf_t> symbols, unsigned port, unsigned l, unsigned k_init, const srsran::bounded_bitset<srsran::MAX_RB * srsran::NRE>& mask) const override
+    {
+      return owner.host_view().get(symbols, port, l, k_init, mask);
+    }
+    srsran::span<srsran::cbf16_t> get(srsran::span<srsran::cbf16_t> symbols, unsigned port, unsigned l, unsigned k_init, const srsran::bounded_bitset<srsran::MAX_RB * srsran::NRE>& mask) const override
+    {
+      return owner.host_view().get(symbols, port, l, k_init, mask);
+    }
+    void get(srsran::span<srsran::cf_t> symbols, unsigned port, unsigned l, unsigned k_init, unsigned stride = 1) const override
+    {
+      owner.host_view().get(symbols, port, l, k_init, stride);
+    }
+    void get(srsran::span<srsran::cbf16_t> symbols, unsigned port, unsigned l, unsigned k_init) const override
+    {
+      owner.host_view().get(symbols, port, l, k_init);
+    }
+    srsran::span<const srsran::cbf16_t> get_view(unsigned port, unsigned l) const override { return owner.host_view().get_view(port, l); }
+    const device_resource_grid& owner;
+  };
+
+  void touch_host()
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    host_touched = true;
+    merged_valid = false;
+  }
+
+  void release_slot_locked()
+  {
+    if (have_slot) {
+      nrphy_dl_slot_close(pool->get(), slot_id);
+    }
+    have_slot   = false;
+    handed_over = false;
+  }
+
+  // The host layer's resource elements as sparse entries (a value of zero is "not written": what the reference's writers
+  // leave untouched stays zero too, and channels of a slot do not overlap).
+  void host_layer_entries(std::vector<nrphy_grid_re_t>& entries) const
+  {
+    const srsran::resource_grid_reader& r = host_layer->get_reader();
+    for (unsigned port = 0, nof_ports = r.get_nof_ports(); port != nof_ports; ++port) {
+      if (r.is_empty(port)) {
+        continue;
+      }
+      for (unsigned l = 0, nof_symbols = r.get_nof_symbols(); l != nof_symbols; ++l) {
+        srsran::span<const srsran::cbf16_t> row = r.get_view(port, l);
+        for (unsigned k = 0; k != row.size(); ++k) {
+          uint32_t word;
+          std::memcpy(&word, &row[k], sizeof(word));
+          if ((word & 0x7FFF7FFFU) != 0) {
+            entries.push_back({static_cast<uint16_t>(port), static_cast<uint16_t>(l), k, word});
+          }
+        }
+      }
+    }
+  }
+
+  int flush_host_layer()
+  {
+    if (!host_touched) {
+      return NRPHY_OK;
+    }
+    std::vector<nrphy_grid_re_t> entries;
+    host_layer_entries(entries);
+    host_touched = false; // (what the host layer holds stays there: a later read merges it again, idempotently)
+    return entries.empty() ? NRPHY_OK : nrphy_dl_slot_put(pool->get(), slot_id, entries.size(), entries.data());
+  }
+
+  // The whole grid on the host, for whoever reads it there: blocking.
+  const srsran::resource_grid_reader& host_view() const
+  {
+    device_resource_grid& self = const_cast<device_resource_grid&>(*this);
+    std::lock_guard<std::mutex> lock(self.mutex);
+    if (!have_slot) {
+      return host_layer->get_reader();
+    }
+    if (!merged_valid) {
+      const srsran::resource_grid_reader& r        = host_layer->get_reader();
+      const unsigned                      nof_subc = r.get_nof_subc(), nof_ports = r.get_nof_ports();
+      std::vector<srsran::cbf16_t>        raw(static_cast<size_t>(pool->get_nof_ports()) * NRPHY_NSYMB * nof_subc);
+      int rc = nrphy_dl_slot_read_grid(pool->get(), slot_id, raw.data());
+      report_failure("nrphy_dl_slot_read_grid", rc);
+      self.merged->set_all_zero();
+      for (unsigned port = 0; port != nof_ports && port != pool->get_nof_ports(); ++port) {
+        for (unsigned l = 0; l != r.get_nof_symbols(); ++l) {
+          self.merged->get_writer().put(port, l, 0, 1, srsran::span<const srsran::cbf16_t>(&raw[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc], nof_subc));
+        }
+      }
+      std::vector<nrphy_grid_re_t> entries;
+      host_layer_entries(entries);
+      for (const nrphy_grid_re_t& e : entries) {
+        srsran::cbf16_t v;
+        std::memcpy(&v, &e.value, sizeof(v));
+        self.merged->get_writer().put(e.port, e.symbol, e.subc, 1, srsran::span<const srsran::cbf16_t>(&v, 1));
+      }
+      self.merged_valid = true;
+    }
+    return merged->get_reader();
+  }
+
+  std::shared_ptr<dl_slot_pool>          pool;
+  std::unique_ptr<srsran::resource_grid> host_layer; // what host-side processors write
+  std::unique_ptr<srsran::resource_grid> merged;     // device + host layers, built only when somebody reads on the host
+  mapper_type                            mapper;
+  writer_type                            writer;
+  reader_type                            reader;
+  std::mutex                             mutex;
+  uint32_t                               slot_id      = 0;
+  std::atomic<bool>                      have_slot{false};     // the device layer exists (a slot is held)
+  bool                                   handed_over  = false; // its modulation has been submitted
+  bool                                   host_touched = false;
+  bool                                   merged_valid = false;
+};
+
+/// resource_grid_factory whose grids keep the accelerated channels on the device.  `inner` makes the host layers (the
+/// reference's own factory, create_resource_grid_factory()).  Grids of another geometry than the pool's come out as plain
+/// writer-access grids (resource_grid_adaptor), e.g. the uplink grids if the same factory is used for them.
+class device_resource_grid_factory : public srsran::resource_grid_factory
+{
+public:
+  device_resource_grid_factory(std::shared_ptr<dl_slot_pool> pool_, std::shared_ptr<srsran::resource_grid_factory> inner_) :
+    pool(std::move(pool_)), inner(std::move(inner_))
+  {
+  }
+  std::unique_ptr<srsran::resource_grid> create(unsigned nof_ports, unsigned nof_symbols, unsigned nof_subc) override
+  {
+    if (nof_ports != pool->get_nof_ports() || nof_subc != pool->get_nof_subc() || nof_symbols != NRPHY_NSYMB) {
+      return std::make_unique<resource_grid_adaptor>(inner->create(nof_ports, nof_symbols, nof_subc));
+    }
+    return std::make_unique<device_resource_grid>(pool, inner->create(nof_ports, nof_symbols, nof_subc), inner->create(nof_ports, nof_symbols, nof_subc));
+  }
+
+private:
+  std::shared_ptr<dl_slot_pool>                  pool;
+  std::shared_ptr<srsran::resource_grid_factory> inner;
+};
+
 /// The RE of one transmission: per OFDM symbol the subcarriers it owns.
 using re_symbol_masks = std::array<srsran::bounded_bitset<srsran::MAX_RB * srsran::NRE>, NRPHY_NSYMB>;
 
@@ -250,19 +601,25 @@ inline void put_staging_grid(srsran::resource_grid_mapper& mapper,
                              const re_symbol_masks&        masks)
 {
   using namespace srsran;
-  auto*                with_writer = dynamic_cast<resource_grid_mapper_with_writer*>(&mapper);
+  // A grid that gives its writer: resource_grid_adaptor, or the host layer of a device-mirrored grid.
+  resource_grid_writer* direct = nullptr;
+  if (auto* with_writer = dynamic_cast<resource_grid_mapper_with_writer*>(&mapper)) {
+    direct = &with_writer->get_writer();
+  } else if (device_resource_grid* dg = device_resource_grid::from(mapper)) {
+    direct = &dg->get_writer();
+  }
   std::vector<cbf16_t> packed(nof_subc);
   for (unsigned l = 0; l != NRPHY_NSYMB; ++l) {
     const bounded_bitset<MAX_RB * NRE>& mask = masks[l];
     if (mask.size() == 0 || mask.none()) {
       continue;
     }
-    if (with_writer != nullptr) {
+    if (direct != nullptr) {
       for (unsigned port = 0; port != nof_ports; ++port) {
         const cbf16_t* row = &staging[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc];
         unsigned       n   = 0;
         mask.for_each(0, mask.size(), [&](unsigned k) { packed[n++] = row[k]; });
-        with_writer->get_writer().put(port, l, 0, mask, span<const cbf16_t>(packed).first(n));
+        direct->put(port, l, 0, mask, span<const cbf16_t>(packed).first(n));
       }
       continue;
     }
@@ -384,6 +741,19 @@ public:
     nrphy_pdsch_pdu_t  pod = to_pod(pdu, data[0].size(), weights);
     // The reference asserts on invalid PDUs (pdsch_processor_validator_impl::assert_pdu).
     srsran_assert(nrphy_pdsch_validate(&pod) == NRPHY_OK, "Invalid PDSCH PDU.");
+    if (device_resource_grid* dg = device_resource_grid::from(mapper)) {
+      // A device-mirrored grid: the PDU goes into the slot's grid in HBM, ordered on the slot's stream with everything
+      // else of the slot; the transport block is copied at the call, so the PDU is "done" as far as the caller's spans
+      // and the grid's hand-over are concerned (a device failure surfaces when the slot is transmitted).
+      const uint8_t* tb = data[0].data();
+      int rc = dg->on_device([&](nrphy_dl_slots_t* p, uint32_t id) { return nrphy_dl_slot_pdsch(p, id, 1, &pod, &tb); });
+      if (rc != NRPHY_ERR_CAPACITY) {
+        report_failure("nrphy_dl_slot_pdsch", rc);
+        notifier.on_finish_processing();
+        return;
+      }
+      // no slot free, or the slot's staging is full: through the host, into the grid's host layer
+    }
     for (;;) {
       operation* op = nullptr;
       for (operation& o : ops) {
@@ -674,6 +1044,246 @@ public:
 private:
   std::shared_ptr<context> ctx;
   unsigned                 nof_ports;
+};
+
+// ---- the downlink slot pipeline: a device-mirrored resource grid and the lower PHY's pdxch_processor ------------------
+// Seam C as SURVEY.md section 8b asks for it: the slot is modulated WHEN THE GRID IS HANDED OVER
+// (pdxch_processor_request_handler::handle_request, lib/phy/lower/processors/downlink/pdxch/pdxch_processor_impl.cpp:97-112)
+// and the real-time thread (pdxch_processor_baseband::process_symbol, :47-95) only copies from pinned host memory -- and
+// seam A with the grid staying in HBM in between: the channel processor adaptors of this header, handed a grid made by
+// device_resource_grid_factory, write the slot's DEVICE grid (nrphy_dl_slot_pdsch / _pdcch / _ssb / _csi_rs) instead of
+// bringing their resource elements to the host.  What the gNB swaps: the resource_grid_factory where upper_phy builds its
+// downlink grid pool (upper_phy_factories.cpp:313-328) and the pdxch_processor_factory where the lower PHY's downlink
+// processor is built (create_pdxch_processor_factory_sw, pdxch_processor_factories.h:52-59); see INTEGRATION.md section 4.
+
+/// pdxch_processor over the slot pipeline.  handle_request (upper PHY thread) submits the slot: a device-mirrored grid is
+/// handed over where it is (device_resource_grid::hand_over), any other grid is copied into a slot of the pool
+/// (nrphy_dl_slot_load_grid: one host-to-device copy, asynchronous) -- either way the whole slot is modulated on the
+/// device at once and its IQ lands in pinned host memory.  process_symbol (real-time thread) makes no device or library
+/// call beyond an atomic load (nrphy_dl_slot_poll) and pointer arithmetic (nrphy_dl_slot_iq): it copies one symbol per port.
+/// A slot whose IQ has not arrived when its first symbol is due is treated like a late request: on_pdxch_request_late,
+/// silence for the slot (the reference's own behaviour for a request that misses its slot, pdxch_processor_impl.cpp:65-74)
+/// -- unless `max_wait_us` allows the real-time thread to wait that long once per slot.
+class pdxch_processor_adaptor : public srsran::pdxch_processor,
+                                private srsran::pdxch_processor_baseband,
+                                private srsran::pdxch_processor_request_handler
+{
+public:
+  pdxch_processor_adaptor(std::shared_ptr<dl_slot_pool> pool_, srsran::cyclic_prefix cp, unsigned nof_tx_ports_, unsigned max_wait_us_ = 0) :
+    pool(std::move(pool_)), nof_symbols_per_slot(srsran::get_nsymb_per_slot(cp)), nof_tx_ports(nof_tx_ports_), max_wait_us(max_wait_us_)
+  {
+    srsran_assert(nof_tx_ports <= pool->get_nof_ports(), "More transmit ports than the slot pool has.");
+    const nrphy_ofdm_config_t& cfg = pool->ofdm_config();
+    const unsigned nof_symbols_subframe = nof_symbols_per_slot << cfg.numerology;
+    symbol_offset.resize(nof_symbols_subframe);
+    symbol_size.resize(nof_symbols_subframe);
+    for (unsigned s = 0, offset = 0; s != nof_symbols_subframe; ++s) {
+      if (s % nof_symbols_per_slot == 0) {
+        offset = 0;
+      }
+      symbol_offset[s] = offset;
+      symbol_size[s]   = nrphy_ofdm_symbol_size(&cfg, s);
+      offset += symbol_size[s];
+    }
+    staging.resize(static_cast<size_t>(pool->get_nof_ports()) * NRPHY_NSYMB * pool->get_nof_subc());
+  }
+  ~pdxch_processor_adaptor() override
+  {
+    for (request_slot& r : requests) {
+      release(r.take());
+    }
+    release(current);
+    drain_retired();
+  }
+
+  void                                     connect(srsran::pdxch_processor_notifier& notifier_) override { notifier = &notifier_; }
+  srsran::pdxch_processor_request_handler& get_request_handler() override { return *this; }
+  srsran::pdxch_processor_baseband&        get_baseband() override { return *this; }
+
+private:
+  // A request of the pool: the slot it is for and where its IQ will be.
+  struct request {
+    srsran::slot_point          slot;
+    const device_resource_grid* grid      = nullptr; // device-mirrored grid handed over (it owns its pool slot)
+    int                         pool_slot = -1;      // pool slot with the request's IQ; -1: nothing to transmit
+    bool                        own_slot  = false;   // the adaptor opened pool_slot (a plain host grid was loaded into it)
+    bool                        valid     = false;   // a grid was given (what the reference encodes as grid != nullptr)
+  };
+  // resource_grid_request_pool (lib/phy/lower/processors/resource_grid_request_pool.h:37-77): one request per slot modulo 16,
+  // exchanged under a lock that is only ever held for a copy.
+  struct request_slot {
+    request exchange(const request& r)
+    {
+      std::lock_guard<std::mutex> lock(mutex);
+      return std::exchange(value, r);
+    }
+    request take() { return exchange(request()); }
+    request    value;
+    std::mutex mutex;
+  };
+  static constexpr unsigned REQUEST_ARRAY_SIZE = 16;
+
+  void handle_request(const srsran::resource_grid_reader& grid, const srsran::resource_grid_context& context) override
+  {
+    using namespace srsran;
+    srsran_assert(notifier != nullptr, "Notifier has not been connected.");
+    drain_retired(); // slots the real-time thread is done with (it never calls the library itself)
+    request r;
+    r.slot  = context.slot;
+    r.valid = true;
+    int status = NRPHY_OK;
+    if (const device_resource_grid* dg = device_resource_grid::from(grid)) {
+      r.grid      = dg;
+      r.pool_slot = dg->hand_over(context.slot.subframe_slot_index(), status);
+    } else if (!grid.is_empty()) {
+      uint32_t id = 0;
+      status      = nrphy_dl_slot_open(pool->get(), &id);
+      if (status == NRPHY_OK) {
+        std::lock_guard<std::mutex> staging_lock(staging_mutex);
+        const unsigned nof_subc = pool->get_nof_subc();
+        std::fill(staging.begin(), staging.end(), cbf16_t());
+        for (unsigned port = 0; port != pool->get_nof_ports() && port != grid.get_nof_ports(); ++port) {
+          if (grid.is_empty(port)) {
+            continue;
+          }
+          for (unsigned l = 0; l != nof_symbols_per_slot; ++l) {
+            span<const cbf16_t> view = grid.get_view(port, l);
+            std::memcpy(&staging[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc], view.data(), nof_subc * sizeof(cbf16_t));
+          }
+        }
+        status = nrphy_dl_slot_load_grid(pool->get(), id, staging.data());
+        if (status == NRPHY_OK) {
+          status = nrphy_dl_slot_modulate(pool->get(), id, context.slot.subframe_slot_index(), nullptr, nullptr);
+        }
+        if (status == NRPHY_OK) {
+          r.pool_slot = static_cast<int>(id);
+          r.own_slot  = true;
+        } else {
+          nrphy_dl_slot_close(pool->get(), id);
+        }
+      }
+    }
+    report_failure("downlink slot submission", status);
+    request previous = requests[context.slot.system_slot() % REQUEST_ARRAY_SIZE].exchange(r);
+    if (previous.valid) {
+      // A request for this position was never transmitted (pdxch_processor_impl.cpp:104-111).
+      resource_grid_context late_context;
+      late_context.slot   = previous.slot;
+      late_context.sector = context.sector;
+      notifier->on_pdxch_request_late(late_context);
+      release(previous);
+    }
+  }
+
+  bool process_symbol(srsran::baseband_gateway_buffer_writer& samples, const symbol_context& context) override
+  {
+    using namespace srsran;
+    srsran_assert(notifier != nullptr, "Notifier has not been connected.");
+    if (context.slot != current_slot) {
+      retire(current);
+      current      = request();
+      current_slot = context.slot;
+      request r    = requests[context.slot.system_slot() % REQUEST_ARRAY_SIZE].take();
+      if (!r.valid) {
+        return false;
+      }
+      bool late = r.slot != current_slot;
+      if (!late && r.pool_slot >= 0) {
+        int rc = nrphy_dl_slot_poll(pool->get(), r.pool_slot);
+        for (unsigned waited = 0; rc == NRPHY_ERR_NOT_READY && waited < max_wait_us; waited += 5) {
+          std::this_thread::sleep_for(std::chrono::microseconds(5));
+          rc = nrphy_dl_slot_poll(pool->get(), r.pool_slot);
+        }
+        late = rc != NRPHY_OK; // not there yet, or the device failed: silence either way
+      }
+      if (late) {
+        resource_grid_context late_context;
+        late_context.slot   = r.slot;
+        late_context.sector = context.sector;
+        notifier->on_pdxch_request_late(late_context);
+        retire(r);
+        return false;
+      }
+      current = r;
+    }
+    if (current.pool_slot < 0) {
+      return false; // no request, or an empty grid
+    }
+    const unsigned symbol_index_subframe = context.symbol + context.slot.subframe_slot_index() * nof_symbols_per_slot;
+    const unsigned size = symbol_size[symbol_index_subframe], offset = symbol_offset[symbol_index_subframe];
+    for (unsigned i_port = 0; i_port != nof_tx_ports; ++i_port) {
+      span<cf_t> out = samples.get_channel_buffer(i_port);
+      srsran_assert(out.size() == size, "Invalid output size."); // ofdm_modulator_impl.cpp:68-75
+      const cf_t* iq = static_cast<const cf_t*>(nrphy_dl_slot_iq(pool->get(), current.pool_slot, i_port, nullptr));
+      std::memcpy(out.data(), iq + offset, size * sizeof(cf_t));
+    }
+    return true;
+  }
+
+  // Real-time side: a request it is done with goes onto a list the upper PHY's thread empties (closing a pool slot
+  // synchronises its stream -- idle by then, but still a runtime call).
+  void retire(const request& r)
+  {
+    if (!r.valid || (r.grid == nullptr && !r.own_slot)) {
+      return;
+    }
+    std::lock_guard<std::mutex> lock(retired_mutex);
+    retired.push_back(r);
+  }
+  void drain_retired()
+  {
+    std::vector<request> list;
+    {
+      std::lock_guard<std::mutex> lock(retired_mutex);
+      list.swap(retired);
+    }
+    for (const request& r : list) {
+      release(r);
+    }
+  }
+  void release(const request& r)
+  {
+    if (r.grid != nullptr) {
+      r.grid->release_slot();
+    } else if (r.own_slot && r.pool_slot >= 0) {
+      nrphy_dl_slot_close(pool->get(), r.pool_slot);
+    }
+  }
+
+  std::shared_ptr<dl_slot_pool>                 pool;
+  unsigned                                      nof_symbols_per_slot;
+  unsigned                                      nof_tx_ports;
+  unsigned                                      max_wait_us;
+  srsran::pdxch_processor_notifier*             notifier = nullptr;
+  std::vector<unsigned>                         symbol_offset, symbol_size; // within the slot, per symbol of the subframe
+  std::vector<srsran::cbf16_t>                  staging;
+  std::mutex                                    staging_mutex;
+  std::array<request_slot, REQUEST_ARRAY_SIZE>  requests;
+  srsran::slot_point                            current_slot;
+  request                                       current;
+  std::mutex                                    retired_mutex;
+  std::vector<request>                          retired;
+};
+
+/// Drop-in for create_pdxch_processor_factory_sw (pdxch_processor_factories.h:52-59).
+class pdxch_processor_factory_adaptor : public srsran::pdxch_processor_factory
+{
+public:
+  explicit pdxch_processor_factory_adaptor(std::shared_ptr<dl_slot_pool> pool_, unsigned max_wait_us_ = 0) : pool(std::move(pool_)), max_wait_us(max_wait_us_) {}
+  std::unique_ptr<srsran::pdxch_processor> create(const srsran::pdxch_processor_configuration& config) override
+  {
+    // The pool was made for one modulator configuration (pdxch_processor_factories.cpp:41-48 derives the same from `config`).
+    const nrphy_ofdm_config_t& c = pool->ofdm_config();
+    srsran_assert(c.numerology == srsran::to_numerology_value(config.scs) && c.bw_rb == config.bandwidth_rb &&
+                      c.dft_size == config.srate.get_dft_size(config.scs) && (c.cp != 0) == (config.cp == srsran::cyclic_prefix::EXTENDED) &&
+                      c.center_freq_hz == config.center_freq_Hz && config.nof_tx_ports <= pool->get_nof_ports(),
+                  "The slot pool was created for another carrier configuration.");
+    return std::make_unique<pdxch_processor_adaptor>(pool, config.cp, config.nof_tx_ports, max_wait_us);
+  }
+
+private:
+  std::shared_ptr<dl_slot_pool> pool;
+  unsigned                      max_wait_us;
 };
 
 /// ofdm_symbol_demodulator / ofdm_slot_demodulator over the host-span demodulator entry points (receive side,
@@ -1121,6 +1731,13 @@ public:
     std::vector<float> weights;
     nrphy_csi_rs_cfg_t c = to_pod(config, weights);
     srsran_assert(nrphy_csi_rs_validate(&c) == NRPHY_OK, "CSI-RS configuration outside rows 1-5 / wideband precoding.");
+    if (device_resource_grid* dg = device_resource_grid::from(mapper)) {
+      int rc = dg->on_device([&](nrphy_dl_slots_t* p, uint32_t id) { return nrphy_dl_slot_csi_rs(p, id, 1, &c); });
+      if (rc != NRPHY_ERR_CAPACITY) {
+        report_failure("nrphy_dl_slot_csi_rs", rc);
+        return;
+      }
+    }
     std::fill(staging.begin(), staging.end(), cbf16_t());
     int rc = nrphy_csi_rs_map_host(ctx->get(), &c, staging.data(), nof_ports, nof_subc);
     report_failure("nrphy_csi_rs_map_host", rc);
@@ -1228,6 +1845,13 @@ public:
     std::vector<float> weights;
     nrphy_pdcch_pdu_t  pod = to_pod(pdu, weights);
     srsran_assert(nrphy_pdcch_validate(&pod) == NRPHY_OK, "Invalid PDCCH PDU.");
+    if (device_resource_grid* dg = device_resource_grid::from(mapper)) {
+      int rc = dg->on_device([&](nrphy_dl_slots_t* p, uint32_t id) { return nrphy_dl_slot_pdcch(p, id, 1, &pod); });
+      if (rc != NRPHY_ERR_CAPACITY) {
+        report_failure("nrphy_dl_slot_pdcch", rc);
+        return;
+      }
+    }
     // A marker no precoder output equals (a NaN pattern) tells the candidate's RE from the rest of the staging grid.
     cbf16_t marker;
     const uint32_t marker_bits = 0x7FC17FC1U;
@@ -1327,6 +1951,13 @@ public:
     using namespace srsran;
     nrphy_ssb_pdu_t pod = to_pod(pdu);
     srsran_assert(nrphy_ssb_validate(&pod) == NRPHY_OK, "Invalid SS/PBCH block PDU.");
+    if (device_resource_grid* dg = device_resource_grid::from(grid)) {
+      int rc = dg->on_device([&](nrphy_dl_slots_t* p, uint32_t id) { return nrphy_dl_slot_ssb(p, id, 1, &pod); });
+      if (rc != NRPHY_ERR_CAPACITY) {
+        report_failure("nrphy_dl_slot_ssb", rc);
+        return;
+      }
+    }
     cbf16_t        marker;
     const uint32_t marker_bits = 0x7FC17FC1U;
     std::memcpy(&marker, &marker_bits, sizeof(marker));

@@ -197,3 +197,82 @@ def test_fapi_pdsch_shim(harness):
     assert rc == 0, rc
     assert not np.array_equal(want, init)
     assert np.array_equal(got, want)
+
+
+def _dl_pipeline_inputs(rng, n_slots, nof_ports, nof_rb):
+    """Per slot one PDCCH and one PDSCH PDU (other transport block, RNTI, slot index each), an SS/PBCH block and a CSI-RS."""
+    w = cases.codebook("two_layer_two_ports_0")
+    pdsch, tbs, pdcch = [], [], []
+    for i in range(n_slots):
+        tb_bits = cases.tbs(12, 12, 4, 490, 2, 30)
+        p = abi.make_pdu(bwp_size_rb=nof_rb, qm=4, rnti=17 + i, n_id=5, dmrs_symbols=(2, 11), prb_start=22, prb_count=30,
+                         start_symbol=2, nof_symbols=12, precoding=w, tb_size_bytes=tb_bits // 8, slot_index=i)
+        pdsch.append(p)
+        tbs.append(cases.random_tb(rng, p))
+        pdcch.append(abi.make_pdcch(payload=rng.integers(0, 2, 41, dtype=np.uint8), rnti=17 + i, cce_index=0, aggregation_level=4,
+                                    duration=2, frequency_resources=tuple(range(8)), mapping="interleaved", reg_bundle_size=6,
+                                    interleaver_size=2, shift_index=3, n_id_dmrs=5, n_id_data=5, n_rnti=17 + i, bwp_size_rb=nof_rb,
+                                    slot_index=i, precoding=np.array([[1.0, 1.0j]], np.complex64) / np.sqrt(2)))
+    ssb = abi.make_ssb(pattern_case="A", ssb_idx=0, L_max=4, phys_cell_id=5, payload=rng.integers(0, 2, 32, dtype=np.uint8),
+                       sfn=0, ports=(0,))
+    csi = abi.make_csi_rs(row=3, start_rb=0, nof_rb=nof_rb, k0=4, l0=13, density="one", scrambling_id=5,
+                          precoding=np.eye(2, dtype=np.complex64)[None])
+    return pdsch, tbs, pdcch, ssb, csi
+
+
+def _run_dl_pipeline(harness, rng, n_slots, mirrored, max_wait_us, settle_ms):
+    nof_ports, nof_rb = 2, 52
+    nof_subc = 12 * nof_rb
+    cfg = abi.OfdmConfig(1, nof_rb, 1024, 0, 1.0, 2.4e9)     # 30 kHz: two slots per subframe, so the slot index matters
+    pdsch, tbs, pdcch, ssb, csi = _dl_pipeline_inputs(rng, n_slots, nof_ports, nof_rb)
+    arr = (abi.PdschPdu * n_slots)(*pdsch)
+    cch = (abi.PdcchPdu * n_slots)(*pdcch)
+    tb_ptrs = (C.c_void_p * n_slots)(*[t.ctypes.data for t in tbs])
+    stride = backends.pkg.lib.slot_size(cfg, 0)
+    grids = [np.zeros((n_slots, nof_ports, 14, nof_subc, 2), np.uint16) for _ in range(2)]
+    iqs = [np.zeros((n_slots, nof_ports, stride), np.complex64) for _ in range(2)]
+    info = np.zeros(10, np.int32)
+    harness.adaptor_test_dl_pipeline.restype = _i
+    rc = harness.adaptor_test_dl_pipeline(_u32(n_slots), C.byref(cfg), _u32(nof_ports), arr, tb_ptrs, cch, C.byref(ssb), C.byref(csi),
+                                          _i(mirrored), _u32(max_wait_us), _u32(settle_ms), _p(grids[0]), _p(grids[1]), _p(iqs[0]),
+                                          _p(iqs[1]), _p(info))
+    assert rc == 0
+    return grids, iqs, info
+
+
+@pytest.mark.parametrize("mirrored", [1, 0])
+def test_dl_slot_pipeline_adaptors_against_the_references_lower_phy_loop(harness, mirrored):
+    """The compiled reference's lower-PHY loop -- handle_request per slot, then process_symbol 14 x per slot with a
+    baseband buffer of every transmit port (downlink_processor_baseband_impl.cpp:224-235) -- on pdxch_processor_adaptor next
+    to pdxch_processor_impl.  Device-mirrored grids (mirrored = 1): the channel processor adaptors write the slot's device
+    grid (the PDSCH adaptor acknowledges at once), the host layer's few resource elements join them at hand-over through ONE
+    sparse put, nothing is loaded from or read back to the host until the test itself reads the grids; plain grids
+    (mirrored = 0): one grid load per slot.  Either way every process_symbol is served from the slot's finished IQ: the
+    same samples as the reference's modulator to 1e-5, no late notification, and no call longer than a copy."""
+    rng = np.random.default_rng(41)
+    n_slots = 3
+    grids, iqs, info = _run_dl_pipeline(harness, rng, n_slots, mirrored, 0, 40)
+    late_a, late_r, proc_a, proc_r, longest_ns, synchronous, n_mod, n_load, n_read, n_put = (int(v) for v in info)
+    assert (late_a, late_r) == (0, 0) and proc_a == proc_r == 14 * n_slots
+    assert np.array_equal(grids[0], grids[1]) if mirrored else np.array_equal(backends.bf16_to_f32(grids[0]), backends.bf16_to_f32(grids[1]))
+    scale = np.abs(iqs[1]).max()
+    assert scale > 0 and np.abs(iqs[0] - iqs[1]).max() / scale < 1e-5
+    assert n_mod == n_slots
+    if mirrored:
+        assert synchronous == n_slots and n_load == 0 and n_put == n_slots and n_read == n_slots   # (the reads: this test's own)
+    else:
+        assert synchronous == 0 and n_load == n_slots and n_put == 0 and n_read == 0
+    # a symbol of two ports is 2 x 1096 x 8 bytes: microseconds; the bound is loose because the container's clock is noisy
+    assert longest_ns < 2_000_000, longest_ns
+
+
+def test_dl_slot_pipeline_adaptor_late_slot_and_bounded_wait(harness):
+    """A slot whose IQ has not arrived when its first symbol is due: with max_wait_us = 0 the real-time call does not wait --
+    on_pdxch_request_late, silence for the slot (pdxch_processor_impl.cpp:65-74 does the same for a request that misses its
+    slot); with a bounded wait that covers the (mock's 3 ms) modulation the slot is transmitted."""
+    rng = np.random.default_rng(42)
+    grids, iqs, info = _run_dl_pipeline(harness, rng, 1, 1, 0, 0)
+    assert int(info[0]) == 1 and int(info[2]) == 0 and int(info[3]) == 14 and not iqs[0].any()
+    grids, iqs, info = _run_dl_pipeline(harness, rng, 1, 1, 50000, 0)
+    assert int(info[0]) == 0 and int(info[2]) == 14
+    assert np.abs(iqs[0] - iqs[1]).max() / np.abs(iqs[1]).max() < 1e-5
