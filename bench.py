@@ -296,12 +296,12 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
         step()
     ctx.synchronize()
     torch.cuda.synchronize()
+    local_dt = time.perf_counter() - t0   # this rank's own timed region: before the barrier, so that the ranks can differ
     barrier()
     dt = time.perf_counter() - t0
     lib.ORDER_AFTER_TORCH = True
     # Whole-job totals: slots and IQ samples summed over ranks, time = max over ranks (RCCL all-reduce of 3 numbers).
     samples_per_slot = nof_ports * oplan.slot_stride
-    local_dt = dt
     total_slots, total_samples, dt = sharding.aggregate(dist, device, slots * steps, slots * steps * samples_per_slot, dt)
 
     (ms_crc, ms_cb, ms_dmrs, ms_run), _ = plan.kernel_times()
@@ -332,11 +332,17 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
             "value": round(total_slots / dt, 1),
             "unit": "slots/s",
             "steps": steps,
-            "warmup": warmup,
+            # every untimed step before the timed region: the W asked for plus the settling steps in front of them
+            "warmup": settle_steps + warmup,
+            "warmup_requested": warmup,
             "settle_steps": settle_steps,
             "ms_per_step": round(1e3 * dt / steps, 4),
             "config": {"workload": workload, "slots_per_gpu_per_step": slots,
-                       "parallelism": "slot-sharded x%d, no data-path collective" % world},
+                       "parallelism": "slot-sharded x%d, no data-path collective" % world,
+                       "clock": ("settled: %d untimed steps (%d requested + %d settling) precede the timed region -- the engine clocks need "
+                                 "about 30 ms of load; --settle 0 times straight after the requested warm-up" % (
+                                     settle_steps + warmup, warmup, settle_steps)) if settle_steps else
+                                "as requested: %d untimed warm-up steps" % warmup},
             "iq_gsamples_per_sec": round(total_samples / dt / 1e9, 3),
             "whole_path_hbm_frac": round(total_slots * (alg_pdsch + alg_ofdm) / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
             "kernel_ms": {"prologue_tbcrc_scrambling_seq": round(ms_crc, 4), "codeblock_dmrs_zerofill": round(ms_cb, 4),
@@ -377,7 +383,16 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
                 w16 = o.iq_convert_ci16(y, wire_cfg.ci16_scale).reshape(-1, 2).astype(np.int32)
                 g16 = d_iq[0, 0, : w16.shape[0]].cpu().numpy().astype(np.int32)
                 ok = bool(np.abs(g16 - w16).max() <= 1)
+            elif ok:
+                # the dominant kernel's output: slot 0, every port, against the oracle's modulator (north-star tolerance 1e-5)
+                ref_iq = o.ofdm_slot(ofdm, want, 0)
+                got_iq = d_iq[0].cpu().numpy().view(np.complex64).reshape(nof_ports, -1)[:, : ref_iq.shape[1]]
+                err = float(np.abs(got_iq - ref_iq).max() / np.abs(ref_iq).max())
+                out["iq_rel_err_vs_oracle"] = float("%.3g" % err)
+                ok = bool(err < 1e-5)
             out["verified_vs_oracle"] = ok
+            out["verified"] = "grid 0 bit-exact (bf16) and its IQ (%s) against the CPU oracle" % (
+                "int16, one LSB" if wire else "f32, 1e-5 relative, all ports")
         except Exception as e:  # the oracle is optional at bench time
             out["verified_vs_oracle"] = "unavailable: %s" % e
         out["_first_pdu"] = (pdus[0], last[: pdus[0].tb_size_bytes].cpu().numpy().copy(), nof_ports, nof_subc, ofdm)
@@ -386,6 +401,55 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
     del tb_sets, d_grid, d_iq
     torch.cuda.empty_cache()
     return out
+
+
+def shim_entry(env):
+    """Through-the-shim figures ("host spans, boundary A/C semantics, reported separately"): config-3-sized
+    live traffic -- every PDU / slot differs -- through the host-span seams, PCIe included.  Bounded: about two seconds."""
+    import ctypes as C
+    import shim_latency
+    ctx, lib = env["ctx"], env["lib"]
+    h = ctx.lib
+    rng = np.random.default_rng(7)
+    items = shim_latency.live_pdu_pool(rng)
+    max_tb = max(p.tb_size_bytes for p, _ in items)
+    # seam A alone, asynchronous, 4 PDUs in flight: transport block down, whole grid up per PDU
+    done_fn = C.cast(h.nrphy_pdsch_async_count_done, C.c_void_p)
+    qh = C.c_void_p()
+    assert h.nrphy_pdsch_async_create(ctx.handle, 4, 4, 273 * 12, max_tb, C.byref(qh)) == 0
+    count = C.c_uint64(0)
+    refs = [(C.byref(p), tb.ctypes.data) for p, tb in items]
+
+    def pump(n):
+        for k in range(n):
+            pr, tbp = refs[k % len(refs)]
+            while True:
+                rc = h.nrphy_pdsch_async_submit(qh, pr, tbp, done_fn, C.byref(count))
+                if rc == 0:
+                    break
+                assert rc == 4, rc
+                h.nrphy_pdsch_async_wait_slot(qh)
+        h.nrphy_pdsch_async_wait(qh)
+
+    pump(64)
+    count.value = 0
+    total = 800
+    t0 = time.perf_counter()
+    pump(total)
+    dt = time.perf_counter() - t0
+    assert count.value == total
+    h.nrphy_pdsch_async_destroy(qh)
+    grid_bytes = 4 * 14 * 273 * 12 * 4
+    legs = shim_latency.dl_slot_pipeline(ctx, depths=(1, 4), total=400, verbose=False)
+    return {
+        "workload": "config-3-sized live traffic (64 PDU shapes; slot index, RNTI, identities, MCS, allocation all changing), host spans",
+        "seam_a_async_4_in_flight": {"pdus_per_sec": round(total / dt, 1), "ms_per_pdu": round(1e3 * dt / total, 4),
+                                     "pcie_bytes_down": int(np.mean([p.tb_size_bytes for p, _ in items])) + 4096,
+                                     "pcie_bytes_up": grid_bytes,
+                                     "entry": "nrphy_pdsch_async_submit (pdsch_processor::process; grid merged on the host)"},
+        "seams_a_c_slot_pipeline": legs,
+        "entry": "nrphy_dl_slot_open / _pdsch / _modulate / _wait / _close (grid stays in HBM; pdxch_processor hand-over semantics)",
+    }
 
 
 def free_port():
@@ -522,7 +586,7 @@ def main():
         first = head.pop("_first_pdu")
         out = {
             "metric": head["metric"], "value": head["value"], "unit": head["unit"], "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "warmup": head["warmup"], "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32 bit-packed GF(2) + bf16 grid + %s IQ" % ("ci16" if args.wire else "f32"),
             "data": "synthetic",
@@ -542,6 +606,7 @@ def main():
             sec[name] = e
         import rx_chain_bench
         sec["config5"] = rx_chain_bench.run_all(s_steps, s_warm)
+        sec["shim"] = shim_entry(env)
     elif world > 1 and not args.no_secondary and args.config == 3 and not args.wire:
         # N ranks: BASELINE config 4 is the one quoted as a stream sharded over the GPUs -- placed by cell affinity, every
         # rank its share, whole-job totals like the headline.

@@ -235,9 +235,146 @@ def live_traffic():
             h.nrphy_pdsch_async_destroy(qh)
 
 
+def live_pdu_pool(rng, vary_shape=True, n=64):
+    """64 config-3-sized PDUs that all differ (see live_traffic)."""
+    import backends
+    import cases
+    abi = backends.abi
+    w = cases.codebook("four_layer_four_ports_0_0")
+    out = []
+    for i in range(n):
+        n_prb = int(rng.integers(262, 271)) if vary_shape else 270
+        start = int(rng.integers(0, 273 - n_prb + 1)) if vary_shape else 0
+        rate = float(rng.uniform(700, 948))
+        tb_bits = cases.tbs(12, 36, 8, rate, 4, n_prb)
+        pdu = abi.make_pdu(slot_index=i % 20, rnti=int(rng.integers(1, 65520)), n_id=int(rng.integers(0, 1024)),
+                           scrambling_id=int(rng.integers(0, 65536)), bwp_start_rb=0, bwp_size_rb=273, qm=8,
+                           dmrs_symbols=(2, 7, 11), nof_cdm_groups_without_data=2, prb_start=start, prb_count=n_prb,
+                           start_symbol=0, nof_symbols=12, base_graph=1, precoding=w, tb_size_bytes=tb_bits // 8)
+        out.append((pdu, cases.random_tb(rng, pdu)))
+    return out
+
+
+def dl_slot_pipeline(ctx=None, depths=(1, 2, 4, 8), total=600, verbose=True, check=True):
+    """Seams A + C through the downlink slot pipeline (nrphy_dl_slots_*), config-3-sized live traffic (every slot another
+    PDU): per slot the transport block goes down (one copy with the plan's tables), the grid stays in HBM, the whole slot is
+    modulated when the grid is handed over and the IQ comes up into pinned memory -- float32 as pdxch_processor_baseband hands
+    it to the radio buffers, or int16 after the amplitude controller.  `k in flight` = slots opened before the oldest is
+    waited for.  Returns a list of {"leg", "in_flight", "slots_per_sec", "ms_per_slot", "pcie_bytes_down", "pcie_bytes_up"}."""
+    import ctypes as C
+    import backends
+    import cases
+    abi, lib = backends.abi, backends.pkg.lib
+    ctx = ctx or lib.Context(0)
+    h = ctx.lib
+    rng = np.random.default_rng(11)
+    items = live_pdu_pool(rng)
+    _, ports, subc, ofdm = cases.baseline_config(3)
+    max_tb = max(p.tb_size_bytes for p, _ in items)
+    refs = [(C.byref(p), (C.c_void_p * 1)(tb.ctypes.data)) for p, tb in items]
+    wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -12.0, 1.0, -1.0), 32767.0 / 64.0)
+    results = []
+    for leg, wire_cfg, sample_bytes in (("tb_in_f32_iq_out", None, 8), ("tb_in_ci16_iq_out", wire, 4)):
+        if check:
+            # parity of the leg first: one slot against the blocking host-span calls of the same library
+            pool = lib.DlSlotPool(ctx, ofdm, ports, 1, max_tb, wire_cfg=wire_cfg)
+            sid = pool.open()
+            assert pool.pdsch(sid, [items[0][0]], [items[0][1]]) == 0 and pool.modulate(sid, 1) == 0 and pool.wait(sid) == 0
+            grid = ctx.pdsch_process_host(items[0][0], items[0][1], ports, subc)
+            assert np.array_equal(pool.read_grid(sid), grid)
+            if wire_cfg is None:
+                oplan = lib.OfdmPlan(ctx, ofdm, ports)
+                want = oplan.modulate_slot_host(grid, 1)
+                got = np.stack([pool.iq(sid, p) for p in range(ports)])
+                assert np.array_equal(got, want.reshape(ports, -1)), "pipeline IQ differs from the blocking call"
+                oplan.close()
+            pool.close(sid)
+            pool.destroy()
+        slot_samples = lib.slot_size(ofdm, 0)
+        for depth in depths:
+            pool = lib.DlSlotPool(ctx, ofdm, ports, depth, max_tb, wire_cfg=wire_cfg)
+            ph = pool.handle
+            sid = C.c_uint32()
+
+            def pump(n_slots):
+                ring = []
+                for k in range(n_slots):
+                    if len(ring) == depth:
+                        old = ring.pop(0)
+                        assert h.nrphy_dl_slot_wait(ph, old) == 0
+                        assert h.nrphy_dl_slot_close(ph, old) == 0
+                    assert h.nrphy_dl_slot_open(ph, C.byref(sid)) == 0
+                    pr, tbp = refs[k % len(refs)]
+                    assert h.nrphy_dl_slot_pdsch(ph, sid.value, 1, pr, tbp) == 0
+                    assert h.nrphy_dl_slot_modulate(ph, sid.value, k % 2, None, None) == 0
+                    ring.append(sid.value)
+                for old in ring:
+                    assert h.nrphy_dl_slot_wait(ph, old) == 0
+                    assert h.nrphy_dl_slot_close(ph, old) == 0
+
+            pump(64)
+            t0 = time.perf_counter()
+            pump(total)
+            dt = time.perf_counter() - t0
+            pool.destroy()
+            r = {"leg": leg, "in_flight": depth, "slots_per_sec": round(total / dt, 1), "ms_per_slot": round(1e3 * dt / total, 4),
+                 "pcie_bytes_down": int(np.mean([p.tb_size_bytes for p, _ in items])) + 4096,
+                 "pcie_bytes_up": ports * slot_samples * sample_bytes}
+            results.append(r)
+            if verbose:
+                print("slot pipeline %s, live traffic, %d in flight: %.0f slots/s (%.3f ms per slot); PCIe per slot: %d B down "
+                      "(transport block + plan tables), %d B up (IQ)" % (leg, depth, r["slots_per_sec"], r["ms_per_slot"],
+                                                                         r["pcie_bytes_down"], r["pcie_bytes_up"]), flush=True)
+    return results
+
+
+def seams_apart(ctx=None, total=300, verbose=True):
+    """What round 3's adaptors did per slot, for comparison: seam A through the asynchronous queue (transport block down, grid
+    up), then seam C through the blocking host-span modulator (grid down, IQ up), one slot in flight."""
+    import backends
+    import cases
+    lib = backends.pkg.lib
+    ctx = ctx or lib.Context(0)
+    rng = np.random.default_rng(11)
+    items = live_pdu_pool(rng)
+    _, ports, subc, ofdm = cases.baseline_config(3)
+    oplan = lib.OfdmPlan(ctx, ofdm, ports)
+    q = lib.PdschAsyncQueue(ctx, 1, ports, subc, max(p.tb_size_bytes for p, _ in items))
+    box = {}
+
+    def one(k):
+        pdu, tb = items[k % len(items)]
+        assert q.submit(pdu, tb, lambda st, g: box.__setitem__("g", g))
+        q.wait()
+        oplan.modulate_slot_host(box["g"], k % 2)
+
+    for k in range(20):
+        one(k)
+    t0 = time.perf_counter()
+    for k in range(total):
+        one(k)
+    dt = time.perf_counter() - t0
+    q.close()
+    oplan.close()
+    grid_bytes = ports * 14 * subc * 4
+    r = {"leg": "seam_a_async_then_seam_c_host", "in_flight": 1, "slots_per_sec": round(total / dt, 1), "ms_per_slot": round(1e3 * dt / total, 4),
+         "pcie_bytes_down": int(np.mean([p.tb_size_bytes for p, _ in items])) + 4096 + grid_bytes,
+         "pcie_bytes_up": grid_bytes + ports * lib.slot_size(ofdm, 0) * 8}
+    if verbose:
+        print("seams apart (asynchronous seam A, grid to the host, blocking seam C), live traffic, 1 in flight: %.0f slots/s (%.3f ms per "
+              "slot); PCIe per slot: %d B down, %d B up" % (r["slots_per_sec"], r["ms_per_slot"], r["pcie_bytes_down"], r["pcie_bytes_up"]),
+              flush=True)
+    return r
+
+
 if __name__ == "__main__":
     if "--live" in sys.argv:
         live_traffic()
+    elif "--pipeline" in sys.argv:
+        dl_slot_pipeline()
+        seams_apart()
     else:
         main()
         live_traffic()
+        dl_slot_pipeline()
+        seams_apart()

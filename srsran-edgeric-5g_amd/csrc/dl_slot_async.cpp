@@ -131,7 +131,7 @@ extern "C" int nrphy_dl_slots_create(nrphy_ctx_t* ctx, const nrphy_dl_slots_cfg_
   // the same way); room for four calls' worth of tables, more calls share what is left.
   const size_t table_cap = ((size_t)64 * 1024 + (size_t)NRPHY_NSYMB * pool->nof_subc * 6 + 255) & ~(size_t)255;
   pool->tb_cap           = ((size_t)cfg->max_tb_bytes + 7 + 255) & ~(size_t)255;
-  pool->stage_bytes      = pool->tb_cap + 4 * table_cap + 16 * 256;
+  pool->stage_bytes      = pool->tb_cap + 4 * table_cap + 64 * 256; // (every call's blocks and tables start on 256 bytes)
   pool->scratch_words    = (size_t)NRPHY_NSYMB * pool->nof_subc * 2 + 16384;
   if (const char* e = std::getenv("NRPHY_DL_SLOT_STAGE_BYTES")) { // tests: a small value exercises the capacity paths
     pool->stage_bytes = ((size_t)std::max(1024, std::atoi(e)) + 255) & ~(size_t)255;
@@ -291,7 +291,11 @@ extern "C" int nrphy_dl_slot_pdsch(nrphy_dl_slots_t* pool, uint32_t slot_id, uin
     tb_total += ((size_t)pdus[i].tb_size_bytes + 7) & ~(size_t)3; // readable to the next multiple of 4
   }
   const size_t tables_at = (tb_total + 255) & ~(size_t)255; // relative to this call's region of the staging
-  if (s->tb_used + tables_at > pool->tb_cap || s->stage_used + tables_at + 256 > pool->stage_bytes) {
+  size_t       tb_bytes  = 0;
+  for (uint32_t i = 0; i != n_pdu; ++i) {
+    tb_bytes += pdus[i].tb_size_bytes;
+  }
+  if (s->tb_used + tb_bytes > pool->cfg.max_tb_bytes || s->stage_used + tables_at + 256 > pool->stage_bytes) {
     return NRPHY_ERR_CAPACITY;
   }
   if (hipSetDevice(pool->ctx->device) != hipSuccess) {
@@ -335,7 +339,7 @@ extern "C" int nrphy_dl_slot_pdsch(nrphy_dl_slots_t* pool, uint32_t slot_id, uin
     return rc;
   }
   s->grid_defined = true;
-  s->tb_used += tables_at;
+  s->tb_used += tb_bytes;
   s->stage_used += (copy_bytes + 255) & ~(size_t)255;
   return NRPHY_OK;
 }
