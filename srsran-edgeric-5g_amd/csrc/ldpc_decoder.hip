@@ -464,10 +464,10 @@ struct LmEdges {
     lds_store_i8(addr2[T], out >> 16);
     return as_word(msg);
   }
-  // Edges T and T + 1 (T even): new soft bits, and the word of their messages.
-  static __device__ __forceinline__ void backward(uint32_t mrow, uint32_t row_bytes, const uint32_t (&addr1)[DEG],
-                                                  const uint32_t (&addr2)[DEG], const uint32_t (&x)[DEG], uint32_t m1, uint32_t m2,
-                                                  uint32_t hot0, uint32_t hot1)
+  // Edges T and T + 1 (T even): new soft bits, and the word of their messages (store(r, word): row r of the layer).
+  template <typename Store>
+  static __device__ __forceinline__ void backward(const Store& store, const uint32_t (&addr1)[DEG], const uint32_t (&addr2)[DEG],
+                                                  const uint32_t (&x)[DEG], uint32_t m1, uint32_t m2, uint32_t hot0, uint32_t hot1)
   {
     if constexpr (T < DEG) {
       const uint32_t lo = answer(addr1, addr2, x, m1, m2, hot0, hot1);
@@ -475,26 +475,48 @@ struct LmEdges {
       if constexpr (T + 1 < DEG) {
         hi = LmEdges<DEG, T + 1, FIRST>::answer(addr1, addr2, x, m1, m2, hot0, hot1);
       }
-      lds_store_u32(mrow + (T / 2u) * row_bytes, __builtin_amdgcn_perm(hi, lo, 0x06040200u)); // bytes: A(T), B(T), A(T + 1), B(T + 1)
-      LmEdges<DEG, T + 2, FIRST>::backward(mrow, row_bytes, addr1, addr2, x, m1, m2, hot0, hot1);
+      store(T / 2u, __builtin_amdgcn_perm(hi, lo, 0x06040200u)); // bytes: A(T), B(T), A(T + 1), B(T + 1)
+      LmEdges<DEG, T + 2, FIRST>::backward(store, addr1, addr2, x, m1, m2, hot0, hot1);
     }
   }
 };
 
-// mrow: LDS address of the lane's word in the layer's first row of messages; row_bytes = 2 Zc.  aq: the lane's soft-bit
-// addresses on the layer's edges from the graph's table (LdpcDecodeLaunch::pair_addr; the kernel's soft bits start at LDS
-// address 0), four edges per element: check j in the low half, check j + Zc / 2 in the high half.
-template <uint32_t DEG, bool FIRST>
-__device__ __forceinline__ void process_check_pair_lm(uint32_t mrow, uint32_t row_bytes, const ScaleRule& scale, const uint4 (&aq)[5],
-                                                      uint32_t k512, Trace* tr)
+// Where the messages of a codeblock live.  MsgLds: behind its soft bits in LDS (row r of a layer at mrow + r * row_bytes, the
+// lane's own word).  MsgSlot: in the codeblock's slot of the caller's scratch, [row][lane] words, when the LDS has no room for
+// them -- every lane reads back only what it wrote itself, an iteration later; the words of a layer's first PF rows are
+// requested a layer ahead by the caller (`pre`), the rest (layers of degree 19 only) at the start of the layer.  The stores are
+// write-through at agent scope like the check records' (see acquire_slot: a slot passes from workgroup to workgroup).
+struct MsgLds {
+  uint32_t mrow, row_bytes;
+  __device__ __forceinline__ uint32_t load(uint32_t r) const { return lds_load_u32(mrow + r * row_bytes); }
+  __device__ __forceinline__ void     operator()(uint32_t r, uint32_t word) const { lds_store_u32(mrow + r * row_bytes, word); }
+};
+template <uint32_t PF>
+struct MsgSlot {
+  uint32_t* row0;      // the lane's word in the layer's first row
+  uint32_t  row_words; // lanes per row
+  uint32_t  pre[PF];   // rows 0 .. PF - 1 as requested a layer ahead
+  __device__ __forceinline__ uint32_t load(uint32_t r) const { return r < PF ? pre[r] : row0[(size_t)r * row_words]; }
+  __device__ __forceinline__ void     operator()(uint32_t r, uint32_t word) const
+  {
+    __hip_atomic_store(row0 + (size_t)r * row_words, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+
+// msg: the layer's messages (MsgLds / MsgSlot).  aq: the lane's soft-bit addresses on the layer's edges from the graph's table
+// (LdpcDecodeLaunch::pair_addr; the kernel's soft bits start at LDS address 0), four edges per element: check j in the low
+// half, check j + Zc / 2 in the high half.
+template <uint32_t DEG, bool FIRST, uint32_t NQ, typename Msg>
+__device__ __forceinline__ void process_check_pair_lm(const Msg& msg, const ScaleRule& scale, const uint4 (&aq)[NQ], uint32_t k512, Trace* tr)
 {
+  static_assert(DEG <= 4u * NQ, "the address rows of the layer");
   constexpr uint32_t NP = (DEG + 1u) / 2u;
   uint32_t           addr1[DEG], addr2[DEG], x[DEG], c[DEG], w[NP];
   TR(0);
   if (!FIRST) { // the lane's own words of old messages: on their way while the addresses are computed
 #pragma unroll
     for (uint32_t r = 0; r != NP; ++r) {
-      w[r] = lds_load_u32(mrow + r * row_bytes);
+      w[r] = msg.load(r);
     }
   }
 #pragma unroll
@@ -540,24 +562,29 @@ __device__ __forceinline__ void process_check_pair_lm(uint32_t mrow, uint32_t ro
   uint32_t       hot0, hot1;
   pair_one_hot(k1 & 0x00FF00FFu, hot0, hot1);
   TR(5);
-  LmEdges<DEG, 0, FIRST>::backward(mrow, row_bytes, addr1, addr2, x, m1, m2, hot0, hot1);
+  LmEdges<DEG, 0, FIRST>::backward(msg, addr1, addr2, x, m1, m2, hot0, hot1);
   TR(6);
 }
 
-template <bool FIRST>
-__device__ __forceinline__ void process_layer_pair_lm(uint32_t deg, uint32_t mrow, uint32_t row_bytes, const ScaleRule& scale,
-                                                      const uint4 (&aq)[5], uint32_t k512, Trace* tr)
+// MAXDEG: the largest row degree of the base graph the kernel was built for (19: base graph 1, 10: base graph 2).
+template <bool FIRST, uint32_t MAXDEG, uint32_t NQ, typename Msg>
+__device__ __forceinline__ void process_layer_pair_lm(uint32_t deg, const Msg& msg, const ScaleRule& scale, const uint4 (&aq)[NQ],
+                                                      uint32_t k512, Trace* tr)
 {
   switch (deg) {
-    case 3: return process_check_pair_lm<3, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
-    case 4: return process_check_pair_lm<4, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
-    case 5: return process_check_pair_lm<5, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
-    case 6: return process_check_pair_lm<6, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
-    case 7: return process_check_pair_lm<7, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
-    case 8: return process_check_pair_lm<8, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
-    case 9: return process_check_pair_lm<9, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
-    case 10: return process_check_pair_lm<10, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
-    default: return process_check_pair_lm<19, FIRST>(mrow, row_bytes, scale, aq, k512, tr);
+    case 3: return process_check_pair_lm<3, FIRST>(msg, scale, aq, k512, tr);
+    case 4: return process_check_pair_lm<4, FIRST>(msg, scale, aq, k512, tr);
+    case 5: return process_check_pair_lm<5, FIRST>(msg, scale, aq, k512, tr);
+    case 6: return process_check_pair_lm<6, FIRST>(msg, scale, aq, k512, tr);
+    case 7: return process_check_pair_lm<7, FIRST>(msg, scale, aq, k512, tr);
+    case 8: return process_check_pair_lm<8, FIRST>(msg, scale, aq, k512, tr);
+    case 9: return process_check_pair_lm<9, FIRST>(msg, scale, aq, k512, tr);
+    case 10: return process_check_pair_lm<10, FIRST>(msg, scale, aq, k512, tr);
+    default:
+      if constexpr (MAXDEG > 10u) {
+        return process_check_pair_lm<19, FIRST>(msg, scale, aq, k512, tr);
+      }
+      return;
   }
 }
 
@@ -635,9 +662,11 @@ __device__ __forceinline__ void store_record(uint4* rec, uint4 v) // a pair of c
 }
 
 // PAIR: two checks per lane (even lifting sizes: Zc / 2 threads per codeblock), see process_check_pair.
-// LM: with the messages-per-edge-in-LDS path (for launches whose LDS was sized for it); both forms of the pair kernel hold the
-// record path, which a codeblock that needs more layers than expected falls back to.
-template <bool PAIR, bool LM = false>
+// LM: the check-to-variable messages kept per edge instead of as compressed records -- behind the soft bits in LDS when the
+// layers a codeblock runs leave room for them there, else in the codeblock's slot of the caller's scratch (decided per
+// codeblock; the record path is not part of such a kernel).
+// MAXDEG (LM only): the largest row degree of the base graph -- 19 (base graph 1) or 10 (base graph 2).
+template <bool PAIR, bool LM = false, uint32_t MAXDEG = 19>
 __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
 {
   // All of the kernel's LDS is the launch's dynamic allocation, the soft bits at its start: with a static variable in front
@@ -800,8 +829,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
     // codeblock from its own soft bits, so the result never depends on the launch's LDS budget.
     const uint32_t msg_off = (cb_len + 48u + 15u) & ~15u;
     // (the table of soft-bit addresses counts from LDS address 0, where this kernel's only LDS array starts)
-    const bool     lm      = LM && p.lm_lds_bytes != 0 && soft_a == 0 && p.pair_addr != nullptr &&
-                             msg_off + graph->pair_ptr[nof_layers] * 2u * zc <= p.lm_lds_bytes;
+    const bool     lm      = LM && p.lm_lds_bytes != 0 && msg_off + graph->pair_ptr[nof_layers] * 2u * zc <= p.lm_lds_bytes;
     if (claim_late && !lm && pooled) {
       if (j == 0) {
         s_flag[3] = acquire_slot(p.slot_flags, p.nof_slots, blockIdx.x);
@@ -809,8 +837,10 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
       __syncthreads();
     }
     const uint32_t slot = lm ? 0u : s_flag[3];
-    uint2*         rec  = p.scratch + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * p.nof_layers_max * zc;
-    const uint32_t max_iterations = slot == 0xFFFFFFFFu ? 0u : p.max_iterations; // no slot: reported as not decoded
+    uint8_t* const slot_mem = reinterpret_cast<uint8_t*>(p.scratch) + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * p.slot_bytes;
+    // no slot: reported as not decoded (and likewise should the soft bits ever not start at LDS address 0, which the table of
+    // soft-bit addresses of the message kernels assumes)
+    const uint32_t max_iterations = (slot == 0xFFFFFFFFu || (LM && soft_a != 0)) ? 0u : p.max_iterations;
     const uint32_t  msgs  = soft_a + msg_off + 4u * j; // LDS address of the lane's word: [row of two edges][lane], four bytes
     const uint32_t  k512  = 0x02000200u;
     const ScaleRule scale = {s_scaled, p.scaling_factor, p.scale_arithmetic != 0};
@@ -823,99 +853,149 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
 #endif
 
     typedef typename std::conditional<PAIR, uint4, uint2>::type Record; // a pair of checks per lane has a record of twice the size
-    Record*        recs        = reinterpret_cast<Record*>(rec);
+    Record*        recs        = reinterpret_cast<Record*>(slot_mem);
     const uint32_t rec_stride  = PAIR ? half : zc;                       // records of one layer
     const uint32_t minus_half  = 0u - half;
-    uint4 wrap[5] = {}; // (messages in LDS) the first layer's soft-bit addresses, requested at the end of the previous iteration
+    constexpr uint32_t NQ = MAXDEG > 12u ? 5u : 3u; // rows of four soft-bit addresses a layer can have
+    constexpr uint32_t PF = 5u;                     // rows of messages requested a layer ahead (messages in the slot)
+    // (messages kept per edge) the first layer's soft-bit addresses and, in the slot, its old messages: requested at the end of
+    // the previous iteration
+    uint4    wrap[NQ]    = {};
+    uint32_t wrap_pre[PF] = {};
     for (uint32_t it = 0; it != max_iterations && iterations == 0; ++it) {
       if constexpr (LM) {
-        if (lm) { // workgroup-uniform
-          // The lane's soft-bit addresses of a layer: five rows of the table (sixteen bytes per lane and row: four edges),
-          // requested a layer ahead.
-          const uint4* atab = reinterpret_cast<const uint4*>(p.pair_addr) + (active ? j : half - 1u); // (idle lanes stay inside the table)
-          uint4        cur[5];
-          if (it == 0) {
+        // The lane's soft-bit addresses of a layer: NQ rows of the table (sixteen bytes per lane and row: four edges),
+        // requested a layer ahead.
+        const uint32_t jj   = active ? j : half - 1u; // (idle lanes stay inside the tables)
+        const uint4*   atab = reinterpret_cast<const uint4*>(p.pair_addr) + jj;
+        uint32_t*      gmsg = reinterpret_cast<uint32_t*>(slot_mem) + jj; // (messages in the slot) the lane's word of row 0
+        uint4          cur[NQ];
+        uint32_t       pre[PF];
+        if (it == 0) {
 #pragma unroll
-            for (uint32_t q = 0; q != 5; ++q) {
-              cur[q] = atab[q * half];
-            }
-          } else {
+          for (uint32_t q = 0; q != NQ; ++q) {
+            cur[q] = atab[q * half];
+          }
 #pragma unroll
-            for (uint32_t q = 0; q != 5; ++q) {
-              cur[q] = wrap[q];
+          for (uint32_t r = 0; r != PF; ++r) {
+            pre[r] = 0;
+          }
+        } else {
+#pragma unroll
+          for (uint32_t q = 0; q != NQ; ++q) {
+            cur[q] = wrap[q];
+          }
+#pragma unroll
+          for (uint32_t r = 0; r != PF; ++r) {
+            pre[r] = wrap_pre[r];
+          }
+        }
+        uint32_t e0 = graph->row_ptr[0], e1 = graph->row_ptr[1], rows = 0, quads = 0;
+        // One layer with the addresses in `now` (and, in the slot, the first rows of its old messages in `pre_now`); the
+        // next layer's (after the last: the first's, for the next iteration) are requested into `next` / `pre_next` before
+        // the layer starts.  Two calls per trip with the arrays swapped: no copies.
+        auto layer = [&](uint32_t m, const uint4 (&now)[NQ], uint4 (&next)[NQ], const uint32_t (&pre_now)[PF],
+                         uint32_t (&pre_next)[PF]) __attribute__((always_inline)) {
+          const uint32_t e2  = graph->row_ptr[m + 2u]; // (the array has a spare element) a layer ahead: off the critical path
+          const uint32_t deg = e1 - e0;
+          const bool     last      = m + 1u == nof_layers;
+          const uint32_t rows_next = last ? 0u : rows + ((deg + 1u) >> 1);
+          quads                    = last ? 0u : quads + ((deg + 3u) >> 2);
+#pragma unroll
+          for (uint32_t q = 0; q != NQ; ++q) {
+            next[q] = atab[(quads + q) * half];
+          }
+          if (!lm) { // workgroup-uniform (the rows read past a layer's own lie inside the slot: it has PF spare rows)
+#pragma unroll
+            for (uint32_t r = 0; r != PF; ++r) {
+              pre_next[r] = gmsg[(size_t)(rows_next + r) * half];
             }
           }
-          uint32_t e0 = graph->row_ptr[0], e1 = graph->row_ptr[1], rows = 0, quads = 0;
-          // One layer with the addresses in `now`; the next layer's (after the last: the first's, for the next iteration)
-          // are requested into `next` before the layer starts.  Two calls per trip with the arrays swapped: no copies.
-          auto layer = [&](uint32_t m, const uint4 (&now)[5], uint4 (&next)[5]) __attribute__((always_inline)) {
-            const uint32_t e2  = graph->row_ptr[m + 2u]; // (the array has a spare element) a layer ahead: off the critical path
-            const uint32_t deg = e1 - e0;
-            quads              = m + 1u != nof_layers ? quads + ((deg + 3u) >> 2) : 0u;
-#pragma unroll
-            for (uint32_t q = 0; q != 5; ++q) {
-              next[q] = atab[(quads + q) * half];
-            }
-            if (active) {
+          if (active) {
+            if (lm) {
+              const MsgLds msg = {msgs + rows * 2u * zc, 2u * zc};
               if (it == 0) {
-                process_layer_pair_lm<true>(deg, msgs + rows * 2u * zc, 2u * zc, scale, now, k512, nullptr);
+                process_layer_pair_lm<true, MAXDEG>(deg, msg, scale, now, k512, nullptr);
               } else {
-                process_layer_pair_lm<false>(deg, msgs + rows * 2u * zc, 2u * zc, scale, now, k512, tr);
+                process_layer_pair_lm<false, MAXDEG>(deg, msg, scale, now, k512, tr);
               }
-            }
-            rows += (deg + 1u) >> 1;
-            lds_barrier();
-#ifdef NRPHY_DEC_TRACE
-            if (it != 0) { TR(7); } else if (tr) { tr->last = __builtin_readcyclecounter(); }
-#endif
-            e0 = e1;
-            e1 = e2;
-          };
-          uint4 alt[5];
-          for (uint32_t m = 0; m < nof_layers; m += 2u) {
-            layer(m, cur, alt);
-            if (m + 1u != nof_layers) {
-              layer(m + 1u, alt, cur);
             } else {
+              MsgSlot<PF> msg;
+              msg.row0      = gmsg + (size_t)rows * half;
+              msg.row_words = half;
 #pragma unroll
-              for (uint32_t q = 0; q != 5; ++q) {
-                cur[q] = alt[q];
+              for (uint32_t r = 0; r != PF; ++r) {
+                msg.pre[r] = pre_now[r];
+              }
+              if (it == 0) {
+                process_layer_pair_lm<true, MAXDEG>(deg, msg, scale, now, k512, nullptr);
+              } else {
+                process_layer_pair_lm<false, MAXDEG>(deg, msg, scale, now, k512, tr);
               }
             }
           }
-#pragma unroll
-          for (uint32_t q = 0; q != 5; ++q) {
-            wrap[q] = cur[q];
-          }
-        }
-      }
-      Record next = {};
-      if (!lm && it != 0 && active) {
-        next = recs[j];
-      }
-      uint32_t e0 = graph->row_ptr[0], e1 = graph->row_ptr[1];
-      for (uint32_t m = 0; m != (lm ? 0u : nof_layers); ++m) {
-        const uint32_t e2  = graph->row_ptr[m + 2u]; // (the array has a spare element) a layer ahead: off the critical path
-        const uint32_t deg = e1 - e0;
-        const Record   old = next;
-        if (it != 0 && active && m + 1u != nof_layers) {
-          next = recs[(size_t)(m + 1u) * rec_stride + j];
-        }
-        if (active) {
-          const auto* edge = graph->edge + e0;
-          if constexpr (PAIR) {
-            const uint4 mine = it == 0 ? process_layer_pair<true>(deg, soft_a, s_scaled, edge, half, minus_half, j, jm, old)
-                                       : process_layer_pair<false>(deg, soft_a, s_scaled, edge, half, minus_half, j, jm, old);
-            store_record(&recs[(size_t)m * rec_stride + j], mine);
+          rows += (deg + 1u) >> 1;
+          lds_barrier();
+#ifdef NRPHY_DEC_TRACE
+          if (it != 0) { TR(7); } else if (tr) { tr->last = __builtin_readcyclecounter(); }
+#endif
+          e0 = e1;
+          e1 = e2;
+        };
+        uint4    alt[NQ];
+        uint32_t pre_alt[PF];
+        for (uint32_t m = 0; m < nof_layers; m += 2u) {
+          layer(m, cur, alt, pre, pre_alt);
+          if (m + 1u != nof_layers) {
+            layer(m + 1u, alt, cur, pre_alt, pre);
           } else {
-            const uint2 mine = it == 0 ? process_layer<true>(deg, soft, s_scaled, edge, zc, j, jm, old)
-                                       : process_layer<false>(deg, soft, s_scaled, edge, zc, j, jm, old);
-            store_record(&recs[(size_t)m * rec_stride + j], mine);
+#pragma unroll
+            for (uint32_t q = 0; q != NQ; ++q) {
+              cur[q] = alt[q];
+            }
+#pragma unroll
+            for (uint32_t r = 0; r != PF; ++r) {
+              pre[r] = pre_alt[r];
+            }
           }
         }
-        lds_barrier();
-        e0 = e1;
-        e1 = e2;
+#pragma unroll
+        for (uint32_t q = 0; q != NQ; ++q) {
+          wrap[q] = cur[q];
+        }
+#pragma unroll
+        for (uint32_t r = 0; r != PF; ++r) {
+          wrap_pre[r] = pre[r];
+        }
+      } else {
+        Record next = {};
+        if (it != 0 && active) {
+          next = recs[j];
+        }
+        uint32_t e0 = graph->row_ptr[0], e1 = graph->row_ptr[1];
+        for (uint32_t m = 0; m != nof_layers; ++m) {
+          const uint32_t e2  = graph->row_ptr[m + 2u]; // (the array has a spare element) a layer ahead: off the critical path
+          const uint32_t deg = e1 - e0;
+          const Record   old = next;
+          if (it != 0 && active && m + 1u != nof_layers) {
+            next = recs[(size_t)(m + 1u) * rec_stride + j];
+          }
+          if (active) {
+            const auto* edge = graph->edge + e0;
+            if constexpr (PAIR) {
+              const uint4 mine = it == 0 ? process_layer_pair<true>(deg, soft_a, s_scaled, edge, half, minus_half, j, jm, old)
+                                         : process_layer_pair<false>(deg, soft_a, s_scaled, edge, half, minus_half, j, jm, old);
+              store_record(&recs[(size_t)m * rec_stride + j], mine);
+            } else {
+              const uint2 mine = it == 0 ? process_layer<true>(deg, soft, s_scaled, edge, zc, j, jm, old)
+                                         : process_layer<false>(deg, soft, s_scaled, edge, zc, j, jm, old);
+              store_record(&recs[(size_t)m * rec_stride + j], mine);
+            }
+          }
+          lds_barrier();
+          e0 = e1;
+          e1 = e2;
+        }
       }
       // Early stop (ldpc_decoder_impl.cpp:118-126): every hard bit decided and the CRC of the significant bits zero.
       // crc_at_end (pusch_codeblock_decoder.cpp:59-68): no check until the last iteration, then the CRC alone decides.
@@ -1010,12 +1090,18 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(NRPHY_DECOD
 {
   ldpc_decode_body<true>(p);
 }
-// ... with the messages per edge in LDS: the LDS of such a launch holds three waves per SIMD at most (four workgroups of
-// three waves per CU at BASELINE config 5), so the kernel takes their registers -- with 128 the compiler serialises the LDS
-// reads of an edge pass through two temporaries.
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void ldpc_decode_pairs_lm_kernel(LdpcDecodeLaunch p)
+// ... with the messages kept per edge (LDS or slot), one kernel per base graph: base graph 1 has four rows of degree 19 --
+// two address arrays, a value array and the words of old messages for nineteen edges -- and runs with the registers of three
+// waves per SIMD (all that the LDS of a high-rate launch holds anyway: four workgroups of three waves per CU at BASELINE config
+// 5; with 128 registers the compiler serialises the LDS reads of an edge pass through two temporaries); base graph 2 stops at
+// degree 10 and fits the registers of four.
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void ldpc_decode_msg_bg1_kernel(LdpcDecodeLaunch p)
 {
-  ldpc_decode_body<true, true>(p);
+  ldpc_decode_body<true, true, 19>(p);
+}
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(4))) void ldpc_decode_msg_bg2_kernel(LdpcDecodeLaunch p)
+{
+  ldpc_decode_body<true, true, 10>(p);
 }
 
 constexpr uint32_t LDS_TAIL_BYTES = 16u + 128u;
@@ -1032,18 +1118,22 @@ hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p_in, uint32_t n_cb, hipSt
   }
   LdpcDecodeLaunch p = p_in;
   // NRPHY_DECODER_PAIRS=0: one check per lane whatever the lifting size (A/B runs; the results are identical).
-  const char*        pairs_env = std::getenv("NRPHY_DECODER_PAIRS"); // (read per launch: the tests run both kernels in one process)
+  const char*        pairs_env = std::getenv("NRPHY_DECODER_PAIRS"); // (read per launch: the tests run every form in one process)
   const bool         pairs     = (p.zc & 1u) == 0 && p.zc >= 4u && !(pairs_env != nullptr && pairs_env[0] == '0');
   const uint32_t     checks    = pairs ? p.zc / 2u : p.zc;
   const uint32_t     threads   = ((checks + WAVE - 1) / WAVE) * WAVE;
   size_t             lds       = ldpc_decode_lds_bytes(p);
-  // Messages per edge in LDS (NRPHY_DECODER_LDSMSG=0: never): taken when the expected layers leave the CU at least twelve
-  // wavefronts (three per SIMD, where the pair kernel's edge passes still hide their LDS round trips).
-  // NRPHY_DECODER_LDSMSG=2: whenever a workgroup's LDS can hold them at all (tests).
+  // Two checks per lane: messages per edge (NRPHY_DECODER_MSG=0: compressed records instead, the round-3 form, for A/B runs).
+  // Behind the soft bits in LDS when the expected layers leave the CU at least twelve wavefronts (three per SIMD, where the
+  // edge passes still hide their LDS round trips) -- NRPHY_DECODER_LDSMSG=2: whenever a workgroup's LDS can hold them at all
+  // (tests), =0: never --, else in the codeblock's slot of the scratch.
+  const char*        msg_env   = std::getenv("NRPHY_DECODER_MSG");
+  const bool         msg       = pairs && p.pair_addr != nullptr && (p.bg_k == 22u || p.bg_k == 10u) &&
+                                 !(msg_env != nullptr && msg_env[0] == '0');
   const char*        lm_env    = std::getenv("NRPHY_DECODER_LDSMSG");
   const uint32_t     waves     = threads / WAVE;
   const uint32_t     lm_cap    = (lm_env != nullptr && lm_env[0] == '2') ? 160u * 1024u : ((160u * 1024u) / ((12u + waves - 1u) / waves)) & ~255u;
-  if (pairs && p.lm_lds_bytes != 0 && p.lm_lds_bytes + LDS_TAIL_BYTES <= lm_cap && !(lm_env != nullptr && lm_env[0] == '0')) {
+  if (msg && p.lm_lds_bytes != 0 && p.lm_lds_bytes + LDS_TAIL_BYTES <= lm_cap && !(lm_env != nullptr && lm_env[0] == '0')) {
     lds            = lds > p.lm_lds_bytes ? lds : (size_t)p.lm_lds_bytes;
     p.lm_lds_bytes = (uint32_t)lds;
   } else {
@@ -1051,8 +1141,8 @@ hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p_in, uint32_t n_cb, hipSt
   }
   p.lds_tail_off = (uint32_t)lds; // the flags and the scaling table behind the soft bits (and messages)
   lds += LDS_TAIL_BYTES;
-  const bool         lm        = p.lm_lds_bytes != 0;
-  const void*        kernel    = lm      ? reinterpret_cast<const void*>(ldpc_decode_pairs_lm_kernel)
+  const void*        kernel    = msg     ? (p.bg_k == 22u ? reinterpret_cast<const void*>(ldpc_decode_msg_bg1_kernel)
+                                                          : reinterpret_cast<const void*>(ldpc_decode_msg_bg2_kernel))
                                  : pairs ? reinterpret_cast<const void*>(ldpc_decode_pairs_kernel)
                                          : reinterpret_cast<const void*>(ldpc_decode_kernel);
   if (lds > 64 * 1024) {
@@ -1061,8 +1151,10 @@ hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p_in, uint32_t n_cb, hipSt
       return e;
     }
   }
-  if (lm) {
-    hipLaunchKernelGGL(ldpc_decode_pairs_lm_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
+  if (msg && p.bg_k == 22u) {
+    hipLaunchKernelGGL(ldpc_decode_msg_bg1_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
+  } else if (msg) {
+    hipLaunchKernelGGL(ldpc_decode_msg_bg2_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
   } else if (pairs) {
     hipLaunchKernelGGL(ldpc_decode_pairs_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
   } else {

@@ -2366,7 +2366,7 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
 // The caller-owned scratch of a decoder launch: a pool of check-record slots + the bitmap that hands them out.
 struct DecoderScratch {
   uint32_t nof_slots, nof_layers_max;
-  uint64_t records_bytes, flags_bytes, total_bytes;
+  uint64_t slot_bytes, records_bytes, flags_bytes, total_bytes;
 };
 bool decoder_scratch_layout(const nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t& cfg, uint32_t n_cb, DecoderScratch& s)
 {
@@ -2388,7 +2388,24 @@ bool decoder_scratch_layout(const nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg
       s.nof_slots = n_cb;
     }
   }
-  s.records_bytes         = (uint64_t)s.nof_slots * s.nof_layers_max * zc * sizeof(uint2);
+  // A slot holds a codeblock's check records (8 bytes per lifted check and layer) or, with two checks per lane, its messages
+  // per edge: rows of two edges, 2 Zc bytes each, five spare rows (the kernel requests five rows from a layer's first).
+  {
+    const nr_ldpc_edge_t* edges   = (cfg.base_graph == 1) ? NR_LDPC_BG1_EDGES : NR_LDPC_BG2_EDGES;
+    const unsigned        n_edges = (cfg.base_graph == 1) ? NR_LDPC_BG1_NOF_EDGES : NR_LDPC_BG2_NOF_EDGES;
+    std::vector<uint32_t> degree(s.nof_layers_max, 0);
+    for (unsigned e = 0; e != n_edges; ++e) {
+      if (edges[e].row < s.nof_layers_max) {
+        ++degree[edges[e].row];
+      }
+    }
+    uint64_t rows = 5;
+    for (uint32_t dg : degree) {
+      rows += (dg + 1) / 2;
+    }
+    s.slot_bytes = (std::max<uint64_t>((uint64_t)s.nof_layers_max * zc * sizeof(uint2), rows * 2 * zc) + 255) & ~(uint64_t)255;
+  }
+  s.records_bytes         = (uint64_t)s.nof_slots * s.slot_bytes;
   s.flags_bytes           = ((uint64_t)s.nof_slots * 4 + 255) & ~(uint64_t)255;
   s.total_bytes           = ((s.records_bytes + 255) & ~(uint64_t)255) + s.flags_bytes;
   return true;
@@ -2535,6 +2552,7 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
   p.scratch     = (uint2*)d_scratch;
   p.slot_flags = (uint32_t*)((uint8_t*)d_scratch + ((sl.records_bytes + 255) & ~(uint64_t)255));
   p.nof_slots   = sl.nof_slots;
+  p.slot_bytes  = (uint32_t)sl.slot_bytes;
   if (sl.nof_slots < n_cb) {
     HIP_TRY(hipMemsetAsync(p.slot_flags, 0, sl.flags_bytes, s));
   }

@@ -268,9 +268,10 @@ struct LdpcDecodeLaunch {
   const DecoderGraph* graph;
   const uint32_t*     pair_addr;  // even lifting sizes: soft-bit addresses of (edge, pair of checks), [row of four edges][lane][4]; else null
   const int8_t*       llr;        // per codeblock: nof_llr soft bits (the codeblock without its first 2 Zc bits)
-  uint2*              scratch;    // check records of 8 bytes: nof_slots slots of nof_layers_max * Zc records
+  uint2*              scratch;    // nof_slots slots of slot_bytes each: a codeblock's check records (8 bytes per check and layer) or its messages per edge
   uint32_t*           slot_flags;  // one word per slot (0 = free), all clear at launch; unused when every codeblock has a slot of its own
   uint32_t            nof_slots;  // >= the workgroups of this kernel the device can hold at once, <= codeblocks
+  uint32_t            slot_bytes; // of one slot
   uint8_t*            out;        // per codeblock: Kb * Zc hard bits, packed MSB first
   uint32_t*           iterations; // per codeblock: iterations until the CRC passed, 0 = it did not (may be null)
   const uint32_t*     crc_weight; // per 32-bit word of the message DEC_CRC_TABLE_WORDS words: [nibble k][value v] = (v x^(4k)) x^(bits after the word) mod the CRC polynomial

@@ -754,15 +754,16 @@ def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
 # to the reference's generic decoder (tests/test_oracle.py)
 # ---------------------------------------------------------------------------------------------------------------------
 DECODER_KERNELS = {  # environment of a launch (read per launch) -> which form of the decoder runs
-    "default": {},                                # two checks per lane; messages per edge in LDS where the occupancy rule allows
-    "lds-messages": {"NRPHY_DECODER_LDSMSG": "2"},  # ... wherever a workgroup's LDS can hold them
-    "records": {"NRPHY_DECODER_LDSMSG": "0"},       # two checks per lane, compressed records in the caller's scratch
+    "default": {},                                  # two checks per lane, messages per edge: in LDS where the occupancy rule allows, else in the scratch slot
+    "lds-messages": {"NRPHY_DECODER_LDSMSG": "2"},  # ... in LDS wherever a workgroup's LDS can hold them
+    "slot-messages": {"NRPHY_DECODER_LDSMSG": "0"}, # ... always in the codeblock's slot of the caller's scratch
+    "records": {"NRPHY_DECODER_MSG": "0"},          # two checks per lane, compressed records in the caller's scratch (round 3's form)
     "one-check": {"NRPHY_DECODER_PAIRS": "0"},      # one check per lane (what odd lifting sizes always take)
 }
 
 
 def select_decoder_kernel(monkeypatch, kernel):
-    for name in ("NRPHY_DECODER_PAIRS", "NRPHY_DECODER_LDSMSG"):
+    for name in ("NRPHY_DECODER_PAIRS", "NRPHY_DECODER_LDSMSG", "NRPHY_DECODER_MSG"):
         monkeypatch.delenv(name, raising=False)
     for name, value in DECODER_KERNELS[kernel].items():
         monkeypatch.setenv(name, value)
