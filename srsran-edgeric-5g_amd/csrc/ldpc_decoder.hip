@@ -495,7 +495,7 @@ template <uint32_t PF>
 struct MsgSlot {
   uint32_t* row0;      // the lane's word in the layer's first row
   uint32_t  row_words; // lanes per row
-  uint32_t  pre[PF];   // rows 0 .. PF - 1 as requested a layer ahead
+  uint32_t  pre[PF != 0 ? PF : 1]; // rows 0 .. PF - 1 as requested a layer ahead
   __device__ __forceinline__ uint32_t load(uint32_t r) const { return r < PF ? pre[r] : row0[(size_t)r * row_words]; }
   __device__ __forceinline__ void     operator()(uint32_t r, uint32_t word) const
   {
@@ -506,8 +506,11 @@ struct MsgSlot {
 // msg: the layer's messages (MsgLds / MsgSlot).  aq: the lane's soft-bit addresses on the layer's edges from the graph's table
 // (LdpcDecodeLaunch::pair_addr; the kernel's soft bits start at LDS address 0), four edges per element: check j in the low
 // half, check j + Zc / 2 in the high half.
-template <uint32_t DEG, bool FIRST, uint32_t NQ, typename Msg>
-__device__ __forceinline__ void process_check_pair_lm(const Msg& msg, const ScaleRule& scale, const uint4 (&aq)[NQ], uint32_t k512, Trace* tr)
+// ahead(): called between the two edge passes -- the caller requests the next layer's soft-bit addresses there: early enough
+// for the backward pass to cover the trip to L2, late enough not to hold twenty more registers through the forward pass.
+template <uint32_t DEG, bool FIRST, uint32_t NQ, typename Msg, typename Ahead>
+__device__ __forceinline__ void process_check_pair_lm(const Msg& msg, const ScaleRule& scale, const uint4 (&aq)[NQ], uint32_t k512, Trace* tr,
+                                                      const Ahead& ahead)
 {
   static_assert(DEG <= 4u * NQ, "the address rows of the layer");
   constexpr uint32_t NP = (DEG + 1u) / 2u;
@@ -561,28 +564,29 @@ __device__ __forceinline__ void process_check_pair_lm(const Msg& msg, const Scal
   const uint32_t m1 = as_word(as_s16x2(n1 ^ pm) - as_s16x2(pm)), m2 = as_word(as_s16x2(n2 ^ pm) - as_s16x2(pm));
   uint32_t       hot0, hot1;
   pair_one_hot(k1 & 0x00FF00FFu, hot0, hot1);
+  ahead();
   TR(5);
   LmEdges<DEG, 0, FIRST>::backward(msg, addr1, addr2, x, m1, m2, hot0, hot1);
   TR(6);
 }
 
 // MAXDEG: the largest row degree of the base graph the kernel was built for (19: base graph 1, 10: base graph 2).
-template <bool FIRST, uint32_t MAXDEG, uint32_t NQ, typename Msg>
+template <bool FIRST, uint32_t MAXDEG, uint32_t NQ, typename Msg, typename Ahead>
 __device__ __forceinline__ void process_layer_pair_lm(uint32_t deg, const Msg& msg, const ScaleRule& scale, const uint4 (&aq)[NQ],
-                                                      uint32_t k512, Trace* tr)
+                                                      uint32_t k512, Trace* tr, const Ahead& ahead)
 {
   switch (deg) {
-    case 3: return process_check_pair_lm<3, FIRST>(msg, scale, aq, k512, tr);
-    case 4: return process_check_pair_lm<4, FIRST>(msg, scale, aq, k512, tr);
-    case 5: return process_check_pair_lm<5, FIRST>(msg, scale, aq, k512, tr);
-    case 6: return process_check_pair_lm<6, FIRST>(msg, scale, aq, k512, tr);
-    case 7: return process_check_pair_lm<7, FIRST>(msg, scale, aq, k512, tr);
-    case 8: return process_check_pair_lm<8, FIRST>(msg, scale, aq, k512, tr);
-    case 9: return process_check_pair_lm<9, FIRST>(msg, scale, aq, k512, tr);
-    case 10: return process_check_pair_lm<10, FIRST>(msg, scale, aq, k512, tr);
+    case 3: return process_check_pair_lm<3, FIRST>(msg, scale, aq, k512, tr, ahead);
+    case 4: return process_check_pair_lm<4, FIRST>(msg, scale, aq, k512, tr, ahead);
+    case 5: return process_check_pair_lm<5, FIRST>(msg, scale, aq, k512, tr, ahead);
+    case 6: return process_check_pair_lm<6, FIRST>(msg, scale, aq, k512, tr, ahead);
+    case 7: return process_check_pair_lm<7, FIRST>(msg, scale, aq, k512, tr, ahead);
+    case 8: return process_check_pair_lm<8, FIRST>(msg, scale, aq, k512, tr, ahead);
+    case 9: return process_check_pair_lm<9, FIRST>(msg, scale, aq, k512, tr, ahead);
+    case 10: return process_check_pair_lm<10, FIRST>(msg, scale, aq, k512, tr, ahead);
     default:
       if constexpr (MAXDEG > 10u) {
-        return process_check_pair_lm<19, FIRST>(msg, scale, aq, k512, tr);
+        return process_check_pair_lm<19, FIRST>(msg, scale, aq, k512, tr, ahead);
       }
       return;
   }
@@ -666,7 +670,10 @@ __device__ __forceinline__ void store_record(uint4* rec, uint4 v) // a pair of c
 // layers a codeblock runs leave room for them there, else in the codeblock's slot of the caller's scratch (decided per
 // codeblock; the record path is not part of such a kernel).
 // MAXDEG (LM only): the largest row degree of the base graph -- 19 (base graph 1) or 10 (base graph 2).
-template <bool PAIR, bool LM = false, uint32_t MAXDEG = 19>
+// SLOT_ONLY (LM only): a launch without room for messages in LDS -- every codeblock keeps them in its slot, the first rows of a
+// layer's old messages requested a layer ahead; otherwise the launch's LDS was sized for the messages of the expected layers and
+// only a codeblock that runs more than those (stale soft bits in a HARQ buffer) takes its slot, without the requests ahead.
+template <bool PAIR, bool LM = false, uint32_t MAXDEG = 19, bool SLOT_ONLY = false>
 __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
 {
   // All of the kernel's LDS is the launch's dynamic allocation, the soft bits at its start: with a static variable in front
@@ -829,7 +836,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
     // codeblock from its own soft bits, so the result never depends on the launch's LDS budget.
     const uint32_t msg_off = (cb_len + 48u + 15u) & ~15u;
     // (the table of soft-bit addresses counts from LDS address 0, where this kernel's only LDS array starts)
-    const bool     lm      = LM && p.lm_lds_bytes != 0 && msg_off + graph->pair_ptr[nof_layers] * 2u * zc <= p.lm_lds_bytes;
+    const bool     lm      = LM && !SLOT_ONLY && p.lm_lds_bytes != 0 && msg_off + graph->pair_ptr[nof_layers] * 2u * zc <= p.lm_lds_bytes;
     if (claim_late && !lm && pooled) {
       if (j == 0) {
         s_flag[3] = acquire_slot(p.slot_flags, p.nof_slots, blockIdx.x);
@@ -857,11 +864,12 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
     const uint32_t rec_stride  = PAIR ? half : zc;                       // records of one layer
     const uint32_t minus_half  = 0u - half;
     constexpr uint32_t NQ = MAXDEG > 12u ? 5u : 3u; // rows of four soft-bit addresses a layer can have
-    constexpr uint32_t PF = 5u;                     // rows of messages requested a layer ahead (messages in the slot)
+    constexpr uint32_t PF  = SLOT_ONLY ? 5u : 0u;   // rows of messages requested a layer ahead (messages in the slot)
+    constexpr uint32_t PFA = PF != 0u ? PF : 1u;    // (array extent)
     // (messages kept per edge) the first layer's soft-bit addresses and, in the slot, its old messages: requested at the end of
     // the previous iteration
     uint4    wrap[NQ]    = {};
-    uint32_t wrap_pre[PF] = {};
+    uint32_t wrap_pre[PFA] = {};
     for (uint32_t it = 0; it != max_iterations && iterations == 0; ++it) {
       if constexpr (LM) {
         // The lane's soft-bit addresses of a layer: NQ rows of the table (sixteen bytes per lane and row: four edges),
@@ -870,7 +878,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
         const uint4*   atab = reinterpret_cast<const uint4*>(p.pair_addr) + jj;
         uint32_t*      gmsg = reinterpret_cast<uint32_t*>(slot_mem) + jj; // (messages in the slot) the lane's word of row 0
         uint4          cur[NQ];
-        uint32_t       pre[PF];
+        uint32_t       pre[PFA];
         if (it == 0) {
 #pragma unroll
           for (uint32_t q = 0; q != NQ; ++q) {
@@ -894,32 +902,39 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
         // One layer with the addresses in `now` (and, in the slot, the first rows of its old messages in `pre_now`); the
         // next layer's (after the last: the first's, for the next iteration) are requested into `next` / `pre_next` before
         // the layer starts.  Two calls per trip with the arrays swapped: no copies.
-        auto layer = [&](uint32_t m, const uint4 (&now)[NQ], uint4 (&next)[NQ], const uint32_t (&pre_now)[PF],
-                         uint32_t (&pre_next)[PF]) __attribute__((always_inline)) {
+        auto layer = [&](uint32_t m, const uint4 (&now)[NQ], uint4 (&next)[NQ], const uint32_t (&pre_now)[PFA],
+                         uint32_t (&pre_next)[PFA]) __attribute__((always_inline)) {
           const uint32_t e2  = graph->row_ptr[m + 2u]; // (the array has a spare element) a layer ahead: off the critical path
           const uint32_t deg = e1 - e0;
           const bool     last      = m + 1u == nof_layers;
           const uint32_t rows_next = last ? 0u : rows + ((deg + 1u) >> 1);
           quads                    = last ? 0u : quads + ((deg + 3u) >> 2);
+          auto ahead = [&]() __attribute__((always_inline)) {
 #pragma unroll
-          for (uint32_t q = 0; q != NQ; ++q) {
-            next[q] = atab[(quads + q) * half];
-          }
-          if (!lm) { // workgroup-uniform (the rows read past a layer's own lie inside the slot: it has PF spare rows)
+            for (uint32_t q = 0; q != NQ; ++q) {
+              next[q] = atab[(quads + q) * half];
+            }
+          };
+          if constexpr (PF != 0u) { // (the rows read past a layer's own lie inside the slot: it has five spare rows)
 #pragma unroll
             for (uint32_t r = 0; r != PF; ++r) {
               pre_next[r] = gmsg[(size_t)(rows_next + r) * half];
             }
           }
           if (active) {
-            if (lm) {
-              const MsgLds msg = {msgs + rows * 2u * zc, 2u * zc};
-              if (it == 0) {
-                process_layer_pair_lm<true, MAXDEG>(deg, msg, scale, now, k512, nullptr);
-              } else {
-                process_layer_pair_lm<false, MAXDEG>(deg, msg, scale, now, k512, tr);
+            bool in_lds = false;
+            if constexpr (!SLOT_ONLY) {
+              in_lds = lm; // workgroup-uniform
+              if (lm) {
+                const MsgLds msg = {msgs + rows * 2u * zc, 2u * zc};
+                if (it == 0) {
+                  process_layer_pair_lm<true, MAXDEG>(deg, msg, scale, now, k512, nullptr, ahead);
+                } else {
+                  process_layer_pair_lm<false, MAXDEG>(deg, msg, scale, now, k512, tr, ahead);
+                }
               }
-            } else {
+            }
+            if (!in_lds) {
               MsgSlot<PF> msg;
               msg.row0      = gmsg + (size_t)rows * half;
               msg.row_words = half;
@@ -928,9 +943,9 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
                 msg.pre[r] = pre_now[r];
               }
               if (it == 0) {
-                process_layer_pair_lm<true, MAXDEG>(deg, msg, scale, now, k512, nullptr);
+                process_layer_pair_lm<true, MAXDEG>(deg, msg, scale, now, k512, nullptr, ahead);
               } else {
-                process_layer_pair_lm<false, MAXDEG>(deg, msg, scale, now, k512, tr);
+                process_layer_pair_lm<false, MAXDEG>(deg, msg, scale, now, k512, tr, ahead);
               }
             }
           }
@@ -943,7 +958,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
           e1 = e2;
         };
         uint4    alt[NQ];
-        uint32_t pre_alt[PF];
+        uint32_t pre_alt[PFA];
         for (uint32_t m = 0; m < nof_layers; m += 2u) {
           layer(m, cur, alt, pre, pre_alt);
           if (m + 1u != nof_layers) {
@@ -1095,13 +1110,24 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(NRPHY_DECOD
 // waves per SIMD (all that the LDS of a high-rate launch holds anyway: four workgroups of three waves per CU at BASELINE config
 // 5; with 128 registers the compiler serialises the LDS reads of an edge pass through two temporaries); base graph 2 stops at
 // degree 10 and fits the registers of four.
+#ifndef NRPHY_DECODER_BG1_SLOT_WAVES
+#define NRPHY_DECODER_BG1_SLOT_WAVES 3
+#endif
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3))) void ldpc_decode_msg_bg1_kernel(LdpcDecodeLaunch p)
 {
-  ldpc_decode_body<true, true, 19>(p);
+  ldpc_decode_body<true, true, 19, false>(p);
+}
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(NRPHY_DECODER_BG1_SLOT_WAVES))) void ldpc_decode_msg_bg1_slot_kernel(LdpcDecodeLaunch p)
+{
+  ldpc_decode_body<true, true, 19, true>(p);
 }
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(4))) void ldpc_decode_msg_bg2_kernel(LdpcDecodeLaunch p)
 {
-  ldpc_decode_body<true, true, 10>(p);
+  ldpc_decode_body<true, true, 10, false>(p);
+}
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(4))) void ldpc_decode_msg_bg2_slot_kernel(LdpcDecodeLaunch p)
+{
+  ldpc_decode_body<true, true, 10, true>(p);
 }
 
 constexpr uint32_t LDS_TAIL_BYTES = 16u + 128u;
@@ -1141,25 +1167,19 @@ hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p_in, uint32_t n_cb, hipSt
   }
   p.lds_tail_off = (uint32_t)lds; // the flags and the scaling table behind the soft bits (and messages)
   lds += LDS_TAIL_BYTES;
-  const void*        kernel    = msg     ? (p.bg_k == 22u ? reinterpret_cast<const void*>(ldpc_decode_msg_bg1_kernel)
-                                                          : reinterpret_cast<const void*>(ldpc_decode_msg_bg2_kernel))
-                                 : pairs ? reinterpret_cast<const void*>(ldpc_decode_pairs_kernel)
-                                         : reinterpret_cast<const void*>(ldpc_decode_kernel);
+  typedef void (*kernel_t)(LdpcDecodeLaunch);
+  const bool         in_lds    = p.lm_lds_bytes != 0;
+  const kernel_t     kernel    = msg     ? (p.bg_k == 22u ? (in_lds ? ldpc_decode_msg_bg1_kernel : ldpc_decode_msg_bg1_slot_kernel)
+                                                          : (in_lds ? ldpc_decode_msg_bg2_kernel : ldpc_decode_msg_bg2_slot_kernel))
+                                 : pairs ? ldpc_decode_pairs_kernel
+                                         : ldpc_decode_kernel;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       return e;
     }
   }
-  if (msg && p.bg_k == 22u) {
-    hipLaunchKernelGGL(ldpc_decode_msg_bg1_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
-  } else if (msg) {
-    hipLaunchKernelGGL(ldpc_decode_msg_bg2_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
-  } else if (pairs) {
-    hipLaunchKernelGGL(ldpc_decode_pairs_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
-  } else {
-    hipLaunchKernelGGL(ldpc_decode_kernel, dim3(n_cb), dim3(threads), lds, stream, p);
-  }
+  hipLaunchKernelGGL(kernel, dim3(n_cb), dim3(threads), lds, stream, p);
   return hipGetLastError();
 }
 
