@@ -271,6 +271,9 @@ __device__ __forceinline__ void load_pairs10(uint32_t (&out)[DEG], AddrA addr_a,
   }
 }
 
+// (ds_read_i8_d16 / _d16_hi would place the two bytes in the halves of one register without the v_perm -- not on this device:
+// with SRAM ECC enabled, as on MI300 / MI355X, a d16 load writes the whole register and clears the other half, which is why the
+// compiler never selects them; tried in assembly in round 4, wrong results.)
 template <uint32_t DEG, uint32_t T, bool FIRST>
 struct PairEdges {
   // Pass 1 over edges T .. DEG - 1: v2c messages, running minima, sign bits.
@@ -396,22 +399,45 @@ __device__ __forceinline__ s16x2 llr_sub_pair_first_mad(s16x2 a, uint32_t k512)
   return as_s16x2(pk_mad_i16(as_word(a - d), k512, as_word(d)));
 }
 
-// scale_llr (ldpc_decoder_generic.cpp:69-79) of the magnitudes in bytes 1 and 3 of a pair of keys: A | B << 16.
+// scale_llr (ldpc_decoder_generic.cpp:69-79) of the magnitudes of a pair of keys (magnitude << 5 | edge in each half) ->
+// A | B << 16.  Three rules, each used only where the host has checked that it gives round(m * scaling_factor) for every m the
+// decoder can meet (0 .. LLR_MAX): packed 16-bit fixed point (m * F + 256) >> 9 -- three instructions for both halves --, float
+// arithmetic, or the table in LDS (one more LDS round trip per layer).
 struct ScaleRule {
   const uint8_t* table;      // round(m * scaling_factor), m = 0 .. LLR_MAX
   float          factor;
-  bool           arithmetic; // (unsigned)(m * factor + 0.5f) equals the table for every m (checked by the host)
+  uint32_t       mode;       // 2: fixed point with `fixed`, 1: float arithmetic, 0: the table
+  uint32_t       fixed;      // F in both halves
   __device__ __forceinline__ uint32_t operator()(uint32_t keys) const
   {
-    if (arithmetic) {
-      const float    a  = (float)((keys >> 8) & 0xFFu), b = (float)(keys >> 24);
-      const uint32_t ra = (uint32_t)__fadd_rn(__fmul_rn(a, factor), 0.5f), rb = (uint32_t)__fadd_rn(__fmul_rn(b, factor), 0.5f);
+    const u16x2 m = as_u16x2(keys) >> u16x2{5, 5};
+    if (mode == 2u) {
+      return as_word((m * as_u16x2(fixed) + u16x2{256, 256}) >> u16x2{9, 9});
+    }
+    const uint32_t ma = as_word(m) & 0xFFFFu, mb = as_word(m) >> 16;
+    if (mode == 1u) {
+      const uint32_t ra = (uint32_t)__fadd_rn(__fmul_rn((float)ma, factor), 0.5f), rb = (uint32_t)__fadd_rn(__fmul_rn((float)mb, factor), 0.5f);
       return ra | (rb << 16);
     }
-    const uint32_t sa = table[(keys >> 8) & 0xFFu], sb = table[keys >> 24];
-    return sa | (sb << 16);
+    return (uint32_t)table[ma] | ((uint32_t)table[mb] << 16);
   }
 };
+
+// One-hot masks of the edges holding the minima from a pair of keys (edge index in the low five bits of each half; 31: none, a
+// bit no edge tests).
+template <uint32_t DEG>
+__device__ __forceinline__ void key_one_hot(uint32_t keys, uint32_t& hot0, uint32_t& hot1)
+{
+  if constexpr (DEG <= 16u) { // (edge 31 -> 1 << 15 in a 16-bit shift: bit 15, beyond the edges of such a check)
+    hot0 = as_word(u16x2{1, 1} << (as_u16x2(keys) & u16x2{15, 15}));
+    hot1 = 0;
+  } else {
+    const uint32_t ia = keys & 31u, ib = (keys >> 16) & 31u;
+    const uint32_t ha = 1u << ia, hb = 1u << ib;
+    hot0              = (ha & 0xFFFFu) | (hb << 16);
+    hot1              = (ha >> 16) | (hb & 0xFFFF0000u);
+  }
+}
 
 // -DNRPHY_DEC_TRACE (profiles/probes/decoder_trace_run.py): one wave of one codeblock adds up the cycles between the marks TR(k) of
 // a layer (s_memtime; ~300 cycles of its own per mark) and leaves the sums in the launch's scratch.
@@ -440,10 +466,11 @@ struct LmEdges {
     if constexpr (T < DEG) {
       const s16x2 v = FIRST ? llr_sub_pair_first_mad(as_s16x2(x[T]), k512) : llr_sub_pair_mad(as_s16x2(x[T]), as_s16x2(c[T]), k512);
       x[T]          = as_word(v);
-      const s16x2    mag = __builtin_elementwise_max(v, splat_s16(0) - v);
-      const uint32_t cap = as_word(__builtin_elementwise_min(as_u16x2(as_word(mag)), u16x2{255, 255}));
-      uint32_t key; // cap * 256 + T in both halves: the edge index as an inline constant (as (cap << 8) | literal it costs a move)
-      asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(key) : "v"(cap), "s"(k512 >> 1), "n"(T));
+      // key = magnitude * 32 + T in both halves: ten bits of magnitude (an infinite soft bit's value is below 640) over five of
+      // edge index -- no clamp of the magnitude; the edge index as an inline constant (as (mag << 5) | literal it costs a move)
+      const s16x2 mag = __builtin_elementwise_max(v, splat_s16(0) - v);
+      uint32_t    key;
+      asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(key) : "v"(as_word(mag)), "s"(k512 >> 4), "n"(T));
       k2 = as_word(__builtin_elementwise_min(__builtin_elementwise_max(as_u16x2(key), as_u16x2(k1)), as_u16x2(k2)));
       k1 = as_word(__builtin_elementwise_min(as_u16x2(key), as_u16x2(k1)));
       par ^= as_word(v); // bit 15 of a half: parity of the negative values so far
@@ -555,7 +582,7 @@ __device__ __forceinline__ void process_check_pair_lm(const Msg& msg, const Scal
     }
   }
   TR(3);
-  uint32_t k1 = (((uint32_t)LLR_MAX_V << 8) | 0xFFu) * 0x00010001u, k2 = k1, par = 0;
+  uint32_t k1 = (((uint32_t)LLR_MAX_V << 5) | 31u) * 0x00010001u, k2 = k1, par = 0; // (edge 31: none)
   LmEdges<DEG, 0, FIRST>::forward(c, x, k512, k1, k2, par);
   TR(4);
   // scale_llr of the four minima; the sign of a message = parity of the OTHER signs
@@ -563,7 +590,7 @@ __device__ __forceinline__ void process_check_pair_lm(const Msg& msg, const Scal
   const uint32_t pm = as_word(as_s16x2(par) >> splat_s16(15)); // 0xFFFF in a half with an odd number of negative values
   const uint32_t m1 = as_word(as_s16x2(n1 ^ pm) - as_s16x2(pm)), m2 = as_word(as_s16x2(n2 ^ pm) - as_s16x2(pm));
   uint32_t       hot0, hot1;
-  pair_one_hot(k1 & 0x00FF00FFu, hot0, hot1);
+  key_one_hot<DEG>(k1, hot0, hot1);
   ahead();
   TR(5);
   LmEdges<DEG, 0, FIRST>::backward(msg, addr1, addr2, x, m1, m2, hot0, hot1);
@@ -850,7 +877,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
     const uint32_t max_iterations = (slot == 0xFFFFFFFFu || (LM && soft_a != 0)) ? 0u : p.max_iterations;
     const uint32_t  msgs  = soft_a + msg_off + 4u * j; // LDS address of the lane's word: [row of two edges][lane], four bytes
     const uint32_t  k512  = 0x02000200u;
-    const ScaleRule scale = {s_scaled, p.scaling_factor, p.scale_arithmetic != 0};
+    const ScaleRule scale = {s_scaled, p.scaling_factor, p.scale_arithmetic, p.scale_fixed * 0x00010001u};
 #ifdef NRPHY_DEC_TRACE
     Trace  trace = {};
     Trace* tr    = (blockIdx.x == gridDim.x / 2u && j < 64u) ? &trace : nullptr;

@@ -2524,11 +2524,20 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
     // The scaling of the minima by arithmetic instead of a table look-up, where it gives the table's values
     // (round half away from zero: ldpc_decoder_generic.cpp:69-79).
     p.scale_arithmetic = 1;
+    p.scale_fixed      = (uint32_t)std::lround((double)cfg->scaling_factor * 512.0); // < 512: 120 * F + 256 stays below 2^16
+    bool fixed_ok      = p.scale_fixed < 512;
     for (unsigned m = 0; m <= 120; ++m) {
-      const float x = (float)m * cfg->scaling_factor;
-      if ((uint32_t)(x + 0.5F) != (uint32_t)(uint8_t)roundf(x)) {
+      const float    x    = (float)m * cfg->scaling_factor;
+      const uint32_t want = (uint32_t)(uint8_t)roundf(x);
+      if ((uint32_t)(x + 0.5F) != want) {
         p.scale_arithmetic = 0;
       }
+      if (((m * p.scale_fixed + 256U) & 0xFFFFU) >> 9 != want) {
+        fixed_ok = false;
+      }
+    }
+    if (fixed_ok) {
+      p.scale_arithmetic = 2;
     }
   }
   p.crc_weight     = nullptr;

@@ -288,7 +288,10 @@ struct LdpcDecodeLaunch {
   // Each codeblock decides by the layers its own soft bits ask for whether it fits.
   uint32_t            lm_lds_bytes;
   uint32_t            lds_tail_off;     // set by launch_ldpc_decode(): where the kernel's flags and scaling table sit in its LDS
-  uint32_t            scale_arithmetic; // 1: (unsigned)(m * scaling_factor + 0.5f) == round(m * scaling_factor) for m = 0 .. 120
+  // How the message kernels scale a minimum m = 0 .. 120 to round(m * scaling_factor): 2 = (m * scale_fixed + 256) >> 9 in
+  // 16-bit arithmetic, 1 = (unsigned)(m * scaling_factor + 0.5f), 0 = the table in LDS -- the cheapest the host has verified.
+  uint32_t            scale_arithmetic;
+  uint32_t            scale_fixed;
 };
 hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStream_t stream);
 
