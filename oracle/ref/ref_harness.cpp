@@ -952,4 +952,103 @@ double ref_bench_pdsch(const nrphy_pdsch_pdu_t*   in,
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// CPU baseline of the receive-side coding chain (BASELINE config 5): `threads` workers, each with its own
+// pusch_decoder_impl -- rate dematcher + LDPC decoder (simd 1: ldpc_rate_dematcher_avx2_impl + ldpc_decoder_avx2, the
+// reference's defaults on this host; 0: the generic ones) + codeblock and transport-block CRCs -- and its own receive-buffer
+// pool, decoding the same codeword LLRs `reps` times as new data: the threads x batch scheme of the reference's benchmarks
+// (tests/benchmarks/phy/upper/channel_coding/ldpc/ldpc_decoder_benchmark.cpp:36-182 times ldpc_decoder::decode alone;
+// pdsch_processor_benchmark.cpp:684-737 is the threads x batch harness).  Returns the elapsed seconds for threads * reps
+// transport blocks; *nof_ok receives how many of them passed their CRC.
+double ref_bench_pusch_decode(uint32_t      bg,
+                              uint32_t      qm,
+                              uint32_t      rv,
+                              uint32_t      nof_layers,
+                              uint32_t      nref,
+                              uint32_t      tb_size_bytes,
+                              uint32_t      max_iterations,
+                              int           use_early_stop,
+                              uint32_t      nof_codeblocks,
+                              const int8_t* llr,
+                              uint32_t      nof_llr,
+                              unsigned      threads,
+                              unsigned      reps,
+                              int           simd,
+                              uint32_t*     nof_ok)
+{
+  std::vector<log_likelihood_ratio> soft(nof_llr);
+  for (unsigned i = 0; i != nof_llr; ++i) {
+    soft[i] = log_likelihood_ratio(llr[i]);
+  }
+  pusch_decoder::configuration cfg;
+  cfg.base_graph          = (bg == 1) ? ldpc_base_graph_type::BG1 : ldpc_base_graph_type::BG2;
+  cfg.rv                  = rv;
+  cfg.mod                 = to_mod(qm);
+  cfg.Nref                = nref;
+  cfg.nof_layers          = nof_layers;
+  cfg.nof_ldpc_iterations = max_iterations;
+  cfg.use_early_stop      = use_early_stop != 0;
+  cfg.new_data            = true;
+  std::vector<uint32_t>    ok(threads, 0);
+  std::vector<std::thread> pool;
+  auto                     t0 = std::chrono::steady_clock::now();
+  for (unsigned t = 0; t != threads; ++t) {
+    pool.emplace_back([&, t]() {
+      auto make_crcs = [](auto& set) {
+        set.crc16  = std::make_unique<crc_calculator_lut_impl>(crc_generator_poly::CRC16);
+        set.crc24A = std::make_unique<crc_calculator_lut_impl>(crc_generator_poly::CRC24A);
+        set.crc24B = std::make_unique<crc_calculator_lut_impl>(crc_generator_poly::CRC24B);
+      };
+      pusch_codeblock_decoder::sch_crc cb_crcs;
+      make_crcs(cb_crcs);
+      std::unique_ptr<ldpc_rate_dematcher> dematcher;
+      std::unique_ptr<ldpc_decoder>        ldpc;
+      if (simd) {
+        dematcher = std::make_unique<ldpc_rate_dematcher_avx2_impl>();
+        ldpc      = std::make_unique<ldpc_decoder_avx2>();
+      } else {
+        dematcher = std::make_unique<ldpc_rate_dematcher_impl>();
+        ldpc      = std::make_unique<ldpc_decoder_generic>();
+      }
+      std::vector<std::unique_ptr<pusch_codeblock_decoder>> instances;
+      instances.push_back(std::make_unique<pusch_codeblock_decoder>(std::move(dematcher), std::move(ldpc), cb_crcs));
+      auto decoder_pool = std::make_shared<pusch_decoder_impl::codeblock_decoder_pool>(std::move(instances));
+      pusch_decoder_impl::sch_crc tb_crcs;
+      make_crcs(tb_crcs);
+      pusch_decoder_impl decoder(
+          ldpc_segmenter_impl::create_ldpc_segmenter_impl_rx(), decoder_pool, std::move(tb_crcs), nullptr, 275, 4);
+      rx_buffer_pool_config pool_cfg;
+      pool_cfg.max_codeblock_size   = ldpc::MAX_CODEBLOCK_SIZE;
+      pool_cfg.nof_buffers          = 2;
+      pool_cfg.nof_codeblocks       = 2 * 170;
+      pool_cfg.expire_timeout_slots = 100000;
+      pool_cfg.external_soft_bits   = false;
+      std::unique_ptr<rx_buffer_pool_controller> buffers = create_rx_buffer_pool(pool_cfg);
+      std::vector<uint8_t>                       tb(tb_size_bytes);
+      for (unsigned r = 0; r != reps; ++r) {
+        unique_rx_buffer buffer = buffers->get_pool().reserve(
+            slot_point(1, 0), trx_buffer_identifier(static_cast<uint16_t>(0x4601 + t), 0), nof_codeblocks, true);
+        if (!buffer.is_valid()) {
+          return;
+        }
+        pusch_notifier        notifier;
+        pusch_decoder_buffer& in = decoder.new_data(tb, std::move(buffer), notifier, cfg);
+        in.on_new_softbits(soft);
+        in.on_end_softbits();
+        ok[t] += (notifier.done && notifier.result.tb_crc_ok) ? 1u : 0u;
+      }
+    });
+  }
+  for (auto& th : pool) {
+    th.join();
+  }
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (nof_ok != nullptr) {
+    *nof_ok = 0;
+    for (uint32_t v : ok) {
+      *nof_ok += v;
+    }
+  }
+  return dt;
+}
+
 } // extern "C"

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-early-stop", action="store_true")
     ap.add_argument("--allow-failures", action="store_true", help="do not insist that every transport block decodes")
     ap.add_argument("--all", action="store_true", help="the four legs bench.py reports")
+    ap.add_argument("--cpu-baseline", action="store_true", help="time the reference's CPU decoding chain on the same soft bits")
     ap.add_argument("--sweep", nargs=4, metavar=("LEG", "FROM", "TO", "STEP"), help="mean iterations against SNR")
     args = ap.parse_args()
     if args.sweep:
@@ -87,7 +88,8 @@ def run_all(steps, warmup):
     """The config-5 entry of bench.py: the four legs of the module docstring; the entry's headline `value` is the workload as
     BASELINE.json states it (BG1, 8 iterations, no early stop)."""
     def leg(name, **kw):
-        a = dict(slots=RX_SLOTS, iterations=8, steps=steps, warmup=warmup, snr_db=32.0, leg="bg1", early_stop=True, require_all=True)
+        a = dict(slots=RX_SLOTS, iterations=8, steps=steps, warmup=warmup, snr_db=32.0, leg="bg1", early_stop=True, require_all=True,
+                 cpu_baseline=True)
         a.update(kw)
         return run(argparse.Namespace(**a))
     out = leg("bg1_fixed8", early_stop=False)
@@ -97,6 +99,53 @@ def run_all(steps, warmup):
         "bg1_early_stop": leg("bg1_early_stop"),
     }
     return out
+
+
+def cpu_decode_baseline(pdu, d, iterations, early_stop, llr, budget_s=5.0):
+    """The reference's CPU receive-side coding chain on the same soft bits (one transport block's, as the device chain hands them
+    to its decoder): pusch_decoder_impl with ldpc_rate_dematcher_avx2_impl + ldpc_decoder_avx2 (oracle/_ref, compiled from the
+    reference's sources: ref_bench_pusch_decode), T worker threads each with its own decoder instance, batches of transport
+    blocks per thread -- the scheme of the reference's benchmarks (ldpc_decoder_benchmark.cpp:36-182,
+    pdsch_processor_benchmark.cpp:684-737).  Bounded: about `budget_s` seconds.  None when the compiled reference is absent."""
+    import ctypes as C
+    import backends
+    r = backends.ref()
+    if r is None or not hasattr(r.lib, "ref_bench_pusch_decode"):
+        return None
+    fn = r.lib.ref_bench_pusch_decode
+    fn.restype = C.c_double
+    llr = np.ascontiguousarray(llr, dtype=np.int8)
+    nok = C.c_uint32(0)
+
+    def go(threads, reps):
+        return fn(C.c_uint32(pdu.ldpc_base_graph), C.c_uint32(pdu.qm), C.c_uint32(0), C.c_uint32(pdu.nof_layers), C.c_uint32(d["n_ref"]),
+                  C.c_uint32(pdu.tb_size_bytes), C.c_uint32(iterations), C.c_int(1 if early_stop else 0), C.c_uint32(d["nof_codeblocks"]),
+                  llr.ctypes.data_as(C.c_void_p), C.c_uint32(llr.size), C.c_uint(threads), C.c_uint(reps), C.c_int(1), C.byref(nok))
+
+    def cpu_quota():
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            return None if quota == "max" else float(quota) / float(period)
+        except Exception:
+            return None
+
+    quota, affinity = cpu_quota(), len(os.sched_getaffinity(0))
+    many = max(2, min(affinity, int(quota) if quota else affinity, 64))
+    t1 = go(1, 1)                                   # calibration (and page faults): seconds per transport block, one thread
+    out = {}
+    for threads, share in ((many, 0.6), (1, 0.4)):
+        reps = int(max(1, min(2000, budget_s * share / max(t1, 1e-4))))
+        dt = go(threads, reps)
+        out[threads] = {"threads": threads, "slots_per_sec": round(threads * reps / dt, 2), "tb_per_thread": reps,
+                        "tb_crc_ok": int(nok.value), "of": threads * reps, "seconds": round(dt, 2)}
+    best = max(out.values(), key=lambda e: e["slots_per_sec"])
+    return {"value": best["slots_per_sec"], "unit": "slots/s", "cores": best["threads"], "kind": "reference",
+            "all_threads": out[many], "one_thread": out[1], "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
+            "sample": "one transport block's soft bits (slot 0 of the device leg, after descrambling) through the reference's "
+                      "pusch_decoder_impl (AVX2 rate dematcher + AVX2 LDPC decoder, %d iterations%s, CRCs), %d threads x %d and 1 x %d "
+                      "transport blocks; the coding chain only -- the device leg's value also contains OFDM demodulation, soft "
+                      "demodulation and descrambling" % (iterations, " with early stop" if early_stop else ", no early stop", many,
+                                                         out[many]["tb_per_thread"], out[1]["tb_per_thread"])}
 
 
 def run(args):
@@ -228,7 +277,18 @@ def run(args):
                                 "launch time of this run (the whole nrphy_pusch_decode_batch call: dematcher, decoder, assembly)"}
     except Exception:
         pass
+    cpu = None
+    if getattr(args, "cpu_baseline", False):
+        try:
+            cpu = cpu_decode_baseline(pdu, d, args.iterations, early_stop, d_llr[0].cpu().numpy())
+        except Exception as e:  # the checker is optional at bench time
+            cpu = {"unavailable": str(e)}
+    extra = {}
+    if cpu is not None:
+        extra["cpu_baseline"] = cpu
+        extra["decode_chain_only_slots_per_sec"] = slots / kernel_ms["pusch_decode_batch"] * 1e3  # what cpu_baseline is the counterpart of
     return {
+        **extra,
         "metric": "pusch_rx_slots_per_second", "value": slots / ms * 1e3, "unit": "slots/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int8 LLR / f32 IQ", "data": "synthetic",

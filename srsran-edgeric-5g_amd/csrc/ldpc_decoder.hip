@@ -891,7 +891,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
     const uint32_t rec_stride  = PAIR ? half : zc;                       // records of one layer
     const uint32_t minus_half  = 0u - half;
     constexpr uint32_t NQ = MAXDEG > 12u ? 5u : 3u; // rows of four soft-bit addresses a layer can have
-    constexpr uint32_t PF  = SLOT_ONLY ? 5u : 0u;   // rows of messages requested a layer ahead (messages in the slot)
+    constexpr uint32_t PF  = SLOT_ONLY ? (MAXDEG > 12u ? 5u : 3u) : 0u; // rows of messages requested a layer ahead (messages in the slot)
     constexpr uint32_t PFA = PF != 0u ? PF : 1u;    // (array extent)
     // (messages kept per edge) the first layer's soft-bit addresses and, in the slot, its old messages: requested at the end of
     // the previous iteration
@@ -902,14 +902,16 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
         // The lane's soft-bit addresses of a layer: NQ rows of the table (sixteen bytes per lane and row: four edges),
         // requested a layer ahead.
         const uint32_t jj   = active ? j : half - 1u; // (idle lanes stay inside the tables)
-        const uint4*   atab = reinterpret_cast<const uint4*>(p.pair_addr) + jj;
-        uint32_t*      gmsg = reinterpret_cast<uint32_t*>(slot_mem) + jj; // (messages in the slot) the lane's word of row 0
+        // (uniform base + 32-bit lane index: the loads take their base from scalar registers instead of a 64-bit pointer per
+        // lane and table row held -- or spilled -- across the iteration)
+        const uint4* const atab = reinterpret_cast<const uint4*>(p.pair_addr);
+        uint32_t* const    gmsg = reinterpret_cast<uint32_t*>(slot_mem); // (messages in the slot) row 0
         uint4          cur[NQ];
         uint32_t       pre[PFA];
         if (it == 0) {
 #pragma unroll
           for (uint32_t q = 0; q != NQ; ++q) {
-            cur[q] = atab[q * half];
+            cur[q] = atab[q * half + jj];
           }
 #pragma unroll
           for (uint32_t r = 0; r != PF; ++r) {
@@ -939,13 +941,13 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
           auto ahead = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (uint32_t q = 0; q != NQ; ++q) {
-              next[q] = atab[(quads + q) * half];
+              next[q] = atab[(quads + q) * half + jj];
             }
           };
           if constexpr (PF != 0u) { // (the rows read past a layer's own lie inside the slot: it has five spare rows)
 #pragma unroll
             for (uint32_t r = 0; r != PF; ++r) {
-              pre_next[r] = gmsg[(size_t)(rows_next + r) * half];
+              pre_next[r] = gmsg[(rows_next + r) * half + jj];
             }
           }
           if (active) {
@@ -963,7 +965,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
             }
             if (!in_lds) {
               MsgSlot<PF> msg;
-              msg.row0      = gmsg + (size_t)rows * half;
+              msg.row0      = gmsg + (rows * half + jj);
               msg.row_words = half;
 #pragma unroll
               for (uint32_t r = 0; r != PF; ++r) {
@@ -1116,7 +1118,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
   }
 }
 
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(8))) void ldpc_decode_kernel(LdpcDecodeLaunch p)
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(5))) void ldpc_decode_kernel(LdpcDecodeLaunch p)
 {
   ldpc_decode_body<false>(p);
 }
