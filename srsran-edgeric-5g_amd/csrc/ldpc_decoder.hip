@@ -520,13 +520,14 @@ struct MsgLds {
 };
 template <uint32_t PF>
 struct MsgSlot {
-  uint32_t* row0;      // the lane's word in the layer's first row
+  uint32_t* row0;      // the layer's first row (wave-uniform: the accesses take it as a scalar base, the lane as a 32-bit offset)
   uint32_t  row_words; // lanes per row
+  uint32_t  lane;
   uint32_t  pre[PF != 0 ? PF : 1]; // rows 0 .. PF - 1 as requested a layer ahead
-  __device__ __forceinline__ uint32_t load(uint32_t r) const { return r < PF ? pre[r] : row0[(size_t)r * row_words]; }
+  __device__ __forceinline__ uint32_t load(uint32_t r) const { return r < PF ? pre[r] : (row0 + r * row_words)[lane]; }
   __device__ __forceinline__ void     operator()(uint32_t r, uint32_t word) const
   {
-    __hip_atomic_store(row0 + (size_t)r * row_words, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&(row0 + r * row_words)[lane], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
 
@@ -870,7 +871,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
       }
       __syncthreads();
     }
-    const uint32_t slot = lm ? 0u : s_flag[3];
+    const uint32_t slot = lm ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flag[3]); // (an LDS read: uniform, but not to the compiler)
     uint8_t* const slot_mem = reinterpret_cast<uint8_t*>(p.scratch) + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * p.slot_bytes;
     // no slot: reported as not decoded (and likewise should the soft bits ever not start at LDS address 0, which the table of
     // soft-bit addresses of the message kernels assumes)
@@ -911,7 +912,7 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
         if (it == 0) {
 #pragma unroll
           for (uint32_t q = 0; q != NQ; ++q) {
-            cur[q] = atab[q * half + jj];
+            cur[q] = (atab + q * half)[jj];
           }
 #pragma unroll
           for (uint32_t r = 0; r != PF; ++r) {
@@ -941,13 +942,13 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
           auto ahead = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (uint32_t q = 0; q != NQ; ++q) {
-              next[q] = atab[(quads + q) * half + jj];
+              next[q] = (atab + (quads + q) * half)[jj];
             }
           };
           if constexpr (PF != 0u) { // (the rows read past a layer's own lie inside the slot: it has five spare rows)
 #pragma unroll
             for (uint32_t r = 0; r != PF; ++r) {
-              pre_next[r] = gmsg[(rows_next + r) * half + jj];
+              pre_next[r] = (gmsg + (rows_next + r) * half)[jj];
             }
           }
           if (active) {
@@ -965,8 +966,9 @@ __device__ __forceinline__ void ldpc_decode_body(const LdpcDecodeLaunch& p)
             }
             if (!in_lds) {
               MsgSlot<PF> msg;
-              msg.row0      = gmsg + (rows * half + jj);
+              msg.row0      = gmsg + rows * half;
               msg.row_words = half;
+              msg.lane      = jj;
 #pragma unroll
               for (uint32_t r = 0; r != PF; ++r) {
                 msg.pre[r] = pre_now[r];
