@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: rx_pmc_one.sh <lib.so> <outdir>
-LIB=$1; OUT=$(realpath -m "$2"); mkdir -p "$OUT"; ROOT=$PWD
-cp $LIB srsran-edgeric-5g_amd/csrc/libmi355nrphy.so
+LIB=$(realpath "$1"); OUT=$(realpath -m "$2"); mkdir -p "$OUT"; ROOT=$PWD
+export NRPHY_LIB_SO=$LIB   # the loader's override: the product library in the tree is never overwritten
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU \
   --output-format csv -d "$OUT/a" -- python3 "$ROOT/profiles/rx_chain_bench.py" --no-early-stop --steps 2 --warmup 1 --slots 64 > "$OUT/a.log" 2>&1

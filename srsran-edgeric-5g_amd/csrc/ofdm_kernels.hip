@@ -831,20 +831,26 @@ __global__ void wire_stats_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_s
   p.wire_stats[gp] = st;
 }
 
-// Symbols per workgroup.  Measured at 1024 slots: 1 -> 0.512 ms, 7 (with the register prefetch) -> 0.519 ms; the
-// arithmetic-free probe of the same traffic (profiles/probes/stream_mix.hip) takes 0.495 ms, so the kernel sits at the
-// memory system's rate for this access shape either way and 1 keeps small batches spread over the chip.
+// Symbols per workgroup, the next symbol's grid row requested before the current symbol's butterflies.
+// Complex float output: measured at 1024 slots in round 2, 1 -> 0.512 ms, 7 -> 0.519 ms; in round 4 (A/B on one box, two rounds,
+// profiles/r04_ofdm_spw.txt) 1 -> 0.454 ms, 2 -> 0.51, 4 -> 0.53: the kernel sits at the memory system's rate for its access
+// shape with one symbol per workgroup, and more only take parallelism away (1 also keeps small batches spread over the chip).
+// Complex int16 output (half the store traffic, more arithmetic per sample): 1 -> 0.434-0.444 ms, 2 -> 0.419-0.420,
+// 3 -> 0.411-0.419, 4 -> 0.447-0.452 -- there the row of symbol k + 1 arriving under the butterflies of symbol k pays.
 #ifndef NRPHY_OFDM_SPW
 #define NRPHY_OFDM_SPW 1
 #endif
-constexpr int OFDM_SYMBOLS_PER_WG = NRPHY_OFDM_SPW;
+#ifndef NRPHY_OFDM_SPW_WIRE
+#define NRPHY_OFDM_SPW_WIRE 3
+#endif
+constexpr int OFDM_SYMBOLS_PER_WG = NRPHY_OFDM_SPW, OFDM_SYMBOLS_PER_WG_WIRE = NRPHY_OFDM_SPW_WIRE;
 
 template <int N>
 static hipError_t launch_ofdm_n(const OfdmLaunch& p, uint32_t nof_grids, const uint32_t* d_grid,
                                 const uint32_t* d_slot_index, float2* d_iq, hipStream_t stream)
 {
-  constexpr int SPW    = OFDM_SYMBOLS_PER_WG;
   if (p.wire) {
+    constexpr int SPW = OFDM_SYMBOLS_PER_WG_WIRE;
     hipLaunchKernelGGL((ofdm_kernel<N, SPW, true>), dim3((p.nsymb + SPW - 1) / SPW, p.nof_ports, nof_grids), dim3(Plan<N>::T), 0,
                        stream, p, d_grid, d_slot_index, d_iq);
     if (p.wire_stats != nullptr) {
@@ -853,6 +859,7 @@ static hipError_t launch_ofdm_n(const OfdmLaunch& p, uint32_t nof_grids, const u
                          (p.nsymb + SPW - 1) / SPW);
     }
   } else {
+    constexpr int SPW = OFDM_SYMBOLS_PER_WG;
     hipLaunchKernelGGL((ofdm_kernel<N, SPW, false>), dim3((p.nsymb + SPW - 1) / SPW, p.nof_ports, nof_grids), dim3(Plan<N>::T), 0,
                        stream, p, d_grid, d_slot_index, d_iq);
   }
