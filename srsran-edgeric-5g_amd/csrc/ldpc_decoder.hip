@@ -21,7 +21,6 @@
 // rates --, decided per codeblock; see "messages kept per edge in LDS" below).
 #include "bits_device.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace nrphy {
@@ -1174,9 +1173,8 @@ hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p_in, uint32_t n_cb, hipSt
     return hipSuccess;
   }
   LdpcDecodeLaunch p = p_in;
-  // NRPHY_DECODER_PAIRS=0: one check per lane whatever the lifting size (A/B runs; the results are identical).
-  const char*        pairs_env = std::getenv("NRPHY_DECODER_PAIRS"); // (read per launch: the tests run every form in one process)
-  const bool         pairs     = (p.zc & 1u) == 0 && p.zc >= 4u && !(pairs_env != nullptr && pairs_env[0] == '0');
+  // NRPHY_DECODER_PAIRS=0 (read when the context is created): one check per lane whatever the lifting size (A/B runs; the results are identical).
+  const bool         pairs     = (p.zc & 1u) == 0 && p.zc >= 4u && p.knob_pairs != 0;
   const uint32_t     checks    = pairs ? p.zc / 2u : p.zc;
   const uint32_t     threads   = ((checks + WAVE - 1) / WAVE) * WAVE;
   size_t             lds       = ldpc_decode_lds_bytes(p);
@@ -1184,13 +1182,10 @@ hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p_in, uint32_t n_cb, hipSt
   // Behind the soft bits in LDS when the expected layers leave the CU at least twelve wavefronts (three per SIMD, where the
   // edge passes still hide their LDS round trips) -- NRPHY_DECODER_LDSMSG=2: whenever a workgroup's LDS can hold them at all
   // (tests), =0: never --, else in the codeblock's slot of the scratch.
-  const char*        msg_env   = std::getenv("NRPHY_DECODER_MSG");
-  const bool         msg       = pairs && p.pair_addr != nullptr && (p.bg_k == 22u || p.bg_k == 10u) &&
-                                 !(msg_env != nullptr && msg_env[0] == '0');
-  const char*        lm_env    = std::getenv("NRPHY_DECODER_LDSMSG");
+  const bool         msg       = pairs && p.pair_addr != nullptr && (p.bg_k == 22u || p.bg_k == 10u) && p.knob_msg != 0;
   const uint32_t     waves     = threads / WAVE;
-  const uint32_t     lm_cap    = (lm_env != nullptr && lm_env[0] == '2') ? 160u * 1024u : ((160u * 1024u) / ((12u + waves - 1u) / waves)) & ~255u;
-  if (msg && p.lm_lds_bytes != 0 && p.lm_lds_bytes + LDS_TAIL_BYTES <= lm_cap && !(lm_env != nullptr && lm_env[0] == '0')) {
+  const uint32_t     lm_cap    = p.knob_ldsmsg == 2 ? 160u * 1024u : ((160u * 1024u) / ((12u + waves - 1u) / waves)) & ~255u;
+  if (msg && p.lm_lds_bytes != 0 && p.lm_lds_bytes + LDS_TAIL_BYTES <= lm_cap && p.knob_ldsmsg != 0) {
     lds            = lds > p.lm_lds_bytes ? lds : (size_t)p.lm_lds_bytes;
     p.lm_lds_bytes = (uint32_t)lds;
   } else {

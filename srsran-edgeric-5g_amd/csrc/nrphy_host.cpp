@@ -701,6 +701,29 @@ extern "C" uint32_t nrphy_ofdm_slot_size(const nrphy_ofdm_config_t* cfg, uint32_
 // Context
 // ================================================================================================================
 
+Tunables read_tunables()
+{
+  Tunables t;
+  auto     number = [](const char* name, int unset) {
+    const char* e = std::getenv(name);
+    return (e != nullptr && e[0] != 0) ? std::atoi(e) : unset;
+  };
+  t.cb_dispatch       = number("NRPHY_CB_DISPATCH", 0);
+  t.crc_regions       = number("NRPHY_CRC_REGIONS", 0);
+  t.scr_parts_big     = number("NRPHY_SCR_PARTS_BIG", 0);
+  t.extras_nt         = (uint32_t)number("NRPHY_EXTRAS_NT", 1);
+  t.prologue_order    = (uint32_t)number("NRPHY_PROLOGUE_ORDER", 0);
+  t.decoder_pairs     = number("NRPHY_DECODER_PAIRS", -1);
+  t.decoder_msg       = number("NRPHY_DECODER_MSG", -1);
+  t.decoder_ldsmsg    = number("NRPHY_DECODER_LDSMSG", -1);
+  t.decoder_slots_all = number("NRPHY_DECODER_SLOTS_ALL", 0) == 1;
+#ifdef NRPHY_PROBES
+  t.profile_stage = (uint32_t)number("NRPHY_PROFILE_STAGE", 0);
+  t.ofdm_probe    = (uint32_t)number("NRPHY_OFDM_PROBE", 0);
+#endif
+  return t;
+}
+
 extern "C" int nrphy_create(nrphy_ctx_t** out, int device_id)
 {
   if (out == nullptr) {
@@ -717,6 +740,7 @@ extern "C" int nrphy_create(nrphy_ctx_t** out, int device_id)
     return NRPHY_ERR_CAPACITY;
   }
   ctx->device = device_id;
+  ctx->tune   = read_tunables();
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -1155,11 +1179,10 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
       const CrcField& f = (d.nof_tb_crc_bits == 16) ? CRC16_FIELD : CRC24A_FIELD;
       const uint32_t  n = pdu.tb_size_bytes;
       const uint32_t  regions = divide_ceil(n, TB_CRC_REGION_BYTES);
-      const char*     per_env = std::getenv("NRPHY_CRC_REGIONS"); // (A/B and test knob, read per plan: regions per workgroup)
       const uint32_t  want  = std::max<uint32_t>(1, std::min<uint32_t>(regions, TB_CRC_TARGET_WORK / std::max<uint32_t>(1, n_pdu)));
       uint32_t        per   = std::min<uint32_t>(TB_CRC_MAX_REGIONS_PER_WORK, divide_ceil(regions, want));
-      if (per_env) {
-        per = std::max(1, std::min((int)TB_CRC_MAX_REGIONS_PER_WORK, std::atoi(per_env)));
+      if (ctx->tune.crc_regions > 0) { // (A/B and test knob: regions per workgroup)
+        per = std::max(1, std::min((int)TB_CRC_MAX_REGIONS_PER_WORK, ctx->tune.crc_regions));
       }
       pd.crc_first      = (uint32_t)crc_work.size();
       pd.crc_count      = divide_ceil(regions, per);
@@ -1211,8 +1234,8 @@ int plan_create(nrphy_ctx_t* ctx, uint32_t n_pdu, const nrphy_pdsch_pdu_t* pdus,
       // A big batch has enough PDUs to fill the device with one workgroup each (seeding a generator is the costly
       // part: measured 0.111 / 0.098 / 0.096 ms per 1024 config-3 PDUs with 4 / 2 / 1 parts); a small one is split
       // for latency.
-      const char*        parts_env = std::getenv("NRPHY_SCR_PARTS_BIG"); // (A/B and test knob, read per plan: parts of a sequence in a big batch)
-      const uint32_t     parts_big = parts_env ? std::max(1, std::min((int)SCR_PARTS, std::atoi(parts_env))) : 1U;
+      // (A/B and test knob: parts of a sequence in a big batch)
+      const uint32_t     parts_big = ctx->tune.scr_parts_big > 0 ? (uint32_t)std::min((int)SCR_PARTS, ctx->tune.scr_parts_big) : 1U;
       const uint32_t parts_max = n_pdu >= 128 ? parts_big : SCR_PARTS;
       const uint32_t parts     = std::min<uint32_t>(parts_max, std::max<uint32_t>(1, pd.scr_words >> 11));
       const uint32_t chunk = divide_ceil(pd.scr_words, parts);
@@ -1532,22 +1555,21 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.grid_nof_subc  = plan->grid_nof_subc;
   p.lds_lin_words  = plan->lds_lin_words;
   p.lds_u_words    = plan->lds_u_words;
-  {
-    // Profiling aid: stop the codeblock waves after a stage to time the stages apart (outputs are then incomplete).
-    static const char* stage_env = std::getenv("NRPHY_PROFILE_STAGE");
-    p.profile_stage              = stage_env ? (uint32_t)std::atoi(stage_env) : 0;
-    // Store policy of the DM-RS / zero-fill waves at the tail of the codeblock launch: non-temporal (NRPHY_EXTRAS_NT=0: default
-    // policy).  It moves time from the OFDM launch that follows to the codeblock launch.  Before the OFDM launch took its grids
-    // last to first the balance depended on the box (+1.2 % whole step where the OFDM launch is slow, 0 ... -1 % where it is
-    // fast); with that order, A/B on one box, two rounds (profiles/r03_codeblock_experiments.txt): codeblock 0.301 -> 0.314 ms,
-    // OFDM 0.500 -> 0.466 ms, whole step +2.0 %.
-    // (Placing those waves first or between the codeblock waves instead: the codeblock launch 0.44 / 0.46 ms -- their stores push
-    // the transport blocks and sequences out of the cache.)
-    static const char* nt_env = std::getenv("NRPHY_EXTRAS_NT");
-    p.extras_nt               = nt_env ? (uint32_t)std::atoi(nt_env) : 1;
-    static const char* order_env = std::getenv("NRPHY_PROLOGUE_ORDER");
-    p.prologue_order             = order_env ? (uint32_t)std::atoi(order_env) : 0;
-  }
+  // Store policy of the DM-RS / zero-fill waves at the tail of the codeblock launch: non-temporal (NRPHY_EXTRAS_NT=0: default
+  // policy).  It moves time from the OFDM launch that follows to the codeblock launch.  Before the OFDM launch took its grids
+  // last to first the balance depended on the box (+1.2 % whole step where the OFDM launch is slow, 0 ... -1 % where it is
+  // fast); with that order, A/B on one box, two rounds (profiles/r03_codeblock_experiments.txt): codeblock 0.301 -> 0.314 ms,
+  // OFDM 0.500 -> 0.466 ms, whole step +2.0 %.
+  // (Placing those waves first or between the codeblock waves instead: the codeblock launch 0.44 / 0.46 ms -- their stores push
+  // the transport blocks and sequences out of the cache.)
+  p.extras_nt      = ctx->tune.extras_nt;
+  p.prologue_order = ctx->tune.prologue_order;
+#ifdef NRPHY_PROBES
+  // Profiling variant: stop the codeblock waves after a stage to time the stages apart (outputs are then incomplete).
+  p.profile_stage = ctx->tune.profile_stage;
+#else
+  p.profile_stage = 0;
+#endif
   const size_t cw_bytes = (size_t)(plan->cw_bits / 8);
   if (d_cw_rm) {
     HIP_TRY(hipMemsetAsync(d_cw_rm, 0, cw_bytes, s));
@@ -1567,8 +1589,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   {
     const TraceRange trace_cb("CB batch");
     // NRPHY_CB_DISPATCH: 1 = the one-launch mixed kernel, 2 = one launch per (Qm, layers) bucket, unset = by plan shape.
-    const char* dispatch_env = std::getenv("NRPHY_CB_DISPATCH");
-    const int   dispatch     = dispatch_env ? std::atoi(dispatch_env) : 0;
+    const int   dispatch     = ctx->tune.cb_dispatch;
     uint32_t    nof_buckets  = 0;
     hipStream_t streams[1 + nrphy_pdsch_plan::MAX_AUX] = {s};
     uint32_t    n_streams = 1;
@@ -2381,12 +2402,8 @@ bool decoder_scratch_layout(const nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg
   const uint32_t waves    = divide_ceil(zc, 64);
   const uint32_t resident = ctx->nof_cus * (32U / waves) + ctx->nof_cus;
   s.nof_slots             = std::min<uint32_t>(n_cb, resident);
-  {
-    // Profiling aid (profiles/): a slot per codeblock, i.e. no pooling.
-    static const char* all_env = std::getenv("NRPHY_DECODER_SLOTS_ALL");
-    if (all_env != nullptr && all_env[0] == '1') {
-      s.nof_slots = n_cb;
-    }
+  if (ctx->tune.decoder_slots_all) { // profiling aid (profiles/): a slot per codeblock, i.e. no pooling
+    s.nof_slots = n_cb;
   }
   // A slot holds a codeblock's check records (8 bytes per lifted check and layer) or, with two checks per lane, its messages
   // per edge: rows of two edges, 2 Zc bytes each, five spare rows (the kernel requests five rows from a layer's first).
@@ -2501,6 +2518,9 @@ int ldpc_decode_batch(nrphy_ctx_t* ctx, const nrphy_ldpc_decoder_cfg_t* cfg, uin
   p.skip           = d_skip;
   p.ok_flags       = d_ok_flags;
   p.crc_at_end     = crc_at_end ? 1U : 0U;
+  p.knob_pairs     = ctx->tune.decoder_pairs;
+  p.knob_msg       = ctx->tune.decoder_msg;
+  p.knob_ldsmsg    = ctx->tune.decoder_ldsmsg;
   {
     // LDS for the messages-per-edge form (ldpc_decoder.hip) at the expected extent: the soft bits of the layers it needs (the
     // kernel's own rule: ldpc_decoder_impl.cpp:88-116), then one byte per edge and lifted check of those layers.
@@ -3260,11 +3280,11 @@ int ofdm_run(nrphy_ofdm_plan_t* plan, uint32_t nof_grids, const void* d_grid, co
   p.phase       = plan->d_phase;
   p.cp_len      = plan->d_cp;
   p.sym_offset  = plan->d_off;
-  {
-    // Profiling aid (profiles/): 1 = drop the IQ stores, 2 = drop the grid loads, 3 = both (outputs are then wrong).
-    static const char* probe_env = std::getenv("NRPHY_OFDM_PROBE");
-    p.probe                      = probe_env ? (uint32_t)std::atoi(probe_env) : 0;
-  }
+#ifdef NRPHY_PROBES
+  p.probe = ctx->tune.ofdm_probe; // profiling variant: 1 = drop the IQ stores, 2 = drop the grid loads, 3 = both (outputs are then wrong)
+#else
+  p.probe = 0;
+#endif
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   if (wire != nullptr) {
     AmplitudeParams a;

@@ -75,8 +75,30 @@ hipError_t upload(T** dptr, const void* src, size_t bytes)
 
 } // namespace
 
+// Environment knobs (INTEGRATION.md section 5 lists them): A/B and test aids, none changes a result.  Read ONCE, when the
+// context is created -- never on a submit path, where several threads of the host may be running -- so a process that wants
+// another setting creates another context.  -1 / 0 = not set.
+struct Tunables {
+  int      cb_dispatch     = 0;  // NRPHY_CB_DISPATCH: 1 = the mixed codeblock kernel, 2 = one launch per bucket, 0 = by plan shape
+  int      crc_regions     = 0;  // NRPHY_CRC_REGIONS: 16 KiB regions per TB-CRC workgroup (0: by batch size)
+  int      scr_parts_big   = 0;  // NRPHY_SCR_PARTS_BIG: parts per scrambling sequence in a batch of 128 PDUs or more (0: 1)
+  uint32_t extras_nt       = 1;  // NRPHY_EXTRAS_NT=0: DM-RS / zero-fill stores with the default cache policy
+  uint32_t prologue_order  = 0;  // NRPHY_PROLOGUE_ORDER=1: sequence workgroups spread among the TB-CRC workgroups
+  int      decoder_pairs   = -1; // NRPHY_DECODER_PAIRS=0: one check per lane whatever the lifting size
+  int      decoder_msg     = -1; // NRPHY_DECODER_MSG=0: compressed check records instead of messages per edge
+  int      decoder_ldsmsg  = -1; // NRPHY_DECODER_LDSMSG: 0 = messages never in LDS, 2 = wherever a workgroup's LDS can hold them
+  bool     decoder_slots_all = false; // NRPHY_DECODER_SLOTS_ALL=1: a scratch slot per codeblock (no pooling)
+#ifdef NRPHY_PROBES
+  // Profiling variants only (profiles/make_variant.sh ... -DNRPHY_PROBES): with these set the outputs are INCOMPLETE.
+  uint32_t profile_stage   = 0;  // NRPHY_PROFILE_STAGE: the codeblock waves stop after a stage
+  uint32_t ofdm_probe      = 0;  // NRPHY_OFDM_PROBE: bit 0 drops the IQ stores, bit 1 the grid loads, bit 2 takes the grids first to last
+#endif
+};
+Tunables read_tunables();
+
 struct nrphy_ctx {
   int          device   = 0;
+  Tunables     tune;
   uint32_t     nof_cus  = 256; // compute units of the device (sizes the decoder's scratch pool)
   hipStream_t  stream   = nullptr;
   LiftedGraph* d_graphs = nullptr;

@@ -292,6 +292,9 @@ struct LdpcDecodeLaunch {
   // 16-bit arithmetic, 1 = (unsigned)(m * scaling_factor + 0.5f), 0 = the table in LDS -- the cheapest the host has verified.
   uint32_t            scale_arithmetic;
   uint32_t            scale_fixed;
+  // The context's A/B knobs (Tunables): -1 = not set.  pairs 0: one check per lane; msg 0: check records instead of messages;
+  // ldsmsg 0: messages never in LDS, 2: wherever a workgroup's LDS can hold them.
+  int                 knob_pairs, knob_msg, knob_ldsmsg;
 };
 hipError_t launch_ldpc_decode(const LdpcDecodeLaunch& p, uint32_t n_cb, hipStream_t stream);
 

@@ -12,6 +12,14 @@
 
 #include <type_traits>
 
+// Probes of the profiling variants (-DNRPHY_PROBES, see pdsch_kernels.hip): bit 0 drops the IQ stores, bit 1 the grid loads
+// (buffer ranges of zero bytes), bit 2 takes the grids first to last.  Not in the product library.
+#ifdef NRPHY_PROBES
+#define NRPHY_PROBE(p) ((p).probe)
+#else
+#define NRPHY_PROBE(p) 0u
+#endif
+
 namespace nrphy {
 
 template <uint32_t V>
@@ -700,7 +708,7 @@ __device__ __forceinline__ void load_symbol_row(uint32_t (&raw)[Plan<N>::R0], co
                                                 const uint32_t* row, uint32_t t4)
 {
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint32_t*>(row), 0, (int)((p.probe & 2u) ? 0u : p.rg_size * 4u), 0x00020000);
+      const_cast<uint32_t*>(row), 0, (int)((NRPHY_PROBE(p) & 2u) ? 0u : p.rg_size * 4u), 0x00020000);
 #pragma unroll
   for (int k = 0; k != Plan<N>::R0; ++k) {
     uint32_t off = t4 + (uint32_t)k * (N / Plan<N>::R0) * 4u; // byte offset of element (i + rg / 2) mod N
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(Plan<N>::T) OFDM_OCCUPANCY void ofdm_kernel(OfdmLau
   // memory-side cache still holds of them is the end (A/B on one box, three rounds: this launch 0.504 -> 0.496 ms, the whole
   // step +1.1 %; with non-temporal DM-RS / zero-fill stores 0.481 -> 0.467 ms; profiles/r03_codeblock_experiments.txt).
   // NRPHY_OFDM_PROBE bit 2 restores first to last.
-  const uint32_t    gz   = (p.probe & 4u) ? blockIdx.z : gridDim.z - 1u - blockIdx.z;
+  const uint32_t    gz   = (NRPHY_PROBE(p) & 4u) ? blockIdx.z : gridDim.z - 1u - blockIdx.z;
   const uint32_t    gp   = gz * p.nof_ports + blockIdx.y; // grid * nof_ports + port
   const uint32_t    slot = d_slot_index ? to_constant(d_slot_index)[gz] : 0u;
   const uint32_t    t4   = (tid + (p.rg_size >> 1)) * 4u;
@@ -763,14 +771,14 @@ __global__ __launch_bounds__(Plan<N>::T) OFDM_OCCUPANCY void ofdm_kernel(OfdmLau
       // complex int16 out: [grid][port][slot_stride] samples of 4 bytes
       uint32_t* iq16 = reinterpret_cast<uint32_t*>(d_iq) + (size_t)gp * p.slot_stride + to_constant(p.sym_offset)[sym];
       const __amdgpu_buffer_rsrc_t rsrc_out =
-          __builtin_amdgcn_make_buffer_rsrc(iq16, 0, (int)((p.probe & 1u) ? 0u : (N + cp) * 4u), 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc(iq16, 0, (int)((NRPHY_PROBE(p) & 1u) ? 0u : (N + cp) * 4u), 0x00020000);
       // no clipping = a ceiling nothing exceeds
       const IqSinkCi16<N> store = {rsrc_out, ph, cp, p.wire_gain, p.wire_clip != 0 ? p.wire_ceiling : __builtin_inff(), p.wire_scale,
                                    p.wire_limit, &w_sum, &w_peak, &w_clipped};
       fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
     } else {
       const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(
-          iq + to_constant(p.sym_offset)[sym], 0, (int)((p.probe & 1u) ? 0u : (N + cp) * 8u), 0x00020000);
+          iq + to_constant(p.sym_offset)[sym], 0, (int)((NRPHY_PROBE(p) & 1u) ? 0u : (N + cp) * 8u), 0x00020000);
       const IqSink<N> store = {rsrc_out, ph, cp};
       fft_from_registers<+1, N>(cur, tb, lds, p.twiddle, tid, store);
     }

@@ -18,6 +18,15 @@
 #define NRPHY_PHASE_A_STAGED 1
 #endif
 
+// Stage stops of the profiling variants (profiles/make_variant.sh NAME "pdsch_kernels.hip ofdm_kernels.hip nrphy_host.cpp"
+// "-DNRPHY_PROBES"; profiles/stage_pmc.sh, stage_times.sh): the codeblock waves return after stage n, the outputs are then
+// incomplete.  The product library is built without them -- the tests compile to nothing.
+#ifdef NRPHY_PROBES
+#define NRPHY_STAGE(p) ((p).profile_stage)
+#else
+#define NRPHY_STAGE(p) 0u
+#endif
+
 namespace nrphy {
 
 // ================================================================================================================
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
   NRPHY_WG_TRACE_MARK(0);
   NRPHY_WG_TRACE_WHERE(scr_role ? 1 : 2);
   if (scr_role) { // workgroup-uniform
-    if (p.profile_stage == 8) {
+    if (NRPHY_STAGE(p) == 8) {
       return;
     }
     const auto*    swc   = to_constant(&p.scr_work[scr_index]);
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(TB_CRC_THREADS) void prologue_kernel(PdschLaunch p,
     return;
   }
 
-  if (p.profile_stage == 9) {
+  if (NRPHY_STAGE(p) == 9) {
     return;
   }
   const auto*     wkc = to_constant(&p.crc_work[crc_index]);
@@ -217,6 +226,24 @@ struct CbShared {
   LdpcScratch* ldpc; // u + LDPC_DBL_WORDS
 };
 
+// Bounding experiment of round 4 (profiles/r04_lds_conflicts.txt; variant builds only, the results are then WRONG): what the
+// LDS bank conflicts of the data-indexed table look-ups cost.  NRPHY_LDS_PROBE bit 0: the modulation table is read at the
+// lane's own entry, bit 1: the codeblock CRC's byte tables likewise -- the same instructions and dependences (the index still
+// depends on the data through an opaque zero), consecutive addresses instead of data-dependent ones: no conflicts.
+#ifndef NRPHY_LDS_PROBE
+#define NRPHY_LDS_PROBE 0
+#endif
+__device__ __forceinline__ uint32_t lds_probe_index(uint32_t idx, uint32_t bit)
+{
+  if ((NRPHY_LDS_PROBE >> bit) & 1) {
+    uint32_t zero = 0;
+    asm volatile("" : "+v"(zero));
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return (idx & zero) + lane;
+  }
+  return idx;
+}
+
 // reg <- CRC24B register after the 32 bits of `word`: independent look-ups (tab[k][b] = (b x^(8k) x^24) mod g) instead of
 // four dependent byte steps.
 __device__ __forceinline__ uint32_t crc24_word_step(const uint32_t* tab, uint32_t reg, uint32_t word)
@@ -226,8 +253,8 @@ __device__ __forceinline__ uint32_t crc24_word_step(const uint32_t* tab, uint32_
   return tab[v & 0xFFu] ^ tab[256u + ((v >> 8) & 0xFFu)] ^ tab[512u + ((v >> 16) & 0xFFu)] ^ tab[768u + (v >> 24)];
 #else
   const uint32_t v = reg ^ (word >> 8); // 24 bits through three tables, then the last byte
-  uint32_t       r = tab[v & 0xFFu] ^ tab[256u + ((v >> 8) & 0xFFu)] ^ tab[512u + (v >> 16)];
-  return ((r << 8) & 0xFFFFFFu) ^ tab[((r >> 16) ^ word) & 0xFFu];
+  uint32_t       r = tab[lds_probe_index(v & 0xFFu, 1)] ^ tab[256u + lds_probe_index((v >> 8) & 0xFFu, 1)] ^ tab[512u + lds_probe_index(v >> 16, 1)];
+  return ((r << 8) & 0xFFFFFFu) ^ tab[lds_probe_index(((r >> 16) ^ word) & 0xFFu, 1)];
 #endif
 }
 
@@ -655,7 +682,7 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
   // no 64-bit address arithmetic in the vector unit.  (Profiling aid, NRPHY_PROFILE_STAGE=11: a zero-sized descriptor
   // drops the data stores, everything else runs.)
   const __amdgpu_buffer_rsrc_t grid_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      d_grid + grid_base, 0, (int)(p.profile_stage == 11 ? 0u : p.grid_nof_ports * plane_words * 4u), 0x00020000);
+      d_grid + grid_base, 0, (int)(NRPHY_STAGE(p) == 11 ? 0u : p.grid_nof_ports * plane_words * 4u), 0x00020000);
   cf2 wu[P > 0 ? P : 1][L];
   if constexpr (P > 0) {
     const float NRPHY_CONSTANT* wuni = to_constant(p.weights + pd.weights_offset);
@@ -752,7 +779,7 @@ __device__ __forceinline__ void phase_b_grid(const PdschLaunch& p, PduRef pd, co
     for (int l = 0; l != L; ++l) {
       const uint32_t raw   = ((bytes >> (24 - 8 * l)) & 0xFFu) >> (8 - QM);
       const uint32_t idx   = raw ^ ((gbits >> (32 - (l + 1) * QM)) & ((1u << QM) - 1u));
-      const float2   point = reinterpret_cast<const float2*>(sh.u)[idx];
+      const float2   point = reinterpret_cast<const float2*>(sh.u)[lds_probe_index(idx, 0)];
       x[l]                 = cf2{point.x, point.y};
     }
     if constexpr (P > 0) {
@@ -841,7 +868,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
   g.E     = is_long ? pd.e_long : pd.e_short;
   g.cw_cb = is_long ? pd.n_short * pd.e_short + (wk.cb - pd.n_short) * pd.e_long : wk.cb * pd.e_short;
   g.bit0  = g.cw_cb + wk.re_begin * (uint32_t)(QM * L);
-  if (p.profile_stage == 3) {
+  if (NRPHY_STAGE(p) == 3) {
     return;
   }
   ChunkMap cm;
@@ -860,7 +887,7 @@ __device__ __forceinline__ void map_chunk(const PdschLaunch& p, PduRef pd, const
       phase_a<QM, L, false>(p, pd, wk, sh, g.E, lane);
     }
   }
-  if (p.profile_stage == 4) {
+  if (NRPHY_STAGE(p) == 4) {
     return;
   }
   NRPHY_WG_TRACE_MARK(3); // rate matched and interleaved
@@ -1163,7 +1190,7 @@ __device__ __forceinline__ bool codeblock_front(const PdschLaunch& p, PduRef pd,
                                                 const uint8_t* __restrict__ d_tb, uint32_t lane)
 {
   const uint32_t zc = pd.zc, kb = pd.kb;
-  if (p.profile_stage == 5 || p.profile_stage == 6) {
+  if (NRPHY_STAGE(p) == 5 || NRPHY_STAGE(p) == 6) {
     return false;
   }
   const uint32_t total_words = (((kb + pd.nof_rows) * zc + 31u) >> 5) + 2u;
@@ -1172,15 +1199,15 @@ __device__ __forceinline__ bool codeblock_front(const PdschLaunch& p, PduRef pd,
   GraphRows rows;
   rows.fetch(&p.graphs[pd.graph], pd.nof_rows, lane);
   build_codeblock(pd, wk.cb, reinterpret_cast<const uint32_t*>(d_tb + pd.tb_offset), p.tb_crc_part, p.gold, &sh,
-                  total_words, lane, p.profile_stage);
-  if (p.profile_stage == 1 || p.profile_stage == 7) {
+                  total_words, lane, NRPHY_STAGE(p));
+  if (NRPHY_STAGE(p) == 1 || NRPHY_STAGE(p) == 7) {
     return false;
   }
   NRPHY_WG_TRACE_MARK(1); // codeblock built (segmentation, CRCs)
   rows.store(pd.nof_rows, sh.graph, lane); // (build_codeblock ends with a wave barrier; ldpc_encode_wave synchronises before it reads)
   ldpc_encode_wave(&p.graphs[pd.graph], sh.graph, kb, zc, pd.nof_rows, sh.lin, sh.u, sh.ldpc, lane);
   NRPHY_WG_TRACE_MARK(2); // encoded
-  return p.profile_stage != 2;
+  return NRPHY_STAGE(p) != 2;
 }
 
 template <int QM, int L>
@@ -1197,7 +1224,7 @@ __global__ __launch_bounds__(WAVE * CB_WAVES) void codeblock_kernel_t(PdschLaunc
   sh.symb  = sh.u + CB_U_QAM_WORDS;
   sh.graph = sh.u + CB_U_GRAPH_OFFSET;
   sh.ldpc  = reinterpret_cast<LdpcScratch*>(sh.u + LDPC_DBL_WORDS);
-  if (p.profile_stage == 10 || extra_wave(p, w, d_grid)) {
+  if (NRPHY_STAGE(p) == 10 || extra_wave(p, w, d_grid)) {
     return;
   }
   const uint32_t item = xcd_work_item(p.n_work, w);
@@ -1229,7 +1256,7 @@ __global__ __launch_bounds__(WAVE * CB_WAVES) void codeblock_kernel(PdschLaunch 
   sh.symb  = sh.u + CB_U_QAM_WORDS;
   sh.graph = sh.u + CB_U_GRAPH_OFFSET;
   sh.ldpc  = reinterpret_cast<LdpcScratch*>(sh.u + LDPC_DBL_WORDS);
-  if (p.profile_stage == 10 || extra_wave(p, w, d_grid)) {
+  if (NRPHY_STAGE(p) == 10 || extra_wave(p, w, d_grid)) {
     return;
   }
   const uint32_t item = xcd_work_item(p.n_work, w);

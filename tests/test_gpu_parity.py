@@ -263,15 +263,14 @@ def test_pdsch_batched_plan_mixed_cell(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("regions", ["1", "2", "3", "8"])
 @pytest.mark.parametrize("parts", ["1", "4"])
-def test_pdsch_prologue_work_split(gpu_ctx, oracle, regions, parts, monkeypatch):
-    """The prologue's work lists however they are cut (knobs read per plan): a TB-CRC workgroup per 1 / 2 / 3 / 8 regions of
+def test_pdsch_prologue_work_split(gpu_ctx_for, oracle, regions, parts):
+    """The prologue's work lists however they are cut (knobs of the context): a TB-CRC workgroup per 1 / 2 / 3 / 8 regions of
     16 KiB (the next region's words in flight), a scrambling sequence in one or four parts -- transport blocks of one and of
     many regions, with CRC16 and CRC24A, lengths that are no multiple of four bytes, on 16-byte boundaries (16-byte loads) and
     off them (single words); >= 128 PDUs so that the big-batch rules apply.  Rate-matched codeword (carries the CRCs) and grid
     equal the oracle's."""
     import torch
-    monkeypatch.setenv("NRPHY_CRC_REGIONS", regions)
-    monkeypatch.setenv("NRPHY_SCR_PARTS_BIG", parts)
+    gpu_ctx = gpu_ctx_for({"NRPHY_CRC_REGIONS": regions, "NRPHY_SCR_PARTS_BIG": parts})
     rng = np.random.default_rng(int(regions) * 10 + int(parts))
     big, nof_ports, nof_subc, _ = cases.baseline_config(3)       # 108,573 bytes: 7 regions, an odd length
     shapes = [big]
@@ -753,7 +752,7 @@ def test_host_span_dft_and_slot_modulator(gpu_ctx, oracle):
 # LDPC decoder ("next" row, receive side): bit-exact hard bits and iteration counts against the oracle, which is pinned
 # to the reference's generic decoder (tests/test_oracle.py)
 # ---------------------------------------------------------------------------------------------------------------------
-DECODER_KERNELS = {  # environment of a launch (read per launch) -> which form of the decoder runs
+DECODER_KERNELS = {  # environment a context is created under -> which form of the decoder its launches take
     "default": {},                                  # two checks per lane, messages per edge: in LDS where the occupancy rule allows, else in the scratch slot
     "lds-messages": {"NRPHY_DECODER_LDSMSG": "2"},  # ... in LDS wherever a workgroup's LDS can hold them
     "slot-messages": {"NRPHY_DECODER_LDSMSG": "0"}, # ... always in the codeblock's slot of the caller's scratch
@@ -762,20 +761,13 @@ DECODER_KERNELS = {  # environment of a launch (read per launch) -> which form o
 }
 
 
-def select_decoder_kernel(monkeypatch, kernel):
-    for name in ("NRPHY_DECODER_PAIRS", "NRPHY_DECODER_LDSMSG", "NRPHY_DECODER_MSG"):
-        monkeypatch.delenv(name, raising=False)
-    for name, value in DECODER_KERNELS[kernel].items():
-        monkeypatch.setenv(name, value)
-
-
 @pytest.mark.parametrize("kernel", list(DECODER_KERNELS))
 @pytest.mark.parametrize("case", cases.LDPC_DECODE_CASES)
-def test_ldpc_decoder_vs_oracle(gpu_ctx, oracle, case, kernel, monkeypatch):
+def test_ldpc_decoder_vs_oracle(gpu_ctx_for, oracle, case, kernel):
     """Every form of the decoder kernel: two checks per lane in packed 16-bit arithmetic (even lifting sizes) with the messages
     per edge in LDS or as compressed records, and one check per lane -- hard bits and iteration counts of all equal the
     oracle's."""
-    select_decoder_kernel(monkeypatch, kernel)
+    gpu_ctx = gpu_ctx_for(DECODER_KERNELS[kernel])
     bg, zc, extra, tail, crc_id, filler, amp, sigma = case
     rng = np.random.default_rng(zc * 1000 + extra)
     nof_llr = cases.ldpc_decode_nof_llr(case)
