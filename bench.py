@@ -138,51 +138,40 @@ def cpu_baseline(pdu, tb, nof_ports, nof_subc, ofdm, budget_s=30.0):
     }
 
 
-# Vector-issue roof: 1,024 SIMDs (256 CUs x 4) each issue one 64-lane vector instruction per four cycles at the 2.4 GHz
-# peak engine clock (MI355X_MICROARCH.md) -> 614.4 G wavefront-instructions/s.
-VALU_PEAK_GINST = 1024 * 2.4 / 4.0
-
-_PROFILE = None
-
-
-def profile_table():
-    """profiles/traffic.json: per kernel, HBM bytes and vector instructions per launch from the PMC passes of the default
-    command (profiles/pmc.sh) -- measured in the profile run named there, not in this process."""
-    global _PROFILE
-    if _PROFILE is None:
-        try:
-            _PROFILE = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        except Exception:
-            _PROFILE = {}
-    return _PROFILE
+sys.path.insert(0, os.path.join(ROOT, "profiles"))
+from roofline_util import profile_table, valu_roof  # noqa: E402  (vector-issue cost model, profiles/traffic.json with its source check)
 
 
 def roof(name, ms, nbytes, slots=None, config=None, wire=False):
     """Roofline dict of one kernel.  HBM figures always; for a kernel that profiles/traffic.json lists as bound by vector
-    instruction issue ("valu_bound"), `bound` says so and achieved / peak / frac are its vector-issue rate (instructions
-    per launch from the PMC profile / this run's launch time), with the HBM figures alongside under "hbm"."""
+    instruction issue ("valu_bound"), `bound` says so and achieved / peak / frac are its vector-issue figures (valu_roof), with
+    the HBM figures alongside under "hbm"."""
     gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     out = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes),
            "traffic": None}
     tj = profile_table()
-    if config == 3 and not wire and tj.get("slots") == slots:
-        out["traffic"] = tj.get("hbm_bytes_per_launch", {}).get(name)
-        valu = tj.get("valu_insts_per_launch", {}).get(name)
-        if valu and name in tj.get("valu_bound", []) and ms > 0:
-            ginst = valu / (ms * 1e-3) / 1e9
-            out.update({"bound": "valu", "achieved": round(ginst, 1), "peak": round(VALU_PEAK_GINST, 1),
-                        "unit": "Gwaveinst/s", "frac": round(ginst / VALU_PEAK_GINST, 4),
-                        "valu_insts_per_launch": int(valu),
-                        "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(gbs / HBM_PEAK_GBS, 4)}})
-        elif valu and name == "prologue_kernel" and ms > 0:
-            # neither roof binds this launch (DESIGN.md section 5): both figures, and what the workgroup timeline shows
-            ginst = valu / (ms * 1e-3) / 1e9
-            out["valu"] = {"achieved": round(ginst, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "Gwaveinst/s",
-                           "frac": round(ginst / VALU_PEAK_GINST, 4), "valu_insts_per_launch": int(valu)}
-            out["note"] = ("bound by its two dependent chains, whose waves take turns at the SIMDs and the LDS: a TB-CRC workgroup's "
-                           "regions (byte-table look-ups) and a sequence wave's blocks of 31 rows (profiles/r03_prologue_trace.txt)")
+    if tj.get("stale"):
+        out["note"] = tj["stale"]
+    key = name if not wire else name   # (the wire-format kernel has its own key: "ofdm_kernel<4096, ci16>")
+    if config == 3 and tj.get("slots") == slots:
+        if not wire or "ci16" in name:
+            out["traffic"] = tj.get("hbm_bytes_per_launch", {}).get(key)
+        valu = tj.get("valu_insts_per_launch", {}).get(key)
+        cost = tj.get("valu_issue_model", {}).get(key, {}).get("avg_issue_cycles_per_instruction")
+        clock = tj.get("clock_ghz", {}).get(key)
+        if valu and cost and ms > 0:
+            v = valu_roof(valu, ms, cost, clock)
+            if name in tj.get("valu_bound", []):
+                hbm = {k: out[k] for k in ("achieved", "peak", "unit", "frac")}
+                out.update(v)
+                out["hbm"] = hbm
+            else:
+                out["valu"] = {k: v[k] for k in v if k != "bound"}
+                if name == "prologue_kernel":
+                    # neither roof binds this launch (DESIGN.md section 5): both figures, and what the workgroup timeline shows
+                    out["note"] = ("bound by its two dependent chains, whose waves take turns at the SIMDs and the LDS: a TB-CRC workgroup's "
+                                   "regions (byte-table look-ups) and a sequence wave's blocks of 31 rows (profiles/r03_prologue_trace.txt)")
     return out
 
 

@@ -14,11 +14,16 @@ root, label = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
     per_dispatch, names = defaultdict(float), {}
+    spans = {}
     for row in csv.DictReader(open(path)):
         per_dispatch[(row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
         names[row["Dispatch_Id"]] = row["Kernel_Name"]
+        if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+            spans[(row["Dispatch_Id"], row["Counter_Name"])] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
     for (disp, counter), v in per_dispatch.items():
         acc[names[disp].split("(")[0].replace("void ", "")][counter].append(v)
+        if counter == "SQ_BUSY_CYCLES" and (disp, counter) in spans:   # the dispatch's duration in the pass that counted its cycles
+            acc[names[disp].split("(")[0].replace("void ", "")]["_busy_span_ns"].append(spans[(disp, counter)])
 
 
 def key_of(kernel):
@@ -49,6 +54,9 @@ for kernel, counters in acc.items():
         out["valu_insts_per_launch"][k] = int(mean["SQ_INSTS_VALU"])
     if "SQ_INSTS_SALU" in mean:
         out["salu_insts_per_launch"][k] = int(mean["SQ_INSTS_SALU"])
+    if "SQ_BUSY_CYCLES" in mean and mean.get("_busy_span_ns"):
+        # engine clock under the kernel: SQ_BUSY_CYCLES counts every shader engine (32 on MI355X) while a wave of the dispatch is resident
+        out.setdefault("clock_ghz", {})[k] = round(mean["SQ_BUSY_CYCLES"] / 32.0 / mean["_busy_span_ns"], 3)
 # the receive chain's entries: profiles/rx_pmc_summary.py output (third argument), else kept from the previous file
 try:
     rx = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else json.load(
@@ -58,4 +66,16 @@ try:
             out[k] = v
 except Exception:
     pass
+# what the counters were measured on, and the issue-cost model of the same sources (bench.py refuses the file for other kernels)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import valu_issue_model
+out["kernel_source_sha256"] = valu_issue_model.source_sha()
+for k, v in out.items():
+    if k.startswith(("valu_issue_model",)):
+        pass
+try:
+    m = valu_issue_model.model()
+    out["valu_issue_model"], out["valu_issue_model_source"] = m["valu_issue_model"], m["valu_issue_model_source"]
+except Exception as e:
+    out["valu_issue_model_error"] = str(e)
 print(json.dumps(out, indent=1))

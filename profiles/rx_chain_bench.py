@@ -252,29 +252,37 @@ def run(args):
     demod_bytes = slots * nsym * (12 + qm)   # symbol + noise variance in, Qm soft bits out
     n_cb = slots * C
     alg = n_cb * d["full_length"] + slots * tb_size  # decoder: soft buffers in, transport blocks out
-    # The decoder is bound by vector instruction issue: its share of the 614.4 G wavefront-instructions/s
-    # roof comes from the PMC profile of this script (profiles/rx_pmc.sh -> profiles/traffic.json).
+    # The decoder is bound by vector instruction issue: vector instructions per codeblock from the PMC
+    # profile of this script (profiles/rx_leg_profile.sh -> profiles/traffic.json, used only when measured on these kernel
+    # sources) x the average issue cost of the kernel's own instruction mix (profiles/valu_issue_model.py).
     hbm = {"achieved": alg / kernel_ms["pusch_decode_batch"] * 1e-6, "peak": 8000.0, "unit": "GB/s",
            "frac": alg / kernel_ms["pusch_decode_batch"] * 1e-6 / 8000.0}
-    roofline = dict(hbm, bound="hbm", kernel="ldpc_decode_pairs_lm_kernel | ldpc_decode_pairs_kernel", traffic=None)
+    kernel_name = "ldpc_decode_msg_bg1_kernel" if leg == "bg1" else "ldpc_decode_msg_bg2_slot_kernel"
+    roofline = dict(hbm, bound="hbm", kernel=kernel_name, traffic=None)
     mean_it = float(res[:, 2].sum()) / n_cb
     iterations_run = float(args.iterations) if not early_stop else mean_it
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        import roofline_util
+        tj = roofline_util.profile_table()
+        if tj.get("stale"):
+            roofline["note"] = tj["stale"]
         c4 = tj.get("rx_valu_insts_per_codeblock_at_4_iterations", {}).get(leg)
         c8 = tj.get("rx_valu_insts_per_codeblock_at_8_iterations", {}).get(leg)
-        if c4 and c8:
+        cost = tj.get("valu_issue_model", {}).get(kernel_name, {}).get("avg_issue_cycles_per_instruction")
+        if c8 and cost:
             # instructions at this run's iteration count: on the line through the two profiled points (below four iterations:
-            # pro rata of the first point -- the first iteration is the cheaper one, so that is an upper estimate)
+            # pro rata of the first point -- the first iteration is the cheaper one, so that is an upper estimate); with one
+            # point only, pro rata of it
             it = iterations_run
-            per_cb = c4 + (c8 - c4) * (it - 4.0) / 4.0 if it >= 4.0 else c4 * it / 4.0
-            ginst = n_cb * per_cb / kernel_ms["pusch_decode_batch"] * 1e-6
-            roofline = {"bound": "valu", "kernel": "ldpc_decode_pairs_lm_kernel | ldpc_decode_pairs_kernel", "achieved": ginst, "peak": 1024 * 2.4 / 4, "unit": "Gwaveinst/s",
-                        "frac": ginst / (1024 * 2.4 / 4),
-                        "traffic": (int(tj["rx_hbm_bytes_per_codeblock"][leg] * n_cb) if leg in tj.get("rx_hbm_bytes_per_codeblock", {}) else None),
-                        "hbm": hbm, "valu_insts_per_codeblock": per_cb,
-                        "note": "vector instructions per codeblock from the PMC profile named in profiles/traffic.json (rx_source), "
-                                "launch time of this run (the whole nrphy_pusch_decode_batch call: dematcher, decoder, assembly)"}
+            if c4:
+                per_cb = c4 + (c8 - c4) * (it - 4.0) / 4.0 if it >= 4.0 else c4 * it / 4.0
+            else:
+                per_cb = c8 * it / 8.0
+            roofline = roofline_util.valu_roof(n_cb * per_cb, kernel_ms["pusch_decode_batch"], cost, tj.get("rx_clock_ghz", {}).get(leg))
+            roofline.update({"kernel": kernel_name, "hbm": hbm, "valu_insts_per_codeblock": per_cb,
+                             "traffic": (int(tj["rx_hbm_bytes_per_codeblock"][leg] * n_cb) if leg in tj.get("rx_hbm_bytes_per_codeblock", {}) else None),
+                             "note": "vector instructions per codeblock from the PMC profile named in profiles/traffic.json (rx_source), "
+                                     "launch time of this run (the whole nrphy_pusch_decode_batch call: dematcher, decoder, assembly)"})
     except Exception:
         pass
     cpu = None

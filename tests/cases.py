@@ -603,3 +603,92 @@ def rm_corner_expected(oracle, case, tb):
         full = np.unpackbits(oracle.ldpc_encode(bg, zc, segs[c], 66 * zc))[: 66 * zc]
         out.append(spec_rate_match(bg, zc, rv, qm, nref, int(meta[c][2]), full, int(meta[c][0])))
     return np.concatenate(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The scrambling-seed walk of the prologue (csrc/pdsch_kernels.hip, prologue_kernel): constructive corner cases
+# ---------------------------------------------------------------------------------------------------------------------
+SEED_BLOCK_WORDS = 31 * 64   # a block of 31 rows of the sequence wave (bits_device.h: GOLD_SEED_ROWS x WAVE)
+RE_CHUNK = 512               # resource elements per codeblock work item (nrphy_internal.h)
+
+
+def seed_walk_layout(d, lq, nof_pdus_in_plan=1):
+    """Where the prologue's sequence wave meets the work items of a PDU: (items, boundaries).  items = [(first word of the
+    item's scrambling bits, resource elements of the item)] in order; boundaries = the word indices at which a block of 31 rows
+    or a part of the sequence ends (plan rule: csrc/nrphy_host.cpp, "parts"; one part in a plan of 128 PDUs or more)."""
+    G, C, n_short = d["codeword_bits"], d["nof_codeblocks"], d["nof_short_segments"]
+    items, bit_cb = [], 0
+    for cb in range(C):
+        e = d["rm_length_short"] if cb < n_short else d["rm_length_long"]
+        nre = e // lq
+        for re_begin in range(0, nre, RE_CHUNK):
+            items.append(((bit_cb + re_begin * lq) >> 5, min(RE_CHUNK, nre - re_begin)))
+        bit_cb += e
+    scr_words = (G + 31) // 32 + 1 + 31
+    parts = min(1 if nof_pdus_in_plan >= 128 else 4, max(1, scr_words >> 11))
+    chunk = -(-scr_words // parts)
+    bounds = set()
+    for first in range(0, scr_words, chunk):
+        end = min(first + chunk, scr_words)
+        bounds.add(end)
+        bounds.update(range(first + SEED_BLOCK_WORDS, end, SEED_BLOCK_WORDS))
+    return items, sorted(bounds)
+
+
+def seed_walk_pdus(tbs, rng, count, max_draws=200000):
+    """PDUs built so that a SHORT work item (the 1 ... 40 resource-element tail of a codeblock cut into RE_CHUNK pieces, whose
+    31-word seed overlaps its neighbours') has its first scrambling word within -31 ... +1 words of the end of a 31-row block
+    or of a sequence part -- the four interacting boundaries of the seed walk (the walk's one bug showed in 6
+    of 64 sweep legs and in no fixed test).  Drawn at random over allocation, symbols, modulation x layers (2 ... 32 bits per
+    resource element) and rate, kept when the layout computed from nrphy_pdsch_derive meets the condition; spread over the
+    bits-per-RE values and both kinds of boundary.  [(pdu, nof_ports, nof_subc, (lq, tail RE, distance, kind))]."""
+    lib = backends.pkg.lib
+    out, seen = [], {}
+    for _ in range(max_draws):
+        if len(out) >= count:
+            break
+        layers = int(rng.integers(1, 5))
+        qm = int(rng.choice([2, 4, 6, 8]))
+        lq = qm * layers
+        n_prb = int(rng.integers(24, 274))
+        nsym = int(rng.integers(6, 15))
+        dmrs = [2] if nsym < 10 else [2, 9]
+        groups = int(rng.integers((layers + 1) // 2, 3))
+        rate = float(rng.uniform(120, 948))
+        tb_bits = tbs(nsym, len(dmrs) * 6 * groups, 0, qm, rate, layers, n_prb)
+        if tb_bits < 3840 or tb_bits > 1277992:
+            continue
+        r = rate / 1024
+        bg = 2 if (tb_bits <= 3824 and r <= 0.67) or r <= 0.25 else 1
+        w = np.zeros((1, layers, layers), np.complex64)
+        w[0] = np.eye(layers) / np.sqrt(layers)
+        pdu = abi.make_pdu(slot_index=int(rng.integers(0, 20)), rnti=int(rng.integers(1, 65520)), bwp_start_rb=0, bwp_size_rb=273, qm=qm,
+                           n_id=int(rng.integers(0, 1024)), dmrs_symbols=dmrs, scrambling_id=int(rng.integers(0, 65536)),
+                           nof_cdm_groups_without_data=groups, prb_start=0, prb_count=n_prb, start_symbol=0, nof_symbols=nsym,
+                           base_graph=bg, precoding=w, tb_size_bytes=tb_bits // 8)
+        if lib.validate(pdu) != 0:
+            continue
+        d = lib.derive(pdu)
+        if d["codeword_bits"] <= 32 * SEED_BLOCK_WORDS:
+            continue   # a sequence of one block: no boundary inside
+        items, bounds = seed_walk_layout(d, lq)
+        part_ends = set(seed_walk_layout(d, lq)[1]) - {b for b in bounds if b % SEED_BLOCK_WORDS == 0 and b != bounds[-1]}
+        hit = None
+        for k, (w0, nre) in enumerate(items):
+            if not 1 <= nre <= 40:
+                continue
+            for b in bounds:
+                if -31 <= w0 - b <= 1:
+                    kind = "part" if (b in part_ends and b % SEED_BLOCK_WORDS != 0) else "block"
+                    hit = (lq, nre, w0 - b, kind)
+                    break
+            if hit:
+                break
+        if hit is None:
+            continue
+        key = (hit[0], hit[3], hit[2] // 8)
+        if seen.get(key, 0) >= 2:   # spread: at most two per (bits per RE, boundary kind, distance octave)
+            continue
+        seen[key] = seen.get(key, 0) + 1
+        out.append((pdu, layers, 273 * 12, hit))
+    return out

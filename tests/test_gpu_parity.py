@@ -331,6 +331,55 @@ def test_pdsch_overlapping_scrambling_seeds(gpu_ctx, oracle):
     assert np.array_equal(got, want)
 
 
+def test_pdsch_seed_walk_boundaries(gpu_ctx, oracle):
+    """The constructive net around the prologue's seed walk (cases.seed_walk_pdus): PDUs in which a short tail item -- 1 ... 40
+    resource elements, its 31-word seed overlapping its neighbours' -- starts -31 ... +1 words around the end of a 31-row block
+    or of a sequence part, for 2 ... 32 bits per resource element.  Each PDU alone through the host-span call (a plan of one PDU:
+    up to four parts) and all of them in one batched plan: scrambled codeword and grid equal the oracle's.  The library as it
+    was before the round-3 fix (commit 13d24f2) fails this test on the first PDU of either kind (checked once, round 4, with
+    NRPHY_LIB_SO on a build of that commit: profiles/r04_seed_walk_regression.txt)."""
+    import torch
+    rng = np.random.default_rng(404)
+    picked = cases.seed_walk_pdus(oracle.tbs, rng, 96, max_draws=120000)
+    kinds = {h[3] for *_, h in picked}
+    assert len(picked) >= 40 and kinds == {"block", "part"}, (len(picked), kinds)
+    assert len({h[0] for *_, h in picked}) >= 6 and len({h[2] for *_, h in picked}) >= 28, "the generator lost its spread"
+    want = []
+    for pdu, nof_ports, nof_subc, hit in picked:
+        tb = cases.random_tb(rng, pdu)
+        d = oracle.derive(pdu)
+        g, orm, oscr = oracle.pdsch_process(pdu, tb, nof_ports, nof_subc, taps=True, codeword_bits=d["codeword_bits"])
+        want.append((tb, g, oscr))
+        got, rm, scr = gpu_ctx.pdsch_process_host(pdu, tb, nof_ports, nof_subc, taps=True)
+        assert np.array_equal(scr, oscr), hit
+        assert np.array_equal(rm, orm) and np.array_equal(got, g), hit
+    # the same PDUs in one plan (batched path, device pointers), grouped by port count
+    for ports in sorted({p[1] for p in picked}):
+        idx = [i for i, p in enumerate(picked) if p[1] == ports]
+        pdus = [picked[i][0] for i in idx]
+        nof_subc = picked[idx[0]][2]
+        offs, total = [], 0
+        for q in pdus:
+            offs.append(total)
+            total += (q.tb_size_bytes + 255) & ~255
+        buf = np.zeros(total + 64, np.uint8)
+        for o, i in zip(offs, idx):
+            buf[o:o + len(want[i][0])] = want[i][0]
+        plan = lib.PdschPlan(gpu_ctx, pdus, offs, list(range(len(pdus))), len(pdus), ports, nof_subc)
+        d_grid = torch.full((len(pdus), ports, 14, nof_subc), 0x7FFF7FFF, dtype=torch.int32, device="cuda")
+        d_scr = torch.zeros(plan.codeword_bits // 8, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        plan.run(dev(buf), d_grid, d_cw_scr=d_scr, zero_grids=True)
+        gpu_ctx.synchronize()
+        scr = d_scr.cpu().numpy()
+        grids = d_grid.cpu().numpy().view(np.uint16).reshape(len(pdus), ports, 14, nof_subc, 2)
+        for k, i in enumerate(idx):
+            o = plan.codeword_offset(k) // 8
+            assert np.array_equal(scr[o:o + len(want[i][2])], want[i][2]), picked[i][3]
+            assert np.array_equal(grids[k], want[i][1]), picked[i][3]
+        plan.close()
+
+
 def test_pdsch_full_size_batch_properties(gpu_ctx, oracle):
     """At BASELINE size (config 3, 64 slots in one launch): identical inputs give identical grids (no cross-slot
     interference), different TBs differ, and one slot of the batch matches the oracle bit for bit."""
