@@ -212,6 +212,16 @@ def test_bench_gpus_n_launches_its_own_ranks_dry_run():
     assert sum(lines[0]["per_rank"]["slots_per_step"]) == 24 and lines[0]["total_slots"] == 24
 
 
+def test_bench_eight_ranks_config4_cell_affine_dry_run():
+    """The driver's largest command, rehearsed without devices: `bench.py --gpus 8 --config 4` places BASELINE config 4's stream
+    of cell-slots by cell affinity (cell c on ranks 2c, 2c + 1 alternating slots) -- every one of the eight ranks gets exactly
+    its 1024 cell-slots per step, and rank 0's line adds them up."""
+    rc, lines, err = _bench_line(["--gpus", "8", "--dry-run", "--config", "4", "--steps", "2"], timeout=600)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["dry_run"] is True
+    assert lines[0]["per_rank"]["slots_per_step"] == [1024] * 8 and lines[0]["total_slots"] == 8 * 1024 * 2
+
+
 def test_trace_ranges_follow_the_environment():
     """rocTX ranges named like the reference's trace points ("process_pdsch", "CB batch", ...: nrphy_trace.h) are live when
     NRPHY_TRACE=1 finds the rocTX library, off with NRPHY_TRACE=0 -- decided once per process, so each case is a child."""
