@@ -19,6 +19,6 @@ cd "$ROOT"
 bash profiles/pmc.sh "$OUT/${TAG}_pmc" > "$OUT/${TAG}_pmc.log" 2>&1
 python3 profiles/pmc_summary.py "$OUT/${TAG}_pmc" > "$OUT/${TAG}_pmc_summary.txt"
 # profiles/traffic.json of THIS tree (bytes, instructions, clock, source sha): copy to profiles/traffic.json afterwards
-python3 profiles/make_traffic_json.py "$OUT/${TAG}_pmc" "gpurun_out/${TAG}_pmc_summary.txt (profiles/collect.sh ${TAG}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes via profiles/pmc.sh, bench.py --slots 1024 --no-secondary; FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950; units KiB)" > "$OUT/${TAG}_traffic.json"
+NRPHY_SKIP_ISA_MODEL=1 python3 profiles/make_traffic_json.py "$OUT/${TAG}_pmc" "gpurun_out/${TAG}_pmc_summary.txt (profiles/collect.sh ${TAG}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes via profiles/pmc.sh, bench.py --slots 1024 --no-secondary; FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950; units KiB)" > "$OUT/${TAG}_traffic.json"
 rm -rf "$OUT/${TAG}_pmc" "$OUT/${TAG}_stats"
 echo "pmc done"

@@ -74,6 +74,8 @@ for k, v in out.items():
     if k.startswith(("valu_issue_model",)):
         pass
 try:
+    if os.environ.get("NRPHY_SKIP_ISA_MODEL") == "1":   # on the GPU box: the model needs no GPU, add it afterwards (valu_issue_model.py --update)
+        raise RuntimeError("skipped: run python3 profiles/valu_issue_model.py --update")
     m = valu_issue_model.model()
     out["valu_issue_model"], out["valu_issue_model_source"] = m["valu_issue_model"], m["valu_issue_model_source"]
 except Exception as e:

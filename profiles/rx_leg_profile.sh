@@ -11,10 +11,13 @@ echo "stats rc=$?"
 cp "$OUT/${TAG}_${LEG}_stats"/*/*kernel_stats.csv "$OUT/${TAG}_${LEG}_kernel_stats.csv"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/${TAG}_${LEG}_pmc" -- python3 "$ROOT/profiles/rx_chain_bench.py" --leg $LEG --no-early-stop --steps 2 --warmup 1 > "$OUT/${TAG}_${LEG}_pmc.log" 2>&1
 echo "pmc rc=$?"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d "$OUT/${TAG}_${LEG}_pmc2" -- python3 "$ROOT/profiles/rx_chain_bench.py" --leg $LEG --no-early-stop --steps 2 --warmup 1 > "$OUT/${TAG}_${LEG}_pmc2.log" 2>&1
-echo "pmc2 rc=$?"
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, counter budget of the TCC block)
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/${TAG}_${LEG}_pmc_$C" -- python3 "$ROOT/profiles/rx_chain_bench.py" --leg $LEG --no-early-stop --steps 2 --warmup 1 > "$OUT/${TAG}_${LEG}_pmc_$C.log" 2>&1
+  echo "pmc $C rc=$?"
+done
 cd "$ROOT"
-python3 - "$OUT/${TAG}_${LEG}_pmc" "$OUT/${TAG}_${LEG}_pmc2" > "$OUT/${TAG}_${LEG}_pmc.txt" <<'PY'
+python3 - "$OUT/${TAG}_${LEG}_pmc" "$OUT/${TAG}_${LEG}_pmc_FETCH_SIZE" "$OUT/${TAG}_${LEG}_pmc_WRITE_SIZE" > "$OUT/${TAG}_${LEG}_pmc.txt" <<'PY'
 import collections, csv, glob, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
 for d in sys.argv[1:]:
@@ -30,6 +33,6 @@ for k in sorted(acc):
     for c, v in sorted(acc[k].items()):
         print("   %-22s per dispatch %16.0f  (%d dispatches)" % (c, v / len(n[(k, c)]), len(n[(k, c)])))
 PY
-rm -rf "$OUT/${TAG}_${LEG}_stats" "$OUT/${TAG}_${LEG}_pmc" "$OUT/${TAG}_${LEG}_pmc2"
+rm -rf "$OUT/${TAG}_${LEG}_stats" "$OUT/${TAG}_${LEG}_pmc" "$OUT/${TAG}_${LEG}_pmc_FETCH_SIZE" "$OUT/${TAG}_${LEG}_pmc_WRITE_SIZE"
 head -12 "$OUT/${TAG}_${LEG}_kernel_stats.csv"
-cat "$OUT/${TAG}_${LEG}_pmc.txt"
+grep -A12 "ldpc_decode" "$OUT/${TAG}_${LEG}_pmc.txt"
