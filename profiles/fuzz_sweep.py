@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Larger randomised sweeps than the test-suite runs, GPU against the oracle through the C ABI (the numbers DESIGN.md section
-2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [mutated] [mutated_ctrl] [encode] [batched] [slot] [async] [ctrl_batched] [plan] [pusch] [rx] [ofdm] [wire] [csi] [dlctrl] [demod] [lower]   (default: all)"""
+2 quotes).  Usage (GPU box, repository root): python3 profiles/fuzz_sweep.py [pdsch] [mutated] [mutated_ctrl] [encode] [batched] [slot] [dlslot] [async] [ctrl_batched] [plan] [pusch] [rx] [ofdm] [wire] [csi] [dlctrl] [demod] [lower]   (default: all)"""
 import ctypes as C
 import os
 import sys
@@ -340,6 +340,105 @@ def slot():
             bad += 1
             print("SLOT MISMATCH", n, ports, bwp, k, int(np.count_nonzero(got != want)), flush=True)
     print("pdsch slots: %d random slots of 2-6 PDUs in one grid, %d mismatches" % (n, bad), flush=True)
+    return bad
+
+
+def dlslot():
+    """The downlink slot pipeline (nrphy_dl_slots_*): random slots on a 106-PRB / four-port cell -- one to four PDSCH PDUs with disjoint
+    PRB ranges arriving in one or several calls, a random PDCCH before or after them, sparse puts, sometimes a host grid loaded instead --
+    several slots open at once, the grid read back and the IQ of the slot's pinned buffer against the oracle (float and wire format)."""
+    rng = np.random.default_rng(BASE + 31415)
+    bad = n = 0
+    nof_rb, ports = 106, 4
+    subc = 12 * nof_rb
+    wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -10.0, 1.0, -6.0), 32767.0)
+    for use_wire in (False, True):
+        ocfg = abi.OfdmConfig(1, nof_rb, 2048, 0, 1.0 / np.sqrt(2048), 3.5e9)
+        pool = lib.DlSlotPool(ctx, ocfg, ports, 3, 400000, wire_cfg=wire if use_wire else None)
+        open_slots = []
+
+        def finish(entry):
+            nonlocal bad, n
+            sid, want, slot_index = entry
+            assert pool.wait(sid) == 0
+            n += 1
+            ok = np.array_equal(pool.read_grid(sid), want)
+            ref_iq = o.ofdm_slot(ocfg, want, slot_index)
+            for port in range(ports):
+                got = pool.iq(sid, port)
+                if use_wire:
+                    y, _ = o.amplitude_control(wire.amplitude, ref_iq[port])
+                    w16 = o.iq_convert_ci16(y, wire.ci16_scale).reshape(-1, 2).astype(np.int32)
+                    ok = ok and got.shape == w16.shape and int(np.abs(got.astype(np.int32) - w16).max()) <= 1
+                else:
+                    scale = float(np.abs(ref_iq[port]).max())
+                    ok = ok and got.shape == ref_iq[port].shape and (scale == 0 or float(np.abs(got - ref_iq[port]).max()) / scale < 1e-5)
+            if not ok:
+                bad += 1
+                print("DL-SLOT MISMATCH", n, "wire" if use_wire else "f32", flush=True)
+            pool.close(sid)
+
+        for t in range(24):
+            if len(open_slots) == 3:
+                finish(open_slots.pop(0))
+            sid = pool.open()
+            want = np.zeros((ports, 14, subc, 2), np.uint16)
+            slot_index = int(rng.integers(0, 2))
+            if rng.integers(0, 6) == 0:   # seam C alone: a grid computed elsewhere
+                want = (((rng.standard_normal((ports, 14, subc, 2)) * 0.5).astype(np.float32).view(np.uint32)) >> 16).astype(np.uint16)
+                pool.load_grid(sid, want)
+            else:
+                pdcch = cases.random_pdcch(rng, nof_ports_max=ports, nof_rb_grid=nof_rb)
+                first = bool(rng.integers(0, 2))
+                if first:
+                    pool.pdcch(sid, [pdcch])
+                    want = o.pdcch_process(pdcch, want)
+                k = int(rng.integers(1, 5))
+                edges = [0] + sorted(int(c) for c in rng.choice(np.arange(8, nof_rb - 8), k - 1, replace=False)) + [nof_rb]
+                pdus, tbs_ = [], []
+                for u in range(k):
+                    lo, hi = edges[u], edges[u + 1]
+                    layers = int(rng.integers(1, 5))
+                    qm, rate = int(rng.choice([2, 4, 6, 8])), float(rng.uniform(100, 940))
+                    nsym = int(rng.integers(8, 13))
+                    groups = int(rng.integers((layers + 1) // 2, 3))
+                    tb_bits = o.tbs(nsym, 12 * groups, 0, qm, rate, layers, hi - lo)
+                    r_ = rate / 1024
+                    bg = 2 if (tb_bits <= 292 or (tb_bits <= 3824 and r_ <= 0.67) or r_ <= 0.25) else 1
+                    w = ((rng.standard_normal((1, ports, layers)) + 1j * rng.standard_normal((1, ports, layers))) / 2).astype(np.complex64)
+                    q = abi.make_pdu(slot_index=int(rng.integers(0, 20)), rnti=int(rng.integers(1, 65535)), n_id=int(rng.integers(0, 1024)),
+                                     bwp_size_rb=nof_rb, qm=qm, dmrs_symbols=(2, 2 + nsym - 4), prb_start=lo, prb_count=hi - lo, start_symbol=2,
+                                     nof_symbols=nsym, base_graph=bg, precoding=w, tb_size_bytes=max(3, tb_bits // 8),
+                                     nof_cdm_groups_without_data=groups, rv=int(rng.integers(0, 4)))
+                    if tb_bits < 24 or o.validate(q) != 0 or o.derive(q)["nof_re"] == 0:
+                        continue
+                    pdus.append(q)
+                    tbs_.append(cases.random_tb(rng, q))
+                cut = int(rng.integers(0, len(pdus) + 1))   # the PDUs arrive in up to two calls
+                for part_pdus, part_tbs in ((pdus[:cut], tbs_[:cut]), (pdus[cut:], tbs_[cut:])):
+                    if part_pdus:
+                        assert pool.pdsch(sid, part_pdus, part_tbs) == 0
+                for q, tb in zip(pdus, tbs_):
+                    part = o.pdsch_process(q, tb, ports, subc)
+                    mask = part.view(np.uint32) != 0
+                    want.view(np.uint32)[mask] = part.view(np.uint32)[mask]
+                if not first:
+                    pool.pdcch(sid, [pdcch])
+                    want = o.pdcch_process(pdcch, want)
+                entries = [abi.GridRe(int(rng.integers(0, ports)), 13, int(rng.integers(0, subc)), int(rng.integers(1, 2 ** 31))) for _ in range(int(rng.integers(0, 9)))]
+                if entries:
+                    pool.put(sid, entries)
+                    for e in entries:
+                        want.view(np.uint32).reshape(ports, 14, subc)[e.port, e.symbol, e.subc] = e.value & 0x7F7F7F7F | 0   # (finite bf16 pairs)
+                    # the entries as given (the mask above only documents that the draw stays clear of NaN patterns)
+                    for e in entries:
+                        want.view(np.uint32).reshape(ports, 14, subc)[e.port, e.symbol, e.subc] = e.value
+            assert pool.modulate(sid, slot_index) == 0
+            open_slots.append((sid, want, slot_index))
+        while open_slots:
+            finish(open_slots.pop(0))
+        pool.destroy()
+    print("downlink slot pipeline: %d random slots (float and wire format), %d mismatches" % (n, bad), flush=True)
     return bad
 
 
@@ -781,7 +880,7 @@ def lower():
 
 
 if __name__ == "__main__":
-    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "batched": batched, "slot": slot, "async": async_queue, "ctrl_batched": ctrl_batched, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
+    legs = {"pdsch": pdsch, "mutated": mutated, "mutated_ctrl": mutated_ctrl, "encode": encode, "batched": batched, "slot": slot, "dlslot": dlslot, "async": async_queue, "ctrl_batched": ctrl_batched, "plan": plan, "pusch": pusch, "rx": rx, "ofdm": ofdm, "wire": wire, "csi": csi, "dlctrl": dlctrl, "demod": demod, "lower": lower}
     if "--oracle-only" in sys.argv:   # the oracle side of the mutated leg alone, for the CPU sanitizer build
         sys.exit(mutated(device=False) + mutated_ctrl(device=False))
     which = sys.argv[1:] or list(legs)
