@@ -1546,6 +1546,7 @@ extern "C" int nrphy_pdsch_run(nrphy_pdsch_plan_t* plan, const uint8_t* d_tb, vo
   p.scr                = plan->d_scr;
   p.scr_seed           = plan->d_scr + plan->seed_offset;
   p.n_zero_work        = (d_grid != nullptr && zero_grids) ? plan->n_zero_work : 0;
+  p.zero_fill          = (d_grid != nullptr && zero_grids) ? 1U : 0U;
   p.n_dmrs_in_launch   = merge_dmrs ? plan->n_dmrs : 0;
   p.n_pdu          = (uint32_t)plan->pdus.size();
   p.n_work         = plan->n_work;

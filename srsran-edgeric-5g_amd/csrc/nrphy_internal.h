@@ -233,6 +233,10 @@ struct PdschLaunch {
   uint32_t           profile_stage; // 0 = run everything; n > 0 = codeblock waves stop after stage n (NRPHY_PROFILE_STAGE)
   uint32_t           extras_nt;     // 1: the stores of the DM-RS / zero-fill waves are non-temporal (NRPHY_EXTRAS_NT)
   uint32_t           prologue_order; // 0: sequence workgroups first; 1: spread among the CRC workgroups (NRPHY_PROLOGUE_ORDER)
+  // 1: this run clears what it does not map (zero_grids): the DM-RS waves then also clear the resource elements of a CDM group
+  // that is reserved (no data) but carries no pilots of the PDU; 0: like the reference's mapper, they leave those alone --
+  // whatever another writer of the slot put there stays.
+  uint32_t           zero_fill;
 };
 
 // Kernel launchers (defined in the .hip files).

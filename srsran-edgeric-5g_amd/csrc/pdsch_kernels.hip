@@ -994,7 +994,7 @@ __device__ __forceinline__ void dmrs_items(const PdschLaunch& p, PduRef pd, cons
   const size_t    port_stride = (size_t)NRPHY_NSYMB * p.grid_nof_subc;
   uint32_t*       row = d_grid + (size_t)pd.grid_index * p.grid_nof_ports * port_stride + (size_t)wk.symbol * p.grid_nof_subc;
   const bool      wideband = pd.nof_prg == 1;
-  const bool      zero_other = pd.dmrs_zero_other_group != 0;
+  const bool      zero_other = pd.dmrs_zero_other_group != 0 && p.zero_fill != 0;
   if (wideband) { // wave-uniform
     // With one set of weights a pilot position has eight possible values per port -- r(n) is one of four points and the CDM
     // sign one of two: lane v < 8 computes variant v = c(2n) << 2 | c(2n + 1) << 1 | odd for every port, once per wave, and

@@ -1682,6 +1682,37 @@ def test_dl_slot_pipeline_slots_in_flight_and_host_grids(gpu_ctx, oracle):
     pool.destroy()
 
 
+def test_dl_slot_pdsch_after_other_writers_touches_only_its_own_elements(gpu_ctx, oracle):
+    """A PDSCH run that is not the slot's first writer (zero_grids = 0) behaves like the reference's mapper: it writes the PDU's data
+    and pilot elements and nothing else.  One layer with two CDM groups without data: the elements of the reserved, pilot-less group
+    in the DM-RS symbols keep what the slot held before -- the DM-RS waves used to clear them whatever the run was told (found by the
+    slot-pipeline leg of the device sweep in round 4: a PDCCH under a DM-RS symbol lost a few elements)."""
+    import ctypes as C
+    rng = np.random.default_rng(6006)
+    nof_ports, nof_rb = 2, 52
+    nof_subc = 12 * nof_rb
+    ocfg = abi.OfdmConfig(0, nof_rb, 1024, 0, 1.0, 2.4e9)
+    pool = lib.DlSlotPool(gpu_ctx, ocfg, nof_ports, 1, 65536)
+    for layers, groups in ((1, 2), (2, 2), (1, 1)):
+        w = (rng.standard_normal((1, nof_ports, layers)) + 1j * rng.standard_normal((1, nof_ports, layers))).astype(np.complex64) / 2
+        tbs = cases.tbs(12, 6 * groups * 2, 4, 490, layers, 30)
+        pdu = abi.make_pdu(bwp_size_rb=nof_rb, qm=4, rnti=23, n_id=9, dmrs_symbols=(2, 11), prb_start=11, prb_count=30, start_symbol=2,
+                           nof_symbols=12, precoding=w, tb_size_bytes=tbs // 8, nof_cdm_groups_without_data=groups)
+        tb = cases.random_tb(rng, pdu)
+        before = ((rng.standard_normal((nof_ports, 14, nof_subc, 2)) * 0.5).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        want = before.copy()
+        rc = oracle._f("pdsch_process")(C.byref(pdu), tb.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), nof_ports, nof_subc, None, None)
+        assert rc == 0
+        sid = pool.open()
+        pool.load_grid(sid, before)
+        assert pool.pdsch(sid, [pdu], [tb]) == 0
+        got = pool.read_grid(sid)
+        assert np.array_equal(got, want), (layers, groups, int(np.count_nonzero(got != want)))
+        assert not np.array_equal(got, before)
+        pool.close(sid)
+    pool.destroy()
+
+
 def test_dl_slot_pipeline_wire_format(gpu_ctx, oracle):
     """A pool created with iq_format 1: the slot leaves the device as complex int16 after the amplitude controller
     (nrphy_ofdm_run_ci16) -- half the bytes over PCIe; within one LSB of the oracle's chain."""
