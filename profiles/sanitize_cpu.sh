@@ -15,12 +15,12 @@ LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 NRPHY_
 C=srsran-edgeric-5g_amd/csrc
 python3 srsran-edgeric-5g_amd/build.py > /dev/null
 mkdir -p build/asan
-for s in nrphy_host dl_control_host pdsch_async; do
+for s in nrphy_host dl_control_host pdsch_async dl_slot_async; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-function -Iinclude -I$C -ffp-contract=off \
     -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -x hip -c $C/$s.cpp -o build/asan/$s.o &
 done
 wait
-OBJS=$(ls $C/*.o | grep -v "/nrphy_host.o\|/dl_control_host.o\|/pdsch_async.o")
+OBJS=$(ls $C/*.o | grep -v "/nrphy_host.o\|/dl_control_host.o\|/pdsch_async.o\|/dl_slot_async.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan \
   -o build/asan/libmi355nrphy.so $OBJS build/asan/*.o
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
