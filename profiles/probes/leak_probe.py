@@ -34,6 +34,11 @@ for cycle in range(6):
         q.submit(pdu, tb, lambda status, grid: None)
         q.wait()
         q.close()
+        pool = lib.DlSlotPool(ctx, ofdm, ports, 2, pdu.tb_size_bytes + 64)   # the downlink slot pipeline: open, write, modulate, close
+        sid = pool.open()
+        assert pool.pdsch(sid, [pdu], [tb]) == 0 and pool.modulate(sid, 0) == 0 and pool.wait(sid) == 0
+        pool.close(sid)
+        pool.destroy()
         ctx.synchronize()
         plan.close()
         op.close()

@@ -1713,6 +1713,64 @@ def test_dl_slot_pdsch_after_other_writers_touches_only_its_own_elements(gpu_ctx
     pool.destroy()
 
 
+def test_dl_slot_pipeline_driven_from_several_threads(gpu_ctx, oracle):
+    """Different slots of one pool driven from different host threads at the same time (the reference processes several slots on
+    several downlink executors): four threads, each opening, filling (two PDSCH calls), handing over, waiting for and closing its own
+    slots, a dozen times over, with fewer pool slots than threads x 2 so that open() also meets a full pool.  Every slot's IQ equals the
+    oracle's for ITS transport blocks."""
+    import threading
+    rng = np.random.default_rng(8128)
+    nof_ports, nof_rb = 2, 52
+    nof_subc = 12 * nof_rb
+    ocfg = abi.OfdmConfig(0, nof_rb, 1024, 0, 1.0 / np.sqrt(1024), 2.4e9)
+    w2 = cases.codebook("two_layer_two_ports_0")
+
+    def make(lo, count, rnti, slot_index):
+        tbs = cases.tbs(12, 12, 4, 490, 2, count)
+        return abi.make_pdu(bwp_size_rb=nof_rb, qm=4, rnti=rnti, n_id=5, dmrs_symbols=(2, 11), prb_start=lo, prb_count=count, start_symbol=2,
+                            nof_symbols=12, precoding=w2, tb_size_bytes=tbs // 8, slot_index=slot_index)
+
+    nthreads, rounds = 4, 12
+    work = [[(make(0, 20, 100 + t, r % 10), make(20, 32, 200 + t, r % 10)) for r in range(rounds)] for t in range(nthreads)]
+    tbs_ = [[tuple(cases.random_tb(rng, q) for q in pair) for pair in row] for row in work]
+    want = {}
+    for t in (0, nthreads - 1):   # the oracle's IQ for two of the threads (the others are checked for completion and status)
+        for r in (0, rounds - 1):
+            g = np.zeros((nof_ports, 14, nof_subc, 2), np.uint16)
+            for q, tb in zip(work[t][r], tbs_[t][r]):
+                g = _merge(g, oracle.pdsch_process(q, tb, nof_ports, nof_subc))
+            want[(t, r)] = oracle.ofdm_slot(ocfg, g, 0)
+    pool = lib.DlSlotPool(gpu_ctx, ocfg, nof_ports, 5, 65536)
+    errors, results = [], {}
+
+    def drive(t):
+        try:
+            for r in range(rounds):
+                sid = pool.open()
+                while sid is None:
+                    pool.wait_free()
+                    sid = pool.open()
+                for q, tb in zip(work[t][r], tbs_[t][r]):
+                    assert pool.pdsch(sid, [q], [tb]) == 0
+                assert pool.modulate(sid, 0) == 0 and pool.wait(sid) == 0
+                if (t, r) in want:
+                    results[(t, r)] = np.stack([pool.iq(sid, p) for p in range(nof_ports)])
+                pool.close(sid)
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
+    assert sorted(results) == sorted(want)
+    for key, iq in results.items():
+        assert rel_err(iq, want[key]) < 1e-5, key
+    pool.destroy()
+
+
 def test_dl_slot_pipeline_wire_format(gpu_ctx, oracle):
     """A pool created with iq_format 1: the slot leaves the device as complex int16 after the amplitude controller
     (nrphy_ofdm_run_ci16) -- half the bytes over PCIe; within one LSB of the oracle's chain."""
