@@ -772,7 +772,8 @@ int nrphy_dft_run_host(nrphy_ctx_t* ctx, uint32_t size, int inverse, const float
  *
  * A pool owns `depth` slots, each with a stream, a device grid, pinned staging for transport blocks + plan tables and a
  * pinned IQ buffer.  Everything a slot is asked to do is enqueued on its stream in call order; no call allocates device
- * memory or waits for the device unless it says so.  Calls on ONE slot are serialised by the library (a lock per slot);
+ * memory or waits for the device unless it says so (the control-channel writers and the sparse put stage their descriptors
+ * through a stream-ordered allocation, as their stand-alone forms do).  Calls on ONE slot are serialised by the library (a lock per slot);
  * different slots may be driven from different threads.
  *
  *   nrphy_dl_slot_open      resource_grid::set_all_zero + a free slot: NRPHY_ERR_CAPACITY when all `depth` slots are open
@@ -821,6 +822,11 @@ int nrphy_dl_slot_modulate(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t su
 int nrphy_dl_slot_poll(nrphy_dl_slots_t* pool, uint32_t slot_id);
 int nrphy_dl_slot_wait(nrphy_dl_slots_t* pool, uint32_t slot_id);
 const void* nrphy_dl_slot_iq(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t port, uint32_t* nof_samples);
+/* Wire-format pools (iq_format 1): the amplitude controller's raw measurements of the slot's buffer of `port` (sum and peak of
+ * |x|^2 after the gain and before clipping, clipped parts, samples) in pinned host memory, valid like nrphy_dl_slot_iq;
+ * nrphy_amplitude_metrics() turns them into amplitude_controller_metrics, what downlink_processor_baseband_impl reports per
+ * buffer (R/lib/phy/lower/processors/downlink/downlink_processor_baseband_impl.cpp:238-264).  NULL for a float pool. */
+const nrphy_amplitude_stats_t* nrphy_dl_slot_amplitude_stats(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t port);
 int nrphy_dl_slot_read_grid(nrphy_dl_slots_t* pool, uint32_t slot_id, void* grid);
 /* For callers that keep more of the chain on the device: the slot's grid in HBM and the stream its work is ordered on. */
 void* nrphy_dl_slot_device_grid(nrphy_dl_slots_t* pool, uint32_t slot_id);

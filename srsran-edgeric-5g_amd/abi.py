@@ -469,6 +469,7 @@ def declare(lib, prefix="nrphy_"):
     sig("dl_slot_wait", i32, vp, u32)
     sig("dl_slot_iq", vp, vp, u32, u32, P(u32))
     sig("dl_slot_read_grid", i32, vp, u32, vp)
+    sig("dl_slot_amplitude_stats", P(AmplitudeStats), vp, u32, u32)
     sig("dl_slot_device_grid", vp, vp, u32)
     sig("dl_slot_stream", vp, vp, u32)
     sig("pusch_decode_codeblock_host", i32, vp, P(LdpcRateDematcherCfg), u32, u32, C.c_float, vp, vp, i32, u8p, P(u32))
@@ -502,5 +503,5 @@ ABI_SYMBOLS = [
     "nrphy_dl_slots_create", "nrphy_dl_slots_destroy", "nrphy_dl_slots_wait_free", "nrphy_dl_slot_open", "nrphy_dl_slot_close",
     "nrphy_dl_slot_pdsch", "nrphy_dl_slot_pdcch", "nrphy_dl_slot_ssb", "nrphy_dl_slot_csi_rs", "nrphy_dl_slot_put",
     "nrphy_dl_slot_load_grid", "nrphy_dl_slot_modulate", "nrphy_dl_slot_poll", "nrphy_dl_slot_wait", "nrphy_dl_slot_iq",
-    "nrphy_dl_slot_read_grid", "nrphy_dl_slot_device_grid", "nrphy_dl_slot_stream",
+    "nrphy_dl_slot_read_grid", "nrphy_dl_slot_device_grid", "nrphy_dl_slot_stream", "nrphy_dl_slot_amplitude_stats",
 ]

@@ -32,6 +32,8 @@ struct DlSlot {
   uint8_t*            h_stage = nullptr; // pinned twin of d_stage
   void*               h_grid  = nullptr; // pinned: nrphy_dl_slot_load_grid / _read_grid
   void*               h_iq    = nullptr; // pinned: [port][slot_stride] samples
+  nrphy_amplitude_stats_t* d_stats = nullptr; // wire-format pools: the amplitude controller's measurements per port
+  nrphy_amplitude_stats_t* h_stats = nullptr; // ... and their pinned twin
   uint32_t*           d_scratch = nullptr; // sequences and TB-CRC shares of the slot's PDSCH runs (ordered on the stream)
   PlanShapeCache*     shapes  = nullptr;
   std::vector<nrphy_pdsch_plan_t*> plans; // of this open; destroyed when the slot is opened again
@@ -155,13 +157,35 @@ extern "C" int nrphy_dl_slots_create(nrphy_ctx_t* ctx, const nrphy_dl_slots_cfg_
         hipMalloc((void**)&s.d_scratch, pool->scratch_words * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_stage, pool->stage_bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(&s.h_grid, pool->grid_bytes, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc(&s.h_iq, pool->iq_bytes, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc(&s.h_iq, pool->iq_bytes, hipHostMallocDefault) != hipSuccess ||
+        (cfg->iq_format == 1 &&
+         (hipMalloc((void**)&s.d_stats, sizeof(nrphy_amplitude_stats_t) * cfg->nof_ports) != hipSuccess ||
+          hipHostMalloc((void**)&s.h_stats, sizeof(nrphy_amplitude_stats_t) * cfg->nof_ports, hipHostMallocDefault) != hipSuccess))) {
       nrphy_dl_slots_destroy(pool);
       return NRPHY_ERR_DEVICE;
+    }
+    if (s.h_stats != nullptr) {
+      std::memset(s.h_stats, 0, sizeof(nrphy_amplitude_stats_t) * cfg->nof_ports);
     }
     std::memset(s.h_stage, 0, pool->stage_bytes);
     std::memset(s.h_iq, 0, pool->iq_bytes);
     s.shapes = plan_shape_cache_create();
+  }
+  if (cfg->iq_format == 1 && cfg->wire.amplitude.kind == 0) {
+    // A wire-format run with measurements keeps per-workgroup records in a buffer of the OFDM plan that grows with the batch:
+    // the pool runs one grid at a time, so one run here sizes it and the submit path never reallocates.
+    DlSlot& s = pool->slots[0];
+    rc        = hipMemsetAsync(s.d_grid, 0, pool->grid_bytes, s.stream) == hipSuccess ? NRPHY_OK : NRPHY_ERR_DEVICE;
+    if (rc == NRPHY_OK) {
+      rc = nrphy_ofdm_run_ci16(pool->ofdm, 1, s.d_grid, pool->d_slot_numbers, &cfg->wire, (int16_t*)s.d_iq, s.d_stats, s.stream);
+    }
+    if (rc == NRPHY_OK && hipStreamSynchronize(s.stream) != hipSuccess) {
+      rc = NRPHY_ERR_DEVICE;
+    }
+    if (rc != NRPHY_OK) {
+      nrphy_dl_slots_destroy(pool);
+      return rc;
+    }
   }
   *out = pool;
   return NRPHY_OK;
@@ -188,6 +212,8 @@ extern "C" int nrphy_dl_slots_destroy(nrphy_dl_slots_t* pool)
     (void)hipHostFree(s.h_stage);
     (void)hipHostFree(s.h_grid);
     (void)hipHostFree(s.h_iq);
+    (void)hipFree(s.d_stats);
+    (void)hipHostFree(s.h_stats);
     if (s.stream) {
       (void)hipStreamDestroy(s.stream);
     }
@@ -447,7 +473,11 @@ extern "C" int nrphy_dl_slot_modulate(nrphy_dl_slots_t* pool, uint32_t slot_id, 
   }
   const uint32_t* d_slot = pool->d_slot_numbers + subframe_slot_index;
   if (pool->cfg.iq_format == 1) {
-    rc = nrphy_ofdm_run_ci16(pool->ofdm, 1, s->d_grid, d_slot, &pool->cfg.wire, (int16_t*)s->d_iq, nullptr, s->stream);
+    rc = nrphy_ofdm_run_ci16(pool->ofdm, 1, s->d_grid, d_slot, &pool->cfg.wire, (int16_t*)s->d_iq, s->d_stats, s->stream);
+    if (rc == NRPHY_OK && hipMemcpyAsync(s->h_stats, s->d_stats, sizeof(nrphy_amplitude_stats_t) * pool->cfg.nof_ports,
+                                         hipMemcpyDeviceToHost, s->stream) != hipSuccess) {
+      rc = NRPHY_ERR_DEVICE;
+    }
   } else {
     rc = nrphy_ofdm_run(pool->ofdm, 1, s->d_grid, d_slot, (float*)s->d_iq, s->stream);
   }
@@ -505,6 +535,14 @@ extern "C" const void* nrphy_dl_slot_iq(nrphy_dl_slots_t* pool, uint32_t slot_id
     *nof_samples = nrphy_ofdm_slot_size(&pool->cfg.ofdm, s.slot_index);
   }
   return static_cast<const uint8_t*>(s.h_iq) + (size_t)port * pool->slot_stride * pool->sample_bytes;
+}
+
+extern "C" const nrphy_amplitude_stats_t* nrphy_dl_slot_amplitude_stats(nrphy_dl_slots_t* pool, uint32_t slot_id, uint32_t port)
+{
+  if (pool == nullptr || slot_id >= pool->slots.size() || port >= pool->cfg.nof_ports || pool->slots[slot_id].h_stats == nullptr) {
+    return nullptr;
+  }
+  return pool->slots[slot_id].h_stats + port;
 }
 
 extern "C" int nrphy_dl_slot_read_grid(nrphy_dl_slots_t* pool, uint32_t slot_id, void* grid)

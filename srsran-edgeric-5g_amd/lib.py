@@ -577,6 +577,14 @@ class DlSlotPool:
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(n.value, 2)).copy()
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n.value, 2)).copy().view(np.complex64).reshape(-1)
 
+    def amplitude_stats(self, sid, port):
+        """Wire-format pools: a copy of the amplitude controller's raw measurements of the slot's buffer of `port`."""
+        p = self.ctx.lib.nrphy_dl_slot_amplitude_stats(self.handle, sid, port)
+        assert p
+        st = abi.AmplitudeStats()
+        C.memmove(C.byref(st), p, C.sizeof(abi.AmplitudeStats))
+        return st
+
     def read_grid(self, sid):
         grid = np.zeros((self.nof_ports, 14, self.nof_subc, 2), dtype=np.uint16)
         _check(self.ctx.lib.nrphy_dl_slot_read_grid(self.handle, sid, grid.ctypes.data), "nrphy_dl_slot_read_grid")

@@ -1791,6 +1791,12 @@ def test_dl_slot_pipeline_wire_format(gpu_ctx, oracle):
         got = pool.iq(sid, port)
         assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
         assert np.mean(got == want) > 0.999
+        # the amplitude controller's measurements of the buffer, next to the samples in pinned memory
+        y2, m = oracle.amplitude_control(wire.amplitude, ref_iq[port])
+        st = pool.amplitude_stats(sid, port)
+        assert st.nof_samples == want.shape[0] and abs(int(st.nof_clipped) - int(m["nof_clipped"])) <= 2   # (a sample on the ceiling: 1e-7 apart)
+        assert abs(st.sum_power - m["stats"].sum_power) <= 1e-4 * m["stats"].sum_power
+        assert abs(st.peak_power - m["stats"].peak_power) <= 1e-5 * m["stats"].peak_power
     pool.close(sid)
     pool.destroy()
 
