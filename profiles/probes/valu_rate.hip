@@ -70,6 +70,22 @@ __global__ __launch_bounds__(256) void rate(float* out, float seed)
         asm volatile("v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(a[i].x) : "v"(m.x));
       } else if (KIND == 24) { // v_mov_b32 DPP row_shr
         asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(m.x));
+      } else if (KIND == 25) { // round 4: the packed 16-bit instructions of the LDPC decoder -- v_pk_add_i16
+        asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[i].x) : "v"(m.x));
+      } else if (KIND == 26) { // v_pk_min_i16
+        asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(a[i].x) : "v"(m.x));
+      } else if (KIND == 27) { // v_pk_mad_i16
+        asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(m.x), "v"(c.x));
+      } else if (KIND == 28) { // v_pk_lshlrev_b16
+        asm volatile("v_pk_lshlrev_b16 %0, 3, %0" : "+v"(a[i].x));
+      } else if (KIND == 29) { // v_perm_b32
+        asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(m.x), "v"(c.x));
+      } else if (KIND == 30) { // v_pk_mul_lo_u16
+        asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[i].x) : "v"(m.x));
+      } else if (KIND == 31) { // v_lshrrev_b32 (VOP2)
+        asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[i].x));
+      } else if (KIND == 32) { // v_lshl_add_u32
+        asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i].x) : "v"(m.x));
       }
     }
   }
@@ -134,6 +150,14 @@ int main()
   run<21>("v_fma_f32 sgpr operand", out, cus, mhz);
   run<23>("v_and_b32 sdwa", out, cus, mhz);
   run<24>("v_mov_b32 dpp row_shr", out, cus, mhz);
+  run<25>("v_pk_add_i16", out, cus, mhz);
+  run<26>("v_pk_min_i16", out, cus, mhz);
+  run<27>("v_pk_mad_i16", out, cus, mhz);
+  run<28>("v_pk_lshlrev_b16", out, cus, mhz);
+  run<29>("v_perm_b32", out, cus, mhz);
+  run<30>("v_pk_mul_lo_u16", out, cus, mhz);
+  run<31>("v_lshrrev_b32", out, cus, mhz);
+  run<32>("v_lshl_add_u32", out, cus, mhz);
   hipFree(out);
   return 0;
 }

@@ -24,14 +24,14 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "srsran-edgeric-5g_amd", "csrc")
 
-# cycles per instruction and SIMD with several waves (profiles/r01_valu_rate.txt); classes by mnemonic
+# cycles per instruction and SIMD with several waves (profiles/r01_valu_rate.txt, r04_valu_rate.txt); classes by mnemonic
 COSTS = [
     (r"^v_(add|sub|subrev)_(u32|i32|co_u32)|^v_(xor|and|or|not)_b32|^v_mov_b32|^v_(lshlrev|lshrrev|ashrrev)_b32", 2.57, "plain VOP1/VOP2 integer"),
     (r"^v_bitop3_b32", 2.81, "v_bitop3"),
     (r"^v_(fma|mul|add|sub|mac|fmac|max|min)_f32|^v_cvt_(f32|u32|i32)_", 3.44, "scalar FP32"),
     (r"^v_pk_(fma)_f32", 5.42, "packed FP32 fma"),
     (r"^v_pk_(add|mul)_f32", 4.76, "packed FP32 add / mul"),
-    (r"^v_pk_", 4.40, "packed 16-bit (VOP3P)"),
+    (r"^v_pk_", 4.36, "packed 16-bit (VOP3P; profiles/r04_valu_rate.txt: 4.32-4.40)"),
     (r"^v_(cmp|cmpx)_", 4.73, "compare"),
     (r"^v_(readlane|readfirstlane|writelane)", 4.35, "cross-lane"),
 ]
