@@ -1125,7 +1125,7 @@ int adaptor_test_dl_pipeline(unsigned                   n_slots,
   info[7] = g_last_pool ? g_last_pool->nof_load_grid.load() : -1;
   info[8] = g_last_pool ? g_last_pool->nof_read_grid.load() : -1;
   info[9] = g_last_pool ? g_last_pool->nof_put.load() : -1;
-  adaptor.reset(); // before the grids: it gives their slots back
+  // (no particular order of teardown: the grids go first here, the adaptor -- which still holds their slots' leases -- after them)
   return NRPHY_OK;
 }
 

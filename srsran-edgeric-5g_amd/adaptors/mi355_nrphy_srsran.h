@@ -287,6 +287,36 @@ private:
   unsigned                 nof_subc;
 };
 
+/// The pool slot a device-mirrored grid holds, shared with whoever was handed the grid (the pdxch adaptor keeps it in its request
+/// until the slot has been transmitted): it outlives the grid object, so a deferred release is safe whatever the order of teardown.
+struct dl_slot_lease {
+  explicit dl_slot_lease(std::shared_ptr<dl_slot_pool> pool_) : pool(std::move(pool_)) {}
+  ~dl_slot_lease() { release_locked(); }
+  /// Gives the slot back.  Caller holds `mutex` (or is the destructor).
+  void release_locked()
+  {
+    if (have_slot) {
+      nrphy_dl_slot_close(pool->get(), slot_id);
+    }
+    have_slot   = false;
+    handed_over = false;
+  }
+  /// `use`: what hand_over() reported -- the grid pool may have handed the grid out again (set_all_zero) since; then a no-op.
+  void release(uint64_t use)
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    if (use == generation) {
+      release_locked();
+    }
+  }
+  std::shared_ptr<dl_slot_pool> pool;
+  std::mutex                    mutex;               // also guards the owning grid's bookkeeping
+  uint32_t                      slot_id     = 0;
+  std::atomic<bool>             have_slot{false};    // the device layer exists (a slot is held)
+  bool                          handed_over = false; // its modulation has been submitted
+  uint64_t                      generation  = 0;     // uses of the grid (set_all_zero starts a new one)
+};
+
 /// A resource grid whose accelerated channels live in a slot of the pool (HBM) and whose other channels -- whatever is
 /// written through get_writer() or mapped through get_mapper() by processors that are not adaptors of this header -- live
 /// in a host grid of the reference.  The two layers meet on the device when the grid is handed over (hand_over(): the host
@@ -297,19 +327,26 @@ class device_resource_grid : public srsran::resource_grid
 {
 public:
   device_resource_grid(std::shared_ptr<dl_slot_pool> pool_, std::unique_ptr<srsran::resource_grid> host_layer_, std::unique_ptr<srsran::resource_grid> merged_) :
-    pool(std::move(pool_)), host_layer(std::move(host_layer_)), merged(std::move(merged_)), mapper(*this), writer(*this), reader(*this)
+    pool(pool_), lease(std::make_shared<dl_slot_lease>(std::move(pool_))), host_layer(std::move(host_layer_)), merged(std::move(merged_)),
+    mapper(*this), writer(*this), reader(*this)
   {
   }
-  ~device_resource_grid() override { release_slot(); }
+  ~device_resource_grid() override
+  {
+    std::lock_guard<std::mutex> lock(lease->mutex);
+    lease->release_locked();
+    ++lease->generation; // (a release still queued somewhere finds nothing to do)
+  }
 
   // resource_grid
   void set_all_zero() override
   {
-    std::lock_guard<std::mutex> lock(mutex);
+    std::lock_guard<std::mutex> lock(lease->mutex);
     host_layer->set_all_zero();
-    release_slot_locked();
+    lease->release_locked();
     host_touched = false;
     merged_valid = false;
+    ++lease->generation; // a new use of the grid object: a release still queued for the previous use must not touch it
   }
   srsran::resource_grid_writer&       get_writer() override { return writer; }
   const srsran::resource_grid_reader& get_reader() const override { return reader; }
@@ -337,63 +374,58 @@ public:
   template <typename Fn>
   int on_device(Fn&& fn)
   {
-    std::lock_guard<std::mutex> lock(mutex);
-    if (handed_over) {
+    std::lock_guard<std::mutex> lock(lease->mutex);
+    if (lease->handed_over) {
       return NRPHY_ERR_ARGUMENT;
     }
-    if (!have_slot) {
-      int rc = nrphy_dl_slot_open(pool->get(), &slot_id);
+    if (!lease->have_slot) {
+      int rc = nrphy_dl_slot_open(pool->get(), &lease->slot_id);
       if (rc != NRPHY_OK) {
         return rc;
       }
-      have_slot = true;
+      lease->have_slot = true;
     }
     merged_valid = false;
-    return fn(pool->get(), slot_id);
+    return fn(pool->get(), lease->slot_id);
   }
 
   /// Grid hand-over (pdxch_processor_request_handler::handle_request): merges the host layer into the slot's grid and
   /// submits the slot's modulation.  Returns the slot to poll, or -1 when the grid is empty (nothing to transmit) or
   /// no slot could be had (`status` then says why).  Runs on the caller's (upper PHY) thread; const because the
   /// reference hands the grid over as a const reader.
-  int hand_over(unsigned subframe_slot_index, int& status) const
+  int hand_over(unsigned subframe_slot_index, int& status, std::shared_ptr<dl_slot_lease>& held, uint64_t& use) const
   {
     device_resource_grid& self = const_cast<device_resource_grid&>(*this);
-    std::lock_guard<std::mutex> lock(self.mutex);
+    dl_slot_lease&        ls   = *self.lease;
+    std::lock_guard<std::mutex> lock(ls.mutex);
     status = NRPHY_OK;
-    if (!self.have_slot && self.host_layer->get_reader().is_empty()) {
+    held   = self.lease;
+    use    = ls.generation;
+    if (!ls.have_slot && self.host_layer->get_reader().is_empty()) {
       return -1;
     }
-    if (self.handed_over) { // the same grid requested twice for one slot: the IQ is (being) computed already
-      return static_cast<int>(self.slot_id);
+    if (ls.handed_over) { // the same grid requested twice for one slot: the IQ is (being) computed already
+      return static_cast<int>(ls.slot_id);
     }
-    if (!self.have_slot) {
-      status = nrphy_dl_slot_open(pool->get(), &self.slot_id);
+    if (!ls.have_slot) {
+      status = nrphy_dl_slot_open(pool->get(), &ls.slot_id);
       if (status != NRPHY_OK) {
         return -1;
       }
-      self.have_slot = true;
+      ls.have_slot = true;
     }
     status = self.flush_host_layer();
     if (status == NRPHY_OK) {
-      status = nrphy_dl_slot_modulate(pool->get(), self.slot_id, subframe_slot_index, nullptr, nullptr);
+      status = nrphy_dl_slot_modulate(pool->get(), ls.slot_id, subframe_slot_index, nullptr, nullptr);
     }
     if (status != NRPHY_OK) {
       return -1;
     }
-    self.handed_over = true;
-    return static_cast<int>(self.slot_id);
+    ls.handed_over = true;
+    return static_cast<int>(ls.slot_id);
   }
 
-  /// Gives the slot back (the slot has been transmitted, or was dropped): what the pdxch adaptor calls from the upper
-  /// PHY's thread.  The next set_all_zero() would do it too -- this makes the slot available a grid-pool cycle earlier.
-  void release_slot() const
-  {
-    device_resource_grid& self = const_cast<device_resource_grid&>(*this);
-    std::lock_guard<std::mutex> lock(self.mutex);
-    self.release_slot_locked();
-  }
-
+  /// (Giving the slot back early -- once it has been transmitted -- goes through the lease hand_over() returned: dl_slot_lease::release.)
   const std::shared_ptr<dl_slot_pool>& get_pool() const { return pool; }
 
 private:
@@ -450,8 +482,8 @@ private:
     unsigned get_nof_symbols() const override { return owner.host_layer->get_reader().get_nof_symbols(); }
     // No device access here: pdxch_processor_impl::process_symbol asks on the real-time thread.  A port the device layer
     // may have written counts as not empty.
-    bool is_empty(unsigned port) const override { return !owner.have_slot && owner.host_layer->get_reader().is_empty(port); }
-    bool is_empty() const override { return !owner.have_slot && owner.host_layer->get_reader().is_empty(); }
+    bool is_empty(unsigned port) const override { return !owner.lease->have_slot && owner.host_layer->get_reader().is_empty(port); }
+    bool is_empty() const override { return !owner.lease->have_slot && owner.host_layer->get_reader().is_empty(); }
     srsran::span<srsran::cf_t> get(srsran::span<srsran::cf_t> symbols, unsigned port, unsigned l, unsigned k_init, const srsran::bounded_bitset<srsran::MAX_RB * srsran::NRE>& mask) const override
     {
       return owner.host_view().get(symbols, port, l, k_init, mask);
@@ -474,18 +506,9 @@ private:
 
   void touch_host()
   {
-    std::lock_guard<std::mutex> lock(mutex);
+    std::lock_guard<std::mutex> lock(lease->mutex);
     host_touched = true;
     merged_valid = false;
-  }
-
-  void release_slot_locked()
-  {
-    if (have_slot) {
-      nrphy_dl_slot_close(pool->get(), slot_id);
-    }
-    have_slot   = false;
-    handed_over = false;
   }
 
   // The host layer's resource elements as sparse entries (a value of zero is "not written": what the reference's writers
@@ -518,22 +541,22 @@ private:
     std::vector<nrphy_grid_re_t> entries;
     host_layer_entries(entries);
     host_touched = false; // (what the host layer holds stays there: a later read merges it again, idempotently)
-    return entries.empty() ? NRPHY_OK : nrphy_dl_slot_put(pool->get(), slot_id, entries.size(), entries.data());
+    return entries.empty() ? NRPHY_OK : nrphy_dl_slot_put(pool->get(), lease->slot_id, entries.size(), entries.data());
   }
 
   // The whole grid on the host, for whoever reads it there: blocking.
   const srsran::resource_grid_reader& host_view() const
   {
     device_resource_grid& self = const_cast<device_resource_grid&>(*this);
-    std::lock_guard<std::mutex> lock(self.mutex);
-    if (!have_slot) {
+    std::lock_guard<std::mutex> lock(self.lease->mutex);
+    if (!lease->have_slot) {
       return host_layer->get_reader();
     }
     if (!merged_valid) {
       const srsran::resource_grid_reader& r        = host_layer->get_reader();
       const unsigned                      nof_subc = r.get_nof_subc(), nof_ports = r.get_nof_ports();
       std::vector<srsran::cbf16_t>        raw(static_cast<size_t>(pool->get_nof_ports()) * NRPHY_NSYMB * nof_subc);
-      int rc = nrphy_dl_slot_read_grid(pool->get(), slot_id, raw.data());
+      int rc = nrphy_dl_slot_read_grid(pool->get(), lease->slot_id, raw.data());
       report_failure("nrphy_dl_slot_read_grid", rc);
       self.merged->set_all_zero();
       for (unsigned port = 0; port != nof_ports && port != pool->get_nof_ports(); ++port) {
@@ -554,15 +577,12 @@ private:
   }
 
   std::shared_ptr<dl_slot_pool>          pool;
+  std::shared_ptr<dl_slot_lease>         lease;      // the pool slot of the device layer (shared with the lower PHY's request)
   std::unique_ptr<srsran::resource_grid> host_layer; // what host-side processors write
   std::unique_ptr<srsran::resource_grid> merged;     // device + host layers, built only when somebody reads on the host
   mapper_type                            mapper;
   writer_type                            writer;
   reader_type                            reader;
-  std::mutex                             mutex;
-  uint32_t                               slot_id      = 0;
-  std::atomic<bool>                      have_slot{false};     // the device layer exists (a slot is held)
-  bool                                   handed_over  = false; // its modulation has been submitted
   bool                                   host_touched = false;
   bool                                   merged_valid = false;
 };
@@ -1104,7 +1124,8 @@ private:
   // A request of the pool: the slot it is for and where its IQ will be.
   struct request {
     srsran::slot_point          slot;
-    const device_resource_grid* grid      = nullptr; // device-mirrored grid handed over (it owns its pool slot)
+    std::shared_ptr<dl_slot_lease> lease;            // a device-mirrored grid was handed over: its pool slot ...
+    uint64_t                       lease_use = 0;    // ... and which use of the grid object this request belongs to
     int                         pool_slot = -1;      // pool slot with the request's IQ; -1: nothing to transmit
     bool                        own_slot  = false;   // the adaptor opened pool_slot (a plain host grid was loaded into it)
     bool                        valid     = false;   // a grid was given (what the reference encodes as grid != nullptr)
@@ -1133,8 +1154,7 @@ private:
     r.valid = true;
     int status = NRPHY_OK;
     if (const device_resource_grid* dg = device_resource_grid::from(grid)) {
-      r.grid      = dg;
-      r.pool_slot = dg->hand_over(context.slot.subframe_slot_index(), status);
+      r.pool_slot = dg->hand_over(context.slot.subframe_slot_index(), status, r.lease, r.lease_use);
     } else if (!grid.is_empty()) {
       uint32_t id = 0;
       status      = nrphy_dl_slot_open(pool->get(), &id);
@@ -1224,7 +1244,7 @@ private:
   // synchronises its stream -- idle by then, but still a runtime call).
   void retire(const request& r)
   {
-    if (!r.valid || (r.grid == nullptr && !r.own_slot)) {
+    if (!r.valid || (!r.lease && !r.own_slot)) {
       return;
     }
     std::lock_guard<std::mutex> lock(retired_mutex);
@@ -1243,8 +1263,8 @@ private:
   }
   void release(const request& r)
   {
-    if (r.grid != nullptr) {
-      r.grid->release_slot();
+    if (r.lease) {
+      r.lease->release(r.lease_use);
     } else if (r.own_slot && r.pool_slot >= 0) {
       nrphy_dl_slot_close(pool->get(), r.pool_slot);
     }
