@@ -296,35 +296,48 @@ def dl_slot_pipeline(ctx=None, depths=(1, 2, 4, 8), total=600, verbose=True, che
             ph = pool.handle
             sid = C.c_uint32()
 
+            spans = {"wait": 0.0, "pdsch": 0.0, "modulate": 0.0}   # host time inside the calls (seconds, timed region)
+
             def pump(n_slots):
                 ring = []
+                clock = time.perf_counter
                 for k in range(n_slots):
                     if len(ring) == depth:
                         old = ring.pop(0)
+                        t = clock()
                         assert h.nrphy_dl_slot_wait(ph, old) == 0
+                        spans["wait"] += clock() - t
                         assert h.nrphy_dl_slot_close(ph, old) == 0
                     assert h.nrphy_dl_slot_open(ph, C.byref(sid)) == 0
                     pr, tbp = refs[k % len(refs)]
+                    t = clock()
                     assert h.nrphy_dl_slot_pdsch(ph, sid.value, 1, pr, tbp) == 0
+                    t1 = clock()
                     assert h.nrphy_dl_slot_modulate(ph, sid.value, k % 2, None, None) == 0
+                    spans["pdsch"] += t1 - t
+                    spans["modulate"] += clock() - t1
                     ring.append(sid.value)
                 for old in ring:
                     assert h.nrphy_dl_slot_wait(ph, old) == 0
                     assert h.nrphy_dl_slot_close(ph, old) == 0
 
             pump(64)
+            for key in spans:
+                spans[key] = 0.0
             t0 = time.perf_counter()
             pump(total)
             dt = time.perf_counter() - t0
             pool.destroy()
             r = {"leg": leg, "in_flight": depth, "slots_per_sec": round(total / dt, 1), "ms_per_slot": round(1e3 * dt / total, 4),
                  "pcie_bytes_down": int(np.mean([p.tb_size_bytes for p, _ in items])) + 4096,
-                 "pcie_bytes_up": ports * slot_samples * sample_bytes}
+                 "pcie_bytes_up": ports * slot_samples * sample_bytes,
+                 "host_us_per_slot": {key: round(1e6 * v / total, 1) for key, v in spans.items()}}
             results.append(r)
             if verbose:
                 print("slot pipeline %s, live traffic, %d in flight: %.0f slots/s (%.3f ms per slot); PCIe per slot: %d B down "
-                      "(transport block + plan tables), %d B up (IQ)" % (leg, depth, r["slots_per_sec"], r["ms_per_slot"],
-                                                                         r["pcie_bytes_down"], r["pcie_bytes_up"]), flush=True)
+                      "(transport block + plan tables), %d B up (IQ); host time inside the calls, us per slot: %s" % (
+                          leg, depth, r["slots_per_sec"], r["ms_per_slot"], r["pcie_bytes_down"], r["pcie_bytes_up"],
+                          r["host_us_per_slot"]), flush=True)
     return results
 
 

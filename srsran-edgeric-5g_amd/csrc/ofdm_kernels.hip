@@ -381,6 +381,15 @@ __device__ __forceinline__ void stage_first(cf (&a)[Plan<N>::R0], cf base, cf* l
   __syncthreads();
 }
 
+// A sink that wants the R outputs of a last-stage thread in one call says so with a member constant `all_outputs`.
+// (std::is_invocable on the sink's call operator is no test for it: the trait is evaluated inside host-side library templates,
+// where a __device__ operator is never viable -- it answered "no" for every sink, and until round 4 both modulator kernels
+// silently took the one-output-at-a-time form.)
+template <typename Store, typename = void>
+struct takes_all_outputs : std::false_type {};
+template <typename Store>
+struct takes_all_outputs<Store, std::void_t<decltype(Store::all_outputs)>> : std::bool_constant<Store::all_outputs> {};
+
 // A later Stockham stage (decimation in frequency, autosort).  n = N / S is the current transform length.
 //   a[k] = x[q + S (p + k n/R)],   y[q + S (R p + j)] = DFT_R(a)[j] * w_n^(j p),   p < n/R, q < S.
 template <int SIGN, int N, int T, int R, int S, bool LAST, typename Store>
@@ -420,7 +429,7 @@ __device__ __forceinline__ void stage_lds(cf* lds, const float2* __restrict__ tw
       if constexpr (LAST) {
         // The last stage has S * R = N, hence p = 0: output index = q + S * j, a per-thread part and a constant.
         static_assert(S * R == N, "last stage");
-        if constexpr (std::is_invocable_v<Store, uint32_t, Const<S>, cf(&)[R]>) {
+        if constexpr (takes_all_outputs<Store>::value) {
           store(q, Const<S>{}, a[it]); // the sink takes the thread's R outputs together (it may pair them up)
         } else {
           static_for<R>([&](auto J) { store(q, Const<S * decltype(J)::value>{}, Const<S>{}, a[it][decltype(J)::value]); });
@@ -484,20 +493,18 @@ constexpr int AUX_NT = NRPHY_IQ_STORE_AUX;
 // constant part of every address in the scalar offset.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-// The value lane ^ 1 holds (DPP quad_perm [1, 0, 3, 2]).
-__device__ __forceinline__ cf from_neighbour(cf v)
-{
-  const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0xB1, 0xF, 0xF, true);
-  const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0xB1, 0xF, 0xF, true);
-  return make_cf(__int_as_float(x), __int_as_float(y));
-}
-
 // Output side of ofdm_kernel: phase compensation x scale, then the symbol and its cyclic prefix (the tail of the
 // symbol, ofdm_modulator_impl.cpp:92-99) through the buffer descriptor `rsrc` whose record 0 is the first sample of
-// the prefix.  A thread of the last stage holds outputs q + S j; neighbouring lanes hold neighbouring samples, so lane
-// pairs swap half of their outputs and every lane writes 16-byte pairs of consecutive samples (the arithmetic-free
-// probe of this traffic shape streams 2.5 % faster with 16-byte stores).  The prefix never exceeds N / 4 (extended
-// CP), so only the outputs of the last quarter test for it.
+// the prefix.  A thread of the last stage holds outputs q + S j; neighbouring lanes hold neighbouring samples, so every store
+// instruction of a wave writes 512 contiguous bytes.  The prefix never exceeds N / 4 (extended CP), so only the outputs of the
+// last quarter test for it.
+// (A form that swapped half of the outputs between lane pairs to write 16-byte pairs of consecutive samples existed from
+// round 2 on and was never selected -- see takes_all_outputs.  Selected at last in round 4 it was slower, 0.58 against 0.46 ms
+// per 1024 config-3 slots: 80 more vector instructions per symbol for the swaps outweigh the wider stores; removed,
+// profiles/r04_ofdm_sinks.txt.)
+#ifndef NRPHY_SINK_ALL_WIRE
+#define NRPHY_SINK_ALL_WIRE 1 // 0: the wire-format sink one output per call, always through the exact path (the form that ran until round 4)
+#endif
 template <int N>
 struct IqSink {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -523,29 +530,6 @@ struct IqSink {
     }
   }
 
-  // The thread's R outputs idx = q + S j at once.
-  template <uint32_t S, int R>
-  __device__ __forceinline__ void operator()(uint32_t q, Const<S>, cf (&a)[R]) const
-  {
-    const bool     odd  = (q & 1u) != 0;
-    const uint32_t voff = ((q & ~1u) + (odd ? S : 0u)) * 8u; // even lanes write pair j0 = 2i, odd lanes j1 = 2i + 1
-    static_for<R / 2>([&](auto I) {
-      constexpr uint32_t j0   = 2 * decltype(I)::value;
-      const cf           keep = odd ? a[j0 + 1] : a[j0];
-      const cf           recv = from_neighbour(odd ? a[j0] : a[j0 + 1]);
-      const cf           y0 = cmul_uniform(odd ? recv : keep, ph), y1 = cmul_uniform(odd ? keep : recv, ph);
-      const u32x4_t      d  = {__float_as_uint(y0.x), __float_as_uint(y0.y), __float_as_uint(y1.x), __float_as_uint(y1.y)};
-      __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)voff, (int)((cp + S * j0) * 8u), AUX_NT);
-      if constexpr (S * (j0 + 2) > N - N / 4) {
-        const uint32_t i = (q & ~1u) + S * (odd ? j0 + 1 : j0);
-        prefix_copy(i, u32x2_t{d.x, d.y});
-        prefix_copy(i + 1u, u32x2_t{d.z, d.w});
-      }
-    });
-    if constexpr (R % 2 != 0) { // the odd one out (radix 3) goes alone
-      (*this)(q, Const<S * (R - 1)>{}, Const<S>{}, a[R - 1]);
-    }
-  }
 };
 
 // The same output side with the samples leaving as complex int16: every sample goes through
@@ -592,6 +576,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 #endif
 template <int N>
 struct IqSinkCi16 {
+  static constexpr bool  all_outputs = NRPHY_SINK_ALL_WIRE != 0;
   __amdgpu_buffer_rsrc_t rsrc;
   cf                     ph;
   uint32_t               cp;
