@@ -341,6 +341,70 @@ def dl_slot_pipeline(ctx=None, depths=(1, 2, 4, 8), total=600, verbose=True, che
     return results
 
 
+def dl_slot_pipeline_threads(ctx=None, thread_counts=(1, 2, 4), depth=4, total=1200, verbose=True):
+    """The wire-format leg of dl_slot_pipeline with several submitting threads on ONE pool (a DU runs one upper-PHY thread per
+    cell): every thread opens, fills, modulates and waits for its own slots, `depth` of them in flight per thread.  The calls
+    release Python's interpreter lock, so the threads really overlap inside the library and the HIP runtime."""
+    import ctypes as C
+    import threading
+    import backends
+    import cases
+    abi, lib = backends.abi, backends.pkg.lib
+    ctx = ctx or lib.Context(0)
+    h = ctx.lib
+    rng = np.random.default_rng(11)
+    items = live_pdu_pool(rng)
+    _, ports, subc, ofdm = cases.baseline_config(3)
+    max_tb = max(p.tb_size_bytes for p, _ in items)
+    refs = [(C.byref(p), (C.c_void_p * 1)(tb.ctypes.data)) for p, tb in items]
+    wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -12.0, 1.0, -1.0), 32767.0 / 64.0)
+    results = []
+    for n_threads in thread_counts:
+        pool = lib.DlSlotPool(ctx, ofdm, ports, depth * n_threads, max_tb, wire_cfg=wire)
+        ph = pool.handle
+        errors = []
+
+        def pump(n_slots, first):
+            sid = C.c_uint32()
+            ring = []
+            try:
+                for k in range(n_slots):
+                    if len(ring) == depth:
+                        old = ring.pop(0)
+                        assert h.nrphy_dl_slot_wait(ph, old) == 0 and h.nrphy_dl_slot_close(ph, old) == 0
+                    assert h.nrphy_dl_slot_open(ph, C.byref(sid)) == 0
+                    pr, tbp = refs[(first + k) % len(refs)]
+                    assert h.nrphy_dl_slot_pdsch(ph, sid.value, 1, pr, tbp) == 0
+                    assert h.nrphy_dl_slot_modulate(ph, sid.value, k % 2, None, None) == 0
+                    ring.append(sid.value)
+                for old in ring:
+                    assert h.nrphy_dl_slot_wait(ph, old) == 0 and h.nrphy_dl_slot_close(ph, old) == 0
+            except AssertionError as e:   # (reported by the caller: an exception in a thread would otherwise go unnoticed)
+                errors.append(e)
+
+        def run(n_each):
+            threads = [threading.Thread(target=pump, args=(n_each, 17 * t)) for t in range(n_threads)]
+            t0 = time.perf_counter()
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            return time.perf_counter() - t0
+
+        run(64)
+        dt = run(total // n_threads)
+        pool.destroy()
+        assert not errors, errors
+        done = (total // n_threads) * n_threads
+        r = {"leg": "tb_in_ci16_iq_out", "submitting_threads": n_threads, "in_flight_per_thread": depth,
+             "slots_per_sec": round(done / dt, 1), "ms_per_slot": round(1e3 * dt / done, 4)}
+        results.append(r)
+        if verbose:
+            print("slot pipeline tb_in_ci16_iq_out, live traffic, %d submitting thread(s) x %d in flight: %.0f slots/s (%.3f ms per slot)"
+                  % (n_threads, depth, r["slots_per_sec"], r["ms_per_slot"]), flush=True)
+    return results
+
+
 def seams_apart(ctx=None, total=300, verbose=True):
     """What round 3's adaptors did per slot, for comparison: seam A through the asynchronous queue (transport block down, grid
     up), then seam C through the blocking host-span modulator (grid down, IQ up), one slot in flight."""
@@ -385,9 +449,11 @@ if __name__ == "__main__":
         live_traffic()
     elif "--pipeline" in sys.argv:
         dl_slot_pipeline()
+        dl_slot_pipeline_threads()
         seams_apart()
     else:
         main()
         live_traffic()
         dl_slot_pipeline()
+        dl_slot_pipeline_threads()
         seams_apart()

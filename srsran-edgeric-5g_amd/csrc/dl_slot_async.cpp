@@ -57,6 +57,11 @@ struct nrphy_dl_slots {
   uint32_t                nof_subc = 0, slot_stride = 0, sample_bytes = 8;
   size_t                  grid_bytes = 0, iq_bytes = 0, stage_bytes = 0, scratch_words = 0, tb_cap = 0;
   uint32_t*               d_slot_numbers = nullptr; // 0, 1, ... : nrphy_ofdm_run takes the slot index from device memory
+  size_t                  iq_block_bytes = 0; // the IQ of a slot and, behind it on a 256-byte boundary, a wire-format pool's measurements
+  // NRPHY_DL_SLOT_ZERO_COPY (read at creation): bit 0 = the kernels read transport blocks and plan tables from the pinned staging
+  // in place (no copy down), bit 1 = the modulator writes IQ and measurements into the pinned buffer in place (no copy up).
+  // hipMemcpyAsync is the most expensive call of a submit (9 us of host time each, DESIGN_HISTORY.md round 2).
+  uint32_t                zero_copy = 0;
   std::vector<DlSlot>     slots;
   std::mutex              mutex; // open / close
   std::condition_variable changed;
@@ -128,6 +133,11 @@ extern "C" int nrphy_dl_slots_create(nrphy_ctx_t* ctx, const nrphy_dl_slots_cfg_
   pool->sample_bytes = cfg->iq_format == 1 ? 4 : 8;
   pool->grid_bytes   = (size_t)cfg->nof_ports * NRPHY_NSYMB * pool->nof_subc * 4;
   pool->iq_bytes     = (size_t)cfg->nof_ports * pool->slot_stride * pool->sample_bytes;
+  const size_t stats_bytes = cfg->iq_format == 1 ? sizeof(nrphy_amplitude_stats_t) * cfg->nof_ports : 0;
+  pool->iq_block_bytes     = stats_bytes != 0 ? ((pool->iq_bytes + 255) & ~(size_t)255) + stats_bytes : pool->iq_bytes;
+  if (const char* e = std::getenv("NRPHY_DL_SLOT_ZERO_COPY")) {
+    pool->zero_copy = (uint32_t)std::atoi(e) & 3u;
+  }
   // Staging: the slot's transport blocks (each call's rounded up to 256 bytes) and, behind each call's blocks, its plan
   // tables -- a few KB for wideband PDUs, two bytes per RE for fragmented allocations (pdsch_async.cpp sizes one operation
   // the same way); room for four calls' worth of tables, more calls share what is left.
@@ -151,24 +161,26 @@ extern "C" int nrphy_dl_slots_create(nrphy_ctx_t* ctx, const nrphy_dl_slots_cfg_
   for (DlSlot& s : pool->slots) {
     s.pool = pool;
     s.id   = id++;
+    const bool stage_in_place = (pool->zero_copy & 1u) != 0, iq_in_place = (pool->zero_copy & 2u) != 0;
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&s.d_grid, pool->grid_bytes) != hipSuccess || hipMalloc(&s.d_iq, pool->iq_bytes) != hipSuccess ||
-        hipMalloc((void**)&s.d_stage, pool->stage_bytes) != hipSuccess ||
+        hipMalloc((void**)&s.d_grid, pool->grid_bytes) != hipSuccess ||
         hipMalloc((void**)&s.d_scratch, pool->scratch_words * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_stage, pool->stage_bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(&s.h_grid, pool->grid_bytes, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc(&s.h_iq, pool->iq_bytes, hipHostMallocDefault) != hipSuccess ||
-        (cfg->iq_format == 1 &&
-         (hipMalloc((void**)&s.d_stats, sizeof(nrphy_amplitude_stats_t) * cfg->nof_ports) != hipSuccess ||
-          hipHostMalloc((void**)&s.h_stats, sizeof(nrphy_amplitude_stats_t) * cfg->nof_ports, hipHostMallocDefault) != hipSuccess))) {
+        hipHostMalloc(&s.h_iq, pool->iq_block_bytes, hipHostMallocDefault) != hipSuccess ||
+        (stage_in_place ? hipHostGetDevicePointer((void**)&s.d_stage, s.h_stage, 0)
+                        : hipMalloc((void**)&s.d_stage, pool->stage_bytes)) != hipSuccess ||
+        (iq_in_place ? hipHostGetDevicePointer(&s.d_iq, s.h_iq, 0) : hipMalloc(&s.d_iq, pool->iq_block_bytes)) != hipSuccess) {
       nrphy_dl_slots_destroy(pool);
       return NRPHY_ERR_DEVICE;
     }
-    if (s.h_stats != nullptr) {
-      std::memset(s.h_stats, 0, sizeof(nrphy_amplitude_stats_t) * cfg->nof_ports);
-    }
     std::memset(s.h_stage, 0, pool->stage_bytes);
-    std::memset(s.h_iq, 0, pool->iq_bytes);
+    std::memset(s.h_iq, 0, pool->iq_block_bytes);
+    if (stats_bytes != 0) { // (behind the IQ on both sides: one copy brings both up)
+      const size_t at = pool->iq_block_bytes - stats_bytes;
+      s.d_stats       = reinterpret_cast<nrphy_amplitude_stats_t*>(static_cast<uint8_t*>(s.d_iq) + at);
+      s.h_stats       = reinterpret_cast<nrphy_amplitude_stats_t*>(static_cast<uint8_t*>(s.h_iq) + at);
+    }
     s.shapes = plan_shape_cache_create();
   }
   if (cfg->iq_format == 1 && cfg->wire.amplitude.kind == 0) {
@@ -206,14 +218,16 @@ extern "C" int nrphy_dl_slots_destroy(nrphy_dl_slots_t* pool)
     }
     plan_shape_cache_destroy(s.shapes);
     (void)hipFree(s.d_grid);
-    (void)hipFree(s.d_iq);
-    (void)hipFree(s.d_stage);
+    if ((pool->zero_copy & 2u) == 0) {
+      (void)hipFree(s.d_iq);
+    }
+    if ((pool->zero_copy & 1u) == 0) {
+      (void)hipFree(s.d_stage);
+    }
     (void)hipFree(s.d_scratch);
     (void)hipHostFree(s.h_stage);
     (void)hipHostFree(s.h_grid);
-    (void)hipHostFree(s.h_iq);
-    (void)hipFree(s.d_stats);
-    (void)hipHostFree(s.h_stats);
+    (void)hipHostFree(s.h_iq); // (the measurements live in the same blocks)
     if (s.stream) {
       (void)hipStreamDestroy(s.stream);
     }
@@ -357,7 +371,9 @@ extern "C" int nrphy_dl_slot_pdsch(nrphy_dl_slots_t* pool, uint32_t slot_id, uin
     std::memset(h_base + tb_off[i] + pdus[i].tb_size_bytes, 0, span - pdus[i].tb_size_bytes);
   }
   const size_t copy_bytes = own_memory ? tb_total : tables_at + place.table_bytes;
-  HIP_TRY(hipMemcpyAsync(d_base, h_base, copy_bytes, hipMemcpyHostToDevice, s->stream));
+  if ((pool->zero_copy & 1u) == 0) {
+    HIP_TRY(hipMemcpyAsync(d_base, h_base, copy_bytes, hipMemcpyHostToDevice, s->stream));
+  }
   // The first writer of the slot clears what it does not map in the same launch; later ones leave the rest alone.
   const int zero_grids = s->grid_defined ? 0 : 1;
   rc                   = nrphy_pdsch_run(plan, d_base, s->d_grid, nullptr, nullptr, zero_grids, s->stream);
@@ -474,10 +490,6 @@ extern "C" int nrphy_dl_slot_modulate(nrphy_dl_slots_t* pool, uint32_t slot_id, 
   const uint32_t* d_slot = pool->d_slot_numbers + subframe_slot_index;
   if (pool->cfg.iq_format == 1) {
     rc = nrphy_ofdm_run_ci16(pool->ofdm, 1, s->d_grid, d_slot, &pool->cfg.wire, (int16_t*)s->d_iq, s->d_stats, s->stream);
-    if (rc == NRPHY_OK && hipMemcpyAsync(s->h_stats, s->d_stats, sizeof(nrphy_amplitude_stats_t) * pool->cfg.nof_ports,
-                                         hipMemcpyDeviceToHost, s->stream) != hipSuccess) {
-      rc = NRPHY_ERR_DEVICE;
-    }
   } else {
     rc = nrphy_ofdm_run(pool->ofdm, 1, s->d_grid, d_slot, (float*)s->d_iq, s->stream);
   }
@@ -488,7 +500,9 @@ extern "C" int nrphy_dl_slot_modulate(nrphy_dl_slots_t* pool, uint32_t slot_id, 
   s->done       = done;
   s->user       = user;
   s->state.store(SLOT_MODULATING, std::memory_order_release);
-  if (hipMemcpyAsync(s->h_iq, s->d_iq, pool->iq_bytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+  // IQ and, for a wire-format pool, the measurements behind it come up in ONE copy -- or were written in place.
+  if (((pool->zero_copy & 2u) == 0 &&
+       hipMemcpyAsync(s->h_iq, s->d_iq, pool->iq_block_bytes, hipMemcpyDeviceToHost, s->stream) != hipSuccess) ||
       hipStreamAddCallback(s->stream, on_slot_done, s, 0) != hipSuccess) {
     (void)hipStreamSynchronize(s->stream);
     s->status.store(NRPHY_ERR_DEVICE, std::memory_order_relaxed);

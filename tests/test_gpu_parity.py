@@ -1569,13 +1569,15 @@ def _merge(want, part):
     return want
 
 
-@pytest.mark.parametrize("first", ["pdcch", "pdsch"])
-def test_dl_slot_pipeline_whole_slot_tb_to_iq(gpu_ctx, oracle, first):
+@pytest.mark.parametrize("first", ["pdcch", "pdsch", "pdsch-zero-copy"])
+def test_dl_slot_pipeline_whole_slot_tb_to_iq(gpu_ctx, oracle, monkeypatch, first):
     """Every grid writer of a slot through nrphy_dl_slot_* into the slot's device grid, the grid handed over with
     nrphy_dl_slot_modulate, IQ read from the slot's pinned buffer: grid bit-exact (read back only to check), IQ <= 1e-5, the
     completion handler called once from another thread, poll / wait / iq as process_symbol uses them.  `first` = which writer
     meets the still undefined grid (a PDSCH run clears what it does not map itself, the others need the memset)."""
     import threading
+    if first == "pdsch-zero-copy":   # (NRPHY_DL_SLOT_ZERO_COPY=3: no copy down, no copy up; read when the pool is created)
+        monkeypatch.setenv("NRPHY_DL_SLOT_ZERO_COPY", "3")
     rng = np.random.default_rng(2718)
     nof_ports, nof_rb = 2, 52
     nof_subc = 12 * nof_rb
@@ -1771,9 +1773,13 @@ def test_dl_slot_pipeline_driven_from_several_threads(gpu_ctx, oracle):
     pool.destroy()
 
 
-def test_dl_slot_pipeline_wire_format(gpu_ctx, oracle):
+@pytest.mark.parametrize("zero_copy", [0, 1, 2, 3])
+def test_dl_slot_pipeline_wire_format(gpu_ctx, oracle, monkeypatch, zero_copy):
     """A pool created with iq_format 1: the slot leaves the device as complex int16 after the amplitude controller
-    (nrphy_ofdm_run_ci16) -- half the bytes over PCIe; within one LSB of the oracle's chain."""
+    (nrphy_ofdm_run_ci16) -- half the bytes over PCIe; within one LSB of the oracle's chain.  IQ and measurements share one
+    pinned block (one copy up).  zero_copy: NRPHY_DL_SLOT_ZERO_COPY, read when the pool is created -- bit 0: the kernels read
+    the pinned staging in place, bit 1: the modulator writes the pinned IQ block in place."""
+    monkeypatch.setenv("NRPHY_DL_SLOT_ZERO_COPY", str(zero_copy))
     rng = np.random.default_rng(515)
     nof_ports, nof_rb = 2, 106
     ocfg = abi.OfdmConfig(0, nof_rb, 2048, 0, 1.0 / np.sqrt(2048), 3.5e9)
