@@ -728,7 +728,8 @@ __global__ __launch_bounds__(Plan<N>::T) OFDM_OCCUPANCY void ofdm_kernel(OfdmLau
   const uint32_t    gp   = gz * p.nof_ports + blockIdx.y; // grid * nof_ports + port
   const uint32_t    slot = d_slot_index ? to_constant(d_slot_index)[gz] : 0u;
   const uint32_t    t4   = (tid + (p.rg_size >> 1)) * 4u;
-  const uint32_t*   rows = d_grid + (size_t)gp * NRPHY_NSYMB * p.rg_size;
+  // (NRPHY_OFDM_PROBE bit 3: every workgroup reads the first (grid, port)'s rows -- the same loads from 183 KB that stay in the L2)
+  const uint32_t*   rows = d_grid + ((NRPHY_PROBE(p) & 8u) ? (size_t)0 : (size_t)gp * NRPHY_NSYMB * p.rg_size);
   float2*           iq   = d_iq + (size_t)gp * p.slot_stride;
   float             w_sum = 0.f, w_peak = 0.f; // amplitude controller measurements of this thread (WIRE)
   uint32_t          w_clipped = 0;
