@@ -960,7 +960,8 @@ public:
 
 // The downlink slot pipeline end to end on the reference's own objects: per slot a PDCCH, a PDSCH, (slot 0) an SS/PBCH
 // block and a CSI-RS through the adaptors of this repository into a grid of device_resource_grid_factory (mirrored != 0)
-// or a plain grid of the reference, plus a few resource elements written through the grid's own writer (a channel the
+// or a plain grid of the reference (mirrored == 2: a device-mirrored grid filled by the REFERENCE's own processors through
+// its mapper / writer -- everything lands in the host layer, and the hand-over takes it to the device as one grid copy), plus a few resource elements written through the grid's own writer (a channel the
 // library does not generate); the grid handed to pdxch_processor_adaptor::handle_request; then the lower PHY's loop --
 // process_symbol for every symbol of every slot, as downlink_processor_baseband_impl::process_new_symbol calls it -- next
 // to the reference's pdxch_processor_impl + ofdm_symbol_modulator_impl fed by the reference's own processors.
@@ -1038,24 +1039,38 @@ int adaptor_test_dl_pipeline(unsigned                   n_slots,
     ref_grids[i]->set_all_zero();
     const slot_point slot(c->numerology, 0, i);
     // PDCCH
+    const bool host_processors = mirrored == 2;
     pdcch_processor::pdu_t cch = ref_make_pdcch_pdu(pdcch[i]);
-    pdcch_adaptor.process(grids[i]->get_mapper(), cch);
+    if (host_processors) {
+      ref_make_pdcch_processor()->process(grids[i]->get_mapper(), cch);
+    } else {
+      pdcch_adaptor.process(grids[i]->get_mapper(), cch);
+    }
     ref_make_pdcch_processor()->process(ref_grids[i]->get_mapper(), cch);
     // PDSCH
     pdsch_processor::pdu_t sch = ref_make_pdsch_pdu(pdsch[i]);
     counting_notifier      done, ref_done;
     static_vector<span<const uint8_t>, pdsch_processor::MAX_NOF_TRANSPORT_BLOCKS> data;
     data.push_back(span<const uint8_t>(tbs[i], pdsch[i].tb_size_bytes));
-    pdsch_adaptor.process(grids[i]->get_mapper(), done, data, sch);
+    if (host_processors) {
+      ref_pdsch->process(grids[i]->get_mapper(), done, data, sch);
+    } else {
+      pdsch_adaptor.process(grids[i]->get_mapper(), done, data, sch);
+    }
     synchronous += done.count; // a device-mirrored grid: the PDU is enqueued and acknowledged at once
     done.wait(1);
     ref_pdsch->process(ref_grids[i]->get_mapper(), ref_done, data, sch);
     if (i == 0) {
       ssb_processor::pdu_t blk = ref_make_ssb_pdu(*ssb);
-      ssb_adaptor.process(grids[i]->get_writer(), blk);
-      ref_make_ssb_processor()->process(ref_grids[i]->get_writer(), blk);
       nzp_csi_rs_generator::config_t rs = make_csi_rs_config(csi);
-      csi_adaptor.map(grids[i]->get_mapper(), rs);
+      if (host_processors) {
+        ref_make_ssb_processor()->process(grids[i]->get_writer(), blk);
+        ref_csi.map(grids[i]->get_mapper(), rs);
+      } else {
+        ssb_adaptor.process(grids[i]->get_writer(), blk);
+        csi_adaptor.map(grids[i]->get_mapper(), rs);
+      }
+      ref_make_ssb_processor()->process(ref_grids[i]->get_writer(), blk);
       ref_csi.map(ref_grids[i]->get_mapper(), rs);
     }
     // a channel the library does not generate: straight through the grid's writer on the host

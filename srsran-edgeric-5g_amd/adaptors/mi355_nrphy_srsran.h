@@ -407,14 +407,16 @@ public:
     if (ls.handed_over) { // the same grid requested twice for one slot: the IQ is (being) computed already
       return static_cast<int>(ls.slot_id);
     }
-    if (!ls.have_slot) {
+    bool device_layer_empty = false;
+    if (!ls.have_slot) { // no processor of this repository wrote the grid: everything in it came through the host layer
       status = nrphy_dl_slot_open(pool->get(), &ls.slot_id);
       if (status != NRPHY_OK) {
         return -1;
       }
-      ls.have_slot = true;
+      ls.have_slot       = true;
+      device_layer_empty = true;
     }
-    status = self.flush_host_layer();
+    status = self.flush_host_layer(device_layer_empty);
     if (status == NRPHY_OK) {
       status = nrphy_dl_slot_modulate(pool->get(), ls.slot_id, subframe_slot_index, nullptr, nullptr);
     }
@@ -533,7 +535,10 @@ private:
     }
   }
 
-  int flush_host_layer()
+  /// The host layer joins the slot's device grid: its non-zero elements as one sparse put -- or, when nothing else has written
+  /// the slot (`device_layer_empty`) and the host layer is dense (a slot whose channels were all generated on the host: the
+  /// device only modulates), the whole layer as ONE grid copy, which is cheaper than twelve bytes per element and a scatter.
+  int flush_host_layer(bool device_layer_empty = false)
   {
     if (!host_touched) {
       return NRPHY_OK;
@@ -541,7 +546,23 @@ private:
     std::vector<nrphy_grid_re_t> entries;
     host_layer_entries(entries);
     host_touched = false; // (what the host layer holds stays there: a later read merges it again, idempotently)
-    return entries.empty() ? NRPHY_OK : nrphy_dl_slot_put(pool->get(), lease->slot_id, entries.size(), entries.data());
+    if (entries.empty()) {
+      return NRPHY_OK;
+    }
+    const srsran::resource_grid_reader& r        = host_layer->get_reader();
+    const unsigned                      nof_subc = r.get_nof_subc();
+    const size_t grid_bytes = static_cast<size_t>(pool->get_nof_ports()) * NRPHY_NSYMB * nof_subc * sizeof(srsran::cbf16_t);
+    if (device_layer_empty && entries.size() * sizeof(nrphy_grid_re_t) >= grid_bytes) {
+      whole.assign(static_cast<size_t>(pool->get_nof_ports()) * NRPHY_NSYMB * nof_subc, srsran::cbf16_t());
+      for (unsigned port = 0; port != r.get_nof_ports() && port != pool->get_nof_ports(); ++port) {
+        for (unsigned l = 0; l != r.get_nof_symbols() && l != NRPHY_NSYMB; ++l) {
+          srsran::span<const srsran::cbf16_t> row = r.get_view(port, l);
+          std::memcpy(&whole[(static_cast<size_t>(port) * NRPHY_NSYMB + l) * nof_subc], row.data(), row.size() * sizeof(srsran::cbf16_t));
+        }
+      }
+      return nrphy_dl_slot_load_grid(pool->get(), lease->slot_id, whole.data());
+    }
+    return nrphy_dl_slot_put(pool->get(), lease->slot_id, entries.size(), entries.data());
   }
 
   // The whole grid on the host, for whoever reads it there: blocking.
@@ -583,6 +604,7 @@ private:
   mapper_type                            mapper;
   writer_type                            writer;
   reader_type                            reader;
+  std::vector<srsran::cbf16_t>           whole;      // staging of a dense host layer on its way to the device (flush_host_layer)
   bool                                   host_touched = false;
   bool                                   merged_valid = false;
 };

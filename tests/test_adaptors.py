@@ -266,6 +266,21 @@ def test_dl_slot_pipeline_adaptors_against_the_references_lower_phy_loop(harness
     assert longest_ns < 2_000_000, longest_ns
 
 
+def test_dl_slot_pipeline_device_grid_filled_on_the_host_goes_down_as_one_copy(harness):
+    """A device-mirrored grid that only the REFERENCE's processors wrote (through its mapper / writer: everything is in the host
+    layer): at hand-over the dense layer goes to the slot as ONE grid copy (nrphy_dl_slot_load_grid) instead of a sparse put of
+    most of the grid; same grid, same IQ as the reference's own lower PHY."""
+    rng = np.random.default_rng(43)
+    n_slots = 2
+    grids, iqs, info = _run_dl_pipeline(harness, rng, n_slots, 2, 0, 40)
+    late_a, late_r, proc_a, proc_r, longest_ns, synchronous, n_mod, n_load, n_read, n_put = (int(v) for v in info)
+    assert (late_a, late_r) == (0, 0) and proc_a == proc_r == 14 * n_slots
+    assert np.array_equal(grids[0], grids[1])
+    scale = np.abs(iqs[1]).max()
+    assert scale > 0 and np.abs(iqs[0] - iqs[1]).max() / scale < 1e-5
+    assert n_mod == n_slots and n_load == n_slots and n_put == 0
+
+
 def test_dl_slot_pipeline_adaptor_late_slot_and_bounded_wait(harness):
     """A slot whose IQ has not arrived when its first symbol is due: with max_wait_us = 0 the real-time call does not wait --
     on_pdxch_request_late, silence for the slot (pdxch_processor_impl.cpp:65-74 does the same for a request that misses its
