@@ -457,6 +457,9 @@ struct Trace;
 #define TR(k)
 #endif
 
+#ifndef NRPHY_DEC_SELECT_BY_MASK
+#define NRPHY_DEC_SELECT_BY_MASK 0 // 1: the message magnitude selected through a full-width mask (the form until late round 4), for A/B
+#endif
 template <uint32_t DEG, uint32_t T, bool FIRST>
 struct LmEdges {
   static __device__ __forceinline__ void forward(const uint32_t (&c)[DEG], uint32_t (&x)[DEG], uint32_t k512, uint32_t& k1, uint32_t& k2,
@@ -472,7 +475,12 @@ struct LmEdges {
       asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(key) : "v"(as_word(mag)), "s"(k512 >> 4), "n"(T));
       k2 = as_word(__builtin_elementwise_min(__builtin_elementwise_max(as_u16x2(key), as_u16x2(k1)), as_u16x2(k2)));
       k1 = as_word(__builtin_elementwise_min(as_u16x2(key), as_u16x2(k1)));
-      par ^= as_word(v); // bit 15 of a half: parity of the negative values so far
+      // bit 15 of a half of `par`: parity of the negative values so far -- two edges per instruction (a ^ b ^ c as one v_bitop3)
+      if constexpr (T % 2u == 1u) {
+        par = __builtin_amdgcn_bitop3_b32(par, x[T - 1u], x[T], 0x96);
+      } else if constexpr (T + 1u == DEG) {
+        par ^= x[T];
+      }
       LmEdges<DEG, T + 1, FIRST>::forward(c, x, k512, k1, k2, par);
     }
   }
@@ -482,8 +490,17 @@ struct LmEdges {
                                                     const uint32_t (&x)[DEG], uint32_t m1, uint32_t m2, uint32_t hot0, uint32_t hot1)
   {
     const uint32_t s   = as_word(as_s16x2(x[T]) >> splat_s16(15)) | 0x00010001u; // -1 / +1: the sign of the value answered
+#if NRPHY_DEC_SELECT_BY_MASK
     const uint32_t sel = half_masks(T < 16u ? hot0 : hot1, T & 15u);
     const uint32_t mag = __builtin_amdgcn_bitop3_b32(sel, m2, m1, 0xCA);
+#else
+    // the second minimum for the edge that holds the first: m1 + bit * (m2 - m1) in every half, `m2` arriving here as the
+    // difference (process_check_pair_lm) -- a shift and a mask (plain VOP2) and one packed multiply-add instead of two packed
+    // shifts for a full-width mask and a select
+    const uint32_t bit = ((T < 16u ? hot0 : hot1) >> (T & 15u)) & 0x00010001u;
+    uint32_t       mag;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(mag) : "v"(bit), "v"(m2), "v"(m1));
+#endif
     const s16x2    msg = as_s16x2(as_word(as_u16x2(mag) * as_u16x2(s)));
     const uint32_t out = as_word(clamp_s16x2(msg + as_s16x2(x[T]), LLR_INF_V));
     lds_store_i8(addr1[T], out);
@@ -593,7 +610,11 @@ __device__ __forceinline__ void process_check_pair_lm(const Msg& msg, const Scal
   key_one_hot<DEG>(k1, hot0, hot1);
   ahead();
   TR(5);
+#if NRPHY_DEC_SELECT_BY_MASK
   LmEdges<DEG, 0, FIRST>::backward(msg, addr1, addr2, x, m1, m2, hot0, hot1);
+#else
+  LmEdges<DEG, 0, FIRST>::backward(msg, addr1, addr2, x, m1, as_word(as_s16x2(m2) - as_s16x2(m1)), hot0, hot1);
+#endif
   TR(6);
 }
 
