@@ -633,12 +633,12 @@ struct IqSinkCi16 {
   {
 #pragma clang fp contract(off)
     // The product must be rounded on its own before the addition (the reference rounds v * scale to float, then to the nearest
-    // even integer).  Without the empty assembly statement below -- which makes the product a value of its own -- the seeded sweep
-    // found 1.5e-4 of the samples one LSB off, every one of them a product that is an exact tie (x.5) and every one rounded the way
-    // a FUSED multiply-add rounds (by the unrounded product), in all transform sizes (profiles/r04_fuzz_sweep_summary.txt).  This
-    // file is compiled with -ffp-contract=fast and the pragma above does not bind the backend under that flag; the ISA of both
-    // forms nevertheless shows a packed multiply followed by a packed add, and that pair rounds twice on this GPU in isolation
-    // (profiles/probes/pk_round2.hip, pk_round3.hip), so the mechanism is not pinned down -- the effect and the cure are.
+    // even integer).  This file is compiled with -ffp-contract=fast, and under that flag the backend fuses a multiply and an add
+    // whatever the pragma above says: the shipped library had v_pk_fma_f32 here (86 instead of 82 in the N = 512 instance), and a
+    // fused multiply-add breaks ties at x.5 by the unrounded product -- the seeded sweep found 1.5e-4 of the samples one LSB off,
+    // every one of them such a tie (profiles/r04_fuzz_sweep_summary.txt).  The empty assembly statement makes the rounded product a
+    // value of its own.  (A `hipcc -c -save-temps` listing does NOT show the fusion -- that pipeline happens not to fuse here; the
+    // code object inside the library does: disassemble that.)
     cf sc = g * scale;
     asm("" : "+v"(sc));
     const cf r = sc + MAGIC;
