@@ -88,12 +88,32 @@ def price(body):
     return total, cycles, classes, hist
 
 
+def shipped_isa():
+    """Disassembly of the code objects inside the built library (profiles/disasm_lib.py): what really runs -- a separate
+    `hipcc -c -save-temps` compile can differ from it (round 4: a multiply-add fused only in the library).  None without a library."""
+    lib = os.path.join(CSRC, "libmi355nrphy.so")
+    if not os.path.exists(lib):
+        return None
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import disasm_lib
+    text = ""
+    for co in disasm_lib.code_objects(lib):
+        dis = subprocess.run([os.path.join(disasm_lib.LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True).stdout
+        # objdump's "0000... <symbol>:" headers in the shape of the assembler listing's "symbol:" labels
+        text += re.sub(r"^[0-9a-f]+ <(\S+)>:$", r"\1:", dis, flags=re.M)
+    return text
+
+
 def model():
     out, isa = {}, {}
+    shipped = shipped_isa()
     for name, (src, pat, contract) in KERNELS.items():
-        if src not in isa:
-            isa[src] = isa_of(src, contract)
-        text = isa[src]
+        if shipped is not None:
+            text = shipped
+        else:
+            if src not in isa:
+                isa[src] = isa_of(src, contract)
+            text = isa[src]
         m = re.search(r"^(_ZN5nrphy\w*%s\w*):" % pat, text, re.M)
         if not m:
             continue
@@ -103,7 +123,8 @@ def model():
         out[name] = {"static_vector_instructions": total, "avg_issue_cycles_per_instruction": round(cycles / total, 3),
                      "classes": classes, "top_mnemonics": dict(sorted(hist.items(), key=lambda kv: -kv[1])[:12])}
     return {"kernel_source_sha256": source_sha(), "valu_issue_model": out,
-            "valu_issue_model_source": "profiles/valu_issue_model.py: static ISA mix x profiles/r01_valu_rate.txt costs"}
+            "valu_issue_model_source": "profiles/valu_issue_model.py: static instruction mix of the %s x profiles/r01_valu_rate.txt costs" % (
+                "code objects inside the built library" if shipped is not None else "kernels' ISA (hipcc -save-temps)")}
 
 
 if __name__ == "__main__":
