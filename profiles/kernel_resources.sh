@@ -6,7 +6,6 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$1; shift
 CONTRACT=-ffp-contract=off
-[ "$SRC" = ofdm_kernels.hip ] && CONTRACT=-ffp-contract=fast
 TMP=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$ROOT/srsran-edgeric-5g_amd/csrc" $CONTRACT "$@" \
   -x hip -c "$ROOT/srsran-edgeric-5g_amd/csrc/$SRC" -o "$TMP/out.o" -Rpass-analysis=kernel-resource-usage 2>&1 |

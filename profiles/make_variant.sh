@@ -11,7 +11,6 @@ python3 srsran-edgeric-5g_amd/build.py > /dev/null          # the other objects,
 OBJS=$(ls $C/*.o)
 for SRC in $SRCS; do
   CONTRACT=-ffp-contract=off
-  [ "$SRC" = ofdm_kernels.hip ] && CONTRACT=-ffp-contract=fast
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Iinclude -I$C $CONTRACT $EXTRA -x hip -c $C/$SRC -o build/variants/$NAME.${SRC%.*}.o
   OBJS=$(echo "$OBJS" | tr ' ' '\n' | grep -v "/${SRC%.*}.o$")
   OBJS="$OBJS

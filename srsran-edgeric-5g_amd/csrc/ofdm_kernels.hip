@@ -596,8 +596,8 @@ struct IqSinkCi16 {
   template <bool PREFIX>
   __device__ __forceinline__ cf measure(cf v, uint32_t idx, float& reach) const
   {
-#pragma clang fp contract(off) // every product is rounded on its own, as the reference's separate steps are -- and because the
-    // pragma does not bind the backend under this file's -ffp-contract=fast (see pack_plain), the squares are made values of their own
+#pragma clang fp contract(off) // every product is rounded on its own, as the reference's separate steps are (the squares are made
+    // values of their own as well: see pack_plain)
     const cf    g  = cmul_uniform(v, ph) * gain; // packed: (re, im) x gain
 #if NRPHY_WIRE_EXP != 1
     cf          sq = g * g;
@@ -633,12 +633,12 @@ struct IqSinkCi16 {
   {
 #pragma clang fp contract(off)
     // The product must be rounded on its own before the addition (the reference rounds v * scale to float, then to the nearest
-    // even integer).  This file is compiled with -ffp-contract=fast, and under that flag the backend fuses a multiply and an add
-    // whatever the pragma above says: the shipped library had v_pk_fma_f32 here (86 instead of 82 in the N = 512 instance), and a
-    // fused multiply-add breaks ties at x.5 by the unrounded product -- the seeded sweep found 1.5e-4 of the samples one LSB off,
-    // every one of them such a tie (profiles/r04_fuzz_sweep_summary.txt).  The empty assembly statement makes the rounded product a
-    // value of its own.  (A `hipcc -c -save-temps` listing does NOT show the fusion -- that pipeline happens not to fuse here; the
-    // code object inside the library does: disassemble that.)
+    // even integer).  When this file was still compiled with -ffp-contract=fast the backend fused the two whatever the pragma
+    // above said: the shipped library had v_pk_fma_f32 here (86 instead of 82 in the N = 512 instance), and a fused multiply-add
+    // breaks ties at x.5 by the unrounded product -- the seeded sweep found 1.5e-4 of the samples one LSB off, every one of them
+    // such a tie (profiles/r04_fuzz_sweep_summary.txt).  The file is built without contraction now (build.py) AND the rounded
+    // product is made a value of its own by the empty assembly statement.  (A `hipcc -c -save-temps` listing did NOT show the
+    // fusion -- that pipeline happened not to fuse here; the code object inside the library did: profiles/disasm_lib.py.)
     cf sc = g * scale;
     asm("" : "+v"(sc));
     const cf r = sc + MAGIC;
