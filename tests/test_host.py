@@ -383,3 +383,29 @@ def test_host_only_helpers_of_the_lower_phy_tail():
                 assert lib.slot_size(cfg, slot) == sum(sizes[slot * nsym:(slot + 1) * nsym])
             # one subframe is 1 ms: 15 kHz * 512 samples * 2^mu per ms
             assert sum(sizes) == 15 * 512 * (1 << mu)
+
+
+def test_shipped_code_objects_spill_no_vector_registers_and_use_no_scratch():
+    """What the library really contains (profiles/disasm_lib.py: .hip_fatbin -> bundle entries -> the code objects' metadata), not
+    what a separate compile reports: every kernel without vector-register spills and without scratch memory; the headline kernels
+    within the register budgets DESIGN.md states (eight codeblock waves per SIMD need <= 96 scalar and <= 64 vector registers)."""
+    sys.path.insert(0, os.path.join(backends.ROOT, "profiles"))
+    import disasm_lib
+    rows = disasm_lib.resources(os.path.join(backends.ROOT, "srsran-edgeric-5g_amd", "csrc", "libmi355nrphy.so"))
+    assert len(rows) > 100
+    by_name = {r[0]: r for r in rows}
+    for name, sgpr, vgpr, sgpr_spill, vgpr_spill, scratch, lds in rows:
+        assert vgpr_spill == "0" and scratch == "0", (name, vgpr_spill, scratch)
+    cb = by_name["void nrphy::codeblock_kernel_t<8, 4>"]
+    assert int(cb[1]) <= 96 and int(cb[2]) <= 64 and cb[3] == "0"
+    assert int(by_name["void nrphy::ofdm_kernel<4096, 1, false>"][2]) <= 168      # three workgroups per CU
+    assert int(by_name["nrphy::ldpc_decode_msg_bg2_slot_kernel"][2]) <= 128        # four waves per SIMD
+
+
+def test_no_source_is_built_with_floating_point_contraction():
+    """Under -ffp-contract=fast the backend fuses across `#pragma clang fp contract(off)` (round 4: the wire-format sink's exact
+    rounding): every source is built with contraction off, and where a kernel wants a fused multiply-add it says so."""
+    build = open(os.path.join(backends.ROOT, "srsran-edgeric-5g_amd", "build.py")).read()
+    assert "CONTRACT = {}" in build and '"-ffp-contract=off"' in build and "contract=fast\"" not in build
+    for script in ("make_variant.sh", "kernel_resources.sh"):
+        assert "contract=fast" not in open(os.path.join(backends.ROOT, "profiles", script)).read()
