@@ -307,6 +307,20 @@ __device__ __forceinline__ uint32_t pad(uint32_t i)
   return i + (i >> 4);
 }
 
+// pad(base + k * C) for k = 0, 1, ... from pb = pad(base): where the step is a multiple of 16 elements the padding is affine in k --
+// (base + k C) >> 4 = (base >> 4) + k C / 16 -- so ONE address register serves all k and the rest is the instruction's immediate
+// offset.  Written as pad(base + k * C) the compiler does not see that and keeps a register per address: sixteen per stage and
+// direction, alive across the whole kernel -- 64 of the modulator's 160 vector registers.
+template <int C>
+__device__ __forceinline__ uint32_t pad_step(uint32_t base, uint32_t pb, int k)
+{
+  if constexpr (C % 16 == 0) {
+    return pb + (uint32_t)k * (uint32_t)(C + C / 16);
+  } else {
+    return pad(base + (uint32_t)k * (uint32_t)C);
+  }
+}
+
 // Radix plans: N = R0 * R1 * R2 * R3 (R2 = 1 when two stages suffice, R3 = 1 when three do), T = threads per
 // transform = N / 16.
 struct ThreeStages {
@@ -373,9 +387,10 @@ __device__ __forceinline__ void stage_first(cf (&a)[Plan<N>::R0], cf base, cf* l
   if (NB >= Plan<N>::T || tid < NB) {
     Butterfly<SIGN, R>::run(a);
     apply_twiddle_powers<R>(base, a);
+    const uint32_t pb = pad(R * tid);
 #pragma unroll
     for (int j = 0; j != R; ++j) {
-      lds[pad(R * tid + j)] = a[j];
+      lds[R == 16 ? pb + j : pad(R * tid + j)] = a[j]; // (R = 16: the sixteen outputs share one padding step)
     }
   }
   __syncthreads();
@@ -405,9 +420,10 @@ __device__ __forceinline__ void stage_lds(cf* lds, const float2* __restrict__ tw
     uint32_t b = tid + it * T;
     if (NB % T == 0 || b < NB) {
       uint32_t p = b / S, q = b % S;
+      const uint32_t rb = q + S * p, prb = pad(rb);
 #pragma unroll
       for (int k = 0; k != R; ++k) {
-        a[it][k] = lds[pad(q + S * (p + k * n1))];
+        a[it][k] = lds[pad_step<S * n1>(rb, prb, k)];
       }
     }
   }
@@ -435,9 +451,10 @@ __device__ __forceinline__ void stage_lds(cf* lds, const float2* __restrict__ tw
           static_for<R>([&](auto J) { store(q, Const<S * decltype(J)::value>{}, Const<S>{}, a[it][decltype(J)::value]); });
         }
       } else {
+        const uint32_t wb = q + S * R * p, pwb = pad(wb);
 #pragma unroll
         for (int j = 0; j != R; ++j) {
-          lds[pad(q + S * (R * p + j))] = a[it][j];
+          lds[pad_step<S>(wb, pwb, j)] = a[it][j];
         }
       }
     }
@@ -717,10 +734,15 @@ __device__ __forceinline__ void load_symbol_row(uint32_t (&raw)[Plan<N>::R0], co
   }
 }
 
-#ifdef NRPHY_OFDM_WAVES // profiling experiment: register budget for this many waves per SIMD
+// Workgroups per CU.  With one address register per stage (pad_step) the transforms need 88 (float) / 119 (wire format) vector
+// registers instead of 160 / 165 and four workgroups fit a CU where three did.  The wire-format kernel wants the fourth -- its
+// residents cover one another's barriers and waits: 0.41 -> 0.38 ms per 1024 config-3 slots --, the float kernel, which sits at the
+// memory system's rate, does not: 0.47 -> 0.51 ms with four, so it keeps three (A/B on one box, three rounds,
+// profiles/r04_ofdm_sinks.txt).  -DNRPHY_OFDM_WAVES=n: both kernels at n waves per SIMD (experiments).
+#ifdef NRPHY_OFDM_WAVES
 #define OFDM_OCCUPANCY __attribute__((amdgpu_waves_per_eu(NRPHY_OFDM_WAVES, NRPHY_OFDM_WAVES)))
 #else
-#define OFDM_OCCUPANCY
+#define OFDM_OCCUPANCY __attribute__((amdgpu_waves_per_eu(WIRE ? 1 : 3, WIRE ? 4 : 3)))
 #endif
 template <int N, int SPW, bool WIRE>
 __global__ __launch_bounds__(Plan<N>::T) OFDM_OCCUPANCY void ofdm_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_grid,
