@@ -41,7 +41,7 @@ KERNELS = {   # bench.py's name -> (source, mangled-name pattern, contraction fl
     "codeblock_kernel": ("pdsch_kernels.hip", r"codeblock_kernel_tILi8ELi4E", "-ffp-contract=off"),
     "prologue_kernel": ("pdsch_kernels.hip", r"prologue_kernel", "-ffp-contract=off"),
     "ofdm_kernel<4096>": ("ofdm_kernels.hip", r"ofdm_kernelILi4096ELi1ELb0E", "-ffp-contract=off"),
-    "ofdm_kernel<4096, ci16>": ("ofdm_kernels.hip", r"ofdm_kernelILi4096ELi3ELb1E", "-ffp-contract=off"),
+    "ofdm_kernel<4096, ci16>": ("ofdm_kernels.hip", r"ofdm_kernelILi4096ELi2ELb1E", "-ffp-contract=off"),
     "ldpc_decode_msg_bg1_kernel": ("ldpc_decoder.hip", r"ldpc_decode_msg_bg1_kernel", "-ffp-contract=off"),
     "ldpc_decode_msg_bg2_slot_kernel": ("ldpc_decoder.hip", r"ldpc_decode_msg_bg2_slot_kernel", "-ffp-contract=off"),
 }

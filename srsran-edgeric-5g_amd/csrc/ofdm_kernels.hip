@@ -863,12 +863,14 @@ __global__ void wire_stats_kernel(OfdmLaunch p, const uint32_t* __restrict__ d_s
 // profiles/r04_ofdm_spw.txt) 1 -> 0.454 ms, 2 -> 0.51, 4 -> 0.53: the kernel sits at the memory system's rate for its access
 // shape with one symbol per workgroup, and more only take parallelism away (1 also keeps small batches spread over the chip).
 // Complex int16 output (half the store traffic, more arithmetic per sample): 1 -> 0.434-0.444 ms, 2 -> 0.419-0.420,
-// 3 -> 0.411-0.419, 4 -> 0.447-0.452 -- there the row of symbol k + 1 arriving under the butterflies of symbol k pays.
+// 3 -> 0.411-0.419, 4 -> 0.447-0.452 -- there the row of symbol k + 1 arriving under the butterflies of symbol k pays.  With four
+// workgroups per CU (late round 4) the steps flatten: 1 -> 0.392-0.399, 2 -> 0.3875 / 0.3876, 3 -> 0.392, 4 -> 0.42 (14 = 4 + 4 + 4 + 2),
+// 5 -> 0.386-0.390: two it is -- seven equal units per slot and port, and a single slot spread over more workgroups.
 #ifndef NRPHY_OFDM_SPW
 #define NRPHY_OFDM_SPW 1
 #endif
 #ifndef NRPHY_OFDM_SPW_WIRE
-#define NRPHY_OFDM_SPW_WIRE 3
+#define NRPHY_OFDM_SPW_WIRE 2
 #endif
 constexpr int OFDM_SYMBOLS_PER_WG = NRPHY_OFDM_SPW, OFDM_SYMBOLS_PER_WG_WIRE = NRPHY_OFDM_SPW_WIRE;
 
