@@ -32,7 +32,7 @@ def key_of(kernel):
     if "prologue_kernel" in kernel:
         return "prologue_kernel"
     if "ofdm_kernel<4096" in kernel:
-        return "ofdm_kernel<4096>"
+        return "ofdm_kernel<4096, ci16>" if kernel.rstrip().endswith("true>") else "ofdm_kernel<4096>"   # (the wire-format instance: bench.py --wire)
     return None
 
 
