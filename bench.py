@@ -236,8 +236,13 @@ def run_downlink(env, config, slots, steps, warmup, wire=False):
     oplan = lib.OfdmPlan(ctx, ofdm, nof_ports)
     d_grid = torch.zeros((slots, nof_ports, 14, nof_subc), dtype=torch.int32, device="cuda")
     if wire:
-        # clipping enabled with a realistic back-off: gain -14 dB puts the signal about 14 dB (rms) under the -1 dBFS ceiling
-        wire_cfg = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -14.0, 1.0, -1.0), 32767.0)
+        # The amplitude controller as the reference's radio unit configures it: the modulator's scale is 1 (pdxch_processor_factories.cpp:59),
+        # and the input gain takes out the DFT's power gain plus a back-off for the signal's peaks -- input_gain_dB =
+        # -10 log10(subcarriers) - tx_gain_backoff (12 dB), ceiling -0.1 dBFS (apps/units/flexible_du/split_8/ru_sdr_config_translator.cpp:
+        # 94-100, ru_sdr_config.h:75-81) -- with clipping switched ON (the reference's default is off), the costlier setting.
+        # (Until late round 4 this leg ran with a gain of -14 dB: at scale 1 that puts the signal 14 dB ABOVE full scale -- every sample
+        # clipped, the conversion's exact path for all of them: a measurement of the wrong thing.  profiles/r04_ofdm_sinks.txt.)
+        wire_cfg = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -(10.0 * float(np.log10(nof_subc)) + 12.0), 1.0, -0.1), 32767.0)
         d_iq = torch.zeros((slots, nof_ports, oplan.slot_stride, 2), dtype=torch.int16, device="cuda")
         d_stats = torch.zeros((slots * nof_ports, 4), dtype=torch.int32, device="cuda")
     else:

@@ -272,7 +272,7 @@ def dl_slot_pipeline(ctx=None, depths=(1, 2, 4, 8), total=600, verbose=True, che
     _, ports, subc, ofdm = cases.baseline_config(3)
     max_tb = max(p.tb_size_bytes for p, _ in items)
     refs = [(C.byref(p), (C.c_void_p * 1)(tb.ctypes.data)) for p, tb in items]
-    wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -12.0, 1.0, -1.0), 32767.0 / 64.0)
+    wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -(10.0 * float(np.log10(subc)) + 12.0), 1.0, -0.1), 32767.0)   # the reference's radio unit setting (bench.py)
     results = []
     for leg, wire_cfg, sample_bytes in (("tb_in_f32_iq_out", None, 8), ("tb_in_ci16_iq_out", wire, 4)):
         if check:
@@ -357,7 +357,7 @@ def dl_slot_pipeline_threads(ctx=None, thread_counts=(1, 2, 4), depth=4, total=1
     _, ports, subc, ofdm = cases.baseline_config(3)
     max_tb = max(p.tb_size_bytes for p, _ in items)
     refs = [(C.byref(p), (C.c_void_p * 1)(tb.ctypes.data)) for p, tb in items]
-    wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -12.0, 1.0, -1.0), 32767.0 / 64.0)
+    wire = abi.IqWireCfg(abi.AmplitudeCfg(0, 1, -(10.0 * float(np.log10(subc)) + 12.0), 1.0, -0.1), 32767.0)   # the reference's radio unit setting (bench.py)
     results = []
     for n_threads in thread_counts:
         pool = lib.DlSlotPool(ctx, ofdm, ports, depth * n_threads, max_tb, wire_cfg=wire)
